@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of BASELINE.json: distributed CSR SpMV, 2-D 5-point Poisson, fp64.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload poisson2d] [--size 4096]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one y = A*x (``mul!(y, A, x)``) over the resident matrix: halo exchange (N > 1, RCCL on a
+side stream, overlapped with the interior row blocks) + SpMV.  Workload at N = 1: BASELINE
+configs[1], the 4096^2 Poisson matrix (n = 16 777 216, nnz = 83 869 696, Int32 indices).  N > 1:
+weak scaling -- every GPU owns one 4096 x 4096 slab of a 4096 x (4096*N) grid (same per-GPU work as
+N = 1, two 32 KiB halo lines per interior GPU).
+
+Output: ONE JSON line on rank 0 (contract in the task statement) with `roofline` (HBM, algorithmic
+bytes / per-launch time measured with HIP events on the launch stream) and `cpu_baseline` (the
+oracle's restatement of the reference kernel, timed on this host's cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="poisson2d", choices=["poisson2d", "poisson3d_cg", "sprand_spmm"])
+    ap.add_argument("--size", type=int, default=0, help="grid edge N (default: 4096 for poisson2d)")
+    ap.add_argument("--index", default="i32", choices=["i32", "i64"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def cpu_baseline_spmv(rowptr, colval, vals, x_gathered, budget_s):
+    """cpu_baseline leg: the oracle's restatement of _spmv_kernel! (src/sparse.jl:2055-2066), OpenMP
+    static over rows like the reference's KernelAbstractions CPU backend, on all cores this
+    process may use, then on 1 core; bounded to ~budget_s seconds."""
+    from oracle import oracle as orc
+    cores = len(os.sched_getaffinity(0))
+    nnz = len(vals)
+    out = {}
+    for label, nt, share in (("all", cores, 0.6), ("one", 1, 0.4)):
+        orc.lib().orc_set_threads(nt)
+        orc.spmv(rowptr, colval, vals, x_gathered, nthreads=nt)          # warm-up
+        ts = []
+        t_end = time.perf_counter() + budget_s * share
+        while time.perf_counter() < t_end or len(ts) < 3:
+            t0 = time.perf_counter()
+            orc.spmv(rowptr, colval, vals, x_gathered, nthreads=nt)
+            ts.append(time.perf_counter() - t0)
+            if len(ts) >= 200:
+                break
+        out[label] = (2.0 * nnz / np.median(ts) / 1e9, len(ts), float(np.median(ts)))
+    orc.lib().orc_set_threads(cores)
+    return {
+        "value": round(out["all"][0], 3), "unit": "GFLOP/s", "cores": cores, "kind": "port",
+        "sample": (f"same matrix and x as the GPU run (rank 0 slab), {out['all'][1]} SpMVs on {cores} threads "
+                   f"(median {out['all'][2]*1e3:.2f} ms) + {out['one'][1]} on 1 thread"),
+        "value_1core": round(out["one"][0], 3), "ms_per_spmv": round(out["all"][2] * 1e3, 3),
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
+
+    import hpcla_amd as hp
+    from hpcla_amd import workloads as wl
+
+    Ti = np.int32 if args.index == "i32" else np.int64
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("cpu:gloo,cuda:nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
+        backend = hp.backend_rocm_mpi(np.float64, Ti)
+    else:
+        backend = hp.backend_rocm_serial(np.float64, Ti, device_index=torch.cuda.current_device())
+
+    if args.workload != "poisson2d":
+        from benchmarks import extra_workloads          # configs 4/5: separate harness
+        return extra_workloads.run(args, backend, rank, world)
+
+    # ---- build the workload ------------------------------------------------------------------------
+    N = args.size or 4096
+    nx, ny_loc = N, N
+    ny = ny_loc * world
+    n_glob = nx * ny
+    lo, hi = rank * nx * ny_loc, (rank + 1) * nx * ny_loc
+    t0 = time.perf_counter()
+    rowptr, colidx, vals = wl.poisson2d_rows(nx, ny, lo, hi)
+    A = hp.HPCSparseMatrix_local(rowptr, colidx, vals, n_glob, backend)
+    del colidx
+    part = A.row_partition
+    x = hp.HPCVector.zeros(part, backend)
+    hp._capi.call("hpcla_fill_uniform_f64", x.v.data_ptr(), lo, hi - lo, wl.SEED_X,
+                  torch.cuda.current_stream().cuda_stream)
+    y = hp.HPCVector.zeros(part, backend)
+    plan = hp.get_vector_plan(A, x)
+    setup_s = time.perf_counter() - t0
+    nnz_loc, nrows_loc = A.nnz, A.nrows_local
+    b_alg_loc = wl.spmv_algorithmic_bytes(nnz_loc, nrows_loc, A.ncols_compressed, np.dtype(Ti).itemsize)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- verification of this rank's result on sampled rows (incl. halo-adjacent rows) -----------------
+    hp.mul_(y, A, x)
+    torch.cuda.synchronize()
+    samp = np.unique(np.concatenate([np.arange(0, min(3 * nx, nrows_loc)),
+                                     np.arange(max(0, nrows_loc - 3 * nx), nrows_loc),
+                                     np.random.default_rng(rank).integers(0, nrows_loc, 4096)]))
+    g = samp + lo
+    gi, gj = g % nx, g // nx
+    xs = lambda idx: wl.u01(wl.SEED_X, idx)
+    want = np.zeros(len(g))
+    # same order and rounding as the kernel: ascending column, mul then add
+    for col, ok, coef in ((g - nx, gj > 0, -1.0), (g - 1, gi > 0, -1.0), (g, np.ones_like(g, bool), 4.0),
+                          (g + 1, gi < nx - 1, -1.0), (g + nx, gj < ny - 1, -1.0)):
+        term = coef * xs(np.where(ok, col, 0))
+        want = np.where(ok, want + term, want)
+    got = y.v[torch.from_numpy(samp).cuda()].cpu().numpy()
+    verified = bool(np.array_equal(got, want))
+    if world > 1:
+        flag = torch.tensor([1 if verified else 0], device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        verified = bool(flag.item())
+
+    # ---- warm-up, then EXACTLY K timed steps -----------------------------------------------------------
+    for _ in range(args.warmup):
+        hp.mul_(y, A, x)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        hp.mul_(y, A, x)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- per-launch duration with HIP events on the launch stream (roofline.achieved) ----------------
+    reps = min(max(args.steps, 20), 200)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    barrier()
+    for a, b in evs:
+        a.record()
+        hp.mul_(y, A, x)
+        b.record()
+    torch.cuda.synchronize()
+    per_launch_ms = np.array([a.elapsed_time(b) for a, b in evs])
+    launch_ms = float(np.mean(per_launch_ms))
+    # back-to-back launches between ONE event pair (no per-launch event overhead)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        hp.mul_(y, A, x)
+    b.record()
+    torch.cuda.synchronize()
+    stream_ms = a.elapsed_time(b) / reps
+
+    nnz_tot = nnz_loc * world            # slabs differ by <= 2*nx nonzeros; rank 0 reports its own * N
+    if world > 1:
+        t = torch.tensor([float(nnz_loc), float(b_alg_loc)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t)
+        nnz_tot, b_alg_tot = int(t[0].item()), int(t[1].item())
+    else:
+        b_alg_tot = b_alg_loc
+    ms_per_step = elapsed / args.steps * 1e3
+    gflops = 2.0 * nnz_tot / (elapsed / args.steps) / 1e9
+    achieved = b_alg_loc / (launch_ms * 1e-3) / 1e9
+
+    traffic = None
+    tj = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if os.path.exists(tj):
+        try:
+            traffic = json.load(open(tj)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    result = {
+        "metric": "SpMV GFLOP/s (2*nnz/t), 2-D 5-pt Poisson, fp64",
+        "value": round(gflops, 2), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"poisson2d 5-pt, {nx}x{ny_loc} slab per GPU ({nx}x{ny} global), "
+                               f"n={n_glob}, nnz={nnz_tot}, index={args.index}, CSR SpMV y=A*x",
+                   "global_rows": n_glob, "nnz": nnz_tot, "index_type": args.index,
+                   "parallelism": f"row-slab x{world}, RCCL halo" if world > 1 else "single GPU"},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "kernel": "spmv_rowblock_kernel", "algorithmic_bytes_per_launch": b_alg_loc,
+                     "launch_ms_event_pairs": round(launch_ms, 5), "launch_ms_back_to_back": round(stream_ms, 5),
+                     "launch_ms_min": round(float(per_launch_ms.min()), 5)},
+        "hbm_gbs_whole_job": round(b_alg_tot / (elapsed / args.steps) / 1e9, 1),
+        "hbm_frac_of_peak_whole_job": round(b_alg_tot / (elapsed / args.steps) / 1e9 / (HBM_PEAK_GBS * world), 4),
+        "verified_vs_closed_form": verified, "setup_s": round(setup_s, 2),
+    }
+    if rank == 0 and not args.no_cpu_baseline:
+        xg = x.local_values()
+        ghost = np.zeros(0)
+        if plan.has_halo:
+            ghost_idx = A.col_indices[A.col_indices >= hi]
+            ghost_lo = A.col_indices[A.col_indices < lo]
+            xfull = np.concatenate([wl.u01(wl.SEED_X, ghost_lo), xg, wl.u01(wl.SEED_X, ghost_idx)])
+        else:
+            xfull = xg
+        result["cpu_baseline"] = cpu_baseline_spmv(A.rowptr, A.colval, vals, xfull, args.cpu_seconds)
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    hp.clear_plan_cache()
+    if world > 1:
+        dist.destroy_process_group()
+    if not verified:
+        raise SystemExit("bench: result verification FAILED")
+
+
+if __name__ == "__main__":
+    main()

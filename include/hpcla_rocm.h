@@ -1,0 +1,236 @@
+/*
+ * hpcla_rocm.h -- C ABI of libhpcla_rocm.so, the MI355X (gfx950) device library behind the
+ * `DeviceROCm` backend of HPCLinearAlgebra.jl (sloisel/LinearAlgebraMPI.jl).
+ *
+ * Boundary.  The reference has no FFI for this path: its device work is Julia
+ * KernelAbstractions kernels plus CPU-staged MPI.  The entry points below are what a
+ * `ext/HPCLinearAlgebraROCmExt.jl` binds with `@ccall`, one per reference
+ * function it replaces; each declaration cites that function (paths relative to the reference
+ * repository root).  The pattern -- `ccall` returning an int status that the Julia wrapper checks --
+ * is the one the reference already uses for cuDSS/NCCL (ext/HPCLinearAlgebraCUDAExt.jl:247-251,
+ * 388-402).
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every data buffer is a DEVICE pointer owned by the caller
+ *    (ROCArray / torch tensor / hipMalloc) unless the parameter name ends in `_host`;
+ *  - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream); all work is
+ *    enqueued asynchronously, nothing synchronises the host unless documented;
+ *  - return value: HPCLA_OK (0) or a negative status; hpcla_last_error() gives the text;
+ *  - index arrays are int32 (`_i32`) or int64 (`_i64`, the reference default Ti=Int,
+ *    src/backends.jl:348); `index_base` is 1 for arrays passed untouched from Julia
+ *    (rowptr[1]==1, src/sparse.jl:2060) and 0 for C/Python callers;
+ *  - handles (comm, halo plan) are library-owned, explicitly destroyed, never finalised with a
+ *    collective (the reference's rule: ext/HPCLinearAlgebraCUDAExt.jl:9-10, 384-386);
+ *  - not thread-safe per handle; re-entrant across handles.
+ *
+ * Arithmetic contract (fp64): every row sum is accumulated sequentially in stored order with a
+ * separately rounded multiply and add (no FMA contraction), i.e. bit-identical to the reference
+ * loop `acc += nzval[j] * x[colval[j]]` (src/sparse.jl:2055-2066) on IEEE hardware.
+ */
+#ifndef HPCLA_ROCM_H
+#define HPCLA_ROCM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HPCLA_VERSION 100 /* 0.1.0 */
+
+/* status codes */
+#define HPCLA_OK 0
+#define HPCLA_ERR_INVALID -1     /* bad argument (null pointer, negative size, bad base/layout) */
+#define HPCLA_ERR_HIP -2         /* a HIP runtime call failed */
+#define HPCLA_ERR_RCCL -3        /* an RCCL call failed or librccl could not be loaded */
+#define HPCLA_ERR_NO_DEVICE -4   /* no gfx950 device visible */
+#define HPCLA_ERR_UNSUPPORTED -5 /* valid request this build does not implement */
+#define HPCLA_ERR_ALLOC -6       /* device or host allocation failed */
+
+/* dense layouts for SpMM operands: element (i,c) at ptr[i*ld + c] (ROW) or ptr[i + c*ld] (COL).
+ * COL is Julia's Matrix (src/dense.jl:63); ROW is the device-native layout (one 128-byte line per
+ * row at k=16). */
+#define HPCLA_LAYOUT_ROW 0
+#define HPCLA_LAYOUT_COL 1
+
+typedef struct hpcla_comm hpcla_comm_t;           /* one RCCL communicator (or a serial stub) */
+typedef struct hpcla_halo_plan hpcla_halo_plan_t; /* device half of a VectorPlan */
+
+/* ---- library ------------------------------------------------------------------------------ */
+int hpcla_version(void);
+const char *hpcla_last_error(void);
+/* Number of visible devices / select device for the calling thread (hipSetDevice).
+ * Mirrors the rank->device assignment of ext/HPCLinearAlgebraCUDAExt.jl:611-613. */
+int hpcla_device_count(int *count);
+int hpcla_set_device(int device);
+/* Device properties the host layer and bench report (CU count, arch name up to 63 chars). */
+int hpcla_device_info(int device, int *num_cus, char *arch_name_host, int arch_name_len);
+
+/* ---- SpMV:  replaces _spmv_kernel!/_spmv! (src/sparse.jl:2055-2084) ----------------------------
+ * y[r] = sum_{j=rowptr[r]}^{rowptr[r+1]-1} nzval[j] * x[colval[j]],  r in [0,nrows).
+ * `x` is the gathered vector x[col_indices] (length ncols_compressed), exactly the operand the
+ * reference passes (`plan.gathered`, src/sparse.jl:2114-2119).  nnz = rowptr[nrows]-index_base is
+ * passed by the caller (Julia: length(A.nzval)) so the launch needs no device->host read. */
+int hpcla_spmv_csr_f64_i32(const int32_t *rowptr, const int32_t *colval, const double *nzval,
+                           const double *x, double *y, int64_t nrows, int64_t nnz, int index_base,
+                           void *stream);
+int hpcla_spmv_csr_f64_i64(const int64_t *rowptr, const int64_t *colval, const double *nzval,
+                           const double *x, double *y, int64_t nrows, int64_t nnz, int index_base,
+                           void *stream);
+
+/* Split-column SpMV used by the distributed path: a column index c < n_own reads x_own[c] (the
+ * caller's HPCVector storage, x.v, untouched), c >= n_own reads x_ghost[c - n_own] (the halo
+ * plan's receive segment).  This removes the reference's local gather loop
+ * (src/vectors.jl:426-428, _gather_kernel! :174-177) from the hot path altogether.
+ * `block_list` (device, int32, may be NULL) restricts the launch to the listed row blocks of
+ * hpcla_spmv_rows_per_block() rows each -- the interior/boundary split.  colval is 0-based. */
+int hpcla_spmv_split_f64_i32(const int32_t *rowptr, const int32_t *colval_split,
+                             const double *nzval, const double *x_own, const double *x_ghost,
+                             int64_t n_own, double *y, int64_t nrows, int64_t nnz, int index_base,
+                             const int32_t *block_list, int64_t n_blocks, void *stream);
+int hpcla_spmv_split_f64_i64(const int64_t *rowptr, const int64_t *colval_split,
+                             const double *nzval, const double *x_own, const double *x_ghost,
+                             int64_t n_own, double *y, int64_t nrows, int64_t nnz, int index_base,
+                             const int32_t *block_list, int64_t n_blocks, void *stream);
+int hpcla_spmv_rows_per_block(void);
+int hpcla_spmm_rows_per_block(void);
+
+/* Plan-time helpers (run once per (A, x.partition), cached with the VectorPlan like
+ * _vector_plan_cache, src/HPCLinearAlgebra.jl:133).
+ * remap: out[j] = map[in[j] - index_base]   (compressed column -> split column; out is 0-based)
+ * classify: flags[b] = 1 if row block b (rows_per_block rows: hpcla_spmv_rows_per_block() or
+ *           hpcla_spmm_rows_per_block()) references any column >= n_own, else 0. */
+int hpcla_remap_i32(const int32_t *in, const int32_t *map, int32_t *out, int64_t n, int index_base,
+                    void *stream);
+int hpcla_remap_i64(const int64_t *in, const int64_t *map, int64_t *out, int64_t n, int index_base,
+                    void *stream);
+int hpcla_classify_blocks_i32(const int32_t *rowptr, const int32_t *colval_split, int64_t nrows,
+                              int index_base, int64_t n_own, int rows_per_block, int32_t *flags,
+                              void *stream);
+int hpcla_classify_blocks_i64(const int64_t *rowptr, const int64_t *colval_split, int64_t nrows,
+                              int index_base, int64_t n_own, int rows_per_block, int32_t *flags,
+                              void *stream);
+
+/* ---- SpMM:  replaces A*B column loop (src/sparse.jl:2391-2413) -------------------------------
+ * C[r,c] = sum_j nzval[j] * B[colval[j], c], c in [0,k): one pass over A for all k columns, each
+ * (r,c) accumulated sequentially in stored order (bit-identical to k reference SpMVs).
+ * B has ncols_compressed rows (or, split form, n_own rows in B_own and ghosts in B_ghost). */
+int hpcla_spmm_csr_f64_i32(const int32_t *rowptr, const int32_t *colval, const double *nzval,
+                           const double *B, int64_t ldb, int b_layout, double *C, int64_t ldc,
+                           int c_layout, int64_t nrows, int64_t nnz, int k, int index_base,
+                           void *stream);
+int hpcla_spmm_csr_f64_i64(const int64_t *rowptr, const int64_t *colval, const double *nzval,
+                           const double *B, int64_t ldb, int b_layout, double *C, int64_t ldc,
+                           int c_layout, int64_t nrows, int64_t nnz, int k, int index_base,
+                           void *stream);
+int hpcla_spmm_split_f64_i32(const int32_t *rowptr, const int32_t *colval_split,
+                             const double *nzval, const double *B_own, int64_t ldb_own,
+                             const double *B_ghost, int64_t ldb_ghost, int64_t n_own, double *C,
+                             int64_t ldc, int64_t nrows, int64_t nnz, int k, int index_base,
+                             const int32_t *block_list, int64_t n_blocks, void *stream);
+/* layout conversion for column-major callers (Julia Matrix): dst(row-major, ld=k) <- src */
+int hpcla_transpose_f64(const double *src, int64_t ld_src, int src_layout, double *dst,
+                        int64_t ld_dst, int dst_layout, int64_t rows, int64_t cols, void *stream);
+
+/* ---- gather: replaces _gather_kernel! (src/vectors.jl:174-194) --------------------------------
+ * out[dst[i]] = x[src[i]] (dst may be NULL = identity).  Kept for API parity
+ * (execute_plan! returning `gathered`); the SpMV hot path does not need it. */
+int hpcla_gather_f64_i32(const double *x, const int32_t *src, const int32_t *dst, double *out,
+                         int64_t n, int index_base, void *stream);
+int hpcla_gather_f64_i64(const double *x, const int64_t *src, const int64_t *dst, double *out,
+                         int64_t n, int index_base, void *stream);
+
+/* ---- communicator: RCCL over xGMI, replaces comm_* on the hot path (src/backends.jl:264-327)
+ * Bootstrap follows ext/HPCLinearAlgebraCUDAExt.jl:388-443: rank 0 gets a 128-byte unique id,
+ * the host runtime (MPI.Bcast! / torch.distributed) broadcasts it, every rank calls init_rank.
+ * nranks==1 creates a serial communicator that never loads librccl (CommSerial,
+ * src/backends.jl:63). */
+#define HPCLA_UNIQUE_ID_BYTES 128
+int hpcla_comm_get_unique_id(uint8_t *id_host /* 128 bytes */);
+int hpcla_comm_init_rank(hpcla_comm_t **comm, const uint8_t *id_host, int nranks, int rank);
+int hpcla_comm_rank(const hpcla_comm_t *comm, int *rank);
+int hpcla_comm_size(const hpcla_comm_t *comm, int *nranks);
+int hpcla_comm_destroy(hpcla_comm_t *comm);
+/* in-place all-reduce of `count` doubles on `stream`: op 0 = sum, 1 = max
+ * (comm_allreduce(comm, x, + | max), src/backends.jl:264-277). */
+int hpcla_allreduce_f64(hpcla_comm_t *comm, double *buf, int64_t count, int op, void *stream);
+
+/* ---- halo plan: device half of VectorPlan / execute_plan! (src/vectors.jl:229-251, 394-463)
+ * Inputs are the reference plan's own lists (0-based here):
+ *   send_ranks_host[i], send_counts_host[i], send_idx (device, int32 or int64, concatenated in
+ *   send_ranks order; local indices into x.v  == plan.send_indices, src/sparse.jl:1939-1944);
+ *   recv_ranks_host[i], recv_counts_host[i]: ghost segment i (plan.recv_perm[i]) has
+ *   recv_counts[i] entries; segments are stored back to back in recv_ranks order in the ghost
+ *   buffer.  Because col_indices is sorted (src/sparse.jl:501) and owners are contiguous rank
+ *   ranges (src/sparse.jl:1890), that order IS ascending global column order.
+ * `width` = values per index (1 for vectors, k for SpMM ghost rows, row-major).
+ * The plan owns: packed send buffer, ghost buffer, one side stream, two events. */
+int hpcla_halo_plan_create(hpcla_halo_plan_t **plan, hpcla_comm_t *comm, int n_send,
+                           const int32_t *send_ranks_host, const int64_t *send_counts_host,
+                           const void *send_idx, int idx_is_i64, int n_recv,
+                           const int32_t *recv_ranks_host, const int64_t *recv_counts_host,
+                           int width);
+int hpcla_halo_plan_destroy(hpcla_halo_plan_t *plan);
+/* device pointer of the ghost buffer (n_ghost*width doubles) and its length in indices */
+int hpcla_halo_ghost_ptr(hpcla_halo_plan_t *plan, double **ghost, int64_t *n_ghost);
+/* begin: after everything already enqueued on `stream`, pack x[send_idx] and post the
+ * ncclSend/ncclRecv group on the plan's side stream (tag-21 exchange, src/vectors.jl:431-446).
+ * end: make `stream` wait for the exchange.  Work enqueued on `stream` between begin and end
+ * (the interior SpMV) overlaps the exchange.  x has leading dimension `width` (row-major). */
+int hpcla_halo_begin(hpcla_halo_plan_t *plan, const double *x, void *stream);
+int hpcla_halo_end(hpcla_halo_plan_t *plan, void *stream);
+
+/* Fused distributed SpMV  y = A*x  (Base.:*(A,x), src/sparse.jl:2096-2128; mul!, :2019-2037):
+ * halo_begin -> interior blocks -> halo_end -> boundary blocks.  block lists from
+ * hpcla_classify_blocks_*; with plan==NULL or no neighbours it is a plain split SpMV. */
+int hpcla_spmv_dist_f64_i32(hpcla_halo_plan_t *plan, const int32_t *rowptr,
+                            const int32_t *colval_split, const double *nzval, const double *x,
+                            int64_t n_own, double *y, int64_t nrows, int64_t nnz, int index_base,
+                            const int32_t *interior_blocks, int64_t n_interior,
+                            const int32_t *boundary_blocks, int64_t n_boundary, void *stream);
+int hpcla_spmv_dist_f64_i64(hpcla_halo_plan_t *plan, const int64_t *rowptr,
+                            const int64_t *colval_split, const double *nzval, const double *x,
+                            int64_t n_own, double *y, int64_t nrows, int64_t nnz, int index_base,
+                            const int32_t *interior_blocks, int64_t n_interior,
+                            const int32_t *boundary_blocks, int64_t n_boundary, void *stream);
+
+/* ---- reductions: replace dot / norm (src/vectors.jl:798-812, 758-780) --------------------------
+ * Local deterministic two-stage reduction into out_dev[0] (device double), then, if comm has
+ * more than one rank, an in-place RCCL all-reduce on the same stream.  No host sync: CG keeps the
+ * scalar on the device.  `work` is a caller-provided device scratch of hpcla_reduce_work_bytes().
+ *  dot:   sum x[i]*y[i]
+ *  nrm2sq: sum x[i]^2 (the reference squares the local 2-norm before summing, :764-765; the
+ *          caller takes sqrt), asum: sum |x[i]| (p=1), amax: max |x[i]| (p=Inf). */
+int64_t hpcla_reduce_work_bytes(void);
+int hpcla_dot_f64(hpcla_comm_t *comm, const double *x, const double *y, int64_t n, double *out_dev,
+                  void *work, void *stream);
+int hpcla_nrm2sq_f64(hpcla_comm_t *comm, const double *x, int64_t n, double *out_dev, void *work,
+                     void *stream);
+int hpcla_asum_f64(hpcla_comm_t *comm, const double *x, int64_t n, double *out_dev, void *work,
+                   void *stream);
+int hpcla_amax_f64(hpcla_comm_t *comm, const double *x, int64_t n, double *out_dev, void *work,
+                   void *stream);
+
+/* ---- vector updates: replace u+v, a*v and fused broadcast (src/vectors.jl:868-903, 944-964,
+ * 1203-1226).  The scalar is alpha_host * (num_dev ? *num_dev : 1) / (den_dev ? *den_dev : 1),
+ * so CG coefficients computed by the reductions above never visit the host.
+ *  axpy: y[i] = y[i] + a*x[i]      xpay: y[i] = x[i] + a*y[i]
+ *  scale: y[i] = a*x[i]            axpby: z[i] = a*x[i] + b*y[i] (host scalars)
+ *  divide: y[i] = x[i] / a  (v / a, src/vectors.jl:960-964; a true division, not a reciprocal) */
+int hpcla_axpy_f64(double alpha_host, const double *num_dev, const double *den_dev, const double *x,
+                   double *y, int64_t n, void *stream);
+int hpcla_xpay_f64(const double *x, double alpha_host, const double *num_dev, const double *den_dev,
+                   double *y, int64_t n, void *stream);
+int hpcla_scale_f64(double alpha_host, const double *x, double *y, int64_t n, void *stream);
+int hpcla_divide_f64(const double *x, double a_host, double *y, int64_t n, void *stream);
+int hpcla_axpby_f64(double a, const double *x, double b, const double *y, double *z, int64_t n,
+                    void *stream);
+
+/* ---- synthetic inputs on the device (bench/tests): the SURVEY section 8d counter-based
+ * generator, v[i] = u01(seed, start+i). */
+int hpcla_fill_uniform_f64(double *v, int64_t start, int64_t count, uint64_t seed, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HPCLA_ROCM_H */

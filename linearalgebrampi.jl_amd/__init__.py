@@ -1,0 +1,31 @@
+"""linearalgebrampi.jl_amd -- MI355X-native DeviceROCm backend for the HPCLinearAlgebra.jl
+(sloisel/LinearAlgebraMPI.jl) distributed SpMV / SpMM / CG hot path.
+
+Layout
+  csrc/              hand-written HIP kernels + the C ABI (include/hpcla_rocm.h) -> libhpcla_rocm.so
+  _capi.py           ctypes binding of the C ABI (no fallback)
+  backends.py        HPCBackend{T,Ti,Device,Comm,Solver}, DeviceROCm, comm_* primitives
+  partition.py       uniform_partition, structural hashes
+  vectors.py         HPCVector, dot, norm, fused updates
+  sparse.py          HPCSparseMatrix, VectorPlan (host lists + device plan), A*x, mul!
+  dense.py           HPCMatrix, A*B (SpMM)
+  cg.py              fixed-iteration CG harness
+
+The directory name contains a dot, so it is imported through the top-level alias module
+``hpcla_amd`` (``import hpcla_amd as hp``).
+"""
+from . import _capi
+from .backends import (AbstractComm, AbstractDevice, CommSerial, CommTorch, DeviceROCm, HPCBackend,
+                       SolverNone, assert_backends_compatible, backend_rocm_mpi,
+                       backend_rocm_serial, backends_compatible, comm_rank, comm_size,
+                       eltype_backend, indextype_backend)
+from .partition import (compute_partition_hash, compute_structural_hash, owner_of,
+                        uniform_partition)
+from .vectors import HPCVector, HPCVector_local, dot, norm
+from .sparse import (HPCSparseMatrix, HPCSparseMatrix_from_global, HPCSparseMatrix_local,
+                     HostVectorPlan, VectorPlan, build_host_vector_plan, cache_sizes,
+                     clear_plan_cache, execute_plan, get_vector_plan, mul_, split_column_map)
+from .dense import HPCMatrix, HPCMatrix_local, clear_spmm_cache, spmm
+from .cg import cg_fixed_iterations
+
+__all__ = [n for n in dir() if not n.startswith("_")] + ["_capi"]

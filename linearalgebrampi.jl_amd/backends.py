@@ -1,0 +1,331 @@
+"""HPCBackend plugin surface with the new ``DeviceROCm`` device (reference: src/backends.jl).
+
+Mirrors ``HPCBackend{T,Ti,Device,Comm,Solver}`` (src/backends.jl:137-141), the device/comm tags
+(:22-75), the factories (``backend_cuda_mpi``-style stubs :416-432, implemented by the CUDA
+extension at ext/HPCLinearAlgebraCUDAExt.jl:98-121) and the ``comm_*`` primitives (:199-327).
+
+Host-side collectives (plan construction: counts, index lists, partition sizes) go through
+``torch.distributed`` -- gloo on CPU, or the NCCL(=RCCL) group via device tensors -- exactly where
+the reference uses host MPI.  Data-path collectives (halo values, dot/norm scalars) go through the
+library's own RCCL communicator (``hpcla_comm_*``), bootstrapped the way the reference bootstraps
+NCCL from MPI (ext/HPCLinearAlgebraCUDAExt.jl:411-443): rank 0 makes the unique id, the host
+runtime broadcasts it.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+
+# ---- devices (src/backends.jl:22-45) -------------------------------------------------------------
+class AbstractDevice:
+    pass
+
+
+class DeviceROCm(AbstractDevice):
+    """AMD GPU device (gfx950).  ``index`` is the HIP device ordinal of this process."""
+
+    def __init__(self, index: int = 0):
+        self.index = int(index)
+
+    def __repr__(self):
+        return f"DeviceROCm({self.index})"
+
+
+# ---- solvers: out of scope for this path, tag kept so the 5-parameter shape matches ---------------
+class AbstractSolver:
+    pass
+
+
+class SolverNone(AbstractSolver):
+    def __repr__(self):
+        return "SolverNone()"
+
+
+# ---- comms (src/backends.jl:56-75, 199-327) ------------------------------------------------------
+class AbstractComm:
+    pass
+
+
+class CommSerial(AbstractComm):
+    """Single process; collectives are copies/no-ops (src/backends.jl:63, 207-327)."""
+
+    def __eq__(self, other):
+        return isinstance(other, CommSerial)
+
+    def __hash__(self):
+        return hash("CommSerial")
+
+    def __repr__(self):
+        return "CommSerial()"
+
+
+class CommTorch(AbstractComm):
+    """The CommMPI analogue (src/backends.jl:75): a ``torch.distributed`` process group for the
+    host-side collectives.  ``group=None`` is the default (world) group."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            raise RuntimeError("CommTorch requires torch.distributed.init_process_group first")
+        self.group = group
+
+    def __eq__(self, other):
+        return isinstance(other, CommTorch) and other.group is self.group
+
+    def __hash__(self):
+        return hash(("CommTorch", id(self.group)))
+
+    def __repr__(self):
+        return f"CommTorch(rank={comm_rank(self)}, size={comm_size(self)})"
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist
+
+
+def _host_device(comm: "CommTorch"):
+    """Device on which host-side collectives stage their tensors: CPU when the group has a CPU
+    backend (gloo), else the current GPU (NCCL/RCCL-only groups).  Decided once per communicator
+    by the backend name, falling back to a one-element probe collective (every rank takes the same
+    branch, so the probe cannot desynchronise ranks)."""
+    import torch
+    if getattr(comm, "_host_dev", None) is not None:
+        return comm._host_dev
+    dist = _dist()
+    name = str(dist.get_backend(comm.group)).lower()
+    if "gloo" in name or "mpi" in name:
+        dev = torch.device("cpu")
+    elif name == "nccl":
+        dev = torch.device("cuda", torch.cuda.current_device())
+    else:
+        try:
+            t = torch.zeros(1, dtype=torch.int64)
+            dist.all_reduce(t, group=comm.group)
+            dev = torch.device("cpu")
+        except Exception:
+            dev = torch.device("cuda", torch.cuda.current_device())
+    comm._host_dev = dev
+    return dev
+
+
+def comm_rank(comm: AbstractComm) -> int:            # src/backends.jl:207-209
+    if isinstance(comm, CommSerial):
+        return 0
+    return _dist().get_rank(comm.group)
+
+
+def comm_size(comm: AbstractComm) -> int:            # src/backends.jl:214-216
+    if isinstance(comm, CommSerial):
+        return 1
+    return _dist().get_world_size(comm.group)
+
+
+def comm_barrier(comm: AbstractComm) -> None:
+    if isinstance(comm, CommSerial):
+        return
+    _dist().barrier(group=comm.group)
+
+
+def comm_allgather(comm: AbstractComm, values: np.ndarray) -> np.ndarray:
+    """Allgather of equal-length int64 arrays -> flat concatenation (src/backends.jl:225-230)."""
+    values = np.ascontiguousarray(values, dtype=np.int64).reshape(-1)
+    if isinstance(comm, CommSerial):
+        return values.copy()
+    import torch
+    dev = _host_device(comm)
+    t = torch.from_numpy(values).to(dev)
+    out = [torch.empty_like(t) for _ in range(comm_size(comm))]
+    _dist().all_gather(out, t, group=comm.group)
+    return torch.cat(out).cpu().numpy()
+
+
+def comm_allgather_bytes(comm: AbstractComm, payload: bytes) -> List[bytes]:
+    """Allgather of equal-length byte strings (the 32-byte digests of compute_structural_hash,
+    src/sparse.jl:115)."""
+    if isinstance(comm, CommSerial):
+        return [payload]
+    arr = np.frombuffer(payload, dtype=np.uint8).astype(np.int64)
+    flat = comm_allgather(comm, arr)
+    n = len(arr)
+    return [bytes(flat[i * n:(i + 1) * n].astype(np.uint8)) for i in range(comm_size(comm))]
+
+
+def comm_alltoall_counts(comm: AbstractComm, send_counts: Sequence[int]) -> np.ndarray:
+    """comm_alltoall(comm, UBuffer(send_counts, 1)) (src/sparse.jl:1899-1900): element r of the
+    result is what rank r announced for me.  Implemented as an allgather of the count rows (the
+    matrix is nranks x nranks int64 -- tiny), which every torch.distributed backend supports."""
+    send_counts = np.asarray(send_counts, dtype=np.int64)
+    if isinstance(comm, CommSerial):
+        return send_counts.copy()
+    n = comm_size(comm)
+    allc = comm_allgather(comm, send_counts).reshape(n, n)
+    return allc[:, comm_rank(comm)].copy()
+
+
+def comm_exchange_indices(comm: AbstractComm, send_to: Sequence[int], send_arrays: Sequence[np.ndarray],
+                          recv_from: Sequence[int], recv_counts: Sequence[int]) -> List[np.ndarray]:
+    """Isend/Irecv/Waitall of int64 index lists (tag 20 exchange, src/sparse.jl:1908-1936)."""
+    if isinstance(comm, CommSerial):
+        assert len(send_to) == 0 and len(recv_from) == 0
+        return []
+    import torch
+    dist = _dist()
+    dev = _host_device(comm)
+    ops = []
+    keep = []
+    recv_bufs = []
+    for r, cnt in zip(recv_from, recv_counts):
+        buf = torch.empty(int(cnt), dtype=torch.int64, device=dev)
+        recv_bufs.append(buf)
+        ops.append(dist.P2POp(dist.irecv, buf, _global_rank(comm, r), group=comm.group))
+    for r, arr in zip(send_to, send_arrays):
+        t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.int64)).to(dev)
+        keep.append(t)
+        ops.append(dist.P2POp(dist.isend, t, _global_rank(comm, r), group=comm.group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return [b.cpu().numpy() for b in recv_bufs]
+
+
+def _global_rank(comm: "CommTorch", group_rank: int) -> int:
+    dist = _dist()
+    if comm.group is None:
+        return int(group_rank)
+    return dist.get_global_rank(comm.group, int(group_rank))
+
+
+def comm_bcast_bytes(comm: AbstractComm, payload: Optional[bytes], nbytes: int, root: int = 0) -> bytes:
+    """comm_bcast! of a byte buffer (the 128-byte RCCL unique id, cf. MPI.Bcast! at
+    ext/HPCLinearAlgebraCUDAExt.jl:425-432)."""
+    if isinstance(comm, CommSerial):
+        return payload
+    import torch
+    dev = _host_device(comm)
+    if comm_rank(comm) == root:
+        t = torch.tensor(list(payload), dtype=torch.uint8, device=dev)
+    else:
+        t = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+    _dist().broadcast(t, src=_global_rank(comm, root), group=comm.group)
+    return bytes(t.cpu().numpy().tolist())
+
+
+# ---- HPCBackend (src/backends.jl:137-141) ----------------------------------------------------------
+_INDEX_TYPES = {np.dtype(np.int32): np.int32, np.dtype(np.int64): np.int64}
+
+
+class HPCBackend:
+    """``HPCBackend{T,Ti,D,C,S}``: element type, index type, device, comm, solver.
+
+    For ``DeviceROCm`` the backend also owns the library communicator handle (``rccl``): a serial
+    stub for CommSerial, an RCCL communicator over xGMI for CommTorch.  Like the reference's NCCL
+    communicator it lives until process exit (no finaliser issues a collective,
+    ext/HPCLinearAlgebraCUDAExt.jl:384-386)."""
+
+    def __init__(self, T, Ti, device: AbstractDevice, comm: AbstractComm, solver: AbstractSolver,
+                 rccl=None):
+        self.T = np.dtype(T)
+        self.Ti = np.dtype(Ti)
+        if self.T != np.dtype(np.float64):
+            raise TypeError(f"DeviceROCm backend implements Float64 only, got {self.T}")
+        if self.Ti not in _INDEX_TYPES:
+            raise TypeError(f"index type must be int32 or int64, got {self.Ti}")
+        self.device = device
+        self.comm = comm
+        self.solver = solver
+        self.rccl = rccl           # ctypes.c_void_p handle of hpcla_comm_t
+
+    def __repr__(self):
+        return (f"HPCBackend{{{self.T},{self.Ti},{type(self.device).__name__},"
+                f"{type(self.comm).__name__},{type(self.solver).__name__}}}")
+
+    @property
+    def torch_device(self):
+        import torch
+        return torch.device("cuda", self.device.index)
+
+
+def eltype_backend(b: HPCBackend):        # src/backends.jl:153-154
+    return b.T
+
+
+def indextype_backend(b: HPCBackend):     # src/backends.jl:162-163
+    return b.Ti
+
+
+def backends_compatible(b1: HPCBackend, b2: HPCBackend) -> bool:   # src/backends.jl:444-455
+    if type(b1.device) is not type(b2.device):
+        return False
+    if type(b1.comm) is not type(b2.comm):
+        return False
+    if isinstance(b1.comm, CommTorch) and b1.comm.group is not b2.comm.group:
+        return False
+    return True
+
+
+def assert_backends_compatible(b1: HPCBackend, b2: HPCBackend) -> None:   # :460-464
+    if not backends_compatible(b1, b2):
+        raise ValueError(f"Incompatible backends: {b1!r} vs {b2!r}")
+
+
+def _require_gpu(index: int) -> None:
+    from . import _capi
+    cnt = ctypes.c_int(0)
+    _capi.call("hpcla_device_count", ctypes.byref(cnt))
+    if index >= cnt.value:
+        raise RuntimeError(f"DeviceROCm({index}) requested but only {cnt.value} device(s) visible")
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("DeviceROCm needs a visible MI355X (torch.cuda.is_available() is False)")
+    torch.cuda.set_device(index)
+    _capi.call("hpcla_set_device", index)
+
+
+def _make_rccl(comm: AbstractComm):
+    from . import _capi
+    lib = _capi.load()
+    nranks, rank = comm_size(comm), comm_rank(comm)
+    handle = ctypes.c_void_p()
+    need_id = nranks > 1 or os.environ.get("HPCLA_FORCE_RCCL", "") == "1"
+    uid = None
+    if need_id:
+        if rank == 0:
+            buf = (ctypes.c_uint8 * _capi.UNIQUE_ID_BYTES)()
+            _capi.call("hpcla_comm_get_unique_id", buf)
+            uid = bytes(buf)
+        uid = comm_bcast_bytes(comm, uid, _capi.UNIQUE_ID_BYTES, root=0)
+        idbuf = (ctypes.c_uint8 * _capi.UNIQUE_ID_BYTES).from_buffer_copy(uid)
+        _capi.check("hpcla_comm_init_rank",
+                    lib.hpcla_comm_init_rank(ctypes.byref(handle), idbuf, nranks, rank))
+    else:
+        _capi.check("hpcla_comm_init_rank",
+                    lib.hpcla_comm_init_rank(ctypes.byref(handle), None, 1, 0))
+    return handle
+
+
+def backend_rocm_serial(T=np.float64, Ti=np.int64, device_index: int = 0) -> HPCBackend:
+    """``backend_rocm_serial(T=Float64, Ti=Int)`` -- the DeviceROCm twin of backend_cuda_serial
+    (src/backends.jl:424, ext/HPCLinearAlgebraCUDAExt.jl:98-103).  Ti defaults to Int64 like the
+    reference (`Ti=Int`); the headline benchmark uses Int32."""
+    _require_gpu(device_index)
+    comm = CommSerial()
+    return HPCBackend(T, Ti, DeviceROCm(device_index), comm, SolverNone(), rccl=_make_rccl(comm))
+
+
+def backend_rocm_mpi(T=np.float64, Ti=np.int64, group=None, device_index: Optional[int] = None) -> HPCBackend:
+    """``backend_rocm_mpi(T, Ti; comm)`` -- one process per GPU; the device is
+    ``local_rank % ndevices`` as in ext/HPCLinearAlgebraCUDAExt.jl:611-613."""
+    import torch
+    comm = CommTorch(group)
+    if device_index is None:
+        local_rank = int(os.environ.get("LOCAL_RANK", comm_rank(comm)))
+        ndev = max(torch.cuda.device_count(), 1)
+        device_index = local_rank % ndev
+    _require_gpu(device_index)
+    return HPCBackend(T, Ti, DeviceROCm(device_index), comm, SolverNone(), rccl=_make_rccl(comm))

@@ -1,0 +1,53 @@
+"""Conjugate-gradient harness for BASELINE config 4 (3-D Poisson, 100 iterations).
+
+The reference has no Krylov solver; a caller composes one from ``A*p``
+(src/sparse.jl:2096-2128), ``dot`` (src/vectors.jl:798-812) and broadcast updates
+(src/vectors.jl:1203-1226).  This harness does exactly that with the DeviceROCm operators, keeping
+every scalar on the device: alpha = rr/pAp and beta = rr_new/rr are consumed by the update kernels
+as (numerator, denominator) device pointers, so an iteration is 1 SpMV (+halo), 2 reductions
+(+2 one-double RCCL all-reduces), 3 vector updates and NO host synchronisation.
+"""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+from .sparse import get_vector_plan, mul_
+from .vectors import HPCVector, dot
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def cg_fixed_iterations(A, b: HPCVector, iters: int, record_history: bool = True) -> Tuple[HPCVector, List[float]]:
+    """Textbook CG from x0 = 0, exactly ``iters`` iterations, no convergence exit.
+    Returns (x, [||r_0||, ..., ||r_iters||]) (history read back once at the end)."""
+    torch = _torch()
+    dev = b.v.device
+    x = HPCVector.zeros(b.partition, b.backend)
+    r = b.copy()
+    p = b.copy()
+    Ap = b.similar()
+    get_vector_plan(A, p)                      # build/cached plan outside the loop
+    # device scalars: rr[2] ping-pong, pAp
+    rr = torch.zeros(2, dtype=torch.float64, device=dev)
+    pAp = torch.zeros(1, dtype=torch.float64, device=dev)
+    hist = torch.zeros(iters + 1, dtype=torch.float64, device=dev)
+    dot(r, r, out=rr[0:1])
+    if record_history:
+        hist[0:1].copy_(rr[0:1])
+    cur = 0
+    for it in range(iters):
+        nxt = 1 - cur
+        mul_(Ap, A, p)                                          # Ap = A*p
+        dot(p, Ap, out=pAp)                                     # pAp
+        x.axpy_(1.0, p, num=rr[cur:cur + 1], den=pAp)           # x += (rr/pAp) p
+        r.axpy_(-1.0, Ap, num=rr[cur:cur + 1], den=pAp)         # r -= (rr/pAp) Ap
+        dot(r, r, out=rr[nxt:nxt + 1])                          # rr_new
+        p.xpay_(r, 1.0, num=rr[nxt:nxt + 1], den=rr[cur:cur + 1])   # p = r + (rr_new/rr) p
+        if record_history:
+            hist[it + 1:it + 2].copy_(rr[nxt:nxt + 1])
+        cur = nxt
+    h = hist.sqrt().cpu().tolist() if record_history else []
+    return x, h

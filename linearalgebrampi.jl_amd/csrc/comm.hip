@@ -1,0 +1,445 @@
+// comm.hip -- RCCL communicator, GPU-resident halo exchange and the fused distributed SpMV.
+//
+// Replaces the execute half of the reference's VectorPlan (execute_plan!, src/vectors.jl:394-463):
+// there every SpMV copies x to the host, packs send buffers on the CPU, runs MPI Isend/Irecv on host
+// memory, unpacks and copies the gathered vector back to the device, strictly before the kernel.
+// Here the exchange never leaves the GPUs: a pack kernel (skipped when a neighbour's indices are one
+// contiguous run, as for stencil slabs) and one ncclGroup of ncclSend/ncclRecv over xGMI run on the
+// plan's side stream while the interior row blocks are computed on the caller's stream; receives
+// land directly in the ghost segment the boundary row blocks read (no unpack, no local copy).
+//
+// librccl is loaded lazily with dlopen so the single-GPU path has no RCCL dependency; inside a
+// PyTorch process the already-loaded librccl.so.1 is reused (same SONAME).
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "common.h"
+
+namespace hpcla {
+
+int spmv_split_i32(const int32_t *, const int32_t *, const double *, const double *, const double *,
+                   int64_t, double *, int64_t, int64_t, int, const int32_t *, int64_t, void *);
+int spmv_split_i64(const int64_t *, const int64_t *, const double *, const double *, const double *,
+                   int64_t, double *, int64_t, int64_t, int, const int32_t *, int64_t, void *);
+
+// ---- RCCL entry points, resolved at first use ------------------------------------------------
+struct RcclApi {
+    void *handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+
+static RcclApi g_rccl;
+
+static int rccl_load()
+{
+    if (g_rccl.handle) return HPCLA_OK;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *h = nullptr;
+    for (const char *n : names) {
+        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+    }
+    if (!h) return set_error(HPCLA_ERR_RCCL, "cannot dlopen librccl: %s", dlerror());
+#define HPCLA_SYM(field, name)                                                                    \
+    g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(h, name));                      \
+    if (!g_rccl.field) return set_error(HPCLA_ERR_RCCL, "librccl lacks symbol %s", name);
+    HPCLA_SYM(GetUniqueId, "ncclGetUniqueId")
+    HPCLA_SYM(CommInitRank, "ncclCommInitRank")
+    HPCLA_SYM(CommDestroy, "ncclCommDestroy")
+    HPCLA_SYM(Send, "ncclSend")
+    HPCLA_SYM(Recv, "ncclRecv")
+    HPCLA_SYM(GroupStart, "ncclGroupStart")
+    HPCLA_SYM(GroupEnd, "ncclGroupEnd")
+    HPCLA_SYM(AllReduce, "ncclAllReduce")
+    HPCLA_SYM(GetErrorString, "ncclGetErrorString")
+#undef HPCLA_SYM
+    g_rccl.handle = h;
+    return HPCLA_OK;
+}
+
+#define HPCLA_CHECK_RCCL(expr)                                                                    \
+    do {                                                                                          \
+        ncclResult_t _r = (expr);                                                                 \
+        if (_r != ncclSuccess)                                                                    \
+            return hpcla::set_error(HPCLA_ERR_RCCL, "%s failed: %s (%s:%d)", #expr,               \
+                                    g_rccl.GetErrorString(_r), __FILE__, __LINE__);               \
+    } while (0)
+
+}  // namespace hpcla
+
+struct hpcla_comm {
+    int nranks = 1;
+    int rank = 0;
+    ncclComm_t nccl = nullptr;   // null for the serial communicator
+};
+
+struct hpcla_halo_plan {
+    hpcla_comm *comm = nullptr;
+    int width = 1;
+    std::vector<int> send_ranks, recv_ranks;
+    std::vector<int64_t> send_counts, recv_counts, send_off, recv_off;
+    std::vector<int64_t> send_first;   // first index of neighbour i when its run is contiguous
+    std::vector<char> send_contig;
+    bool need_pack = false;
+    int64_t n_send_total = 0, n_ghost = 0;
+    void *send_idx = nullptr;   // device copy of the concatenated send indices
+    int idx_is_i64 = 0;
+    double *send_buf = nullptr; // device, n_send_total * width
+    double *ghost = nullptr;    // device, n_ghost * width
+    hipStream_t side = nullptr;
+    hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+};
+
+namespace hpcla {
+
+// pack: buf[(off+i)*w + c] = x[idx[off+i]*w + c]
+template <typename I>
+__global__ __launch_bounds__(256) void pack_kernel(const double *__restrict__ x,
+                                                   const I *__restrict__ idx,
+                                                   double *__restrict__ buf, int64_t n, int w)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t total = n * w;
+    for (; t < total; t += stride) {
+        const int64_t i = t / w;
+        const int c = (int)(t - i * w);
+        buf[t] = x[(int64_t)idx[i] * w + c];
+    }
+}
+
+int allreduce_on(hpcla_comm_t *comm, double *buf, int64_t count, int op, void *stream)
+{
+    if (!comm) return set_error(HPCLA_ERR_INVALID, "allreduce: null communicator");
+    if (count < 0) return set_error(HPCLA_ERR_INVALID, "allreduce: negative count");
+    if (op != 0 && op != 1) return set_error(HPCLA_ERR_INVALID, "allreduce: op must be 0 or 1");
+    if (comm->nranks == 1 || !comm->nccl || count == 0) return HPCLA_OK;
+    if (!buf) return set_error(HPCLA_ERR_INVALID, "allreduce: null buffer");
+    HPCLA_CHECK_RCCL(g_rccl.AllReduce(buf, buf, (size_t)count, ncclDouble,
+                                      op == 0 ? ncclSum : ncclMax, comm->nccl, as_stream(stream)));
+    return HPCLA_OK;
+}
+
+}  // namespace hpcla
+
+using namespace hpcla;
+
+HPCLA_API int hpcla_comm_get_unique_id(uint8_t *id_host)
+{
+    if (!id_host) return set_error(HPCLA_ERR_INVALID, "get_unique_id: null buffer");
+    static_assert(sizeof(ncclUniqueId) == HPCLA_UNIQUE_ID_BYTES, "ncclUniqueId size");
+    int rc = rccl_load();
+    if (rc) return rc;
+    ncclUniqueId id;
+    HPCLA_CHECK_RCCL(g_rccl.GetUniqueId(&id));
+    memcpy(id_host, &id, sizeof(id));
+    return HPCLA_OK;
+}
+
+HPCLA_API int hpcla_comm_init_rank(hpcla_comm_t **comm, const uint8_t *id_host, int nranks,
+                                   int rank)
+{
+    if (!comm) return set_error(HPCLA_ERR_INVALID, "comm_init_rank: null output");
+    if (nranks < 1 || rank < 0 || rank >= nranks)
+        return set_error(HPCLA_ERR_INVALID, "comm_init_rank: bad rank %d of %d", rank, nranks);
+    hpcla_comm *c = new (std::nothrow) hpcla_comm();
+    if (!c) return set_error(HPCLA_ERR_ALLOC, "comm_init_rank: out of memory");
+    c->nranks = nranks;
+    c->rank = rank;
+    // nranks == 1: serial communicator (CommSerial, src/backends.jl:63).  HPCLA_FORCE_RCCL=1 makes
+    // a real one-rank RCCL communicator, used by the self-send test of the exchange code.
+    const char *force = getenv("HPCLA_FORCE_RCCL");
+    if (nranks > 1 || (force && force[0] == '1')) {
+        if (!id_host) { delete c; return set_error(HPCLA_ERR_INVALID, "comm_init_rank: null id"); }
+        int rc = rccl_load();
+        if (rc) { delete c; return rc; }
+        ncclUniqueId id;
+        memcpy(&id, id_host, sizeof(id));
+        ncclResult_t r = g_rccl.CommInitRank(&c->nccl, nranks, id, rank);
+        if (r != ncclSuccess) {
+            delete c;
+            return set_error(HPCLA_ERR_RCCL, "ncclCommInitRank failed: %s", g_rccl.GetErrorString(r));
+        }
+    }
+    *comm = c;
+    return HPCLA_OK;
+}
+
+HPCLA_API int hpcla_comm_rank(const hpcla_comm_t *comm, int *rank)
+{
+    if (!comm || !rank) return set_error(HPCLA_ERR_INVALID, "comm_rank: null pointer");
+    *rank = comm->rank;
+    return HPCLA_OK;
+}
+
+HPCLA_API int hpcla_comm_size(const hpcla_comm_t *comm, int *nranks)
+{
+    if (!comm || !nranks) return set_error(HPCLA_ERR_INVALID, "comm_size: null pointer");
+    *nranks = comm->nranks;
+    return HPCLA_OK;
+}
+
+HPCLA_API int hpcla_comm_destroy(hpcla_comm_t *comm)
+{
+    if (!comm) return HPCLA_OK;
+    if (comm->nccl) {
+        ncclResult_t r = g_rccl.CommDestroy(comm->nccl);
+        comm->nccl = nullptr;
+        if (r != ncclSuccess) {
+            delete comm;
+            return set_error(HPCLA_ERR_RCCL, "ncclCommDestroy failed: %s", g_rccl.GetErrorString(r));
+        }
+    }
+    delete comm;
+    return HPCLA_OK;
+}
+
+HPCLA_API int hpcla_allreduce_f64(hpcla_comm_t *comm, double *buf, int64_t count, int op,
+                                  void *stream)
+{
+    return allreduce_on(comm, buf, count, op, stream);
+}
+
+// ---- halo plan ----------------------------------------------------------------------------------
+static void halo_free(hpcla_halo_plan *p)
+{
+    if (!p) return;
+    if (p->send_idx) (void)hipFree(p->send_idx);
+    if (p->send_buf) (void)hipFree(p->send_buf);
+    if (p->ghost) (void)hipFree(p->ghost);
+    if (p->ev_ready) (void)hipEventDestroy(p->ev_ready);
+    if (p->ev_done) (void)hipEventDestroy(p->ev_done);
+    if (p->side) (void)hipStreamDestroy(p->side);
+    delete p;
+}
+
+template <typename I>
+static void scan_contiguous(hpcla_halo_plan *p, const std::vector<I> &idx)
+{
+    p->need_pack = false;
+    for (size_t i = 0; i < p->send_ranks.size(); ++i) {
+        const int64_t off = p->send_off[i], cnt = p->send_counts[i];
+        bool contig = true;
+        for (int64_t k = 1; k < cnt; ++k)
+            if ((int64_t)idx[off + k] != (int64_t)idx[off] + k) { contig = false; break; }
+        p->send_contig[i] = contig ? 1 : 0;
+        p->send_first[i] = cnt > 0 ? (int64_t)idx[off] : 0;
+        if (!contig) p->need_pack = true;
+    }
+}
+
+HPCLA_API int hpcla_halo_plan_create(hpcla_halo_plan_t **plan, hpcla_comm_t *comm, int n_send,
+                                     const int32_t *send_ranks_host,
+                                     const int64_t *send_counts_host, const void *send_idx,
+                                     int idx_is_i64, int n_recv, const int32_t *recv_ranks_host,
+                                     const int64_t *recv_counts_host, int width)
+{
+    if (!plan || !comm) return set_error(HPCLA_ERR_INVALID, "halo_plan_create: null plan/comm");
+    if (n_send < 0 || n_recv < 0 || width < 1)
+        return set_error(HPCLA_ERR_INVALID, "halo_plan_create: bad counts/width");
+    if ((n_send > 0 && (!send_ranks_host || !send_counts_host)) ||
+        (n_recv > 0 && (!recv_ranks_host || !recv_counts_host)))
+        return set_error(HPCLA_ERR_INVALID, "halo_plan_create: null rank/count lists");
+    if ((n_send > 0 || n_recv > 0) && !comm->nccl)
+        return set_error(HPCLA_ERR_INVALID,
+                         "halo_plan_create: neighbours given but the communicator is serial");
+    hpcla_halo_plan *p = new (std::nothrow) hpcla_halo_plan();
+    if (!p) return set_error(HPCLA_ERR_ALLOC, "halo_plan_create: out of memory");
+    p->comm = comm;
+    p->width = width;
+    p->idx_is_i64 = idx_is_i64 ? 1 : 0;
+    for (int i = 0; i < n_send; ++i) {
+        if (send_ranks_host[i] < 0 || send_ranks_host[i] >= comm->nranks || send_counts_host[i] < 0) {
+            halo_free(p);
+            return set_error(HPCLA_ERR_INVALID, "halo_plan_create: bad send entry %d", i);
+        }
+        p->send_ranks.push_back(send_ranks_host[i]);
+        p->send_counts.push_back(send_counts_host[i]);
+        p->send_off.push_back(p->n_send_total);
+        p->n_send_total += send_counts_host[i];
+    }
+    for (int i = 0; i < n_recv; ++i) {
+        if (recv_ranks_host[i] < 0 || recv_ranks_host[i] >= comm->nranks || recv_counts_host[i] < 0) {
+            halo_free(p);
+            return set_error(HPCLA_ERR_INVALID, "halo_plan_create: bad recv entry %d", i);
+        }
+        p->recv_ranks.push_back(recv_ranks_host[i]);
+        p->recv_counts.push_back(recv_counts_host[i]);
+        p->recv_off.push_back(p->n_ghost);
+        p->n_ghost += recv_counts_host[i];
+    }
+    p->send_contig.assign(n_send, 1);
+    p->send_first.assign(n_send, 0);
+    if (p->n_send_total > 0 && !send_idx) {
+        halo_free(p);
+        return set_error(HPCLA_ERR_INVALID, "halo_plan_create: null send_idx");
+    }
+#define HALO_HIP(expr)                                                                            \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) {                                                                   \
+            halo_free(p);                                                                         \
+            return set_error(HPCLA_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e));       \
+        }                                                                                         \
+    } while (0)
+    const size_t isz = idx_is_i64 ? 8 : 4;
+    if (p->n_send_total > 0) {
+        HALO_HIP(hipMalloc(&p->send_idx, p->n_send_total * isz));
+        HALO_HIP(hipMemcpy(p->send_idx, send_idx, p->n_send_total * isz, hipMemcpyDeviceToDevice));
+        // host scan: a neighbour whose indices are one ascending run is sent straight from x
+        if (idx_is_i64) {
+            std::vector<int64_t> h(p->n_send_total);
+            HALO_HIP(hipMemcpy(h.data(), p->send_idx, p->n_send_total * isz, hipMemcpyDeviceToHost));
+            scan_contiguous(p, h);
+        } else {
+            std::vector<int32_t> h(p->n_send_total);
+            HALO_HIP(hipMemcpy(h.data(), p->send_idx, p->n_send_total * isz, hipMemcpyDeviceToHost));
+            scan_contiguous(p, h);
+        }
+        if (p->need_pack)
+            HALO_HIP(hipMalloc((void **)&p->send_buf, p->n_send_total * width * sizeof(double)));
+    }
+    if (p->n_ghost > 0) {
+        HALO_HIP(hipMalloc((void **)&p->ghost, p->n_ghost * width * sizeof(double)));
+        HALO_HIP(hipMemset(p->ghost, 0, p->n_ghost * width * sizeof(double)));
+    }
+    HALO_HIP(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+    HALO_HIP(hipEventCreateWithFlags(&p->ev_ready, hipEventDisableTiming));
+    HALO_HIP(hipEventCreateWithFlags(&p->ev_done, hipEventDisableTiming));
+#undef HALO_HIP
+    *plan = p;
+    return HPCLA_OK;
+}
+
+HPCLA_API int hpcla_halo_plan_destroy(hpcla_halo_plan_t *plan)
+{
+    if (!plan) return HPCLA_OK;
+    if (plan->side) (void)hipStreamSynchronize(plan->side);
+    halo_free(plan);
+    return HPCLA_OK;
+}
+
+HPCLA_API int hpcla_halo_ghost_ptr(hpcla_halo_plan_t *plan, double **ghost, int64_t *n_ghost)
+{
+    if (!plan) return set_error(HPCLA_ERR_INVALID, "halo_ghost_ptr: null plan");
+    if (ghost) *ghost = plan->ghost;
+    if (n_ghost) *n_ghost = plan->n_ghost;
+    return HPCLA_OK;
+}
+
+HPCLA_API int hpcla_halo_begin(hpcla_halo_plan_t *plan, const double *x, void *stream)
+{
+    if (!plan) return set_error(HPCLA_ERR_INVALID, "halo_begin: null plan");
+    if (plan->send_ranks.empty() && plan->recv_ranks.empty()) return HPCLA_OK;
+    if (plan->n_send_total > 0 && !x) return set_error(HPCLA_ERR_INVALID, "halo_begin: null x");
+    hipStream_t main = as_stream(stream);
+    const int w = plan->width;
+    // the exchange may start once everything enqueued on the caller's stream (the producer of x, and
+    // the previous consumer of the ghost segment) has finished
+    HPCLA_CHECK_HIP(hipEventRecord(plan->ev_ready, main));
+    HPCLA_CHECK_HIP(hipStreamWaitEvent(plan->side, plan->ev_ready, 0));
+    if (plan->need_pack) {
+        const int64_t total = plan->n_send_total * w;
+        int64_t g = (total + 255) / 256;
+        if (g > 4096) g = 4096;
+        if (plan->idx_is_i64)
+            pack_kernel<int64_t><<<(uint32_t)g, 256, 0, plan->side>>>(
+                x, (const int64_t *)plan->send_idx, plan->send_buf, plan->n_send_total, w);
+        else
+            pack_kernel<int32_t><<<(uint32_t)g, 256, 0, plan->side>>>(
+                x, (const int32_t *)plan->send_idx, plan->send_buf, plan->n_send_total, w);
+        HPCLA_CHECK_LAUNCH();
+    }
+    ncclComm_t nc = plan->comm->nccl;
+    HPCLA_CHECK_RCCL(g_rccl.GroupStart());
+    for (size_t i = 0; i < plan->recv_ranks.size(); ++i) {
+        if (plan->recv_counts[i] == 0) continue;
+        HPCLA_CHECK_RCCL(g_rccl.Recv(plan->ghost + plan->recv_off[i] * w,
+                                     (size_t)(plan->recv_counts[i] * w), ncclDouble,
+                                     plan->recv_ranks[i], nc, plan->side));
+    }
+    for (size_t i = 0; i < plan->send_ranks.size(); ++i) {
+        if (plan->send_counts[i] == 0) continue;
+        const double *src = plan->send_contig[i] ? x + plan->send_first[i] * w
+                                                 : plan->send_buf + plan->send_off[i] * w;
+        HPCLA_CHECK_RCCL(g_rccl.Send(src, (size_t)(plan->send_counts[i] * w), ncclDouble,
+                                     plan->send_ranks[i], nc, plan->side));
+    }
+    HPCLA_CHECK_RCCL(g_rccl.GroupEnd());
+    HPCLA_CHECK_HIP(hipEventRecord(plan->ev_done, plan->side));
+    return HPCLA_OK;
+}
+
+HPCLA_API int hpcla_halo_end(hpcla_halo_plan_t *plan, void *stream)
+{
+    if (!plan) return set_error(HPCLA_ERR_INVALID, "halo_end: null plan");
+    if (plan->send_ranks.empty() && plan->recv_ranks.empty()) return HPCLA_OK;
+    HPCLA_CHECK_HIP(hipStreamWaitEvent(as_stream(stream), plan->ev_done, 0));
+    return HPCLA_OK;
+}
+
+template <typename I, typename F>
+static int spmv_dist_impl(F split_fn, hpcla_halo_plan_t *plan, const I *rowptr, const I *colval,
+                          const double *nzval, const double *x, int64_t n_own, double *y,
+                          int64_t nrows, int64_t nnz, int index_base, const int32_t *interior,
+                          int64_t n_interior, const int32_t *boundary, int64_t n_boundary,
+                          void *stream)
+{
+    const bool has_halo = plan && !(plan->send_ranks.empty() && plan->recv_ranks.empty());
+    if (!has_halo) {
+        // no neighbours: every column is owned; one launch over all row blocks
+        return split_fn(rowptr, colval, nzval, x, plan ? plan->ghost : nullptr, n_own, y, nrows,
+                        nnz, index_base, nullptr, 0, stream);
+    }
+    if ((n_interior > 0 && !interior) || (n_boundary > 0 && !boundary))
+        return set_error(HPCLA_ERR_INVALID, "spmv_dist: null block list");
+    int rc = hpcla_halo_begin(plan, x, stream);
+    if (rc) return rc;
+    if (n_interior > 0) {
+        rc = split_fn(rowptr, colval, nzval, x, plan->ghost, n_own, y, nrows, nnz, index_base,
+                      interior, n_interior, stream);
+        if (rc) return rc;
+    }
+    rc = hpcla_halo_end(plan, stream);
+    if (rc) return rc;
+    if (n_boundary > 0)
+        rc = split_fn(rowptr, colval, nzval, x, plan->ghost, n_own, y, nrows, nnz, index_base,
+                      boundary, n_boundary, stream);
+    return rc;
+}
+
+HPCLA_API int hpcla_spmv_dist_f64_i32(hpcla_halo_plan_t *plan, const int32_t *rowptr,
+                                      const int32_t *colval_split, const double *nzval,
+                                      const double *x, int64_t n_own, double *y, int64_t nrows,
+                                      int64_t nnz, int index_base, const int32_t *interior_blocks,
+                                      int64_t n_interior, const int32_t *boundary_blocks,
+                                      int64_t n_boundary, void *stream)
+{
+    return spmv_dist_impl<int32_t>(spmv_split_i32, plan, rowptr, colval_split, nzval, x, n_own, y,
+                                   nrows, nnz, index_base, interior_blocks, n_interior,
+                                   boundary_blocks, n_boundary, stream);
+}
+
+HPCLA_API int hpcla_spmv_dist_f64_i64(hpcla_halo_plan_t *plan, const int64_t *rowptr,
+                                      const int64_t *colval_split, const double *nzval,
+                                      const double *x, int64_t n_own, double *y, int64_t nrows,
+                                      int64_t nnz, int index_base, const int32_t *interior_blocks,
+                                      int64_t n_interior, const int32_t *boundary_blocks,
+                                      int64_t n_boundary, void *stream)
+{
+    return spmv_dist_impl<int64_t>(spmv_split_i64, plan, rowptr, colval_split, nzval, x, n_own, y,
+                                   nrows, nnz, index_base, interior_blocks, n_interior,
+                                   boundary_blocks, n_boundary, stream);
+}

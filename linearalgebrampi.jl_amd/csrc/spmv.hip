@@ -1,0 +1,318 @@
+// spmv.hip -- CSR SpMV for MI355X (gfx950), fp64 values, int32/int64 indices.
+//
+// Replaces the reference's one-work-item-per-row KernelAbstractions kernel
+// (_spmv_kernel!, src/sparse.jl:2055-2066), whose lanes read nzval/colval with a stride of one
+// row length (uncoalesced).  Design ("row-block stream"):
+//
+//   * a 256-thread workgroup owns RPB = 256 consecutive rows; the nonzeros of those rows are one
+//     contiguous range [p0,p1) of colval/nzval, which the whole workgroup streams with perfectly
+//     coalesced loads (lane i reads element p0 + i), CHUNK entries at a time;
+//   * each streamed entry is multiplied with its gathered x value (L1/L2 hit for stencil-like
+//     matrices: the XCD slice mapping keeps the x window of a row block in that XCD's L2) and the
+//     PRODUCT is parked in LDS;
+//   * thread t then adds up the products of row t from LDS, sequentially, in stored order.
+//
+// The sum therefore runs in exactly the reference's order with a separately rounded multiply and
+// add (this file is compiled with -ffp-contract=off): results are bit-identical to the reference
+// loop, not merely within tolerance.  No MFMA: 2 flop per 12 bytes is a bandwidth-bound gather.
+//
+// HBM traffic per row block = the algorithmic bytes: 12 B/nnz (int32) + 4 B/row rowptr + 8 B/row y
+// (+ x once per XCD slice).  Rows longer than CHUNK are handled by the chunk loop (the row's
+// running sum is carried in a register), so there is no row-length limit and no preprocessing.
+#include "common.h"
+
+namespace hpcla {
+
+constexpr int RPB = 256;      // rows per block == threads per block
+constexpr int CHUNK = 2048;   // products parked in LDS per pass (16 KiB)
+constexpr int UNROLL = CHUNK / RPB;
+
+template <typename I, bool SPLIT>
+__global__ __launch_bounds__(RPB) void spmv_rowblock_kernel(
+    const I *__restrict__ rowptr, const I *__restrict__ colval, const double *__restrict__ nzval,
+    const double *__restrict__ x_own, const double *__restrict__ x_ghost, int64_t n_own,
+    double *__restrict__ y, int64_t nrows, int base, const int32_t *__restrict__ block_list,
+    uint32_t nblocks)
+{
+    __shared__ double s_prod[CHUNK];
+
+    const int tid = threadIdx.x;
+    uint32_t b = xcd_slice_index(blockIdx.x, nblocks);
+    const int64_t blk = block_list ? (int64_t)block_list[b] : (int64_t)b;
+    const int64_t r0 = blk * RPB;
+    const int nr = (int)((nrows - r0) < RPB ? (nrows - r0) : RPB);
+
+    // block-uniform range of nonzeros (scalar loads)
+    const int64_t p0 = (int64_t)rowptr[r0] - base;
+    const int64_t p1 = (int64_t)rowptr[r0 + nr] - base;
+    const int64_t total = p1 - p0;
+
+    // this thread's row, relative to p0
+    int64_t lo = 0, hi = 0;
+    if (tid < nr) {
+        lo = (int64_t)rowptr[r0 + tid] - base - p0;
+        hi = (int64_t)rowptr[r0 + tid + 1] - base - p0;
+    }
+
+    double acc = 0.0;
+    for (int64_t c = 0; c < total; c += CHUNK) {
+        const int n = (int)((total - c) < CHUNK ? (total - c) : CHUNK);
+        const I *cv = colval + p0 + c;
+        const double *nv = nzval + p0 + c;
+
+        // stream phase: issue every load of the pass before the first use
+        int64_t col[UNROLL];
+        double val[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int i = tid + u * RPB;
+            if (i < n) {
+                col[u] = (int64_t)__builtin_nontemporal_load(cv + i) - base;
+                val[u] = __builtin_nontemporal_load(nv + i);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int i = tid + u * RPB;
+            if (i < n) {
+                double xv;
+                if (SPLIT)
+                    xv = col[u] < n_own ? x_own[col[u]] : x_ghost[col[u] - n_own];
+                else
+                    xv = x_own[col[u]];
+                s_prod[i] = val[u] * xv;
+            }
+        }
+        __syncthreads();
+
+        // reduce phase: sequential, stored order (== reference order)
+        if (tid < nr) {
+            const int64_t a = lo > c ? lo : c;
+            const int64_t e = hi < c + n ? hi : c + n;
+            for (int64_t j = a; j < e; ++j) acc += s_prod[j - c];
+        }
+        __syncthreads();
+    }
+    if (tid < nr) y[r0 + tid] = acc;
+}
+
+template <typename I>
+__global__ __launch_bounds__(256) void remap_kernel(const I *__restrict__ in,
+                                                    const I *__restrict__ map, I *__restrict__ out,
+                                                    int64_t n, int base)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) out[i] = map[(int64_t)in[i] - base];
+}
+
+template <typename I>
+__global__ __launch_bounds__(RPB) void classify_blocks_kernel(const I *__restrict__ rowptr,
+                                                              const I *__restrict__ colval,
+                                                              int64_t nrows, int base,
+                                                              int64_t n_own, int rpb,
+                                                              int32_t *__restrict__ flags)
+{
+    const int64_t r0 = (int64_t)blockIdx.x * rpb;
+    const int nr = (int)((nrows - r0) < rpb ? (nrows - r0) : rpb);
+    const int64_t p0 = (int64_t)rowptr[r0] - base;
+    const int64_t p1 = (int64_t)rowptr[r0 + nr] - base;
+    int any = 0;
+    for (int64_t j = p0 + threadIdx.x; j < p1; j += RPB) any |= ((int64_t)colval[j] >= n_own);
+    any = __syncthreads_or(any);
+    if (threadIdx.x == 0) flags[blockIdx.x] = any ? 1 : 0;
+}
+
+template <typename I>
+__global__ __launch_bounds__(256) void gather_kernel(const double *__restrict__ x,
+                                                     const I *__restrict__ src,
+                                                     const I *__restrict__ dst,
+                                                     double *__restrict__ out, int64_t n, int base)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const int64_t d = dst ? (int64_t)dst[i] - base : i;
+        out[d] = x[(int64_t)src[i] - base];
+    }
+}
+
+static inline uint32_t stream_grid(int64_t n, int threads)
+{
+    int64_t g = (n + threads - 1) / threads;
+    if (g < 1) g = 1;
+    if (g > 256 * 16) g = 256 * 16;   // 256 CUs x 16: grid-stride the rest
+    return (uint32_t)g;
+}
+
+template <typename I>
+static int spmv_launch(const I *rowptr, const I *colval, const double *nzval, const double *x_own,
+                       const double *x_ghost, int64_t n_own, bool split, double *y, int64_t nrows,
+                       int64_t nnz, int index_base, const int32_t *block_list, int64_t n_blocks,
+                       void *stream)
+{
+    if (nrows < 0 || nnz < 0) return set_error(HPCLA_ERR_INVALID, "spmv: negative size");
+    if (index_base != 0 && index_base != 1)
+        return set_error(HPCLA_ERR_INVALID, "spmv: index_base must be 0 or 1");
+    if (nrows == 0) return HPCLA_OK;
+    if (!rowptr || !y) return set_error(HPCLA_ERR_INVALID, "spmv: null rowptr/y");
+    if (nnz > 0 && (!colval || !nzval || !x_own))
+        return set_error(HPCLA_ERR_INVALID, "spmv: null colval/nzval/x with nnz > 0");
+    const int64_t all_blocks = (nrows + RPB - 1) / RPB;
+    int64_t launch_blocks = all_blocks;
+    if (block_list) {
+        if (n_blocks < 0 || n_blocks > all_blocks)
+            return set_error(HPCLA_ERR_INVALID, "spmv: n_blocks out of range");
+        launch_blocks = n_blocks;
+    }
+    if (launch_blocks == 0) return HPCLA_OK;
+    if (launch_blocks > 0x7fffffffLL) return set_error(HPCLA_ERR_INVALID, "spmv: too many blocks");
+    dim3 grid((uint32_t)launch_blocks), block(RPB);
+    hipStream_t s = as_stream(stream);
+    if (split)
+        spmv_rowblock_kernel<I, true><<<grid, block, 0, s>>>(rowptr, colval, nzval, x_own, x_ghost,
+                                                            n_own, y, nrows, index_base,
+                                                            block_list, (uint32_t)launch_blocks);
+    else
+        spmv_rowblock_kernel<I, false><<<grid, block, 0, s>>>(rowptr, colval, nzval, x_own,
+                                                             nullptr, 0, y, nrows, index_base,
+                                                             block_list, (uint32_t)launch_blocks);
+    HPCLA_CHECK_LAUNCH();
+    return HPCLA_OK;
+}
+
+// exported to comm.hip (spmv_dist)
+int spmv_split_i32(const int32_t *rowptr, const int32_t *colval, const double *nzval,
+                   const double *x_own, const double *x_ghost, int64_t n_own, double *y,
+                   int64_t nrows, int64_t nnz, int index_base, const int32_t *bl, int64_t nb,
+                   void *stream)
+{
+    return spmv_launch<int32_t>(rowptr, colval, nzval, x_own, x_ghost, n_own, true, y, nrows, nnz,
+                                index_base, bl, nb, stream);
+}
+int spmv_split_i64(const int64_t *rowptr, const int64_t *colval, const double *nzval,
+                   const double *x_own, const double *x_ghost, int64_t n_own, double *y,
+                   int64_t nrows, int64_t nnz, int index_base, const int32_t *bl, int64_t nb,
+                   void *stream)
+{
+    return spmv_launch<int64_t>(rowptr, colval, nzval, x_own, x_ghost, n_own, true, y, nrows, nnz,
+                                index_base, bl, nb, stream);
+}
+
+}  // namespace hpcla
+
+using namespace hpcla;
+
+HPCLA_API int hpcla_spmv_rows_per_block(void) { return RPB; }
+
+HPCLA_API int hpcla_spmv_csr_f64_i32(const int32_t *rowptr, const int32_t *colval,
+                                     const double *nzval, const double *x, double *y,
+                                     int64_t nrows, int64_t nnz, int index_base, void *stream)
+{
+    return spmv_launch<int32_t>(rowptr, colval, nzval, x, nullptr, 0, false, y, nrows, nnz,
+                                index_base, nullptr, 0, stream);
+}
+
+HPCLA_API int hpcla_spmv_csr_f64_i64(const int64_t *rowptr, const int64_t *colval,
+                                     const double *nzval, const double *x, double *y,
+                                     int64_t nrows, int64_t nnz, int index_base, void *stream)
+{
+    return spmv_launch<int64_t>(rowptr, colval, nzval, x, nullptr, 0, false, y, nrows, nnz,
+                                index_base, nullptr, 0, stream);
+}
+
+HPCLA_API int hpcla_spmv_split_f64_i32(const int32_t *rowptr, const int32_t *colval_split,
+                                       const double *nzval, const double *x_own,
+                                       const double *x_ghost, int64_t n_own, double *y,
+                                       int64_t nrows, int64_t nnz, int index_base,
+                                       const int32_t *block_list, int64_t n_blocks, void *stream)
+{
+    return spmv_split_i32(rowptr, colval_split, nzval, x_own, x_ghost, n_own, y, nrows, nnz,
+                          index_base, block_list, n_blocks, stream);
+}
+
+HPCLA_API int hpcla_spmv_split_f64_i64(const int64_t *rowptr, const int64_t *colval_split,
+                                       const double *nzval, const double *x_own,
+                                       const double *x_ghost, int64_t n_own, double *y,
+                                       int64_t nrows, int64_t nnz, int index_base,
+                                       const int32_t *block_list, int64_t n_blocks, void *stream)
+{
+    return spmv_split_i64(rowptr, colval_split, nzval, x_own, x_ghost, n_own, y, nrows, nnz,
+                          index_base, block_list, n_blocks, stream);
+}
+
+template <typename I>
+static int remap_impl(const I *in, const I *map, I *out, int64_t n, int index_base, void *stream)
+{
+    if (n < 0) return set_error(HPCLA_ERR_INVALID, "remap: negative size");
+    if (n == 0) return HPCLA_OK;
+    if (!in || !map || !out) return set_error(HPCLA_ERR_INVALID, "remap: null pointer");
+    remap_kernel<I><<<stream_grid(n, 256), 256, 0, as_stream(stream)>>>(in, map, out, n,
+                                                                         index_base);
+    HPCLA_CHECK_LAUNCH();
+    return HPCLA_OK;
+}
+
+HPCLA_API int hpcla_remap_i32(const int32_t *in, const int32_t *map, int32_t *out, int64_t n,
+                              int index_base, void *stream)
+{
+    return remap_impl<int32_t>(in, map, out, n, index_base, stream);
+}
+HPCLA_API int hpcla_remap_i64(const int64_t *in, const int64_t *map, int64_t *out, int64_t n,
+                              int index_base, void *stream)
+{
+    return remap_impl<int64_t>(in, map, out, n, index_base, stream);
+}
+
+template <typename I>
+static int classify_impl(const I *rowptr, const I *colval, int64_t nrows, int index_base,
+                         int64_t n_own, int rpb, int32_t *flags, void *stream)
+{
+    if (nrows < 0 || rpb < 1) return set_error(HPCLA_ERR_INVALID, "classify: bad size");
+    if (nrows == 0) return HPCLA_OK;
+    if (!rowptr || !flags) return set_error(HPCLA_ERR_INVALID, "classify: null pointer");
+    const int64_t nb = (nrows + rpb - 1) / rpb;
+    classify_blocks_kernel<I><<<(uint32_t)nb, RPB, 0, as_stream(stream)>>>(
+        rowptr, colval, nrows, index_base, n_own, rpb, flags);
+    HPCLA_CHECK_LAUNCH();
+    return HPCLA_OK;
+}
+
+HPCLA_API int hpcla_classify_blocks_i32(const int32_t *rowptr, const int32_t *colval_split,
+                                        int64_t nrows, int index_base, int64_t n_own,
+                                        int rows_per_block, int32_t *flags, void *stream)
+{
+    return classify_impl<int32_t>(rowptr, colval_split, nrows, index_base, n_own, rows_per_block,
+                                  flags, stream);
+}
+HPCLA_API int hpcla_classify_blocks_i64(const int64_t *rowptr, const int64_t *colval_split,
+                                        int64_t nrows, int index_base, int64_t n_own,
+                                        int rows_per_block, int32_t *flags, void *stream)
+{
+    return classify_impl<int64_t>(rowptr, colval_split, nrows, index_base, n_own, rows_per_block,
+                                  flags, stream);
+}
+
+template <typename I>
+static int gather_impl(const double *x, const I *src, const I *dst, double *out, int64_t n,
+                       int index_base, void *stream)
+{
+    if (n < 0) return set_error(HPCLA_ERR_INVALID, "gather: negative size");
+    if (n == 0) return HPCLA_OK;
+    if (!x || !src || !out) return set_error(HPCLA_ERR_INVALID, "gather: null pointer");
+    gather_kernel<I><<<stream_grid(n, 256), 256, 0, as_stream(stream)>>>(x, src, dst, out, n,
+                                                                          index_base);
+    HPCLA_CHECK_LAUNCH();
+    return HPCLA_OK;
+}
+
+HPCLA_API int hpcla_gather_f64_i32(const double *x, const int32_t *src, const int32_t *dst,
+                                   double *out, int64_t n, int index_base, void *stream)
+{
+    return gather_impl<int32_t>(x, src, dst, out, n, index_base, stream);
+}
+HPCLA_API int hpcla_gather_f64_i64(const double *x, const int64_t *src, const int64_t *dst,
+                                   double *out, int64_t n, int index_base, void *stream)
+{
+    return gather_impl<int64_t>(x, src, dst, out, n, index_base, stream);
+}

@@ -1,0 +1,270 @@
+// vecops.hip -- dot / norm reductions and fused vector updates (the CG building blocks).
+//
+// Replaces the reference's local BLAS dot/nrm2 + host MPI Allreduce (src/vectors.jl:758-812) and
+// its allocating elementwise ops / broadcast (src/vectors.jl:868-903, 944-964, 1203-1226).
+// All kernels are pure HBM streams (16-byte loads, grid-stride, <= 4096 blocks).  Reductions are
+// two-stage and deterministic: fixed grid, per-block partial -> one block sums the partials in
+// index order; the scalar stays on the device so a CG iteration never synchronises the host.
+// Bytes per element: dot 16 (8 for x.x), nrm2sq/asum/amax 8, axpy/xpay 24, scale 16, axpby 24.
+#include "common.h"
+
+namespace hpcla {
+
+constexpr int RT = 256;            // threads per reduction block
+constexpr int MAX_PARTIALS = 2048; // upper bound of stage-1 blocks
+
+enum RedOp { RED_DOT = 0, RED_SQ = 1, RED_ABS = 2, RED_MAX = 3 };
+
+template <int OP>
+__device__ __forceinline__ double red_map(double a, double b)
+{
+    if (OP == RED_DOT) return a * b;
+    if (OP == RED_SQ) return a * a;
+    return fabs(a);
+}
+template <int OP>
+__device__ __forceinline__ double red_comb(double s, double v)
+{
+    if (OP == RED_MAX) return v > s ? v : s;
+    return s + v;
+}
+
+template <int OP>
+__device__ __forceinline__ double block_reduce(double v)
+{
+    __shared__ double s_w[RT / 64];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = red_comb<OP>(v, __shfl_down(v, off, 64));
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) s_w[w] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) {
+        r = s_w[0];
+#pragma unroll
+        for (int i = 1; i < RT / 64; ++i) r = red_comb<OP>(r, s_w[i]);
+    }
+    return r;   // valid in thread 0
+}
+
+template <int OP>
+__global__ __launch_bounds__(RT) void reduce_stage1(const double *__restrict__ x,
+                                                    const double *__restrict__ y, int64_t n,
+                                                    double *__restrict__ partial)
+{
+    // 16-byte loads on the aligned body, scalar tail
+    double acc = 0.0;
+    const int64_t n2 = n / 2;
+    const double2 *x2 = reinterpret_cast<const double2 *>(x);
+    const double2 *y2 = reinterpret_cast<const double2 *>(OP == RED_DOT ? y : x);
+    int64_t i = (int64_t)blockIdx.x * RT + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * RT;
+    for (; i < n2; i += stride) {
+        const double2 a = x2[i];
+        double2 b = a;
+        if (OP == RED_DOT) b = y2[i];
+        acc = red_comb<OP>(acc, red_map<OP>(a.x, b.x));
+        acc = red_comb<OP>(acc, red_map<OP>(a.y, b.y));
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0)
+        acc = red_comb<OP>(acc, red_map<OP>(x[n - 1], OP == RED_DOT ? y[n - 1] : x[n - 1]));
+    const double r = block_reduce<OP>(acc);
+    if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+
+template <int OP>
+__global__ __launch_bounds__(RT) void reduce_stage2(const double *__restrict__ partial, int np,
+                                                    double *__restrict__ out)
+{
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < np; i += RT) acc = red_comb<OP>(acc, partial[i]);
+    const double r = block_reduce<OP>(acc);
+    if (threadIdx.x == 0) out[0] = r;
+}
+
+static inline int reduce_grid(int64_t n)
+{
+    int64_t g = (n / 2 + RT * 4 - 1) / (RT * 4);   // >= 4 double2 per thread
+    if (g < 1) g = 1;
+    if (g > MAX_PARTIALS) g = MAX_PARTIALS;
+    return (int)g;
+}
+
+int allreduce_on(hpcla_comm_t *comm, double *buf, int64_t count, int op, void *stream);  // comm.hip
+
+template <int OP>
+static int reduce_impl(hpcla_comm_t *comm, const double *x, const double *y, int64_t n,
+                       double *out_dev, void *work, void *stream)
+{
+    if (n < 0) return set_error(HPCLA_ERR_INVALID, "reduce: negative size");
+    if (!out_dev || !work) return set_error(HPCLA_ERR_INVALID, "reduce: null out/work");
+    if (n > 0 && (!x || (OP == RED_DOT && !y)))
+        return set_error(HPCLA_ERR_INVALID, "reduce: null input");
+    if ((reinterpret_cast<uintptr_t>(x) & 15) || (OP == RED_DOT && (reinterpret_cast<uintptr_t>(y) & 15)))
+        return set_error(HPCLA_ERR_INVALID, "reduce: inputs must be 16-byte aligned");
+    hipStream_t s = as_stream(stream);
+    double *partial = reinterpret_cast<double *>(work);
+    const int g = reduce_grid(n);
+    reduce_stage1<OP><<<g, RT, 0, s>>>(x, y, n, partial);
+    HPCLA_CHECK_LAUNCH();
+    reduce_stage2<OP><<<1, RT, 0, s>>>(partial, g, out_dev);
+    HPCLA_CHECK_LAUNCH();
+    if (comm) return allreduce_on(comm, out_dev, 1, OP == RED_MAX ? 1 : 0, stream);
+    return HPCLA_OK;
+}
+
+__device__ __forceinline__ double dev_scalar(double alpha, const double *num, const double *den)
+{
+    double a = alpha;
+    if (num) a = a * num[0];
+    if (den) a = a / den[0];
+    return a;
+}
+
+// MODE 0: y = y + a*x   MODE 1: y = x + a*y   MODE 2: y = a*x   MODE 3: y = x / a
+template <int MODE>
+__global__ __launch_bounds__(256) void update_kernel(double alpha, const double *__restrict__ num,
+                                                     const double *__restrict__ den,
+                                                     const double *__restrict__ x,
+                                                     double *__restrict__ y, int64_t n)
+{
+    const double a = dev_scalar(alpha, num, den);
+    const int64_t n2 = n / 2;
+    const double2 *x2 = reinterpret_cast<const double2 *>(x);
+    double2 *y2 = reinterpret_cast<double2 *>(y);
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (; i < n2; i += stride) {
+        const double2 xv = x2[i];
+        double2 yv;
+        if (MODE == 0) { yv = y2[i]; yv.x = yv.x + a * xv.x; yv.y = yv.y + a * xv.y; }
+        if (MODE == 1) { yv = y2[i]; yv.x = xv.x + a * yv.x; yv.y = xv.y + a * yv.y; }
+        if (MODE == 2) { yv.x = a * xv.x; yv.y = a * xv.y; }
+        if (MODE == 3) { yv.x = xv.x / a; yv.y = xv.y / a; }
+        y2[i] = yv;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const int64_t j = n - 1;
+        if (MODE == 0) y[j] = y[j] + a * x[j];
+        if (MODE == 1) y[j] = x[j] + a * y[j];
+        if (MODE == 2) y[j] = a * x[j];
+        if (MODE == 3) y[j] = x[j] / a;
+    }
+}
+
+__global__ __launch_bounds__(256) void axpby_kernel(double a, const double *__restrict__ x,
+                                                    double b, const double *__restrict__ y,
+                                                    double *__restrict__ z, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (; i < n; i += stride) z[i] = a * x[i] + b * y[i];
+}
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(256) void fill_uniform_kernel(double *__restrict__ v, int64_t start,
+                                                           int64_t count, uint64_t seed)
+{
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (; i < count; i += stride) {
+        const uint64_t z = splitmix64(seed + 0x9E3779B97F4A7C15ULL * (uint64_t)(start + i + 1));
+        v[i] = (double)(z >> 11) * 0x1.0p-53;
+    }
+}
+
+static inline uint32_t ew_grid(int64_t n_items)
+{
+    int64_t g = (n_items + 255) / 256;
+    if (g < 1) g = 1;
+    if (g > 4096) g = 4096;
+    return (uint32_t)g;
+}
+
+template <int MODE>
+static int update_impl(double alpha, const double *num, const double *den, const double *x,
+                       double *y, int64_t n, void *stream)
+{
+    if (n < 0) return set_error(HPCLA_ERR_INVALID, "update: negative size");
+    if (n == 0) return HPCLA_OK;
+    if (!x || !y) return set_error(HPCLA_ERR_INVALID, "update: null pointer");
+    if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(y) & 15))
+        return set_error(HPCLA_ERR_INVALID, "update: inputs must be 16-byte aligned");
+    update_kernel<MODE><<<ew_grid(n / 2), 256, 0, as_stream(stream)>>>(alpha, num, den, x, y, n);
+    HPCLA_CHECK_LAUNCH();
+    return HPCLA_OK;
+}
+
+}  // namespace hpcla
+
+using namespace hpcla;
+
+HPCLA_API int64_t hpcla_reduce_work_bytes(void) { return (int64_t)MAX_PARTIALS * sizeof(double); }
+
+HPCLA_API int hpcla_dot_f64(hpcla_comm_t *comm, const double *x, const double *y, int64_t n,
+                            double *out_dev, void *work, void *stream)
+{
+    return reduce_impl<RED_DOT>(comm, x, y, n, out_dev, work, stream);
+}
+HPCLA_API int hpcla_nrm2sq_f64(hpcla_comm_t *comm, const double *x, int64_t n, double *out_dev,
+                               void *work, void *stream)
+{
+    return reduce_impl<RED_SQ>(comm, x, nullptr, n, out_dev, work, stream);
+}
+HPCLA_API int hpcla_asum_f64(hpcla_comm_t *comm, const double *x, int64_t n, double *out_dev,
+                             void *work, void *stream)
+{
+    return reduce_impl<RED_ABS>(comm, x, nullptr, n, out_dev, work, stream);
+}
+HPCLA_API int hpcla_amax_f64(hpcla_comm_t *comm, const double *x, int64_t n, double *out_dev,
+                             void *work, void *stream)
+{
+    return reduce_impl<RED_MAX>(comm, x, nullptr, n, out_dev, work, stream);
+}
+
+HPCLA_API int hpcla_axpy_f64(double alpha_host, const double *num_dev, const double *den_dev,
+                             const double *x, double *y, int64_t n, void *stream)
+{
+    return update_impl<0>(alpha_host, num_dev, den_dev, x, y, n, stream);
+}
+HPCLA_API int hpcla_xpay_f64(const double *x, double alpha_host, const double *num_dev,
+                             const double *den_dev, double *y, int64_t n, void *stream)
+{
+    return update_impl<1>(alpha_host, num_dev, den_dev, x, y, n, stream);
+}
+HPCLA_API int hpcla_scale_f64(double alpha_host, const double *x, double *y, int64_t n,
+                              void *stream)
+{
+    return update_impl<2>(alpha_host, nullptr, nullptr, x, y, n, stream);
+}
+HPCLA_API int hpcla_divide_f64(const double *x, double a_host, double *y, int64_t n, void *stream)
+{
+    return update_impl<3>(a_host, nullptr, nullptr, x, y, n, stream);
+}
+HPCLA_API int hpcla_axpby_f64(double a, const double *x, double b, const double *y, double *z,
+                              int64_t n, void *stream)
+{
+    if (n < 0) return set_error(HPCLA_ERR_INVALID, "axpby: negative size");
+    if (n == 0) return HPCLA_OK;
+    if (!x || !y || !z) return set_error(HPCLA_ERR_INVALID, "axpby: null pointer");
+    axpby_kernel<<<ew_grid(n), 256, 0, as_stream(stream)>>>(a, x, b, y, z, n);
+    HPCLA_CHECK_LAUNCH();
+    return HPCLA_OK;
+}
+
+HPCLA_API int hpcla_fill_uniform_f64(double *v, int64_t start, int64_t count, uint64_t seed,
+                                     void *stream)
+{
+    if (count < 0) return set_error(HPCLA_ERR_INVALID, "fill: negative size");
+    if (count == 0) return HPCLA_OK;
+    if (!v) return set_error(HPCLA_ERR_INVALID, "fill: null pointer");
+    fill_uniform_kernel<<<ew_grid(count), 256, 0, as_stream(stream)>>>(v, start, count, seed);
+    HPCLA_CHECK_LAUNCH();
+    return HPCLA_OK;
+}

@@ -1,0 +1,182 @@
+"""HPCMatrix (dense, row-partitioned) and ``HPCSparseMatrix * HPCMatrix`` on DeviceROCm.
+
+Reference: container + ``HPCMatrix_local`` (src/dense.jl:59-69, 125-156), ``HPCMatrix(M, backend)``
+(:185-201) and the SpMM column loop (src/sparse.jl:2391-2413).  Only what SpMM touches is built.
+
+Layout: the reference's local block is a column-major Julia ``Matrix`` (src/dense.jl:63).  On the
+device the local block is stored ROW-major (a ``(rows_local, k)`` torch tensor): at k=16 one row is
+exactly one 128-byte line, so the gather of a B row per stored entry of A is a single full-line
+read, and ghost rows travel as contiguous ``count*k`` RCCL messages.  Column-major callers convert
+with ``hpcla_transpose_f64``.
+
+SpMM runs ONE kernel over all k columns and ONE halo exchange of ``count*k`` doubles per
+neighbour (the reference: k exchanges, k kernel launches, 17 Allgathers, A streamed k times).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import _capi
+from .backends import HPCBackend, assert_backends_compatible, comm_allgather, comm_rank, comm_size
+from .partition import compute_partition_hash, uniform_partition
+from .vectors import current_stream_ptr, dptr
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class HPCMatrix:
+    """``HPCMatrix{T,B}`` (src/dense.jl:59-69): ``row_partition``, ``col_partition``, local block
+    ``A`` (device, row-major ``(rows_local, ncols)``), ``backend``."""
+
+    def __init__(self, row_partition, col_partition, A_dev, backend: HPCBackend):
+        self.structural_hash = None
+        self.row_partition = np.asarray(row_partition, dtype=np.int64)
+        self.col_partition = np.asarray(col_partition, dtype=np.int64)
+        self.A = A_dev
+        self.backend = backend
+
+    @property
+    def shape(self):
+        return int(self.row_partition[-1]), int(self.A.shape[1])
+
+    def local_values(self) -> np.ndarray:
+        return self.A.detach().cpu().numpy()
+
+    def gather(self) -> np.ndarray:
+        """``Matrix(A)`` (src/HPCLinearAlgebra.jl:840-880): parity checks only."""
+        from .backends import CommSerial, _dist, _host_device
+        loc = self.local_values()
+        comm = self.backend.comm
+        if isinstance(comm, CommSerial):
+            return loc
+        torch = _torch()
+        dev = _host_device(comm)
+        sizes = np.diff(self.row_partition)
+        nmax, k = int(sizes.max()), loc.shape[1]
+        pad = torch.zeros((nmax, k), dtype=torch.float64, device=dev)
+        pad[:loc.shape[0]] = torch.from_numpy(loc).to(dev)
+        outs = [torch.empty_like(pad) for _ in range(comm_size(comm))]
+        _dist().all_gather(outs, pad, group=comm.group)
+        return np.concatenate([o[:int(s)].cpu().numpy() for o, s in zip(outs, sizes)], axis=0)
+
+    @classmethod
+    def from_global(cls, M, backend: HPCBackend, row_partition=None, col_partition=None):
+        """``HPCMatrix(M, backend; row_partition, col_partition)`` (src/dense.jl:185-201)."""
+        torch = _torch()
+        M = np.asarray(M, dtype=np.float64)
+        nranks, rank = comm_size(backend.comm), comm_rank(backend.comm)
+        if row_partition is None:
+            row_partition = uniform_partition(M.shape[0], nranks)
+        if col_partition is None:
+            col_partition = uniform_partition(M.shape[1], nranks)
+        lo, hi = int(row_partition[rank]), int(row_partition[rank + 1])
+        loc = torch.from_numpy(np.ascontiguousarray(M[lo:hi, :])).to(backend.torch_device)
+        return cls(row_partition, col_partition, loc, backend)
+
+
+def HPCMatrix_local(A_local, backend: HPCBackend, col_partition=None) -> HPCMatrix:
+    """src/dense.jl:125-156: row partition inferred by Allgather of ``[nrows, ncols]``."""
+    torch = _torch()
+    if isinstance(A_local, np.ndarray):
+        A_local = torch.from_numpy(np.ascontiguousarray(A_local, dtype=np.float64))
+    A_local = A_local.to(device=backend.torch_device, dtype=torch.float64).contiguous()
+    nranks = comm_size(backend.comm)
+    info = comm_allgather(backend.comm, np.array(list(A_local.shape), dtype=np.int64)).reshape(nranks, 2)
+    if not np.all(info[:, 1] == info[0, 1]):                       # src/dense.jl:139-143
+        raise ValueError("HPCMatrix_local: All ranks must have the same number of columns. "
+                         f"Got column counts: {info[:, 1].tolist()}")
+    row_partition = np.concatenate([[0], np.cumsum(info[:, 0])]).astype(np.int64)
+    if col_partition is None:
+        col_partition = uniform_partition(int(A_local.shape[1]), nranks)
+    return HPCMatrix(row_partition, col_partition, A_local, backend)
+
+
+# width-k halo plans hang off the same key as the vector plan, plus k
+_spmm_halo_cache: Dict[tuple, object] = {}
+
+
+def clear_spmm_cache() -> None:
+    for h in _spmm_halo_cache.values():
+        if h[0]:
+            _capi.call("hpcla_halo_plan_destroy", h[0])
+    _spmm_halo_cache.clear()
+
+
+def spmm(A, B: HPCMatrix) -> HPCMatrix:
+    """``A * B`` (src/sparse.jl:2391-2413): result has A's row partition and B's backend."""
+    from .sparse import get_vector_plan
+    from .vectors import HPCVector
+    torch = _torch()
+    assert_backends_compatible(A.backend, B.backend)
+    backend = A.backend
+    dev = backend.torch_device
+    k = int(B.A.shape[1])
+    # the vector plan for (A, B's row partition) provides neighbour lists, split colval, blocks
+    probe = HPCVector(compute_partition_hash(B.row_partition), B.row_partition,
+                      B.A[:, 0] if k > 0 else torch.empty(0, dtype=torch.float64, device=dev), backend)
+    plan = get_vector_plan(A, probe)
+    if int(B.A.shape[0]) != plan.n_own:
+        raise ValueError("A*B: B's local rows do not match its row partition")
+    C = torch.empty((A.nrows_local, k), dtype=torch.float64, device=dev)
+    out = HPCMatrix(plan.result_partition, uniform_partition(k, comm_size(backend.comm)), C, backend)
+    if k == 0 or A.nrows_local == 0:
+        return out
+    s = current_stream_ptr()
+    sfx = "i64" if plan.is_i64 else "i32"
+    Bc = B.A.contiguous()
+    if not plan.has_halo:
+        # every column owned: split indices == offsets into B's local rows
+        _capi.call(f"hpcla_spmm_csr_f64_{sfx}", dptr(A.rowptr_target), dptr(plan.colval_split),
+                   dptr(A.nzval), dptr(Bc), k, _capi.LAYOUT_ROW, dptr(C), k, _capi.LAYOUT_ROW,
+                   A.nrows_local, A.nnz, k, 0, s)
+        return out
+    if plan.is_i64:
+        raise NotImplementedError("distributed SpMM is implemented for Int32 indices")
+    key = (A._ensure_hash(), probe.structural_hash, k)
+    ent = _spmm_halo_cache.get(key)
+    if ent is None:
+        h = plan.host
+        n_send, n_recv = len(h.send_rank_ids), len(h.recv_rank_ids)
+        send_ranks = (ctypes.c_int32 * max(n_send, 1))(*h.send_rank_ids)
+        send_counts = (ctypes.c_int64 * max(n_send, 1))(*[len(i) for i in h.send_indices])
+        recv_ranks = (ctypes.c_int32 * max(n_recv, 1))(*h.recv_rank_ids)
+        recv_counts = (ctypes.c_int64 * max(n_recv, 1))(*[len(p) for p in h.recv_perm])
+        send_idx = (torch.from_numpy(np.concatenate(h.send_indices).astype(np.int32)).to(dev)
+                    if n_send else None)
+        halo = ctypes.c_void_p()
+        torch.cuda.current_stream().synchronize()
+        _capi.check("hpcla_halo_plan_create", _capi.load().hpcla_halo_plan_create(
+            ctypes.byref(halo), backend.rccl, n_send, send_ranks, send_counts, dptr(send_idx), 0,
+            n_recv, recv_ranks, recv_counts, k))
+        # SpMM row blocks are smaller than SpMV row blocks: classify at SpMM granularity
+        rpb = _capi.load().hpcla_spmm_rows_per_block()
+        nblk = (A.nrows_local + rpb - 1) // rpb
+        flags_i = torch.empty(nblk, dtype=torch.int32, device=dev)
+        _capi.call("hpcla_classify_blocks_i32", dptr(A.rowptr_target), dptr(plan.colval_split),
+                   A.nrows_local, 0, plan.n_own, rpb, dptr(flags_i), s)
+        flags = flags_i != 0
+        interior = torch.nonzero(~flags).flatten().to(torch.int32).contiguous()
+        boundary = torch.nonzero(flags).flatten().to(torch.int32).contiguous()
+        ent = (halo, interior, boundary, send_idx)
+        _spmm_halo_cache[key] = ent
+    halo, interior, boundary, _ = ent
+    ghost = ctypes.c_void_p()
+    ng = ctypes.c_int64()
+    _capi.call("hpcla_halo_ghost_ptr", halo, ctypes.byref(ghost), ctypes.byref(ng))
+    _capi.call("hpcla_halo_begin", halo, dptr(Bc), s)
+    if interior.numel():
+        _capi.call("hpcla_spmm_split_f64_i32", dptr(A.rowptr_target), dptr(plan.colval_split),
+                   dptr(A.nzval), dptr(Bc), k, ghost, k, plan.n_own, dptr(C), k, A.nrows_local,
+                   A.nnz, k, 0, dptr(interior), int(interior.numel()), s)
+    _capi.call("hpcla_halo_end", halo, s)
+    if boundary.numel():
+        _capi.call("hpcla_spmm_split_f64_i32", dptr(A.rowptr_target), dptr(plan.colval_split),
+                   dptr(A.nzval), dptr(Bc), k, ghost, k, plan.n_own, dptr(C), k, A.nrows_local,
+                   A.nnz, k, 0, dptr(boundary), int(boundary.numel()), s)
+    return out

@@ -1,0 +1,396 @@
+"""HPCSparseMatrix on DeviceROCm: construction, VectorPlan, ``A*x`` / ``mul!`` (reference: src/sparse.jl).
+
+Kept bit-for-bit from the reference (host side, numpy): row partition inference, the compressed
+local column space ``col_indices`` (sorted unique global columns, src/sparse.jl:501) and local
+``colval`` (src/sparse.jl:137-144), the VectorPlan neighbour lists (src/sparse.jl:1875-1984) and the
+memoization key ``(hash(A), hash(x.partition), T, Ti, array type)`` (src/sparse.jl:1992-2001).
+
+Replaced (device side, libhpcla_rocm through the C ABI): the execute half of the plan
+(src/vectors.jl:394-463 -> GPU-resident RCCL halo on a side stream), the kernel
+(src/sparse.jl:2055-2084 -> row-block stream SpMV), and the CPU ``mul!`` (src/sparse.jl:2019-2037 ->
+the same device kernel writing ``y.v`` in place).
+
+Index translation: everything here is 0-based (partitions ``[0..n]``, ``colval`` in
+``0:ncols_compressed-1``); the C ABI takes ``index_base`` so Julia callers pass 1-based arrays as is.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from . import _capi
+from .backends import (CommSerial, HPCBackend, assert_backends_compatible, comm_allgather,
+                       comm_alltoall_counts, comm_exchange_indices, comm_rank, comm_size)
+from .partition import (compute_partition_hash, compute_structural_hash, owner_of,
+                        uniform_partition)
+from .vectors import HPCVector, current_stream_ptr, dptr
+
+
+def _torch():
+    import torch
+    return torch
+
+
+# =====================================================================================================
+# host plan (pure numpy + comm_*; testable on CPU with gloo)
+# =====================================================================================================
+@dataclass
+class HostVectorPlan:
+    """The index half of ``VectorPlan{T,Ti,AV}`` (src/vectors.jl:229-251), 0-based."""
+    send_rank_ids: List[int]
+    send_indices: List[np.ndarray]      # local indices into x.v
+    recv_rank_ids: List[int]
+    recv_perm: List[np.ndarray]         # destination positions in `gathered`
+    local_src_indices: np.ndarray
+    local_dst_indices: np.ndarray
+    n_gathered: int
+    n_own: int                          # length of x.v on this rank
+
+
+def build_host_vector_plan(col_indices: np.ndarray, x_partition: np.ndarray, comm) -> HostVectorPlan:
+    """``VectorPlan(A, x)`` steps 1-6 (src/sparse.jl:1875-1953)."""
+    rank, nranks = comm_rank(comm), comm_size(comm)
+    col_indices = np.asarray(col_indices, dtype=np.int64)
+    my_x_start = int(x_partition[rank])
+
+    # step 1: group col_indices by owner rank in x's partition (:1888-1896)
+    owners = owner_of(x_partition, col_indices)
+    # col_indices is sorted and owners are contiguous rank ranges, so each owner's entries are one
+    # contiguous run: boundaries by searchsorted instead of per-element push!
+    bounds = np.searchsorted(owners, np.arange(nranks + 1), side="left")
+    send_counts = np.diff(bounds)                                           # :1899 (what I need)
+
+    # step 2: Alltoall of counts (:1899-1900)
+    recv_counts = comm_alltoall_counts(comm, send_counts)
+
+    # step 3/4: request indices from owners, receive requests (:1908-1936)
+    recv_rank_ids = [r for r in range(nranks) if send_counts[r] > 0 and r != rank]
+    send_rank_ids = [r for r in range(nranks) if recv_counts[r] > 0 and r != rank]
+    requests = [col_indices[bounds[r]:bounds[r + 1]] for r in recv_rank_ids]
+    recv_perm = [np.arange(bounds[r], bounds[r + 1], dtype=np.int64) for r in recv_rank_ids]
+    received = comm_exchange_indices(comm, recv_rank_ids, requests, send_rank_ids,
+                                     [int(recv_counts[r]) for r in send_rank_ids])
+
+    # step 5: global -> local indices for sending (:1939-1944)
+    send_indices = [np.asarray(g, dtype=np.int64) - my_x_start for g in received]
+
+    # step 6: local elements (:1947-1953)
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    local_src = col_indices[lo:hi] - my_x_start
+    local_dst = np.arange(lo, hi, dtype=np.int64)
+
+    n_own = int(x_partition[rank + 1] - x_partition[rank])
+    for idx in send_indices:
+        if len(idx) and (idx.min() < 0 or idx.max() >= n_own):
+            raise ValueError("VectorPlan: a neighbour requested an index this rank does not own")
+    return HostVectorPlan(send_rank_ids, send_indices, recv_rank_ids, recv_perm, local_src,
+                          local_dst, len(col_indices), n_own)
+
+
+def split_column_map(plan: HostVectorPlan) -> np.ndarray:
+    """compressed column c -> split column: owned columns map to their offset in x.v
+    (``< n_own``), ghosts to ``n_own + position in the ghost buffer``.  The ghost buffer stores the
+    receive segments in recv_rank order, which is ascending global column order."""
+    m = np.empty(plan.n_gathered, dtype=np.int64)
+    m[plan.local_dst_indices] = plan.local_src_indices
+    off = plan.n_own
+    for perm in plan.recv_perm:
+        m[perm] = off + np.arange(len(perm), dtype=np.int64)
+        off += len(perm)
+    return m
+
+
+# =====================================================================================================
+# device plan
+# =====================================================================================================
+class VectorPlan:
+    """Memoized communication + launch plan for ``A*x`` (the cache entry of _vector_plan_cache,
+    src/HPCLinearAlgebra.jl:133).  Holds the reference plan's lists (``host``) and their device
+    form: the RCCL halo plan handle, the split-column ``colval`` copy, and the interior/boundary
+    row-block lists."""
+
+    def __init__(self, A: "HPCSparseMatrix", x: HPCVector):
+        assert_backends_compatible(A.backend, x.backend)
+        torch = _torch()
+        backend = A.backend
+        dev = backend.torch_device
+        self.backend = backend
+        self.host = build_host_vector_plan(A.col_indices, x.partition, backend.comm)
+        h = self.host
+        self.n_own = h.n_own
+        self.result_partition = A.row_partition.copy()                       # src/sparse.jl:2103-2106
+        self.result_partition_hash = compute_partition_hash(self.result_partition)
+        self.is_i64 = A.Ti == np.dtype(np.int64)
+        sfx = "i64" if self.is_i64 else "i32"
+        tdt = torch.int64 if self.is_i64 else torch.int32
+        s = current_stream_ptr()
+
+        # split-column colval (device): one remap kernel over the nonzeros
+        cmap = split_column_map(h)
+        n_ghost = h.n_gathered - len(h.local_dst_indices)
+        if self.n_own + n_ghost > np.iinfo(A.Ti).max:
+            raise OverflowError("split column space does not fit the index type")
+        cmap_dev = torch.from_numpy(cmap.astype(A.Ti)).to(dev)
+        colval_dev = A.colval_target()
+        self.colval_split = torch.empty(A.nnz, dtype=tdt, device=dev)
+        _capi.call(f"hpcla_remap_{sfx}", dptr(colval_dev), dptr(cmap_dev), dptr(self.colval_split),
+                   A.nnz, 0, s)
+
+        # halo plan (RCCL)
+        self.halo = ctypes.c_void_p()
+        self.n_ghost = n_ghost
+        n_send, n_recv = len(h.send_rank_ids), len(h.recv_rank_ids)
+        send_ranks = (ctypes.c_int32 * max(n_send, 1))(*h.send_rank_ids)
+        send_counts = (ctypes.c_int64 * max(n_send, 1))(*[len(i) for i in h.send_indices])
+        recv_ranks = (ctypes.c_int32 * max(n_recv, 1))(*h.recv_rank_ids)
+        recv_counts = (ctypes.c_int64 * max(n_recv, 1))(*[len(p) for p in h.recv_perm])
+        if n_send:
+            send_idx = torch.from_numpy(np.concatenate(h.send_indices).astype(A.Ti)).to(dev)
+        else:
+            send_idx = None
+        self.has_halo = (n_send + n_recv) > 0
+        if self.has_halo:
+            torch.cuda.current_stream().synchronize()
+            _capi.check("hpcla_halo_plan_create", _capi.load().hpcla_halo_plan_create(
+                ctypes.byref(self.halo), backend.rccl, n_send, send_ranks, send_counts,
+                dptr(send_idx), 1 if self.is_i64 else 0, n_recv, recv_ranks, recv_counts, 1))
+
+        # interior / boundary row blocks
+        self.interior = self.boundary = None
+        self.n_interior = self.n_boundary = 0
+        if self.has_halo and A.nrows_local > 0:
+            rpb = _capi.load().hpcla_spmv_rows_per_block()
+            nblk = (A.nrows_local + rpb - 1) // rpb
+            flags = torch.empty(nblk, dtype=torch.int32, device=dev)
+            _capi.call(f"hpcla_classify_blocks_{sfx}", dptr(A.rowptr_target), dptr(self.colval_split),
+                       A.nrows_local, 0, self.n_own, rpb, dptr(flags), s)
+            self.interior = torch.nonzero(flags == 0).flatten().to(torch.int32).contiguous()
+            self.boundary = torch.nonzero(flags != 0).flatten().to(torch.int32).contiguous()
+            self.n_interior = int(self.interior.numel())
+            self.n_boundary = int(self.boundary.numel())
+        self._keep = (cmap_dev, send_idx)
+
+    def ghost_tensor_ptr(self) -> Tuple[ctypes.c_void_p, int]:
+        g = ctypes.c_void_p()
+        n = ctypes.c_int64()
+        if self.has_halo:
+            _capi.call("hpcla_halo_ghost_ptr", self.halo, ctypes.byref(g), ctypes.byref(n))
+        return g, n.value
+
+    def destroy(self) -> None:
+        if self.halo:
+            _capi.call("hpcla_halo_plan_destroy", self.halo)
+            self.halo = ctypes.c_void_p()
+
+
+# memoization (src/HPCLinearAlgebra.jl:126-164; clear_plan_cache! :181-201)
+_vector_plan_cache: Dict[tuple, VectorPlan] = {}
+
+
+def get_vector_plan(A: "HPCSparseMatrix", x: HPCVector) -> VectorPlan:
+    """src/sparse.jl:1992-2001."""
+    key = (A._ensure_hash(), x.structural_hash, str(A.T), str(A.Ti), "ROCArray")
+    plan = _vector_plan_cache.get(key)
+    if plan is None:
+        plan = VectorPlan(A, x)
+        _vector_plan_cache[key] = plan
+    return plan
+
+
+def clear_plan_cache() -> None:
+    """``clear_plan_cache!`` (src/HPCLinearAlgebra.jl:181-201): plans are freed only here, never
+    by a finaliser (a finaliser must not issue device/collective work)."""
+    for p in _vector_plan_cache.values():
+        p.destroy()
+    _vector_plan_cache.clear()
+
+
+def cache_sizes() -> Dict[str, int]:
+    return {"vector_plan_cache": len(_vector_plan_cache)}
+
+
+def execute_plan(plan: VectorPlan, x: HPCVector):
+    """``execute_plan!(plan, x)`` (src/vectors.jl:394-463): returns ``gathered = x[col_indices]``
+    as a device tensor.  API-parity form only -- ``A*x`` never materialises ``gathered``: it reads
+    x.v and the ghost segment in place."""
+    torch = _torch()
+    h = plan.host
+    dev = x.v.device
+    s = current_stream_ptr()
+    gathered = torch.empty(h.n_gathered, dtype=torch.float64, device=dev)
+    if plan.has_halo:
+        _capi.call("hpcla_halo_begin", plan.halo, dptr(x.v), s)
+        _capi.call("hpcla_halo_end", plan.halo, s)
+    if len(h.local_src_indices):
+        src = torch.from_numpy(h.local_src_indices).to(dev)
+        dst = torch.from_numpy(h.local_dst_indices).to(dev)
+        _capi.call("hpcla_gather_f64_i64", dptr(x.v), dptr(src), dptr(dst), dptr(gathered),
+                   len(h.local_src_indices), 0, s)
+    if plan.has_halo:
+        gptr, n = plan.ghost_tensor_ptr()
+        ghost_pos = torch.from_numpy(np.concatenate(h.recv_perm)).to(dev)
+        ident = torch.arange(n, dtype=torch.int64, device=dev)
+        _capi.call("hpcla_gather_f64_i64", gptr, dptr(ident), dptr(ghost_pos), dptr(gathered), n, 0, s)
+    return gathered
+
+
+# =====================================================================================================
+# HPCSparseMatrix
+# =====================================================================================================
+class HPCSparseMatrix:
+    """``HPCSparseMatrix{T,Ti,B}`` (src/sparse.jl:319-337).  Host: partitions, ``col_indices``,
+    ``rowptr``/``colval`` (compressed local columns).  Device: ``nzval``, ``rowptr_target`` and --
+    uploaded lazily, the hot path uses the plan's split copy -- ``colval_target``."""
+
+    def __init__(self, row_partition, col_partition, col_indices, rowptr, colval, nzval_dev,
+                 rowptr_dev, backend: HPCBackend):
+        self.structural_hash: Optional[bytes] = None
+        self.row_partition = np.asarray(row_partition, dtype=np.int64)
+        self.col_partition = np.asarray(col_partition, dtype=np.int64)
+        self.col_indices = np.asarray(col_indices, dtype=np.int64)
+        self.rowptr = rowptr
+        self.colval = colval
+        self.nzval = nzval_dev
+        self.rowptr_target = rowptr_dev
+        self._colval_target = None
+        self.nrows_local = len(rowptr) - 1
+        self.ncols_compressed = len(self.col_indices)
+        self.backend = backend
+        self.T = backend.T
+        self.Ti = backend.Ti
+
+    @property
+    def nnz(self) -> int:
+        return int(self.nzval.numel())
+
+    @property
+    def shape(self) -> Tuple[int, int]:                  # src/sparse.jl:2151-2155
+        return int(self.row_partition[-1]), int(self.col_partition[-1])
+
+    def colval_target(self):
+        if self._colval_target is None:
+            torch = _torch()
+            self._colval_target = torch.from_numpy(self.colval).to(self.backend.torch_device)
+        return self._colval_target
+
+    def _ensure_hash(self) -> bytes:                     # src/HPCLinearAlgebra.jl:759-764
+        if self.structural_hash is None:
+            self.structural_hash = compute_structural_hash(
+                self.row_partition, self.col_indices, self.rowptr, self.colval, self.backend.comm)
+        return self.structural_hash
+
+    # -- A * x (src/sparse.jl:2096-2128) and A * B (src/sparse.jl:2391-2413) ---------------------------
+    def __matmul__(self, other):
+        from .dense import HPCMatrix, spmm
+        if isinstance(other, HPCVector):
+            plan = get_vector_plan(self, other)
+            y = HPCVector(plan.result_partition_hash, plan.result_partition,
+                          _torch().empty(self.nrows_local, dtype=_torch().float64,
+                                         device=self.backend.torch_device), self.backend)
+            _spmv_into(y, self, other, plan)
+            return y
+        if isinstance(other, HPCMatrix):
+            return spmm(self, other)
+        return NotImplemented
+
+    __mul__ = __matmul__
+
+
+def _spmv_into(y: HPCVector, A: HPCSparseMatrix, x: HPCVector, plan: VectorPlan) -> None:
+    if y.local_length != A.nrows_local:
+        raise ValueError("mul!: y has the wrong local length")
+    if x.local_length != plan.n_own:
+        raise ValueError("A*x: x does not match the plan's partition")
+    sfx = "i64" if plan.is_i64 else "i32"
+    _capi.call(f"hpcla_spmv_dist_f64_{sfx}", plan.halo if plan.has_halo else None,
+               dptr(A.rowptr_target), dptr(plan.colval_split), dptr(A.nzval), dptr(x.v), plan.n_own,
+               dptr(y.v), A.nrows_local, A.nnz, 0, dptr(plan.interior), plan.n_interior,
+               dptr(plan.boundary), plan.n_boundary, current_stream_ptr())
+
+
+def mul_(y: HPCVector, A: HPCSparseMatrix, x: HPCVector) -> HPCVector:
+    """``LinearAlgebra.mul!(y, A, x)`` (src/sparse.jl:2019-2037), run on the device into ``y.v`` --
+    the reference's version multiplies on the CPU and reads a stale buffer on 1-rank GPU backends
+    (SURVEY.md section 3.2); neither is reproduced."""
+    assert_backends_compatible(A.backend, x.backend)
+    assert_backends_compatible(A.backend, y.backend)
+    if y.structural_hash != compute_partition_hash(A.row_partition):
+        raise ValueError("mul!: y must have A's row partition")
+    _spmv_into(y, A, x, get_vector_plan(A, x))
+    return y
+
+
+def _compress_columns(colidx_global: np.ndarray, ncols_global: int, Ti) -> Tuple[np.ndarray, np.ndarray]:
+    """``col_indices = unique!(sort(copy(rowval)))`` + ``compress_AT`` (src/sparse.jl:501-509,
+    137-144).  Same result via a presence bitmap (O(nnz + ncols) instead of a sort and a binary
+    search per nonzero)."""
+    if len(colidx_global) == 0:
+        return np.empty(0, dtype=np.int64), np.empty(0, dtype=Ti)
+    lo, hi = int(colidx_global.min()), int(colidx_global.max())
+    if lo < 0 or hi >= ncols_global:
+        raise ValueError("column index out of range")
+    present = np.zeros(hi - lo + 1, dtype=bool)
+    present[colidx_global - lo] = True
+    col_indices = np.flatnonzero(present).astype(np.int64) + lo
+    lut = np.cumsum(present, dtype=np.int64) - 1
+    colval = lut[colidx_global - lo].astype(Ti)
+    return col_indices, colval
+
+
+def HPCSparseMatrix_local(rowptr, colidx_global, vals, ncols_global: int, backend: HPCBackend,
+                          col_partition: Optional[np.ndarray] = None) -> HPCSparseMatrix:
+    """``HPCSparseMatrix_local(A_local, backend; col_partition)`` (src/sparse.jl:454-525): this rank's
+    rows as CSR with GLOBAL column ids (the reference's ``A_local.parent.rowval``).  Row partition is
+    inferred by an Allgather of ``[nrows, ncols]``; all ranks must agree on the column count."""
+    torch = _torch()
+    comm = backend.comm
+    nranks = comm_size(comm)
+    Ti = backend.Ti.type
+    rowptr = np.asarray(rowptr, dtype=np.int64)
+    colidx_global = np.asarray(colidx_global, dtype=np.int64)
+    vals = np.ascontiguousarray(vals, dtype=np.float64)
+    nrows = len(rowptr) - 1
+    if rowptr[0] != 0 or rowptr[-1] != len(colidx_global) or len(vals) != len(colidx_global):
+        raise ValueError("HPCSparseMatrix_local: inconsistent CSR arrays")
+    info = comm_allgather(comm, np.array([nrows, ncols_global], dtype=np.int64)).reshape(nranks, 2)
+    if not np.all(info[:, 1] == info[0, 1]):                       # src/sparse.jl:487-490
+        raise ValueError("HPCSparseMatrix_local: All ranks must have the same number of columns. "
+                         f"Got column counts: {info[:, 1].tolist()}")
+    row_partition = np.concatenate([[0], np.cumsum(info[:, 0])]).astype(np.int64)
+    if col_partition is None:
+        col_partition = uniform_partition(ncols_global, nranks)
+    if len(colidx_global) > np.iinfo(Ti).max:
+        raise OverflowError("nnz does not fit the backend index type")
+    col_indices, colval = _compress_columns(colidx_global, ncols_global, Ti)
+    rowptr_ti = rowptr.astype(Ti)
+    dev = backend.torch_device
+    nzval_dev = torch.from_numpy(vals).to(dev)                     # _convert_array hook (:518)
+    rowptr_dev = torch.from_numpy(rowptr_ti).to(dev)               # _to_target_device hook (:519)
+    return HPCSparseMatrix(row_partition, col_partition, col_indices, rowptr_ti, colval, nzval_dev,
+                           rowptr_dev, backend)
+
+
+def HPCSparseMatrix_from_global(A, backend: HPCBackend, row_partition=None, col_partition=None) -> HPCSparseMatrix:
+    """``HPCSparseMatrix(A::SparseMatrixCSC, backend; row_partition, col_partition)``
+    (src/sparse.jl:398-413): every rank passes the same global scipy.sparse matrix and keeps its
+    row slice."""
+    import scipy.sparse as sp
+    comm = backend.comm
+    nranks, rank = comm_size(comm), comm_rank(comm)
+    A = sp.csr_matrix(A)
+    A.sum_duplicates()
+    A.sort_indices()
+    m, n = A.shape
+    if row_partition is None:
+        row_partition = uniform_partition(m, nranks)
+    if col_partition is None:
+        col_partition = uniform_partition(n, nranks)
+    lo, hi = int(row_partition[rank]), int(row_partition[rank + 1])
+    loc = A[lo:hi, :]
+    M = HPCSparseMatrix_local(loc.indptr, loc.indices, loc.data, n, backend, col_partition=col_partition)
+    if not np.array_equal(M.row_partition, np.asarray(row_partition, dtype=np.int64)):
+        raise ValueError("row_partition inconsistent across ranks")
+    return M

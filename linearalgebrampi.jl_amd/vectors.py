@@ -1,0 +1,234 @@
+"""HPCVector on DeviceROCm (reference: src/vectors.jl).
+
+``HPCVector{T,B}`` (src/vectors.jl:21-30): ``structural_hash`` (hash of the partition),
+``partition`` (host), ``v`` (local slice, here a device buffer held as a torch.float64 CUDA tensor
+-- torch is only the allocator/stream provider), ``backend``.
+
+Every arithmetic method launches kernels of libhpcla_rocm through the C ABI on torch's current
+stream; nothing here computes on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Optional
+
+import numpy as np
+
+from . import _capi
+from .backends import (HPCBackend, assert_backends_compatible, comm_allgather, comm_rank,
+                       comm_size)
+from .partition import compute_partition_hash, uniform_partition
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def current_stream_ptr() -> ctypes.c_void_p:
+    return ctypes.c_void_p(_torch().cuda.current_stream().cuda_stream)
+
+
+def dptr(t) -> ctypes.c_void_p:
+    """Raw device pointer of a torch tensor (None -> NULL)."""
+    if t is None:
+        return ctypes.c_void_p(0)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+class _Scratch:
+    """Per-device reduction workspace + result scalar (allocated once; the launch functions never
+    allocate, cdna_hip_programming.md Guideline 9)."""
+    _by_device = {}
+
+    @classmethod
+    def get(cls, device):
+        torch = _torch()
+        key = (device.type, device.index)
+        if key not in cls._by_device:
+            nbytes = _capi.load().hpcla_reduce_work_bytes()
+            cls._by_device[key] = (torch.empty(nbytes // 8, dtype=torch.float64, device=device),
+                                   torch.zeros(8, dtype=torch.float64, device=device))
+        return cls._by_device[key]
+
+
+class HPCVector:
+    """Row-partitioned distributed vector.  Construct with :func:`HPCVector.from_global`
+    (``HPCVector(v_global, backend)``, src/vectors.jl:119-129) or :func:`HPCVector_local`."""
+
+    def __init__(self, structural_hash: bytes, partition: np.ndarray, v, backend: HPCBackend):
+        self.structural_hash = structural_hash
+        self.partition = np.asarray(partition, dtype=np.int64)
+        self.v = v
+        self.backend = backend
+
+    # -- constructors ------------------------------------------------------------------------------
+    @classmethod
+    def from_global(cls, v_global, backend: HPCBackend, partition: Optional[np.ndarray] = None):
+        torch = _torch()
+        v_global = np.asarray(v_global, dtype=np.float64)
+        nranks, rank = comm_size(backend.comm), comm_rank(backend.comm)
+        if partition is None:
+            partition = uniform_partition(len(v_global), nranks)
+        lo, hi = int(partition[rank]), int(partition[rank + 1])
+        local = torch.from_numpy(np.ascontiguousarray(v_global[lo:hi])).to(backend.torch_device)
+        return cls(compute_partition_hash(partition), partition, local, backend)
+
+    @classmethod
+    def zeros(cls, partition: np.ndarray, backend: HPCBackend):
+        torch = _torch()
+        rank = comm_rank(backend.comm)
+        n = int(partition[rank + 1] - partition[rank])
+        return cls(compute_partition_hash(partition), partition,
+                   torch.zeros(n, dtype=torch.float64, device=backend.torch_device), backend)
+
+    def similar(self):
+        torch = _torch()
+        return HPCVector(self.structural_hash, self.partition, torch.empty_like(self.v), self.backend)
+
+    def copy(self):
+        return HPCVector(self.structural_hash, self.partition, self.v.clone(), self.backend)
+
+    # -- shape ------------------------------------------------------------------------------------
+    def __len__(self):
+        return int(self.partition[-1])
+
+    @property
+    def local_length(self) -> int:
+        return int(self.v.numel())
+
+    # -- host views (parity checks only) -------------------------------------------------------------
+    def local_values(self) -> np.ndarray:
+        """test/test_utils.jl:235-243 ``local_values``: Array(v.v)."""
+        return self.v.detach().cpu().numpy()
+
+    def gather(self) -> np.ndarray:
+        """``Vector(v)`` (src/HPCLinearAlgebra.jl:817-830): allgatherv of the whole vector to every
+        rank's host -- used by parity checks, never on the hot path."""
+        from .backends import CommSerial, _dist, _host_device
+        loc = self.local_values()
+        if isinstance(self.backend.comm, CommSerial):
+            return loc
+        torch = _torch()
+        dist = _dist()
+        comm = self.backend.comm
+        dev = _host_device(comm)
+        sizes = np.diff(self.partition)
+        nmax = int(sizes.max()) if len(sizes) else 0
+        pad = torch.zeros(nmax, dtype=torch.float64, device=dev)
+        pad[:len(loc)] = torch.from_numpy(loc).to(dev)
+        outs = [torch.empty_like(pad) for _ in range(comm_size(comm))]
+        dist.all_gather(outs, pad, group=comm.group)
+        return np.concatenate([o[:int(s)].cpu().numpy() for o, s in zip(outs, sizes)])
+
+    # -- checks -------------------------------------------------------------------------------------
+    def _same_partition(self, other: "HPCVector") -> None:
+        assert_backends_compatible(self.backend, other.backend)
+        if self.structural_hash != other.structural_hash:
+            # the reference silently repartitions here (src/vectors.jl:803-811, 870-876); the ROCm
+            # path requires equal partitions (may error for v0)
+            raise ValueError("HPCVector operands have different partitions; repartition is not "
+                             "implemented on DeviceROCm")
+
+    # -- elementwise: u+v, u-v, -v, a*v, v/a (src/vectors.jl:868-903, 944-964) -----------------------
+    def _axpby(self, a: float, other: "HPCVector", b: float) -> "HPCVector":
+        self._same_partition(other)
+        out = self.similar()
+        _capi.call("hpcla_axpby_f64", float(a), dptr(self.v), float(b), dptr(other.v), dptr(out.v),
+                   self.local_length, current_stream_ptr())
+        return out
+
+    def __add__(self, other):
+        return self._axpby(1.0, other, 1.0)
+
+    def __sub__(self, other):
+        return self._axpby(1.0, other, -1.0)
+
+    def __neg__(self):
+        return self.__mul__(-1.0)
+
+    def __mul__(self, a):
+        if isinstance(a, HPCVector):
+            return NotImplemented
+        out = self.similar()
+        _capi.call("hpcla_scale_f64", float(a), dptr(self.v), dptr(out.v), self.local_length,
+                   current_stream_ptr())
+        return out
+
+    __rmul__ = __mul__
+
+    def __truediv__(self, a):
+        out = self.similar()
+        _capi.call("hpcla_divide_f64", dptr(self.v), float(a), dptr(out.v), self.local_length,
+                   current_stream_ptr())
+        return out
+
+    # -- fused updates (broadcast `dest .= x .+ a .* p`, src/vectors.jl:1203-1226) --------------------
+    def axpy_(self, a: float, x: "HPCVector", num=None, den=None) -> "HPCVector":
+        """self .= self .+ (a*num/den) .* x ; num/den optional device scalars (1-element tensors)."""
+        self._same_partition(x)
+        _capi.call("hpcla_axpy_f64", float(a), dptr(num), dptr(den), dptr(x.v), dptr(self.v),
+                   self.local_length, current_stream_ptr())
+        return self
+
+    def xpay_(self, x: "HPCVector", a: float, num=None, den=None) -> "HPCVector":
+        """self .= x .+ (a*num/den) .* self."""
+        self._same_partition(x)
+        _capi.call("hpcla_xpay_f64", dptr(x.v), float(a), dptr(num), dptr(den), dptr(self.v),
+                   self.local_length, current_stream_ptr())
+        return self
+
+
+def HPCVector_local(v_local, backend: HPCBackend) -> HPCVector:
+    """src/vectors.jl:76-94: partition inferred by an Allgather of the local sizes."""
+    torch = _torch()
+    if isinstance(v_local, np.ndarray):
+        v_local = torch.from_numpy(np.ascontiguousarray(v_local, dtype=np.float64))
+    v_local = v_local.to(device=backend.torch_device, dtype=torch.float64).contiguous()
+    sizes = comm_allgather(backend.comm, np.array([v_local.numel()], dtype=np.int64))
+    partition = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    return HPCVector(compute_partition_hash(partition), partition, v_local, backend)
+
+
+# ---- reductions -----------------------------------------------------------------------------------
+def _reduce(kind: str, x: HPCVector, y: Optional[HPCVector], out=None):
+    """Launch the local reduction + RCCL all-reduce; returns the 1-element device tensor."""
+    work, scal = _Scratch.get(x.v.device)
+    if out is None:
+        out = scal[:1]
+    comm = x.backend.rccl
+    s = current_stream_ptr()
+    if kind == "dot":
+        _capi.call("hpcla_dot_f64", comm, dptr(x.v), dptr(y.v), x.local_length, dptr(out), dptr(work), s)
+    elif kind == "nrm2sq":
+        _capi.call("hpcla_nrm2sq_f64", comm, dptr(x.v), x.local_length, dptr(out), dptr(work), s)
+    elif kind == "asum":
+        _capi.call("hpcla_asum_f64", comm, dptr(x.v), x.local_length, dptr(out), dptr(work), s)
+    elif kind == "amax":
+        _capi.call("hpcla_amax_f64", comm, dptr(x.v), x.local_length, dptr(out), dptr(work), s)
+    else:  # pragma: no cover
+        raise ValueError(kind)
+    return out
+
+
+def dot(x: HPCVector, y: HPCVector, out=None):
+    """``dot(x, y)`` (src/vectors.jl:798-812).  Returns a Python float (host sync), or, when ``out``
+    (1-element device tensor) is given, leaves the result on the device and returns ``out``."""
+    x._same_partition(y)
+    r = _reduce("dot", x, y, out)
+    return r if out is not None else float(r.item())
+
+
+def norm(v: HPCVector, p: float = 2, out=None):
+    """``norm(v, p)`` (src/vectors.jl:758-780): p=2 sums squares then sqrt, p=1 asum, p=Inf max."""
+    if p == 2:
+        r = _reduce("nrm2sq", v, None, out)
+        return r if out is not None else math.sqrt(float(r.item()))
+    if p == 1:
+        r = _reduce("asum", v, None, out)
+        return r if out is not None else float(r.item())
+    if p == math.inf:
+        r = _reduce("amax", v, None, out)
+        return r if out is not None else float(r.item())
+    raise NotImplementedError("general p-norms are outside the SpMV/CG hot path (SURVEY.md section 8)")

@@ -1,0 +1,94 @@
+"""Worker for tests/test_distributed_cpu.py: one process per rank, gloo backend, CPU only.
+Exercises the real comm_* primitives and build_host_vector_plan across processes and checks the
+result against the single-process oracle restatement.  Exit code 0 = all checks passed."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch.distributed as dist
+    import hpcla_amd as hp
+    from hpcla_amd import backends as B
+    from oracle import oracle as orc
+
+    dist.init_process_group("gloo")
+    rank, nranks = dist.get_rank(), dist.get_world_size()
+    comm = hp.CommTorch()
+    assert hp.comm_rank(comm) == rank and hp.comm_size(comm) == nranks
+
+    # comm primitives (src/backends.jl:225-327)
+    ag = B.comm_allgather(comm, np.array([rank, 10 * rank]))
+    assert ag.tolist() == [v for r in range(nranks) for v in (r, 10 * r)]
+    a2a = B.comm_alltoall_counts(comm, np.array([100 * rank + q for q in range(nranks)]))
+    assert a2a.tolist() == [100 * q + rank for q in range(nranks)]
+    blob = B.comm_bcast_bytes(comm, bytes(range(128)) if rank == 0 else None, 128, root=0)
+    assert blob == bytes(range(128))
+    hs = B.comm_allgather_bytes(comm, bytes([rank]) * 32)
+    assert hs == [bytes([r]) * 32 for r in range(nranks)]
+
+    for kind in ("poisson", "sprand", "nonuniform"):
+        if kind == "poisson":
+            nx, ny = 16, 4 * nranks + 1
+            n = nx * ny
+            gen = lambda lo, hi: orc.poisson2d_rows(nx, ny, lo, hi)
+            xp = orc.uniform_partition(n, nranks)
+        elif kind == "sprand":
+            n = 500
+            gen = lambda lo, hi: orc.sprand_rows(n, 0.02, lo, hi)
+            xp = orc.uniform_partition(n, nranks)
+        else:
+            n = 300
+            gen = lambda lo, hi: orc.sprand_rows(n, 0.03, lo, hi)
+            xp = np.array([0] + [min(n, 40 + (n * r) // nranks) for r in range(1, nranks)] + [n])
+        rp = orc.uniform_partition(n, nranks)
+        cis = [orc.compress_columns(gen(int(rp[r]), int(rp[r + 1])))[0] for r in range(nranks)]
+        want = orc.vector_plans(cis, xp)[rank]
+        got = hp.build_host_vector_plan(cis[rank], xp, comm)
+        assert got.send_rank_ids == want.send_rank_ids, (kind, got.send_rank_ids, want.send_rank_ids)
+        assert got.recv_rank_ids == want.recv_rank_ids
+        for a, b in zip(got.send_indices, want.send_indices):
+            np.testing.assert_array_equal(a, b)
+        for a, b in zip(got.recv_perm, want.recv_perm):
+            np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(got.local_src_indices, want.local_src_indices)
+        np.testing.assert_array_equal(got.local_dst_indices, want.local_dst_indices)
+
+        # tag-21 value exchange over gloo, driven by the plan lists, must reproduce x[col_indices]
+        import torch
+        x = orc.fill_uniform(0, n, 11)
+        xl = x[xp[rank]:xp[rank + 1]]
+        ops, bufs, keep = [], [], []
+        for r, perm in zip(got.recv_rank_ids, got.recv_perm):
+            t = torch.empty(len(perm), dtype=torch.float64)
+            bufs.append(t)
+            ops.append(dist.P2POp(dist.irecv, t, r))
+        for r, idx in zip(got.send_rank_ids, got.send_indices):
+            t = torch.from_numpy(xl[idx].copy())
+            keep.append(t)
+            ops.append(dist.P2POp(dist.isend, t, r))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        ghost = np.concatenate([b.numpy() for b in bufs]) if bufs else np.empty(0)
+        ext = np.concatenate([xl, ghost])
+        np.testing.assert_array_equal(ext[hp.split_column_map(got)], x[cis[rank]])
+
+        # structural hash agrees on every rank
+        rows = gen(int(rp[rank]), int(rp[rank + 1]))
+        _, cv = orc.compress_columns(rows)
+        hsh = hp.compute_structural_hash(rp, cis[rank], rows.rowptr, cv, comm)
+        allh = B.comm_allgather_bytes(comm, hsh)
+        assert all(h == hsh for h in allh)
+
+    dist.barrier()
+    dist.destroy_process_group()
+    print(f"rank {rank}: OK")
+
+
+if __name__ == "__main__":
+    main()

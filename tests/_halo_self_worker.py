@@ -1,0 +1,110 @@
+"""GPU worker: drives hpcla_halo_* with a ONE-rank RCCL communicator that sends to itself
+(HPCLA_FORCE_RCCL=1), so the ncclGroup send/recv, pack kernel, side stream and event ordering of the
+multi-GPU path run on a single MI355X.  Also runs the fused hpcla_spmv_dist with that plan."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+    import hpcla_amd as hp
+    from oracle import oracle as orc
+
+    assert os.environ.get("HPCLA_FORCE_RCCL") == "1"
+    backend = hp.backend_rocm_serial(np.float64, np.int32)
+    capi = hp._capi
+    lib = capi.load()
+    s = torch.cuda.current_stream().cuda_stream
+    n = 100_000
+    x = torch.from_numpy(orc.fill_uniform(0, n, 42)).cuda()
+
+    def run(idx_np, width, xsrc):
+        plan = ctypes.c_void_p()
+        idx = torch.from_numpy(idx_np.astype(np.int32)).cuda()
+        ranks = (ctypes.c_int32 * 1)(0)
+        counts = (ctypes.c_int64 * 1)(len(idx_np))
+        torch.cuda.synchronize()
+        capi.check("create", lib.hpcla_halo_plan_create(ctypes.byref(plan), backend.rccl, 1, ranks, counts,
+                                                       idx.data_ptr(), 0, 1, ranks, counts, width))
+        ghost = ctypes.c_void_p(); ng = ctypes.c_int64()
+        capi.call("hpcla_halo_ghost_ptr", plan, ctypes.byref(ghost), ctypes.byref(ng))
+        assert ng.value == len(idx_np)
+        for rep in range(3):                       # repeated use: WAR ordering of the ghost buffer
+            xs = xsrc * (rep + 1.0)
+            capi.call("hpcla_halo_begin", plan, xs.data_ptr(), s)
+            busy = torch.ones(1 << 20, device="cuda").cumsum(0)      # overlapping work on the main stream
+            capi.call("hpcla_halo_end", plan, s)
+            # read the ghost buffer on the main stream (ordered after halo_end)
+            tmp = torch.empty(len(idx_np) * width, dtype=torch.float64, device="cuda")
+            ident = torch.arange(len(idx_np) * width, dtype=torch.int64, device="cuda")
+            capi.call("hpcla_gather_f64_i64", ghost, ident.data_ptr(), None, tmp.data_ptr(), ident.numel(), 0, s)
+            torch.cuda.synchronize()
+            want = xs.view(-1, width)[torch.from_numpy(idx_np).cuda()].reshape(-1)
+            assert torch.equal(tmp, want), f"ghost mismatch (width={width}, rep={rep})"
+        capi.call("hpcla_halo_plan_destroy", plan)
+
+    rng = np.random.default_rng(0)
+    run(np.sort(rng.choice(n, size=5000, replace=False)), 1, x)          # scattered -> pack kernel
+    run(np.arange(777, 777 + 8192), 1, x)                                 # contiguous -> direct send
+    k = 16
+    xk = torch.from_numpy(orc.fill_uniform(0, 4096 * k, 43)).cuda()
+    run(np.sort(rng.choice(4096, size=300, replace=False)), k, xk)       # SpMM ghost rows, width 16
+    run(np.arange(100, 400), k, xk)
+
+    # all-reduce on the one-rank communicator is the identity
+    t = torch.tensor([3.25, -1.0], dtype=torch.float64, device="cuda")
+    capi.call("hpcla_allreduce_f64", backend.rccl, t.data_ptr(), 2, 0, s)
+    capi.call("hpcla_allreduce_f64", backend.rccl, t.data_ptr(), 2, 1, s)
+    torch.cuda.synchronize()
+    assert t.tolist() == [3.25, -1.0]
+
+    # fused distributed SpMV: a "periodic" 1-rank problem -- rank 0's ghosts are its own last rows.
+    # rows: 2-D Poisson slab whose upper neighbour line is fetched through the halo from itself.
+    nx, ny = 512, 40
+    nloc = nx * ny
+    rows = orc.poisson2d_rows(nx, ny + 1, 0, nloc)            # local rows of a taller grid
+    ci, cv = orc.compress_columns(rows)                        # columns reach nloc .. nloc+nx-1 (ghosts)
+    n_ghost = int((ci >= nloc).sum())
+    assert n_ghost == nx
+    xg = orc.fill_uniform(0, nloc, 44)
+    # ghost g (global col nloc+g) is served by "neighbour" rank 0 from its local index g + 3*nx
+    send_idx = np.arange(nx) + 3 * nx
+    x_ext = np.concatenate([xg, xg[send_idx]])
+    want = orc.spmv(rows.rowptr.astype(np.int32), cv.astype(np.int32), rows.vals, x_ext[ci])
+    plan = ctypes.c_void_p()
+    d_idx = torch.from_numpy(send_idx.astype(np.int32)).cuda()
+    ranks = (ctypes.c_int32 * 1)(0)
+    counts = (ctypes.c_int64 * 1)(nx)
+    torch.cuda.synchronize()
+    capi.check("create", lib.hpcla_halo_plan_create(ctypes.byref(plan), backend.rccl, 1, ranks, counts,
+                                                   d_idx.data_ptr(), 0, 1, ranks, counts, 1))
+    d_rp = torch.from_numpy(rows.rowptr.astype(np.int32)).cuda()
+    d_cv = torch.from_numpy(ci[cv].astype(np.int32)).cuda()    # split columns: own < nloc, ghosts nloc+g
+    d_nz = torch.from_numpy(rows.vals).cuda()
+    d_x = torch.from_numpy(xg).cuda()
+    rpb = lib.hpcla_spmv_rows_per_block()
+    nblk = (nloc + rpb - 1) // rpb
+    flags = torch.empty(nblk, dtype=torch.int32, device="cuda")
+    capi.call("hpcla_classify_blocks_i32", d_rp.data_ptr(), d_cv.data_ptr(), nloc, 0, nloc, rpb, flags.data_ptr(), s)
+    interior = torch.nonzero(flags == 0).flatten().to(torch.int32)
+    boundary = torch.nonzero(flags != 0).flatten().to(torch.int32)
+    assert boundary.numel() == nx // rpb and interior.numel() == nblk - nx // rpb
+    y = torch.full((nloc,), float("nan"), dtype=torch.float64, device="cuda")
+    for rep in range(3):
+        capi.call("hpcla_spmv_dist_f64_i32", plan, d_rp.data_ptr(), d_cv.data_ptr(), d_nz.data_ptr(),
+                  d_x.data_ptr(), nloc, y.data_ptr(), nloc, rows.nnz, 0, interior.data_ptr(), interior.numel(),
+                  boundary.data_ptr(), boundary.numel(), s)
+    torch.cuda.synchronize()
+    assert np.array_equal(y.cpu().numpy(), want), "fused distributed SpMV mismatch"
+    capi.call("hpcla_halo_plan_destroy", plan)
+    print("halo self-exchange OK")
+
+
+if __name__ == "__main__":
+    main()

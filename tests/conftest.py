@@ -1,0 +1,44 @@
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    with open(os.path.join(ROOT, "tests", "golden", "hotpath_golden.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def orc():
+    from oracle import oracle
+    oracle.build()
+    return oracle
+
+
+@pytest.fixture(scope="session")
+def hp():
+    import hpcla_amd
+    return hpcla_amd
+
+
+@pytest.fixture(scope="session")
+def gpu_backend_i32(hp):
+    import numpy as np
+    return hp.backend_rocm_serial(np.float64, np.int32)
+
+
+@pytest.fixture(scope="session")
+def gpu_backend_i64(hp):
+    import numpy as np
+    return hp.backend_rocm_serial(np.float64, np.int64)

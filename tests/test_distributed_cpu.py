@@ -1,0 +1,20 @@
+"""world_size-2 (and 3) gloo tests of the multi-rank host path on CPU."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_vector_plan_across_processes_gloo(nranks):
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    port = 29600 + nranks
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "tests", "_dist_worker.py")]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert out.stdout.count(": OK") == nranks

