@@ -42,12 +42,36 @@ def parse():
     return ap.parse_args()
 
 
+def usable_cores() -> int:
+    """Host threads this process may actually run: the affinity mask capped by the cgroup CPU quota
+    (the GPU box exposes every host core in the mask but grants a 16-core share per GPU), or
+    HPCLA_CPU_THREADS if set."""
+    if os.environ.get("HPCLA_CPU_THREADS"):
+        return max(1, int(os.environ["HPCLA_CPU_THREADS"]))
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+            break
+        except Exception:
+            continue
+    return min(n, 64)
+
+
 def cpu_baseline_spmv(rowptr, colval, vals, x_gathered, budget_s):
     """cpu_baseline leg: the oracle's restatement of _spmv_kernel! (src/sparse.jl:2055-2066), OpenMP
     static over rows like the reference's KernelAbstractions CPU backend, on all cores this
     process may use, then on 1 core; bounded to ~budget_s seconds."""
     from oracle import oracle as orc
-    cores = len(os.sched_getaffinity(0))
+    cores = usable_cores()
     nnz = len(vals)
     out = {}
     for label, nt, share in (("all", cores, 0.6), ("one", 1, 0.4)):

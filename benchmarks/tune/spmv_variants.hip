@@ -1,0 +1,601 @@
+// spmv_variants.hip -- TUNING HARNESS ONLY (built into benchmarks/tune/libhpcla_tune.so by
+// benchmarks/tune_spmv.py; never linked into libhpcla_rocm.so).  Candidate structures for the
+// row-block stream SpMV, plus ablations that remove one phase at a time, all int32 / base 0.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+constexpr uint32_t NUM_XCD = 8;
+__device__ __forceinline__ uint32_t xcd_slice_index(uint32_t b, uint32_t n)
+{
+    uint32_t k = b % NUM_XCD, q = b / NUM_XCD;
+    uint32_t per = n / NUM_XCD, rem = n % NUM_XCD;
+    return k * per + (k < rem ? k : rem) + q;
+}
+
+template <typename T, bool NT>
+__device__ __forceinline__ T ld(const T *p)
+{
+    if (NT) return __builtin_nontemporal_load(p);
+    return *p;
+}
+
+// ---- narrow (element-per-lane) kernel: the production structure --------------------------------
+// ABL: 0 full, 1 no LDS (thread sums its own products -> wrong y, same traffic), 2 no gather either
+template <int TPB, int RPT, int UNROLL, bool NT, bool XCD, int ABL>
+__global__ __launch_bounds__(TPB) void k_narrow(const int *__restrict__ rowptr,
+                                                const int *__restrict__ colval,
+                                                const double *__restrict__ nzval,
+                                                const double *__restrict__ x, double *__restrict__ y,
+                                                int64_t nrows, uint32_t nblocks)
+{
+    constexpr int R = TPB * RPT;
+    constexpr int CHUNK = TPB * UNROLL;
+    __shared__ double s_prod[CHUNK];
+    const int tid = threadIdx.x;
+    const uint32_t b = XCD ? xcd_slice_index(blockIdx.x, nblocks) : blockIdx.x;
+    const int64_t r0 = (int64_t)b * R;
+    const int nr = (int)((nrows - r0) < R ? (nrows - r0) : R);
+    const int64_t p0 = rowptr[r0], p1 = rowptr[r0 + nr];
+    const int64_t total = p1 - p0;
+    int lo[RPT], hi[RPT];
+    double acc[RPT];
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+        const int r = tid + q * TPB;
+        lo[q] = hi[q] = 0;
+        acc[q] = 0.0;
+        if (r < nr) { lo[q] = (int)(rowptr[r0 + r] - p0); hi[q] = (int)(rowptr[r0 + r + 1] - p0); }
+    }
+    for (int64_t c = 0; c < total; c += CHUNK) {
+        const int n = (int)((total - c) < CHUNK ? (total - c) : CHUNK);
+        const int *cv = colval + p0 + c;
+        const double *nv = nzval + p0 + c;
+        int col[UNROLL];
+        double val[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int i = tid + u * TPB;
+            if (i < n) { col[u] = ld<int, NT>(cv + i); val[u] = ld<double, NT>(nv + i); }
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int i = tid + u * TPB;
+            if (i < n) {
+                if (ABL == 0) s_prod[i] = val[u] * x[col[u]];
+                if (ABL == 1) acc[0] += val[u] * x[col[u]];
+                if (ABL == 2) acc[0] += val[u] * (double)col[u];
+            }
+        }
+        if (ABL == 0) {
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < RPT; ++q) {
+                const int a = lo[q] > c ? lo[q] : (int)c;
+                const int e = hi[q] < c + n ? hi[q] : (int)(c + n);
+                for (int j = a; j < e; ++j) acc[q] += s_prod[j - c];
+            }
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+        const int r = tid + q * TPB;
+        if (r < nr) y[r0 + r] = acc[q] + (ABL ? (double)(lo[q] + hi[q]) * 1e-300 : 0.0);
+    }
+}
+
+// ---- wide kernel: 16-byte loads (4 entries per lane per load), aligned to 4 entries ----------------
+template <int TPB, int RPT, int U, bool NT, bool XCD>
+__global__ __launch_bounds__(TPB) void k_wide(const int *__restrict__ rowptr,
+                                              const int *__restrict__ colval,
+                                              const double *__restrict__ nzval,
+                                              const double *__restrict__ x, double *__restrict__ y,
+                                              int64_t nrows, int64_t nnz, uint32_t nblocks)
+{
+    constexpr int R = TPB * RPT;
+    constexpr int CHUNK = TPB * 4 * U;
+    __shared__ double s_prod[CHUNK];
+    const int tid = threadIdx.x;
+    const uint32_t b = XCD ? xcd_slice_index(blockIdx.x, nblocks) : blockIdx.x;
+    const int64_t r0 = (int64_t)b * R;
+    const int nr = (int)((nrows - r0) < R ? (nrows - r0) : R);
+    const int64_t p0 = rowptr[r0], p1 = rowptr[r0 + nr];
+    const int64_t pa = p0 & ~(int64_t)3;
+    const int64_t total = p1 - pa;
+    int lo[RPT], hi[RPT];
+    double acc[RPT];
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+        const int r = tid + q * TPB;
+        lo[q] = hi[q] = 0;
+        acc[q] = 0.0;
+        if (r < nr) { lo[q] = (int)(rowptr[r0 + r] - pa); hi[q] = (int)(rowptr[r0 + r + 1] - pa); }
+    }
+    for (int64_t c = 0; c < total; c += CHUNK) {
+        const int n = (int)((total - c) < CHUNK ? (total - c) : CHUNK);
+        v4i col[U];
+        v2d va[U], vb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e0 = (u * TPB + tid) * 4;
+            const int64_t g = pa + c + e0;
+            col[u] = (v4i)(0);
+            va[u] = (v2d)(0.0);
+            vb[u] = (v2d)(0.0);
+            if (e0 < n) {
+                if (g + 3 < nnz) {
+                    col[u] = ld<v4i, NT>(reinterpret_cast<const v4i *>(colval + g));
+                    va[u] = ld<v2d, NT>(reinterpret_cast<const v2d *>(nzval + g));
+                    vb[u] = ld<v2d, NT>(reinterpret_cast<const v2d *>(nzval + g + 2));
+                } else {
+                    if (g + 0 < nnz) { col[u].x = colval[g + 0]; va[u].x = nzval[g + 0]; }
+                    if (g + 1 < nnz) { col[u].y = colval[g + 1]; va[u].y = nzval[g + 1]; }
+                    if (g + 2 < nnz) { col[u].z = colval[g + 2]; vb[u].x = nzval[g + 2]; }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e0 = (u * TPB + tid) * 4;
+            if (e0 < n) {
+                double2 pa2, pb2;
+                pa2.x = va[u].x * x[col[u].x];
+                pa2.y = va[u].y * x[col[u].y];
+                pb2.x = vb[u].x * x[col[u].z];
+                pb2.y = vb[u].y * x[col[u].w];
+                *reinterpret_cast<double2 *>(&s_prod[e0]) = pa2;
+                *reinterpret_cast<double2 *>(&s_prod[e0 + 2]) = pb2;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const int a = lo[q] > c ? lo[q] : (int)c;
+            const int e = hi[q] < c + n ? hi[q] : (int)(c + n);
+            for (int j = a; j < e; ++j) acc[q] += s_prod[j - c];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+        const int r = tid + q * TPB;
+        if (r < nr) y[r0 + r] = acc[q];
+    }
+}
+
+// ---- pure stream: read the three arrays + write y with 16-byte accesses (ceiling for this byte mix)
+__global__ __launch_bounds__(256) void k_copy(const v4i *__restrict__ colval4,
+                                              const v2d *__restrict__ nz2,
+                                              const v4i *__restrict__ rowptr4, double2 *__restrict__ y2,
+                                              const double2 *__restrict__ x2, int64_t nnz, int64_t nrows)
+{
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    double acc = 0.0;
+    for (int64_t j = i; j < nnz / 4; j += stride) {
+        v4i c = __builtin_nontemporal_load(colval4 + j);
+        v2d a = __builtin_nontemporal_load(nz2 + 2 * j), b = __builtin_nontemporal_load(nz2 + 2 * j + 1);
+        acc += a.x + a.y + b.x + b.y + (double)(c.x ^ c.y ^ c.z ^ c.w);
+    }
+    for (int64_t j = i; j < nrows / 4; j += stride) {
+        v4i r = __builtin_nontemporal_load(rowptr4 + j);
+        acc += (double)(r.x ^ r.y ^ r.z ^ r.w);
+    }
+    for (int64_t j = i; j < nrows / 2; j += stride) {
+        double2 xv = x2[j];
+        y2[j] = make_double2(acc + xv.x, acc + xv.y);
+    }
+}
+
+// ---- software-pipelined persistent kernel ---------------------------------------------------------
+// Each workgroup walks row blocks b = blockIdx.x, +gridDim.x, ...; work item = one CHUNK of one row
+// block.  While the products of the current item go through LDS and are summed, the colval/nzval
+// loads of the NEXT item (and the rowptr entries of the next row block) are already in flight.
+// vmcnt is in-order, so per iteration: issue the x gathers of the current item FIRST, then the
+// prefetch loads, then wait only for the gathers.
+template <int U>
+struct ChunkRegs {
+    v4i col[U];
+    v2d va[U], vb[U];
+};
+
+template <int TPB, int U, bool NT>
+__device__ __forceinline__ void load_chunk(ChunkRegs<U> &r, const int *__restrict__ colval,
+                                           const double *__restrict__ nzval, int64_t pa, int64_t c,
+                                           int64_t total, int64_t nnz, int tid)
+{
+    const int n = (int)((total - c) < (int64_t)TPB * 4 * U ? (total - c) : (int64_t)TPB * 4 * U);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int e0 = (u * TPB + tid) * 4;
+        const int64_t g = pa + c + e0;
+        r.col[u] = (v4i)(0);
+        r.va[u] = (v2d)(0.0);
+        r.vb[u] = (v2d)(0.0);
+        if (e0 < n) {
+            if (g + 3 < nnz) {
+                r.col[u] = ld<v4i, NT>(reinterpret_cast<const v4i *>(colval + g));
+                r.va[u] = ld<v2d, NT>(reinterpret_cast<const v2d *>(nzval + g));
+                r.vb[u] = ld<v2d, NT>(reinterpret_cast<const v2d *>(nzval + g + 2));
+            } else {
+                if (g + 0 < nnz) { r.col[u].x = colval[g + 0]; r.va[u].x = nzval[g + 0]; }
+                if (g + 1 < nnz) { r.col[u].y = colval[g + 1]; r.va[u].y = nzval[g + 1]; }
+                if (g + 2 < nnz) { r.col[u].z = colval[g + 2]; r.vb[u].x = nzval[g + 2]; }
+            }
+        }
+    }
+}
+
+template <int TPB, int RPT, int U, bool NT>
+__global__ __launch_bounds__(TPB) void k_pipe(const int *__restrict__ rowptr,
+                                              const int *__restrict__ colval,
+                                              const double *__restrict__ nzval,
+                                              const double *__restrict__ x, double *__restrict__ y,
+                                              int64_t nrows, int64_t nnz, int64_t nblk)
+{
+    constexpr int R = TPB * RPT;
+    constexpr int CHUNK = TPB * 4 * U;
+    __shared__ double s_prod[CHUNK];
+    const int tid = threadIdx.x;
+    int64_t b = blockIdx.x;
+    if (b >= nblk) return;
+    const int64_t gstride = gridDim.x;
+
+    // current row block
+    int64_t r0 = b * R;
+    int nr = (int)((nrows - r0) < R ? (nrows - r0) : R);
+    int64_t p0 = rowptr[r0], p1 = rowptr[r0 + nr];
+    int64_t pa = p0 & ~(int64_t)3, total = p1 - pa;
+    int lo[RPT], hi[RPT];
+    double acc[RPT];
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+        const int r = tid + q * TPB;
+        lo[q] = hi[q] = 0;
+        acc[q] = 0.0;
+        if (r < nr) { lo[q] = (int)(rowptr[r0 + r] - pa); hi[q] = (int)(rowptr[r0 + r + 1] - pa); }
+    }
+    // rowptr ends of the NEXT row block (prefetched one block ahead)
+    int64_t nb = b + gstride;
+    int64_t nb_p0 = 0, nb_p1 = 0;
+    if (nb < nblk) {
+        const int64_t q0 = nb * R;
+        const int qn = (int)((nrows - q0) < R ? (nrows - q0) : R);
+        nb_p0 = rowptr[q0];
+        nb_p1 = rowptr[q0 + qn];
+    }
+    int64_t c = 0;
+    ChunkRegs<U> cur, nxt;
+    load_chunk<TPB, U, NT>(cur, colval, nzval, pa, c, total, nnz, tid);
+
+    while (true) {
+        const int n = (int)((total - c) < CHUNK ? (total - c) : CHUNK);
+        // 1. gathers of the current item
+        double xg[U][4];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e0 = (u * TPB + tid) * 4;
+            if (e0 < n) {
+                xg[u][0] = x[cur.col[u].x];
+                xg[u][1] = x[cur.col[u].y];
+                xg[u][2] = x[cur.col[u].z];
+                xg[u][3] = x[cur.col[u].w];
+            }
+        }
+        // 2. prefetch the next item
+        const bool last_chunk = (c + CHUNK >= total);
+        const bool has_next = !last_chunk || nb < nblk;
+        int64_t n_pa = pa, n_total = total, n_c = c + CHUNK;
+        int nlo[RPT], nhi[RPT];
+        int n_nr = nr;
+        int64_t n_r0 = r0;
+        int64_t nn_p0 = 0, nn_p1 = 0;
+        if (last_chunk && nb < nblk) {
+            n_r0 = nb * R;
+            n_nr = (int)((nrows - n_r0) < R ? (nrows - n_r0) : R);
+            n_pa = nb_p0 & ~(int64_t)3;
+            n_total = nb_p1 - n_pa;
+            n_c = 0;
+#pragma unroll
+            for (int q = 0; q < RPT; ++q) {
+                const int r = tid + q * TPB;
+                nlo[q] = nhi[q] = 0;
+                if (r < n_nr) { nlo[q] = (int)(rowptr[n_r0 + r] - n_pa); nhi[q] = (int)(rowptr[n_r0 + r + 1] - n_pa); }
+            }
+            const int64_t nnb = nb + gstride;
+            if (nnb < nblk) {
+                const int64_t q0 = nnb * R;
+                const int qn = (int)((nrows - q0) < R ? (nrows - q0) : R);
+                nn_p0 = rowptr[q0];
+                nn_p1 = rowptr[q0 + qn];
+            }
+        }
+        if (has_next) load_chunk<TPB, U, NT>(nxt, colval, nzval, n_pa, n_c, n_total, nnz, tid);
+
+        // 3. products -> LDS -> per-row sequential sums
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e0 = (u * TPB + tid) * 4;
+            if (e0 < n) {
+                double2 pa2, pb2;
+                pa2.x = cur.va[u].x * xg[u][0];
+                pa2.y = cur.va[u].y * xg[u][1];
+                pb2.x = cur.vb[u].x * xg[u][2];
+                pb2.y = cur.vb[u].y * xg[u][3];
+                *reinterpret_cast<double2 *>(&s_prod[e0]) = pa2;
+                *reinterpret_cast<double2 *>(&s_prod[e0 + 2]) = pb2;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const int a = lo[q] > c ? lo[q] : (int)c;
+            const int e = hi[q] < c + n ? hi[q] : (int)(c + n);
+            for (int j = a; j < e; ++j) acc[q] += s_prod[j - c];
+        }
+        __syncthreads();
+
+        if (last_chunk) {
+#pragma unroll
+            for (int q = 0; q < RPT; ++q) {
+                const int r = tid + q * TPB;
+                if (r < nr) y[r0 + r] = acc[q];
+                acc[q] = 0.0;
+            }
+            if (nb >= nblk) break;
+            b = nb; r0 = n_r0; nr = n_nr; pa = n_pa; total = n_total; c = 0;
+#pragma unroll
+            for (int q = 0; q < RPT; ++q) { lo[q] = nlo[q]; hi[q] = nhi[q]; }
+            nb = b + gstride; nb_p0 = nn_p0; nb_p1 = nn_p1;
+        } else {
+            c += CHUNK;
+        }
+        cur = nxt;
+    }
+}
+
+// ---- branch-free pipelined kernel -------------------------------------------------------------------
+// Same structure as k_pipe, but no exec-masked branches around loads (hipcc waits vmcnt(0) at their
+// joins, which drains the prefetch): lanes past the end of a chunk re-read the chunk's first quad
+// (same line as lane 0, no extra HBM traffic) and write garbage products that are never summed.
+// Requires colval 16-byte and nzval 32-byte aligned (a quad never straddles a page).
+template <int TPB, int U, bool NT>
+__device__ __forceinline__ void load_chunk_bf(ChunkRegs<U> &r, const int *__restrict__ colval,
+                                              const double *__restrict__ nzval, int64_t base_elem,
+                                              int n, int tid)
+{
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        int e0 = (u * TPB + tid) * 4;
+        e0 = e0 < n ? e0 : 0;
+        const int64_t g = base_elem + e0;
+        r.col[u] = ld<v4i, NT>(reinterpret_cast<const v4i *>(colval + g));
+        r.va[u] = ld<v2d, NT>(reinterpret_cast<const v2d *>(nzval + g));
+        r.vb[u] = ld<v2d, NT>(reinterpret_cast<const v2d *>(nzval + g + 2));
+    }
+}
+
+template <int TPB, int RPT, int U, bool NT, int PEEL>
+__global__ __launch_bounds__(TPB) void k_pipe2(const int *__restrict__ rowptr,
+                                               const int *__restrict__ colval,
+                                               const double *__restrict__ nzval,
+                                               const double *__restrict__ x, double *__restrict__ y,
+                                               int64_t nrows, int64_t nnz, int64_t nblk)
+{
+    constexpr int R = TPB * RPT;
+    constexpr int CHUNK = TPB * 4 * U;
+    __shared__ double s_prod[CHUNK];
+    const int tid = threadIdx.x;
+    int64_t b = blockIdx.x;
+    if (b >= nblk) return;
+    int vzero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));   // opaque 0: keeps block-uniform rowptr reads on the vector
+                                                     // memory path (in-order vmcnt) instead of SMEM + lgkmcnt(0)
+    const int64_t gstride = gridDim.x;
+
+    int64_t r0 = b * R;
+    int nr = (int)((nrows - r0) < R ? (nrows - r0) : R);
+    int64_t p0 = rowptr[r0], p1 = rowptr[r0 + nr];
+    int64_t pa = p0 & ~(int64_t)3, total = p1 - pa;
+    int lo[RPT], hi[RPT];
+    double acc[RPT];
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+        const int r = tid + q * TPB;
+        const int rc = r < nr ? r : nr - 1;
+        const int a = rowptr[r0 + rc], e = rowptr[r0 + rc + 1];
+        lo[q] = r < nr ? (int)(a - pa) : 0;
+        hi[q] = r < nr ? (int)(e - pa) : 0;
+        acc[q] = 0.0;
+    }
+    int64_t nb = b + gstride;
+    int64_t nb_p0 = 0, nb_p1 = 0;
+    {
+        const int64_t nbc = nb < nblk ? nb : b;
+        const int64_t q0 = nbc * R;
+        const int qn = (int)((nrows - q0) < R ? (nrows - q0) : R);
+        nb_p0 = rowptr[q0];
+        nb_p1 = rowptr[q0 + qn];
+    }
+    int64_t c = 0;
+    ChunkRegs<U> cur, nxt;
+    load_chunk_bf<TPB, U, NT>(cur, colval, nzval, pa, (int)(total < CHUNK ? total : CHUNK), tid);
+
+    while (true) {
+        const int n = (int)((total - c) < CHUNK ? (total - c) : CHUNK);
+        // 1. gathers of the current item (every lane: masked lanes hold the first quad's columns)
+        double xg[U][4];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            xg[u][0] = x[cur.col[u].x];
+            xg[u][1] = x[cur.col[u].y];
+            xg[u][2] = x[cur.col[u].z];
+            xg[u][3] = x[cur.col[u].w];
+        }
+        // 2. prefetch the next item (uniform control flow only)
+        const bool last_chunk = (c + CHUNK >= total);
+        const bool more_blocks = nb < nblk;
+        int64_t n_pa = pa, n_total = total, n_c = c + CHUNK, n_r0 = r0;
+        int n_nr = nr;
+        if (last_chunk) {
+            const int64_t nbc = more_blocks ? nb : b;       // clamp: re-read own block when finished
+            n_r0 = nbc * R;
+            n_nr = (int)((nrows - n_r0) < R ? (nrows - n_r0) : R);
+            n_pa = (more_blocks ? nb_p0 : p0) & ~(int64_t)3;
+            n_total = (more_blocks ? nb_p1 : p1) - n_pa;
+            n_c = 0;
+        }
+        int ra[RPT], re[RPT];      // raw rowptr entries of the next row block, consumed at the switch
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const int r = tid + q * TPB;
+            const int rc = r < n_nr ? r : n_nr - 1;
+            ra[q] = rowptr[n_r0 + rc];
+            re[q] = rowptr[n_r0 + rc + 1];
+        }
+        int nn_p0, nn_p1;
+        {
+            const int64_t nnb = nb + gstride;
+            const int64_t nnbc = nnb < nblk ? nnb : b;
+            const int64_t q0 = nnbc * R;
+            const int qn = (int)((nrows - q0) < R ? (nrows - q0) : R);
+            nn_p0 = rowptr[q0 + vzero];
+            nn_p1 = rowptr[q0 + qn + vzero];
+        }
+        {
+            const int64_t rem = n_total - n_c;
+            load_chunk_bf<TPB, U, NT>(nxt, colval, nzval, n_pa + n_c, (int)(rem < CHUNK ? rem : CHUNK), tid);
+        }
+        // 3. products -> LDS -> per-row sequential sums
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e0 = (u * TPB + tid) * 4;
+            double2 pa2, pb2;
+            pa2.x = cur.va[u].x * xg[u][0];
+            pa2.y = cur.va[u].y * xg[u][1];
+            pb2.x = cur.vb[u].x * xg[u][2];
+            pb2.y = cur.vb[u].y * xg[u][3];
+            *reinterpret_cast<double2 *>(&s_prod[e0]) = pa2;
+            *reinterpret_cast<double2 *>(&s_prod[e0 + 2]) = pb2;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const int a = (lo[q] > c ? lo[q] : (int)c) - (int)c;
+            const int e = (hi[q] < c + n ? hi[q] : (int)(c + n)) - (int)c;
+            // first PEEL entries: independent LDS reads, predicated adds (order and rounding unchanged)
+            double pv[PEEL];
+#pragma unroll
+            for (int t = 0; t < PEEL; ++t) {
+                int idx = a + t;
+                idx = idx < CHUNK ? idx : CHUNK - 1;
+                pv[t] = s_prod[idx];
+            }
+#pragma unroll
+            for (int t = 0; t < PEEL; ++t) acc[q] = (a + t < e) ? acc[q] + pv[t] : acc[q];
+            for (int j = a + PEEL; j < e; ++j) acc[q] += s_prod[j];
+        }
+        __syncthreads();
+
+        if (last_chunk) {
+#pragma unroll
+            for (int q = 0; q < RPT; ++q) {
+                const int r = tid + q * TPB;
+                if (r < nr) y[r0 + r] = acc[q];
+                acc[q] = 0.0;
+            }
+            if (!more_blocks) break;
+            b = nb; r0 = n_r0; nr = n_nr; pa = n_pa; total = n_total; c = 0; p0 = nb_p0; p1 = nb_p1;
+#pragma unroll
+            for (int q = 0; q < RPT; ++q) {
+                const int r = tid + q * TPB;
+                lo[q] = r < nr ? (int)(ra[q] - pa) : 0;
+                hi[q] = r < nr ? (int)(re[q] - pa) : 0;
+            }
+            nb = b + gstride;
+            nb_p0 = __builtin_amdgcn_readfirstlane(nn_p0);
+            nb_p1 = __builtin_amdgcn_readfirstlane(nn_p1);
+        } else {
+            c += CHUNK;
+        }
+        cur = nxt;
+    }
+}
+
+extern "C" __attribute__((visibility("default"))) int hpcla_tune_spmv(
+    int variant, const int *rowptr, const int *colval, const double *nzval, const double *x, double *y,
+    int64_t nrows, int64_t nnz, void *stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+#define NARROW(TPB, RPT, UN, NT, XCD, ABL)                                                        \
+    {                                                                                             \
+        uint32_t nb = (uint32_t)((nrows + TPB * RPT - 1) / (TPB * RPT));                          \
+        k_narrow<TPB, RPT, UN, NT, XCD, ABL><<<nb, TPB, 0, s>>>(rowptr, colval, nzval, x, y, nrows, nb); \
+    }
+#define WIDE(TPB, RPT, U, NT, XCD)                                                                \
+    {                                                                                             \
+        uint32_t nb = (uint32_t)((nrows + TPB * RPT - 1) / (TPB * RPT));                          \
+        k_wide<TPB, RPT, U, NT, XCD><<<nb, TPB, 0, s>>>(rowptr, colval, nzval, x, y, nrows, nnz, nb); \
+    }
+    switch (variant) {
+        case 0: NARROW(256, 1, 8, true, true, 0) break;    // production structure
+        case 1: NARROW(256, 1, 8, false, true, 0) break;   // no nontemporal
+        case 2: NARROW(256, 1, 8, true, false, 0) break;   // no XCD slice mapping
+        case 3: NARROW(256, 2, 12, true, true, 0) break;   // 512 rows / block
+        case 4: NARROW(256, 1, 8, true, true, 1) break;    // ablation: no LDS round trip
+        case 5: NARROW(256, 1, 8, true, true, 2) break;    // ablation: no LDS, no gather
+        case 6: NARROW(512, 1, 6, true, true, 0) break;    // 512 threads, 512 rows
+        case 7: NARROW(128, 1, 8, true, true, 0) break;    // 128 threads, 128 rows
+        case 10: WIDE(256, 1, 2, true, true) break;        // 16-byte loads, 256 rows, 2048 chunk
+        case 11: WIDE(256, 2, 3, true, true) break;        // 16-byte loads, 512 rows, 3072 chunk
+        case 12: WIDE(256, 1, 2, false, true) break;
+        case 13: WIDE(256, 4, 6, true, true) break;        // 1024 rows, 6144 chunk (48 KiB LDS)
+        case 14: WIDE(128, 2, 3, true, true) break;        // 128 threads, 256 rows
+        case 15: WIDE(256, 2, 3, true, false) break;
+        case 16: WIDE(256, 1, 2, false, false) break;      // wide, no NT, no XCD
+        case 17: NARROW(256, 1, 8, false, false, 0) break; // narrow, no NT, no XCD
+        case 18: WIDE(256, 1, 1, false, false) break;      // wide, 1024 chunk (8 KiB LDS)
+        case 19: WIDE(256, 2, 3, false, false) break;      // wide, 512 rows, no NT, no XCD
+#define PIPE(TPB, RPT, U, NT, PERCU)                                                              \
+    {                                                                                             \
+        int64_t nb = (nrows + TPB * RPT - 1) / (TPB * RPT);                                       \
+        int64_t g = nb < 256 * PERCU ? nb : 256 * PERCU;                                          \
+        k_pipe<TPB, RPT, U, NT><<<(uint32_t)g, TPB, 0, s>>>(rowptr, colval, nzval, x, y, nrows, nnz, nb); \
+    }
+        case 30: PIPE(256, 1, 2, false, 4) break;
+        case 31: PIPE(256, 1, 2, false, 6) break;
+        case 32: PIPE(256, 1, 2, false, 8) break;
+        case 33: PIPE(256, 1, 2, true, 6) break;
+        case 34: PIPE(256, 2, 3, false, 4) break;
+        case 35: PIPE(256, 2, 3, false, 6) break;
+        case 36: PIPE(256, 1, 2, false, 5) break;
+        case 37: PIPE(512, 1, 2, false, 3) break;
+#define PIPE2(TPB, RPT, U, NT, PERCU, PEEL)                                                            \
+    {                                                                                             \
+        int64_t nb = (nrows + TPB * RPT - 1) / (TPB * RPT);                                       \
+        int64_t g = nb < 256 * PERCU ? nb : 256 * PERCU;                                          \
+        k_pipe2<TPB, RPT, U, NT, PEEL><<<(uint32_t)g, TPB, 0, s>>>(rowptr, colval, nzval, x, y, nrows, nnz, nb); \
+    }
+        case 40: PIPE2(256, 1, 2, false, 4, 8) break;
+        case 41: PIPE2(256, 1, 2, false, 5, 8) break;
+        case 42: PIPE2(256, 1, 2, false, 8, 8) break;
+        case 43: PIPE2(256, 1, 2, true, 4, 8) break;
+        case 44: PIPE2(256, 2, 3, false, 3, 8) break;
+        case 45: PIPE2(256, 2, 3, false, 4, 8) break;
+        case 46: PIPE2(256, 1, 1, false, 6, 8) break;
+        case 47: PIPE2(256, 1, 1, false, 8, 8) break;
+        case 48: PIPE2(512, 1, 2, false, 2, 8) break;
+        case 49: PIPE2(256, 1, 2, false, 16, 8) break;
+        case 50: PIPE2(256, 1, 2, false, 4, 1) break;
+        case 51: PIPE2(256, 1, 2, false, 5, 1) break;
+        case 52: PIPE2(256, 1, 2, false, 6, 8) break;
+        case 20:
+            k_copy<<<256 * 16, 256, 0, s>>>((const v4i *)colval, (const v2d *)nzval, (const v4i *)rowptr,
+                                            (double2 *)y, (const double2 *)x, nnz, nrows);
+            break;
+        default: return -1;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}

@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Tuning harness: interleaved rounds of SpMV kernel variants in ONE process (cdna_hip_programming.md
+section 5.4 rule 24) on BASELINE configs[1] (or --size N).  Prints median/min ms, GB/s of algorithmic
+bytes, and whether the variant's y is bit-identical to the production library's."""
+import argparse
+import ctypes
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def build():
+    src = os.path.join(ROOT, "benchmarks", "tune", "spmv_variants.hip")
+    out = os.path.join(ROOT, "benchmarks", "tune", "libhpcla_tune.so")
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+                               "--offload-arch=gfx950", src, "-o", out])
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--size", type=int, default=4096)
+    ap.add_argument("--dim", type=int, default=2)
+    ap.add_argument("--variants", default="0,1,2,3,4,5,6,7,10,11,12,13,14,15,20")
+    ap.add_argument("--rounds", type=int, default=7)
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--build-only", action="store_true")
+    args = ap.parse_args()
+    so = build()
+    if args.build_only:
+        return
+    import torch
+    import hpcla_amd as hp
+    from hpcla_amd import workloads as wl
+    tune = ctypes.CDLL(so)
+    tune.hpcla_tune_spmv.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
+    backend = hp.backend_rocm_serial(np.float64, np.int32)
+    N = args.size
+    if args.dim == 2:
+        rowptr, colidx, vals = wl.poisson2d_rows(N, N, 0, N * N); n = N * N
+    else:
+        rowptr, colidx, vals = wl.poisson3d_rows(N, N, N, 0, N ** 3); n = N ** 3
+    A = hp.HPCSparseMatrix_local(rowptr, colidx, vals, n, backend)
+    x = hp.HPCVector.zeros(A.row_partition, backend)
+    s = torch.cuda.current_stream().cuda_stream
+    hp._capi.call("hpcla_fill_uniform_f64", x.v.data_ptr(), 0, n, wl.SEED_X, s)
+    y_ref = (A @ x).v.clone()
+    cv = A.colval_target()
+    nnz = A.nnz
+    b_alg = wl.spmv_algorithmic_bytes(nnz, n, n, 4)
+    variants = [int(v) for v in args.variants.split(",")]
+    y = torch.empty_like(y_ref)
+    ghost = torch.zeros(16, dtype=torch.float64, device="cuda")
+
+    def launch(v):
+        if v == 100:     # production library, plain kernel
+            return hp._capi.load().hpcla_spmv_csr_f64_i32(A.rowptr_target.data_ptr(), cv.data_ptr(), A.nzval.data_ptr(),
+                                                         x.v.data_ptr(), y.data_ptr(), n, nnz, 0, s)
+        if v == 101:     # production library, split-column kernel (ghost select per entry)
+            return hp._capi.load().hpcla_spmv_split_f64_i32(A.rowptr_target.data_ptr(), cv.data_ptr(), A.nzval.data_ptr(),
+                                                           x.v.data_ptr(), ghost.data_ptr(), n, y.data_ptr(), n, nnz, 0,
+                                                           None, 0, s)
+        return tune.hpcla_tune_spmv(v, A.rowptr_target.data_ptr(), cv.data_ptr(), A.nzval.data_ptr(), x.v.data_ptr(),
+                                    y.data_ptr(), n, nnz, s)
+    times = {v: [] for v in variants}
+    exact = {}
+    for v in variants:                       # correctness + warm-up
+        y.fill_(float("nan"))
+        rc = launch(v)
+        assert rc == 0, (v, rc)
+        torch.cuda.synchronize()
+        exact[v] = bool(torch.equal(y, y_ref))
+    for rnd in range(args.rounds):
+        for v in variants:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(args.reps):
+                launch(v)
+            b.record()
+            torch.cuda.synchronize()
+            times[v].append(a.elapsed_time(b) / args.reps)
+    print(f"# poisson{args.dim}d N={N} n={n} nnz={nnz} B_alg={b_alg} bytes")
+    print(f"{'variant':>8} {'median_ms':>10} {'min_ms':>10} {'GB/s(med)':>10} {'frac_8TB':>9} exact")
+    res = {}
+    for v in variants:
+        med, mn = float(np.median(times[v])), float(np.min(times[v]))
+        res[v] = dict(median_ms=med, min_ms=mn, gbs=b_alg / med / 1e6, exact=exact[v])
+        print(f"{v:>8} {med:>10.4f} {mn:>10.4f} {b_alg / med / 1e6:>10.1f} {b_alg / med / 1e6 / 8000:>9.3f} {exact[v]}")
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

@@ -6,10 +6,10 @@
 //
 //   * a 256-thread workgroup owns RPB = 256 consecutive rows; the nonzeros of those rows are one
 //     contiguous range [p0,p1) of colval/nzval, which the whole workgroup streams with perfectly
-//     coalesced loads (lane i reads element p0 + i), CHUNK entries at a time;
-//   * each streamed entry is multiplied with its gathered x value (L1/L2 hit for stencil-like
-//     matrices: the XCD slice mapping keeps the x window of a row block in that XCD's L2) and the
-//     PRODUCT is parked in LDS;
+//     coalesced 16-byte loads (a lane reads one aligned quad of 4 entries: one colval load, two
+//     nzval loads), CHUNK = 2048 entries per pass;
+//   * each streamed entry is multiplied with its gathered x value (an L1/L2 hit for stencil-like
+//     matrices) and the PRODUCT is parked in LDS;
 //   * thread t then adds up the products of row t from LDS, sequentially, in stored order.
 //
 // The sum therefore runs in exactly the reference's order with a separately rounded multiply and
@@ -17,37 +17,136 @@
 // loop, not merely within tolerance.  No MFMA: 2 flop per 12 bytes is a bandwidth-bound gather.
 //
 // HBM traffic per row block = the algorithmic bytes: 12 B/nnz (int32) + 4 B/row rowptr + 8 B/row y
-// (+ x once per XCD slice).  Rows longer than CHUNK are handled by the chunk loop (the row's
-// running sum is carried in a register), so there is no row-length limit and no preprocessing.
+// (+ x once).  Rows longer than CHUNK are handled by the chunk loop (the row's running sum is
+// carried in a register), so there is no row-length limit and no preprocessing.
+//
+// Measured choices (benchmarks/tune_spmv.py, 4096^2 Poisson, profiles/): 16-byte loads beat
+// element-per-lane loads; plain loads beat nontemporal ones; the natural blockIdx order beats an
+// XCD-sliced order (one moving window over the matrix keeps DRAM pages and the x window hot for all
+// 8 XCDs through the 256 MiB Infinity Cache); a software-pipelined persistent variant and a
+// branch-free variant (idle lanes re-reading quad 0) both lose to plain high occupancy
+// (8 workgroups per CU) with whole waves skipping the quads past the end of a row block.
 #include "common.h"
 
 namespace hpcla {
 
 constexpr int RPB = 256;      // rows per block == threads per block
-constexpr int CHUNK = 2048;   // products parked in LDS per pass (16 KiB)
-constexpr int UNROLL = CHUNK / RPB;
+constexpr int QUADS = 2;      // aligned 4-entry quads per lane per pass
+constexpr int CHUNK = RPB * 4 * QUADS;   // 2048 products parked in LDS per pass (16 KiB)
+constexpr int UNROLL = CHUNK / RPB;      // narrow fallback: entries per lane per pass
 
+template <typename T, int N>
+using vec = T __attribute__((ext_vector_type(N)));
+
+template <bool SPLIT>
+__device__ __forceinline__ double gather_x(const double *__restrict__ x_own,
+                                           const double *__restrict__ x_ghost, int64_t n_own,
+                                           int64_t col)
+{
+    if (SPLIT) {
+        const double *p = col < n_own ? x_own + col : x_ghost + (col - n_own);
+        return *p;
+    }
+    return x_own[col];
+}
+
+// ---- primary kernel: aligned quads (needs colval 4*sizeof(I)- and nzval 32-byte aligned) -----------
 template <typename I, bool SPLIT>
-__global__ __launch_bounds__(RPB) void spmv_rowblock_kernel(
+__global__ __launch_bounds__(RPB) void spmv_rowblock_quad_kernel(
     const I *__restrict__ rowptr, const I *__restrict__ colval, const double *__restrict__ nzval,
     const double *__restrict__ x_own, const double *__restrict__ x_ghost, int64_t n_own,
-    double *__restrict__ y, int64_t nrows, int base, const int32_t *__restrict__ block_list,
-    uint32_t nblocks)
+    double *__restrict__ y, int64_t nrows, int64_t nnz, int base,
+    const int32_t *__restrict__ block_list)
 {
     __shared__ double s_prod[CHUNK];
 
     const int tid = threadIdx.x;
-    uint32_t b = xcd_slice_index(blockIdx.x, nblocks);
-    const int64_t blk = block_list ? (int64_t)block_list[b] : (int64_t)b;
+    const int64_t blk = block_list ? (int64_t)block_list[blockIdx.x] : (int64_t)blockIdx.x;
     const int64_t r0 = blk * RPB;
     const int nr = (int)((nrows - r0) < RPB ? (nrows - r0) : RPB);
 
-    // block-uniform range of nonzeros (scalar loads)
+    const int64_t p0 = (int64_t)rowptr[r0] - base;
+    const int64_t p1 = (int64_t)rowptr[r0 + nr] - base;
+    const int64_t pa = p0 & ~(int64_t)3;          // quad-aligned start (<= 3 entries of the previous block)
+    const int64_t total = p1 - pa;
+
+    // this thread's row, relative to pa
+    int lo = 0, hi = 0;
+    if (tid < nr) {
+        lo = (int)((int64_t)rowptr[r0 + tid] - base - pa);
+        hi = (int)((int64_t)rowptr[r0 + tid + 1] - base - pa);
+    }
+
+    double acc = 0.0;
+    for (int64_t c = 0; c < total; c += CHUNK) {
+        const int n = (int)((total - c) < CHUNK ? (total - c) : CHUNK);
+
+        // stream phase: QUADS aligned quads per lane, all loads issued before the first use
+        vec<I, 4> col[QUADS];
+        vec<double, 2> va[QUADS], vb[QUADS];
+#pragma unroll
+        for (int u = 0; u < QUADS; ++u) {
+            const int e0 = (u * RPB + tid) * 4;
+            const int64_t g = pa + c + e0;
+            col[u] = (vec<I, 4>)(base);            // entries past nnz (<= 3 in the last quad): column 0, value 0
+            va[u] = (vec<double, 2>)(0.0);
+            vb[u] = (vec<double, 2>)(0.0);
+            if (e0 < n) {
+                if (g + 3 < nnz) {
+                    col[u] = *reinterpret_cast<const vec<I, 4> *>(colval + g);
+                    va[u] = *reinterpret_cast<const vec<double, 2> *>(nzval + g);
+                    vb[u] = *reinterpret_cast<const vec<double, 2> *>(nzval + g + 2);
+                } else {
+                    if (g + 0 < nnz) { col[u].x = colval[g + 0]; va[u].x = nzval[g + 0]; }
+                    if (g + 1 < nnz) { col[u].y = colval[g + 1]; va[u].y = nzval[g + 1]; }
+                    if (g + 2 < nnz) { col[u].z = colval[g + 2]; vb[u].x = nzval[g + 2]; }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < QUADS; ++u) {
+            const int e0 = (u * RPB + tid) * 4;
+            if (e0 < n) {
+                vec<double, 2> pa2, pb2;
+                pa2.x = va[u].x * gather_x<SPLIT>(x_own, x_ghost, n_own, (int64_t)col[u].x - base);
+                pa2.y = va[u].y * gather_x<SPLIT>(x_own, x_ghost, n_own, (int64_t)col[u].y - base);
+                pb2.x = vb[u].x * gather_x<SPLIT>(x_own, x_ghost, n_own, (int64_t)col[u].z - base);
+                pb2.y = vb[u].y * gather_x<SPLIT>(x_own, x_ghost, n_own, (int64_t)col[u].w - base);
+                *reinterpret_cast<vec<double, 2> *>(&s_prod[e0]) = pa2;
+                *reinterpret_cast<vec<double, 2> *>(&s_prod[e0 + 2]) = pb2;
+            }
+        }
+        __syncthreads();
+
+        // reduce phase: sequential, stored order (== reference order)
+        {
+            const int a = lo > c ? lo : (int)c;
+            const int e = hi < c + n ? hi : (int)(c + n);
+            for (int j = a; j < e; ++j) acc += s_prod[j - c];
+        }
+        __syncthreads();
+    }
+    if (tid < nr) y[r0 + tid] = acc;
+}
+
+// ---- fallback kernel: element-per-lane loads, no alignment requirement --------------------------------
+template <typename I, bool SPLIT>
+__global__ __launch_bounds__(RPB) void spmv_rowblock_kernel(
+    const I *__restrict__ rowptr, const I *__restrict__ colval, const double *__restrict__ nzval,
+    const double *__restrict__ x_own, const double *__restrict__ x_ghost, int64_t n_own,
+    double *__restrict__ y, int64_t nrows, int base, const int32_t *__restrict__ block_list)
+{
+    __shared__ double s_prod[CHUNK];
+
+    const int tid = threadIdx.x;
+    const int64_t blk = block_list ? (int64_t)block_list[blockIdx.x] : (int64_t)blockIdx.x;
+    const int64_t r0 = blk * RPB;
+    const int nr = (int)((nrows - r0) < RPB ? (nrows - r0) : RPB);
+
     const int64_t p0 = (int64_t)rowptr[r0] - base;
     const int64_t p1 = (int64_t)rowptr[r0 + nr] - base;
     const int64_t total = p1 - p0;
 
-    // this thread's row, relative to p0
     int64_t lo = 0, hi = 0;
     if (tid < nr) {
         lo = (int64_t)rowptr[r0 + tid] - base - p0;
@@ -59,33 +158,22 @@ __global__ __launch_bounds__(RPB) void spmv_rowblock_kernel(
         const int n = (int)((total - c) < CHUNK ? (total - c) : CHUNK);
         const I *cv = colval + p0 + c;
         const double *nv = nzval + p0 + c;
-
-        // stream phase: issue every load of the pass before the first use
         int64_t col[UNROLL];
         double val[UNROLL];
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             const int i = tid + u * RPB;
             if (i < n) {
-                col[u] = (int64_t)__builtin_nontemporal_load(cv + i) - base;
-                val[u] = __builtin_nontemporal_load(nv + i);
+                col[u] = (int64_t)cv[i] - base;
+                val[u] = nv[i];
             }
         }
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             const int i = tid + u * RPB;
-            if (i < n) {
-                double xv;
-                if (SPLIT)
-                    xv = col[u] < n_own ? x_own[col[u]] : x_ghost[col[u] - n_own];
-                else
-                    xv = x_own[col[u]];
-                s_prod[i] = val[u] * xv;
-            }
+            if (i < n) s_prod[i] = val[u] * gather_x<SPLIT>(x_own, x_ghost, n_own, col[u]);
         }
         __syncthreads();
-
-        // reduce phase: sequential, stored order (== reference order)
         if (tid < nr) {
             const int64_t a = lo > c ? lo : c;
             const int64_t e = hi < c + n ? hi : c + n;
@@ -169,14 +257,26 @@ static int spmv_launch(const I *rowptr, const I *colval, const double *nzval, co
     if (launch_blocks > 0x7fffffffLL) return set_error(HPCLA_ERR_INVALID, "spmv: too many blocks");
     dim3 grid((uint32_t)launch_blocks), block(RPB);
     hipStream_t s = as_stream(stream);
-    if (split)
-        spmv_rowblock_kernel<I, true><<<grid, block, 0, s>>>(rowptr, colval, nzval, x_own, x_ghost,
-                                                            n_own, y, nrows, index_base,
-                                                            block_list, (uint32_t)launch_blocks);
-    else
-        spmv_rowblock_kernel<I, false><<<grid, block, 0, s>>>(rowptr, colval, nzval, x_own,
-                                                             nullptr, 0, y, nrows, index_base,
-                                                             block_list, (uint32_t)launch_blocks);
+    // no ghost segment => no column can be >= n_own: take the plain-x kernel (no per-entry select)
+    if (split && !x_ghost) split = false;
+    // quad kernel: a 4-entry quad must never straddle a page -> colval 4*sizeof(I)-, nzval 32-byte aligned
+    const bool aligned = (reinterpret_cast<uintptr_t>(colval) % (4 * sizeof(I)) == 0) &&
+                         (reinterpret_cast<uintptr_t>(nzval) % 32 == 0);
+    if (aligned) {
+        if (split)
+            spmv_rowblock_quad_kernel<I, true><<<grid, block, 0, s>>>(
+                rowptr, colval, nzval, x_own, x_ghost, n_own, y, nrows, nnz, index_base, block_list);
+        else
+            spmv_rowblock_quad_kernel<I, false><<<grid, block, 0, s>>>(
+                rowptr, colval, nzval, x_own, nullptr, 0, y, nrows, nnz, index_base, block_list);
+    } else {
+        if (split)
+            spmv_rowblock_kernel<I, true><<<grid, block, 0, s>>>(
+                rowptr, colval, nzval, x_own, x_ghost, n_own, y, nrows, index_base, block_list);
+        else
+            spmv_rowblock_kernel<I, false><<<grid, block, 0, s>>>(
+                rowptr, colval, nzval, x_own, nullptr, 0, y, nrows, index_base, block_list);
+    }
     HPCLA_CHECK_LAUNCH();
     return HPCLA_OK;
 }

@@ -1,9 +1,10 @@
 #!/bin/bash
-# Helper for gpurun calls: GPU tests, then bench, then (optionally) a rocprofv3 kernel trace.
+# Helper for gpurun calls.  usage: ./run_gpu_checks.sh TAG [steps...]   steps: pytest bench tune prof
 # Stops at the first step that is killed by its timeout (never start a GPU step after a hang).
 set -o pipefail
 mkdir -p gpurun_out
-TAG=${1:-r01}
+TAG=${1:-r01}; shift
+STEPS=${@:-pytest bench}
 run() {  # run <timeout_s> <logfile> <cmd...>
   local t=$1 log=$2; shift 2
   timeout -k 10 "$t" "$@" > "$log" 2>&1
@@ -12,7 +13,21 @@ run() {  # run <timeout_s> <logfile> <cmd...>
   if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "step timed out/killed -- stopping"; exit $rc; fi
   return 0
 }
-run 900 gpurun_out/${TAG}_pytest.log python -m pytest tests -m gpu -q -x
-tail -5 gpurun_out/${TAG}_pytest.log
-run 600 gpurun_out/${TAG}_bench.log python bench.py --steps 100 --warmup 10
-tail -3 gpurun_out/${TAG}_bench.log
+for st in $STEPS; do
+  case $st in
+    pytest) run 900 gpurun_out/${TAG}_pytest.log python -m pytest tests -m gpu -q -x; tail -5 gpurun_out/${TAG}_pytest.log;;
+    bench)  run 600 gpurun_out/${TAG}_bench.log python bench.py --steps 100 --warmup 10; tail -3 gpurun_out/${TAG}_bench.log;;
+    tune)   run 600 gpurun_out/${TAG}_tune.log python benchmarks/tune_spmv.py ${TUNE_ARGS}; tail -25 gpurun_out/${TAG}_tune.log;;
+    tune3d) run 600 gpurun_out/${TAG}_tune3d.log python benchmarks/tune_spmv.py --dim 3 --size 256 ${TUNE_ARGS}; tail -25 gpurun_out/${TAG}_tune3d.log;;
+    prof)
+      cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
+      run 600 gpurun_out/${TAG}_prof.log rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_prof -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline
+      tail -3 gpurun_out/${TAG}_prof.log;;
+    pmc_rd)
+      run 600 gpurun_out/${TAG}_pmc_rd.log rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/${TAG}_pmc_rd -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline
+      tail -2 gpurun_out/${TAG}_pmc_rd.log;;
+    pmc_wr)
+      run 600 gpurun_out/${TAG}_pmc_wr.log rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/${TAG}_pmc_wr -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline
+      tail -2 gpurun_out/${TAG}_pmc_wr.log;;
+  esac
+done
