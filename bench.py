@@ -237,7 +237,7 @@ def main():
                    "parallelism": f"row-slab x{world}, RCCL halo" if world > 1 else "single GPU"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "kernel": "spmv_rowblock_kernel", "algorithmic_bytes_per_launch": b_alg_loc,
+                     "kernel": "hpcla::spmv_rowblock_quad_kernel", "algorithmic_bytes_per_launch": b_alg_loc,
                      "launch_ms_event_pairs": round(launch_ms, 5), "launch_ms_back_to_back": round(stream_ms, 5),
                      "launch_ms_min": round(float(per_launch_ms.min()), 5)},
         "hbm_gbs_whole_job": round(b_alg_tot / (elapsed / args.steps) / 1e9, 1),

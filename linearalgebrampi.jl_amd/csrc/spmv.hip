@@ -39,6 +39,15 @@ template <typename T, int N>
 using vec = T __attribute__((ext_vector_type(N)));
 
 template <bool SPLIT>
+__device__ __forceinline__ const double *gather_ptr(const double *__restrict__ x_own,
+                                                    const double *__restrict__ x_ghost,
+                                                    int64_t n_own, int64_t col)
+{
+    if (SPLIT) return col < n_own ? x_own + col : x_ghost + (col - n_own);
+    return x_own + col;
+}
+
+template <bool SPLIT>
 __device__ __forceinline__ double gather_x(const double *__restrict__ x_own,
                                            const double *__restrict__ x_ghost, int64_t n_own,
                                            int64_t col)
@@ -103,15 +112,35 @@ __global__ __launch_bounds__(RPB) void spmv_rowblock_quad_kernel(
                 }
             }
         }
+        // gather phase: all x loads of the pass issued back to back (addresses first, then loads, then
+        // the multiplies -- written as separate loops so hipcc clusters the loads instead of waiting
+        // for each gather before issuing the next)
+        const double *xp[QUADS][4];
+#pragma unroll
+        for (int u = 0; u < QUADS; ++u) {
+            xp[u][0] = gather_ptr<SPLIT>(x_own, x_ghost, n_own, (int64_t)col[u].x - base);
+            xp[u][1] = gather_ptr<SPLIT>(x_own, x_ghost, n_own, (int64_t)col[u].y - base);
+            xp[u][2] = gather_ptr<SPLIT>(x_own, x_ghost, n_own, (int64_t)col[u].z - base);
+            xp[u][3] = gather_ptr<SPLIT>(x_own, x_ghost, n_own, (int64_t)col[u].w - base);
+        }
+        double xv[QUADS][4];
+#pragma unroll
+        for (int u = 0; u < QUADS; ++u) {
+            const int e0 = (u * RPB + tid) * 4;
+            if (e0 < n) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) xv[u][k] = *xp[u][k];
+            }
+        }
 #pragma unroll
         for (int u = 0; u < QUADS; ++u) {
             const int e0 = (u * RPB + tid) * 4;
             if (e0 < n) {
                 vec<double, 2> pa2, pb2;
-                pa2.x = va[u].x * gather_x<SPLIT>(x_own, x_ghost, n_own, (int64_t)col[u].x - base);
-                pa2.y = va[u].y * gather_x<SPLIT>(x_own, x_ghost, n_own, (int64_t)col[u].y - base);
-                pb2.x = vb[u].x * gather_x<SPLIT>(x_own, x_ghost, n_own, (int64_t)col[u].z - base);
-                pb2.y = vb[u].y * gather_x<SPLIT>(x_own, x_ghost, n_own, (int64_t)col[u].w - base);
+                pa2.x = va[u].x * xv[u][0];
+                pa2.y = va[u].y * xv[u][1];
+                pb2.x = vb[u].x * xv[u][2];
+                pb2.y = vb[u].y * xv[u][3];
                 *reinterpret_cast<vec<double, 2> *>(&s_prod[e0]) = pa2;
                 *reinterpret_cast<vec<double, 2> *>(&s_prod[e0 + 2]) = pb2;
             }

@@ -23,6 +23,12 @@ for st in $STEPS; do
       cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
       run 600 gpurun_out/${TAG}_prof.log rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_prof -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline
       tail -3 gpurun_out/${TAG}_prof.log;;
+    pmc_tune_rd)
+      run 600 gpurun_out/${TAG}_pmc_tune_rd.log rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/${TAG}_pmc_tune_rd -- python3 benchmarks/tune_spmv.py --variants 20,100,101 --rounds 1 --reps 3
+      tail -2 gpurun_out/${TAG}_pmc_tune_rd.log;;
+    pmc_tune_wr)
+      run 600 gpurun_out/${TAG}_pmc_tune_wr.log rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/${TAG}_pmc_tune_wr -- python3 benchmarks/tune_spmv.py --variants 20,100,101 --rounds 1 --reps 3
+      tail -2 gpurun_out/${TAG}_pmc_tune_wr.log;;
     pmc_rd)
       run 600 gpurun_out/${TAG}_pmc_rd.log rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/${TAG}_pmc_rd -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline
       tail -2 gpurun_out/${TAG}_pmc_rd.log;;
