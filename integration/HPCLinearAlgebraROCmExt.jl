@@ -1,0 +1,246 @@
+"""
+    HPCLinearAlgebraROCmExt
+
+DeviceROCm extension for HPCLinearAlgebra (sloisel/LinearAlgebraMPI.jl): AMD Instinct MI355X
+(gfx950) support through `libhpcla_rocm.so` (C ABI: include/hpcla_rocm.h in this repository).
+
+Install as `ext/HPCLinearAlgebraROCmExt.jl` of the reference package together with the parent
+patches listed in INTEGRATION.md (struct DeviceROCm, factory stubs, [weakdeps] AMDGPU).
+
+STATUS: written to the reference's hook contract (the method set of ext/HPCLinearAlgebraCUDAExt.jl:98-187
+and ext/HPCLinearAlgebraMetalExt.jl:35-116) but NOT executed -- Julia is not available in the
+build environment.  Every `@ccall` below has a tested twin in linearalgebrampi.jl_amd/_capi.py, which
+drives the same entry points with the same argument order from Python.
+
+The library path comes from ENV["HPCLA_ROCM_LIB"] (default "libhpcla_rocm").
+"""
+module HPCLinearAlgebraROCmExt
+
+using HPCLinearAlgebra
+using AMDGPU
+using MPI
+using LinearAlgebra
+using SparseArrays
+
+using HPCLinearAlgebra: HPCBackend, DeviceROCm, CommSerial, CommMPI, AbstractComm, SolverMUMPS,
+                        HPCVector, HPCSparseMatrix, HPCMatrix, VectorPlan,
+                        comm_rank, comm_size, indextype_backend, get_vector_plan,
+                        compute_partition_hash, assert_backends_compatible
+
+const LIB = get(ENV, "HPCLA_ROCM_LIB", "libhpcla_rocm")
+const ROCBackend{T,Ti,C,S} = HPCBackend{T,Ti,DeviceROCm,C,S}
+
+# ---- status convention (cf. ext/HPCLinearAlgebraCUDAExt.jl:248-251) ------------------------------
+function _check(status::Cint, what::AbstractString)
+    status == 0 || error("$what failed with status $status: " *
+                         unsafe_string(@ccall LIB.hpcla_last_error()::Cstring))
+    return nothing
+end
+_stream() = Ptr{Cvoid}(UInt(AMDGPU.stream().stream))          # task-local HIP stream
+_ptr(a::ROCArray) = Ptr{Cvoid}(UInt(pointer(a)))
+_ptr(::Nothing) = C_NULL
+
+# ---- backend factories (cf. ext/HPCLinearAlgebraCUDAExt.jl:98-121) ---------------------------------
+function HPCLinearAlgebra.backend_rocm_serial(::Type{T}=Float64, ::Type{Ti}=Int) where {T,Ti<:Integer}
+    return HPCBackend{T,Ti,DeviceROCm,CommSerial,SolverMUMPS}(DeviceROCm(), CommSerial(), SolverMUMPS())
+end
+function HPCLinearAlgebra.backend_rocm_mpi(::Type{T}=Float64, ::Type{Ti}=Int;
+                                           comm::MPI.Comm=MPI.COMM_WORLD) where {T,Ti<:Integer}
+    # one process per GPU: device = rank % ndevices (ext/HPCLinearAlgebraCUDAExt.jl:611-613)
+    AMDGPU.device!(AMDGPU.devices()[MPI.Comm_rank(comm) % length(AMDGPU.devices()) + 1])
+    return HPCBackend{T,Ti,DeviceROCm,CommMPI,SolverMUMPS}(DeviceROCm(), CommMPI(comm), SolverMUMPS())
+end
+HPCLinearAlgebra.backend_rocm_mpi(comm::MPI.Comm) = HPCLinearAlgebra.backend_rocm_mpi(Float64, Int; comm=comm)
+
+# ---- array conversion hooks (cf. :129-187) -----------------------------------------------------------
+HPCLinearAlgebra._convert_array(v::Vector, ::DeviceROCm) = ROCVector(v)
+HPCLinearAlgebra._convert_array(A::Matrix, ::DeviceROCm) = ROCMatrix(A)
+HPCLinearAlgebra._convert_array(v::ROCVector, ::DeviceROCm) = v
+HPCLinearAlgebra._convert_array(A::ROCMatrix, ::DeviceROCm) = A
+HPCLinearAlgebra._zeros_device(::DeviceROCm, ::Type{T}, dims...) where T = AMDGPU.zeros(T, dims...)
+HPCLinearAlgebra._index_array_type(::DeviceROCm, ::Type{Ti}) where Ti = ROCVector{Ti}
+HPCLinearAlgebra._to_target_device(v::Vector{Ti}, ::DeviceROCm) where Ti = ROCVector(v)
+HPCLinearAlgebra._array_to_device(v::Vector{T}, ::DeviceROCm) where T = ROCVector(v)
+function HPCLinearAlgebra._convert_vector_to_device(v::HPCVector{T,B}, device::DeviceROCm) where {T,B}
+    Ti = indextype_backend(B)
+    b = HPCBackend{T,Ti,DeviceROCm,typeof(v.backend.comm),typeof(v.backend.solver)}(
+        device, v.backend.comm, v.backend.solver)
+    return HPCLinearAlgebra.to_backend(v, b)
+end
+
+# ---- RCCL communicator, bootstrapped from MPI (cf. :376-443) -------------------------------------------
+# Lives until process exit: no finalizer may issue a collective (:384-386).
+const _comms = Dict{Any,Ptr{Cvoid}}()
+function _rccl(comm::AbstractComm)
+    key = comm isa CommMPI ? comm.comm : :serial
+    haskey(_comms, key) && return _comms[key]
+    nranks, rank = comm_size(comm), comm_rank(comm)
+    id = zeros(UInt8, 128)
+    if nranks > 1
+        rank == 0 && _check(@ccall(LIB.hpcla_comm_get_unique_id(id::Ptr{UInt8})::Cint), "hpcla_comm_get_unique_id")
+        MPI.Bcast!(id, 0, comm.comm)
+    end
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    _check(@ccall(LIB.hpcla_comm_init_rank(h::Ptr{Ptr{Cvoid}}, id::Ptr{UInt8}, nranks::Cint, rank::Cint)::Cint),
+           "hpcla_comm_init_rank")
+    return _comms[key] = h[]
+end
+
+# ---- device half of the VectorPlan, cached next to the reference plan -----------------------------------
+mutable struct ROCVectorPlan{Ti}
+    halo::Ptr{Cvoid}                 # hpcla_halo_plan_t* (C_NULL when there are no neighbours)
+    colval_split::ROCVector{Ti}      # 0-based split columns: < n_own -> x.v, >= n_own -> ghost segment
+    interior::ROCVector{Int32}
+    boundary::ROCVector{Int32}
+    n_own::Int
+end
+const _rocm_plans = IdDict{Any,Any}()    # reference plan object -> ROCVectorPlan (cleared with clear_plan_cache!)
+
+function _device_plan(A::HPCSparseMatrix{T,Ti,B}, x::HPCVector{T,B}, plan) where {T,Ti,B<:ROCBackend}
+    get!(_rocm_plans, plan) do
+        n_own = length(x.v)
+        # compressed column -> split column (0-based): own columns map to their offset in x.v,
+        # ghosts to n_own + position in the ghost segment (recv_perm order == ascending global column)
+        cmap = Vector{Ti}(undef, length(A.col_indices))
+        cmap[plan.local_dst_indices] .= plan.local_src_indices .- one(Ti)
+        off = n_own
+        for perm in plan.recv_perm
+            cmap[perm] .= Ti.(off .+ (0:length(perm)-1)); off += length(perm)
+        end
+        cmap_d = ROCVector(cmap)
+        split = similar(A.colval_target)
+        nnz = length(A.nzval)
+        if Ti === Int32
+            _check(@ccall(LIB.hpcla_remap_i32(_ptr(A.colval_target)::Ptr{Cvoid}, _ptr(cmap_d)::Ptr{Cvoid},
+                   _ptr(split)::Ptr{Cvoid}, nnz::Int64, 1::Cint, _stream()::Ptr{Cvoid})::Cint), "hpcla_remap_i32")
+        else
+            _check(@ccall(LIB.hpcla_remap_i64(_ptr(A.colval_target)::Ptr{Cvoid}, _ptr(cmap_d)::Ptr{Cvoid},
+                   _ptr(split)::Ptr{Cvoid}, nnz::Int64, 1::Cint, _stream()::Ptr{Cvoid})::Cint), "hpcla_remap_i64")
+        end
+        halo = Ref{Ptr{Cvoid}}(C_NULL)
+        interior = ROCVector{Int32}(undef, 0); boundary = ROCVector{Int32}(undef, 0)
+        if !isempty(plan.send_rank_ids) || !isempty(plan.recv_rank_ids)
+            send_idx = ROCVector(Ti.(reduce(vcat, plan.send_indices; init=Ti[]) .- one(Ti)))   # 0-based
+            AMDGPU.synchronize()
+            _check(@ccall(LIB.hpcla_halo_plan_create(halo::Ptr{Ptr{Cvoid}}, _rccl(A.backend.comm)::Ptr{Cvoid},
+                   length(plan.send_rank_ids)::Cint, Int32.(plan.send_rank_ids)::Ptr{Int32},
+                   Int64.(length.(plan.send_indices))::Ptr{Int64}, _ptr(send_idx)::Ptr{Cvoid},
+                   (Ti === Int64 ? 1 : 0)::Cint, length(plan.recv_rank_ids)::Cint,
+                   Int32.(plan.recv_rank_ids)::Ptr{Int32}, Int64.(length.(plan.recv_perm))::Ptr{Int64},
+                   1::Cint)::Cint), "hpcla_halo_plan_create")
+            rpb = @ccall LIB.hpcla_spmv_rows_per_block()::Cint
+            flags = AMDGPU.zeros(Int32, cld(A.nrows_local, rpb))
+            if Ti === Int32
+                _check(@ccall(LIB.hpcla_classify_blocks_i32(_ptr(A.rowptr_target)::Ptr{Cvoid}, _ptr(split)::Ptr{Cvoid},
+                       A.nrows_local::Int64, 1::Cint, n_own::Int64, rpb::Cint, _ptr(flags)::Ptr{Cvoid},
+                       _stream()::Ptr{Cvoid})::Cint), "hpcla_classify_blocks_i32")
+            else
+                _check(@ccall(LIB.hpcla_classify_blocks_i64(_ptr(A.rowptr_target)::Ptr{Cvoid}, _ptr(split)::Ptr{Cvoid},
+                       A.nrows_local::Int64, 1::Cint, n_own::Int64, rpb::Cint, _ptr(flags)::Ptr{Cvoid},
+                       _stream()::Ptr{Cvoid})::Cint), "hpcla_classify_blocks_i64")
+            end
+            f = Array(flags)
+            interior = ROCVector(Int32.(findall(==(0), f) .- 1)); boundary = ROCVector(Int32.(findall(!=(0), f) .- 1))
+        end
+        ROCVectorPlan{Ti}(halo[], split, interior, boundary, n_own)
+    end
+end
+
+# The split-column copy made by hpcla_remap is 0-based, while A.rowptr_target keeps the reference's
+# 1-based values; the SpMV entry points apply ONE index_base to rowptr and colval alike, so the
+# extension keeps a 0-based rowptr copy next to the plan and calls the split kernels with index_base = 0.
+_rowptr0(A) = get!(() -> A.rowptr_target .- one(eltype(A.rowptr_target)), _rocm_plans, (A, :rowptr0))
+
+function _spmv_dist!(y::ROCVector{T}, A::HPCSparseMatrix{T,Ti,B}, x::HPCVector{T,B}) where {T<:Float64,Ti,B<:ROCBackend}
+    plan = get_vector_plan(A, x)                   # reference host plan, memoized (src/sparse.jl:1992-2001)
+    d = _device_plan(A, x, plan)
+    rp0 = _rowptr0(A)
+    nnz = length(A.nzval)
+    if Ti === Int32
+        _check(@ccall(LIB.hpcla_spmv_dist_f64_i32(d.halo::Ptr{Cvoid}, _ptr(rp0)::Ptr{Cvoid},
+               _ptr(d.colval_split)::Ptr{Cvoid}, _ptr(A.nzval)::Ptr{Cvoid}, _ptr(x.v)::Ptr{Cvoid}, d.n_own::Int64,
+               _ptr(y)::Ptr{Cvoid}, A.nrows_local::Int64, nnz::Int64, 0::Cint, _ptr(d.interior)::Ptr{Cvoid},
+               length(d.interior)::Int64, _ptr(d.boundary)::Ptr{Cvoid}, length(d.boundary)::Int64,
+               _stream()::Ptr{Cvoid})::Cint), "hpcla_spmv_dist_f64_i32")
+    else
+        _check(@ccall(LIB.hpcla_spmv_dist_f64_i64(d.halo::Ptr{Cvoid}, _ptr(rp0)::Ptr{Cvoid},
+               _ptr(d.colval_split)::Ptr{Cvoid}, _ptr(A.nzval)::Ptr{Cvoid}, _ptr(x.v)::Ptr{Cvoid}, d.n_own::Int64,
+               _ptr(y)::Ptr{Cvoid}, A.nrows_local::Int64, nnz::Int64, 0::Cint, _ptr(d.interior)::Ptr{Cvoid},
+               length(d.interior)::Int64, _ptr(d.boundary)::Ptr{Cvoid}, length(d.boundary)::Int64,
+               _stream()::Ptr{Cvoid})::Cint), "hpcla_spmv_dist_f64_i64")
+    end
+    return plan
+end
+
+# ---- A * x  (replaces src/sparse.jl:2096-2128 for DeviceROCm) ---------------------------------------------
+function Base.:*(A::HPCSparseMatrix{T,Ti,B}, x::HPCVector{T,B}) where {T<:Float64,Ti,B<:ROCBackend}
+    assert_backends_compatible(A.backend, x.backend)
+    y_local = similar(A.nzval, A.nrows_local)
+    plan = _spmv_dist!(y_local, A, x)
+    if plan.result_partition_hash === nothing
+        plan.result_partition_hash = compute_partition_hash(A.row_partition)
+        plan.result_partition = copy(A.row_partition)
+    end
+    return HPCVector{T,B}(plan.result_partition_hash, plan.result_partition, y_local, A.backend)
+end
+
+# ---- mul!(y, A, x)  (replaces the CPU multiply of src/sparse.jl:2019-2037) --------------------------------
+function LinearAlgebra.mul!(y::HPCVector{T,B}, A::HPCSparseMatrix{T,Ti,B}, x::HPCVector{T,B}) where {T<:Float64,Ti,B<:ROCBackend}
+    _spmv_dist!(y.v, A, x)
+    return y
+end
+
+# ---- dot / norm  (replace src/vectors.jl:798-812, 758-780) ------------------------------------------------
+const _work = Ref{Any}(nothing)
+function _scratch()
+    _work[] === nothing && (_work[] = (AMDGPU.zeros(UInt8, @ccall LIB.hpcla_reduce_work_bytes()::Int64), AMDGPU.zeros(Float64, 1)))
+    return _work[]
+end
+function LinearAlgebra.dot(x::HPCVector{T,B}, y::HPCVector{T,B}) where {T<:Float64,B<:ROCBackend}
+    x.structural_hash == y.structural_hash || (y = HPCLinearAlgebra.repartition(y, x.partition))
+    work, out = _scratch()
+    _check(@ccall(LIB.hpcla_dot_f64(_rccl(x.backend.comm)::Ptr{Cvoid}, _ptr(x.v)::Ptr{Cvoid}, _ptr(y.v)::Ptr{Cvoid},
+           length(x.v)::Int64, _ptr(out)::Ptr{Cvoid}, _ptr(work)::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_dot_f64")
+    return Array(out)[1]
+end
+function LinearAlgebra.norm(v::HPCVector{T,B}, p::Real=2) where {T<:Float64,B<:ROCBackend}
+    work, out = _scratch(); c = _rccl(v.backend.comm); n = length(v.v)
+    if p == 2
+        _check(@ccall(LIB.hpcla_nrm2sq_f64(c::Ptr{Cvoid}, _ptr(v.v)::Ptr{Cvoid}, n::Int64, _ptr(out)::Ptr{Cvoid},
+               _ptr(work)::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_nrm2sq_f64")
+        return sqrt(Array(out)[1])
+    elseif p == 1
+        _check(@ccall(LIB.hpcla_asum_f64(c::Ptr{Cvoid}, _ptr(v.v)::Ptr{Cvoid}, n::Int64, _ptr(out)::Ptr{Cvoid},
+               _ptr(work)::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_asum_f64")
+        return Array(out)[1]
+    elseif p == Inf
+        _check(@ccall(LIB.hpcla_amax_f64(c::Ptr{Cvoid}, _ptr(v.v)::Ptr{Cvoid}, n::Int64, _ptr(out)::Ptr{Cvoid},
+               _ptr(work)::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_amax_f64")
+        return Array(out)[1]
+    else
+        return invoke(LinearAlgebra.norm, Tuple{HPCVector,Real}, v, p)      # generic path of the parent
+    end
+end
+
+# ---- A * B, B::HPCMatrix  (replaces the column loop of src/sparse.jl:2391-2413) ---------------------------
+# Julia's Matrix is column-major; the kernel's fast layout is row-major (one 128-byte line per B row at
+# k = 16), so B is converted once with hpcla_transpose_f64 and C converted back.
+function Base.:*(A::HPCSparseMatrix{T,Ti,B}, M::HPCMatrix{T,B}) where {T<:Float64,Ti<:Int32,B<:ROCBackend}
+    comm_size(A.backend.comm) == 1 || error("multi-rank SpMM: bind hpcla_spmm_split_f64_i32 + a width-k halo plan (see linearalgebrampi.jl_amd/dense.py)")
+    nloc, k = size(M.A)
+    Brow = AMDGPU.zeros(T, k, nloc)                 # k x nloc column-major == nloc x k row-major
+    _check(@ccall(LIB.hpcla_transpose_f64(_ptr(M.A)::Ptr{Cvoid}, nloc::Int64, 1::Cint, _ptr(Brow)::Ptr{Cvoid}, k::Int64,
+           0::Cint, nloc::Int64, k::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_transpose_f64")
+    gathered = Brow                                  # 1 rank and col_indices == 1:n (else gather rows first)
+    Crow = AMDGPU.zeros(T, k, A.nrows_local)
+    _check(@ccall(LIB.hpcla_spmm_csr_f64_i32(_ptr(A.rowptr_target)::Ptr{Cvoid}, _ptr(A.colval_target)::Ptr{Cvoid},
+           _ptr(A.nzval)::Ptr{Cvoid}, _ptr(gathered)::Ptr{Cvoid}, k::Int64, 0::Cint, _ptr(Crow)::Ptr{Cvoid}, k::Int64,
+           0::Cint, A.nrows_local::Int64, length(A.nzval)::Int64, k::Cint, 1::Cint, _stream()::Ptr{Cvoid})::Cint),
+           "hpcla_spmm_csr_f64_i32")
+    C = AMDGPU.zeros(T, A.nrows_local, k)
+    _check(@ccall(LIB.hpcla_transpose_f64(_ptr(Crow)::Ptr{Cvoid}, k::Int64, 0::Cint, _ptr(C)::Ptr{Cvoid},
+           A.nrows_local::Int64, 1::Cint, A.nrows_local::Int64, k::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_transpose_f64")
+    return HPCLinearAlgebra.HPCMatrix_local(C, A.backend)
+end
+
+end # module
