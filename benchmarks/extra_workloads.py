@@ -1,0 +1,135 @@
+"""BASELINE configs 4 and 5 (and per-kernel vector-op rates): separate harness behind
+``bench.py --workload {poisson3d_cg,sprand_spmm}``.  Weak scaling per GPU like bench.py:
+
+* poisson3d_cg  -- 3-D 7-point Poisson, 512 x 512 x (64*N) grid (config 4's per-GPU share: 64 planes
+  = 16 777 216 rows, ~117 M nonzeros per GPU), exactly --steps CG iterations from x0 = 0 (default 100),
+  no convergence exit; reports ms/iteration, algorithmic GB/s per GPU and the final residual.
+* sprand_spmm   -- unstructured sprand-like matrix, 2 097 152 rows per GPU, ~29.8 nnz/row, columns
+  uniform over the global 2 097 152*N columns, B with k = 16 dense columns (row-major on device).
+"""
+import json
+import os
+import time
+
+import numpy as np
+
+HBM_PEAK_GBS = 8000.0
+
+
+def _sync_barrier(torch, dist, world):
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def run(args, backend, rank, world):
+    import torch
+    import torch.distributed as dist
+    import hpcla_amd as hp
+    from hpcla_amd import workloads as wl
+    dev = backend.torch_device
+    out = {}
+    if args.workload == "poisson3d_cg":
+        N = args.size or 512
+        planes = (N // 8) if N >= 64 else N
+        nz = planes * world
+        n_glob = N * N * nz
+        lo, hi = rank * N * N * planes, (rank + 1) * N * N * planes
+        t0 = time.perf_counter()
+        rowptr, colidx, vals = wl.poisson3d_rows(N, N, nz, lo, hi)
+        A = hp.HPCSparseMatrix_local(rowptr, colidx, vals, n_glob, backend)
+        del rowptr, colidx, vals
+        b = hp.HPCVector.zeros(A.row_partition, backend)
+        hp._capi.call("hpcla_fill_uniform_f64", b.v.data_ptr(), lo, hi - lo, wl.SEED_RHS,
+                      torch.cuda.current_stream().cuda_stream)
+        setup_s = time.perf_counter() - t0
+        iters = args.steps if args.steps != 200 else 100
+        hp.cg_fixed_iterations(A, b, max(args.warmup // 4, 2), record_history=False)    # warm-up (plan, RCCL)
+        _sync_barrier(torch, dist, world)
+        t0 = time.perf_counter()
+        x, hist = hp.cg_fixed_iterations(A, b, iters, record_history=True)
+        _sync_barrier(torch, dist, world)
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        n_loc, nnz_loc = A.nrows_local, A.nnz
+        b_spmv = wl.spmv_algorithmic_bytes(nnz_loc, n_loc, A.ncols_compressed, 4)
+        b_iter = b_spmv + 96 * n_loc        # textbook unfused CG = SpMV + 96 n bytes
+        ms_iter = elapsed / iters * 1e3
+        out = {
+            "metric": "CG ms/iteration, 3-D 7-pt Poisson, fp64", "value": round(ms_iter, 4), "unit": "ms/iter",
+            "n_gpus": world, "steps": iters, "warmup": args.warmup, "ms_per_step": round(ms_iter, 4),
+            "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"poisson3d 7-pt {N}x{N}x{planes} per GPU ({N}x{N}x{nz} global), {iters} CG iterations",
+                       "global_rows": n_glob, "nnz_per_gpu": nnz_loc},
+            "roofline": {"bound": "hbm", "achieved": round(b_iter / (ms_iter * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(b_iter / (ms_iter * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_iteration": b_iter, "note": "whole iteration (SpMV + 2 reductions + 3 updates), wall clock"},
+            "residual_first": hist[0], "residual_last": hist[-1], "setup_s": round(setup_s, 2),
+        }
+    elif args.workload == "sprand_spmm":
+        k = 16
+        rows_loc = args.size or 2_097_152
+        ncols = rows_loc * world
+        mean_nnz = 29.8
+        rng = np.random.default_rng(0xA11CE + rank)
+        t0 = time.perf_counter()
+        counts = rng.binomial(ncols, mean_nnz / ncols, size=rows_loc).astype(np.int64)
+        rowptr = np.concatenate([[0], np.cumsum(counts)])
+        nnz = int(rowptr[-1])
+        cols = rng.integers(0, ncols, size=nnz, dtype=np.int64)
+        rowid = np.repeat(np.arange(rows_loc, dtype=np.int64), counts)
+        order = np.lexsort((cols, rowid))
+        cols = cols[order]
+        del order, rowid
+        vals = rng.random(nnz)
+        A = hp.HPCSparseMatrix_local(rowptr, cols, vals, ncols, backend)
+        del cols, vals
+        Bl = torch.empty((rows_loc, k), dtype=torch.float64, device=dev)
+        hp._capi.call("hpcla_fill_uniform_f64", Bl.data_ptr(), rank * rows_loc * k, rows_loc * k, wl.SEED_X,
+                      torch.cuda.current_stream().cuda_stream)
+        B = hp.HPCMatrix_local(Bl, backend)
+        setup_s = time.perf_counter() - t0
+        C = A @ B
+        for _ in range(args.warmup):
+            C = A @ B
+        _sync_barrier(torch, dist, world)
+        steps = min(args.steps, 50)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            C = A @ B
+        _sync_barrier(torch, dist, world)
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        ms = elapsed / steps * 1e3
+        b_alg = wl.spmm_algorithmic_bytes(A.nnz, A.nrows_local, A.ncols_compressed, k, 4)
+        b_gather = A.nnz * (12 + 8 * k) + 4 * A.nrows_local + 8 * k * A.nrows_local    # every B row read per entry
+        out = {
+            "metric": "SpMM GFLOP/s (2*k*nnz/t), sprand ~29.8 nnz/row, k=16, fp64", "value": round(2.0 * k * A.nnz * world / (ms * 1e-3) / 1e9, 1),
+            "unit": "GFLOP/s", "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"sprand-like {rows_loc} rows per GPU x {ncols} cols, nnz/GPU={A.nnz}, k={k}, C = A*B",
+                       "ncols_compressed": A.ncols_compressed},
+            "roofline": {"bound": "hbm", "achieved": round(b_alg / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": b_alg,
+                         "gather_bytes_per_launch": b_gather,
+                         "gather_gbs": round(b_gather / (ms * 1e-3) / 1e9, 1),
+                         "note": "algorithmic bytes count each touched B row once; a random-column matrix re-reads B rows "
+                                 "(gather_bytes = one 128-byte line per stored entry), which is what HBM actually serves"},
+            "setup_s": round(setup_s, 2),
+        }
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    hp.clear_plan_cache()
+    hp.clear_spmm_cache()
+    if world > 1:
+        dist.destroy_process_group()

@@ -524,6 +524,103 @@ __global__ __launch_bounds__(TPB) void k_pipe2(const int *__restrict__ rowptr,
     }
 }
 
+// ---- wave-independent kernel: every 64-lane wave owns its own rows and LDS slice, no workgroup
+// barrier (waves of a workgroup drift apart freely, which hides more latency) ---------------------------
+template <int RPL, int QPL>
+__global__ __launch_bounds__(256) void k_wave(const int *__restrict__ rowptr,
+                                              const int *__restrict__ colval,
+                                              const double *__restrict__ nzval,
+                                              const double *__restrict__ x, double *__restrict__ y,
+                                              int64_t nrows, int64_t nnz)
+{
+    constexpr int R = 64 * RPL;            // rows per wave
+    constexpr int CHUNK = 64 * 4 * QPL;    // entries per pass per wave
+    __shared__ double s_all[4 * CHUNK];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double *s_prod = s_all + w * CHUNK;
+    const int64_t wave_id = (int64_t)blockIdx.x * 4 + w;
+    const int64_t r0 = wave_id * R;
+    if (r0 >= nrows) return;
+    const int nr = (int)((nrows - r0) < R ? (nrows - r0) : R);
+    const int64_t p0 = rowptr[r0], p1 = rowptr[r0 + nr];
+    const int64_t pa = p0 & ~(int64_t)3;
+    const int64_t total = p1 - pa;
+    int lo[RPL], hi[RPL];
+    double acc[RPL];
+#pragma unroll
+    for (int q = 0; q < RPL; ++q) {
+        const int r = lane + q * 64;
+        lo[q] = hi[q] = 0;
+        acc[q] = 0.0;
+        if (r < nr) { lo[q] = (int)(rowptr[r0 + r] - pa); hi[q] = (int)(rowptr[r0 + r + 1] - pa); }
+    }
+    for (int64_t c = 0; c < total; c += CHUNK) {
+        const int n = (int)((total - c) < CHUNK ? (total - c) : CHUNK);
+        v4i col[QPL];
+        v2d va[QPL], vb[QPL];
+#pragma unroll
+        for (int u = 0; u < QPL; ++u) {
+            const int e0 = (u * 64 + lane) * 4;
+            const int64_t g = pa + c + e0;
+            col[u] = (v4i)(0);
+            va[u] = (v2d)(0.0);
+            vb[u] = (v2d)(0.0);
+            if (e0 < n) {
+                if (g + 3 < nnz) {
+                    col[u] = *reinterpret_cast<const v4i *>(colval + g);
+                    va[u] = *reinterpret_cast<const v2d *>(nzval + g);
+                    vb[u] = *reinterpret_cast<const v2d *>(nzval + g + 2);
+                } else {
+                    if (g + 0 < nnz) { col[u].x = colval[g + 0]; va[u].x = nzval[g + 0]; }
+                    if (g + 1 < nnz) { col[u].y = colval[g + 1]; va[u].y = nzval[g + 1]; }
+                    if (g + 2 < nnz) { col[u].z = colval[g + 2]; vb[u].x = nzval[g + 2]; }
+                }
+            }
+        }
+        double xv[QPL][4];
+#pragma unroll
+        for (int u = 0; u < QPL; ++u) {
+            const int e0 = (u * 64 + lane) * 4;
+            if (e0 < n) {
+                xv[u][0] = x[col[u].x];
+                xv[u][1] = x[col[u].y];
+                xv[u][2] = x[col[u].z];
+                xv[u][3] = x[col[u].w];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < QPL; ++u) {
+            const int e0 = (u * 64 + lane) * 4;
+            if (e0 < n) {
+                double2 pa2, pb2;
+                pa2.x = va[u].x * xv[u][0];
+                pa2.y = va[u].y * xv[u][1];
+                pb2.x = vb[u].x * xv[u][2];
+                pb2.y = vb[u].y * xv[u][3];
+                *reinterpret_cast<double2 *>(&s_prod[e0]) = pa2;
+                *reinterpret_cast<double2 *>(&s_prod[e0 + 2]) = pb2;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int q = 0; q < RPL; ++q) {
+            const int a = lo[q] > c ? lo[q] : (int)c;
+            const int e = hi[q] < c + n ? hi[q] : (int)(c + n);
+            for (int j = a; j < e; ++j) acc[q] += s_prod[j - c];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+#pragma unroll
+    for (int q = 0; q < RPL; ++q) {
+        const int r = lane + q * 64;
+        if (r < nr) y[r0 + r] = acc[q];
+    }
+}
+
 extern "C" __attribute__((visibility("default"))) int hpcla_tune_spmv(
     int variant, const int *rowptr, const int *colval, const double *nzval, const double *x, double *y,
     int64_t nrows, int64_t nnz, void *stream)
@@ -591,6 +688,19 @@ extern "C" __attribute__((visibility("default"))) int hpcla_tune_spmv(
         case 50: PIPE2(256, 1, 2, false, 4, 1) break;
         case 51: PIPE2(256, 1, 2, false, 5, 1) break;
         case 52: PIPE2(256, 1, 2, false, 6, 8) break;
+#define WAVE(RPL, QPL)                                                                            \
+    {                                                                                             \
+        int64_t rows_per_block = 4 * 64 * RPL;                                                    \
+        uint32_t nb = (uint32_t)((nrows + rows_per_block - 1) / rows_per_block);                  \
+        k_wave<RPL, QPL><<<nb, 256, 0, s>>>(rowptr, colval, nzval, x, y, nrows, nnz);             \
+    }
+        case 60: WAVE(1, 2) break;     // 64 rows / wave, 512-entry chunk
+        case 61: WAVE(2, 2) break;     // 128 rows / wave
+        case 62: WAVE(2, 3) break;     // 128 rows / wave, 768-entry chunk
+        case 63: WAVE(4, 2) break;     // 256 rows / wave
+        case 64: WAVE(4, 3) break;
+        case 65: WAVE(1, 1) break;
+        case 66: WAVE(2, 4) break;
         case 20:
             k_copy<<<256 * 16, 256, 0, s>>>((const v4i *)colval, (const v2d *)nzval, (const v4i *)rowptr,
                                             (double2 *)y, (const double2 *)x, nnz, nrows);

@@ -58,11 +58,20 @@ def main():
     variants = [int(v) for v in args.variants.split(",")]
     y = torch.empty_like(y_ref)
     ghost = torch.zeros(16, dtype=torch.float64, device="cuda")
+    yvec = hp.HPCVector.zeros(A.row_partition, backend)
+    plan = hp.get_vector_plan(A, x)
 
     def launch(v):
         if v == 100:     # production library, plain kernel
             return hp._capi.load().hpcla_spmv_csr_f64_i32(A.rowptr_target.data_ptr(), cv.data_ptr(), A.nzval.data_ptr(),
                                                          x.v.data_ptr(), y.data_ptr(), n, nnz, 0, s)
+        if v == 102:     # full host-layer path: mul!(y, A, x) (plan lookup + hpcla_spmv_dist)
+            hp.mul_(yvec, A, x)
+            return 0
+        if v == 103:     # hpcla_spmv_dist directly with the plan's arrays (no Python host layer)
+            return hp._capi.load().hpcla_spmv_dist_f64_i32(None, A.rowptr_target.data_ptr(), plan.colval_split.data_ptr(),
+                                                          A.nzval.data_ptr(), x.v.data_ptr(), n, yvec.v.data_ptr(), n, nnz, 0,
+                                                          None, 0, None, 0, s)
         if v == 101:     # production library, split-column kernel (ghost select per entry)
             return hp._capi.load().hpcla_spmv_split_f64_i32(A.rowptr_target.data_ptr(), cv.data_ptr(), A.nzval.data_ptr(),
                                                            x.v.data_ptr(), ghost.data_ptr(), n, y.data_ptr(), n, nnz, 0,
@@ -76,7 +85,7 @@ def main():
         rc = launch(v)
         assert rc == 0, (v, rc)
         torch.cuda.synchronize()
-        exact[v] = bool(torch.equal(y, y_ref))
+        exact[v] = bool(torch.equal(yvec.v if v in (102, 103) else y, y_ref))
     for rnd in range(args.rounds):
         for v in variants:
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

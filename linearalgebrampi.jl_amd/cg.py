@@ -12,7 +12,7 @@ from __future__ import annotations
 from typing import List, Tuple
 
 from .sparse import get_vector_plan, mul_
-from .vectors import HPCVector, dot
+from .vectors import HPCVector, dot, norm
 
 
 def _torch():
@@ -34,7 +34,7 @@ def cg_fixed_iterations(A, b: HPCVector, iters: int, record_history: bool = True
     rr = torch.zeros(2, dtype=torch.float64, device=dev)
     pAp = torch.zeros(1, dtype=torch.float64, device=dev)
     hist = torch.zeros(iters + 1, dtype=torch.float64, device=dev)
-    dot(r, r, out=rr[0:1])
+    norm(r, 2, out=rr[0:1])                    # out form leaves sum(r^2) on the device (8 B/elt)
     if record_history:
         hist[0:1].copy_(rr[0:1])
     cur = 0
@@ -44,7 +44,7 @@ def cg_fixed_iterations(A, b: HPCVector, iters: int, record_history: bool = True
         dot(p, Ap, out=pAp)                                     # pAp
         x.axpy_(1.0, p, num=rr[cur:cur + 1], den=pAp)           # x += (rr/pAp) p
         r.axpy_(-1.0, Ap, num=rr[cur:cur + 1], den=pAp)         # r -= (rr/pAp) Ap
-        dot(r, r, out=rr[nxt:nxt + 1])                          # rr_new
+        norm(r, 2, out=rr[nxt:nxt + 1])                         # rr_new = sum(r^2)
         p.xpay_(r, 1.0, num=rr[nxt:nxt + 1], den=rr[cur:cur + 1])   # p = r + (rr_new/rr) p
         if record_history:
             hist[it + 1:it + 2].copy_(rr[nxt:nxt + 1])

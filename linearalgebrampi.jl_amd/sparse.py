@@ -317,9 +317,10 @@ def mul_(y: HPCVector, A: HPCSparseMatrix, x: HPCVector) -> HPCVector:
     (SURVEY.md section 3.2); neither is reproduced."""
     assert_backends_compatible(A.backend, x.backend)
     assert_backends_compatible(A.backend, y.backend)
-    if y.structural_hash != compute_partition_hash(A.row_partition):
+    plan = get_vector_plan(A, x)
+    if y.structural_hash != plan.result_partition_hash:      # hash cached on the plan (:2103-2106)
         raise ValueError("mul!: y must have A's row partition")
-    _spmv_into(y, A, x, get_vector_plan(A, x))
+    _spmv_into(y, A, x, plan)
     return y
 
 

@@ -221,7 +221,10 @@ def dot(x: HPCVector, y: HPCVector, out=None):
 
 
 def norm(v: HPCVector, p: float = 2, out=None):
-    """``norm(v, p)`` (src/vectors.jl:758-780): p=2 sums squares then sqrt, p=1 asum, p=Inf max."""
+    """``norm(v, p)`` (src/vectors.jl:758-780): p=2 sums squares then sqrt, p=1 asum, p=Inf max.
+    With ``out`` (1-element device tensor) nothing is read back: ``out`` receives the all-reduced
+    quantity the reference feeds to its final step -- for p=2 that is the SUM OF SQUARES (the sqrt is
+    the caller's), for p=1 / Inf the norm itself."""
     if p == 2:
         r = _reduce("nrm2sq", v, None, out)
         return r if out is not None else math.sqrt(float(r.item()))

@@ -18,11 +18,16 @@ for st in $STEPS; do
     pytest) run 900 gpurun_out/${TAG}_pytest.log python -m pytest tests -m gpu -q -x; tail -5 gpurun_out/${TAG}_pytest.log;;
     bench)  run 600 gpurun_out/${TAG}_bench.log python bench.py --steps 100 --warmup 10; tail -3 gpurun_out/${TAG}_bench.log;;
     tune)   run 600 gpurun_out/${TAG}_tune.log python benchmarks/tune_spmv.py ${TUNE_ARGS}; tail -25 gpurun_out/${TAG}_tune.log;;
+    tune8k) run 900 gpurun_out/${TAG}_tune8k.log python benchmarks/tune_spmv.py --size 8192 --variants 16,100,101,102,20 --rounds 5 --reps 10; tail -8 gpurun_out/${TAG}_tune8k.log;;
     tune3d) run 600 gpurun_out/${TAG}_tune3d.log python benchmarks/tune_spmv.py --dim 3 --size 256 ${TUNE_ARGS}; tail -25 gpurun_out/${TAG}_tune3d.log;;
     prof)
       cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
       run 600 gpurun_out/${TAG}_prof.log rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_prof -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline
       tail -3 gpurun_out/${TAG}_prof.log;;
+    vecops) run 600 gpurun_out/${TAG}_vecops.log python benchmarks/bench_vecops.py; tail -8 gpurun_out/${TAG}_vecops.log;;
+    cg)     run 900 gpurun_out/${TAG}_cg.log python bench.py --workload poisson3d_cg --steps 100 --warmup 10; tail -2 gpurun_out/${TAG}_cg.log;;
+    cgsmall) run 900 gpurun_out/${TAG}_cgsmall.log python bench.py --workload poisson3d_cg --size 256 --steps 100 --warmup 10; tail -2 gpurun_out/${TAG}_cgsmall.log;;
+    spmm)   run 900 gpurun_out/${TAG}_spmm.log python bench.py --workload sprand_spmm --steps 20 --warmup 3; tail -2 gpurun_out/${TAG}_spmm.log;;
     pmc_tune_rd)
       run 600 gpurun_out/${TAG}_pmc_tune_rd.log rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/${TAG}_pmc_tune_rd -- python3 benchmarks/tune_spmv.py --variants 20,100,101 --rounds 1 --reps 3
       tail -2 gpurun_out/${TAG}_pmc_tune_rd.log;;

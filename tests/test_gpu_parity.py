@@ -397,3 +397,86 @@ def test_error_convention(hp, gpu_backend_i32):
     A = hp.HPCSparseMatrix_from_global(sp.identity(8, format="csr"), gpu_backend_i32)
     with pytest.raises(ValueError):
         hp.mul_(y, A, hp.HPCVector.from_global(np.ones(8), gpu_backend_i32))
+
+
+# ---------------------------------------------------------------------------------------------------
+# more coverage: unaligned fallback kernel, distributed SpMM semantics, Int64 at moderate scale
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("Ti", [np.int32, np.int64])
+def test_spmv_unaligned_pointers_take_fallback_kernel(hp, orc, gpu_backend_i32, Ti):
+    """colval/nzval views offset by one element are not 16/32-byte aligned: the element-per-lane
+    kernel must be selected and give the same bits."""
+    import torch
+    n = 5000
+    rows = orc.sprand_rows(n, 0.004, 0, n)
+    x = orc.fill_uniform(0, n, orc.SEED_X)
+    want = orc.spmv(rows.rowptr.astype(Ti), rows.colidx.astype(Ti), rows.vals, x)
+    sfx = "i32" if Ti == np.int32 else "i64"
+    d_rp = _t(rows.rowptr.astype(Ti))
+    d_cv_pad = _t(np.concatenate([[0], rows.colidx]).astype(Ti))
+    d_nz_pad = _t(np.concatenate([[0.0], rows.vals]))
+    d_cv, d_nz = d_cv_pad[1:], d_nz_pad[1:]
+    assert d_nz.data_ptr() % 32 != 0
+    d_x = _t(x)
+    y = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+    hp._capi.call(f"hpcla_spmv_csr_f64_{sfx}", d_rp.data_ptr(), d_cv.data_ptr(), d_nz.data_ptr(), d_x.data_ptr(),
+                  y.data_ptr(), n, rows.nnz, 0, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(y.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("nranks,k", [(2, 16), (3, 5)])
+def test_split_spmm_per_rank_matches_reference_pipeline(hp, orc, gpu_backend_i32, nranks, k):
+    """hpcla_spmm_split_f64_i32 (own rows of B + ghost rows, interior/boundary block lists at SpMM
+    granularity) == the reference's column loop over gathered B, for every simulated rank."""
+    import torch
+    n = 4000
+    rp = orc.uniform_partition(n, nranks)
+    Bg = orc.fill_uniform(0, n * k, 21).reshape(n, k)
+    locs = [orc.sprand_rows(n, 0.003, int(rp[r]), int(rp[r + 1])) for r in range(nranks)]
+    comp = [orc.compress_columns(l) for l in locs]
+    plans = orc.vector_plans([c[0] for c in comp], rp)
+    rpb = hp._capi.load().hpcla_spmm_rows_per_block()
+    s = torch.cuda.current_stream().cuda_stream
+    for r in range(nranks):
+        rows, (ci, cv), pl = locs[r], comp[r], plans[r]
+        want = orc.spmm(rows.rowptr.astype(np.int32), cv.astype(np.int32), rows.vals, Bg[ci])
+        n_own = int(rp[r + 1] - rp[r])
+        hplan = hp.HostVectorPlan(pl.send_rank_ids, pl.send_indices, pl.recv_rank_ids, pl.recv_perm,
+                                  pl.local_src_indices, pl.local_dst_indices, pl.n_gathered, n_own)
+        cmap = hp.split_column_map(hplan)
+        ghost_rows = np.concatenate([ci[p] for p in pl.recv_perm]) if pl.recv_perm else np.zeros(0, dtype=np.int64)
+        d_rp, d_split = _t(rows.rowptr.astype(np.int32)), _t(cmap[cv].astype(np.int32))
+        d_nz = _t(rows.vals)
+        d_B, d_G = _t(Bg[rp[r]:rp[r + 1]]), _t(Bg[ghost_rows] if len(ghost_rows) else np.zeros((1, k)))
+        nblk = (rows.nrows + rpb - 1) // rpb
+        flags = torch.empty(nblk, dtype=torch.int32, device="cuda")
+        hp._capi.call("hpcla_classify_blocks_i32", d_rp.data_ptr(), d_split.data_ptr(), rows.nrows, 0, n_own, rpb,
+                      flags.data_ptr(), s)
+        f = flags.cpu().numpy()
+        C = torch.full((rows.nrows, k), float("nan"), dtype=torch.float64, device="cuda")
+        for sel in (np.flatnonzero(f == 0), np.flatnonzero(f != 0)):
+            lst = _t(sel.astype(np.int32))
+            if lst.numel() == 0:
+                continue
+            hp._capi.call("hpcla_spmm_split_f64_i32", d_rp.data_ptr(), d_split.data_ptr(), d_nz.data_ptr(),
+                          d_B.data_ptr(), k, d_G.data_ptr(), k, n_own, C.data_ptr(), k, rows.nrows, rows.nnz, k, 0,
+                          lst.data_ptr(), lst.numel(), s)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(C.cpu().numpy(), want)
+
+
+def test_spmv_int64_moderate_scale(hp, orc, gpu_backend_i64):
+    N = 1500
+    rows = orc.poisson2d_rows(N, N, 0, N * N)
+    A = hp.HPCSparseMatrix_local(rows.rowptr, rows.colidx, rows.vals, N * N, gpu_backend_i64)
+    assert A.rowptr.dtype == np.int64 and A.colval.dtype == np.int64
+    xg = orc.fill_uniform(0, N * N, orc.SEED_X)
+    y = (A @ hp.HPCVector.from_global(xg, gpu_backend_i64)).local_values()
+    want = orc.spmv(rows.rowptr, rows.colidx, rows.vals, xg)
+    np.testing.assert_array_equal(y, want)
+
+
+def test_graft_entry_smoke():
+    import __graft_entry__ as g
+    g.smoke()
