@@ -194,6 +194,24 @@ int hpcla_spmv_dist_f64_i64(hpcla_halo_plan_t *plan, const int64_t *rowptr,
                             const int32_t *interior_blocks, int64_t n_interior,
                             const int32_t *boundary_blocks, int64_t n_boundary, void *stream);
 
+/* Fused y = A*x and out = x.y (CG's p.Ap; SURVEY section 7 step 6 "SpMV+dot fusion"): the SpMV
+ * workgroups leave one partial per row block in `work` (hpcla_spmv_dot_work_bytes(nrows) bytes),
+ * summed in index order (deterministic) and all-reduced over `comm` into out_dev[0].
+ * Requires x partitioned like A's rows (n_own == nrows). */
+int64_t hpcla_spmv_dot_work_bytes(int64_t nrows);
+int hpcla_spmv_dist_dot_f64_i32(hpcla_halo_plan_t *plan, hpcla_comm_t *comm, const int32_t *rowptr,
+                                const int32_t *colval_split, const double *nzval, const double *x,
+                                int64_t n_own, double *y, int64_t nrows, int64_t nnz, int index_base,
+                                const int32_t *interior_blocks, int64_t n_interior,
+                                const int32_t *boundary_blocks, int64_t n_boundary,
+                                double *dot_out_dev, void *work, void *stream);
+int hpcla_spmv_dist_dot_f64_i64(hpcla_halo_plan_t *plan, hpcla_comm_t *comm, const int64_t *rowptr,
+                                const int64_t *colval_split, const double *nzval, const double *x,
+                                int64_t n_own, double *y, int64_t nrows, int64_t nnz, int index_base,
+                                const int32_t *interior_blocks, int64_t n_interior,
+                                const int32_t *boundary_blocks, int64_t n_boundary,
+                                double *dot_out_dev, void *work, void *stream);
+
 /* ---- reductions: replace dot / norm (src/vectors.jl:798-812, 758-780) --------------------------
  * Local deterministic two-stage reduction into out_dev[0] (device double), then, if comm has
  * more than one rank, an in-place RCCL all-reduce on the same stream.  No host sync: CG keeps the
@@ -222,6 +240,12 @@ int hpcla_axpy_f64(double alpha_host, const double *num_dev, const double *den_d
 int hpcla_xpay_f64(const double *x, double alpha_host, const double *num_dev, const double *den_dev,
                    double *y, int64_t n, void *stream);
 int hpcla_scale_f64(double alpha_host, const double *x, double *y, int64_t n, void *stream);
+/* Fused CG update (two broadcasts + one norm of the reference, src/vectors.jl:1203-1226, 758-765):
+ * a = alpha_host * *num_dev / *den_dev;  x += a*p;  r -= a*Ap;  rr_out_dev[0] = allreduce(sum r^2).
+ * `work` as for the reductions (hpcla_reduce_work_bytes()). */
+int hpcla_cg_update_f64(hpcla_comm_t *comm, double alpha_host, const double *num_dev,
+                        const double *den_dev, const double *p, const double *Ap, double *x, double *r,
+                        int64_t n, double *rr_out_dev, void *work, void *stream);
 int hpcla_divide_f64(const double *x, double a_host, double *y, int64_t n, void *stream);
 int hpcla_axpby_f64(double a, const double *x, double b, const double *y, double *z, int64_t n,
                     void *stream);

@@ -21,10 +21,10 @@ from .backends import (AbstractComm, AbstractDevice, CommSerial, CommTorch, Devi
                        eltype_backend, indextype_backend)
 from .partition import (compute_partition_hash, compute_structural_hash, owner_of,
                         uniform_partition)
-from .vectors import HPCVector, HPCVector_local, dot, norm
+from .vectors import HPCVector, HPCVector_local, cg_update_, dot, norm
 from .sparse import (HPCSparseMatrix, HPCSparseMatrix_from_global, HPCSparseMatrix_local,
                      HostVectorPlan, VectorPlan, build_host_vector_plan, cache_sizes,
-                     clear_plan_cache, execute_plan, get_vector_plan, mul_, split_column_map)
+                     clear_plan_cache, execute_plan, get_vector_plan, mul_, mul_dot_, split_column_map)
 from .dense import HPCMatrix, HPCMatrix_local, clear_spmm_cache, spmm
 from .cg import cg_fixed_iterations
 

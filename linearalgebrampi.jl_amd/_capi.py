@@ -69,6 +69,10 @@ _SIGNATURES = {
     "hpcla_halo_end": [_vp, _vp],
     "hpcla_spmv_dist_f64_i32": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _i64, _vp],
     "hpcla_spmv_dist_f64_i64": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _i64, _vp],
+    "hpcla_spmv_dot_work_bytes": [_i64],
+    "hpcla_spmv_dist_dot_f64_i32": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp],
+    "hpcla_spmv_dist_dot_f64_i64": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp],
+    "hpcla_cg_update_f64": [_vp, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp],
     "hpcla_reduce_work_bytes": [],
     "hpcla_dot_f64": [_vp, _vp, _vp, _i64, _vp, _vp, _vp],
     "hpcla_nrm2sq_f64": [_vp, _vp, _i64, _vp, _vp, _vp],
@@ -84,6 +88,7 @@ _SIGNATURES = {
 _RESTYPES = {
     "hpcla_last_error": ctypes.c_char_p,
     "hpcla_reduce_work_bytes": _i64,
+    "hpcla_spmv_dot_work_bytes": _i64,
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -22,9 +22,13 @@
 namespace hpcla {
 
 int spmv_split_i32(const int32_t *, const int32_t *, const double *, const double *, const double *,
-                   int64_t, double *, int64_t, int64_t, int, const int32_t *, int64_t, void *);
+                   int64_t, double *, int64_t, int64_t, int, const int32_t *, int64_t, void *,
+                   double *);
 int spmv_split_i64(const int64_t *, const int64_t *, const double *, const double *, const double *,
-                   int64_t, double *, int64_t, int64_t, int, const int32_t *, int64_t, void *);
+                   int64_t, double *, int64_t, int64_t, int, const int32_t *, int64_t, void *,
+                   double *);
+int reduce_partials_sum(const double *partial, int64_t np, double *scratch, double *out,
+                        void *stream);   // vecops.hip
 
 // ---- RCCL entry points, resolved at first use ------------------------------------------------
 struct RcclApi {
@@ -395,13 +399,13 @@ static int spmv_dist_impl(F split_fn, hpcla_halo_plan_t *plan, const I *rowptr, 
                           const double *nzval, const double *x, int64_t n_own, double *y,
                           int64_t nrows, int64_t nnz, int index_base, const int32_t *interior,
                           int64_t n_interior, const int32_t *boundary, int64_t n_boundary,
-                          void *stream)
+                          void *stream, double *dot_partial = nullptr)
 {
     const bool has_halo = plan && !(plan->send_ranks.empty() && plan->recv_ranks.empty());
     if (!has_halo) {
         // no neighbours: every column is owned; one launch over all row blocks
         return split_fn(rowptr, colval, nzval, x, plan ? plan->ghost : nullptr, n_own, y, nrows,
-                        nnz, index_base, nullptr, 0, stream);
+                        nnz, index_base, nullptr, 0, stream, dot_partial);
     }
     if ((n_interior > 0 && !interior) || (n_boundary > 0 && !boundary))
         return set_error(HPCLA_ERR_INVALID, "spmv_dist: null block list");
@@ -409,15 +413,76 @@ static int spmv_dist_impl(F split_fn, hpcla_halo_plan_t *plan, const I *rowptr, 
     if (rc) return rc;
     if (n_interior > 0) {
         rc = split_fn(rowptr, colval, nzval, x, plan->ghost, n_own, y, nrows, nnz, index_base,
-                      interior, n_interior, stream);
+                      interior, n_interior, stream, dot_partial);
         if (rc) return rc;
     }
     rc = hpcla_halo_end(plan, stream);
     if (rc) return rc;
     if (n_boundary > 0)
         rc = split_fn(rowptr, colval, nzval, x, plan->ghost, n_own, y, nrows, nnz, index_base,
-                      boundary, n_boundary, stream);
+                      boundary, n_boundary, stream, dot_partial);
     return rc;
+}
+
+// y = A*x and out = x.y in one pass over A (CG's p.Ap): the SpMV workgroups leave per-row-block
+// partials in `work`, summed in index order afterwards, then all-reduced.  Needs x partitioned like
+// A's rows (n_own == nrows) and interior+boundary lists that cover every row block exactly once.
+template <typename I, typename F>
+static int spmv_dist_dot_impl(F split_fn, hpcla_halo_plan_t *plan, hpcla_comm_t *comm, const I *rowptr,
+                              const I *colval, const double *nzval, const double *x, int64_t n_own,
+                              double *y, int64_t nrows, int64_t nnz, int index_base,
+                              const int32_t *interior, int64_t n_interior, const int32_t *boundary,
+                              int64_t n_boundary, double *dot_out_dev, void *work, void *stream)
+{
+    if (!dot_out_dev || !work) return set_error(HPCLA_ERR_INVALID, "spmv_dist_dot: null out/work");
+    if (n_own != nrows)
+        return set_error(HPCLA_ERR_INVALID, "spmv_dist_dot: x must be partitioned like the rows of A");
+    const int rpb = hpcla_spmv_rows_per_block();
+    const int64_t all_blocks = (nrows + rpb - 1) / rpb;
+    const bool has_halo = plan && !(plan->send_ranks.empty() && plan->recv_ranks.empty());
+    if (has_halo && n_interior + n_boundary != all_blocks)
+        return set_error(HPCLA_ERR_INVALID, "spmv_dist_dot: block lists must cover every row block");
+    double *scratch = reinterpret_cast<double *>(work);          // 2048 doubles of stage-1 scratch
+    double *partial = scratch + 2048;                            // then one double per row block
+    int rc = spmv_dist_impl<I>(split_fn, plan, rowptr, colval, nzval, x, n_own, y, nrows, nnz, index_base,
+                               interior, n_interior, boundary, n_boundary, stream, partial);
+    if (rc) return rc;
+    rc = reduce_partials_sum(partial, all_blocks, scratch, dot_out_dev, stream);
+    if (rc) return rc;
+    if (comm) return allreduce_on(comm, dot_out_dev, 1, 0, stream);
+    return HPCLA_OK;
+}
+
+HPCLA_API int64_t hpcla_spmv_dot_work_bytes(int64_t nrows)
+{
+    const int rpb = hpcla_spmv_rows_per_block();
+    return (int64_t)sizeof(double) * (2048 + (nrows + rpb - 1) / rpb + 1);
+}
+
+HPCLA_API int hpcla_spmv_dist_dot_f64_i32(hpcla_halo_plan_t *plan, hpcla_comm_t *comm,
+                                          const int32_t *rowptr, const int32_t *colval_split,
+                                          const double *nzval, const double *x, int64_t n_own,
+                                          double *y, int64_t nrows, int64_t nnz, int index_base,
+                                          const int32_t *interior_blocks, int64_t n_interior,
+                                          const int32_t *boundary_blocks, int64_t n_boundary,
+                                          double *dot_out_dev, void *work, void *stream)
+{
+    return spmv_dist_dot_impl<int32_t>(spmv_split_i32, plan, comm, rowptr, colval_split, nzval, x, n_own,
+                                       y, nrows, nnz, index_base, interior_blocks, n_interior,
+                                       boundary_blocks, n_boundary, dot_out_dev, work, stream);
+}
+
+HPCLA_API int hpcla_spmv_dist_dot_f64_i64(hpcla_halo_plan_t *plan, hpcla_comm_t *comm,
+                                          const int64_t *rowptr, const int64_t *colval_split,
+                                          const double *nzval, const double *x, int64_t n_own,
+                                          double *y, int64_t nrows, int64_t nnz, int index_base,
+                                          const int32_t *interior_blocks, int64_t n_interior,
+                                          const int32_t *boundary_blocks, int64_t n_boundary,
+                                          double *dot_out_dev, void *work, void *stream)
+{
+    return spmv_dist_dot_impl<int64_t>(spmv_split_i64, plan, comm, rowptr, colval_split, nzval, x, n_own,
+                                       y, nrows, nnz, index_base, interior_blocks, n_interior,
+                                       boundary_blocks, n_boundary, dot_out_dev, work, stream);
 }
 
 HPCLA_API int hpcla_spmv_dist_f64_i32(hpcla_halo_plan_t *plan, const int32_t *rowptr,

@@ -59,13 +59,27 @@ __device__ __forceinline__ double gather_x(const double *__restrict__ x_own,
     return x_own[col];
 }
 
+// Fused x.y epilogue (CG's p.Ap): every workgroup leaves the
+// deterministic tree sum of x[r]*y[r] over its rows in dot_partial[row block]; hpcla_spmv_dot_finish
+// sums the partials in index order.  Valid when x is partitioned like A's rows (x_own[r] is x at row r).
+__device__ __forceinline__ void block_dot_epilogue(double *s_scratch, double *__restrict__ dot_partial,
+                                                   int64_t blk, double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) s_scratch[w] = v;       // s_prod is free: the chunk loop ended with a barrier
+    __syncthreads();
+    if (threadIdx.x == 0) dot_partial[blk] = ((s_scratch[0] + s_scratch[1]) + s_scratch[2]) + s_scratch[3];
+}
+
 // ---- primary kernel: aligned quads (needs colval 4*sizeof(I)- and nzval 32-byte aligned) -----------
 template <typename I, bool SPLIT>
 __global__ __launch_bounds__(RPB) void spmv_rowblock_quad_kernel(
     const I *__restrict__ rowptr, const I *__restrict__ colval, const double *__restrict__ nzval,
     const double *__restrict__ x_own, const double *__restrict__ x_ghost, int64_t n_own,
     double *__restrict__ y, int64_t nrows, int64_t nnz, int base,
-    const int32_t *__restrict__ block_list)
+    const int32_t *__restrict__ block_list, double *__restrict__ dot_partial)
 {
     __shared__ double s_prod[CHUNK];
 
@@ -156,6 +170,7 @@ __global__ __launch_bounds__(RPB) void spmv_rowblock_quad_kernel(
         __syncthreads();
     }
     if (tid < nr) y[r0 + tid] = acc;
+    if (dot_partial) block_dot_epilogue(s_prod, dot_partial, blk, tid < nr ? acc * x_own[r0 + tid] : 0.0);
 }
 
 // ---- fallback kernel: element-per-lane loads, no alignment requirement --------------------------------
@@ -163,7 +178,8 @@ template <typename I, bool SPLIT>
 __global__ __launch_bounds__(RPB) void spmv_rowblock_kernel(
     const I *__restrict__ rowptr, const I *__restrict__ colval, const double *__restrict__ nzval,
     const double *__restrict__ x_own, const double *__restrict__ x_ghost, int64_t n_own,
-    double *__restrict__ y, int64_t nrows, int base, const int32_t *__restrict__ block_list)
+    double *__restrict__ y, int64_t nrows, int base, const int32_t *__restrict__ block_list,
+    double *__restrict__ dot_partial)
 {
     __shared__ double s_prod[CHUNK];
 
@@ -211,6 +227,7 @@ __global__ __launch_bounds__(RPB) void spmv_rowblock_kernel(
         __syncthreads();
     }
     if (tid < nr) y[r0 + tid] = acc;
+    if (dot_partial) block_dot_epilogue(s_prod, dot_partial, blk, tid < nr ? acc * x_own[r0 + tid] : 0.0);
 }
 
 template <typename I>
@@ -266,7 +283,7 @@ template <typename I>
 static int spmv_launch(const I *rowptr, const I *colval, const double *nzval, const double *x_own,
                        const double *x_ghost, int64_t n_own, bool split, double *y, int64_t nrows,
                        int64_t nnz, int index_base, const int32_t *block_list, int64_t n_blocks,
-                       void *stream)
+                       void *stream, double *dot_partial = nullptr)
 {
     if (nrows < 0 || nnz < 0) return set_error(HPCLA_ERR_INVALID, "spmv: negative size");
     if (index_base != 0 && index_base != 1)
@@ -294,17 +311,20 @@ static int spmv_launch(const I *rowptr, const I *colval, const double *nzval, co
     if (aligned) {
         if (split)
             spmv_rowblock_quad_kernel<I, true><<<grid, block, 0, s>>>(
-                rowptr, colval, nzval, x_own, x_ghost, n_own, y, nrows, nnz, index_base, block_list);
+                rowptr, colval, nzval, x_own, x_ghost, n_own, y, nrows, nnz, index_base, block_list,
+                dot_partial);
         else
             spmv_rowblock_quad_kernel<I, false><<<grid, block, 0, s>>>(
-                rowptr, colval, nzval, x_own, nullptr, 0, y, nrows, nnz, index_base, block_list);
+                rowptr, colval, nzval, x_own, nullptr, 0, y, nrows, nnz, index_base, block_list,
+                dot_partial);
     } else {
         if (split)
             spmv_rowblock_kernel<I, true><<<grid, block, 0, s>>>(
-                rowptr, colval, nzval, x_own, x_ghost, n_own, y, nrows, index_base, block_list);
+                rowptr, colval, nzval, x_own, x_ghost, n_own, y, nrows, index_base, block_list,
+                dot_partial);
         else
             spmv_rowblock_kernel<I, false><<<grid, block, 0, s>>>(
-                rowptr, colval, nzval, x_own, nullptr, 0, y, nrows, index_base, block_list);
+                rowptr, colval, nzval, x_own, nullptr, 0, y, nrows, index_base, block_list, dot_partial);
     }
     HPCLA_CHECK_LAUNCH();
     return HPCLA_OK;
@@ -314,18 +334,18 @@ static int spmv_launch(const I *rowptr, const I *colval, const double *nzval, co
 int spmv_split_i32(const int32_t *rowptr, const int32_t *colval, const double *nzval,
                    const double *x_own, const double *x_ghost, int64_t n_own, double *y,
                    int64_t nrows, int64_t nnz, int index_base, const int32_t *bl, int64_t nb,
-                   void *stream)
+                   void *stream, double *dot_partial)
 {
     return spmv_launch<int32_t>(rowptr, colval, nzval, x_own, x_ghost, n_own, true, y, nrows, nnz,
-                                index_base, bl, nb, stream);
+                                index_base, bl, nb, stream, dot_partial);
 }
 int spmv_split_i64(const int64_t *rowptr, const int64_t *colval, const double *nzval,
                    const double *x_own, const double *x_ghost, int64_t n_own, double *y,
                    int64_t nrows, int64_t nnz, int index_base, const int32_t *bl, int64_t nb,
-                   void *stream)
+                   void *stream, double *dot_partial)
 {
     return spmv_launch<int64_t>(rowptr, colval, nzval, x_own, x_ghost, n_own, true, y, nrows, nnz,
-                                index_base, bl, nb, stream);
+                                index_base, bl, nb, stream, dot_partial);
 }
 
 }  // namespace hpcla
@@ -357,7 +377,7 @@ HPCLA_API int hpcla_spmv_split_f64_i32(const int32_t *rowptr, const int32_t *col
                                        const int32_t *block_list, int64_t n_blocks, void *stream)
 {
     return spmv_split_i32(rowptr, colval_split, nzval, x_own, x_ghost, n_own, y, nrows, nnz,
-                          index_base, block_list, n_blocks, stream);
+                          index_base, block_list, n_blocks, stream, nullptr);
 }
 
 HPCLA_API int hpcla_spmv_split_f64_i64(const int64_t *rowptr, const int64_t *colval_split,
@@ -367,7 +387,7 @@ HPCLA_API int hpcla_spmv_split_f64_i64(const int64_t *rowptr, const int64_t *col
                                        const int32_t *block_list, int64_t n_blocks, void *stream)
 {
     return spmv_split_i64(rowptr, colval_split, nzval, x_own, x_ghost, n_own, y, nrows, nnz,
-                          index_base, block_list, n_blocks, stream);
+                          index_base, block_list, n_blocks, stream, nullptr);
 }
 
 template <typename I>

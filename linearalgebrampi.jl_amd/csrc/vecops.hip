@@ -13,13 +13,14 @@ namespace hpcla {
 constexpr int RT = 256;            // threads per reduction block
 constexpr int MAX_PARTIALS = 2048; // upper bound of stage-1 blocks
 
-enum RedOp { RED_DOT = 0, RED_SQ = 1, RED_ABS = 2, RED_MAX = 3 };
+enum RedOp { RED_DOT = 0, RED_SQ = 1, RED_ABS = 2, RED_MAX = 3, RED_SUM = 4 };
 
 template <int OP>
 __device__ __forceinline__ double red_map(double a, double b)
 {
     if (OP == RED_DOT) return a * b;
     if (OP == RED_SQ) return a * a;
+    if (OP == RED_SUM) return a;
     return fabs(a);
 }
 template <int OP>
@@ -111,6 +112,67 @@ static int reduce_impl(hpcla_comm_t *comm, const double *x, const double *y, int
     HPCLA_CHECK_LAUNCH();
     if (comm) return allreduce_on(comm, out_dev, 1, OP == RED_MAX ? 1 : 0, stream);
     return HPCLA_OK;
+}
+
+// sum `np` per-workgroup partials (deterministic two-stage tree) into out[0]; `scratch` holds
+// MAX_PARTIALS doubles.  Used by the fused SpMV+dot (spmv.hip) and the fused CG update.
+int reduce_partials_sum(const double *partial, int64_t np, double *scratch, double *out, void *stream)
+{
+    if (np < 0) return set_error(HPCLA_ERR_INVALID, "reduce_partials: bad count");
+    hipStream_t s = as_stream(stream);
+    if (np <= 4 * RT) {
+        reduce_stage2<RED_SUM><<<1, RT, 0, s>>>(partial, (int)np, out);
+    } else {
+        const int g = reduce_grid(np);
+        reduce_stage1<RED_SUM><<<g, RT, 0, s>>>(partial, nullptr, np, scratch);
+        HPCLA_CHECK_LAUNCH();
+        reduce_stage2<RED_SUM><<<1, RT, 0, s>>>(scratch, g, out);
+    }
+    HPCLA_CHECK_LAUNCH();
+    return HPCLA_OK;
+}
+
+// fused CG update (replaces two broadcasts + one norm of src/vectors.jl:1203-1226, 758-765):
+//   a = alpha * *num / *den ;  x += a*p ;  r -= a*Ap ;  partial[block] = sum r_new^2
+__global__ __launch_bounds__(RT) void cg_update_kernel(double alpha, const double *__restrict__ num,
+                                                       const double *__restrict__ den,
+                                                       const double *__restrict__ p,
+                                                       const double *__restrict__ Ap,
+                                                       double *__restrict__ x, double *__restrict__ r,
+                                                       int64_t n, double *__restrict__ partial)
+{
+    double a = alpha;
+    if (num) a = a * num[0];
+    if (den) a = a / den[0];
+    const int64_t n2 = n / 2;
+    const double2 *p2 = reinterpret_cast<const double2 *>(p);
+    const double2 *q2 = reinterpret_cast<const double2 *>(Ap);
+    double2 *x2 = reinterpret_cast<double2 *>(x);
+    double2 *r2 = reinterpret_cast<double2 *>(r);
+    double acc = 0.0;
+    int64_t i = (int64_t)blockIdx.x * RT + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * RT;
+    for (; i < n2; i += stride) {
+        const double2 pv = p2[i], qv = q2[i];
+        double2 xv = x2[i], rv = r2[i];
+        xv.x = xv.x + a * pv.x;
+        xv.y = xv.y + a * pv.y;
+        rv.x = rv.x - a * qv.x;
+        rv.y = rv.y - a * qv.y;
+        x2[i] = xv;
+        r2[i] = rv;
+        acc = acc + rv.x * rv.x;
+        acc = acc + rv.y * rv.y;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const int64_t j = n - 1;
+        x[j] = x[j] + a * p[j];
+        const double rn = r[j] - a * Ap[j];
+        r[j] = rn;
+        acc = acc + rn * rn;
+    }
+    const double s = block_reduce<RED_SUM>(acc);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
 
 __device__ __forceinline__ double dev_scalar(double alpha, const double *num, const double *den)
@@ -255,6 +317,26 @@ HPCLA_API int hpcla_axpby_f64(double a, const double *x, double b, const double 
     if (!x || !y || !z) return set_error(HPCLA_ERR_INVALID, "axpby: null pointer");
     axpby_kernel<<<ew_grid(n), 256, 0, as_stream(stream)>>>(a, x, b, y, z, n);
     HPCLA_CHECK_LAUNCH();
+    return HPCLA_OK;
+}
+
+HPCLA_API int hpcla_cg_update_f64(hpcla_comm_t *comm, double alpha_host, const double *num_dev,
+                                  const double *den_dev, const double *p, const double *Ap, double *x,
+                                  double *r, int64_t n, double *rr_out_dev, void *work, void *stream)
+{
+    if (n < 0) return set_error(HPCLA_ERR_INVALID, "cg_update: negative size");
+    if (!rr_out_dev || !work) return set_error(HPCLA_ERR_INVALID, "cg_update: null out/work");
+    if (n > 0 && (!p || !Ap || !x || !r)) return set_error(HPCLA_ERR_INVALID, "cg_update: null vector");
+    if ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(Ap) | reinterpret_cast<uintptr_t>(x) |
+         reinterpret_cast<uintptr_t>(r)) & 15)
+        return set_error(HPCLA_ERR_INVALID, "cg_update: vectors must be 16-byte aligned");
+    double *partial = reinterpret_cast<double *>(work);
+    const int g = reduce_grid(n);
+    cg_update_kernel<<<g, RT, 0, as_stream(stream)>>>(alpha_host, num_dev, den_dev, p, Ap, x, r, n, partial);
+    HPCLA_CHECK_LAUNCH();
+    reduce_stage2<RED_SUM><<<1, RT, 0, as_stream(stream)>>>(partial, g, rr_out_dev);
+    HPCLA_CHECK_LAUNCH();
+    if (comm) return allreduce_on(comm, rr_out_dev, 1, 0, stream);
     return HPCLA_OK;
 }
 

@@ -324,6 +324,28 @@ def mul_(y: HPCVector, A: HPCSparseMatrix, x: HPCVector) -> HPCVector:
     return y
 
 
+def mul_dot_(y: HPCVector, A: HPCSparseMatrix, x: HPCVector, out) -> HPCVector:
+    """Fused ``mul!(y, A, x)`` and ``out = dot(x, y)`` (CG's p.Ap) in one pass over A: the SpMV
+    epilogue leaves per-row-block partial sums that are reduced deterministically and all-reduced;
+    the scalar stays in the 1-element device tensor ``out``.  Requires x partitioned like A's rows."""
+    assert_backends_compatible(A.backend, x.backend)
+    assert_backends_compatible(A.backend, y.backend)
+    plan = get_vector_plan(A, x)
+    if y.structural_hash != plan.result_partition_hash or x.structural_hash != plan.result_partition_hash:
+        raise ValueError("mul_dot_: x and y must have A's row partition")
+    torch = _torch()
+    work = getattr(plan, "_dot_work", None)
+    if work is None:
+        nbytes = _capi.load().hpcla_spmv_dot_work_bytes(A.nrows_local)
+        work = plan._dot_work = torch.empty(nbytes // 8 + 1, dtype=torch.float64, device=x.v.device)
+    sfx = "i64" if plan.is_i64 else "i32"
+    _capi.call(f"hpcla_spmv_dist_dot_f64_{sfx}", plan.halo if plan.has_halo else None, A.backend.rccl,
+               dptr(A.rowptr_target), dptr(plan.colval_split), dptr(A.nzval), dptr(x.v), plan.n_own,
+               dptr(y.v), A.nrows_local, A.nnz, 0, dptr(plan.interior), plan.n_interior,
+               dptr(plan.boundary), plan.n_boundary, dptr(out), dptr(work), current_stream_ptr())
+    return y
+
+
 def _compress_columns(colidx_global: np.ndarray, ncols_global: int, Ti) -> Tuple[np.ndarray, np.ndarray]:
     """``col_indices = unique!(sort(copy(rowval)))`` + ``compress_AT`` (src/sparse.jl:501-509,
     137-144).  Same result via a presence bitmap (O(nnz + ncols) instead of a sort and a binary

@@ -477,6 +477,54 @@ def test_spmv_int64_moderate_scale(hp, orc, gpu_backend_i64):
     np.testing.assert_array_equal(y, want)
 
 
+def test_fused_spmv_dot_and_cg_update(hp, orc, gpu_backend_i32):
+    """mul_dot_ (SpMV with the x.y partials in its epilogue) and cg_update_ vs the oracle."""
+    import torch
+    b = gpu_backend_i32
+    for N in (37, 64, 200):
+        rows = orc.poisson3d_rows(N, N, 3, 0, N * N * 3)
+        n = rows.nrows
+        A = hp.HPCSparseMatrix_local(rows.rowptr, rows.colidx, rows.vals, n, b)
+        xg = orc.fill_uniform(0, n, 5) - 0.5
+        x = hp.HPCVector.from_global(xg, b)
+        y = hp.HPCVector.zeros(A.row_partition, b)
+        out = torch.zeros(1, dtype=torch.float64, device="cuda")
+        hp.mul_dot_(y, A, x, out)
+        want_y = orc.spmv(rows.rowptr.astype(np.int32), rows.colidx.astype(np.int32), rows.vals, xg)
+        np.testing.assert_array_equal(y.local_values(), want_y)          # y still bit-exact
+        want_d = orc.dot([xg], [want_y])
+        assert abs(out.item() - want_d) <= RTOL_RED * float(np.abs(xg) @ np.abs(want_y))
+        out2 = torch.zeros(1, dtype=torch.float64, device="cuda")
+        hp.mul_dot_(y, A, x, out2)
+        assert out.item() == out2.item()                                  # deterministic
+        # cg_update_: x += s p ; r -= s Ap ; rr = sum r^2 with s = a*num/den from device scalars
+        pg, apg = orc.fill_uniform(0, n, 6), orc.fill_uniform(0, n, 7)
+        xx, rrv = orc.fill_uniform(0, n, 8), orc.fill_uniform(0, n, 9)
+        num = torch.tensor([0.75], dtype=torch.float64, device="cuda")
+        den = torch.tensor([1.5], dtype=torch.float64, device="cuda")
+        s = 1.0 * 0.75 / 1.5
+        X, R = hp.HPCVector.from_global(xx, b), hp.HPCVector.from_global(rrv, b)
+        P, AP = hp.HPCVector.from_global(pg, b), hp.HPCVector.from_global(apg, b)
+        rr = torch.zeros(1, dtype=torch.float64, device="cuda")
+        hp.cg_update_(X, R, P, AP, 1.0, num, den, rr)
+        wx = xx.copy(); orc.axpy(s, pg, wx)
+        wr = rrv.copy(); orc.axpy(-s, apg, wr)
+        np.testing.assert_array_equal(X.local_values(), wx)
+        np.testing.assert_array_equal(R.local_values(), wr)
+        assert abs(rr.item() - orc.dot([wr], [wr])) <= RTOL_RED * orc.dot([wr], [wr])
+
+
+def test_cg_fused_equals_unfused(hp, orc, gpu_backend_i32):
+    N = 20
+    rows = orc.poisson3d_rows(N, N, N, 0, N ** 3)
+    A = hp.HPCSparseMatrix_local(rows.rowptr, rows.colidx, rows.vals, N ** 3, gpu_backend_i32)
+    b = hp.HPCVector.from_global(orc.fill_uniform(0, N ** 3, orc.SEED_RHS), gpu_backend_i32)
+    x1, h1 = hp.cg_fixed_iterations(A, b, 30, fused=True)
+    x2, h2 = hp.cg_fixed_iterations(A, b, 30, fused=False)
+    np.testing.assert_allclose(h1, h2, rtol=1e-9)
+    np.testing.assert_allclose(x1.local_values(), x2.local_values(), rtol=0, atol=1e-9)
+
+
 def test_graft_entry_smoke():
     import __graft_entry__ as g
     g.smoke()
