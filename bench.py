@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="poisson2d", choices=["poisson2d", "poisson3d_cg", "sprand_spmm"])
+    ap.add_argument("--workload", default="poisson2d", choices=["poisson2d", "poisson2d_strong", "poisson3d_cg", "sprand_spmm"])
     ap.add_argument("--size", type=int, default=0, help="grid edge N (default: 4096 for poisson2d)")
     ap.add_argument("--index", default="i32", choices=["i32", "i64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -121,16 +121,23 @@ def main():
     else:
         backend = hp.backend_rocm_serial(np.float64, Ti, device_index=torch.cuda.current_device())
 
-    if args.workload != "poisson2d":
+    if args.workload not in ("poisson2d", "poisson2d_strong"):
         from benchmarks import extra_workloads          # configs 4/5: separate harness
         return extra_workloads.run(args, backend, rank, world)
 
     # ---- build the workload ------------------------------------------------------------------------
-    N = args.size or 4096
-    nx, ny_loc = N, N
-    ny = ny_loc * world
+    strong = args.workload == "poisson2d_strong"      # BASELINE configs[2]: fixed 8192^2 grid over N GPUs
+    N = args.size or (8192 if strong else 4096)
+    if strong:
+        nx, ny = N, N
+        ny_loc = (N + world - 1) // world
+        part0 = hp.uniform_partition(nx * ny, world)
+        lo, hi = int(part0[rank]), int(part0[rank + 1])
+    else:
+        nx, ny_loc = N, N
+        ny = ny_loc * world
+        lo, hi = rank * nx * ny_loc, (rank + 1) * nx * ny_loc
     n_glob = nx * ny
-    lo, hi = rank * nx * ny_loc, (rank + 1) * nx * ny_loc
     t0 = time.perf_counter()
     rowptr, colidx, vals = wl.poisson2d_rows(nx, ny, lo, hi)
     A = hp.HPCSparseMatrix_local(rowptr, colidx, vals, n_glob, backend)
@@ -230,7 +237,7 @@ def main():
         "metric": "SpMV GFLOP/s (2*nnz/t), 2-D 5-pt Poisson, fp64",
         "value": round(gflops, 2), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"poisson2d 5-pt, {nx}x{ny_loc} slab per GPU ({nx}x{ny} global), "
                                f"n={n_glob}, nnz={nnz_tot}, index={args.index}, CSR SpMV y=A*x",
                    "global_rows": n_glob, "nnz": nnz_tot, "index_type": args.index,

@@ -17,7 +17,7 @@ The directory name contains a dot, so it is imported through the top-level alias
 from . import _capi
 from .backends import (AbstractComm, AbstractDevice, CommSerial, CommTorch, DeviceROCm, HPCBackend,
                        SolverNone, assert_backends_compatible, backend_rocm_mpi,
-                       backend_rocm_serial, backends_compatible, comm_rank, comm_size,
+                       backend_rocm_serial, backends_compatible, comm_exchange_arrays, comm_rank, comm_size,
                        eltype_backend, indextype_backend)
 from .partition import (compute_partition_hash, compute_structural_hash, owner_of,
                         uniform_partition)
@@ -27,5 +27,6 @@ from .sparse import (HPCSparseMatrix, HPCSparseMatrix_from_global, HPCSparseMatr
                      clear_plan_cache, execute_plan, get_vector_plan, mul_, mul_dot_, split_column_map)
 from .dense import HPCMatrix, HPCMatrix_local, clear_spmm_cache, spmm
 from .cg import cg_fixed_iterations
+from .transpose import TransposedHPCSparseMatrix, transpose, transpose_local_rows
 
 __all__ = [n for n in dir() if not n.startswith("_")] + ["_capi"]

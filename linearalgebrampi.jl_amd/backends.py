@@ -194,6 +194,32 @@ def comm_exchange_indices(comm: AbstractComm, send_to: Sequence[int], send_array
     return [b.cpu().numpy() for b in recv_bufs]
 
 
+def comm_exchange_arrays(comm: AbstractComm, send_to: Sequence[int], send_arrays: Sequence[np.ndarray],
+                         recv_from: Sequence[int], recv_counts: Sequence[int], dtype) -> List[np.ndarray]:
+    """Isend/Irecv/Waitall of int64 or float64 arrays (the p2p pattern of src/sparse.jl:1908-1936,
+    also used by the TransposePlan redistribution)."""
+    if isinstance(comm, CommSerial):
+        assert len(send_to) == 0 and len(recv_from) == 0
+        return []
+    import torch
+    dist = _dist()
+    dev = _host_device(comm)
+    tdt = torch.int64 if np.dtype(dtype) == np.dtype(np.int64) else torch.float64
+    ops, keep, recv_bufs = [], [], []
+    for r, cnt in zip(recv_from, recv_counts):
+        buf = torch.empty(int(cnt), dtype=tdt, device=dev)
+        recv_bufs.append(buf)
+        ops.append(dist.P2POp(dist.irecv, buf, _global_rank(comm, r), group=comm.group))
+    for r, arr in zip(send_to, send_arrays):
+        t = torch.from_numpy(np.ascontiguousarray(arr, dtype=dtype)).to(dev)
+        keep.append(t)
+        ops.append(dist.P2POp(dist.isend, t, _global_rank(comm, r), group=comm.group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return [b.cpu().numpy() for b in recv_bufs]
+
+
 def _global_rank(comm: "CommTorch", group_rank: int) -> int:
     dist = _dist()
     if comm.group is None:

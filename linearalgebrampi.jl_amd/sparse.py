@@ -256,6 +256,7 @@ class HPCSparseMatrix:
         self.nzval = nzval_dev
         self.rowptr_target = rowptr_dev
         self._colval_target = None
+        self.cached_transpose = None                     # src/sparse.jl:331, filled by transpose()
         self.nrows_local = len(rowptr) - 1
         self.ncols_compressed = len(self.col_indices)
         self.backend = backend
@@ -269,6 +270,16 @@ class HPCSparseMatrix:
     @property
     def shape(self) -> Tuple[int, int]:                  # src/sparse.jl:2151-2155
         return int(self.row_partition[-1]), int(self.col_partition[-1])
+
+    def transpose(self):
+        """Lazy ``transpose(A)`` (src/sparse.jl:2254-2258); ``transpose(A) @ x`` materialises and
+        caches A^T (linearalgebrampi.jl_amd/transpose.py)."""
+        from .transpose import TransposedHPCSparseMatrix
+        return TransposedHPCSparseMatrix(self)
+
+    @property
+    def T_(self):
+        return self.transpose()
 
     def colval_target(self):
         if self._colval_target is None:

@@ -85,6 +85,22 @@ def main():
         allh = B.comm_allgather_bytes(comm, hsh)
         assert all(h == hsh for h in allh)
 
+    # TransposePlan redistribution (src/sparse.jl:1519-1865): rows of A^T land on the owner of the
+    # column in col_partition, ascending (row, col); compare with scipy's global transpose
+    import scipy.sparse as sp
+    m, ncol = 230, 170
+    glob = orc.sprand_rows(ncol, 0.03, 0, m)
+    Ag = sp.csr_matrix((glob.vals, glob.colidx, glob.rowptr), shape=(m, ncol))
+    rp, cp = orc.uniform_partition(m, nranks), orc.uniform_partition(ncol, nranks)
+    loc = Ag[rp[rank]:rp[rank + 1], :]
+    trp, tci, tv = hp.transpose_local_rows(loc.indptr, loc.indices, loc.data, rp, cp, comm)
+    AT = Ag.T.tocsr()
+    AT.sort_indices()
+    want = AT[cp[rank]:cp[rank + 1], :]
+    np.testing.assert_array_equal(trp, want.indptr)
+    np.testing.assert_array_equal(tci, want.indices)
+    np.testing.assert_array_equal(tv, want.data)
+
     dist.barrier()
     dist.destroy_process_group()
     print(f"rank {rank}: OK")

@@ -525,6 +525,35 @@ def test_cg_fused_equals_unfused(hp, orc, gpu_backend_i32):
     np.testing.assert_allclose(x1.local_values(), x2.local_values(), rtol=0, atol=1e-9)
 
 
+def test_transpose_times_vector(hp, orc, gpu_backend_i32):
+    """transpose(A) * x (test/test_new_operations.jl:73-76; src/sparse.jl:2375-2379): materialised,
+    cached bidirectionally, result bit-identical to the row-sequential product with the explicit A^T."""
+    import scipy.sparse as sp
+    m, n = 700, 450
+    rows = orc.sprand_rows(n, 0.02, 0, m)
+    A = hp.HPCSparseMatrix_local(rows.rowptr, rows.colidx, rows.vals, n, gpu_backend_i32)
+    xg = orc.fill_uniform(0, m, 12)
+    x = hp.HPCVector.from_global(xg, gpu_backend_i32)
+    At = hp.transpose(A)
+    assert At.shape == (n, m)
+    y = (At @ x).local_values()
+    AT = sp.csr_matrix((rows.vals, rows.colidx, rows.rowptr), shape=(m, n)).T.tocsr()
+    AT.sort_indices()
+    want = orc.spmv(AT.indptr.astype(np.int32), AT.indices.astype(np.int32), AT.data, xg)
+    np.testing.assert_array_equal(y, want)
+    Y = At.materialize()
+    assert Y is A.cached_transpose and Y.cached_transpose is A and A.transpose().materialize() is Y
+    np.testing.assert_array_equal(Y.row_partition, A.col_partition)
+    # golden: S + S' + 2I is symmetric -> transpose(A)*x == A*x (test/test_new_operations.jl:43-50)
+    # and (A^T)^T == A structurally
+    Z = hp.TransposedHPCSparseMatrix(Y)
+    Z.parent.cached_transpose = None
+    back = Z.materialize()
+    np.testing.assert_array_equal(back.rowptr, A.rowptr)
+    np.testing.assert_array_equal(back.col_indices[back.colval], A.col_indices[A.colval])
+    np.testing.assert_array_equal(back.nzval.cpu().numpy(), A.nzval.cpu().numpy())
+
+
 def test_graft_entry_smoke():
     import __graft_entry__ as g
     g.smoke()
