@@ -42,6 +42,14 @@ def parse():
     return ap.parse_args()
 
 
+def _device_barrier(torch, dist):
+    """Barrier through the device collective path (a 1-element all-reduce on the NCCL/RCCL group):
+    unambiguous for mixed gloo+nccl process groups."""
+    t = torch.zeros(1, device="cuda")
+    dist.all_reduce(t)
+    torch.cuda.synchronize()
+
+
 def usable_cores() -> int:
     """Host threads this process may actually run: the affinity mask capped by the cgroup CPU quota
     (the GPU box exposes every host core in the mask but grants a 16-core share per GPU), or
@@ -116,7 +124,7 @@ def main():
     Ti = np.int32 if args.index == "i32" else np.int64
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("cpu:gloo,cuda:nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
+        dist.init_process_group("cpu:gloo,cuda:nccl")
         backend = hp.backend_rocm_mpi(np.float64, Ti)
     else:
         backend = hp.backend_rocm_serial(np.float64, Ti, device_index=torch.cuda.current_device())
@@ -155,7 +163,7 @@ def main():
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            _device_barrier(torch, dist)
         torch.cuda.synchronize()
 
     # ---- verification of this rank's result on sampled rows (incl. halo-adjacent rows) -----------------
@@ -262,7 +270,7 @@ def main():
             xfull = xg
         result["cpu_baseline"] = cpu_baseline_spmv(A.rowptr, A.colval, vals, xfull, args.cpu_seconds)
     if world > 1:
-        dist.barrier()
+        _device_barrier(torch, dist)
     if rank == 0:
         print(json.dumps(result), flush=True)
     hp.clear_plan_cache()

@@ -16,10 +16,16 @@ import numpy as np
 HBM_PEAK_GBS = 8000.0
 
 
+def _device_barrier(torch, dist):
+    t = torch.zeros(1, device="cuda")
+    dist.all_reduce(t)
+    torch.cuda.synchronize()
+
+
 def _sync_barrier(torch, dist, world):
     torch.cuda.synchronize()
     if world > 1:
-        dist.barrier()
+        _device_barrier(torch, dist)
     torch.cuda.synchronize()
 
 
@@ -128,7 +134,7 @@ def run(args, backend, rank, world):
             "setup_s": round(setup_s, 2),
         }
     if world > 1:
-        dist.barrier()
+        _device_barrier(torch, dist)
     if rank == 0:
         print(json.dumps(out), flush=True)
     hp.clear_plan_cache()

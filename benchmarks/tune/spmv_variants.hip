@@ -165,6 +165,86 @@ __global__ __launch_bounds__(TPB) void k_wide(const int *__restrict__ rowptr,
     }
 }
 
+// ---- wide kernel + compact per-block pointer array (16 block starts per 64-byte line)
+// ---- wide kernel: 16-byte loads (4 entries per lane per load), aligned to 4 entries ----------------
+template <int TPB, int RPT, int U, bool NT, bool XCD>
+__global__ __launch_bounds__(TPB) void k_wide_bptr(const int *__restrict__ rowptr,
+                                              const int *__restrict__ colval,
+                                              const double *__restrict__ nzval,
+                                              const double *__restrict__ x, double *__restrict__ y,
+                                              int64_t nrows, int64_t nnz, uint32_t nblocks, const int *__restrict__ bptr)
+{
+    constexpr int R = TPB * RPT;
+    constexpr int CHUNK = TPB * 4 * U;
+    __shared__ double s_prod[CHUNK];
+    const int tid = threadIdx.x;
+    const uint32_t b = XCD ? xcd_slice_index(blockIdx.x, nblocks) : blockIdx.x;
+    const int64_t r0 = (int64_t)b * R;
+    const int nr = (int)((nrows - r0) < R ? (nrows - r0) : R);
+    const int64_t p0 = bptr[b], p1 = bptr[b + 1];
+    const int64_t pa = p0 & ~(int64_t)3;
+    const int64_t total = p1 - pa;
+    int lo[RPT], hi[RPT];
+    double acc[RPT];
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+        const int r = tid + q * TPB;
+        lo[q] = hi[q] = 0;
+        acc[q] = 0.0;
+        if (r < nr) { lo[q] = (int)(rowptr[r0 + r] - pa); hi[q] = (int)(rowptr[r0 + r + 1] - pa); }
+    }
+    for (int64_t c = 0; c < total; c += CHUNK) {
+        const int n = (int)((total - c) < CHUNK ? (total - c) : CHUNK);
+        v4i col[U];
+        v2d va[U], vb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e0 = (u * TPB + tid) * 4;
+            const int64_t g = pa + c + e0;
+            col[u] = (v4i)(0);
+            va[u] = (v2d)(0.0);
+            vb[u] = (v2d)(0.0);
+            if (e0 < n) {
+                if (g + 3 < nnz) {
+                    col[u] = ld<v4i, NT>(reinterpret_cast<const v4i *>(colval + g));
+                    va[u] = ld<v2d, NT>(reinterpret_cast<const v2d *>(nzval + g));
+                    vb[u] = ld<v2d, NT>(reinterpret_cast<const v2d *>(nzval + g + 2));
+                } else {
+                    if (g + 0 < nnz) { col[u].x = colval[g + 0]; va[u].x = nzval[g + 0]; }
+                    if (g + 1 < nnz) { col[u].y = colval[g + 1]; va[u].y = nzval[g + 1]; }
+                    if (g + 2 < nnz) { col[u].z = colval[g + 2]; vb[u].x = nzval[g + 2]; }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e0 = (u * TPB + tid) * 4;
+            if (e0 < n) {
+                double2 pa2, pb2;
+                pa2.x = va[u].x * x[col[u].x];
+                pa2.y = va[u].y * x[col[u].y];
+                pb2.x = vb[u].x * x[col[u].z];
+                pb2.y = vb[u].y * x[col[u].w];
+                *reinterpret_cast<double2 *>(&s_prod[e0]) = pa2;
+                *reinterpret_cast<double2 *>(&s_prod[e0 + 2]) = pb2;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const int a = lo[q] > c ? lo[q] : (int)c;
+            const int e = hi[q] < c + n ? hi[q] : (int)(c + n);
+            for (int j = a; j < e; ++j) acc[q] += s_prod[j - c];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+        const int r = tid + q * TPB;
+        if (r < nr) y[r0 + r] = acc[q];
+    }
+}
+
 // ---- pure stream: read the three arrays + write y with 16-byte accesses (ceiling for this byte mix)
 __global__ __launch_bounds__(256) void k_copy(const v4i *__restrict__ colval4,
                                               const v2d *__restrict__ nz2,
@@ -623,7 +703,7 @@ __global__ __launch_bounds__(256) void k_wave(const int *__restrict__ rowptr,
 
 extern "C" __attribute__((visibility("default"))) int hpcla_tune_spmv(
     int variant, const int *rowptr, const int *colval, const double *nzval, const double *x, double *y,
-    int64_t nrows, int64_t nnz, void *stream)
+    int64_t nrows, int64_t nnz, void *stream, const int *bptr)
 {
     hipStream_t s = (hipStream_t)stream;
 #define NARROW(TPB, RPT, UN, NT, XCD, ABL)                                                        \
@@ -701,6 +781,10 @@ extern "C" __attribute__((visibility("default"))) int hpcla_tune_spmv(
         case 64: WAVE(4, 3) break;
         case 65: WAVE(1, 1) break;
         case 66: WAVE(2, 4) break;
+        case 70: {
+            uint32_t nb = (uint32_t)((nrows + 255) / 256);
+            k_wide_bptr<256, 1, 2, false, false><<<nb, 256, 0, s>>>(rowptr, colval, nzval, x, y, nrows, nnz, nb, bptr);
+        } break;
         case 20:
             k_copy<<<256 * 16, 256, 0, s>>>((const v4i *)colval, (const v2d *)nzval, (const v4i *)rowptr,
                                             (double2 *)y, (const double2 *)x, nnz, nrows);

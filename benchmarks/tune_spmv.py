@@ -40,7 +40,7 @@ def main():
     import hpcla_amd as hp
     from hpcla_amd import workloads as wl
     tune = ctypes.CDLL(so)
-    tune.hpcla_tune_spmv.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
+    tune.hpcla_tune_spmv.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
     backend = hp.backend_rocm_serial(np.float64, np.int32)
     N = args.size
     if args.dim == 2:
@@ -58,6 +58,7 @@ def main():
     variants = [int(v) for v in args.variants.split(",")]
     y = torch.empty_like(y_ref)
     ghost = torch.zeros(16, dtype=torch.float64, device="cuda")
+    bptr = torch.cat([A.rowptr_target[::256], A.rowptr_target[-1:]]).contiguous()
     yvec = hp.HPCVector.zeros(A.row_partition, backend)
     plan = hp.get_vector_plan(A, x)
 
@@ -77,7 +78,7 @@ def main():
                                                            x.v.data_ptr(), ghost.data_ptr(), n, y.data_ptr(), n, nnz, 0,
                                                            None, 0, s)
         return tune.hpcla_tune_spmv(v, A.rowptr_target.data_ptr(), cv.data_ptr(), A.nzval.data_ptr(), x.v.data_ptr(),
-                                    y.data_ptr(), n, nnz, s)
+                                    y.data_ptr(), n, nnz, s, bptr.data_ptr())
     times = {v: [] for v in variants}
     exact = {}
     for v in variants:                       # correctness + warm-up

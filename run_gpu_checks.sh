@@ -28,6 +28,15 @@ for st in $STEPS; do
     cg)     run 900 gpurun_out/${TAG}_cg.log python bench.py --workload poisson3d_cg --steps 100 --warmup 10; tail -2 gpurun_out/${TAG}_cg.log;;
     cgsmall) run 900 gpurun_out/${TAG}_cgsmall.log python bench.py --workload poisson3d_cg --size 256 --steps 100 --warmup 10; tail -2 gpurun_out/${TAG}_cgsmall.log;;
     spmm)   run 900 gpurun_out/${TAG}_spmm.log python bench.py --workload sprand_spmm --steps 20 --warmup 3; tail -2 gpurun_out/${TAG}_spmm.log;;
+    pmc_sq)
+      run 600 gpurun_out/${TAG}_pmc_sq.log rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d gpurun_out/${TAG}_pmc_sq -- python3 benchmarks/tune_spmv.py --variants 100,5,20,0 --rounds 1 --reps 2
+      tail -2 gpurun_out/${TAG}_pmc_sq.log;;
+    pmc_tcc)
+      run 600 gpurun_out/${TAG}_pmc_tcc.log rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum --output-format csv -d gpurun_out/${TAG}_pmc_tcc -- python3 benchmarks/tune_spmv.py --variants 100,5,20,0 --rounds 1 --reps 2
+      tail -2 gpurun_out/${TAG}_pmc_tcc.log;;
+    pmc_sq2)
+      run 600 gpurun_out/${TAG}_pmc_sq2.log rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/${TAG}_pmc_sq2 -- python3 benchmarks/tune_spmv.py --variants 100,5,20,0 --rounds 1 --reps 2
+      tail -2 gpurun_out/${TAG}_pmc_sq2.log;;
     pmc_tune_rd)
       run 600 gpurun_out/${TAG}_pmc_tune_rd.log rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/${TAG}_pmc_tune_rd -- python3 benchmarks/tune_spmv.py --variants 20,100,101 --rounds 1 --reps 3
       tail -2 gpurun_out/${TAG}_pmc_tune_rd.log;;
