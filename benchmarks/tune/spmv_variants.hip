@@ -701,9 +701,91 @@ __global__ __launch_bounds__(256) void k_wave(const int *__restrict__ rowptr,
     }
 }
 
+// ---- packed prototype: 16-bit block-relative columns + 8-bit value codes (dictionary in LDS) ----------
+// Same row-block stream structure; a lane handles one aligned octet (8 entries): 16 B of columns +
+// 8 B of codes instead of 96 B.  Products are dict[code] * x[r0 + dcol] -- identical values, so the
+// result is bit-identical to the plain CSR kernel.
+typedef short v8s __attribute__((ext_vector_type(8)));
+template <int OCT>   // octets per lane per pass
+__global__ __launch_bounds__(256) void k_packed(const int *__restrict__ rowptr,
+                                                const short *__restrict__ dcol,
+                                                const unsigned char *__restrict__ code,
+                                                const double *__restrict__ dict, int ndict,
+                                                const double *__restrict__ x, double *__restrict__ y,
+                                                int64_t nrows, int64_t nnz)
+{
+    constexpr int CHUNK = 256 * 8 * OCT;
+    __shared__ double s_prod[CHUNK];
+    __shared__ double s_dict[256];
+    const int tid = threadIdx.x;
+    if (tid < ndict) s_dict[tid] = dict[tid];
+    const int64_t r0 = (int64_t)blockIdx.x * 256;
+    const int nr = (int)((nrows - r0) < 256 ? (nrows - r0) : 256);
+    const int64_t p0 = rowptr[r0], p1 = rowptr[r0 + nr];
+    const int64_t pa = p0 & ~(int64_t)7;
+    const int64_t total = p1 - pa;
+    int lo = 0, hi = 0;
+    if (tid < nr) { lo = (int)(rowptr[r0 + tid] - pa); hi = (int)(rowptr[r0 + tid + 1] - pa); }
+    __syncthreads();
+    double acc = 0.0;
+    for (int64_t c = 0; c < total; c += CHUNK) {
+        const int n = (int)((total - c) < CHUNK ? (total - c) : CHUNK);
+        v8s dc[OCT];
+        unsigned long long cd[OCT];
+#pragma unroll
+        for (int u = 0; u < OCT; ++u) {
+            const int e0 = (u * 256 + tid) * 8;
+            const int64_t g = pa + c + e0;
+            dc[u] = (v8s)(0);
+            cd[u] = 0;
+            if (e0 < n) {      // arrays are padded to a multiple of 8 entries by the packer
+                dc[u] = *reinterpret_cast<const v8s *>(dcol + g);
+                cd[u] = *reinterpret_cast<const unsigned long long *>(code + g);
+            }
+        }
+        double xv[OCT][8];
+#pragma unroll
+        for (int u = 0; u < OCT; ++u) {
+            const int e0 = (u * 256 + tid) * 8;
+            if (e0 < n) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    // octets shared with the neighbouring row blocks hold deltas relative to THEIR base:
+                    // clamp the index (their products are never summed here)
+                    int64_t idx = r0 + (int)dc[u][k];
+                    idx = idx < 0 ? 0 : (idx >= nrows ? nrows - 1 : idx);
+                    xv[u][k] = x[idx];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < OCT; ++u) {
+            const int e0 = (u * 256 + tid) * 8;
+            if (e0 < n) {
+#pragma unroll
+                for (int k = 0; k < 8; k += 2) {
+                    double2 pr;
+                    pr.x = s_dict[(cd[u] >> (8 * k)) & 0xff] * xv[u][k];
+                    pr.y = s_dict[(cd[u] >> (8 * k + 8)) & 0xff] * xv[u][k + 1];
+                    *reinterpret_cast<double2 *>(&s_prod[e0 + k]) = pr;
+                }
+            }
+        }
+        __syncthreads();
+        {
+            const int a = lo > c ? lo : (int)c;
+            const int e = hi < c + n ? hi : (int)(c + n);
+            for (int j = a; j < e; ++j) acc += s_prod[j - c];
+        }
+        __syncthreads();
+    }
+    if (tid < nr) y[r0 + tid] = acc;
+}
+
 extern "C" __attribute__((visibility("default"))) int hpcla_tune_spmv(
     int variant, const int *rowptr, const int *colval, const double *nzval, const double *x, double *y,
-    int64_t nrows, int64_t nnz, void *stream, const int *bptr)
+    int64_t nrows, int64_t nnz, void *stream, const int *bptr, const short *dcol, const unsigned char *code,
+    const double *dict, int ndict)
 {
     hipStream_t s = (hipStream_t)stream;
 #define NARROW(TPB, RPT, UN, NT, XCD, ABL)                                                        \
@@ -785,6 +867,8 @@ extern "C" __attribute__((visibility("default"))) int hpcla_tune_spmv(
             uint32_t nb = (uint32_t)((nrows + 255) / 256);
             k_wide_bptr<256, 1, 2, false, false><<<nb, 256, 0, s>>>(rowptr, colval, nzval, x, y, nrows, nnz, nb, bptr);
         } break;
+        case 80: k_packed<1><<<(uint32_t)((nrows + 255) / 256), 256, 0, s>>>(rowptr, dcol, code, dict, ndict, x, y, nrows, nnz); break;
+        case 81: k_packed<2><<<(uint32_t)((nrows + 255) / 256), 256, 0, s>>>(rowptr, dcol, code, dict, ndict, x, y, nrows, nnz); break;
         case 20:
             k_copy<<<256 * 16, 256, 0, s>>>((const v4i *)colval, (const v2d *)nzval, (const v4i *)rowptr,
                                             (double2 *)y, (const double2 *)x, nnz, nrows);

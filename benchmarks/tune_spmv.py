@@ -40,7 +40,7 @@ def main():
     import hpcla_amd as hp
     from hpcla_amd import workloads as wl
     tune = ctypes.CDLL(so)
-    tune.hpcla_tune_spmv.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
+    tune.hpcla_tune_spmv.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
     backend = hp.backend_rocm_serial(np.float64, np.int32)
     N = args.size
     if args.dim == 2:
@@ -59,6 +59,18 @@ def main():
     y = torch.empty_like(y_ref)
     ghost = torch.zeros(16, dtype=torch.float64, device="cuda")
     bptr = torch.cat([A.rowptr_target[::256], A.rowptr_target[-1:]]).contiguous()
+    # packed prototype inputs (host packing): 16-bit block-relative columns, 8-bit value codes
+    rp_h = A.rowptr.astype(np.int64)
+    rowid = np.repeat(np.arange(n, dtype=np.int64), np.diff(rp_h))
+    d = A.colval.astype(np.int64) - (rowid // 256) * 256
+    assert d.min() >= -32768 and d.max() <= 32767, "not packable with 16-bit block-relative columns"
+    dv, inv = np.unique(A.nzval.cpu().numpy(), return_inverse=True)
+    assert len(dv) <= 256
+    pad = (-nnz) % 8 + 8
+    dcol = torch.from_numpy(np.concatenate([d.astype(np.int16), np.zeros(pad, np.int16)])).cuda()
+    code = torch.from_numpy(np.concatenate([inv.astype(np.uint8), np.zeros(pad, np.uint8)])).cuda()
+    dictv = torch.from_numpy(dv).cuda()
+    del rowid, d, inv
     yvec = hp.HPCVector.zeros(A.row_partition, backend)
     plan = hp.get_vector_plan(A, x)
 
@@ -78,7 +90,7 @@ def main():
                                                            x.v.data_ptr(), ghost.data_ptr(), n, y.data_ptr(), n, nnz, 0,
                                                            None, 0, s)
         return tune.hpcla_tune_spmv(v, A.rowptr_target.data_ptr(), cv.data_ptr(), A.nzval.data_ptr(), x.v.data_ptr(),
-                                    y.data_ptr(), n, nnz, s, bptr.data_ptr())
+                                    y.data_ptr(), n, nnz, s, bptr.data_ptr(), dcol.data_ptr(), code.data_ptr(), dictv.data_ptr(), int(dictv.numel()))
     times = {v: [] for v in variants}
     exact = {}
     for v in variants:                       # correctness + warm-up

@@ -212,6 +212,32 @@ int hpcla_spmv_dist_dot_f64_i64(hpcla_halo_plan_t *plan, hpcla_comm_t *comm, con
                                 const int32_t *boundary_blocks, int64_t n_boundary,
                                 double *dot_out_dev, void *work, void *stream);
 
+/* ---- OPT-IN packed copy of the matrix for SpMV (no reference counterpart) ----------------------------
+ * For matrices with <= 256 distinct values whose row blocks reach only columns within +-32 K of the
+ * block's first row (stencils, graph Laplacians ...), a plan-time copy with 16-bit block-relative
+ * columns and 8-bit value codes moves 3 B per stored entry instead of 12.  The products are the same
+ * fp64 numbers summed in the same order, so results stay bit-identical to the CSR path.
+ * create returns HPCLA_ERR_UNSUPPORTED when the matrix (restricted to `block_list`, NULL = all row
+ * blocks) is not packable.  Int32 indices only.  Reported separately from the CSR numbers. */
+typedef struct hpcla_packed hpcla_packed_t;
+int hpcla_packed_create_i32(hpcla_packed_t **out, const int32_t *rowptr, const int32_t *colval_split,
+                            const double *nzval, int64_t nrows, int64_t nnz, int64_t n_own,
+                            int index_base, const int32_t *block_list, int64_t n_blocks, void *stream);
+int hpcla_packed_destroy(hpcla_packed_t *p);
+int hpcla_packed_info(const hpcla_packed_t *p, int64_t *bytes, int *ndict);
+int hpcla_spmv_packed_f64_i32(const hpcla_packed_t *p, const int32_t *rowptr, const double *x, double *y,
+                              int index_base, const int32_t *block_list, int64_t n_blocks,
+                              double *dot_partial, void *stream);
+/* distributed form of hpcla_spmv_dist_* / hpcla_spmv_dist_dot_* (dot_out_dev may be NULL): interior
+ * row blocks from the packed copy, boundary row blocks (ghost columns) from the CSR arrays. */
+int hpcla_spmv_dist_packed_f64_i32(hpcla_halo_plan_t *plan, hpcla_comm_t *comm, const hpcla_packed_t *p,
+                                   const int32_t *rowptr, const int32_t *colval_split,
+                                   const double *nzval, const double *x, int64_t n_own, double *y,
+                                   int64_t nrows, int64_t nnz, int index_base,
+                                   const int32_t *interior_blocks, int64_t n_interior,
+                                   const int32_t *boundary_blocks, int64_t n_boundary,
+                                   double *dot_out_dev, void *work, void *stream);
+
 /* ---- reductions: replace dot / norm (src/vectors.jl:798-812, 758-780) --------------------------
  * Local deterministic two-stage reduction into out_dev[0] (device double), then, if comm has
  * more than one rank, an in-place RCCL all-reduce on the same stream.  No host sync: CG keeps the

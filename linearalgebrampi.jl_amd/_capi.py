@@ -73,6 +73,12 @@ _SIGNATURES = {
     "hpcla_spmv_dist_dot_f64_i32": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp],
     "hpcla_spmv_dist_dot_f64_i64": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp],
     "hpcla_cg_update_f64": [_vp, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp],
+    "hpcla_packed_create_i32": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp, _i64, _vp],
+    "hpcla_packed_destroy": [_vp],
+    "hpcla_packed_info": [_vp, _vp, _vp],
+    "hpcla_spmv_packed_f64_i32": [_vp, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _vp],
+    "hpcla_spmv_dist_packed_f64_i32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _i64,
+                                       _vp, _i64, _vp, _vp, _vp],
     "hpcla_reduce_work_bytes": [],
     "hpcla_dot_f64": [_vp, _vp, _vp, _i64, _vp, _vp, _vp],
     "hpcla_nrm2sq_f64": [_vp, _vp, _i64, _vp, _vp, _vp],

@@ -136,6 +136,11 @@ int allreduce_on(hpcla_comm_t *comm, double *buf, int64_t count, int op, void *s
     return HPCLA_OK;
 }
 
+bool halo_active(const hpcla_halo_plan_t *plan)
+{
+    return plan && !(plan->send_ranks.empty() && plan->recv_ranks.empty());
+}
+
 }  // namespace hpcla
 
 using namespace hpcla;

@@ -29,9 +29,19 @@ from .partition import (compute_partition_hash, compute_structural_hash, owner_o
 from .vectors import HPCVector, current_stream_ptr, dptr
 
 
+import os as _os
+
+_PACKED_BY_ENV = _os.environ.get("HPCLA_SPMV_PACKED", "") == "1"
+
+
 def _torch():
     import torch
     return torch
+
+
+def _plan_key(plan):
+    """Stable identity of a cached plan: its memoization key (get_vector_plan), else the object id."""
+    return getattr(plan, "key", None) or id(plan)
 
 
 # =====================================================================================================
@@ -196,6 +206,7 @@ def get_vector_plan(A: "HPCSparseMatrix", x: HPCVector) -> VectorPlan:
     plan = _vector_plan_cache.get(key)
     if plan is None:
         plan = VectorPlan(A, x)
+        plan.key = key
         _vector_plan_cache[key] = plan
     return plan
 
@@ -257,6 +268,8 @@ class HPCSparseMatrix:
         self.rowptr_target = rowptr_dev
         self._colval_target = None
         self.cached_transpose = None                     # src/sparse.jl:331, filled by transpose()
+        self._packed = {}                                # plan cache key -> packed handle (opt-in)
+        self.packed_reason = ""
         self.nrows_local = len(rowptr) - 1
         self.ncols_compressed = len(self.col_indices)
         self.backend = backend
@@ -270,6 +283,49 @@ class HPCSparseMatrix:
     @property
     def shape(self) -> Tuple[int, int]:                  # src/sparse.jl:2151-2155
         return int(self.row_partition[-1]), int(self.col_partition[-1])
+
+    # -- OPT-IN packed copy (csrc/packed.hip).  It snapshots the VALUES, so it lives on the matrix
+    #    object, never on the structure-keyed VectorPlan (two matrices with the same structure share
+    #    a plan).  If nzval is modified in place afterwards, call disable_packed() first.
+    def enable_packed(self, x: HPCVector) -> bool:
+        """Build the packed copy (16-bit block-relative columns + 8-bit value codes: 3 B per stored
+        entry instead of 12) of the interior row blocks of the plan for ``(A, x.partition)``.
+        Returns False, leaving the CSR path in place, when the matrix is not packable (> 256
+        distinct values, column window > 16 bit, Int64 indices); the reason is in
+        ``self.packed_reason``.  Results are bit-identical either way."""
+        return self._packed_create(get_vector_plan(self, x))
+
+    def _packed_create(self, plan) -> bool:
+        if self._packed.get(_plan_key(plan)) is not None:
+            return True
+        self._packed[_plan_key(plan)] = None
+        if plan.is_i64:
+            self.packed_reason = "Int64 indices"
+            return False
+        h = ctypes.c_void_p()
+        rc = _capi.load().hpcla_packed_create_i32(
+            ctypes.byref(h), dptr(self.rowptr_target), dptr(plan.colval_split), dptr(self.nzval),
+            self.nrows_local, self.nnz, plan.n_own, 0, dptr(plan.interior) if plan.has_halo else None,
+            plan.n_interior if plan.has_halo else 0, current_stream_ptr())
+        if rc == -5:        # HPCLA_ERR_UNSUPPORTED: not packable, keep CSR
+            self.packed_reason = _capi.last_error()
+            return False
+        _capi.check("hpcla_packed_create_i32", rc)
+        self._packed[_plan_key(plan)] = h
+        return True
+
+    def disable_packed(self) -> None:
+        for h in self._packed.values():
+            if h is not None:
+                _capi.call("hpcla_packed_destroy", h)
+        self._packed.clear()
+
+    def _packed_for(self, plan):
+        """Packed handle for this plan or None; HPCLA_SPMV_PACKED=1 opts every matrix in."""
+        key = _plan_key(plan)
+        if key not in self._packed and _PACKED_BY_ENV:
+            self._packed_create(plan)
+        return self._packed.get(key)
 
     def transpose(self):
         """Lazy ``transpose(A)`` (src/sparse.jl:2254-2258); ``transpose(A) @ x`` materialises and
@@ -315,6 +371,13 @@ def _spmv_into(y: HPCVector, A: HPCSparseMatrix, x: HPCVector, plan: VectorPlan)
         raise ValueError("mul!: y has the wrong local length")
     if x.local_length != plan.n_own:
         raise ValueError("A*x: x does not match the plan's partition")
+    pk = A._packed_for(plan)
+    if pk is not None:
+        _capi.call("hpcla_spmv_dist_packed_f64_i32", plan.halo if plan.has_halo else None, A.backend.rccl,
+                   pk, dptr(A.rowptr_target), dptr(plan.colval_split), dptr(A.nzval), dptr(x.v),
+                   plan.n_own, dptr(y.v), A.nrows_local, A.nnz, 0, dptr(plan.interior), plan.n_interior,
+                   dptr(plan.boundary), plan.n_boundary, None, None, current_stream_ptr())
+        return
     sfx = "i64" if plan.is_i64 else "i32"
     _capi.call(f"hpcla_spmv_dist_f64_{sfx}", plan.halo if plan.has_halo else None,
                dptr(A.rowptr_target), dptr(plan.colval_split), dptr(A.nzval), dptr(x.v), plan.n_own,
@@ -349,6 +412,13 @@ def mul_dot_(y: HPCVector, A: HPCSparseMatrix, x: HPCVector, out) -> HPCVector:
     if work is None:
         nbytes = _capi.load().hpcla_spmv_dot_work_bytes(A.nrows_local)
         work = plan._dot_work = torch.empty(nbytes // 8 + 1, dtype=torch.float64, device=x.v.device)
+    pk = A._packed_for(plan)
+    if pk is not None:
+        _capi.call("hpcla_spmv_dist_packed_f64_i32", plan.halo if plan.has_halo else None, A.backend.rccl,
+                   pk, dptr(A.rowptr_target), dptr(plan.colval_split), dptr(A.nzval), dptr(x.v),
+                   plan.n_own, dptr(y.v), A.nrows_local, A.nnz, 0, dptr(plan.interior), plan.n_interior,
+                   dptr(plan.boundary), plan.n_boundary, dptr(out), dptr(work), current_stream_ptr())
+        return y
     sfx = "i64" if plan.is_i64 else "i32"
     _capi.call(f"hpcla_spmv_dist_dot_f64_{sfx}", plan.halo if plan.has_halo else None, A.backend.rccl,
                dptr(A.rowptr_target), dptr(plan.colval_split), dptr(A.nzval), dptr(x.v), plan.n_own,

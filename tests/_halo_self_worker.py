@@ -102,6 +102,23 @@ def main():
                   boundary.data_ptr(), boundary.numel(), s)
     torch.cuda.synchronize()
     assert np.array_equal(y.cpu().numpy(), want), "fused distributed SpMV mismatch"
+    # same exchange with the opt-in packed copy for the interior row blocks (+ fused x.y)
+    packed = ctypes.c_void_p()
+    capi.check("packed_create", lib.hpcla_packed_create_i32(ctypes.byref(packed), d_rp.data_ptr(), d_cv.data_ptr(),
+                                                          d_nz.data_ptr(), nloc, rows.nnz, nloc, 0,
+                                                          interior.data_ptr(), interior.numel(), s))
+    work = torch.empty(lib.hpcla_spmv_dot_work_bytes(nloc) // 8 + 1, dtype=torch.float64, device="cuda")
+    dot_out = torch.zeros(1, dtype=torch.float64, device="cuda")
+    y2 = torch.full((nloc,), float("nan"), dtype=torch.float64, device="cuda")
+    for rep in range(2):
+        capi.call("hpcla_spmv_dist_packed_f64_i32", plan, backend.rccl, packed, d_rp.data_ptr(), d_cv.data_ptr(),
+                  d_nz.data_ptr(), d_x.data_ptr(), nloc, y2.data_ptr(), nloc, rows.nnz, 0, interior.data_ptr(),
+                  interior.numel(), boundary.data_ptr(), boundary.numel(), dot_out.data_ptr(), work.data_ptr(), s)
+    torch.cuda.synchronize()
+    assert np.array_equal(y2.cpu().numpy(), want), "packed distributed SpMV mismatch"
+    ref_dot = float(np.dot(xg, want))
+    assert abs(dot_out.item() - ref_dot) <= 1e-12 * float(np.abs(xg) @ np.abs(want)), (dot_out.item(), ref_dot)
+    capi.call("hpcla_packed_destroy", packed)
     capi.call("hpcla_halo_plan_destroy", plan)
     print("halo self-exchange OK")
 

@@ -554,6 +554,73 @@ def test_transpose_times_vector(hp, orc, gpu_backend_i32):
     np.testing.assert_array_equal(back.nzval.cpu().numpy(), A.nzval.cpu().numpy())
 
 
+def test_packed_csr_opt_in_bit_exact(hp, orc, gpu_backend_i32):
+    """Opt-in packed copy (16-bit block-relative columns + 8-bit value codes): same bits as CSR."""
+    import torch
+    b = gpu_backend_i32
+    for gen, n in ((lambda: orc.poisson2d_rows(700, 300, 0, 700 * 300), 700 * 300),
+                   (lambda: orc.poisson3d_rows(20, 20, 50, 0, 20000), 20000)):
+        rows = gen()
+        A = hp.HPCSparseMatrix_local(rows.rowptr, rows.colidx, rows.vals, n, b)
+        xg = orc.fill_uniform(0, n, orc.SEED_X) - 0.3
+        x = hp.HPCVector.from_global(xg, b)
+        want = orc.spmv(rows.rowptr.astype(np.int32), rows.colidx.astype(np.int32), rows.vals, xg)
+        plan = hp.get_vector_plan(A, x)
+        y_csr = (A @ x).local_values()
+        assert A.enable_packed(x) is True
+        y_pk = (A @ x).local_values()
+        np.testing.assert_array_equal(y_csr, want)
+        np.testing.assert_array_equal(y_pk, want)
+        out = torch.zeros(1, dtype=torch.float64, device="cuda")
+        y = hp.HPCVector.zeros(A.row_partition, b)
+        hp.mul_dot_(y, A, x, out)                                     # packed + fused dot epilogue
+        np.testing.assert_array_equal(y.local_values(), want)
+        assert abs(out.item() - orc.dot([xg], [want])) <= RTOL_RED * float(np.abs(xg) @ np.abs(want))
+        nbytes, nd = ctypes.c_int64(), ctypes.c_int()
+        hp._capi.call("hpcla_packed_info", A._packed[plan.key], ctypes.byref(nbytes), ctypes.byref(nd))
+        assert nd.value == 2 and nbytes.value < 4 * rows.nnz
+        A.disable_packed()
+        np.testing.assert_array_equal((A @ x).local_values(), want)
+
+
+def test_packed_csr_eligibility(hp, orc, gpu_backend_i32):
+    import scipy.sparse as sp
+    b = gpu_backend_i32
+    # (1) > 256 distinct values -> not packable, CSR stays
+    rows = orc.sprand_rows(3000, 0.01, 0, 3000)
+    A = hp.HPCSparseMatrix_local(rows.rowptr, rows.colidx, rows.vals, 3000, b)
+    x = hp.HPCVector.from_global(np.ones(3000), b)
+    assert A.enable_packed(x) is False and "distinct" in A.packed_reason
+    # (2) columns outside the 16-bit window
+    n = 100_000
+    M = (sp.identity(n, format="csr") + sp.diags([np.ones(n - 40000)], [40000], format="csr")).tocsr()
+    A2 = hp.HPCSparseMatrix_from_global(M, b)
+    x2 = hp.HPCVector.from_global(np.arange(n, dtype=np.float64), b)
+    assert A2.enable_packed(x2) is False and "window" in A2.packed_reason
+    # (3) dictionary values that the 65 536-entry seed sample does not contain -> iterative extension;
+    #     exactly 256 distinct values is still packable, 257 is not
+    for ndist, ok in ((256, True), (257, False)):
+        n3 = 40_000
+        vals = np.ones(5 * n3)
+        vals[-ndist + 1:] = 2.0 + np.arange(ndist - 1)              # late, outside the seed sample
+        rowptr = np.arange(0, 5 * n3 + 1, 5)
+        cols_b = np.minimum(np.repeat(np.arange(n3), 5) + np.tile(np.arange(5), n3), n3 - 1)   # banded
+        A4 = hp.HPCSparseMatrix_local(rowptr, cols_b, vals, n3, b)
+        x3g = orc.fill_uniform(0, n3, 4)
+        x3 = hp.HPCVector.from_global(x3g, b)
+        # A4 shares its structure -- and therefore its cached VectorPlan -- with the previous
+        # iteration's matrix; the packed copy depends on the VALUES and must not be shared
+        if not ok:
+            assert A4.enable_packed(x3) is False and "distinct" in A4.packed_reason
+            np.testing.assert_array_equal((A4 @ x3).local_values(),
+                                          orc.spmv(rowptr.astype(np.int32), A4.colval, vals, x3g[A4.col_indices]))
+            continue
+        assert A4.enable_packed(x3) is True
+        want = orc.spmv(rowptr.astype(np.int32), A4.colval, vals, x3g[A4.col_indices])
+        np.testing.assert_array_equal((A4 @ x3).local_values(), want)
+    hp.clear_plan_cache()
+
+
 def test_graft_entry_smoke():
     import __graft_entry__ as g
     g.smoke()
