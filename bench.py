@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--index", default="i32", choices=["i32", "i64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-packed", action="store_true", help="skip the extra opt-in packed-copy measurement")
+    ap.add_argument("--host-setup", action="store_true", help="generate/compress the matrix on the host (numpy) instead of on the device")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -148,9 +149,22 @@ def main():
         lo, hi = rank * nx * ny_loc, (rank + 1) * nx * ny_loc
     n_glob = nx * ny
     t0 = time.perf_counter()
-    rowptr, colidx, vals = wl.poisson2d_rows(nx, ny, lo, hi)
-    A = hp.HPCSparseMatrix_local(rowptr, colidx, vals, n_glob, backend)
-    del colidx
+    if args.host_setup:
+        rowptr, colidx, vals = wl.poisson2d_rows(nx, ny, lo, hi)
+        A = hp.HPCSparseMatrix_local(rowptr, colidx, vals, n_glob, backend)
+        del colidx
+    else:
+        # device-side construction: generator kernel + bitmap/scan column compression
+        s0 = torch.cuda.current_stream().cuda_stream
+        nnz_gen = hp._capi.load().hpcla_poisson2d_nnz(nx, ny, lo, hi)
+        rp_d = torch.empty(hi - lo + 1, dtype=torch.int64, device="cuda")
+        ci_d = torch.empty(nnz_gen, dtype=torch.int64, device="cuda")
+        va_d = torch.empty(nnz_gen, dtype=torch.float64, device="cuda")
+        hp._capi.call("hpcla_gen_poisson2d", nx, ny, lo, hi, rp_d.data_ptr(), ci_d.data_ptr(), va_d.data_ptr(), s0)
+        A = hp.HPCSparseMatrix_local_device(rp_d, ci_d, va_d, n_glob, backend,
+                                            col_window=(max(lo - nx, 0), min(hi + nx, n_glob) - 1))
+        del ci_d, rp_d
+        vals = None
     part = A.row_partition
     x = hp.HPCVector.zeros(part, backend)
     hp._capi.call("hpcla_fill_uniform_f64", x.v.data_ptr(), lo, hi - lo, wl.SEED_X,
@@ -305,6 +319,8 @@ def main():
             xfull = np.concatenate([wl.u01(wl.SEED_X, ghost_lo), xg, wl.u01(wl.SEED_X, ghost_idx)])
         else:
             xfull = xg
+        if vals is None:
+            vals = A.nzval.cpu().numpy()
         result["cpu_baseline"] = cpu_baseline_spmv(A.rowptr, A.colval, vals, xfull, args.cpu_seconds)
     if world > 1:
         _device_barrier(torch, dist)

@@ -40,7 +40,7 @@ def main():
     import hpcla_amd as hp
     from hpcla_amd import workloads as wl
     tune = ctypes.CDLL(so)
-    tune.hpcla_tune_spmv.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    tune.hpcla_tune_spmv.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
     backend = hp.backend_rocm_serial(np.float64, np.int32)
     N = args.size
     if args.dim == 2:
@@ -70,6 +70,9 @@ def main():
     dcol = torch.from_numpy(np.concatenate([d.astype(np.int16), np.zeros(pad, np.int16)])).cuda()
     code = torch.from_numpy(np.concatenate([inv.astype(np.uint8), np.zeros(pad, np.uint8)])).cuda()
     dictv = torch.from_numpy(dv).cuda()
+    mk = lambda R: torch.from_numpy(np.concatenate([(A.colval.astype(np.int64) - (rowid // R) * R).astype(np.int16),
+                                                    np.zeros(pad, np.int16)])).cuda()
+    dcol512, dcol1024 = mk(512), mk(1024)
     del rowid, d, inv
     yvec = hp.HPCVector.zeros(A.row_partition, backend)
     plan = hp.get_vector_plan(A, x)
@@ -90,7 +93,7 @@ def main():
                                                            x.v.data_ptr(), ghost.data_ptr(), n, y.data_ptr(), n, nnz, 0,
                                                            None, 0, s)
         return tune.hpcla_tune_spmv(v, A.rowptr_target.data_ptr(), cv.data_ptr(), A.nzval.data_ptr(), x.v.data_ptr(),
-                                    y.data_ptr(), n, nnz, s, bptr.data_ptr(), dcol.data_ptr(), code.data_ptr(), dictv.data_ptr(), int(dictv.numel()))
+                                    y.data_ptr(), n, nnz, s, bptr.data_ptr(), dcol.data_ptr(), code.data_ptr(), dictv.data_ptr(), int(dictv.numel()), dcol512.data_ptr(), dcol1024.data_ptr())
     times = {v: [] for v in variants}
     exact = {}
     for v in variants:                       # correctness + warm-up

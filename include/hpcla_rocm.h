@@ -111,6 +111,27 @@ int hpcla_classify_blocks_i64(const int64_t *rowptr, const int64_t *colval_split
                               int index_base, int64_t n_own, int rows_per_block, int32_t *flags,
                               void *stream);
 
+/* ---- device-side construction: replaces the host sort + per-nonzero binary search of
+ * HPCSparseMatrix_local (col_indices = unique!(sort(rowval)), compress_AT; src/sparse.jl:501-509,
+ * 137-144) by a presence bitmap + exclusive scan + emit pass over a column window.
+ * colidx_global: this rank's nonzeros' GLOBAL 0-based columns (device int64); every id must lie in
+ * [col_lo, col_lo+window).  Outputs: colval_out (local index + index_base per nonzero),
+ * col_indices_out (device int64, capacity `window`; first *ncols_compressed_host entries valid,
+ * ascending).  `work`: hpcla_colspace_work_bytes(window) device bytes.  Synchronises the stream. */
+int64_t hpcla_colspace_work_bytes(int64_t window);
+int hpcla_compress_columns_i32(const int64_t *colidx_global, int64_t nnz, int64_t col_lo, int64_t window,
+                               int32_t *colval_out, int index_base, int64_t *col_indices_out,
+                               int64_t *ncols_compressed_host, void *work, void *stream);
+int hpcla_compress_columns_i64(const int64_t *colidx_global, int64_t nnz, int64_t col_lo, int64_t window,
+                               int64_t *colval_out, int index_base, int64_t *col_indices_out,
+                               int64_t *ncols_compressed_host, void *work, void *stream);
+/* On-device generator of the BASELINE stencil workload (create_2d_laplacian,
+ * test/test_factorization.jl:60-102): rows [row_start,row_end) of the nx*ny 5-point Laplacian as
+ * CSR with GLOBAL 0-based columns (rowptr_out: row_end-row_start+1 int64, 0-based). */
+int64_t hpcla_poisson2d_nnz(int64_t nx, int64_t ny, int64_t row_start, int64_t row_end);
+int hpcla_gen_poisson2d(int64_t nx, int64_t ny, int64_t row_start, int64_t row_end, int64_t *rowptr_out,
+                        int64_t *colidx_out, double *vals_out, void *stream);
+
 /* ---- SpMM:  replaces A*B column loop (src/sparse.jl:2391-2413) -------------------------------
  * C[r,c] = sum_j nzval[j] * B[colval[j], c], c in [0,k): one pass over A for all k columns, each
  * (r,c) accumulated sequentially in stored order (bit-identical to k reference SpMVs).

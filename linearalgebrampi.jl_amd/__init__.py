@@ -23,6 +23,7 @@ from .partition import (compute_partition_hash, compute_structural_hash, owner_o
                         uniform_partition)
 from .vectors import HPCVector, HPCVector_local, cg_update_, dot, norm
 from .sparse import (HPCSparseMatrix, HPCSparseMatrix_from_global, HPCSparseMatrix_local,
+                     HPCSparseMatrix_local_device,
                      HostVectorPlan, VectorPlan, build_host_vector_plan, cache_sizes,
                      clear_plan_cache, execute_plan, get_vector_plan, mul_, mul_dot_, split_column_map)
 from .dense import HPCMatrix, HPCMatrix_local, clear_spmm_cache, spmm

@@ -73,6 +73,11 @@ _SIGNATURES = {
     "hpcla_spmv_dist_dot_f64_i32": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp],
     "hpcla_spmv_dist_dot_f64_i64": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp],
     "hpcla_cg_update_f64": [_vp, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp],
+    "hpcla_colspace_work_bytes": [_i64],
+    "hpcla_compress_columns_i32": [_vp, _i64, _i64, _i64, _vp, _i32, _vp, _vp, _vp, _vp],
+    "hpcla_compress_columns_i64": [_vp, _i64, _i64, _i64, _vp, _i32, _vp, _vp, _vp, _vp],
+    "hpcla_poisson2d_nnz": [_i64, _i64, _i64, _i64],
+    "hpcla_gen_poisson2d": [_i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp],
     "hpcla_packed_create_i32": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp, _i64, _vp],
     "hpcla_packed_destroy": [_vp],
     "hpcla_packed_info": [_vp, _vp, _vp],
@@ -95,6 +100,8 @@ _RESTYPES = {
     "hpcla_last_error": ctypes.c_char_p,
     "hpcla_reduce_work_bytes": _i64,
     "hpcla_spmv_dot_work_bytes": _i64,
+    "hpcla_colspace_work_bytes": _i64,
+    "hpcla_poisson2d_nnz": _i64,
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

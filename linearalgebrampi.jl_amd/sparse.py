@@ -262,15 +262,15 @@ class HPCSparseMatrix:
         self.row_partition = np.asarray(row_partition, dtype=np.int64)
         self.col_partition = np.asarray(col_partition, dtype=np.int64)
         self.col_indices = np.asarray(col_indices, dtype=np.int64)
-        self.rowptr = rowptr
-        self.colval = colval
+        self._rowptr = rowptr                            # host copies ("always CPU" in the reference);
+        self._colval = colval                            # None when built on the device -> lazy D2H
         self.nzval = nzval_dev
         self.rowptr_target = rowptr_dev
         self._colval_target = None
         self.cached_transpose = None                     # src/sparse.jl:331, filled by transpose()
         self._packed = {}                                # plan cache key -> packed handle (opt-in)
         self.packed_reason = ""
-        self.nrows_local = len(rowptr) - 1
+        self.nrows_local = int(rowptr_dev.numel()) - 1
         self.ncols_compressed = len(self.col_indices)
         self.backend = backend
         self.T = backend.T
@@ -279,6 +279,18 @@ class HPCSparseMatrix:
     @property
     def nnz(self) -> int:
         return int(self.nzval.numel())
+
+    @property
+    def rowptr(self) -> np.ndarray:
+        if self._rowptr is None:
+            self._rowptr = self.rowptr_target.cpu().numpy()
+        return self._rowptr
+
+    @property
+    def colval(self) -> np.ndarray:
+        if self._colval is None:
+            self._colval = self._colval_target.cpu().numpy()
+        return self._colval
 
     @property
     def shape(self) -> Tuple[int, int]:                  # src/sparse.jl:2151-2155
@@ -475,6 +487,50 @@ def HPCSparseMatrix_local(rowptr, colidx_global, vals, ncols_global: int, backen
     rowptr_dev = torch.from_numpy(rowptr_ti).to(dev)               # _to_target_device hook (:519)
     return HPCSparseMatrix(row_partition, col_partition, col_indices, rowptr_ti, colval, nzval_dev,
                            rowptr_dev, backend)
+
+
+def HPCSparseMatrix_local_device(rowptr_dev, colidx_global_dev, vals_dev, ncols_global: int,
+                                 backend: HPCBackend, col_partition: Optional[np.ndarray] = None,
+                                 col_window: Optional[Tuple[int, int]] = None) -> HPCSparseMatrix:
+    """Device-side twin of :func:`HPCSparseMatrix_local`: the local rows arrive
+    as DEVICE tensors (``rowptr`` int64 0-based, global column ids int64, values f64) and the
+    compressed column space is built on the GPU (presence bitmap + scan, ``hpcla_compress_columns_*``)
+    instead of the reference's host sort + binary search (src/sparse.jl:501-509, 137-144).
+    ``col_window = (lo, hi)`` bounds the column ids (default: their min/max)."""
+    torch = _torch()
+    comm = backend.comm
+    nranks = comm_size(comm)
+    is64 = backend.Ti == np.dtype(np.int64)
+    tdt = torch.int64 if is64 else torch.int32
+    dev = backend.torch_device
+    nrows, nnz = int(rowptr_dev.numel()) - 1, int(vals_dev.numel())
+    if nnz > np.iinfo(backend.Ti.type).max:
+        raise OverflowError("nnz does not fit the backend index type")
+    info = comm_allgather(comm, np.array([nrows, ncols_global], dtype=np.int64)).reshape(nranks, 2)
+    if not np.all(info[:, 1] == info[0, 1]):
+        raise ValueError("HPCSparseMatrix_local: All ranks must have the same number of columns. "
+                         f"Got column counts: {info[:, 1].tolist()}")
+    row_partition = np.concatenate([[0], np.cumsum(info[:, 0])]).astype(np.int64)
+    if col_partition is None:
+        col_partition = uniform_partition(ncols_global, nranks)
+    if col_window is None:
+        col_window = (int(colidx_global_dev.min().item()), int(colidx_global_dev.max().item())) if nnz else (0, 0)
+    lo, hi = int(col_window[0]), int(col_window[1])
+    if lo < 0 or hi >= ncols_global:
+        raise ValueError("column index out of range")
+    window = hi - lo + 1
+    work = torch.empty(_capi.load().hpcla_colspace_work_bytes(window), dtype=torch.uint8, device=dev)
+    colval_dev = torch.empty(nnz, dtype=tdt, device=dev)
+    col_indices_dev = torch.empty(window, dtype=torch.int64, device=dev)
+    ncomp = ctypes.c_int64()
+    _capi.call("hpcla_compress_columns_i64" if is64 else "hpcla_compress_columns_i32",
+               dptr(colidx_global_dev), nnz, lo, window, dptr(colval_dev), 0, dptr(col_indices_dev),
+               ctypes.byref(ncomp), dptr(work), current_stream_ptr())
+    col_indices = col_indices_dev[:ncomp.value].cpu().numpy()
+    A = HPCSparseMatrix(row_partition, col_partition, col_indices, None, None, vals_dev,
+                        rowptr_dev.to(tdt), backend)
+    A._colval_target = colval_dev
+    return A
 
 
 def HPCSparseMatrix_from_global(A, backend: HPCBackend, row_partition=None, col_partition=None) -> HPCSparseMatrix:

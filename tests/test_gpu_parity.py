@@ -621,6 +621,112 @@ def test_packed_csr_eligibility(hp, orc, gpu_backend_i32):
     hp.clear_plan_cache()
 
 
+def test_spmv_randomised_structures(hp, orc, gpu_backend_i32):
+    """Property test: arbitrary ragged CSR structures (empty rows, rows far longer than the LDS chunk,
+    duplicate columns, nrows around the 256-row block size, both index types and bases) give the
+    oracle's bits."""
+    rng = np.random.default_rng(2024)
+    for trial in range(40):
+        nrows = int(rng.choice([1, 2, 63, 255, 256, 257, 511, 513, 1000, 3001]))
+        ncols = int(rng.integers(1, 5000))
+        kind = trial % 4
+        if kind == 0:
+            lens = rng.integers(0, 12, size=nrows)
+        elif kind == 1:
+            lens = rng.geometric(0.05, size=nrows) - 1
+        elif kind == 2:
+            lens = np.zeros(nrows, dtype=np.int64)
+            lens[rng.integers(0, nrows, size=max(1, nrows // 50))] = rng.integers(1500, 7000)
+        else:
+            lens = rng.integers(0, 3, size=nrows) * rng.integers(0, 400, size=nrows)
+        rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        nnz = int(rowptr[-1])
+        cols = rng.integers(0, ncols, size=nnz)
+        # ascending within each row (duplicates allowed), as the reference's construction yields
+        rowid = np.repeat(np.arange(nrows), lens)
+        order = np.lexsort((cols, rowid))
+        cols = cols[order].astype(np.int64)
+        vals = rng.standard_normal(nnz) * 10.0 ** rng.integers(-8, 8)
+        x = rng.standard_normal(ncols)
+        Ti = np.int32 if trial % 2 == 0 else np.int64
+        base = (trial // 2) % 2
+        want = orc.spmv(rowptr.astype(Ti), cols.astype(Ti), vals, x)
+        got = _raw_spmv(hp, rowptr, cols, vals, x, Ti, base)
+        np.testing.assert_array_equal(got, want, err_msg=f"trial {trial} kind {kind} nrows {nrows} nnz {nnz}")
+
+
+def test_spmv_x_partition_differs_from_row_partition(hp, orc, gpu_backend_i32):
+    """A*x accepts any partition of x (the plan is keyed on it): simulated ranks
+    with a non-uniform x partition, split-column map + ghost segment, bit-exact per rank."""
+    import torch
+    nranks, m, n = 3, 2000, 1500
+    rp = orc.uniform_partition(m, nranks)
+    xp = np.array([0, 200, 1300, n])
+    x = orc.fill_uniform(0, n, 33)
+    s = torch.cuda.current_stream().cuda_stream
+    locs = [orc.sprand_rows(n, 0.01, int(rp[r]), int(rp[r + 1])) for r in range(nranks)]
+    comp = [orc.compress_columns(l) for l in locs]
+    plans = orc.vector_plans([c[0] for c in comp], xp)
+    gathered = orc.execute_plans(plans, [x[xp[r]:xp[r + 1]] for r in range(nranks)])
+    for r in range(nranks):
+        rows, (ci, cv), pl = locs[r], comp[r], plans[r]
+        n_own = int(xp[r + 1] - xp[r])
+        hplan = hp.HostVectorPlan(pl.send_rank_ids, pl.send_indices, pl.recv_rank_ids, pl.recv_perm,
+                                  pl.local_src_indices, pl.local_dst_indices, pl.n_gathered, n_own)
+        cmap = hp.split_column_map(hplan)
+        ghost = np.concatenate([gathered[r][p] for p in pl.recv_perm]) if pl.recv_perm else np.zeros(1)
+        d_rp, d_split, d_nz = _t(rows.rowptr.astype(np.int32)), _t(cmap[cv].astype(np.int32)), _t(rows.vals)
+        d_x, d_g = _t(x[xp[r]:xp[r + 1]]), _t(ghost)
+        y = torch.full((rows.nrows,), float("nan"), dtype=torch.float64, device="cuda")
+        hp._capi.call("hpcla_spmv_split_f64_i32", d_rp.data_ptr(), d_split.data_ptr(), d_nz.data_ptr(),
+                      d_x.data_ptr(), d_g.data_ptr(), n_own, y.data_ptr(), rows.nrows, rows.nnz, 0, None, 0, s)
+        torch.cuda.synchronize()
+        want = orc.spmv(rows.rowptr.astype(np.int32), cv.astype(np.int32), rows.vals, gathered[r])
+        np.testing.assert_array_equal(y.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("which", ["i32", "i64"])
+def test_device_side_construction(hp, orc, gpu_backend_i32, gpu_backend_i64, which):
+    """hpcla_gen_poisson2d + hpcla_compress_columns (device) == oracle generator + the reference's
+    unique!(sort)/searchsortedfirst compression (host), for a row slice whose column window is wider
+    than its rows, and for an unstructured matrix with untouched columns."""
+    import torch
+    b = gpu_backend_i32 if which == "i32" else gpu_backend_i64
+    s = torch.cuda.current_stream().cuda_stream
+    lib = hp._capi.load()
+    for nx, ny, lo, hi in ((300, 200, 0, 60000), (300, 200, 7777, 41234), (5, 3, 2, 13), (1, 9, 0, 9)):
+        want = orc.poisson2d_rows(nx, ny, lo, hi)
+        nnz = lib.hpcla_poisson2d_nnz(nx, ny, lo, hi)
+        assert nnz == want.nnz
+        rp = torch.empty(hi - lo + 1, dtype=torch.int64, device="cuda")
+        ci = torch.empty(nnz, dtype=torch.int64, device="cuda")
+        va = torch.empty(nnz, dtype=torch.float64, device="cuda")
+        hp._capi.call("hpcla_gen_poisson2d", nx, ny, lo, hi, rp.data_ptr(), ci.data_ptr(), va.data_ptr(), s)
+        np.testing.assert_array_equal(rp.cpu().numpy(), want.rowptr)
+        np.testing.assert_array_equal(ci.cpu().numpy(), want.colidx)
+        np.testing.assert_array_equal(va.cpu().numpy(), want.vals)
+        A_dev = hp.HPCSparseMatrix_local_device(rp, ci, va, nx * ny, b)
+        A_host = hp.HPCSparseMatrix_local(want.rowptr, want.colidx, want.vals, nx * ny, b)
+        np.testing.assert_array_equal(A_dev.col_indices, A_host.col_indices)
+        np.testing.assert_array_equal(A_dev.colval, A_host.colval)
+        np.testing.assert_array_equal(A_dev.rowptr, A_host.rowptr)
+        assert A_dev.colval.dtype == A_host.colval.dtype and A_dev._ensure_hash() == A_host._ensure_hash()
+    # unstructured, sparse column usage; then multiply
+    n = 4000
+    rows = orc.sprand_rows(n, 0.0008, 0, n)
+    A = hp.HPCSparseMatrix_local_device(_t(rows.rowptr), _t(rows.colidx), _t(rows.vals), n, b)
+    ci_ref, cv_ref = orc.compress_columns(rows)
+    np.testing.assert_array_equal(A.col_indices, ci_ref)
+    np.testing.assert_array_equal(A.colval, cv_ref)
+    assert A.ncols_compressed < n
+    xg = orc.fill_uniform(0, n, 2)
+    y = (A @ hp.HPCVector.from_global(xg, b)).local_values()
+    Ti = np.int32 if which == "i32" else np.int64
+    np.testing.assert_array_equal(y, orc.spmv(rows.rowptr.astype(Ti), cv_ref.astype(Ti), rows.vals, xg[ci_ref]))
+    with pytest.raises(hp._capi.HPCLAError):
+        hp.HPCSparseMatrix_local_device(_t(rows.rowptr), _t(rows.colidx), _t(rows.vals), n, b, col_window=(10, n - 1))
+
+
 def test_graft_entry_smoke():
     import __graft_entry__ as g
     g.smoke()
