@@ -132,6 +132,34 @@ int64_t hpcla_poisson2d_nnz(int64_t nx, int64_t ny, int64_t row_start, int64_t r
 int hpcla_gen_poisson2d(int64_t nx, int64_t ny, int64_t row_start, int64_t row_end, int64_t *rowptr_out,
                         int64_t *colidx_out, double *vals_out, void *stream);
 
+/* ---- SpGEMM local product (sparse x sparse): replaces the CPU SparseArrays multiply inside
+ * Base.:*(A::HPCSparseMatrix, B::HPCSparseMatrix) (`CT = plan.AT * A_csc`, src/sparse.jl:991-1059).
+ * G = the rows of B named by A.col_indices, gathered by the MatrixPlan (src/sparse.jl:554-978), as
+ * CSR with int64 rowptr and GLOBAL int64 columns; A's colval indexes G's rows.  Each C(i,j) is the sum
+ * over k ascending of separately rounded G(k,j)*A(i,k), first product assigned -- the reference order.
+ *  ub:       ub_out[i] = sum of the lengths of the G rows that row i references
+ *  numeric:  rows `row_list` (all with ub <= hpcla_spgemm_bin_cap(bin)) -> sorted (col,val) runs at
+ *            c_*_tmp[ub_prefix[i] ...] and their lengths cnt[i]
+ *  compact:  c_rowptr (exclusive scan of cnt) -> final CSR arrays */
+int64_t hpcla_spgemm_bin_cap(int bin);
+int hpcla_spgemm_ub_i32(const int32_t *a_rowptr, const int32_t *a_col, int64_t nrows, int index_base,
+                        const int64_t *g_rowptr, int64_t *ub_out, void *stream);
+int hpcla_spgemm_ub_i64(const int64_t *a_rowptr, const int64_t *a_col, int64_t nrows, int index_base,
+                        const int64_t *g_rowptr, int64_t *ub_out, void *stream);
+int hpcla_spgemm_numeric_i32(int bin, const int32_t *a_rowptr, const int32_t *a_col, const double *a_val,
+                             int index_base, const int64_t *g_rowptr, const int64_t *g_col,
+                             const double *g_val, const int32_t *row_list, int64_t n_list,
+                             const int64_t *ub_prefix, int64_t *c_col_tmp, double *c_val_tmp,
+                             int64_t *cnt, void *stream);
+int hpcla_spgemm_numeric_i64(int bin, const int64_t *a_rowptr, const int64_t *a_col, const double *a_val,
+                             int index_base, const int64_t *g_rowptr, const int64_t *g_col,
+                             const double *g_val, const int32_t *row_list, int64_t n_list,
+                             const int64_t *ub_prefix, int64_t *c_col_tmp, double *c_val_tmp,
+                             int64_t *cnt, void *stream);
+int hpcla_spgemm_compact(const int64_t *c_rowptr, const int64_t *ub_prefix, int64_t nrows,
+                         const int64_t *c_col_tmp, const double *c_val_tmp, int64_t *c_col, double *c_val,
+                         void *stream);
+
 /* ---- SpMM:  replaces A*B column loop (src/sparse.jl:2391-2413) -------------------------------
  * C[r,c] = sum_j nzval[j] * B[colval[j], c], c in [0,k): one pass over A for all k columns, each
  * (r,c) accumulated sequentially in stored order (bit-identical to k reference SpMVs).

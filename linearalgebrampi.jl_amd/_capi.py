@@ -78,6 +78,12 @@ _SIGNATURES = {
     "hpcla_compress_columns_i64": [_vp, _i64, _i64, _i64, _vp, _i32, _vp, _vp, _vp, _vp],
     "hpcla_poisson2d_nnz": [_i64, _i64, _i64, _i64],
     "hpcla_gen_poisson2d": [_i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp],
+    "hpcla_spgemm_bin_cap": [_i32],
+    "hpcla_spgemm_ub_i32": [_vp, _vp, _i64, _i32, _vp, _vp, _vp],
+    "hpcla_spgemm_ub_i64": [_vp, _vp, _i64, _i32, _vp, _vp, _vp],
+    "hpcla_spgemm_numeric_i32": [_i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp],
+    "hpcla_spgemm_numeric_i64": [_i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp],
+    "hpcla_spgemm_compact": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp],
     "hpcla_packed_create_i32": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp, _i64, _vp],
     "hpcla_packed_destroy": [_vp],
     "hpcla_packed_info": [_vp, _vp, _vp],
@@ -102,6 +108,7 @@ _RESTYPES = {
     "hpcla_spmv_dot_work_bytes": _i64,
     "hpcla_colspace_work_bytes": _i64,
     "hpcla_poisson2d_nnz": _i64,
+    "hpcla_spgemm_bin_cap": _i64,
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -373,6 +373,9 @@ class HPCSparseMatrix:
             return y
         if isinstance(other, HPCMatrix):
             return spmm(self, other)
+        if isinstance(other, HPCSparseMatrix):
+            from .matmat import spgemm
+            return spgemm(self, other)
         return NotImplemented
 
     __mul__ = __matmul__

@@ -336,3 +336,52 @@ ORC_API void orc_gather(const double *x, const int64_t *src, const int64_t *dst,
 {
     for (int64_t i = 0; i < n; ++i) gathered[dst[i]] = x[src[i]];
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Sparse x sparse local product.  The reference gathers the needed
+ * rows of B (MatrixPlan, src/sparse.jl:554-978) and multiplies with Julia's SparseArrays
+ * (`CT = plan.AT * A_csc`, src/sparse.jl:1011), i.e. Gustavson's algorithm column by column of
+ * A_csc = row by row of A: entries k of the row in stored (ascending) order, every entry j of gathered
+ * row k: `x[j] = nzA*nzB` on first touch, `x[j] += nzA*nzB` afterwards, where nzA is the value of
+ * the LEFT factor plan.AT (gathered B) and nzB the value of A.  Output columns ascending.
+ * g_rowptr/g_col: gathered rows with GLOBAL columns in [0,ncols).  Two-call protocol: c_col==NULL
+ * counts (fills c_rowptr), second call fills.
+ * ---------------------------------------------------------------------------------------- */
+ORC_API int64_t orc_spgemm(const int64_t *a_rowptr, const int64_t *a_col, const double *a_val,
+                           int64_t nrows, const int64_t *g_rowptr, const int64_t *g_col,
+                           const double *g_val, int64_t ncols, int64_t *c_rowptr, int64_t *c_col,
+                           double *c_val)
+{
+    int64_t *mark = (int64_t *)malloc(sizeof(int64_t) * (size_t)(ncols > 0 ? ncols : 1));
+    double *acc = (double *)malloc(sizeof(double) * (size_t)(ncols > 0 ? ncols : 1));
+    int64_t *list = (int64_t *)malloc(sizeof(int64_t) * (size_t)(ncols > 0 ? ncols : 1));
+    for (int64_t j = 0; j < ncols; ++j) mark[j] = -1;
+    int64_t nnz = 0;
+    for (int64_t i = 0; i < nrows; ++i) {
+        int64_t n = 0;
+        for (int64_t p = a_rowptr[i]; p < a_rowptr[i + 1]; ++p) {
+            const int64_t k = a_col[p];
+            const double av = a_val[p];
+            for (int64_t q = g_rowptr[k]; q < g_rowptr[k + 1]; ++q) {
+                const int64_t j = g_col[q];
+                const double prod = g_val[q] * av;
+                if (mark[j] != i) { mark[j] = i; acc[j] = prod; list[n++] = j; }
+                else acc[j] += prod;
+            }
+        }
+        /* ascending columns (insertion sort: rows are short) */
+        for (int64_t a = 1; a < n; ++a) {
+            const int64_t v = list[a];
+            int64_t b = a - 1;
+            while (b >= 0 && list[b] > v) { list[b + 1] = list[b]; --b; }
+            list[b + 1] = v;
+        }
+        if (c_col)
+            for (int64_t a = 0; a < n; ++a) { c_col[nnz + a] = list[a]; c_val[nnz + a] = acc[list[a]]; }
+        c_rowptr[i] = nnz;
+        nnz += n;
+    }
+    c_rowptr[nrows] = nnz;
+    free(mark); free(acc); free(list);
+    return nnz;
+}

@@ -350,3 +350,23 @@ def cg(rowptr, colval, nzval, b: np.ndarray, iters: int):
         rr = rr_new
         hist.append(float(np.sqrt(rr)))
     return x, hist
+
+
+def spgemm(a_rowptr, a_col, a_val, g_rowptr, g_col, g_val, ncols: int):
+    """Local sparse x sparse product in the reference's order (src/sparse.jl:991-1059 + SparseArrays
+    Gustavson): returns (c_rowptr, c_col_global, c_val), columns ascending."""
+    L = lib()
+    L.orc_spgemm.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int64] + [ctypes.c_void_p] * 3 + [ctypes.c_int64] + \
+        [ctypes.c_void_p] * 3
+    L.orc_spgemm.restype = ctypes.c_int64
+    a_rowptr, a_col, g_rowptr, g_col = (np.ascontiguousarray(v, dtype=np.int64) for v in (a_rowptr, a_col, g_rowptr, g_col))
+    a_val, g_val = np.ascontiguousarray(a_val, dtype=np.float64), np.ascontiguousarray(g_val, dtype=np.float64)
+    nrows = len(a_rowptr) - 1
+    c_rowptr = np.empty(nrows + 1, dtype=np.int64)
+    nnz = L.orc_spgemm(_p(a_rowptr), _p(a_col), _p(a_val), nrows, _p(g_rowptr), _p(g_col), _p(g_val), ncols,
+                       _p(c_rowptr), None, None)
+    c_col = np.empty(nnz, dtype=np.int64)
+    c_val = np.empty(nnz, dtype=np.float64)
+    L.orc_spgemm(_p(a_rowptr), _p(a_col), _p(a_val), nrows, _p(g_rowptr), _p(g_col), _p(g_val), ncols,
+                 _p(c_rowptr), _p(c_col), _p(c_val))
+    return c_rowptr, c_col, c_val

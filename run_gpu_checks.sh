@@ -24,6 +24,7 @@ for st in $STEPS; do
       cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
       run 600 gpurun_out/${TAG}_prof.log rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_prof -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline
       tail -3 gpurun_out/${TAG}_prof.log;;
+    spgemm) run 600 gpurun_out/${TAG}_spgemm.log python benchmarks/bench_spgemm.py; tail -5 gpurun_out/${TAG}_spgemm.log;;
     vecops) run 600 gpurun_out/${TAG}_vecops.log python benchmarks/bench_vecops.py; tail -8 gpurun_out/${TAG}_vecops.log;;
     cg)     run 900 gpurun_out/${TAG}_cg.log python bench.py --workload poisson3d_cg --steps 100 --warmup 10; tail -2 gpurun_out/${TAG}_cg.log;;
     cgsmall) run 900 gpurun_out/${TAG}_cgsmall.log python bench.py --workload poisson3d_cg --size 256 --steps 100 --warmup 10; tail -2 gpurun_out/${TAG}_cgsmall.log;;

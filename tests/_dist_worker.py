@@ -101,6 +101,33 @@ def main():
     np.testing.assert_array_equal(tci, want.indices)
     np.testing.assert_array_equal(tv, want.data)
 
+    # MatrixPlan row gather (src/sparse.jl:554-978): structure of the gathered rows of B == B[needed,:]
+    from hpcla_amd.matmat import build_row_gather_plan
+    kk, nb = 170, 90
+    Bg = orc.sprand_rows(nb, 0.05, 0, kk)
+    Bm = sp.csr_matrix((Bg.vals, Bg.colidx, Bg.rowptr), shape=(kk, nb))
+    bp = orc.uniform_partition(kk, nranks)
+    Bloc = Bm[bp[rank]:bp[rank + 1], :]
+    needed = np.unique(np.random.default_rng(100 + rank).integers(0, kk, 60))
+    pl = build_row_gather_plan(needed, bp, Bloc.indptr, lambda pos: Bloc.indices[pos].astype(np.int64), comm)
+    want_g = Bm[needed, :]
+    np.testing.assert_array_equal(pl.g_rowptr, want_g.indptr)
+    np.testing.assert_array_equal(pl.g_col, want_g.indices)
+    # value movement lists reproduce the values: emulate the exchange over gloo
+    ops, bufs, keep = [], [], []
+    for r, cnt in zip(pl.recv_rank_ids, pl.recv_counts):
+        t = torch.empty(cnt, dtype=torch.float64); bufs.append(t); ops.append(dist.P2POp(dist.irecv, t, r))
+    for r, pos in zip(pl.send_rank_ids, pl.send_pos):
+        t = torch.from_numpy(Bloc.data[pos].copy()); keep.append(t); ops.append(dist.P2POp(dist.isend, t, r))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    g_val = np.full(len(pl.g_col), np.nan)
+    g_val[pl.local_dst_start:pl.local_dst_start + len(pl.local_src)] = Bloc.data[pl.local_src]
+    for b, dst in zip(bufs, pl.recv_dst_start):
+        g_val[dst:dst + len(b)] = b.numpy()
+    np.testing.assert_array_equal(g_val, want_g.data)
+
     dist.barrier()
     dist.destroy_process_group()
     print(f"rank {rank}: OK")

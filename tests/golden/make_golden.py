@@ -165,6 +165,37 @@ for nx, ny in ((4, 3), (3, 5)):
         ref="test/test_factorization.jl:60-102", nx=nx, ny=ny, m=nn, n=nn, I=I, J=J, V=V,
         x=x, y=matvec(dense_from_coo(I, J, V, nn, nn), x))
 
+# --- test/test_matrix_multiplication.jl:38-88  sparse x sparse ---------------------------------------
+def matmat_sparse(Aop, Bop):
+    """exact product of two dense-of-Fraction matrices; keep only structurally possible entries"""
+    m, k, n2 = len(Aop), len(Bop), len(Bop[0])
+    C = [[None] * n2 for _ in range(m)]
+    for i in range(m):
+        for j in range(n2):
+            terms = [Aop[i][t] * Bop[t][j] for t in range(k) if Aop[i][t] != 0 and Bop[t][j] != 0]
+            if terms:
+                C[i][j] = float(sum(terms))
+    return C
+
+
+n = 8
+IA = list(range(1, n + 1)) + list(range(1, n)) + list(range(2, n + 1))
+JA = list(range(1, n + 1)) + list(range(2, n + 1)) + list(range(1, n))
+VA = [2.0] * n + [-0.5] * (n - 1) + [-0.5] * (n - 1)
+VB = [1.5] * n + [0.25] * (n - 1) + [0.25] * (n - 1)
+Cd = matmat_sparse(dense_from_coo(IA, JA, VA, n, n), dense_from_coo(IA, JA, VB, n, n))
+cases["spgemm_tridiagonal"] = dict(
+    ref="test/test_matrix_multiplication.jl:38-61", m=n, k=n, n=n, IA=IA, JA=JA, VA=VA, IB=IA, JB=JA, VB=VB,
+    C=[[(j + 1, v) for j, v in enumerate(row) if v is not None] for row in Cd])
+IA2 = [1, 2, 3, 4, 5, 6, 1, 2, 3, 4]; JA2 = [1, 2, 3, 4, 5, 6, 7, 8, 1, 2]
+VA2 = [float(i) for i in range(1, 11)]
+IB2 = [1, 2, 3, 4, 5, 6, 7, 8, 1, 3]; JB2 = [1, 2, 3, 4, 5, 6, 7, 8, 9, 10]
+VB2 = [float(i) for i in range(1, 11)]
+Cd2 = matmat_sparse(dense_from_coo(IA2, JA2, VA2, 6, 8), dense_from_coo(IB2, JB2, VB2, 8, 10))
+cases["spgemm_nonsquare"] = dict(
+    ref="test/test_matrix_multiplication.jl:64-88", m=6, k=8, n=10, IA=IA2, JA=JA2, VA=VA2, IB=IB2, JB=JB2, VB=VB2,
+    C=[[(j + 1, v) for j, v in enumerate(row) if v is not None] for row in Cd2])
+
 # --- uniform_partition docstring example: src/HPCLinearAlgebra.jl:269-277 ------------------------
 cases["uniform_partition"] = dict(
     ref="src/HPCLinearAlgebra.jl:269-289",

@@ -727,6 +727,76 @@ def test_device_side_construction(hp, orc, gpu_backend_i32, gpu_backend_i64, whi
         hp.HPCSparseMatrix_local_device(_t(rows.rowptr), _t(rows.colidx), _t(rows.vals), n, b, col_window=(10, n - 1))
 
 
+def _csr_of(M):
+    """(rowptr, global cols, vals) of an HPCSparseMatrix' local rows, on the host."""
+    return M.rowptr.astype(np.int64), M.col_indices[M.colval.astype(np.int64)], M.nzval.cpu().numpy()
+
+
+@pytest.mark.parametrize("name", ["spgemm_tridiagonal", "spgemm_nonsquare"])
+def test_spgemm_golden_host_layer(hp, golden, gpu_backend_i32, name):
+    """test/test_matrix_multiplication.jl:38-88: HPCSparseMatrix * HPCSparseMatrix."""
+    import scipy.sparse as sp
+    c = golden[name]
+    A = sp.coo_matrix((c["VA"], (np.array(c["IA"]) - 1, np.array(c["JA"]) - 1)), shape=(c["m"], c["k"])).tocsr()
+    B = sp.coo_matrix((c["VB"], (np.array(c["IB"]) - 1, np.array(c["JB"]) - 1)), shape=(c["k"], c["n"])).tocsr()
+    Ad = hp.HPCSparseMatrix_from_global(A, gpu_backend_i32)
+    Bd = hp.HPCSparseMatrix_from_global(B, gpu_backend_i32)
+    Cd = Ad @ Bd
+    assert isinstance(Cd, hp.HPCSparseMatrix) and Cd.shape == (c["m"], c["n"])
+    np.testing.assert_array_equal(Cd.row_partition, Ad.row_partition)
+    np.testing.assert_array_equal(Cd.col_partition, Bd.col_partition)
+    rp, col, val = _csr_of(Cd)
+    for i, row in enumerate(c["C"]):
+        assert (col[rp[i]:rp[i + 1]] + 1).tolist() == [j for j, _ in row]
+        assert np.max(np.abs(val[rp[i]:rp[i + 1]] - np.array([v for _, v in row])), initial=0.0) < TOL_REF
+
+
+@pytest.mark.parametrize("which", ["i32", "i64"])
+def test_spgemm_bit_exact_vs_oracle(hp, orc, gpu_backend_i32, gpu_backend_i64, which):
+    """Random and stencil products incl. every row-length bin (tables of 32/128/512/8192 slots), empty
+    rows, and A*A of the 2-D Laplacian (the reference's only published SpGEMM benchmark case,
+    tools/benchmark_vs_petsc_results.txt:3-11)."""
+    import scipy.sparse as sp
+    b = gpu_backend_i32 if which == "i32" else gpu_backend_i64
+    cases = []
+    lap = orc.poisson2d_rows(100, 100, 0, 10_000)
+    cases.append((lap, lap, 10_000))
+    r1 = orc.sprand_rows(3000, 0.004, 0, 2500)                     # ~12 nnz/row
+    r2 = orc.sprand_rows(2000, 0.02, 0, 3000)                      # ~40 nnz/row -> ub ~ 480 (bins 2-3)
+    cases.append((r1, r2, 2000))
+    # one very long row product (bin 3) next to empty rows
+    rng = np.random.default_rng(3)
+    lens = np.zeros(50, dtype=np.int64); lens[[3, 17]] = [60, 5]
+    rp = np.concatenate([[0], np.cumsum(lens)])
+    cols = np.concatenate([np.sort(rng.choice(400, size=l, replace=False)) for l in lens if l])
+    Along = orc.LocalRows(rp, cols.astype(np.int64), rng.standard_normal(int(rp[-1])), 400)
+    Bwide = orc.sprand_rows(5000, 0.016, 0, 400)                   # ~80 per row -> ub ~ 4800
+    cases.append((Along, Bwide, 5000))
+    for Ar, Br, ncols in cases:
+        A = hp.HPCSparseMatrix_local(Ar.rowptr, Ar.colidx, Ar.vals, Ar.ncols_global, b)
+        B = hp.HPCSparseMatrix_local(Br.rowptr, Br.colidx, Br.vals, Br.ncols_global, b)
+        C = A @ B
+        ci, cv = orc.compress_columns(Ar)
+        g_rowptr = np.concatenate([[0], np.cumsum(np.diff(Br.rowptr)[ci])])
+        sel = (np.concatenate([np.arange(Br.rowptr[r], Br.rowptr[r + 1]) for r in ci])
+               if len(ci) else np.zeros(0, dtype=np.int64))
+        w_rp, w_col, w_val = orc.spgemm(Ar.rowptr, cv, Ar.vals, g_rowptr, Br.colidx[sel], Br.vals[sel], ncols)
+        rp_c, col_c, val_c = _csr_of(C)
+        np.testing.assert_array_equal(rp_c, w_rp)
+        np.testing.assert_array_equal(col_c, w_col)
+        np.testing.assert_array_equal(val_c, w_val)               # bit-identical accumulation order
+        Cs = (sp.csr_matrix((Ar.vals, Ar.colidx, Ar.rowptr), shape=(Ar.nrows, Ar.ncols_global)) @
+              sp.csr_matrix((Br.vals, Br.colidx, Br.rowptr), shape=(Br.nrows, Br.ncols_global))).tocsr()
+        got = sp.csr_matrix((val_c, col_c, rp_c), shape=Cs.shape)
+        assert abs(got - Cs).max() <= 1e-12 * max(abs(Cs).max(), 1.0)
+        # the product is a first-class HPCSparseMatrix: multiply it with a vector
+        xg = orc.fill_uniform(0, ncols, 8)
+        y = (C @ hp.HPCVector.from_global(xg, b)).local_values()
+        np.testing.assert_allclose(y, Cs @ xg, rtol=1e-12, atol=1e-12 * np.abs(Cs @ xg).max())
+    from hpcla_amd.matmat import clear_matrix_plan_cache
+    clear_matrix_plan_cache()
+
+
 def test_graft_entry_smoke():
     import __graft_entry__ as g
     g.smoke()

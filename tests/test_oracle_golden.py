@@ -184,3 +184,28 @@ def test_cg_oracle_converges(orc):
     A = sp.csr_matrix((rows.vals, rows.colidx, rows.rowptr))
     assert np.linalg.norm(A @ x - b) < 1e-8 * np.linalg.norm(b)
     assert hist[-1] < 1e-8 * hist[0]
+
+
+@pytest.mark.parametrize("name", ["spgemm_tridiagonal", "spgemm_nonsquare"])
+def test_spgemm_oracle_golden(orc, golden, name):
+    """Oracle restatement of the reference's sparse x sparse product (src/sparse.jl:991-1059 +
+    SparseArrays Gustavson) vs the exact-rational fixture of test/test_matrix_multiplication.jl:38-88,
+    and vs scipy on a random pair."""
+    import scipy.sparse as sp
+    c = golden[name]
+    A = orc.rows_from_coo(c["IA"], c["JA"], c["VA"], c["m"], c["k"])
+    B = orc.rows_from_coo(c["IB"], c["JB"], c["VB"], c["k"], c["n"])
+    ci, cv = orc.compress_columns(A)                       # A's colval indexes the gathered rows
+    g_rowptr = np.concatenate([[0], np.cumsum(np.diff(B.rowptr)[ci])])
+    sel = np.concatenate([np.arange(B.rowptr[r], B.rowptr[r + 1]) for r in ci])
+    rp, col, val = orc.spgemm(A.rowptr, cv, A.vals, g_rowptr, B.colidx[sel], B.vals[sel], c["n"])
+    for i, row in enumerate(c["C"]):
+        got = list(zip((col[rp[i]:rp[i + 1]] + 1).tolist(), val[rp[i]:rp[i + 1]].tolist()))
+        assert [j for j, _ in got] == [j for j, _ in row]
+        assert max(abs(a - b) for (_, a), (_, b) in zip(got, row)) < TOL if row else True
+    As = sp.random(60, 50, 0.1, format="csr", random_state=1); As.sort_indices()
+    Bs = sp.random(50, 70, 0.1, format="csr", random_state=2); Bs.sort_indices()
+    rp, col, val = orc.spgemm(As.indptr, As.indices, As.data, Bs.indptr, Bs.indices, Bs.data, 70)
+    Cs = (As @ Bs).tocsr(); Cs.sort_indices()
+    got = sp.csr_matrix((val, col, rp), shape=(60, 70))
+    assert abs(got - Cs).max() < 1e-13 and np.array_equal(np.diff(rp) >= np.diff(Cs.indptr), np.ones(60, bool))
