@@ -181,6 +181,16 @@ int hpcla_spmm_split_f64_i32(const int32_t *rowptr, const int32_t *colval_split,
 int hpcla_transpose_f64(const double *src, int64_t ld_src, int src_layout, double *dst,
                         int64_t ld_dst, int dst_layout, int64_t rows, int64_t cols, void *stream);
 
+/* ---- dense mat-vec: replaces `LinearAlgebra.mul!(y.v, A.A, plan.gathered)` of
+ * Base.:*(A::HPCMatrix, x::HPCVector) / mul! (src/dense.jl:614-658).  A: this rank's rows, ROW-major
+ * with leading dimension lda >= ncols; the full x is read in place as three segments (slices owned by
+ * lower ranks | own slice | slices of higher ranks), as delivered by a halo plan in which every rank
+ * sends its whole slice to every other rank.  Summation order is a tree (BLAS order is
+ * implementation-defined): parity by tolerance. */
+int hpcla_gemv_rowmajor_f64(const double *A, int64_t lda, int64_t nrows, const double *x_lo, int64_t n_lo,
+                            const double *x_own, int64_t n_own, const double *x_hi, int64_t n_hi,
+                            double *y, void *stream);
+
 /* ---- gather: replaces _gather_kernel! (src/vectors.jl:174-194) --------------------------------
  * out[dst[i]] = x[src[i]] (dst may be NULL = identity).  Kept for API parity
  * (execute_plan! returning `gathered`); the SpMV hot path does not need it. */

@@ -26,7 +26,8 @@ from .sparse import (HPCSparseMatrix, HPCSparseMatrix_from_global, HPCSparseMatr
                      HPCSparseMatrix_local_device,
                      HostVectorPlan, VectorPlan, build_host_vector_plan, cache_sizes,
                      clear_plan_cache, execute_plan, get_vector_plan, mul_, mul_dot_, split_column_map)
-from .dense import HPCMatrix, HPCMatrix_local, clear_spmm_cache, spmm
+from .dense import HPCMatrix, HPCMatrix_local, clear_dense_plan_cache, clear_spmm_cache, dense_matvec, spmm
+from .matmat import clear_matrix_plan_cache, get_matrix_plan, spgemm
 from .cg import cg_fixed_iterations
 from .transpose import TransposedHPCSparseMatrix, transpose, transpose_local_rows
 

@@ -78,6 +78,7 @@ _SIGNATURES = {
     "hpcla_compress_columns_i64": [_vp, _i64, _i64, _i64, _vp, _i32, _vp, _vp, _vp, _vp],
     "hpcla_poisson2d_nnz": [_i64, _i64, _i64, _i64],
     "hpcla_gen_poisson2d": [_i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp],
+    "hpcla_gemv_rowmajor_f64": [_vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp],
     "hpcla_spgemm_bin_cap": [_i32],
     "hpcla_spgemm_ub_i32": [_vp, _vp, _i64, _i32, _vp, _vp, _vp],
     "hpcla_spgemm_ub_i64": [_vp, _vp, _i64, _i32, _vp, _vp, _vp],

@@ -45,6 +45,14 @@ class HPCMatrix:
     def shape(self):
         return int(self.row_partition[-1]), int(self.A.shape[1])
 
+    def __matmul__(self, x):
+        from .vectors import HPCVector
+        if isinstance(x, HPCVector):
+            return dense_matvec(self, x)
+        return NotImplemented
+
+    __mul__ = __matmul__
+
     def local_values(self) -> np.ndarray:
         return self.A.detach().cpu().numpy()
 
@@ -95,6 +103,81 @@ def HPCMatrix_local(A_local, backend: HPCBackend, col_partition=None) -> HPCMatr
     if col_partition is None:
         col_partition = uniform_partition(int(A_local.shape[1]), nranks)
     return HPCMatrix(row_partition, col_partition, A_local, backend)
+
+
+# ---- dense A * x (src/dense.jl:397-658) -------------------------------------------
+_dense_vector_plan_cache: Dict[tuple, object] = {}
+
+
+def clear_dense_plan_cache() -> None:
+    for halo in _dense_vector_plan_cache.values():
+        if halo:
+            _capi.call("hpcla_halo_plan_destroy", halo)
+    _dense_vector_plan_cache.clear()
+
+
+def _dense_vector_plan(A: HPCMatrix, x):
+    """DenseMatrixVectorPlan (src/dense.jl:424-538): every rank needs the WHOLE of x, so each rank
+    sends its slice to all others.  Memoized on (A's partitions, x's partition) like
+    _dense_vector_plan_cache (src/dense.jl:596-606)."""
+    torch = _torch()
+    backend = A.backend
+    rank, nranks = comm_rank(backend.comm), comm_size(backend.comm)
+    key = (compute_partition_hash(A.row_partition), compute_partition_hash(A.col_partition), x.structural_hash)
+    if key in _dense_vector_plan_cache:
+        return _dense_vector_plan_cache[key]
+    halo = ctypes.c_void_p()
+    if nranks > 1:
+        others = [r for r in range(nranks) if r != rank]
+        n_own = int(x.partition[rank + 1] - x.partition[rank])
+        sizes = np.diff(x.partition)
+        send_to = [r for r in others if n_own > 0]
+        recv_from = [r for r in others if sizes[r] > 0]
+        send_ranks = (ctypes.c_int32 * max(len(send_to), 1))(*send_to)
+        send_counts = (ctypes.c_int64 * max(len(send_to), 1))(*([n_own] * len(send_to)))
+        recv_ranks = (ctypes.c_int32 * max(len(recv_from), 1))(*recv_from)
+        recv_counts = (ctypes.c_int64 * max(len(recv_from), 1))(*[int(sizes[r]) for r in recv_from])
+        idx = (torch.arange(n_own, dtype=torch.int64, device=backend.torch_device).repeat(len(send_to))
+               if send_to else None)
+        torch.cuda.current_stream().synchronize()
+        _capi.check("hpcla_halo_plan_create", _capi.load().hpcla_halo_plan_create(
+            ctypes.byref(halo), backend.rccl, len(send_to), send_ranks, send_counts, dptr(idx), 1,
+            len(recv_from), recv_ranks, recv_counts, 1))
+    _dense_vector_plan_cache[key] = halo
+    return halo
+
+
+def dense_matvec(A: HPCMatrix, x, y=None):
+    """``A * x`` / ``mul!(y, A, x)`` for a dense row-partitioned A (src/dense.jl:614-658)."""
+    from .vectors import HPCVector
+    torch = _torch()
+    assert_backends_compatible(A.backend, x.backend)
+    backend = A.backend
+    rank = comm_rank(backend.comm)
+    nloc, ncols = int(A.A.shape[0]), int(A.A.shape[1])
+    if int(x.partition[-1]) != ncols:
+        raise ValueError(f"dimension mismatch: A has {ncols} columns, x has length {int(x.partition[-1])}")
+    if y is None:
+        y = HPCVector(compute_partition_hash(A.row_partition), A.row_partition,
+                      torch.empty(nloc, dtype=torch.float64, device=backend.torch_device), backend)
+    elif y.local_length != nloc:
+        raise ValueError("mul!: y has the wrong local length")
+    halo = _dense_vector_plan(A, x)
+    s = current_stream_ptr()
+    n_lo, n_own = int(x.partition[rank]), int(x.partition[rank + 1] - x.partition[rank])
+    n_hi = ncols - n_lo - n_own
+    ghost = ctypes.c_void_p()
+    if halo:
+        _capi.call("hpcla_halo_begin", halo, dptr(x.v), s)
+        _capi.call("hpcla_halo_end", halo, s)
+        ng = ctypes.c_int64()
+        _capi.call("hpcla_halo_ghost_ptr", halo, ctypes.byref(ghost), ctypes.byref(ng))
+    Ac = A.A if A.A.is_contiguous() else A.A.contiguous()
+    x_lo = ghost if n_lo else None
+    x_hi = ctypes.c_void_p(ghost.value + 8 * n_lo) if (n_hi and ghost.value) else None
+    _capi.call("hpcla_gemv_rowmajor_f64", dptr(Ac), ncols, nloc, x_lo, n_lo, dptr(x.v), n_own, x_hi, n_hi,
+               dptr(y.v), s)
+    return y
 
 
 # width-k halo plans hang off the same key as the vector plan, plus k
