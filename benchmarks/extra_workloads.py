@@ -81,7 +81,10 @@ def run(args, backend, rank, world):
     elif args.workload == "sprand_spmm":
         k = 16
         rows_loc = args.size or 2_097_152
-        ncols = rows_loc * world
+        # HPCLA_SPMM_COLS_MULT=8 on ONE GPU reproduces config 5's per-GPU access pattern (B has
+        # 8 x 2 097 152 rows = 2.1 GB, far beyond the 256 MiB Infinity Cache) without the exchange
+        mult = int(os.environ.get("HPCLA_SPMM_COLS_MULT", "1"))
+        ncols = rows_loc * world * mult
         mean_nnz = 29.8
         rng = np.random.default_rng(0xA11CE + rank)
         t0 = time.perf_counter()
@@ -96,8 +99,9 @@ def run(args, backend, rank, world):
         vals = rng.random(nnz)
         A = hp.HPCSparseMatrix_local(rowptr, cols, vals, ncols, backend)
         del cols, vals
-        Bl = torch.empty((rows_loc, k), dtype=torch.float64, device=dev)
-        hp._capi.call("hpcla_fill_uniform_f64", Bl.data_ptr(), rank * rows_loc * k, rows_loc * k, wl.SEED_X,
+        b_rows = rows_loc * mult
+        Bl = torch.empty((b_rows, k), dtype=torch.float64, device=dev)
+        hp._capi.call("hpcla_fill_uniform_f64", Bl.data_ptr(), rank * b_rows * k, b_rows * k, wl.SEED_X,
                       torch.cuda.current_stream().cuda_stream)
         B = hp.HPCMatrix_local(Bl, backend)
         setup_s = time.perf_counter() - t0

@@ -32,17 +32,10 @@ int set_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3
 
 static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
-// MI355X: 8 XCDs, workgroups are dealt round-robin over them (block b and b+8 share an XCD's L2).
-// Map the launch index so that every XCD walks ONE contiguous slice of the work in order: the x
-// entries a row block gathers were fetched into the same L2 by the previous blocks of that slice.
-// Bijective for any n (MI355X_MICROARCH.md, "Workgroup dispatch"; speed only, never correctness).
-constexpr uint32_t NUM_XCD = 8;
-__device__ __forceinline__ uint32_t xcd_slice_index(uint32_t b, uint32_t n)
-{
-    uint32_t k = b % NUM_XCD, q = b / NUM_XCD;
-    uint32_t per = n / NUM_XCD, rem = n % NUM_XCD;
-    uint32_t start = k * per + (k < rem ? k : rem);
-    return start + q;
-}
+// Workgroup order: MI355X deals workgroups round-robin over its 8 XCDs (block b and b+8 share an L2).
+// An XCD-sliced remap (each XCD walking one contiguous eighth of the matrix) was measured SLOWER than
+// the natural blockIdx order for SpMV (0.255 vs 0.241 ms) and SpMM (+3 %): one moving window over the
+// matrix keeps DRAM pages and the gathered x / B rows hot for all XCDs through the 256 MiB Infinity
+// Cache.  The kernels therefore use blockIdx.x directly (profiles/r01_tune_spmv_variants_first.log).
 
 }  // namespace hpcla

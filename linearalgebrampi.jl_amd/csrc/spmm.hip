@@ -40,7 +40,7 @@ __global__ __launch_bounds__(TPB_MM) void spmm_rowblock_kernel(
 
     const int tid = threadIdx.x;
     const int g = tid / GROUP, l = tid % GROUP;
-    uint32_t b = xcd_slice_index(blockIdx.x, nblocks);
+    const uint32_t b = blockIdx.x;      // natural order (the XCD-sliced order measured slower, as for SpMV)
     const int64_t blk = block_list ? (int64_t)block_list[b] : (int64_t)b;
     const int64_t r0 = blk * RPB_MM;
     const int nr = (int)((nrows - r0) < RPB_MM ? (nrows - r0) : RPB_MM);

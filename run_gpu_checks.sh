@@ -28,6 +28,7 @@ for st in $STEPS; do
     vecops) run 600 gpurun_out/${TAG}_vecops.log python benchmarks/bench_vecops.py; tail -8 gpurun_out/${TAG}_vecops.log;;
     cg)     run 900 gpurun_out/${TAG}_cg.log python bench.py --workload poisson3d_cg --steps 100 --warmup 10; tail -2 gpurun_out/${TAG}_cg.log;;
     cgsmall) run 900 gpurun_out/${TAG}_cgsmall.log python bench.py --workload poisson3d_cg --size 256 --steps 100 --warmup 10; tail -2 gpurun_out/${TAG}_cgsmall.log;;
+    spmm8)  HPCLA_SPMM_COLS_MULT=8 run 900 gpurun_out/${TAG}_spmm8.log python bench.py --workload sprand_spmm --steps 20 --warmup 3; tail -2 gpurun_out/${TAG}_spmm8.log;;
     spmm)   run 900 gpurun_out/${TAG}_spmm.log python bench.py --workload sprand_spmm --steps 20 --warmup 3; tail -2 gpurun_out/${TAG}_spmm.log;;
     pmc_sq)
       run 600 gpurun_out/${TAG}_pmc_sq.log rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d gpurun_out/${TAG}_pmc_sq -- python3 benchmarks/tune_spmv.py --variants 100,5,20,0 --rounds 1 --reps 2
