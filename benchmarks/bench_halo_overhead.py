@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""Overhead of the distributed step on ONE GPU: a 4096 x 4096 Poisson slab whose upper and lower
+ghost lines are exchanged with ITSELF through a one-rank RCCL communicator (HPCLA_FORCE_RCCL=1), i.e.
+the exact launch sequence of an interior rank in bench.py --gpus N (event, side stream, ncclGroup of
+2 sends + 2 recvs of 32 KiB, interior kernel, event wait, boundary kernel) versus the plain kernel."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["HPCLA_FORCE_RCCL"] = "1"
+
+
+def main():
+    import torch
+    import hpcla_amd as hp
+    from hpcla_amd import workloads as wl
+    backend = hp.backend_rocm_serial(np.float64, np.int32)
+    capi, lib = hp._capi, hp._capi.load()
+    s = torch.cuda.current_stream().cuda_stream
+    nx = ny = 4096
+    nloc = nx * ny
+    # middle slab of a 3-slab grid: ghosts below (nx) and above (nx)
+    rowptr, colidx, vals = wl.poisson2d_rows(nx, 3 * ny, nloc, 2 * nloc)
+    colidx = colidx - nloc                                   # own columns 0..nloc-1, ghosts <0 and >= nloc
+    split = np.where(colidx < 0, nloc + (colidx + nx), np.where(colidx >= nloc, nloc + nx + (colidx - nloc), colidx))
+    d_rp = torch.from_numpy(rowptr.astype(np.int32)).cuda()
+    d_cv = torch.from_numpy(split.astype(np.int32)).cuda()
+    d_nz = torch.from_numpy(vals).cuda()
+    x = torch.rand(nloc, dtype=torch.float64, device="cuda")
+    y = torch.empty(nloc, dtype=torch.float64, device="cuda")
+    rpb = lib.hpcla_spmv_rows_per_block()
+    nblk = (nloc + rpb - 1) // rpb
+    flags = torch.empty(nblk, dtype=torch.int32, device="cuda")
+    capi.call("hpcla_classify_blocks_i32", d_rp.data_ptr(), d_cv.data_ptr(), nloc, 0, nloc, rpb, flags.data_ptr(), s)
+    interior = torch.nonzero(flags == 0).flatten().to(torch.int32)
+    boundary = torch.nonzero(flags != 0).flatten().to(torch.int32)
+    # "neighbours": rank 0 twice (lower ghost = my last line, upper ghost = my first line)
+    send_idx = torch.cat([torch.arange(nloc - nx, nloc), torch.arange(0, nx)]).to(torch.int32).cuda()
+    plan = ctypes.c_void_p()
+    ranks = (ctypes.c_int32 * 2)(0, 0)
+    counts = (ctypes.c_int64 * 2)(nx, nx)
+    torch.cuda.synchronize()
+    capi.check("create", lib.hpcla_halo_plan_create(ctypes.byref(plan), backend.rccl, 2, ranks, counts,
+                                                   send_idx.data_ptr(), 0, 2, ranks, counts, 1))
+
+    def dist():
+        capi.call("hpcla_spmv_dist_f64_i32", plan, d_rp.data_ptr(), d_cv.data_ptr(), d_nz.data_ptr(), x.data_ptr(),
+                  nloc, y.data_ptr(), nloc, len(vals), 0, interior.data_ptr(), interior.numel(),
+                  boundary.data_ptr(), boundary.numel(), s)
+
+    ghost = torch.zeros(2 * nx, dtype=torch.float64, device="cuda")
+
+    def plain():
+        capi.call("hpcla_spmv_split_f64_i32", d_rp.data_ptr(), d_cv.data_ptr(), d_nz.data_ptr(), x.data_ptr(),
+                  ghost.data_ptr(), nloc, y.data_ptr(), nloc, len(vals), 0, None, 0, s)
+
+    def halo_only():
+        capi.call("hpcla_halo_begin", plan, x.data_ptr(), s)
+        capi.call("hpcla_halo_end", plan, s)
+
+    def interior_only():
+        capi.call("hpcla_spmv_split_f64_i32", d_rp.data_ptr(), d_cv.data_ptr(), d_nz.data_ptr(), x.data_ptr(),
+                  ghost.data_ptr(), nloc, y.data_ptr(), nloc, len(vals), 0, interior.data_ptr(), interior.numel(), s)
+
+    def boundary_only():
+        capi.call("hpcla_spmv_split_f64_i32", d_rp.data_ptr(), d_cv.data_ptr(), d_nz.data_ptr(), x.data_ptr(),
+                  ghost.data_ptr(), nloc, y.data_ptr(), nloc, len(vals), 0, boundary.data_ptr(), boundary.numel(), s)
+
+    def interior_then_boundary():
+        interior_only()
+        boundary_only()
+
+    import time
+    for name, fn in (("plain split kernel", plain), ("halo + interior + boundary", dist), ("halo exchange only", halo_only),
+                     ("interior blocks only (list)", interior_only), ("boundary blocks only", boundary_only),
+                     ("interior + boundary, no halo", interior_then_boundary)):
+        for _ in range(20):
+            fn()
+        torch.cuda.synchronize()
+        res = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            for _ in range(200):
+                fn()
+            torch.cuda.synchronize()
+            res.append((time.perf_counter() - t0) / 200 * 1e3)
+        t0 = time.perf_counter()
+        for _ in range(200):
+            fn()
+        host = (time.perf_counter() - t0) / 200 * 1e3
+        torch.cuda.synchronize()
+        print(f"{name:30s} {np.median(res):8.4f} ms/step (min {np.min(res):.4f})   host enqueue {host:.4f} ms/step")
+    print(f"interior blocks {interior.numel()}, boundary blocks {boundary.numel()}")
+    capi.call("hpcla_halo_plan_destroy", plan)
+
+
+if __name__ == "__main__":
+    main()

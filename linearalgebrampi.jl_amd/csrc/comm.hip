@@ -23,10 +23,10 @@ namespace hpcla {
 
 int spmv_split_i32(const int32_t *, const int32_t *, const double *, const double *, const double *,
                    int64_t, double *, int64_t, int64_t, int, const int32_t *, int64_t, void *,
-                   double *);
+                   double *, int64_t);
 int spmv_split_i64(const int64_t *, const int64_t *, const double *, const double *, const double *,
                    int64_t, double *, int64_t, int64_t, int, const int32_t *, int64_t, void *,
-                   double *);
+                   double *, int64_t);
 int reduce_partials_sum(const double *partial, int64_t np, double *scratch, double *out,
                         void *stream);   // vecops.hip
 
@@ -104,6 +104,10 @@ struct hpcla_halo_plan {
     double *ghost = nullptr;    // device, n_ghost * width
     hipStream_t side = nullptr;
     hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+    // contiguity of the caller's (ascending) interior block list, probed once per list
+    const int32_t *probed_list = nullptr;
+    int64_t probed_n = -1, probed_first = -1;
+    bool probed_contig = false;
 };
 
 namespace hpcla {
@@ -324,7 +328,15 @@ HPCLA_API int hpcla_halo_plan_create(hpcla_halo_plan_t **plan, hpcla_comm_t *com
         HALO_HIP(hipMalloc((void **)&p->ghost, p->n_ghost * width * sizeof(double)));
         HALO_HIP(hipMemset(p->ghost, 0, p->n_ghost * width * sizeof(double)));
     }
-    HALO_HIP(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+    {
+        // highest stream priority: the exchange (and the boundary row blocks behind it) must be
+        // dispatched AHEAD of the interior kernel's ~65 000 queued workgroups; at equal priority the
+        // side-stream work only starts when the interior grid has drained (measured: exchange time
+        // added to, instead of hidden under, the interior kernel)
+        int prio_least = 0, prio_greatest = 0;
+        HALO_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+        HALO_HIP(hipStreamCreateWithPriority(&p->side, hipStreamNonBlocking, prio_greatest));
+    }
     HALO_HIP(hipEventCreateWithFlags(&p->ev_ready, hipEventDisableTiming));
     HALO_HIP(hipEventCreateWithFlags(&p->ev_done, hipEventDisableTiming));
 #undef HALO_HIP
@@ -348,7 +360,16 @@ HPCLA_API int hpcla_halo_ghost_ptr(hpcla_halo_plan_t *plan, double **ghost, int6
     return HPCLA_OK;
 }
 
+static int halo_post(hpcla_halo_plan_t *plan, const double *x, void *stream, bool record_done);
+
 HPCLA_API int hpcla_halo_begin(hpcla_halo_plan_t *plan, const double *x, void *stream)
+{
+    return halo_post(plan, x, stream, true);
+}
+
+// posts the exchange on the plan's side stream; with record_done == false the caller enqueues more
+// work on the side stream (the boundary row blocks) and records ev_done itself
+static int halo_post(hpcla_halo_plan_t *plan, const double *x, void *stream, bool record_done)
 {
     if (!plan) return set_error(HPCLA_ERR_INVALID, "halo_begin: null plan");
     if (plan->send_ranks.empty() && plan->recv_ranks.empty()) return HPCLA_OK;
@@ -387,7 +408,7 @@ HPCLA_API int hpcla_halo_begin(hpcla_halo_plan_t *plan, const double *x, void *s
                                      plan->send_ranks[i], nc, plan->side));
     }
     HPCLA_CHECK_RCCL(g_rccl.GroupEnd());
-    HPCLA_CHECK_HIP(hipEventRecord(plan->ev_done, plan->side));
+    if (record_done) HPCLA_CHECK_HIP(hipEventRecord(plan->ev_done, plan->side));
     return HPCLA_OK;
 }
 
@@ -410,23 +431,43 @@ static int spmv_dist_impl(F split_fn, hpcla_halo_plan_t *plan, const I *rowptr, 
     if (!has_halo) {
         // no neighbours: every column is owned; one launch over all row blocks
         return split_fn(rowptr, colval, nzval, x, plan ? plan->ghost : nullptr, n_own, y, nrows,
-                        nnz, index_base, nullptr, 0, stream, dot_partial);
+                        nnz, index_base, nullptr, 0, stream, dot_partial, -1);
     }
     if ((n_interior > 0 && !interior) || (n_boundary > 0 && !boundary))
         return set_error(HPCLA_ERR_INVALID, "spmv_dist: null block list");
-    int rc = hpcla_halo_begin(plan, x, stream);
+    // side stream: exchange, then the boundary row blocks (they need the ghosts); caller's stream:
+    // the interior row blocks, concurrently.  Both write disjoint rows of y; the caller's stream
+    // joins the side stream at the end.
+    int rc = halo_post(plan, x, stream, false);
     if (rc) return rc;
-    if (n_interior > 0) {
+    if (n_boundary > 0) {
         rc = split_fn(rowptr, colval, nzval, x, plan->ghost, n_own, y, nrows, nnz, index_base,
-                      interior, n_interior, stream, dot_partial);
+                      boundary, n_boundary, plan->side, dot_partial, -1);
         if (rc) return rc;
     }
-    rc = hpcla_halo_end(plan, stream);
-    if (rc) return rc;
-    if (n_boundary > 0)
-        rc = split_fn(rowptr, colval, nzval, x, plan->ghost, n_own, y, nrows, nnz, index_base,
-                      boundary, n_boundary, stream, dot_partial);
-    return rc;
+    HPCLA_CHECK_HIP(hipEventRecord(plan->ev_done, plan->side));
+    if (n_interior > 0) {
+        // The interior list is ascending (classify order).  When it is one contiguous run -- every
+        // slab partition -- address the blocks by base: the per-workgroup list load would sit on the
+        // critical path of every workgroup (measured: +30 us per 4096^2 SpMV).  Probed once per list.
+        if (plan->probed_list != interior || plan->probed_n != n_interior) {
+            int32_t ends[2] = {0, 0};
+            HPCLA_CHECK_HIP(hipMemcpy(&ends[0], interior, sizeof(int32_t), hipMemcpyDeviceToHost));
+            HPCLA_CHECK_HIP(hipMemcpy(&ends[1], interior + (n_interior - 1), sizeof(int32_t), hipMemcpyDeviceToHost));
+            plan->probed_list = interior;
+            plan->probed_n = n_interior;
+            plan->probed_first = ends[0];
+            plan->probed_contig = ((int64_t)ends[1] - (int64_t)ends[0] + 1 == n_interior);
+        }
+        if (plan->probed_contig)
+            rc = split_fn(rowptr, colval, nzval, x, plan->ghost, n_own, y, nrows, nnz, index_base,
+                          nullptr, n_interior, stream, dot_partial, plan->probed_first);
+        else
+            rc = split_fn(rowptr, colval, nzval, x, plan->ghost, n_own, y, nrows, nnz, index_base,
+                          interior, n_interior, stream, dot_partial, -1);
+        if (rc) return rc;
+    }
+    return hpcla_halo_end(plan, stream);
 }
 
 // y = A*x and out = x.y in one pass over A (CG's p.Ap): the SpMV workgroups leave per-row-block

@@ -33,7 +33,7 @@ typedef short v8s __attribute__((ext_vector_type(8)));
 
 int spmv_split_i32(const int32_t *, const int32_t *, const double *, const double *, const double *,
                    int64_t, double *, int64_t, int64_t, int, const int32_t *, int64_t, void *,
-                   double *);
+                   double *, int64_t);
 int reduce_partials_sum(const double *partial, int64_t np, double *scratch, double *out,
                         void *stream);
 int allreduce_on(hpcla_comm_t *comm, double *buf, int64_t count, int op, void *stream);
@@ -382,7 +382,7 @@ HPCLA_API int hpcla_spmv_dist_packed_f64_i32(hpcla_halo_plan_t *plan, hpcla_comm
             rc = hpcla_halo_ghost_ptr(plan, &ghost, nullptr);
             if (rc) return rc;
             rc = spmv_split_i32(rowptr, colval_split, nzval, x, ghost, n_own, y, nrows, nnz, index_base,
-                                boundary_blocks, n_boundary, stream, partial);
+                                boundary_blocks, n_boundary, stream, partial, -1);
             if (rc) return rc;
         }
     }

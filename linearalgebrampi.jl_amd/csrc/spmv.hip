@@ -79,12 +79,14 @@ __global__ __launch_bounds__(RPB) void spmv_rowblock_quad_kernel(
     const I *__restrict__ rowptr, const I *__restrict__ colval, const double *__restrict__ nzval,
     const double *__restrict__ x_own, const double *__restrict__ x_ghost, int64_t n_own,
     double *__restrict__ y, int64_t nrows, int64_t nnz, int base,
-    const int32_t *__restrict__ block_list, double *__restrict__ dot_partial)
+    const int32_t *__restrict__ block_list, double *__restrict__ dot_partial, int64_t block_base)
 {
     __shared__ double s_prod[CHUNK];
 
     const int tid = threadIdx.x;
-    const int64_t blk = block_list ? (int64_t)block_list[blockIdx.x] : (int64_t)blockIdx.x;
+    // a contiguous run of row blocks is addressed by its base (no per-workgroup list load on the
+    // critical path rowptr -> A -> x); arbitrary subsets go through the list
+    const int64_t blk = block_list ? (int64_t)block_list[blockIdx.x] : block_base + (int64_t)blockIdx.x;
     const int64_t r0 = blk * RPB;
     const int nr = (int)((nrows - r0) < RPB ? (nrows - r0) : RPB);
 
@@ -179,12 +181,14 @@ __global__ __launch_bounds__(RPB) void spmv_rowblock_kernel(
     const I *__restrict__ rowptr, const I *__restrict__ colval, const double *__restrict__ nzval,
     const double *__restrict__ x_own, const double *__restrict__ x_ghost, int64_t n_own,
     double *__restrict__ y, int64_t nrows, int base, const int32_t *__restrict__ block_list,
-    double *__restrict__ dot_partial)
+    double *__restrict__ dot_partial, int64_t block_base)
 {
     __shared__ double s_prod[CHUNK];
 
     const int tid = threadIdx.x;
-    const int64_t blk = block_list ? (int64_t)block_list[blockIdx.x] : (int64_t)blockIdx.x;
+    // a contiguous run of row blocks is addressed by its base (no per-workgroup list load on the
+    // critical path rowptr -> A -> x); arbitrary subsets go through the list
+    const int64_t blk = block_list ? (int64_t)block_list[blockIdx.x] : block_base + (int64_t)blockIdx.x;
     const int64_t r0 = blk * RPB;
     const int nr = (int)((nrows - r0) < RPB ? (nrows - r0) : RPB);
 
@@ -283,7 +287,7 @@ template <typename I>
 static int spmv_launch(const I *rowptr, const I *colval, const double *nzval, const double *x_own,
                        const double *x_ghost, int64_t n_own, bool split, double *y, int64_t nrows,
                        int64_t nnz, int index_base, const int32_t *block_list, int64_t n_blocks,
-                       void *stream, double *dot_partial = nullptr)
+                       void *stream, double *dot_partial = nullptr, int64_t block_base = -1)
 {
     if (nrows < 0 || nnz < 0) return set_error(HPCLA_ERR_INVALID, "spmv: negative size");
     if (index_base != 0 && index_base != 1)
@@ -298,6 +302,13 @@ static int spmv_launch(const I *rowptr, const I *colval, const double *nzval, co
         if (n_blocks < 0 || n_blocks > all_blocks)
             return set_error(HPCLA_ERR_INVALID, "spmv: n_blocks out of range");
         launch_blocks = n_blocks;
+        block_base = 0;
+    } else if (block_base >= 0) {               // contiguous run [block_base, block_base + n_blocks)
+        if (n_blocks < 0 || block_base + n_blocks > all_blocks)
+            return set_error(HPCLA_ERR_INVALID, "spmv: block range out of bounds");
+        launch_blocks = n_blocks;
+    } else {
+        block_base = 0;
     }
     if (launch_blocks == 0) return HPCLA_OK;
     if (launch_blocks > 0x7fffffffLL) return set_error(HPCLA_ERR_INVALID, "spmv: too many blocks");
@@ -312,19 +323,20 @@ static int spmv_launch(const I *rowptr, const I *colval, const double *nzval, co
         if (split)
             spmv_rowblock_quad_kernel<I, true><<<grid, block, 0, s>>>(
                 rowptr, colval, nzval, x_own, x_ghost, n_own, y, nrows, nnz, index_base, block_list,
-                dot_partial);
+                dot_partial, block_base);
         else
             spmv_rowblock_quad_kernel<I, false><<<grid, block, 0, s>>>(
                 rowptr, colval, nzval, x_own, nullptr, 0, y, nrows, nnz, index_base, block_list,
-                dot_partial);
+                dot_partial, block_base);
     } else {
         if (split)
             spmv_rowblock_kernel<I, true><<<grid, block, 0, s>>>(
                 rowptr, colval, nzval, x_own, x_ghost, n_own, y, nrows, index_base, block_list,
-                dot_partial);
+                dot_partial, block_base);
         else
             spmv_rowblock_kernel<I, false><<<grid, block, 0, s>>>(
-                rowptr, colval, nzval, x_own, nullptr, 0, y, nrows, index_base, block_list, dot_partial);
+                rowptr, colval, nzval, x_own, nullptr, 0, y, nrows, index_base, block_list, dot_partial,
+                block_base);
     }
     HPCLA_CHECK_LAUNCH();
     return HPCLA_OK;
@@ -334,18 +346,18 @@ static int spmv_launch(const I *rowptr, const I *colval, const double *nzval, co
 int spmv_split_i32(const int32_t *rowptr, const int32_t *colval, const double *nzval,
                    const double *x_own, const double *x_ghost, int64_t n_own, double *y,
                    int64_t nrows, int64_t nnz, int index_base, const int32_t *bl, int64_t nb,
-                   void *stream, double *dot_partial)
+                   void *stream, double *dot_partial, int64_t block_base)
 {
     return spmv_launch<int32_t>(rowptr, colval, nzval, x_own, x_ghost, n_own, true, y, nrows, nnz,
-                                index_base, bl, nb, stream, dot_partial);
+                                index_base, bl, nb, stream, dot_partial, block_base);
 }
 int spmv_split_i64(const int64_t *rowptr, const int64_t *colval, const double *nzval,
                    const double *x_own, const double *x_ghost, int64_t n_own, double *y,
                    int64_t nrows, int64_t nnz, int index_base, const int32_t *bl, int64_t nb,
-                   void *stream, double *dot_partial)
+                   void *stream, double *dot_partial, int64_t block_base)
 {
     return spmv_launch<int64_t>(rowptr, colval, nzval, x_own, x_ghost, n_own, true, y, nrows, nnz,
-                                index_base, bl, nb, stream, dot_partial);
+                                index_base, bl, nb, stream, dot_partial, block_base);
 }
 
 }  // namespace hpcla
@@ -377,7 +389,7 @@ HPCLA_API int hpcla_spmv_split_f64_i32(const int32_t *rowptr, const int32_t *col
                                        const int32_t *block_list, int64_t n_blocks, void *stream)
 {
     return spmv_split_i32(rowptr, colval_split, nzval, x_own, x_ghost, n_own, y, nrows, nnz,
-                          index_base, block_list, n_blocks, stream, nullptr);
+                          index_base, block_list, n_blocks, stream, nullptr, -1);
 }
 
 HPCLA_API int hpcla_spmv_split_f64_i64(const int64_t *rowptr, const int64_t *colval_split,
@@ -387,7 +399,7 @@ HPCLA_API int hpcla_spmv_split_f64_i64(const int64_t *rowptr, const int64_t *col
                                        const int32_t *block_list, int64_t n_blocks, void *stream)
 {
     return spmv_split_i64(rowptr, colval_split, nzval, x_own, x_ghost, n_own, y, nrows, nnz,
-                          index_base, block_list, n_blocks, stream, nullptr);
+                          index_base, block_list, n_blocks, stream, nullptr, -1);
 }
 
 template <typename I>

@@ -25,6 +25,11 @@ for st in $STEPS; do
       run 600 gpurun_out/${TAG}_prof.log rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_prof -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline
       tail -3 gpurun_out/${TAG}_prof.log;;
     spgemm) run 600 gpurun_out/${TAG}_spgemm.log python benchmarks/bench_spgemm.py; tail -5 gpurun_out/${TAG}_spgemm.log;;
+    halo)   run 600 gpurun_out/${TAG}_halo.log python benchmarks/bench_halo_overhead.py; tail -5 gpurun_out/${TAG}_halo.log;;
+    halo_ch) for ch in 4 16; do NCCL_MIN_P2P_NCHANNELS=$ch run 600 gpurun_out/${TAG}_halo_ch$ch.log python benchmarks/bench_halo_overhead.py; grep -E 'plain split|halo \+ interior|exchange only' gpurun_out/${TAG}_halo_ch$ch.log; done;;
+    halotrace)
+      run 600 gpurun_out/${TAG}_halotrace.log rocprofv3 --kernel-trace --output-format csv -d gpurun_out/${TAG}_halotrace -- python3 benchmarks/bench_halo_overhead.py
+      tail -2 gpurun_out/${TAG}_halotrace.log;;
     vecops) run 600 gpurun_out/${TAG}_vecops.log python benchmarks/bench_vecops.py; tail -8 gpurun_out/${TAG}_vecops.log;;
     cg)     run 900 gpurun_out/${TAG}_cg.log python bench.py --workload poisson3d_cg --steps 100 --warmup 10; tail -2 gpurun_out/${TAG}_cg.log;;
     cgsmall) run 900 gpurun_out/${TAG}_cgsmall.log python bench.py --workload poisson3d_cg --size 256 --steps 100 --warmup 10; tail -2 gpurun_out/${TAG}_cgsmall.log;;
