@@ -335,6 +335,13 @@ int hpcla_divide_f64(const double *x, double a_host, double *y, int64_t n, void 
 int hpcla_axpby_f64(double a, const double *x, double b, const double *y, double *z, int64_t n,
                     void *stream);
 
+/* ---- sparse A +/- B value pass: the reference's five index-mapped kernels (_copy_a_only_/
+ * _copy_b_only_/_negate_b_only_/_add_both_/_sub_both_kernel!, src/sparse.jl:1258-1303) as one entry:
+ * mode 0 out[dst[i]] = a[a_src[i]]; 1 = -a[a_src[i]]; 2 = a[a_src[i]] + b[b_src[i]]; 3 = a[..] - b[..].
+ * The index lists come from the host AdditionPlan (union of the two sparsity patterns). */
+int hpcla_index_combine_f64(double *out, const double *a, const int64_t *a_src, const double *b,
+                            const int64_t *b_src, const int64_t *dst, int64_t n, int mode, void *stream);
+
 /* ---- synthetic inputs on the device (bench/tests): the SURVEY section 8d counter-based
  * generator, v[i] = u01(seed, start+i). */
 int hpcla_fill_uniform_f64(double *v, int64_t start, int64_t count, uint64_t seed, void *stream);

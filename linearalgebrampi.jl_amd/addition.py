@@ -1,0 +1,96 @@
+"""``A + B`` / ``A - B`` for two HPCSparseMatrix (src/sparse.jl:1072-1494).
+
+Reference: a memoized ``AdditionPlan`` merges the two sparsity patterns on the host (per-row sorted
+union of global columns, structural zeros preserved) and five index-mapped kernels fill the result:
+A-only entries copied, B-only entries copied (or negated), shared entries added (or subtracted)
+(src/sparse.jl:1258-1375).  Here the plan is numpy (same union, same three index groups) and the value
+pass is ``hpcla_index_combine_f64`` -- one rounding per shared entry, so results are bit-identical.
+
+The reference first repartitions B to A's row partition (src/sparse.jl:1407); repartition is out of
+scope here, so both operands must already share the row partition.
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import numpy as np
+
+from . import _capi
+from .backends import assert_backends_compatible
+from .vectors import current_stream_ptr, dptr
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class AdditionPlan:
+    def __init__(self, A, B):
+        from .sparse import _compress_columns
+        torch = _torch()
+        dev = A.backend.torch_device
+        ncols = int(A.col_partition[-1])
+        W = ncols + 1
+        ra, rb = A.rowptr.astype(np.int64), B.rowptr.astype(np.int64)
+        n = A.nrows_local
+        key_a = np.repeat(np.arange(n, dtype=np.int64), np.diff(ra)) * W + A.col_indices[A.colval.astype(np.int64)]
+        key_b = np.repeat(np.arange(n, dtype=np.int64), np.diff(rb)) * W + B.col_indices[B.colval.astype(np.int64)]
+        union = np.union1d(key_a, key_b)                      # sorted: by row, then global column
+        pos_a, pos_b = np.searchsorted(union, key_a), np.searchsorted(union, key_b)
+        inv_a = np.full(len(union), -1, dtype=np.int64); inv_a[pos_a] = np.arange(len(key_a))
+        inv_b = np.full(len(union), -1, dtype=np.int64); inv_b[pos_b] = np.arange(len(key_b))
+        both = np.flatnonzero((inv_a >= 0) & (inv_b >= 0))
+        a_only = np.flatnonzero((inv_a >= 0) & (inv_b < 0))
+        b_only = np.flatnonzero((inv_a < 0) & (inv_b >= 0))
+        up = lambda v: torch.from_numpy(np.ascontiguousarray(v, dtype=np.int64)).to(dev)
+        self.a_only = (up(inv_a[a_only]), up(a_only))
+        self.b_only = (up(inv_b[b_only]), up(b_only))
+        self.both = (up(inv_a[both]), up(inv_b[both]), up(both))
+        self.nnz = len(union)
+        rows_c = union // W
+        self.rowptr = np.concatenate([[0], np.cumsum(np.bincount(rows_c, minlength=n))]).astype(np.int64)
+        cols_glob = union % W
+        Ti = A.backend.Ti.type
+        self.col_indices, self.colval = _compress_columns(cols_glob, ncols, Ti)
+        self.rowptr_ti = self.rowptr.astype(Ti)
+        self.rowptr_dev = torch.from_numpy(self.rowptr_ti).to(dev)
+        self.colval_dev = None
+
+
+_addition_plan_cache: Dict[tuple, AdditionPlan] = {}
+
+
+def clear_addition_plan_cache() -> None:
+    _addition_plan_cache.clear()
+
+
+def _get_addition_plan(A, B) -> AdditionPlan:
+    key = (A._ensure_hash(), B._ensure_hash(), str(A.Ti))          # src/sparse.jl:1384-1395
+    plan = _addition_plan_cache.get(key)
+    if plan is None:
+        plan = _addition_plan_cache[key] = AdditionPlan(A, B)
+    return plan
+
+
+def sparse_add(A, B, subtract: bool = False):
+    """``A + B`` (src/sparse.jl:1405-1445) / ``A - B`` (:1454-1494)."""
+    from .sparse import HPCSparseMatrix
+    torch = _torch()
+    assert_backends_compatible(A.backend, B.backend)
+    if A.shape != B.shape:
+        raise ValueError(f"dimension mismatch: {A.shape} vs {B.shape}")
+    if not np.array_equal(A.row_partition, B.row_partition):
+        raise ValueError("A +/- B: operands must share the row partition (repartition is not implemented on DeviceROCm)")
+    plan = _get_addition_plan(A, B)
+    s = current_stream_ptr()
+    nzval = torch.empty(plan.nnz, dtype=torch.float64, device=A.backend.torch_device)
+    (sa, da), (sb, db), (ba, bb, bd) = plan.a_only, plan.b_only, plan.both
+    _capi.call("hpcla_index_combine_f64", dptr(nzval), dptr(A.nzval), dptr(sa), None, None, dptr(da), int(sa.numel()), 0, s)
+    _capi.call("hpcla_index_combine_f64", dptr(nzval), dptr(B.nzval), dptr(sb), None, None, dptr(db), int(sb.numel()),
+               1 if subtract else 0, s)
+    _capi.call("hpcla_index_combine_f64", dptr(nzval), dptr(A.nzval), dptr(ba), dptr(B.nzval), dptr(bb), dptr(bd),
+               int(ba.numel()), 3 if subtract else 2, s)
+    C = HPCSparseMatrix(A.row_partition, A.col_partition, plan.col_indices, plan.rowptr_ti, plan.colval, nzval,
+                        plan.rowptr_dev, A.backend)
+    return C

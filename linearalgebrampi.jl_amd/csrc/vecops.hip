@@ -340,6 +340,44 @@ HPCLA_API int hpcla_cg_update_f64(hpcla_comm_t *comm, double alpha_host, const d
     return HPCLA_OK;
 }
 
+// index-mapped combine: the five addition kernels of the reference (_copy_a_only_/_copy_b_only_/
+// _negate_b_only_/_add_both_/_sub_both_kernel!, src/sparse.jl:1258-1303) as one entry point.
+// mode 0: out[dst[i]] = a[a_src[i]]          mode 1: out[dst[i]] = -a[a_src[i]]
+// mode 2: out[dst[i]] = a[a_src[i]] + b[b_src[i]]   mode 3: out[dst[i]] = a[a_src[i]] - b[b_src[i]]
+__global__ __launch_bounds__(256) void index_combine_kernel(double *__restrict__ out,
+                                                            const double *__restrict__ a,
+                                                            const int64_t *__restrict__ a_src,
+                                                            const double *__restrict__ b,
+                                                            const int64_t *__restrict__ b_src,
+                                                            const int64_t *__restrict__ dst, int64_t n,
+                                                            int mode)
+{
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (; i < n; i += stride) {
+        const double av = a[a_src[i]];
+        double r;
+        if (mode == 0) r = av;
+        else if (mode == 1) r = -av;
+        else if (mode == 2) r = av + b[b_src[i]];
+        else r = av - b[b_src[i]];
+        out[dst[i]] = r;
+    }
+}
+
+HPCLA_API int hpcla_index_combine_f64(double *out, const double *a, const int64_t *a_src, const double *b,
+                                      const int64_t *b_src, const int64_t *dst, int64_t n, int mode,
+                                      void *stream)
+{
+    if (n < 0 || mode < 0 || mode > 3) return set_error(HPCLA_ERR_INVALID, "index_combine: bad size/mode");
+    if (n == 0) return HPCLA_OK;
+    if (!out || !a || !a_src || !dst || (mode >= 2 && (!b || !b_src)))
+        return set_error(HPCLA_ERR_INVALID, "index_combine: null pointer");
+    index_combine_kernel<<<ew_grid(n), 256, 0, as_stream(stream)>>>(out, a, a_src, b, b_src, dst, n, mode);
+    HPCLA_CHECK_LAUNCH();
+    return HPCLA_OK;
+}
+
 HPCLA_API int hpcla_fill_uniform_f64(double *v, int64_t start, int64_t count, uint64_t seed,
                                      void *stream)
 {

@@ -380,6 +380,18 @@ class HPCSparseMatrix:
 
     __mul__ = __matmul__
 
+    def __add__(self, other):
+        if isinstance(other, HPCSparseMatrix):
+            from .addition import sparse_add
+            return sparse_add(self, other, subtract=False)
+        return NotImplemented
+
+    def __sub__(self, other):
+        if isinstance(other, HPCSparseMatrix):
+            from .addition import sparse_add
+            return sparse_add(self, other, subtract=True)
+        return NotImplemented
+
 
 def _spmv_into(y: HPCVector, A: HPCSparseMatrix, x: HPCVector, plan: VectorPlan) -> None:
     if y.local_length != A.nrows_local:

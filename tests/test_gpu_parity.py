@@ -831,6 +831,37 @@ def test_dense_matvec(hp, orc, gpu_backend_i32):
     hp.clear_dense_plan_cache()
 
 
+def test_sparse_addition_and_subtraction(hp, orc, gpu_backend_i32):
+    """A + B / A - B with different sparsity patterns (test/test_addition_different_sparsity.jl,
+    src/sparse.jl:1405-1494): union structure with structural zeros kept, one rounding per entry."""
+    import scipy.sparse as sp
+    b = gpu_backend_i32
+    n = 3000
+    Ar, Br = orc.sprand_rows(n, 0.004, 0, n), orc.sprand_rows(n, 0.003, 0, n, seed_struct=77, seed_vals=78)
+    # make some shared entries cancel exactly (structural zero must be kept)
+    Br.vals[:50] = 1.0
+    A = hp.HPCSparseMatrix_local(Ar.rowptr, Ar.colidx, Ar.vals, n, b)
+    B = hp.HPCSparseMatrix_local(Br.rowptr, Br.colidx, Br.vals, n, b)
+    As = sp.csr_matrix((Ar.vals, Ar.colidx, Ar.rowptr), shape=(n, n))
+    Bs = sp.csr_matrix((Br.vals, Br.colidx, Br.rowptr), shape=(n, n))
+    pattern = (abs(As) + abs(Bs)).tocsr(); pattern.sort_indices()
+    for op, Cs in (("add", As + Bs), ("sub", As - Bs), ("self_sub", As - As)):
+        C = (A + B) if op == "add" else ((A - B) if op == "sub" else (A - A))
+        rp, col, val = _csr_of(C)
+        want_pat = pattern if op != "self_sub" else As
+        np.testing.assert_array_equal(rp, want_pat.indptr)             # structural zeros preserved
+        np.testing.assert_array_equal(col, want_pat.indices)
+        dense_want = Cs.toarray()
+        got = sp.csr_matrix((val, col, rp), shape=(n, n)).toarray()
+        np.testing.assert_array_equal(got, dense_want)                 # a+b / a-b / copies: exact
+        np.testing.assert_array_equal(C.row_partition, A.row_partition)
+    xg = orc.fill_uniform(0, n, 1)
+    y = ((A + B) @ hp.HPCVector.from_global(xg, b)).local_values()
+    np.testing.assert_allclose(y, (As + Bs) @ xg, rtol=1e-12, atol=1e-13)
+    from hpcla_amd.addition import clear_addition_plan_cache
+    clear_addition_plan_cache()
+
+
 def test_graft_entry_smoke():
     import __graft_entry__ as g
     g.smoke()
