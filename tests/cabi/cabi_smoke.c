@@ -1,0 +1,118 @@
+/* cabi_smoke.c -- a host with NO Python, NO torch drives libhpcla_rocm.so through include/hpcla_rocm.h
+ * only (plain C + the HIP runtime for memory), the way the Julia extension's @ccall stubs do:
+ * generate the 2-D Poisson rows on the device, build the compressed column space on the device,
+ * run y = A*x through the plain CSR entry point AND the distributed entry point (serial communicator,
+ * no neighbours), a dot product and a fused CG update, and compare with a scalar CPU loop.
+ * Build/run: tests/test_cabi_from_c.py (gcc + libamdhip64 for hipMalloc/hipMemcpy only). */
+#include <hip/hip_runtime_api.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "hpcla_rocm.h"
+
+#define CHECK(call)                                                                               \
+    do {                                                                                          \
+        int _s = (call);                                                                          \
+        if (_s != 0) {                                                                            \
+            fprintf(stderr, "%s failed with status %d: %s\n", #call, _s, hpcla_last_error());     \
+            return 1;                                                                             \
+        }                                                                                         \
+    } while (0)
+#define HIPCHECK(call)                                                                            \
+    do {                                                                                          \
+        hipError_t _e = (call);                                                                   \
+        if (_e != hipSuccess) { fprintf(stderr, "%s: %s\n", #call, hipGetErrorString(_e)); return 1; } \
+    } while (0)
+
+int main(void)
+{
+    const int64_t nx = 300, ny = 200, n = nx * ny;
+    int ndev = 0;
+    CHECK(hpcla_device_count(&ndev));
+    CHECK(hpcla_set_device(0));
+    char arch[64];
+    int cus = 0;
+    CHECK(hpcla_device_info(0, &cus, arch, sizeof(arch)));
+    printf("device 0: %s, %d CUs, library version %d\n", arch, cus, hpcla_version());
+
+    /* matrix on the device */
+    const int64_t nnz = hpcla_poisson2d_nnz(nx, ny, 0, n);
+    int64_t *rp64, *colg, *col_indices;
+    int32_t *rowptr, *colval;
+    double *vals, *x, *y, *y2, *z, *scal;
+    void *work;
+    HIPCHECK(hipMalloc((void **)&rp64, (n + 1) * 8));
+    HIPCHECK(hipMalloc((void **)&colg, nnz * 8));
+    HIPCHECK(hipMalloc((void **)&vals, nnz * 8));
+    CHECK(hpcla_gen_poisson2d(nx, ny, 0, n, rp64, colg, vals, NULL));
+    HIPCHECK(hipMalloc(&work, hpcla_colspace_work_bytes(n)));
+    HIPCHECK(hipMalloc((void **)&colval, nnz * 4));
+    HIPCHECK(hipMalloc((void **)&col_indices, n * 8));
+    int64_t ncomp = 0;
+    CHECK(hpcla_compress_columns_i32(colg, nnz, 0, n, colval, 0, col_indices, &ncomp, work, NULL));
+    if (ncomp != n) { fprintf(stderr, "ncols_compressed %lld != %lld\n", (long long)ncomp, (long long)n); return 1; }
+
+    /* host copies for the reference loop; rowptr as int32 */
+    int64_t *h_rp = (int64_t *)malloc((n + 1) * 8), *h_col = (int64_t *)malloc(nnz * 8);
+    double *h_val = (double *)malloc(nnz * 8), *h_x = (double *)malloc(n * 8), *h_y = (double *)malloc(n * 8);
+    int32_t *h_rp32 = (int32_t *)malloc((n + 1) * 4);
+    HIPCHECK(hipMemcpy(h_rp, rp64, (n + 1) * 8, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(h_col, colg, nnz * 8, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(h_val, vals, nnz * 8, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i <= n; ++i) h_rp32[i] = (int32_t)h_rp[i];
+    HIPCHECK(hipMalloc((void **)&rowptr, (n + 1) * 4));
+    HIPCHECK(hipMemcpy(rowptr, h_rp32, (n + 1) * 4, hipMemcpyHostToDevice));
+
+    HIPCHECK(hipMalloc((void **)&x, n * 8));
+    HIPCHECK(hipMalloc((void **)&y, n * 8));
+    HIPCHECK(hipMalloc((void **)&y2, n * 8));
+    HIPCHECK(hipMalloc((void **)&z, n * 8));
+    HIPCHECK(hipMemset(z, 0, n * 8));
+    HIPCHECK(hipMalloc((void **)&scal, 4 * 8));
+    CHECK(hpcla_fill_uniform_f64(x, 0, n, 0xC0FFEEULL, NULL));
+    HIPCHECK(hipMemcpy(h_x, x, n * 8, hipMemcpyDeviceToHost));
+
+    /* (1) plain CSR entry point */
+    CHECK(hpcla_spmv_csr_f64_i32(rowptr, colval, vals, x, y, n, nnz, 0, NULL));
+    /* (2) distributed entry point, serial communicator, no halo plan */
+    hpcla_comm_t *comm = NULL;
+    CHECK(hpcla_comm_init_rank(&comm, NULL, 1, 0));
+    CHECK(hpcla_spmv_dist_f64_i32(NULL, rowptr, colval, vals, x, n, y2, n, nnz, 0, NULL, 0, NULL, 0, NULL));
+    HIPCHECK(hipDeviceSynchronize());
+    HIPCHECK(hipMemcpy(h_y, y, n * 8, hipMemcpyDeviceToHost));
+    double *h_y2 = (double *)malloc(n * 8);
+    HIPCHECK(hipMemcpy(h_y2, y2, n * 8, hipMemcpyDeviceToHost));
+    int64_t bad = 0;
+    double dot_ref = 0.0;
+    for (int64_t r = 0; r < n; ++r) {
+        double acc = 0.0;                                  /* the reference loop, src/sparse.jl:2055-2066 */
+        for (int64_t j = h_rp[r]; j < h_rp[r + 1]; ++j) acc += h_val[j] * h_x[h_col[j]];
+        if (memcmp(&acc, &h_y[r], 8) != 0 || memcmp(&acc, &h_y2[r], 8) != 0) ++bad;
+        dot_ref += h_x[r] * acc;
+    }
+    if (bad) { fprintf(stderr, "SpMV mismatch in %lld rows\n", (long long)bad); return 1; }
+
+    /* (3) dot with the device-resident scalar, (4) fused CG update */
+    void *rwork;
+    HIPCHECK(hipMalloc(&rwork, hpcla_reduce_work_bytes()));
+    CHECK(hpcla_dot_f64(comm, x, y, n, scal, rwork, NULL));
+    double h_s[2];
+    HIPCHECK(hipMemcpy(h_s, scal, 8, hipMemcpyDeviceToHost));
+    if (fabs(h_s[0] - dot_ref) > 1e-12 * fabs(dot_ref) + 1e-9) { fprintf(stderr, "dot %g vs %g\n", h_s[0], dot_ref); return 1; }
+    CHECK(hpcla_cg_update_f64(comm, 0.5, NULL, NULL, x, y2, z, y, n, scal + 1, rwork, NULL)); /* z += .5x ; y -= .5*y2 */
+    HIPCHECK(hipMemcpy(h_s + 1, scal + 1, 8, hipMemcpyDeviceToHost));
+    double rr_ref = 0.0;
+    for (int64_t r = 0; r < n; ++r) { const double rn = h_y[r] - 0.5 * h_y[r]; rr_ref += rn * rn; }
+    if (fabs(h_s[1] - rr_ref) > 1e-12 * rr_ref) { fprintf(stderr, "cg_update rr %g vs %g\n", h_s[1], rr_ref); return 1; }
+
+    /* error convention: negative status + message, never abort */
+    if (hpcla_spmv_csr_f64_i32(NULL, NULL, NULL, NULL, NULL, 5, 5, 0, NULL) != HPCLA_ERR_INVALID ||
+        strlen(hpcla_last_error()) == 0) { fprintf(stderr, "error convention broken\n"); return 1; }
+    CHECK(hpcla_comm_destroy(comm));
+    printf("C-ABI smoke PASS: n=%lld nnz=%lld, SpMV bit-identical to the scalar loop on both entry points\n",
+           (long long)n, (long long)nnz);
+    return 0;
+}
