@@ -190,6 +190,15 @@ int hpcla_transpose_f64(const double *src, int64_t ld_src, int src_layout, doubl
 int hpcla_gemv_rowmajor_f64(const double *A, int64_t lda, int64_t nrows, const double *x_lo, int64_t n_lo,
                             const double *x_own, int64_t n_own, const double *x_hi, int64_t n_hi,
                             double *y, void *stream);
+/* transpose(A) * x for the dense row-partitioned A (Base.:*(At::Transpose{T,HPCMatrix}, x),
+ * src/dense.jl:1210-1261): y_full[j] = sum_i A[i*lda + j] * x[i] over the LOCAL rows, all ncols
+ * columns (the per-rank partial the reference all-reduces: follow with hpcla_allreduce_f64 and keep the
+ * own column slice).  x is the slice of the vector on A's ROW partition.  `work`: device scratch of
+ * hpcla_gemv_t_work_bytes(nrows, ncols) bytes.  Deterministic two-stage column sums. */
+int64_t hpcla_gemv_t_work_bytes(int64_t nrows, int64_t ncols);
+int hpcla_gemv_t_rowmajor_f64(const double *A, int64_t lda, int64_t nrows, int64_t ncols, const double *x,
+                              double *y_full, void *work, void *stream);
+
 
 /* ---- gather: replaces _gather_kernel! (src/vectors.jl:174-194) --------------------------------
  * out[dst[i]] = x[src[i]] (dst may be NULL = identity).  Kept for API parity
@@ -213,6 +222,21 @@ int hpcla_comm_destroy(hpcla_comm_t *comm);
 /* in-place all-reduce of `count` doubles on `stream`: op 0 = sum, 1 = max
  * (comm_allreduce(comm, x, + | max), src/backends.jl:264-277). */
 int hpcla_allreduce_f64(hpcla_comm_t *comm, double *buf, int64_t count, int op, void *stream);
+
+/* Contiguous-range exchange: device form of execute_plan!(::VectorRepartitionPlan)
+ * (src/vectors.jl:624-671; plan lists :511-620), of the dense row repartition (src/dense.jl:1711-1760)
+ * and of the nzval leg of the sparse repartition (src/sparse.jl:4443-4535).  For each i < n_send the
+ * range src[send_offsets[i] .. +send_counts[i]) goes to send_ranks[i]; for each i < n_recv,
+ * recv_counts[i] units from recv_ranks[i] land at dst + recv_offsets[i]; the part that stays
+ * (local_src_range / local_dst_offset of the reference plan) is one device copy.  All offsets and
+ * counts are 0-based and in units of `width` doubles (1 for vectors and nzval, ncols for row-major
+ * dense rows).  Lists are HOST arrays; src/dst are device pointers; one ncclGroup on `stream`. */
+int hpcla_exchange_ranges_f64(hpcla_comm_t *comm, const double *src, double *dst, int n_send,
+                              const int *send_ranks, const int64_t *send_offsets,
+                              const int64_t *send_counts, int n_recv, const int *recv_ranks,
+                              const int64_t *recv_offsets, const int64_t *recv_counts,
+                              int64_t local_src_offset, int64_t local_dst_offset, int64_t local_count,
+                              int width, void *stream);
 
 /* ---- halo plan: device half of VectorPlan / execute_plan! (src/vectors.jl:229-251, 394-463)
  * Inputs are the reference plan's own lists (0-based here):

@@ -10,6 +10,7 @@ Layout
   sparse.py          HPCSparseMatrix, VectorPlan (host lists + device plan), A*x, mul!
   dense.py           HPCMatrix, A*B (SpMM)
   cg.py              fixed-iteration CG harness
+  transpose.py matmat.py addition.py repartition.py   the SURVEY 8f "next" rows and their plans
 
 The directory name contains a dot, so it is imported through the top-level alias module
 ``hpcla_amd`` (``import hpcla_amd as hp``).
@@ -26,9 +27,14 @@ from .sparse import (HPCSparseMatrix, HPCSparseMatrix_from_global, HPCSparseMatr
                      HPCSparseMatrix_local_device,
                      HostVectorPlan, VectorPlan, build_host_vector_plan, cache_sizes,
                      clear_plan_cache, execute_plan, get_vector_plan, mul_, mul_dot_, split_column_map)
-from .dense import HPCMatrix, HPCMatrix_local, clear_dense_plan_cache, clear_spmm_cache, dense_matvec, spmm
+from .dense import (HPCMatrix, HPCMatrix_local, TransposedHPCMatrix, clear_dense_plan_cache, clear_spmm_cache,
+                    dense_matvec, dense_matvec_t, spmm)
 from .matmat import clear_matrix_plan_cache, get_matrix_plan, spgemm
 from .cg import cg_fixed_iterations
-from .transpose import TransposedHPCSparseMatrix, transpose, transpose_local_rows
+from .transpose import (TransposedHPCSparseMatrix, TransposedHPCVector, adjoint, transpose,
+                        transpose_local_rows)
+from .addition import sparse_add
+from .repartition import (RangePlan, SparseRepartitionPlan, clear_repartition_cache, exchange_ranges,
+                          get_sparse_repartition_plan, get_vector_repartition_plan, repartition)
 
 __all__ = [n for n in dir() if not n.startswith("_")] + ["_capi"]

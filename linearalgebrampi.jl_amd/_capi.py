@@ -62,6 +62,7 @@ _SIGNATURES = {
     "hpcla_comm_size": [_vp, _vp],
     "hpcla_comm_destroy": [_vp],
     "hpcla_allreduce_f64": [_vp, _vp, _i64, _i32, _vp],
+    "hpcla_exchange_ranges_f64": [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp],
     "hpcla_halo_plan_create": [_vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32],
     "hpcla_halo_plan_destroy": [_vp],
     "hpcla_halo_ghost_ptr": [_vp, _vp, _vp],
@@ -79,6 +80,8 @@ _SIGNATURES = {
     "hpcla_poisson2d_nnz": [_i64, _i64, _i64, _i64],
     "hpcla_gen_poisson2d": [_i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp],
     "hpcla_gemv_rowmajor_f64": [_vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp],
+    "hpcla_gemv_t_work_bytes": [_i64, _i64],
+    "hpcla_gemv_t_rowmajor_f64": [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp],
     "hpcla_spgemm_bin_cap": [_i32],
     "hpcla_spgemm_ub_i32": [_vp, _vp, _i64, _i32, _vp, _vp, _vp],
     "hpcla_spgemm_ub_i64": [_vp, _vp, _i64, _i32, _vp, _vp, _vp],
@@ -111,6 +114,7 @@ _RESTYPES = {
     "hpcla_colspace_work_bytes": _i64,
     "hpcla_poisson2d_nnz": _i64,
     "hpcla_spgemm_bin_cap": _i64,
+    "hpcla_gemv_t_work_bytes": _i64,
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -6,8 +6,8 @@ A-only entries copied, B-only entries copied (or negated), shared entries added 
 (src/sparse.jl:1258-1375).  Here the plan is numpy (same union, same three index groups) and the value
 pass is ``hpcla_index_combine_f64`` -- one rounding per shared entry, so results are bit-identical.
 
-The reference first repartitions B to A's row partition (src/sparse.jl:1407); repartition is out of
-scope here, so both operands must already share the row partition.
+Like the reference (src/sparse.jl:1407, 1456) B is first repartitioned to A's row partition when the
+two differ (repartition.py: structure on the host at plan time, values device to device).
 """
 from __future__ import annotations
 
@@ -81,7 +81,8 @@ def sparse_add(A, B, subtract: bool = False):
     if A.shape != B.shape:
         raise ValueError(f"dimension mismatch: {A.shape} vs {B.shape}")
     if not np.array_equal(A.row_partition, B.row_partition):
-        raise ValueError("A +/- B: operands must share the row partition (repartition is not implemented on DeviceROCm)")
+        from .repartition import repartition_sparse
+        B = repartition_sparse(B, A.row_partition)                  # src/sparse.jl:1407, 1456
     plan = _get_addition_plan(A, B)
     s = current_stream_ptr()
     nzval = torch.empty(plan.nnz, dtype=torch.float64, device=A.backend.torch_device)

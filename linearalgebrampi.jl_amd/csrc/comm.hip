@@ -225,6 +225,62 @@ HPCLA_API int hpcla_allreduce_f64(hpcla_comm_t *comm, double *buf, int64_t count
     return allreduce_on(comm, buf, count, op, stream);
 }
 
+// ---- contiguous-range exchange (repartition plans) -----------------------------------------------
+// Device form of execute_plan!(::VectorRepartitionPlan) (src/vectors.jl:624-671) and of the dense /
+// sparse-values repartitions (src/dense.jl:1711-1760, src/sparse.jl:4443-4535): every message is a
+// contiguous range of the source, every receive lands at a fixed offset of the result, so there is
+// nothing to pack or unpack -- one ncclGroup between the callers' buffers plus one device copy for
+// the part that stays.  Offsets and counts are in units of `width` doubles (1 for vectors / nzval,
+// ncols for row-major dense rows).
+HPCLA_API int hpcla_exchange_ranges_f64(hpcla_comm_t *comm, const double *src, double *dst,
+                                        int n_send, const int *send_ranks,
+                                        const int64_t *send_offsets, const int64_t *send_counts,
+                                        int n_recv, const int *recv_ranks,
+                                        const int64_t *recv_offsets, const int64_t *recv_counts,
+                                        int64_t local_src_offset, int64_t local_dst_offset,
+                                        int64_t local_count, int width, void *stream)
+{
+    if (!comm) return set_error(HPCLA_ERR_INVALID, "exchange_ranges: null communicator");
+    if (n_send < 0 || n_recv < 0 || local_count < 0 || width < 1)
+        return set_error(HPCLA_ERR_INVALID, "exchange_ranges: bad counts/width");
+    if ((n_send > 0 && (!send_ranks || !send_offsets || !send_counts)) ||
+        (n_recv > 0 && (!recv_ranks || !recv_offsets || !recv_counts)))
+        return set_error(HPCLA_ERR_INVALID, "exchange_ranges: null list");
+    for (int i = 0; i < n_send; ++i)
+        if (send_ranks[i] < 0 || send_ranks[i] >= comm->nranks || send_offsets[i] < 0 || send_counts[i] < 0)
+            return set_error(HPCLA_ERR_INVALID, "exchange_ranges: bad send entry %d", i);
+    for (int i = 0; i < n_recv; ++i)
+        if (recv_ranks[i] < 0 || recv_ranks[i] >= comm->nranks || recv_offsets[i] < 0 || recv_counts[i] < 0)
+            return set_error(HPCLA_ERR_INVALID, "exchange_ranges: bad recv entry %d", i);
+    if ((n_send > 0 || local_count > 0) && !src)
+        return set_error(HPCLA_ERR_INVALID, "exchange_ranges: null source");
+    if ((n_recv > 0 || local_count > 0) && !dst)
+        return set_error(HPCLA_ERR_INVALID, "exchange_ranges: null destination");
+    hipStream_t s = as_stream(stream);
+    if (local_count > 0)
+        HPCLA_CHECK_HIP(hipMemcpyAsync(dst + local_dst_offset * width, src + local_src_offset * width,
+                                       (size_t)local_count * width * sizeof(double),
+                                       hipMemcpyDeviceToDevice, s));
+    if (n_send == 0 && n_recv == 0) return HPCLA_OK;
+    if (!comm->nccl)
+        return set_error(HPCLA_ERR_INVALID, "exchange_ranges: messages on a serial communicator");
+    HPCLA_CHECK_RCCL(g_rccl.GroupStart());
+    for (int i = 0; i < n_recv; ++i)
+        if (recv_counts[i] > 0) {
+            ncclResult_t r = g_rccl.Recv(dst + recv_offsets[i] * width, (size_t)recv_counts[i] * width,
+                                         ncclDouble, recv_ranks[i], comm->nccl, s);
+            if (r != ncclSuccess) { (void)g_rccl.GroupEnd(); return set_error(HPCLA_ERR_RCCL, "ncclRecv failed: %s", g_rccl.GetErrorString(r)); }
+        }
+    for (int i = 0; i < n_send; ++i)
+        if (send_counts[i] > 0) {
+            ncclResult_t r = g_rccl.Send(src + send_offsets[i] * width, (size_t)send_counts[i] * width,
+                                         ncclDouble, send_ranks[i], comm->nccl, s);
+            if (r != ncclSuccess) { (void)g_rccl.GroupEnd(); return set_error(HPCLA_ERR_RCCL, "ncclSend failed: %s", g_rccl.GetErrorString(r)); }
+        }
+    HPCLA_CHECK_RCCL(g_rccl.GroupEnd());
+    return HPCLA_OK;
+}
+
 // ---- halo plan ----------------------------------------------------------------------------------
 static void halo_free(hpcla_halo_plan *p)
 {

@@ -54,9 +54,115 @@ __global__ __launch_bounds__(256) void gemv_rowmajor_kernel(const double *__rest
     if (lane == 0) y[row] = acc;
 }
 
+// ---- y_partial = A_local^T * x_local (transpose(A) * x, src/dense.jl:1210-1261) -------------------
+// The reference multiplies the local block transposed by the local slice of x and all-reduces the
+// ncols partial sums on the host.  Row-major A: consecutive columns are consecutive addresses, so a
+// wavefront covers W = min(64, pow2 >= ncols) columns x (64/W) rows per pass (a tall-skinny block
+// with ncols == W is then read as one contiguous stream); 4 wavefronts per workgroup interleave rows.
+// Deterministic: fixed-order LDS reduction per workgroup into partial[chunk][col], then stage 2 sums
+// the chunks in ascending order.  HBM-bound: 8 B per matrix entry, x re-read once per column tile.
+constexpr int GEMVT_THREADS = 256;
+
+__global__ __launch_bounds__(GEMVT_THREADS) void gemv_t_stage1(const double *__restrict__ A, int64_t lda,
+                                                               int64_t nrows, int64_t ncols,
+                                                               const double *__restrict__ x, int W,
+                                                               int64_t rows_per_chunk,
+                                                               double *__restrict__ partial)
+{
+    __shared__ double red[GEMVT_THREADS];
+    const int tid = threadIdx.x;
+    const int c = tid % W;               // column within the tile
+    const int rl = tid / W;              // row phase, 0 .. 256/W - 1
+    const int rstep = GEMVT_THREADS / W;
+    const int64_t col = (int64_t)blockIdx.x * W + c;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
+    const int64_t r1 = min(nrows, r0 + rows_per_chunk);
+    double acc = 0.0;
+    if (col < ncols) {
+        int64_t r = r0 + rl;
+        for (; r + 3 * rstep < r1; r += 4 * rstep) {      // 4 independent loads in flight
+            const double a0 = A[r * lda + col], a1 = A[(r + rstep) * lda + col];
+            const double a2 = A[(r + 2 * rstep) * lda + col], a3 = A[(r + 3 * rstep) * lda + col];
+            const double x0 = x[r], x1 = x[r + rstep], x2 = x[r + 2 * rstep], x3 = x[r + 3 * rstep];
+            acc += a0 * x0;
+            acc += a1 * x1;
+            acc += a2 * x2;
+            acc += a3 * x3;
+        }
+        for (; r < r1; r += rstep) acc += A[r * lda + col] * x[r];
+    }
+    red[tid] = acc;
+    __syncthreads();
+    if (tid < W && col < ncols) {
+        double s = red[tid];
+        for (int k = 1; k < rstep; ++k) s += red[k * W + tid];   // ascending row phase
+        partial[(int64_t)blockIdx.y * ncols + col] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void gemv_t_stage2(const double *__restrict__ partial, int64_t nchunks,
+                                                     int64_t ncols, double *__restrict__ y)
+{
+    const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= ncols) return;
+    double s = 0.0;
+    for (int64_t k = 0; k < nchunks; ++k) s += partial[k * ncols + col];
+    y[col] = s;
+}
+
+static int64_t gemv_t_rows_per_chunk(int64_t nrows, int64_t ncols)
+{
+    // enough workgroups to fill 256 CUs several times over, but chunks of at least 64 rows
+    int W = 1;
+    while (W < 64 && W < ncols) W <<= 1;
+    const int64_t tiles = (ncols + W - 1) / W;
+    int64_t want_chunks = (4096 + tiles - 1) / (tiles > 0 ? tiles : 1);
+    if (want_chunks < 1) want_chunks = 1;
+    int64_t rpc = (nrows + want_chunks - 1) / want_chunks;
+    if (rpc < 64) rpc = 64;
+    return rpc;
+}
+
 }  // namespace hpcla
 
 using namespace hpcla;
+
+HPCLA_API int64_t hpcla_gemv_t_work_bytes(int64_t nrows, int64_t ncols)
+{
+    if (nrows <= 0 || ncols <= 0) return 8;
+    const int64_t rpc = gemv_t_rows_per_chunk(nrows, ncols);
+    const int64_t nchunks = (nrows + rpc - 1) / rpc;
+    return nchunks * ncols * (int64_t)sizeof(double);
+}
+
+HPCLA_API int hpcla_gemv_t_rowmajor_f64(const double *A, int64_t lda, int64_t nrows, int64_t ncols,
+                                        const double *x, double *y_full, void *work, void *stream)
+{
+    if (nrows < 0 || ncols < 0 || lda < ncols) return set_error(HPCLA_ERR_INVALID, "gemv_t: bad sizes");
+    if (ncols == 0) return HPCLA_OK;
+    if (!y_full) return set_error(HPCLA_ERR_INVALID, "gemv_t: null output");
+    hipStream_t s = as_stream(stream);
+    if (nrows == 0) {                                     // empty local block: the partial sum is zero
+        HPCLA_CHECK_HIP(hipMemsetAsync(y_full, 0, (size_t)ncols * sizeof(double), s));
+        return HPCLA_OK;
+    }
+    if (!A || !x || !work) return set_error(HPCLA_ERR_INVALID, "gemv_t: null pointer");
+    int W = 1;
+    while (W < 64 && W < ncols) W <<= 1;
+    const int64_t rpc = gemv_t_rows_per_chunk(nrows, ncols);
+    const int64_t nchunks = (nrows + rpc - 1) / rpc;
+    const int64_t tiles = (ncols + W - 1) / W;
+    if (nchunks > 65535 || tiles > 0x7fffffff) return set_error(HPCLA_ERR_UNSUPPORTED, "gemv_t: grid too large");
+    gemv_t_stage1<<<dim3((uint32_t)tiles, (uint32_t)nchunks), GEMVT_THREADS, 0, s>>>(
+        A, lda, nrows, ncols, x, W, rpc, static_cast<double *>(work));
+    HPCLA_CHECK_LAUNCH();
+    gemv_t_stage2<<<(uint32_t)((ncols + 255) / 256), 256, 0, s>>>(static_cast<const double *>(work), nchunks,
+                                                                ncols, y_full);
+    HPCLA_CHECK_LAUNCH();
+    return HPCLA_OK;
+}
+
+
 
 HPCLA_API int hpcla_gemv_rowmajor_f64(const double *A, int64_t lda, int64_t nrows, const double *x_lo,
                                       int64_t n_lo, const double *x_own, int64_t n_own,

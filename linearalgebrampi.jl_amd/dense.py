@@ -180,6 +180,55 @@ def dense_matvec(A: HPCMatrix, x, y=None):
     return y
 
 
+class TransposedHPCMatrix:
+    """Lazy ``transpose(A)`` of a dense HPCMatrix (``Transpose(A)``, src/dense.jl:952)."""
+
+    def __init__(self, parent: HPCMatrix):
+        self.parent = parent
+
+    @property
+    def shape(self):
+        m, n = self.parent.shape
+        return n, m
+
+    def __matmul__(self, x):
+        from .vectors import HPCVector
+        if isinstance(x, HPCVector):
+            return dense_matvec_t(self.parent, x)
+        return NotImplemented
+
+    __mul__ = __matmul__
+
+
+def dense_matvec_t(A: HPCMatrix, x):
+    """``transpose(A) * x`` without materialising the transpose (src/dense.jl:1210-1261).  The reference
+    gathers x onto A's row partition through a DenseTransposeVectorPlan (CPU-staged), multiplies the
+    local block transposed, all-reduces the ncols partial sums on the host and keeps the own column
+    slice.  Here: x is aligned to ``A.row_partition`` device to device (repartition.py; a no-op when
+    it already is), ``hpcla_gemv_t_rowmajor_f64`` forms the partial column sums, RCCL all-reduces them
+    in place, and the own slice of ``A.col_partition`` is the result."""
+    from .repartition import repartition_vector
+    from .vectors import HPCVector
+    torch = _torch()
+    assert_backends_compatible(A.backend, x.backend)
+    backend = A.backend
+    rank = comm_rank(backend.comm)
+    nloc, ncols = int(A.A.shape[0]), int(A.A.shape[1])
+    if int(x.partition[-1]) != int(A.row_partition[-1]):
+        raise ValueError(f"dimension mismatch: transpose(A) has {int(A.row_partition[-1])} columns, "
+                         f"x has length {int(x.partition[-1])}")
+    xa = repartition_vector(x, A.row_partition)
+    dev = backend.torch_device
+    full = torch.empty(ncols, dtype=torch.float64, device=dev)
+    work = torch.empty(max(1, _capi.load().hpcla_gemv_t_work_bytes(nloc, ncols) // 8), dtype=torch.float64, device=dev)
+    Ac = A.A if A.A.is_contiguous() else A.A.contiguous()
+    s = current_stream_ptr()
+    _capi.call("hpcla_gemv_t_rowmajor_f64", dptr(Ac), ncols, nloc, ncols, dptr(xa.v), dptr(full), dptr(work), s)
+    _capi.call("hpcla_allreduce_f64", backend.rccl, dptr(full), ncols, 0, s)
+    lo, hi = int(A.col_partition[rank]), int(A.col_partition[rank + 1])
+    return HPCVector(compute_partition_hash(A.col_partition), A.col_partition.copy(), full[lo:hi].clone(), backend)
+
+
 # width-k halo plans hang off the same key as the vector plan, plus k
 _spmm_halo_cache: Dict[tuple, object] = {}
 

@@ -98,5 +98,70 @@ class TransposedHPCSparseMatrix:
     __mul__ = __matmul__
 
 
-def transpose(A) -> TransposedHPCSparseMatrix:
+class TransposedHPCVector:
+    """``transpose(v)`` / ``v'`` for a real HPCVector (``Transpose{T,HPCVector}``, src/vectors.jl:735-746):
+    a lazy row-vector view; ``.parent`` is the column vector.  Supports the reference's row-vector
+    algebra: ``vt @ A`` (src/sparse.jl:2136-2142, src/dense.jl:1270-1274), ``vt @ w`` (the inner product ``dot``),
+    ``a*vt``, ``vt*a``, ``vt/a``, ``vt ± wt``, ``-vt`` (src/vectors.jl:909-940, 969-987)."""
+
+    def __init__(self, parent):
+        self.parent = parent
+
+    @property
+    def shape(self):
+        return (1, len(self.parent))
+
+    def __matmul__(self, other):
+        from .dense import HPCMatrix, dense_matvec_t
+        from .sparse import HPCSparseMatrix
+        from .vectors import HPCVector, dot
+        if isinstance(other, HPCMatrix):                             # src/dense.jl:1270-1274
+            return TransposedHPCVector(dense_matvec_t(other, self.parent))
+        if isinstance(other, HPCSparseMatrix):                       # transpose(transpose(A) * v)
+            return TransposedHPCVector(TransposedHPCSparseMatrix(other) @ self.parent)
+        if isinstance(other, TransposedHPCSparseMatrix):             # vt * transpose(A) = transpose(A * v)
+            return TransposedHPCVector(other.parent @ self.parent)
+        if isinstance(other, HPCVector):
+            return dot(self.parent, other)
+        return NotImplemented
+
+    def __mul__(self, a):
+        if isinstance(a, (int, float, np.floating, np.integer)):
+            return TransposedHPCVector(self.parent * float(a))
+        return self.__matmul__(a)
+
+    def __rmul__(self, a):
+        return TransposedHPCVector(self.parent * float(a))
+
+    def __truediv__(self, a):
+        return TransposedHPCVector(self.parent / float(a))
+
+    def __add__(self, other):
+        if not isinstance(other, TransposedHPCVector):
+            return NotImplemented
+        return TransposedHPCVector(self.parent + other.parent)
+
+    def __sub__(self, other):
+        if not isinstance(other, TransposedHPCVector):
+            return NotImplemented
+        return TransposedHPCVector(self.parent - other.parent)
+
+    def __neg__(self):
+        return TransposedHPCVector(-self.parent)
+
+
+def transpose(A):
+    """``transpose(x)``: lazy for HPCSparseMatrix and HPCVector; the transpose of a lazy transpose is the
+    parent (the element type is real, so ``adjoint`` is the same thing)."""
+    from .dense import HPCMatrix, TransposedHPCMatrix
+    from .vectors import HPCVector
+    if isinstance(A, (TransposedHPCSparseMatrix, TransposedHPCVector, TransposedHPCMatrix)):
+        return A.parent
+    if isinstance(A, HPCVector):
+        return TransposedHPCVector(A)
+    if isinstance(A, HPCMatrix):
+        return TransposedHPCMatrix(A)
     return TransposedHPCSparseMatrix(A)
+
+
+adjoint = transpose

@@ -124,16 +124,27 @@ class HPCVector:
 
     # -- checks -------------------------------------------------------------------------------------
     def _same_partition(self, other: "HPCVector") -> None:
+        """In-place / fused updates write into their operands and so need equal partitions."""
         assert_backends_compatible(self.backend, other.backend)
         if self.structural_hash != other.structural_hash:
-            # the reference silently repartitions here (src/vectors.jl:803-811, 870-876); the ROCm
-            # path requires equal partitions (may error for v0)
-            raise ValueError("HPCVector operands have different partitions; repartition is not "
-                             "implemented on DeviceROCm")
+            raise ValueError("HPCVector operands of an in-place update have different partitions; "
+                             "repartition(v, u.partition) first")
+
+    def _aligned(self, other: "HPCVector") -> "HPCVector":
+        """``other`` on MY partition: the reference repartitions the second operand of ``u+v``,
+        ``u-v`` and ``dot(x,y)`` when the partition hashes differ (src/vectors.jl:803-811, 870-876,
+        887-893); here over RCCL, device to device (repartition.py)."""
+        assert_backends_compatible(self.backend, other.backend)
+        if self.structural_hash == other.structural_hash:
+            return other
+        if len(self) != len(other):
+            raise ValueError(f"HPCVector length mismatch: {len(self)} vs {len(other)}")
+        from .repartition import repartition_vector
+        return repartition_vector(other, self.partition)
 
     # -- elementwise: u+v, u-v, -v, a*v, v/a (src/vectors.jl:868-903, 944-964) -----------------------
     def _axpby(self, a: float, other: "HPCVector", b: float) -> "HPCVector":
-        self._same_partition(other)
+        other = self._aligned(other)
         out = self.similar()
         _capi.call("hpcla_axpby_f64", float(a), dptr(self.v), float(b), dptr(other.v), dptr(out.v),
                    self.local_length, current_stream_ptr())
@@ -226,7 +237,7 @@ def _reduce(kind: str, x: HPCVector, y: Optional[HPCVector], out=None):
 def dot(x: HPCVector, y: HPCVector, out=None):
     """``dot(x, y)`` (src/vectors.jl:798-812).  Returns a Python float (host sync), or, when ``out``
     (1-element device tensor) is given, leaves the result on the device and returns ``out``."""
-    x._same_partition(y)
+    y = x._aligned(y)
     r = _reduce("dot", x, y, out)
     return r if out is not None else float(r.item())
 

@@ -128,6 +128,47 @@ def main():
         g_val[dst:dst + len(b)] = b.numpy()
     np.testing.assert_array_equal(g_val, want_g.data)
 
+    # repartition plans (src/vectors.jl:470-722, src/sparse.jl:4069-4600): range lists drive a gloo
+    # exchange that must reproduce the global object sliced by the target partition
+    from types import SimpleNamespace
+    from hpcla_amd.repartition import RangePlan, SparseRepartitionPlan
+
+    def run_ranges(src, dst, send_ranks, send_off, send_cnt, recv_ranks, recv_off, recv_cnt, ls, ld, lc):
+        dst[ld:ld + lc] = src[ls:ls + lc]
+        got_bufs = B.comm_exchange_arrays(comm, send_ranks, [src[o:o + c] for o, c in zip(send_off, send_cnt)],
+                                          recv_ranks, recv_cnt, np.float64)
+        for o, b in zip(recv_off, got_bufs):
+            dst[o:o + len(b)] = b
+
+    nvec = 97
+    xg = orc.fill_uniform(0, nvec, 5)
+    src_p = orc.uniform_partition(nvec, nranks)
+    for tgt in (np.array([0] + [3 * r for r in range(1, nranks)] + [nvec]),          # almost all on the last rank
+                np.array([0] + [nvec] * nranks),                                      # all on rank 0, others empty
+                src_p):
+        pl = RangePlan(src_p, tgt.astype(np.int64), rank)
+        out = np.full(pl.result_local_size, np.nan)
+        run_ranges(xg[src_p[rank]:src_p[rank + 1]], out, pl.send_rank_ids, [s for s, _ in pl.send_ranges],
+                   [c for _, c in pl.send_ranges], pl.recv_rank_ids, pl.recv_offsets, pl.recv_counts,
+                   pl.local_src_start, pl.local_dst_offset, pl.local_count)
+        np.testing.assert_array_equal(out, xg[tgt[rank]:tgt[rank + 1]])
+
+    tgt = np.array([0] + [min(m, 7 + (m * r) // nranks + 11 * r) for r in range(1, nranks)] + [m], dtype=np.int64)
+    ci = np.unique(loc.indices).astype(np.int64)
+    cv = np.searchsorted(ci, loc.indices).astype(np.int32)
+    fakeA = SimpleNamespace(row_partition=rp, col_partition=cp, rowptr=loc.indptr.astype(np.int32), colval=cv,
+                            col_indices=ci, backend=SimpleNamespace(comm=comm, Ti=np.dtype(np.int32)))
+    sp_plan = SparseRepartitionPlan(fakeA, tgt)
+    want_r = Ag[tgt[rank]:tgt[rank + 1], :]
+    np.testing.assert_array_equal(sp_plan.result_rowptr, want_r.indptr)
+    np.testing.assert_array_equal(sp_plan.result_col_indices[sp_plan.result_colval.astype(np.int64)], want_r.indices)
+    np.testing.assert_array_equal(sp_plan.result_col_indices, np.unique(want_r.indices))
+    vals_out = np.full(len(want_r.data), np.nan)
+    run_ranges(loc.data, vals_out, sp_plan.rows.send_rank_ids, sp_plan.send_value_offsets, sp_plan.send_nnz_counts,
+               sp_plan.rows.recv_rank_ids, sp_plan.recv_value_offsets, sp_plan.recv_nnz_counts,
+               sp_plan.local_value_src, sp_plan.local_value_offset, sp_plan.local_nnz)
+    np.testing.assert_array_equal(vals_out, want_r.data)
+
     dist.barrier()
     dist.destroy_process_group()
     print(f"rank {rank}: OK")

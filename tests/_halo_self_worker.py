@@ -120,6 +120,19 @@ def main():
     assert abs(dot_out.item() - ref_dot) <= 1e-12 * float(np.abs(xg) @ np.abs(want)), (dot_out.item(), ref_dot)
     capi.call("hpcla_packed_destroy", packed)
     capi.call("hpcla_halo_plan_destroy", plan)
+    # contiguous-range exchange (repartition plans): two messages to myself + the part that stays,
+    # widths 1 (vector / nzval) and 5 (row-major dense rows)
+    from hpcla_amd.repartition import exchange_ranges
+    for width in (1, 5):
+        src = torch.from_numpy(orc.fill_uniform(0, 3000 * width, 77)).cuda()
+        dst = torch.full((2600 * width,), float("nan"), dtype=torch.float64, device="cuda")
+        exchange_ranges(backend, src, dst, [0, 0], [100, 2000], [900, 1000], [0, 0], [0, 1600], [900, 1000],
+                        1000, 900, 700, width)
+        torch.cuda.synchronize()
+        sv, dv = src.view(-1, width), dst.view(-1, width)
+        assert torch.equal(dv[0:900], sv[100:1000]) and torch.equal(dv[900:1600], sv[1000:1700]) \
+            and torch.equal(dv[1600:2600], sv[2000:3000]), f"exchange_ranges mismatch (width={width})"
+
     print("halo self-exchange OK")
 
 

@@ -862,6 +862,89 @@ def test_sparse_addition_and_subtraction(hp, orc, gpu_backend_i32):
     clear_addition_plan_cache()
 
 
+def test_repartition_serial_paths_and_range_exchange_errors(hp, orc, gpu_backend_i32):
+    """repartition (src/vectors.jl:712-722, src/dense.jl:1798-1810, src/sparse.jl:4590-4600) on one rank:
+    the only valid target is the current partition -> the object itself comes back; the C entry point
+    performs the local-copy leg and rejects messages on a serial communicator (the RCCL leg runs in
+    tests/_halo_self_worker.py, the plan lists in the gloo tests)."""
+    import torch
+    from hpcla_amd.repartition import exchange_ranges
+    b = gpu_backend_i32
+    n = 1000
+    v = hp.HPCVector.from_global(orc.fill_uniform(0, n, 3), b)
+    assert hp.repartition(v, np.array([0, n])) is v
+    with pytest.raises(ValueError):
+        hp.repartition(v, np.array([0, n - 1]))
+    M = hp.HPCMatrix.from_global(orc.fill_uniform(0, n * 4, 4).reshape(n, 4), b)
+    assert hp.repartition(M, np.array([0, n])) is M
+    R = orc.sprand_rows(n, 0.01, 0, n)
+    A = hp.HPCSparseMatrix_local(R.rowptr, R.colidx, R.vals, n, b)
+    assert hp.repartition(A, np.array([0, n])) is A
+    # local leg only, width 3
+    src = torch.arange(30, dtype=torch.float64, device="cuda")
+    dst = torch.zeros(30, dtype=torch.float64, device="cuda")
+    exchange_ranges(b, src, dst, [], [], [], [], [], [], 2, 5, 4, 3)
+    torch.cuda.synchronize()
+    want = np.zeros(30); want[15:27] = np.arange(6, 18)
+    np.testing.assert_array_equal(dst.cpu().numpy(), want)
+    with pytest.raises(hp._capi.HPCLAError):
+        exchange_ranges(b, src, dst, [0], [0], [4], [0], [0], [4], 0, 0, 0, 1)
+    # dot / + with an operand of another length: explicit error before any launch
+    w = hp.HPCVector.from_global(np.ones(n + 1), b)
+    with pytest.raises(ValueError):
+        hp.dot(v, w)
+
+
+@pytest.mark.parametrize("shape", [(5000, 16), (3001, 37), (257, 64), (40, 700), (1, 1), (100000, 3)])
+def test_dense_transpose_matvec(hp, orc, gpu_backend_i32, shape):
+    """transpose(A) * x and transpose(v) * A for dense A (src/dense.jl:1210-1274,
+    test/test_dense_matrix.jl transpose cases): BLAS + Allreduce order is unspecified in the
+    reference, so tolerance parity: 1e-12 relative to |A|^T |x|."""
+    b = gpu_backend_i32
+    m, n = shape
+    Ag = orc.fill_uniform(0, m * n, 21).reshape(m, n) - 0.5
+    xg = orc.fill_uniform(0, m, 22) - 0.5
+    A = hp.HPCMatrix.from_global(Ag, b)
+    x = hp.HPCVector.from_global(xg, b)
+    y = hp.transpose(A) @ x
+    want = Ag.T @ xg
+    scale = np.abs(Ag).T @ np.abs(xg) + 1e-300
+    assert np.all(np.abs(y.local_values() - want) <= 1e-12 * scale)
+    np.testing.assert_array_equal(y.partition, A.col_partition)
+    yt = hp.transpose(x) @ A
+    assert isinstance(yt, hp.TransposedHPCVector)
+    np.testing.assert_array_equal(yt.parent.local_values(), y.local_values())    # same kernels: same bits
+    with pytest.raises(ValueError):
+        hp.transpose(A) @ hp.HPCVector.from_global(np.ones(m + 1), b)
+
+
+def test_row_vector_algebra(hp, orc, gpu_backend_i32):
+    """transpose(v) * A, a*vt, vt*a, vt/a, vt +/- wt (src/sparse.jl:2136-2142, src/vectors.jl:909-987,
+    test/test_vector_multiplication.jl:141-160, 291-309)."""
+    import scipy.sparse as sp
+    b = gpu_backend_i32
+    n, m = 900, 700
+    R = orc.sprand_rows(m, 0.02, 0, n)
+    A = hp.HPCSparseMatrix_local(R.rowptr, R.colidx, R.vals, m, b)
+    As = sp.csr_matrix((R.vals, R.colidx, R.rowptr), shape=(n, m))
+    vg, wg = orc.fill_uniform(0, n, 31), orc.fill_uniform(0, n, 32)
+    v, w = hp.HPCVector.from_global(vg, b), hp.HPCVector.from_global(wg, b)
+    vt = hp.transpose(v)
+    assert hp.transpose(vt) is v and hp.adjoint(v).parent is v
+    yt = vt @ A
+    ref = hp.transpose(A) @ v                                    # bit-identical by construction ...
+    np.testing.assert_array_equal(yt.parent.local_values(), ref.local_values())
+    ATs = As.T.tocsr(); ATs.sort_indices()
+    np.testing.assert_array_equal(ref.local_values(), orc.spmv(ATs.indptr, ATs.indices, ATs.data, vg))   # ... and to the oracle
+    np.testing.assert_array_equal((2.5 * vt).parent.local_values(), 2.5 * vg)
+    np.testing.assert_array_equal((vt * 2.5).parent.local_values(), vg * 2.5)
+    np.testing.assert_array_equal((vt / 3.0).parent.local_values(), vg / 3.0)
+    np.testing.assert_array_equal((vt + hp.transpose(w)).parent.local_values(), vg + wg)
+    np.testing.assert_array_equal((vt - hp.transpose(w)).parent.local_values(), vg - wg)
+    np.testing.assert_array_equal((-vt).parent.local_values(), -vg)
+    assert abs(vt @ w - float(vg @ wg)) <= 1e-12 * float(np.abs(vg) @ np.abs(wg))
+
+
 def test_graft_entry_smoke():
     import __graft_entry__ as g
     g.smoke()

@@ -166,3 +166,46 @@ def test_backend_requires_gpu(hp):
         pytest.skip("GPU present")
     with pytest.raises(Exception):
         hp.backend_rocm_serial()
+
+
+# ---- repartition range plans (src/vectors.jl:511-620) ---------------------------------------------
+def _random_partition(rng, n, nranks):
+    cuts = np.sort(rng.integers(0, n + 1, nranks - 1))
+    return np.concatenate([[0], cuts, [n]]).astype(np.int64)
+
+
+@pytest.mark.parametrize("nranks", [1, 2, 5, 8])
+def test_range_plans_are_consistent_and_reproduce_the_target_slices(nranks):
+    from hpcla_amd.repartition import RangePlan, check_partition
+    rng = np.random.default_rng(nranks)
+    n = 211
+    x = rng.random(n)
+    for _ in range(20):
+        src, tgt = _random_partition(rng, n, nranks), _random_partition(rng, n, nranks)
+        check_partition(tgt, n, nranks)
+        plans = [RangePlan(src, tgt, r) for r in range(nranks)]
+        outs = [np.full(p.result_local_size, np.nan) for p in plans]
+        for r, p in enumerate(plans):
+            loc = x[src[r]:src[r + 1]]
+            assert p.result_local_size == tgt[r + 1] - tgt[r]
+            assert r not in p.send_rank_ids and r not in p.recv_rank_ids
+            assert p.send_rank_ids == sorted(p.send_rank_ids) and p.recv_rank_ids == sorted(p.recv_rank_ids)
+            outs[r][p.local_dst_offset:p.local_dst_offset + p.local_count] = \
+                loc[p.local_src_start:p.local_src_start + p.local_count]
+            for dest, (s, c) in zip(p.send_rank_ids, p.send_ranges):
+                q = plans[dest]
+                i = q.recv_rank_ids.index(r)                      # every send has its matching receive
+                assert q.recv_counts[i] == c
+                outs[dest][q.recv_offsets[i]:q.recv_offsets[i] + c] = loc[s:s + c]
+        for r, p in enumerate(plans):                             # and every receive a matching send
+            for srcr, c in zip(p.recv_rank_ids, p.recv_counts):
+                j = plans[srcr].send_rank_ids.index(r)
+                assert plans[srcr].send_ranges[j][1] == c
+            np.testing.assert_array_equal(outs[r], x[tgt[r]:tgt[r + 1]])
+
+
+def test_check_partition_rejects_malformed_targets():
+    from hpcla_amd.repartition import check_partition
+    for bad in ([0, 5], [1, 3, 10], [0, 7, 5, 10], [0, 3, 9]):
+        with pytest.raises(ValueError):
+            check_partition(np.array(bad), 10, 2 if len(bad) == 3 else len(bad) - 1 if bad != [0, 5] else 2)
