@@ -30,6 +30,14 @@ int set_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3
 // launch check: hipGetLastError after a <<<>>> launch
 #define HPCLA_CHECK_LAUNCH() HPCLA_CHECK_HIP(hipGetLastError())
 
+// 1-D grid size guard: a launch needs < 2^31 workgroups
+#define HPCLA_CHECK_GRID(nblocks, what)                                                           \
+    do {                                                                                          \
+        if ((int64_t)(nblocks) > 0x7fffffffLL)                                                    \
+            return hpcla::set_error(HPCLA_ERR_UNSUPPORTED, "%s: %lld workgroups exceed the grid limit", \
+                                    what, (long long)(nblocks));                                  \
+    } while (0)
+
 static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 // Workgroup order: MI355X deals workgroups round-robin over its 8 XCDs (block b and b+8 share an L2).

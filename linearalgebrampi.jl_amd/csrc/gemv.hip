@@ -174,6 +174,7 @@ HPCLA_API int hpcla_gemv_rowmajor_f64(const double *A, int64_t lda, int64_t nrow
     if (!y || (n_lo + n_own + n_hi > 0 && !A)) return set_error(HPCLA_ERR_INVALID, "gemv: null pointer");
     if ((n_lo > 0 && !x_lo) || (n_own > 0 && !x_own) || (n_hi > 0 && !x_hi))
         return set_error(HPCLA_ERR_INVALID, "gemv: null x segment");
+    HPCLA_CHECK_GRID((nrows + 3) / 4, "gemv");
     gemv_rowmajor_kernel<<<(uint32_t)((nrows + 3) / 4), 256, 0, as_stream(stream)>>>(
         A, lda, nrows, x_lo, n_lo, x_own, n_own, x_hi, n_hi, y);
     HPCLA_CHECK_LAUNCH();
