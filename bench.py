@@ -309,7 +309,7 @@ def main():
 
     traffic = None
     tj = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if os.path.exists(tj):
+    if os.path.exists(tj) and args.index == "i32" and N == 4096 and not strong:     # measured for that launch only
         try:
             traffic = json.load(open(tj)).get("hbm_bytes_per_launch")
         except Exception:

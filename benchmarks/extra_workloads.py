@@ -52,10 +52,11 @@ def run(args, backend, rank, world):
         setup_s = time.perf_counter() - t0
         iters = args.steps if args.steps != 200 else 100
         fused = os.environ.get("HPCLA_CG_UNFUSED", "") != "1"
+        graph = os.environ.get("HPCLA_CG_GRAPH", "") == "1"     # replay a captured pair of iterations
         hp.cg_fixed_iterations(A, b, max(args.warmup // 4, 2), record_history=False, fused=fused)   # warm-up
         _sync_barrier(torch, dist, world)
         t0 = time.perf_counter()
-        x, hist = hp.cg_fixed_iterations(A, b, iters, record_history=True, fused=fused)
+        x, hist = hp.cg_fixed_iterations(A, b, iters, record_history=True, fused=fused, graph=graph)
         _sync_barrier(torch, dist, world)
         elapsed = time.perf_counter() - t0
         if world > 1:
@@ -71,7 +72,8 @@ def run(args, backend, rank, world):
             "n_gpus": world, "steps": iters, "warmup": args.warmup, "ms_per_step": round(ms_iter, 4),
             "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"poisson3d 7-pt {N}x{N}x{planes} per GPU ({N}x{N}x{nz} global), {iters} CG iterations, "
-                                   f"{'fused SpMV+dot / update' if fused else 'one kernel per reference operator'}",
+                                   f"{'fused SpMV+dot / update' if fused else 'one kernel per reference operator'}"
+                                   f"{', HIP graph replay' if graph else ''}",
                        "global_rows": n_glob, "nnz_per_gpu": nnz_loc},
             "roofline": {"bound": "hbm", "achieved": round(b_iter / (ms_iter * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(b_iter / (ms_iter * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,

@@ -32,6 +32,8 @@ for st in $STEPS; do
       tail -2 gpurun_out/${TAG}_halotrace.log;;
     vecops) run 600 gpurun_out/${TAG}_vecops.log python benchmarks/bench_vecops.py; tail -8 gpurun_out/${TAG}_vecops.log;;
     cg)     run 900 gpurun_out/${TAG}_cg.log python bench.py --workload poisson3d_cg --steps 100 --warmup 10; tail -2 gpurun_out/${TAG}_cg.log;;
+    cggraph) for g in 0 1; do HPCLA_CG_GRAPH=$g run 600 gpurun_out/${TAG}_cggraph$g.log python bench.py --workload poisson3d_cg --size 48 --steps 400 --warmup 10; tail -1 gpurun_out/${TAG}_cggraph$g.log; done;;
+    i64) run 600 gpurun_out/${TAG}_bench_i64.log python bench.py --index i64 --no-cpu-baseline --no-packed; tail -1 gpurun_out/${TAG}_bench_i64.log;;
     cgsmall) run 900 gpurun_out/${TAG}_cgsmall.log python bench.py --workload poisson3d_cg --size 256 --steps 100 --warmup 10; tail -2 gpurun_out/${TAG}_cgsmall.log;;
     spmm8)  HPCLA_SPMM_COLS_MULT=8 run 900 gpurun_out/${TAG}_spmm8.log python bench.py --workload sprand_spmm --steps 20 --warmup 3; tail -2 gpurun_out/${TAG}_spmm8.log;;
     spmm)   run 900 gpurun_out/${TAG}_spmm.log python bench.py --workload sprand_spmm --steps 20 --warmup 3; tail -2 gpurun_out/${TAG}_spmm.log;;

@@ -525,6 +525,21 @@ def test_cg_fused_equals_unfused(hp, orc, gpu_backend_i32):
     np.testing.assert_allclose(x1.local_values(), x2.local_values(), rtol=0, atol=1e-9)
 
 
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("iters", [4, 11])
+def test_cg_graph_replay_is_bit_identical_to_eager(hp, orc, gpu_backend_i32, fused, iters):
+    """graph=True replays a captured pair of iterations (HIP graph): same kernels and arguments as the
+    eager loop, so iterate and residual history must agree bit for bit (odd counts finish eagerly)."""
+    N = 16
+    rows = orc.poisson3d_rows(N, N, N, 0, N ** 3)
+    A = hp.HPCSparseMatrix_local(rows.rowptr, rows.colidx, rows.vals, N ** 3, gpu_backend_i32)
+    b = hp.HPCVector.from_global(orc.fill_uniform(0, N ** 3, orc.SEED_RHS), gpu_backend_i32)
+    x1, h1 = hp.cg_fixed_iterations(A, b, iters, fused=fused, graph=False)
+    x2, h2 = hp.cg_fixed_iterations(A, b, iters, fused=fused, graph=True)
+    assert h1 == h2 and len(h2) == iters + 1
+    np.testing.assert_array_equal(x1.local_values(), x2.local_values())
+
+
 def test_transpose_times_vector(hp, orc, gpu_backend_i32):
     """transpose(A) * x (test/test_new_operations.jl:73-76; src/sparse.jl:2375-2379): materialised,
     cached bidirectionally, result bit-identical to the row-sequential product with the explicit A^T."""
