@@ -29,6 +29,42 @@ def _sync_barrier(torch, dist, world):
     torch.cuda.synchronize()
 
 
+def _measure_spmm(args, torch, dist, hp, wl, A, B, k, world, dev, setup_s, metric, workload):
+    C = A @ B
+    for _ in range(args.warmup):
+        C = A @ B
+    _sync_barrier(torch, dist, world)
+    steps = min(args.steps, 50)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        C = A @ B
+    _sync_barrier(torch, dist, world)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms = elapsed / steps * 1e3
+    b_alg = wl.spmm_algorithmic_bytes(A.nnz, A.nrows_local, A.ncols_compressed, k, 4)
+    b_gather = A.nnz * (12 + 8 * k) + 4 * A.nrows_local + 8 * k * A.nrows_local    # every B row read per entry
+    out = {
+        "metric": metric, "value": round(2.0 * k * A.nnz * world / (ms * 1e-3) / 1e9, 1),
+        "unit": "GFLOP/s", "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": workload,
+                   "ncols_compressed": A.ncols_compressed},
+        "roofline": {"bound": "hbm", "achieved": round(b_alg / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                     "algorithmic_bytes_per_launch": b_alg,
+                     "gather_bytes_per_launch": b_gather,
+                     "gather_gbs": round(b_gather / (ms * 1e-3) / 1e9, 1),
+                     "note": "algorithmic bytes count each touched B row once; a random-column matrix re-reads B rows "
+                             "(gather_bytes = one 128-byte line per stored entry), which is what HBM actually serves"},
+        "setup_s": round(setup_s, 2),
+    }
+    return out
+
+
 def run(args, backend, rank, world):
     import torch
     import torch.distributed as dist
@@ -80,6 +116,28 @@ def run(args, backend, rank, world):
                          "algorithmic_bytes_per_iteration": b_iter, "note": "whole iteration (SpMV + 2 reductions + 3 updates), wall clock"},
             "residual_first": hist[0], "residual_last": hist[-1], "setup_s": round(setup_s, 2),
         }
+    elif args.workload == "poisson2d_spmm":
+        # structured counterpart of config 5: the 5-point matrix times 16 dense columns.  Every B row is
+        # needed by <= 5 matrix rows that sit close together, so the algorithmic byte count (each B row
+        # once) is attainable -- this is the line that shows the SpMM kernel's own efficiency.
+        k = 16
+        N = args.size or 4096
+        nx, ny_loc = N, N // 2
+        ny = ny_loc * world
+        lo, hi = rank * nx * ny_loc, (rank + 1) * nx * ny_loc
+        t0 = time.perf_counter()
+        rowptr, colidx, vals = wl.poisson2d_rows(nx, ny, lo, hi)
+        A = hp.HPCSparseMatrix_local(rowptr, colidx, vals, nx * ny, backend)
+        del rowptr, colidx, vals
+        b_rows = hi - lo
+        Bl = torch.empty((b_rows, k), dtype=torch.float64, device=dev)
+        hp._capi.call("hpcla_fill_uniform_f64", Bl.data_ptr(), lo * k, b_rows * k, wl.SEED_X,
+                      torch.cuda.current_stream().cuda_stream)
+        B = hp.HPCMatrix_local(Bl, backend)
+        setup_s = time.perf_counter() - t0
+        out = _measure_spmm(args, torch, dist, hp, wl, A, B, k, world, dev, setup_s,
+                            "SpMM GFLOP/s (2*k*nnz/t), 2-D 5-pt Poisson, k=16, fp64",
+                            f"poisson2d 5-pt {nx}x{ny_loc} slab per GPU, nnz/GPU={A.nnz}, k={k}, C = A*B")
     elif args.workload == "sprand_spmm":
         k = 16
         rows_loc = args.size or 2_097_152
@@ -107,38 +165,9 @@ def run(args, backend, rank, world):
                       torch.cuda.current_stream().cuda_stream)
         B = hp.HPCMatrix_local(Bl, backend)
         setup_s = time.perf_counter() - t0
-        C = A @ B
-        for _ in range(args.warmup):
-            C = A @ B
-        _sync_barrier(torch, dist, world)
-        steps = min(args.steps, 50)
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            C = A @ B
-        _sync_barrier(torch, dist, world)
-        elapsed = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
-        ms = elapsed / steps * 1e3
-        b_alg = wl.spmm_algorithmic_bytes(A.nnz, A.nrows_local, A.ncols_compressed, k, 4)
-        b_gather = A.nnz * (12 + 8 * k) + 4 * A.nrows_local + 8 * k * A.nrows_local    # every B row read per entry
-        out = {
-            "metric": "SpMM GFLOP/s (2*k*nnz/t), sprand ~29.8 nnz/row, k=16, fp64", "value": round(2.0 * k * A.nnz * world / (ms * 1e-3) / 1e9, 1),
-            "unit": "GFLOP/s", "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"sprand-like {rows_loc} rows per GPU x {ncols} cols, nnz/GPU={A.nnz}, k={k}, C = A*B",
-                       "ncols_compressed": A.ncols_compressed},
-            "roofline": {"bound": "hbm", "achieved": round(b_alg / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
-                         "algorithmic_bytes_per_launch": b_alg,
-                         "gather_bytes_per_launch": b_gather,
-                         "gather_gbs": round(b_gather / (ms * 1e-3) / 1e9, 1),
-                         "note": "algorithmic bytes count each touched B row once; a random-column matrix re-reads B rows "
-                                 "(gather_bytes = one 128-byte line per stored entry), which is what HBM actually serves"},
-            "setup_s": round(setup_s, 2),
-        }
+        out = _measure_spmm(args, torch, dist, hp, wl, A, B, k, world, dev, setup_s,
+                            "SpMM GFLOP/s (2*k*nnz/t), sprand ~29.8 nnz/row, k=16, fp64",
+                            f"sprand-like {rows_loc} rows per GPU x {ncols} cols, nnz/GPU={A.nnz}, k={k}, C = A*B")
     if world > 1:
         _device_barrier(torch, dist)
     if rank == 0:

@@ -360,11 +360,15 @@ int hpcla_axpby_f64(double a, const double *x, double b, const double *y, double
                     void *stream);
 
 /* ---- sparse A +/- B value pass: the reference's five index-mapped kernels (_copy_a_only_/
- * _copy_b_only_/_negate_b_only_/_add_both_/_sub_both_kernel!, src/sparse.jl:1258-1303) as one entry:
- * mode 0 out[dst[i]] = a[a_src[i]]; 1 = -a[a_src[i]]; 2 = a[a_src[i]] + b[b_src[i]]; 3 = a[..] - b[..].
- * The index lists come from the host AdditionPlan (union of the two sparsity patterns). */
-int hpcla_index_combine_f64(double *out, const double *a, const int64_t *a_src, const double *b,
-                            const int64_t *b_src, const int64_t *dst, int64_t n, int mode, void *stream);
+ * _copy_b_only_/_negate_b_only_/_add_both_/_sub_both_kernel!, src/sparse.jl:1258-1303) as ONE pass
+ * over the merged pattern: out[i] = a[ia[i]] (+|-) b[ib[i]] where both indices are >= 0, a copy of
+ * a[ia[i]] or of (+|-) b[ib[i]] where only one is (never an addition to zero), for i in [0, n).
+ * ia/ib (0-based positions in the operands' nzval, -1 = absent) come from the host AdditionPlan
+ * (union of the two sparsity patterns, src/sparse.jl:1112-1245).  subtract: 0 = A+B, 1 = A-B. */
+int hpcla_merge_combine_f64_i32(double *out, const double *a, const int32_t *ia, const double *b,
+                                const int32_t *ib, int64_t n, int subtract, void *stream);
+int hpcla_merge_combine_f64_i64(double *out, const double *a, const int64_t *ia, const double *b,
+                                const int64_t *ib, int64_t n, int subtract, void *stream);
 
 /* ---- synthetic inputs on the device (bench/tests): the SURVEY section 8d counter-based
  * generator, v[i] = u01(seed, start+i). */

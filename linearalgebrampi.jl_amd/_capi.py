@@ -104,7 +104,8 @@ _SIGNATURES = {
     "hpcla_scale_f64": [_f64, _vp, _vp, _i64, _vp],
     "hpcla_divide_f64": [_vp, _f64, _vp, _i64, _vp],
     "hpcla_axpby_f64": [_f64, _vp, _f64, _vp, _vp, _i64, _vp],
-    "hpcla_index_combine_f64": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp],
+    "hpcla_merge_combine_f64_i32": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp],
+    "hpcla_merge_combine_f64_i64": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp],
     "hpcla_fill_uniform_f64": [_vp, _i64, _i64, _u64, _vp],
 }
 _RESTYPES = {

@@ -3,8 +3,9 @@
 Reference: a memoized ``AdditionPlan`` merges the two sparsity patterns on the host (per-row sorted
 union of global columns, structural zeros preserved) and five index-mapped kernels fill the result:
 A-only entries copied, B-only entries copied (or negated), shared entries added (or subtracted)
-(src/sparse.jl:1258-1375).  Here the plan is numpy (same union, same three index groups) and the value
-pass is ``hpcla_index_combine_f64`` -- one rounding per shared entry, so results are bit-identical.
+(src/sparse.jl:1258-1375).  Here the plan is numpy (same union) and the value pass is ONE kernel over the
+merged pattern, ``hpcla_merge_combine_f64_*`` (a plain axpby when the two patterns are identical) -- entries
+present on one side are copied, shared entries take one rounding, so results are bit-identical.
 
 Like the reference (src/sparse.jl:1407, 1456) B is first repartitioned to A's row partition when the
 two differ (repartition.py: structure on the host at plan time, values device to device).
@@ -40,13 +41,17 @@ class AdditionPlan:
         pos_a, pos_b = np.searchsorted(union, key_a), np.searchsorted(union, key_b)
         inv_a = np.full(len(union), -1, dtype=np.int64); inv_a[pos_a] = np.arange(len(key_a))
         inv_b = np.full(len(union), -1, dtype=np.int64); inv_b[pos_b] = np.arange(len(key_b))
-        both = np.flatnonzero((inv_a >= 0) & (inv_b >= 0))
-        a_only = np.flatnonzero((inv_a >= 0) & (inv_b < 0))
-        b_only = np.flatnonzero((inv_a < 0) & (inv_b >= 0))
-        up = lambda v: torch.from_numpy(np.ascontiguousarray(v, dtype=np.int64)).to(dev)
-        self.a_only = (up(inv_a[a_only]), up(a_only))
-        self.b_only = (up(inv_b[b_only]), up(b_only))
-        self.both = (up(inv_a[both]), up(inv_b[both]), up(both))
+        # device lists: position of each merged entry in A.nzval / B.nzval, -1 where absent
+        # (the reference keeps three index groups -- A only, B only, both -- for its five kernels,
+        # src/sparse.jl:1172-1245; the same information, one pass)
+        self.idx64 = max(len(key_a), len(key_b)) > np.iinfo(np.int32).max
+        idt = np.int64 if self.idx64 else np.int32
+        self.same_pattern = len(key_a) == len(key_b) == len(union)   # identical structure: no lists needed
+        if self.same_pattern:
+            self.inv_a = self.inv_b = None
+        else:
+            self.inv_a = torch.from_numpy(inv_a.astype(idt)).to(dev)
+            self.inv_b = torch.from_numpy(inv_b.astype(idt)).to(dev)
         self.nnz = len(union)
         rows_c = union // W
         self.rowptr = np.concatenate([[0], np.cumsum(np.bincount(rows_c, minlength=n))]).astype(np.int64)
@@ -86,12 +91,15 @@ def sparse_add(A, B, subtract: bool = False):
     plan = _get_addition_plan(A, B)
     s = current_stream_ptr()
     nzval = torch.empty(plan.nnz, dtype=torch.float64, device=A.backend.torch_device)
-    (sa, da), (sb, db), (ba, bb, bd) = plan.a_only, plan.b_only, plan.both
-    _capi.call("hpcla_index_combine_f64", dptr(nzval), dptr(A.nzval), dptr(sa), None, None, dptr(da), int(sa.numel()), 0, s)
-    _capi.call("hpcla_index_combine_f64", dptr(nzval), dptr(B.nzval), dptr(sb), None, None, dptr(db), int(sb.numel()),
-               1 if subtract else 0, s)
-    _capi.call("hpcla_index_combine_f64", dptr(nzval), dptr(A.nzval), dptr(ba), dptr(B.nzval), dptr(bb), dptr(bd),
-               int(ba.numel()), 3 if subtract else 2, s)
+    if plan.same_pattern:
+        # identical patterns (the common case: two operators on one mesh): a plain streaming
+        # 1*a + (+-1)*b, 24 B per entry; multiplication by +-1 is exact, so the bits equal a +- b
+        _capi.call("hpcla_axpby_f64", 1.0, dptr(A.nzval), -1.0 if subtract else 1.0, dptr(B.nzval), dptr(nzval),
+                   plan.nnz, s)
+    else:
+        _capi.call("hpcla_merge_combine_f64_i64" if plan.idx64 else "hpcla_merge_combine_f64_i32", dptr(nzval),
+                   dptr(A.nzval), dptr(plan.inv_a), dptr(B.nzval), dptr(plan.inv_b), plan.nnz,
+                   1 if subtract else 0, s)
     C = HPCSparseMatrix(A.row_partition, A.col_partition, plan.col_indices, plan.rowptr_ti, plan.colval, nzval,
                         plan.rowptr_dev, A.backend)
     return C

@@ -54,6 +54,61 @@ __global__ __launch_bounds__(256) void gemv_rowmajor_kernel(const double *__rest
     if (lane == 0) y[row] = acc;
 }
 
+// Tall-skinny blocks (ncols <= 128: multi-vectors, the usual HPCMatrix shape): one wavefront per row
+// would leave most lanes idle and pay a wave launch per 8..512 bytes.  Here L = pow2 >= ncols/2 lanes
+// share a row (each owns two adjacent columns, whose x values stay in registers for the whole kernel),
+// a wavefront covers 64/L rows per pass and loops over ROWS_PER_WAVE_PASSES passes with 4 loads in
+// flight; a contiguous block (lda == ncols == 2L) is then read as one sequential stream.
+constexpr int SKINNY_PASSES = 16;
+
+__device__ __forceinline__ double seg_x(const double *__restrict__ x_lo, int64_t n_lo,
+                                        const double *__restrict__ x_own, int64_t n_own,
+                                        const double *__restrict__ x_hi, int64_t n_hi, int64_t e)
+{
+    if (e < n_lo) return x_lo[e];
+    if (e < n_lo + n_own) return x_own[e - n_lo];
+    if (e < n_lo + n_own + n_hi) return x_hi[e - n_lo - n_own];
+    return 0.0;
+}
+
+__global__ __launch_bounds__(256) void gemv_skinny_kernel(const double *__restrict__ A, int64_t lda,
+                                                          int64_t nrows, int64_t ncols, int L,
+                                                          const double *__restrict__ x_lo, int64_t n_lo,
+                                                          const double *__restrict__ x_own, int64_t n_own,
+                                                          const double *__restrict__ x_hi, int64_t n_hi,
+                                                          double *__restrict__ y)
+{
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % L;                 // column pair within the row
+    const int rsub = lane / L;                // row within the pass
+    const int rpp = 64 / L;                   // rows per pass
+    const int64_t c0 = 2 * (int64_t)sub;
+    const bool has0 = c0 < ncols, has1 = c0 + 1 < ncols;
+    const double xa = has0 ? seg_x(x_lo, n_lo, x_own, n_own, x_hi, n_hi, c0) : 0.0;
+    const double xb = has1 ? seg_x(x_lo, n_lo, x_own, n_own, x_hi, n_hi, c0 + 1) : 0.0;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t row0 = wave * (int64_t)(rpp * SKINNY_PASSES);
+    const bool vec = ((lda & 1) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && has1;
+#pragma unroll 4
+    for (int p = 0; p < SKINNY_PASSES; ++p) {
+        const int64_t row = row0 + (int64_t)p * rpp + rsub;
+        double acc = 0.0;
+        if (row < nrows) {
+            const double *a = A + row * lda + c0;
+            if (vec) {
+                const double2 av = *reinterpret_cast<const double2 *>(a);
+                acc = av.x * xa;
+                acc += av.y * xb;
+            } else {
+                if (has0) acc = a[0] * xa;
+                if (has1) acc += a[1] * xb;
+            }
+        }
+        for (int off = L >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if (sub == 0 && row < nrows) y[row] = acc;
+    }
+}
+
 // ---- y_partial = A_local^T * x_local (transpose(A) * x, src/dense.jl:1210-1261) -------------------
 // The reference multiplies the local block transposed by the local slice of x and all-reduces the
 // ncols partial sums on the host.  Row-major A: consecutive columns are consecutive addresses, so a
@@ -80,14 +135,14 @@ __global__ __launch_bounds__(GEMVT_THREADS) void gemv_t_stage1(const double *__r
     double acc = 0.0;
     if (col < ncols) {
         int64_t r = r0 + rl;
-        for (; r + 3 * rstep < r1; r += 4 * rstep) {      // 4 independent loads in flight
-            const double a0 = A[r * lda + col], a1 = A[(r + rstep) * lda + col];
-            const double a2 = A[(r + 2 * rstep) * lda + col], a3 = A[(r + 3 * rstep) * lda + col];
-            const double x0 = x[r], x1 = x[r + rstep], x2 = x[r + 2 * rstep], x3 = x[r + 3 * rstep];
-            acc += a0 * x0;
-            acc += a1 * x1;
-            acc += a2 * x2;
-            acc += a3 * x3;
+        for (; r + 7 * rstep < r1; r += 8 * rstep) {      // 8 independent loads in flight
+            double av[8], xv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) av[u] = A[(r + (int64_t)u * rstep) * lda + col];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xv[u] = x[r + (int64_t)u * rstep];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += av[u] * xv[u];
         }
         for (; r < r1; r += rstep) acc += A[r * lda + col] * x[r];
     }
@@ -100,14 +155,38 @@ __global__ __launch_bounds__(GEMVT_THREADS) void gemv_t_stage1(const double *__r
     }
 }
 
-__global__ __launch_bounds__(256) void gemv_t_stage2(const double *__restrict__ partial, int64_t nchunks,
-                                                     int64_t ncols, double *__restrict__ y)
+// stage 2: column sums of partial[nchunks][ncols].  A workgroup owns CT = min(64, W) columns; its
+// 1024/CT row phases each sum every (1024/CT)-th chunk in ascending order (8 loads in flight), then
+// the phases are added in ascending order through LDS -- a fixed tree, so the result is deterministic.
+constexpr int GEMVT2_THREADS = 1024;
+
+__global__ __launch_bounds__(GEMVT2_THREADS) void gemv_t_stage2(const double *__restrict__ partial,
+                                                                int64_t nchunks, int64_t ncols, int CT,
+                                                                double *__restrict__ y)
 {
-    const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= ncols) return;
+    __shared__ double red[GEMVT2_THREADS];
+    const int tid = threadIdx.x;
+    const int c = tid % CT, ph = tid / CT, nph = GEMVT2_THREADS / CT;
+    const int64_t col = (int64_t)blockIdx.x * CT + c;
     double s = 0.0;
-    for (int64_t k = 0; k < nchunks; ++k) s += partial[k * ncols + col];
-    y[col] = s;
+    if (col < ncols) {
+        int64_t k = ph;
+        for (; k + 7 * nph < nchunks; k += 8 * (int64_t)nph) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partial[(k + (int64_t)u * nph) * ncols + col];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; k < nchunks; k += nph) s += partial[k * ncols + col];
+    }
+    red[tid] = s;
+    __syncthreads();
+    if (ph == 0 && col < ncols) {
+        double t = red[c];
+        for (int q = 1; q < nph; ++q) t += red[q * CT + c];
+        y[col] = t;
+    }
 }
 
 static int64_t gemv_t_rows_per_chunk(int64_t nrows, int64_t ncols)
@@ -116,7 +195,7 @@ static int64_t gemv_t_rows_per_chunk(int64_t nrows, int64_t ncols)
     int W = 1;
     while (W < 64 && W < ncols) W <<= 1;
     const int64_t tiles = (ncols + W - 1) / W;
-    int64_t want_chunks = (4096 + tiles - 1) / (tiles > 0 ? tiles : 1);
+    int64_t want_chunks = (1024 + tiles - 1) / (tiles > 0 ? tiles : 1);   // ~4 workgroups per CU in stage 1
     if (want_chunks < 1) want_chunks = 1;
     int64_t rpc = (nrows + want_chunks - 1) / want_chunks;
     if (rpc < 64) rpc = 64;
@@ -156,8 +235,9 @@ HPCLA_API int hpcla_gemv_t_rowmajor_f64(const double *A, int64_t lda, int64_t nr
     gemv_t_stage1<<<dim3((uint32_t)tiles, (uint32_t)nchunks), GEMVT_THREADS, 0, s>>>(
         A, lda, nrows, ncols, x, W, rpc, static_cast<double *>(work));
     HPCLA_CHECK_LAUNCH();
-    gemv_t_stage2<<<(uint32_t)((ncols + 255) / 256), 256, 0, s>>>(static_cast<const double *>(work), nchunks,
-                                                                ncols, y_full);
+    const int CT = W < 64 ? W : 64;
+    gemv_t_stage2<<<(uint32_t)((ncols + CT - 1) / CT), GEMVT2_THREADS, 0, s>>>(
+        static_cast<const double *>(work), nchunks, ncols, CT, y_full);
     HPCLA_CHECK_LAUNCH();
     return HPCLA_OK;
 }
@@ -174,6 +254,18 @@ HPCLA_API int hpcla_gemv_rowmajor_f64(const double *A, int64_t lda, int64_t nrow
     if (!y || (n_lo + n_own + n_hi > 0 && !A)) return set_error(HPCLA_ERR_INVALID, "gemv: null pointer");
     if ((n_lo > 0 && !x_lo) || (n_own > 0 && !x_own) || (n_hi > 0 && !x_hi))
         return set_error(HPCLA_ERR_INVALID, "gemv: null x segment");
+    const int64_t ncols = n_lo + n_own + n_hi;
+    if (ncols > 0 && ncols <= 128) {
+        int L = 1;
+        while (2 * L < ncols) L <<= 1;
+        const int64_t rows_per_wave = (int64_t)(64 / L) * SKINNY_PASSES;
+        const int64_t waves = (nrows + rows_per_wave - 1) / rows_per_wave;
+        HPCLA_CHECK_GRID((waves + 3) / 4, "gemv");
+        gemv_skinny_kernel<<<(uint32_t)((waves + 3) / 4), 256, 0, as_stream(stream)>>>(
+            A, lda, nrows, ncols, L, x_lo, n_lo, x_own, n_own, x_hi, n_hi, y);
+        HPCLA_CHECK_LAUNCH();
+        return HPCLA_OK;
+    }
     HPCLA_CHECK_GRID((nrows + 3) / 4, "gemv");
     gemv_rowmajor_kernel<<<(uint32_t)((nrows + 3) / 4), 256, 0, as_stream(stream)>>>(
         A, lda, nrows, x_lo, n_lo, x_own, n_own, x_hi, n_hi, y);

@@ -7,7 +7,8 @@
 //     streamed coalesced into LDS, CHUNK_MM entries at a time;
 //   * the workgroup is 16 lane-groups of 16 lanes; lane-group g owns rows g, g+16, g+32, g+48 of
 //     the block and lane l of the group owns output columns l, l+16, ...; for every stored entry
-//     the group reads (col,val) from LDS (broadcast) and one 16-column slice of row `col` of B;
+//     the group reads (col,val) from LDS (broadcast) and one 16-column slice of row `col` of B
+//     (its four rows interleaved, see the kernel);
 //     with the device-native row-major B (k=16: exactly one 128-byte line per entry) that read is
 //     a single full-line access;
 //   * each C(r,c) is accumulated sequentially in stored order with separate multiply and add, so
@@ -27,6 +28,12 @@ constexpr int RPB_MM = NGROUPS * SLOTS;     // 64 rows per block
 constexpr int CHUNK_MM = 2048;              // entries staged per pass: 2048 * 12 B = 24 KiB
 constexpr int KT = 16;                      // columns per tile (one per lane of a group)
 
+// The four rows of a lane-group advance TOGETHER, two entries each per step, so a lane has up to 8
+// independent B loads in flight.  (A first version walked the rows one after the other with 4 loads
+// in flight: a 5-entry stencil row then costs two latency rounds per row, eight per lane-group; the
+// interleaved form measured 1.255 -> 1.041 ms on the 5-point matrix x 16 columns and 1.707 -> 1.616 ms
+// on config 5's random pattern, profiles/r01_spmm_variants.log.)  Per row the entries are still
+// accumulated one after the other in stored order: same bits.
 template <typename I, bool SPLIT>
 __global__ __launch_bounds__(TPB_MM) void spmm_rowblock_kernel(
     const I *__restrict__ rowptr, const I *__restrict__ colval, const double *__restrict__ nzval,
@@ -40,7 +47,7 @@ __global__ __launch_bounds__(TPB_MM) void spmm_rowblock_kernel(
 
     const int tid = threadIdx.x;
     const int g = tid / GROUP, l = tid % GROUP;
-    const uint32_t b = blockIdx.x;      // natural order (the XCD-sliced order measured slower, as for SpMV)
+    const uint32_t b = blockIdx.x;
     const int64_t blk = block_list ? (int64_t)block_list[b] : (int64_t)b;
     const int64_t r0 = blk * RPB_MM;
     const int nr = (int)((nrows - r0) < RPB_MM ? (nrows - r0) : RPB_MM);
@@ -62,6 +69,7 @@ __global__ __launch_bounds__(TPB_MM) void spmm_rowblock_kernel(
     for (int kt = 0; kt < k; kt += KT) {
         const int c = kt + l;
         const bool col_ok = c < k;
+        const int64_t c_off = (int64_t)c * b_cs;
         double acc[SLOTS];
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) acc[s] = 0.0;
@@ -73,31 +81,60 @@ __global__ __launch_bounds__(TPB_MM) void spmm_rowblock_kernel(
                 const int64_t col = (int64_t)__builtin_nontemporal_load(colval + p0 + ch + i) - base;
                 s_val[i] = __builtin_nontemporal_load(nzval + p0 + ch + i);
                 if (SPLIT)
-                    // ghosts are tagged by a negative offset: -(1 + ghost_row * ghost_row_stride)
                     s_col[i] = col < n_own ? col * b_rs : -(1 + (col - n_own) * bg_rs);
                 else
                     s_col[i] = col * b_rs;
             }
             __syncthreads();
+            if (!col_ok) continue;
+            int a[SLOTS], len[SLOTS];
+            int maxlen = 0;
 #pragma unroll
             for (int s = 0; s < SLOTS; ++s) {
-                const int64_t a = lo[s] > ch ? lo[s] : ch;
-                const int64_t e = hi[s] < ch + n ? hi[s] : ch + n;
-                if (col_ok) {
-#pragma unroll 4
-                    for (int64_t j = a; j < e; ++j) {
-                        const int64_t off = s_col[j - ch];
-                        const double v = s_val[j - ch];
-                        double bv;
-                        if (SPLIT && off < 0)
-                            bv = B_ghost[(-off - 1) + c];          // ghost rows are row-major
-                        else
-                            bv = B_own[off + (int64_t)c * b_cs];
-                        acc[s] += v * bv;
+                const int64_t a64 = lo[s] > ch ? lo[s] : ch;
+                const int64_t e64 = hi[s] < ch + n ? hi[s] : ch + n;
+                a[s] = (int)(a64 - ch);
+                len[s] = e64 > a64 ? (int)(e64 - a64) : 0;
+                maxlen = len[s] > maxlen ? len[s] : maxlen;
+            }
+            for (int i = 0; i < maxlen; i += 2) {
+                double v[SLOTS][2], bv[SLOTS][2];
+                int64_t off[SLOTS][2];
+                bool ok[SLOTS][2];
+                // LDS reads first (all unconditional, index clamped to a valid entry), then the B
+                // loads back to back, then the sums in stored order
+#pragma unroll
+                for (int s = 0; s < SLOTS; ++s) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        ok[s][u] = i + u < len[s];
+                        const int idx = ok[s][u] ? a[s] + i + u : 0;
+                        off[s][u] = s_col[idx];
+                        v[s][u] = s_val[idx];
                     }
+                }
+#pragma unroll
+                for (int s = 0; s < SLOTS; ++s) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        bv[s][u] = 0.0;
+                        if (ok[s][u]) {
+                            if (SPLIT && off[s][u] < 0)
+                                bv[s][u] = B_ghost[(-off[s][u] - 1) + c];
+                            else
+                                bv[s][u] = B_own[off[s][u] + c_off];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < SLOTS; ++s) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+                        if (ok[s][u]) acc[s] += v[s][u] * bv[s][u];
                 }
             }
         }
+        // (col_ok is uniform per lane for the whole kt pass: no barrier is skipped by a subset)
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
             const int r = g + s * NGROUPS;

@@ -340,42 +340,62 @@ HPCLA_API int hpcla_cg_update_f64(hpcla_comm_t *comm, double alpha_host, const d
     return HPCLA_OK;
 }
 
-// index-mapped combine: the five addition kernels of the reference (_copy_a_only_/_copy_b_only_/
-// _negate_b_only_/_add_both_/_sub_both_kernel!, src/sparse.jl:1258-1303) as one entry point.
-// mode 0: out[dst[i]] = a[a_src[i]]          mode 1: out[dst[i]] = -a[a_src[i]]
-// mode 2: out[dst[i]] = a[a_src[i]] + b[b_src[i]]   mode 3: out[dst[i]] = a[a_src[i]] - b[b_src[i]]
-__global__ __launch_bounds__(256) void index_combine_kernel(double *__restrict__ out,
+// merge-combine: the five addition kernels of the reference (_copy_a_only_/_copy_b_only_/
+// _negate_b_only_/_add_both_/_sub_both_kernel!, src/sparse.jl:1258-1303) as ONE pass over the result:
+// entry i of the merged pattern takes a[ia[i]] (ia[i] >= 0) and/or b[ib[i]] (ib[i] >= 0); an entry that
+// exists on one side only is COPIED (or negated), never added to zero, exactly like the reference's
+// copy kernels (so -0.0 survives).  The result is written contiguously and both source index lists
+// are ascending, so all five streams are coalesced; 8 (out) + 2*sizeof(I) (lists) + <= 16 (values)
+// bytes per result entry instead of three index-mapped scatter passes.
+template <typename I>
+__global__ __launch_bounds__(256) void merge_combine_kernel(double *__restrict__ out,
                                                             const double *__restrict__ a,
-                                                            const int64_t *__restrict__ a_src,
+                                                            const I *__restrict__ ia,
                                                             const double *__restrict__ b,
-                                                            const int64_t *__restrict__ b_src,
-                                                            const int64_t *__restrict__ dst, int64_t n,
-                                                            int mode)
+                                                            const I *__restrict__ ib, int64_t n,
+                                                            int subtract)
 {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * 256;
     for (; i < n; i += stride) {
-        const double av = a[a_src[i]];
-        double r;
-        if (mode == 0) r = av;
-        else if (mode == 1) r = -av;
-        else if (mode == 2) r = av + b[b_src[i]];
-        else r = av - b[b_src[i]];
-        out[dst[i]] = r;
+        const I ja = ia[i], jb = ib[i];
+        double r = 0.0;
+        if (ja >= 0 && jb >= 0) {
+            const double av = a[ja], bv = b[jb];
+            r = subtract ? av - bv : av + bv;
+        } else if (ja >= 0) {
+            r = a[ja];
+        } else if (jb >= 0) {
+            const double bv = b[jb];
+            r = subtract ? -bv : bv;
+        }
+        out[i] = r;
     }
 }
 
-HPCLA_API int hpcla_index_combine_f64(double *out, const double *a, const int64_t *a_src, const double *b,
-                                      const int64_t *b_src, const int64_t *dst, int64_t n, int mode,
-                                      void *stream)
+template <typename I>
+static int merge_combine_launch(double *out, const double *a, const I *ia, const double *b, const I *ib,
+                                int64_t n, int subtract, void *stream)
 {
-    if (n < 0 || mode < 0 || mode > 3) return set_error(HPCLA_ERR_INVALID, "index_combine: bad size/mode");
+    if (n < 0 || (subtract != 0 && subtract != 1))
+        return set_error(HPCLA_ERR_INVALID, "merge_combine: bad size/mode");
     if (n == 0) return HPCLA_OK;
-    if (!out || !a || !a_src || !dst || (mode >= 2 && (!b || !b_src)))
-        return set_error(HPCLA_ERR_INVALID, "index_combine: null pointer");
-    index_combine_kernel<<<ew_grid(n), 256, 0, as_stream(stream)>>>(out, a, a_src, b, b_src, dst, n, mode);
+    if (!out || !a || !b || !ia || !ib) return set_error(HPCLA_ERR_INVALID, "merge_combine: null pointer");
+    merge_combine_kernel<I><<<ew_grid(n), 256, 0, as_stream(stream)>>>(out, a, ia, b, ib, n, subtract);
     HPCLA_CHECK_LAUNCH();
     return HPCLA_OK;
+}
+
+HPCLA_API int hpcla_merge_combine_f64_i32(double *out, const double *a, const int32_t *ia, const double *b,
+                                          const int32_t *ib, int64_t n, int subtract, void *stream)
+{
+    return merge_combine_launch<int32_t>(out, a, ia, b, ib, n, subtract, stream);
+}
+
+HPCLA_API int hpcla_merge_combine_f64_i64(double *out, const double *a, const int64_t *ia, const double *b,
+                                          const int64_t *ib, int64_t n, int subtract, void *stream)
+{
+    return merge_combine_launch<int64_t>(out, a, ia, b, ib, n, subtract, stream);
 }
 
 HPCLA_API int hpcla_fill_uniform_f64(double *v, int64_t start, int64_t count, uint64_t seed,

@@ -171,6 +171,67 @@ def test_full_size_config2_poisson4096(hp, orc, gpu_backend_i32):
     torch.cuda.empty_cache()
 
 
+def test_full_size_config4_share_poisson3d_cg_pieces(hp, orc, gpu_backend_i32):
+    """BASELINE configs[3]'s per-GPU share (512 x 512 x 64 planes of the 7-point Laplacian,
+    n = 16 777 216, nnz = 116 785 152): SpMV bit-exact against the oracle, the fused SpMV+dot equals
+    the separate dot to reduction tolerance, and 3 CG iterations keep the Krylov identities
+    (r_k orthogonal to r_{k-1} to rounding; residual norm equals ||b - A x||)."""
+    import torch
+    from hpcla_amd import workloads as wl
+    nx, ny, nz = 512, 512, 64
+    n = nx * ny * nz
+    rp, ci, va = wl.poisson3d_rows(nx, ny, nz, 0, n)
+    assert len(va) == 7 * n - 2 * (nx * ny + ny * nz + nx * nz) == 116_785_152
+    A = hp.HPCSparseMatrix_local(rp, ci, va, n, gpu_backend_i32)
+    bg = orc.fill_uniform(0, n, orc.SEED_RHS)
+    b = hp.HPCVector.from_global(bg, gpu_backend_i32)
+    y = A @ b
+    want = orc.spmv(rp.astype(np.int32), ci.astype(np.int32), va, bg)
+    np.testing.assert_array_equal(y.local_values(), want)
+    out = torch.zeros(1, dtype=torch.float64, device="cuda")
+    y2 = b.similar()
+    hp.mul_dot_(y2, A, b, out)
+    assert torch.equal(y2.v, y.v)
+    ref = float(np.dot(bg, want))
+    assert abs(out.item() - ref) <= RTOL_RED * float(np.dot(np.abs(bg), np.abs(want)))
+    x, hist = hp.cg_fixed_iterations(A, b, 3)
+    res = (b - A @ x)
+    true_norm = hp.norm(res)
+    assert abs(true_norm - hist[-1]) <= 1e-10 * hist[0]
+    del A, b, y, y2, x, res
+    hp.clear_plan_cache()
+    torch.cuda.empty_cache()
+
+
+def test_large_spmm_columns_equal_spmv_bitwise(hp, orc, gpu_backend_i32):
+    """Size-independent property of the reference's SpMM (src/sparse.jl:2391-2413: one SpMV per column):
+    column j of A*B is bit-identical to A*B[:,j], here at 1 048 576 rows, ~2.1e7 stored entries,
+    k = 16 (config 5's access pattern: uniformly random columns)."""
+    import torch
+    n, k, per_row = 1 << 20, 16, 20
+    rng = np.random.default_rng(5)
+    cols = np.sort(rng.integers(0, n, size=(n, per_row), dtype=np.int64), axis=1)
+    keep = np.ones_like(cols, dtype=bool)
+    keep[:, 1:] = cols[:, 1:] != cols[:, :-1]                       # drop duplicate columns within a row
+    counts = keep.sum(axis=1)
+    rp = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    ci = cols[keep]
+    va = rng.random(len(ci))
+    A = hp.HPCSparseMatrix_local(rp, ci, va, n, gpu_backend_i32)
+    Bg = rng.random((n, k))
+    B = hp.HPCMatrix.from_global(Bg, gpu_backend_i32)
+    C = hp.spmm(A, B)
+    for j in (0, 7, 15):
+        xj = hp.HPCVector.from_global(np.ascontiguousarray(Bg[:, j]), gpu_backend_i32)
+        yj = A @ xj
+        assert torch.equal(C.A[:, j].contiguous(), yj.v), f"column {j}"
+    want0 = orc.spmv(rp.astype(np.int32), ci.astype(np.int32), va, np.ascontiguousarray(Bg[:, 0]))
+    np.testing.assert_array_equal(C.A[:, 0].cpu().numpy(), want0)
+    del A, B, C
+    hp.clear_plan_cache(); hp.clear_spmm_cache()
+    torch.cuda.empty_cache()
+
+
 # ---------------------------------------------------------------------------------------------------
 # distributed semantics on ONE GPU: every simulated rank's split-column SpMV with a hand-filled
 # ghost segment + interior/boundary block lists == the reference pipeline for that rank
