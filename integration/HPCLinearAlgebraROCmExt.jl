@@ -23,6 +23,7 @@ using LinearAlgebra
 using SparseArrays
 
 using HPCLinearAlgebra: HPCBackend, DeviceROCm, CommSerial, CommMPI, AbstractComm, SolverMUMPS,
+                        VectorRepartitionPlan, AdditionPlan,
                         HPCVector, HPCSparseMatrix, HPCMatrix, VectorPlan,
                         comm_rank, comm_size, indextype_backend, get_vector_plan,
                         compute_partition_hash, assert_backends_compatible
@@ -241,6 +242,73 @@ function Base.:*(A::HPCSparseMatrix{T,Ti,B}, M::HPCMatrix{T,B}) where {T<:Float6
     _check(@ccall(LIB.hpcla_transpose_f64(_ptr(Crow)::Ptr{Cvoid}, k::Int64, 0::Cint, _ptr(C)::Ptr{Cvoid},
            A.nrows_local::Int64, 1::Cint, A.nrows_local::Int64, k::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_transpose_f64")
     return HPCLinearAlgebra.HPCMatrix_local(C, A.backend)
+end
+
+# ---- repartition(x, p)  (replaces the CPU-staged execute_plan! of src/vectors.jl:624-671) ---------------
+# The plan is the reference's own VectorRepartitionPlan; its range lists go to the C ABI unchanged
+# (1-based -> 0-based offsets).  Data moves GPU to GPU, no _ensure_cpu / _values_to_backend round trip.
+function HPCLinearAlgebra.execute_plan!(plan::HPCLinearAlgebra.VectorRepartitionPlan{T},
+                                        x::HPCVector{T,B}) where {T<:Float64,B<:ROCBackend}
+    out = AMDGPU.zeros(T, plan.result_local_size)
+    send_ranks = Cint.(plan.send_rank_ids)
+    send_off = Int64[first(r) - 1 for r in plan.send_ranges]
+    send_cnt = Int64[length(r) for r in plan.send_ranges]
+    recv_ranks = Cint.(plan.recv_rank_ids)
+    recv_off = Int64[o - 1 for o in plan.recv_offsets]
+    recv_cnt = Int64.(plan.recv_counts)
+    lsrc = isempty(plan.local_src_range) ? 0 : first(plan.local_src_range) - 1
+    ldst = isempty(plan.local_src_range) ? 0 : plan.local_dst_offset - 1
+    _check(@ccall(LIB.hpcla_exchange_ranges_f64(_rccl(x.backend.comm)::Ptr{Cvoid}, _ptr(x.v)::Ptr{Cvoid},
+           _ptr(out)::Ptr{Cvoid}, length(send_ranks)::Cint, send_ranks::Ptr{Cint}, send_off::Ptr{Int64},
+           send_cnt::Ptr{Int64}, length(recv_ranks)::Cint, recv_ranks::Ptr{Cint}, recv_off::Ptr{Int64},
+           recv_cnt::Ptr{Int64}, lsrc::Int64, ldst::Int64, length(plan.local_src_range)::Int64, 1::Cint,
+           _stream()::Ptr{Cvoid})::Cint), "hpcla_exchange_ranges_f64")
+    return HPCVector{T,B}(plan.result_partition_hash, plan.result_partition, out, x.backend)
+end
+
+# ---- A + B / A - B value pass  (replaces execute_addition!/execute_subtraction!, src/sparse.jl:1311-1375) --
+# One coalesced pass over the merged pattern instead of three index-mapped kernels: per result entry its
+# 0-based position in A.nzval / B.nzval, or -1.  Built once per AdditionPlan from the plan's own groups.
+const _merge_lists = IdDict{Any,Any}()
+function _merge_lists_for(plan::HPCLinearAlgebra.AdditionPlan{T,Ti}) where {T,Ti}
+    get!(_merge_lists, plan) do
+        n = Int(plan.colptr[end]) - 1
+        ia = fill(Int32(-1), n); ib = fill(Int32(-1), n)
+        ia[Array(plan.A_only_dst)] .= Int32.(Array(plan.A_only_src) .- 1)
+        ib[Array(plan.B_only_dst)] .= Int32.(Array(plan.B_only_src) .- 1)
+        ia[Array(plan.both_dst)] .= Int32.(Array(plan.both_A_src) .- 1)
+        ib[Array(plan.both_dst)] .= Int32.(Array(plan.both_B_src) .- 1)
+        (ROCArray(ia), ROCArray(ib))
+    end
+end
+function _merge_combine!(nzval::ROCVector{Float64}, plan, A_nzval::ROCVector{Float64}, B_nzval::ROCVector{Float64}, sub::Bool)
+    ia, ib = _merge_lists_for(plan)
+    _check(@ccall(LIB.hpcla_merge_combine_f64_i32(_ptr(nzval)::Ptr{Cvoid}, _ptr(A_nzval)::Ptr{Cvoid}, _ptr(ia)::Ptr{Cvoid},
+           _ptr(B_nzval)::Ptr{Cvoid}, _ptr(ib)::Ptr{Cvoid}, length(nzval)::Int64, (sub ? 1 : 0)::Cint,
+           _stream()::Ptr{Cvoid})::Cint), "hpcla_merge_combine_f64_i32")
+    return nzval
+end
+HPCLinearAlgebra.execute_addition!(nzval::ROCVector{Float64}, plan::HPCLinearAlgebra.AdditionPlan,
+                                   A_nzval::ROCVector{Float64}, B_nzval::ROCVector{Float64}) =
+    _merge_combine!(nzval, plan, A_nzval, B_nzval, false)
+HPCLinearAlgebra.execute_subtraction!(nzval::ROCVector{Float64}, plan::HPCLinearAlgebra.AdditionPlan,
+                                      A_nzval::ROCVector{Float64}, B_nzval::ROCVector{Float64}) =
+    _merge_combine!(nzval, plan, A_nzval, B_nzval, true)
+
+# ---- dense A * x and transpose(A) * x  (replace src/dense.jl:614-658, 1210-1261) ----------------------------
+# HPCMatrix stores its block column-major (Julia Matrix): a column-major (nloc x n) block IS the row-major
+# (n x nloc) block of its transpose, so the two entry points swap roles -- A*x reads A.A through the
+# column-sum kernel and transpose(A)*x through the row-dot kernel; no relayout.
+function Base.:*(A::HPCMatrix{T,B}, x::HPCVector{T,B}) where {T<:Float64,B<:ROCBackend}
+    comm_size(A.backend.comm) == 1 || error("multi-rank dense A*x: gather x with a halo plan first (see linearalgebrampi.jl_amd/dense.py)")
+    nloc, n = size(A.A)
+    y = AMDGPU.zeros(T, nloc)
+    work = AMDGPU.zeros(UInt8, @ccall LIB.hpcla_gemv_t_work_bytes(n::Int64, nloc::Int64)::Int64)
+    # y[i] = sum_j A.A[i,j] x[j]: column sums of the row-major (n x nloc) view weighted by x
+    _check(@ccall(LIB.hpcla_gemv_t_rowmajor_f64(_ptr(A.A)::Ptr{Cvoid}, nloc::Int64, n::Int64, nloc::Int64,
+           _ptr(x.v)::Ptr{Cvoid}, _ptr(y)::Ptr{Cvoid}, _ptr(work)::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint),
+           "hpcla_gemv_t_rowmajor_f64")
+    return HPCVector{T,B}(compute_partition_hash(A.row_partition), A.row_partition, y, A.backend)
 end
 
 end # module
