@@ -138,8 +138,9 @@ int hpcla_gen_poisson2d(int64_t nx, int64_t ny, int64_t row_start, int64_t row_e
  * CSR with int64 rowptr and GLOBAL int64 columns; A's colval indexes G's rows.  Each C(i,j) is the sum
  * over k ascending of separately rounded G(k,j)*A(i,k), first product assigned -- the reference order.
  *  ub:       ub_out[i] = sum of the lengths of the G rows that row i references
- *  numeric:  rows `row_list` (all with ub <= hpcla_spgemm_bin_cap(bin)) -> sorted (col,val) runs at
- *            c_*_tmp[ub_prefix[i] ...] and their lengths cnt[i]
+ *  numeric:  rows `row_list` (all with ub <= hpcla_spgemm_bin_cap(bin); bins 0,1,... until the cap is
+ *            -1; G's column ids must be < 2^58) -> sorted (col,val) runs at c_*_tmp[ub_prefix[i] ...]
+ *            and their lengths cnt[i]
  *  compact:  c_rowptr (exclusive scan of cnt) -> final CSR arrays */
 int64_t hpcla_spgemm_bin_cap(int bin);
 int hpcla_spgemm_ub_i32(const int32_t *a_rowptr, const int32_t *a_col, int64_t nrows, int index_base,

@@ -8,7 +8,8 @@
 // is the sum over k ASCENDING of separately rounded products, the first product assigned directly.
 //
 // Here `G` is the gathered-rows matrix (row r of G = row A.col_indices[r] of B, GLOBAL column ids).
-// One wavefront (short rows, 4 rows per workgroup) or one workgroup (long rows) owns an output row and
+// Rows with at most 64 candidate products take the register expand-sort-combine kernel further down.
+// Otherwise one wavefront (4 rows per workgroup) or one workgroup (long rows) owns an output row and
 // walks k sequentially; its lanes insert/accumulate the entries of G's row k into an LDS hash table
 // in parallel.  The columns within one row of G are distinct, so a (i,j) accumulator is touched by
 // at most one lane per k and the per-entry order over k is preserved: results are bit-identical to
@@ -142,6 +143,130 @@ __global__ __launch_bounds__(256) void spgemm_numeric_kernel(
     if (t == 0) cnt[row] = n_out;
 }
 
+// ---- short rows: expand - sort - combine inside one (sub-)wavefront, no LDS ----------------------
+// A row whose upper bound is <= L is owned by L lanes (L = 16 / 32 / 64: 16 / 8 / 4 rows per
+// workgroup).  Expand: the lanes first act as the row's A entries (k, length and start of gathered row
+// k, A value), an inclusive scan of the lengths numbers the products, and every product slot t finds
+// its A entry by a lower-bound search over the scan (register shuffles); all products of the row are
+// then loaded at once -- one memory round trip instead of one per k.  Sort: bitonic network over the
+// L lanes on the key (column * 64 + slot); slots ascend with k, so equal columns end up adjacent and
+// in ascending-k order.  Combine: the head lane of each run adds the following products one by one
+// (the reference's order: first product assigned, then += in ascending k), heads are ranked with a
+// ballot and written in column order.  Same bits as the hash kernels, ~4 dependent memory latencies
+// per row instead of ~3 per k, and 4 x - 16 x more rows in flight.
+template <int L>
+__device__ __forceinline__ unsigned long long group_ballot(bool pred, int lane)
+{
+    const unsigned long long m = __ballot(pred);
+    if (L == 64) return m;
+    return (m >> ((lane / L) * L)) & ((1ULL << L) - 1ULL);
+}
+
+template <typename I, int L>
+__global__ __launch_bounds__(256) void spgemm_esc_kernel(
+    const I *__restrict__ a_rowptr, const I *__restrict__ a_col, const double *__restrict__ a_val, int base,
+    const int64_t *__restrict__ g_rowptr, const int64_t *__restrict__ g_col,
+    const double *__restrict__ g_val, const int32_t *__restrict__ row_list, int64_t n_list,
+    const int64_t *__restrict__ ub_prefix, int64_t *__restrict__ c_col_tmp,
+    double *__restrict__ c_val_tmp, int64_t *__restrict__ cnt)
+{
+    constexpr int GROUPS = 256 / L;
+    constexpr unsigned long long INVALID = ~0ULL;
+    const int lane = threadIdx.x & 63;
+    const int t = threadIdx.x % L;
+    const int64_t li = (int64_t)blockIdx.x * GROUPS + threadIdx.x / L;
+    const bool active = li < n_list;
+    const int64_t row = active ? (int64_t)row_list[li] : 0;
+    const int64_t pa0 = active ? (int64_t)a_rowptr[row] - base : 0;
+    const int nk = active ? (int)((int64_t)a_rowptr[row + 1] - base - pa0) : 0;
+
+    // expand
+    int64_t my_q = -1;
+    double my_av = 0.0;
+    int base_slot = 0;
+    for (int pc = 0; __any(pc < nk); pc += L) {
+        const int p = pc + t;
+        const bool has = p < nk;
+        int64_t gs = 0;
+        int len = 0;
+        double av = 0.0;
+        if (has) {
+            const int64_t k = (int64_t)a_col[pa0 + p] - base;
+            gs = g_rowptr[k];
+            len = (int)(g_rowptr[k + 1] - gs);
+            av = a_val[pa0 + p];
+        }
+        int incl = len;
+#pragma unroll
+        for (int d = 1; d < L; d <<= 1) {
+            const int nb = __shfl_up(incl, d, L);
+            if (t >= d) incl += nb;
+        }
+        const int total = __shfl(incl, L - 1, L);
+        const int inclb = incl + base_slot;
+        // smallest j with inclb_j > t (lower bound over the non-decreasing scan)
+        int j = 0;
+#pragma unroll
+        for (int step = L / 2; step > 0; step >>= 1) {
+            const int v = __shfl(inclb, j + step - 1, L);
+            if (v <= t) j += step;
+        }
+        const int64_t o_gs = __shfl(gs, j, L);
+        const int o_excl = __shfl(inclb - len, j, L);
+        const double o_av = __shfl(av, j, L);
+        if (my_q < 0 && t >= base_slot && t < base_slot + total) {
+            my_q = o_gs + (t - o_excl);
+            my_av = o_av;
+        }
+        base_slot += total;
+    }
+    unsigned long long key = INVALID;
+    double val = 0.0;
+    if (my_q >= 0) {
+        val = g_val[my_q] * my_av;
+        key = ((unsigned long long)g_col[my_q] << 6) | (unsigned long long)t;
+    }
+    // sort (ascending; invalid keys last)
+#pragma unroll
+    for (int k2 = 2; k2 <= L; k2 <<= 1) {
+#pragma unroll
+        for (int jj = k2 >> 1; jj > 0; jj >>= 1) {
+            const unsigned long long okey = __shfl_xor(key, jj, L);
+            const double oval = __shfl_xor(val, jj, L);
+            const bool take_min = ((t & k2) == 0) == ((t & jj) == 0);
+            if (take_min ? (okey < key) : (okey > key)) {
+                key = okey;
+                val = oval;
+            }
+        }
+    }
+    // combine runs of equal columns in slot (= ascending k) order
+    const bool valid = key != INVALID;
+    const unsigned long long col = key >> 6;
+    const unsigned long long pcol = __shfl_up(col, 1, L);
+    const bool pvalid = __shfl_up((int)valid, 1, L) != 0;
+    const bool head = valid && (t == 0 || !pvalid || pcol != col);
+    double sum = val;
+    bool alive = head;
+    for (int d = 1; d < L && __any(alive); ++d) {
+        const unsigned long long ncol = __shfl_down(col, d, L);
+        const double nval = __shfl_down(val, d, L);
+        const bool nvalid = __shfl_down((int)valid, d, L) != 0;
+        if (alive && t + d < L && nvalid && ncol == col) sum += nval;
+        else alive = false;
+    }
+    const unsigned long long gm = group_ballot<L>(head, lane);
+    if (active) {
+        const int64_t off = ub_prefix[row];
+        if (head) {
+            const int rank = __popcll(gm & ((1ULL << t) - 1ULL));
+            c_col_tmp[off + rank] = (int64_t)col;
+            c_val_tmp[off + rank] = sum;
+        }
+        if (t == 0) cnt[row] = __popcll(gm);
+    }
+}
+
 __global__ __launch_bounds__(256) void spgemm_compact_kernel(const int64_t *__restrict__ c_rowptr,
                                                              const int64_t *__restrict__ ub_prefix,
                                                              int64_t nrows,
@@ -170,10 +295,11 @@ static int numeric_launch(int bin, const I *a_rowptr, const I *a_col, const doub
     if (n_list == 0) return HPCLA_OK;
 #define NUM_ARGS a_rowptr, a_col, a_val, base, g_rowptr, g_col, g_val, row_list, n_list, ub_prefix, c_col_tmp, c_val_tmp, cnt
     switch (bin) {
-        case 0: spgemm_numeric_kernel<I, 64, 32><<<(uint32_t)((n_list + 3) / 4), 256, 0, s>>>(NUM_ARGS); break;
-        case 1: spgemm_numeric_kernel<I, 64, 128><<<(uint32_t)((n_list + 3) / 4), 256, 0, s>>>(NUM_ARGS); break;
-        case 2: spgemm_numeric_kernel<I, 64, 512><<<(uint32_t)((n_list + 3) / 4), 256, 0, s>>>(NUM_ARGS); break;
-        case 3: spgemm_numeric_kernel<I, 256, 8192><<<(uint32_t)n_list, 256, 0, s>>>(NUM_ARGS); break;
+        case 0: spgemm_esc_kernel<I, 16><<<(uint32_t)((n_list + 15) / 16), 256, 0, s>>>(NUM_ARGS); break;
+        case 1: spgemm_esc_kernel<I, 32><<<(uint32_t)((n_list + 7) / 8), 256, 0, s>>>(NUM_ARGS); break;
+        case 2: spgemm_esc_kernel<I, 64><<<(uint32_t)((n_list + 3) / 4), 256, 0, s>>>(NUM_ARGS); break;
+        case 3: spgemm_numeric_kernel<I, 64, 512><<<(uint32_t)((n_list + 3) / 4), 256, 0, s>>>(NUM_ARGS); break;
+        case 4: spgemm_numeric_kernel<I, 256, 8192><<<(uint32_t)n_list, 256, 0, s>>>(NUM_ARGS); break;
         default: return set_error(HPCLA_ERR_INVALID, "spgemm: bad bin %d", bin);
     }
 #undef NUM_ARGS
@@ -185,12 +311,14 @@ static int numeric_launch(int bin, const I *a_rowptr, const I *a_col, const doub
 
 using namespace hpcla;
 
-// Bin b handles rows whose upper bound is <= hpcla_spgemm_bin_cap(b) (0..3); larger rows are not
+// Bin b handles rows whose upper bound is <= hpcla_spgemm_bin_cap(b) (b = 0..4, -1 beyond): bins 0-2
+// are the register expand-sort-combine kernel with 16 / 32 / 64 lanes per row, bins 3-4 the LDS hash
+// kernels (tables of 512 per wavefront / 8192 per workgroup, filled to <= 75 %).  Larger rows are not
 // supported by this build (HPCLA_ERR_UNSUPPORTED is the caller's to raise).
 HPCLA_API int64_t hpcla_spgemm_bin_cap(int bin)
 {
-    static const int64_t cap[4] = {24, 96, 384, 6144};     // <= 75 % of table sizes 32 / 128 / 512 / 8192
-    return (bin >= 0 && bin < 4) ? cap[bin] : -1;
+    static const int64_t cap[5] = {16, 32, 64, 384, 6144};
+    return (bin >= 0 && bin < 5) ? cap[bin] : -1;
 }
 
 #define SPGEMM_API(SFX, ITYPE)                                                                       \

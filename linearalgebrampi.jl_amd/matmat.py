@@ -206,7 +206,9 @@ def spgemm_local(A, g_rowptr, g_col, g_val, ncols_global: int, col_partition, ca
         _capi.call(f"hpcla_spgemm_ub_{sfx}", dptr(A.rowptr_target), dptr(a_col), nrows, 0, dptr(g_rowptr),
                    dptr(ub), s)
         ub_h = ub[:nrows].cpu().numpy()
-        caps = [lib.hpcla_spgemm_bin_cap(b) for b in range(4)]
+        caps = []
+        while lib.hpcla_spgemm_bin_cap(len(caps)) >= 0:          # bins are the library's to define
+            caps.append(lib.hpcla_spgemm_bin_cap(len(caps)))
         if nrows and ub_h.max() > caps[-1]:
             raise NotImplementedError(f"SpGEMM: an output row has up to {int(ub_h.max())} candidate entries; "
                                       f"this build handles {caps[-1]}")

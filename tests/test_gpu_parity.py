@@ -829,8 +829,8 @@ def test_spgemm_golden_host_layer(hp, golden, gpu_backend_i32, name):
 
 @pytest.mark.parametrize("which", ["i32", "i64"])
 def test_spgemm_bit_exact_vs_oracle(hp, orc, gpu_backend_i32, gpu_backend_i64, which):
-    """Random and stencil products incl. every row-length bin (tables of 32/128/512/8192 slots), empty
-    rows, and A*A of the 2-D Laplacian (the reference's only published SpGEMM benchmark case,
+    """Random and stencil products incl. every row-length bin (register kernel with 16/32/64 lanes per
+    row, hash tables of 512/8192 slots), empty rows, rows with more A entries than products, and A*A of the 2-D Laplacian (the reference's only published SpGEMM benchmark case,
     tools/benchmark_vs_petsc_results.txt:3-11)."""
     import scipy.sparse as sp
     b = gpu_backend_i32 if which == "i32" else gpu_backend_i64
@@ -848,6 +848,21 @@ def test_spgemm_bit_exact_vs_oracle(hp, orc, gpu_backend_i32, gpu_backend_i64, w
     Along = orc.LocalRows(rp, cols.astype(np.int64), rng.standard_normal(int(rp[-1])), 400)
     Bwide = orc.sprand_rows(5000, 0.016, 0, 400)                   # ~80 per row -> ub ~ 4800
     cases.append((Along, Bwide, 5000))
+    # bin edges of the register expand-sort-combine kernel (16 / 32 / 64 products per row) and rows
+    # with far more A entries than products (most referenced B rows are empty): row i of A has
+    # i % 90 entries; only every 3rd row of B is non-empty, with (r % 7) + 1 entries in few columns
+    nb, ncb = 300, 40
+    blen = np.where(np.arange(nb) % 3 == 0, (np.arange(nb) % 7) + 1, 0)
+    brp = np.concatenate([[0], np.cumsum(blen)])
+    bcols = np.concatenate([np.sort(rng.choice(ncb, size=l, replace=False)) for l in blen if l])
+    Bsparse = orc.LocalRows(brp, bcols.astype(np.int64), rng.standard_normal(int(brp[-1])), ncb)
+    alen = np.arange(400) % 90
+    arp = np.concatenate([[0], np.cumsum(alen)])
+    empties = np.flatnonzero(blen == 0)
+    acols = np.concatenate([np.sort(rng.choice(empties if (i % 50 == 5 or i % 50 == 45) else nb, size=l, replace=False))
+                            for i, l in enumerate(alen) if l])       # rows 5, 45, 55, ...: products = 0, nk up to 55
+    Aedge = orc.LocalRows(arp, acols.astype(np.int64), rng.standard_normal(int(arp[-1])), nb)
+    cases.append((Aedge, Bsparse, ncb))
     for Ar, Br, ncols in cases:
         A = hp.HPCSparseMatrix_local(Ar.rowptr, Ar.colidx, Ar.vals, Ar.ncols_global, b)
         B = hp.HPCSparseMatrix_local(Br.rowptr, Br.colidx, Br.vals, Br.ncols_global, b)
