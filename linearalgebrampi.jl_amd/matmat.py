@@ -225,11 +225,14 @@ def spgemm_local(A, g_rowptr, g_col, g_val, ncols_global: int, col_partition, ca
         sym["c_val_tmp"] = torch.empty(max(sym["total_ub"], 1), dtype=torch.float64, device=dev)
         if cache is not None:
             cache["symbolic"] = sym
-    for b, row_list, n in sym["bins"]:
-        _capi.call(f"hpcla_spgemm_numeric_{sfx}", b, dptr(A.rowptr_target), dptr(a_col), dptr(A.nzval), 0,
-                   dptr(g_rowptr), dptr(g_col), dptr(g_val), dptr(row_list), n, dptr(sym["ub_prefix"]),
-                   dptr(sym["c_col_tmp"]), dptr(sym["c_val_tmp"]), dptr(sym["cnt"]), s)
+    def numeric(offsets, col_out, val_out):
+        for b, row_list, n in sym["bins"]:
+            _capi.call(f"hpcla_spgemm_numeric_{sfx}", b, dptr(A.rowptr_target), dptr(a_col), dptr(A.nzval), 0,
+                       dptr(g_rowptr), dptr(g_col), dptr(g_val), dptr(row_list), n, dptr(offsets),
+                       dptr(col_out), dptr(val_out), dptr(sym["cnt"]), s)
+
     if sym["result"] is None:
+        numeric(sym["ub_prefix"], sym["c_col_tmp"], sym["c_val_tmp"])
         cnt_h = sym["cnt"][:nrows].cpu().numpy()
         c_rowptr_h = np.concatenate([[0], np.cumsum(cnt_h)]).astype(np.int64)
         nnz_c = int(c_rowptr_h[-1])
@@ -241,13 +244,15 @@ def spgemm_local(A, g_rowptr, g_col, g_val, ncols_global: int, col_partition, ca
         C = HPCSparseMatrix_local_device(c_rowptr, c_col, c_val, ncols_global, A.backend,
                                          col_partition=col_partition)
         sym["result"] = dict(c_rowptr64=c_rowptr, nnz=nnz_c, template=C, scratch_col=c_col)
+        sym["c_col_tmp"] = sym["c_val_tmp"] = sym["ub_prefix"] = None      # upper-bound slots: first product only
         return C
     # structure known: only the values are new (same structure arrays, like conj(A), src/sparse.jl:2261-2270)
     res = sym["result"]
     T = res["template"]
+    # the rows' final offsets are known, so the numeric kernels write the compacted arrays directly
+    # (offsets = the result's rowptr): no upper-bound slots, no compaction pass
     c_val = torch.empty(res["nnz"], dtype=torch.float64, device=dev)
-    _capi.call("hpcla_spgemm_compact", dptr(res["c_rowptr64"]), dptr(sym["ub_prefix"]), nrows,
-               dptr(sym["c_col_tmp"]), dptr(sym["c_val_tmp"]), dptr(res["scratch_col"]), dptr(c_val), s)
+    numeric(res["c_rowptr64"], res["scratch_col"], c_val)
     C = HPCSparseMatrix(T.row_partition, T.col_partition, T.col_indices, T._rowptr, T._colval, c_val,
                         T.rowptr_target, A.backend)
     C._colval_target = T._colval_target

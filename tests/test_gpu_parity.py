@@ -876,6 +876,13 @@ def test_spgemm_bit_exact_vs_oracle(hp, orc, gpu_backend_i32, gpu_backend_i64, w
         np.testing.assert_array_equal(rp_c, w_rp)
         np.testing.assert_array_equal(col_c, w_col)
         np.testing.assert_array_equal(val_c, w_val)               # bit-identical accumulation order
+        # repeated product with new values on the cached structure: numeric kernels write the final
+        # arrays directly (no upper-bound slots, no compaction) -- same structure, values scale exactly
+        A2 = hp.HPCSparseMatrix_local(Ar.rowptr, Ar.colidx, Ar.vals * 2.0, Ar.ncols_global, b)
+        rp_2, col_2, val_2 = _csr_of(A2 @ B)
+        np.testing.assert_array_equal(rp_2, w_rp)
+        np.testing.assert_array_equal(col_2, w_col)
+        np.testing.assert_array_equal(val_2, 2.0 * w_val)
         Cs = (sp.csr_matrix((Ar.vals, Ar.colidx, Ar.rowptr), shape=(Ar.nrows, Ar.ncols_global)) @
               sp.csr_matrix((Br.vals, Br.colidx, Br.rowptr), shape=(Br.nrows, Br.ncols_global))).tocsr()
         got = sp.csr_matrix((val_c, col_c, rp_c), shape=Cs.shape)
