@@ -196,6 +196,72 @@ cases["spgemm_nonsquare"] = dict(
     ref="test/test_matrix_multiplication.jl:64-88", m=6, k=8, n=10, IA=IA2, JA=JA2, VA=VA2, IB=IB2, JB=JB2, VB=VB2,
     C=[[(j + 1, v) for j, v in enumerate(row) if v is not None] for row in Cd2])
 
+# --- widened rows: transposes, A +/- B, D' * W * D chains --------------------------------
+def transpose_d(A):
+    return [list(r) for r in zip(*A)]
+
+
+def add_d(A, B, sign=1):
+    return [[a + sign * b for a, b in zip(ra, rb)] for ra, rb in zip(A, B)]
+
+
+def mul_d(A, B):
+    return [[sum(a * B[j][c] for j, a in enumerate(row) if a != 0) for c in range(len(B[0]))] for row in A]
+
+
+def coo_of(A):
+    I, J, V = [], [], []
+    for i, row in enumerate(A):
+        for j, v in enumerate(row):
+            if v != 0:
+                I.append(i + 1); J.append(j + 1); V.append(float(v))
+    return I, J, V
+
+
+def dense_f(A):
+    return [[float(v) for v in row] for row in A]
+
+
+def spdiagm(n, diags):
+    A = [[Fraction(0)] * n for _ in range(n)]
+    for off, vals in diags.items():
+        for t, v in enumerate(vals):
+            i, j = (t, t + off) if off >= 0 else (t - off, t)
+            A[i][j] = F(v)
+    return A
+
+
+# test/test_new_operations.jl:43-76: transpose(A_sparse) * x with the spmm_sym matrix, x = (1:8) .+ 0.1
+xt = [float(i) + 0.1 for i in range(1, 9)]
+cases["transpose_spmv"] = dict(
+    ref="test/test_new_operations.jl:43-76", m=8, n=8, I=I2, J=J2, V=V2, x=xt,
+    y=[float(sum(A[j][i] * F(xt[j]) for j in range(8))) for i in range(8)])
+
+# test/test_addition_different_sparsity.jl:41-62: tridiagonal + (diagonal, second superdiagonal)
+n8 = 8
+Aa = spdiagm(n8, {-1: [1.0] * 7, 0: [2.0] * 8, 1: [1.0] * 7})
+Bb = spdiagm(n8, {0: [3.0] * 8, 2: [0.5] * 6})
+IAa, JAa, VAa = coo_of(Aa)
+IBb, JBb, VBb = coo_of(Bb)
+cases["add_different_sparsity"] = dict(
+    ref="test/test_addition_different_sparsity.jl:41-62 (A+B); A-B by the same inputs (src/sparse.jl:1454-1494)",
+    n=n8, IA=IAa, JA=JAa, VA=VAa, IB=IBb, JB=JBb, VB=VBb,
+    sum=dense_f(add_d(Aa, Bb)), diff=dense_f(add_d(Aa, Bb, -1)))
+
+# test/test_addition_different_sparsity.jl:65-118: D' * W * D products and their sums
+dx = spdiagm(n8, {0: [-1.0] * 8, 1: [1.0] * 7})
+dx[7][7] = Fraction(0)
+idm = spdiagm(n8, {0: [1.0] * 8})
+Wm = spdiagm(n8, {0: [0.5] * 8})
+M1 = mul_d(mul_d(transpose_d(idm), Wm), dx)
+M2 = mul_d(mul_d(transpose_d(dx), Wm), idm)
+Hh = add_d(mul_d(mul_d(transpose_d(dx), Wm), dx), mul_d(mul_d(transpose_d(idm), Wm), idm))
+Idx, Jdx, Vdx = coo_of(dx)
+cases["dtwd_products"] = dict(
+    ref="test/test_addition_different_sparsity.jl:65-118",
+    n=n8, Idx=Idx, Jdx=Jdx, Vdx=Vdx, w=[0.5] * 8,
+    M_sum=dense_f(add_d(M1, M2)), H=dense_f(Hh))
+
 # --- uniform_partition docstring example: src/HPCLinearAlgebra.jl:269-277 ------------------------
 cases["uniform_partition"] = dict(
     ref="src/HPCLinearAlgebra.jl:269-289",

@@ -1043,6 +1043,49 @@ def test_row_vector_algebra(hp, orc, gpu_backend_i32):
     assert abs(vt @ w - float(vg @ wg)) <= 1e-12 * float(np.abs(vg) @ np.abs(wg))
 
 
+def _dense_of(M, shape):
+    import scipy.sparse as sp
+    rp, col, val = _csr_of(M)
+    return sp.csr_matrix((val, col, rp), shape=shape).toarray()
+
+
+def _from_coo(hp, I, J, V, m, n, backend):
+    import scipy.sparse as sp
+    return hp.HPCSparseMatrix_from_global(sp.coo_matrix((V, (np.array(I) - 1, np.array(J) - 1)), shape=(m, n)), backend)
+
+
+def test_widened_rows_on_reference_fixtures(hp, golden, gpu_backend_i32):
+    """The reference's own closed-form inputs for the SURVEY 8f rows, expected values in exact
+    rational arithmetic (tests/golden/make_golden.py), reference tolerance 1e-10 absolute:
+    transpose(A)*x (test/test_new_operations.jl:43-76), A+B / A-B with different sparsity and the
+    D' * W * D product chains (test/test_addition_different_sparsity.jl:41-118)."""
+    b = gpu_backend_i32
+    c = golden["transpose_spmv"]
+    A = _from_coo(hp, c["I"], c["J"], c["V"], c["m"], c["n"], b)
+    y = (hp.transpose(A) @ hp.HPCVector.from_global(np.array(c["x"]), b)).local_values()
+    assert np.max(np.abs(y - np.array(c["y"]))) < TOL_REF
+    c = golden["add_different_sparsity"]
+    n = c["n"]
+    A = _from_coo(hp, c["IA"], c["JA"], c["VA"], n, n, b)
+    B = _from_coo(hp, c["IB"], c["JB"], c["VB"], n, n, b)
+    np.testing.assert_array_equal(_dense_of(A + B, (n, n)), np.array(c["sum"]))      # small integers / halves: exact
+    np.testing.assert_array_equal(_dense_of(A - B, (n, n)), np.array(c["diff"]))
+    c = golden["dtwd_products"]
+    n = c["n"]
+    dx = _from_coo(hp, c["Idx"], c["Jdx"], c["Vdx"], n, n, b)
+    eye = _from_coo(hp, list(range(1, n + 1)), list(range(1, n + 1)), [1.0] * n, n, n, b)
+    W = _from_coo(hp, list(range(1, n + 1)), list(range(1, n + 1)), c["w"], n, n, b)
+    M1 = (hp.transpose(eye) @ W) @ dx
+    M2 = (hp.transpose(dx) @ W) @ eye
+    assert np.max(np.abs(_dense_of(M1 + M2, (n, n)) - np.array(c["M_sum"]))) < TOL_REF
+    H = (hp.transpose(dx) @ W) @ dx
+    H = H + (hp.transpose(eye) @ W) @ eye
+    assert np.max(np.abs(_dense_of(H, (n, n)) - np.array(c["H"]))) < TOL_REF
+    from hpcla_amd.addition import clear_addition_plan_cache
+    from hpcla_amd.matmat import clear_matrix_plan_cache
+    clear_addition_plan_cache(); clear_matrix_plan_cache(); hp.clear_plan_cache()
+
+
 def test_graft_entry_smoke():
     import __graft_entry__ as g
     g.smoke()

@@ -209,3 +209,19 @@ def test_spgemm_oracle_golden(orc, golden, name):
     Cs = (As @ Bs).tocsr(); Cs.sort_indices()
     got = sp.csr_matrix((val, col, rp), shape=(60, 70))
     assert abs(got - Cs).max() < 1e-13 and np.array_equal(np.diff(rp) >= np.diff(Cs.indptr), np.ones(60, bool))
+
+
+def test_widened_row_fixtures_are_self_consistent(golden):
+    """The SURVEY 8f fixtures (exact rational arithmetic, tests/golden/make_golden.py) against plain
+    float numpy on the same inputs: guards the generator itself (reference tolerance 1e-10)."""
+    import scipy.sparse as sp
+    coo = lambda I, J, V, n: sp.coo_matrix((V, (np.array(I) - 1, np.array(J) - 1)), shape=(n, n)).toarray()
+    c = golden["transpose_spmv"]
+    assert np.max(np.abs(coo(c["I"], c["J"], c["V"], 8).T @ np.array(c["x"]) - np.array(c["y"]))) < TOL
+    c = golden["add_different_sparsity"]
+    A, B = coo(c["IA"], c["JA"], c["VA"], 8), coo(c["IB"], c["JB"], c["VB"], 8)
+    assert np.array_equal(A + B, np.array(c["sum"])) and np.array_equal(A - B, np.array(c["diff"]))
+    c = golden["dtwd_products"]
+    dx, W, eye = coo(c["Idx"], c["Jdx"], c["Vdx"], 8), np.diag(c["w"]), np.eye(8)
+    assert np.max(np.abs(eye.T @ W @ dx + dx.T @ W @ eye - np.array(c["M_sum"]))) < TOL
+    assert np.max(np.abs(dx.T @ W @ dx + eye.T @ W @ eye - np.array(c["H"]))) < TOL
