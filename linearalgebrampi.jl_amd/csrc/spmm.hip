@@ -5,12 +5,10 @@
 //
 //   * a 256-thread workgroup owns RPB_MM = 64 consecutive rows; their (colval, nzval) range is
 //     streamed coalesced into LDS, CHUNK_MM entries at a time;
-//   * the workgroup is 16 lane-groups of 16 lanes; lane-group g owns rows g, g+16, g+32, g+48 of
-//     the block and lane l of the group owns output columns l, l+16, ...; for every stored entry
-//     the group reads (col,val) from LDS (broadcast) and one 16-column slice of row `col` of B
-//     (its four rows interleaved, see the kernel);
-//     with the device-native row-major B (k=16: exactly one 128-byte line per entry) that read is
-//     a single full-line access;
+//   * device-native layout (row-major B and C, k % 4 == 0): FOUR lanes share a row, each owns four
+//     adjacent output columns and reads its 32-byte slice of a B row with two 16-byte loads
+//     (spmm_rowblock_vec_kernel); any other layout / k: 16 lanes per row, one column each, generic
+//     strides (spmm_rowblock_kernel);
 //   * each C(r,c) is accumulated sequentially in stored order with separate multiply and add, so
 //     every output column is bit-identical to a reference SpMV of that column.
 //
@@ -143,6 +141,114 @@ __global__ __launch_bounds__(TPB_MM) void spmm_rowblock_kernel(
     }
 }
 
+// Vector form for the device-native layout (row-major B and C, k a multiple of 4, 16-byte aligned):
+// FOUR lanes share a matrix row, each owns four adjacent output columns and reads its 32-byte slice of
+// a B row with two 16-byte loads.  Per stored entry a lane now issues 2 loads and 8 flops instead of
+// 1 load and 2 flops behind the same address / predicate arithmetic -- the 8-byte-per-lane form above
+// is bound by instruction issue (~11 instructions per multiply-add), not by memory.  A workgroup still
+// owns 64 rows (one lane-group each), entries staged through LDS as 32-bit column ids; the entry loop
+// advances two entries per step (4 independent 16-byte loads per lane).  Deeper unrolling was slower:
+// 60 registers keep 7-8 wavefronts per SIMD resident, 96 (four entries per step) only 5.  Measured on
+// one box (profiles/r01_spmm_variants.log), 8-byte form -> this form: 5-point matrix x 16 columns
+// 1.043 -> 0.643 ms; config 5's random pattern with the 2.1 GB gather set 1.622 -> 1.516 ms; random with
+// B inside the Infinity Cache 1.247 -> 1.275 ms.  Also tried and dropped: no LDS staging (entries handed
+// round a lane-group with shuffles: 0.99 / 1.34 / 1.56 ms) and an XCD-sliced block order (1.03 / 1.24 /
+// 1.63 ms).  Each output column is still accumulated entry by entry in stored order: same bits.
+constexpr int VG = 4;                        // lanes per row
+constexpr int VCPL = KT / VG;                // 4 columns per lane
+constexpr int VU = 2;                        // entries per step: 4 independent 16-byte loads per lane
+
+typedef double vdouble2 __attribute__((ext_vector_type(2)));
+
+template <typename I, bool SPLIT>
+__global__ __launch_bounds__(TPB_MM) void spmm_rowblock_vec_kernel(
+    const I *__restrict__ rowptr, const I *__restrict__ colval, const double *__restrict__ nzval,
+    const double *__restrict__ B_own, int64_t b_rs, const double *__restrict__ B_ghost, int64_t bg_rs,
+    int64_t n_own, double *__restrict__ C, int64_t c_rs, int64_t nrows, int k, int base,
+    const int32_t *__restrict__ block_list, uint32_t nblocks)
+{
+    __shared__ double s_val[CHUNK_MM];
+    __shared__ int32_t s_col[CHUNK_MM];     // own: row of B; ghost: -(1 + ghost row)
+
+    const int tid = threadIdx.x;
+    const int g = tid / VG, l = tid % VG;   // g = row of the block (0..63)
+    const uint32_t b = blockIdx.x;
+    const int64_t blk = block_list ? (int64_t)block_list[b] : (int64_t)b;
+    const int64_t r0 = blk * RPB_MM;
+    const int nr = (int)((nrows - r0) < RPB_MM ? (nrows - r0) : RPB_MM);
+    const int64_t p0 = (int64_t)rowptr[r0] - base;
+    const int64_t p1 = (int64_t)rowptr[r0 + nr] - base;
+    const int64_t total = p1 - p0;
+    int64_t lo = 0, hi = 0;
+    if (g < nr) {
+        lo = (int64_t)rowptr[r0 + g] - base - p0;
+        hi = (int64_t)rowptr[r0 + g + 1] - base - p0;
+    }
+
+    for (int kt = 0; kt < k; kt += KT) {
+        const int c = kt + VCPL * l;
+        const bool col_ok = c < k;
+        double acc[VCPL];
+#pragma unroll
+        for (int q = 0; q < VCPL; ++q) acc[q] = 0.0;
+
+        for (int64_t ch = 0; ch < total; ch += CHUNK_MM) {
+            const int n = (int)((total - ch) < CHUNK_MM ? (total - ch) : CHUNK_MM);
+            __syncthreads();   // previous pass finished reading LDS
+            for (int i = tid; i < n; i += TPB_MM) {
+                const int64_t col = (int64_t)__builtin_nontemporal_load(colval + p0 + ch + i) - base;
+                s_val[i] = __builtin_nontemporal_load(nzval + p0 + ch + i);
+                s_col[i] = (SPLIT && col >= n_own) ? (int32_t)(-(1 + (col - n_own))) : (int32_t)col;
+            }
+            __syncthreads();
+            if (!col_ok) continue;
+            const int a = (int)((lo > ch ? lo : ch) - ch);
+            const int e = (int)((hi < ch + n ? hi : ch + n) - ch);
+            for (int j = a; j < e; j += VU) {
+                int32_t cj[VU];
+                double v[VU];
+                bool ok[VU];
+                vdouble2 b0[VU], b1[VU];
+#pragma unroll
+                for (int u = 0; u < VU; ++u) {
+                    ok[u] = j + u < e;
+                    const int idx = ok[u] ? j + u : j;
+                    cj[u] = s_col[idx];
+                    v[u] = s_val[idx];
+                }
+#pragma unroll
+                for (int u = 0; u < VU; ++u) {
+                    b0[u] = (vdouble2)(0.0);
+                    b1[u] = (vdouble2)(0.0);
+                    if (ok[u]) {
+                        const double *src = (SPLIT && cj[u] < 0)
+                                                ? B_ghost + (int64_t)(-cj[u] - 1) * bg_rs + c
+                                                : B_own + (int64_t)cj[u] * b_rs + c;
+                        b0[u] = *reinterpret_cast<const vdouble2 *>(src);
+                        b1[u] = *reinterpret_cast<const vdouble2 *>(src + 2);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < VU; ++u) {
+                    if (ok[u]) {
+                        acc[0] += v[u] * b0[u].x;
+                        acc[1] += v[u] * b0[u].y;
+                        acc[2] += v[u] * b1[u].x;
+                        acc[3] += v[u] * b1[u].y;
+                    }
+                }
+            }
+        }
+        if (g < nr && col_ok) {
+            double *dst = C + (r0 + g) * c_rs + c;
+            vdouble2 o0, o1;
+            o0.x = acc[0]; o0.y = acc[1]; o1.x = acc[2]; o1.y = acc[3];
+            *reinterpret_cast<vdouble2 *>(dst) = o0;
+            *reinterpret_cast<vdouble2 *>(dst + 2) = o1;
+        }
+    }
+}
+
 // tiled transpose / layout conversion: dst(i,c) = src(i,c), arbitrary (row,col) strides
 __global__ __launch_bounds__(256) void relayout_kernel(const double *__restrict__ src,
                                                        int64_t s_rs, int64_t s_cs,
@@ -201,7 +307,22 @@ static int spmm_launch(const I *rowptr, const I *colval, const double *nzval, co
     if (launch_blocks > 0x7fffffffLL) return set_error(HPCLA_ERR_INVALID, "spmm: too many blocks");
     hipStream_t s = as_stream(stream);
     dim3 grid((uint32_t)launch_blocks), block(TPB_MM);
-    if (split)
+    // device-native layout: row-major B / C, k % 4 == 0, everything 16-byte aligned, 32-bit column space
+    const bool vec_ok = b_cs == 1 && c_cs == 1 && (k % 4) == 0 && (b_rs % 2) == 0 && (c_rs % 2) == 0 &&
+                        (!split || (bg_rs % 2) == 0) &&
+                        ((reinterpret_cast<uintptr_t>(B_own) | reinterpret_cast<uintptr_t>(C) |
+                          (split ? reinterpret_cast<uintptr_t>(B_ghost) : 0)) & 15) == 0 &&
+                        sizeof(I) == 4;
+    if (vec_ok) {
+        if (split)
+            spmm_rowblock_vec_kernel<I, true><<<grid, block, 0, s>>>(
+                rowptr, colval, nzval, B_own, b_rs, B_ghost, bg_rs, n_own, C, c_rs, nrows, k, index_base,
+                block_list, (uint32_t)launch_blocks);
+        else
+            spmm_rowblock_vec_kernel<I, false><<<grid, block, 0, s>>>(
+                rowptr, colval, nzval, B_own, b_rs, nullptr, 0, 0, C, c_rs, nrows, k, index_base,
+                block_list, (uint32_t)launch_blocks);
+    } else if (split)
         spmm_rowblock_kernel<I, true><<<grid, block, 0, s>>>(
             rowptr, colval, nzval, B_own, b_rs, b_cs, B_ghost, bg_rs, n_own, C, c_rs, c_cs, nrows,
             k, index_base, block_list, (uint32_t)launch_blocks);
