@@ -129,6 +129,47 @@ def cpu_baseline_spmv(rowptr, colval, vals, x_gathered, budget_s):
     }
 
 
+def step_breakdown(hp, torch, dist, world, plan, A, x, y, barrier):
+    """Device time per call (HIP events, max over ranks) of the pieces of one distributed step."""
+    import ctypes
+    capi = hp._capi
+    sp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    cur = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    gp, gn = ctypes.c_void_p(), ctypes.c_int64(0)
+    if plan.has_halo:
+        capi.call("hpcla_halo_ghost_ptr", plan.halo, ctypes.byref(gp), ctypes.byref(gn))
+
+    def split(blocks, nb):
+        capi.call("hpcla_spmv_split_f64_i32", sp(A.rowptr_target), sp(plan.colval_split), sp(A.nzval), sp(x.v),
+                  gp if gp.value else None, plan.n_own, sp(y.v), A.nrows_local, A.nnz, 0, sp(blocks), nb, cur())
+
+    def exchange():
+        capi.call("hpcla_halo_begin", plan.halo, sp(x.v), cur())
+        capi.call("hpcla_halo_end", plan.halo, cur())
+
+    legs = [("all_row_blocks_no_exchange", lambda: split(None, 0))]
+    if plan.has_halo:
+        legs += [("interior_blocks", lambda: split(plan.interior, plan.n_interior)),
+                 ("boundary_blocks", lambda: split(plan.boundary, plan.n_boundary)),
+                 ("exchange_only", exchange)]
+    legs.append(("full_step", lambda: hp.mul_(y, A, x)))
+    out = {"n_interior_blocks": plan.n_interior, "n_boundary_blocks": plan.n_boundary, "ghost_values": int(gn.value)}
+    for name, fn in legs:
+        fn()
+        barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50):
+            fn()
+        e1.record()
+        barrier()
+        t = torch.tensor([e0.elapsed_time(e1) / 50], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        out[name + "_ms"] = round(float(t.item()), 5)
+    return out
+
+
 def main():
     args = parse()
     import torch
@@ -265,6 +306,16 @@ def main():
     torch.cuda.synchronize()
     stream_ms = a.elapsed_time(b) / reps
 
+    # ---- N > 1: where a distributed step spends its time (device time per call, HIP events; every rank makes
+    #      the same calls in the same order, and the only communication is the step's own halo exchange) ----
+    breakdown = None
+    selftest = os.environ.get("HPCLA_BENCH_BREAKDOWN_SELFTEST", "") == "1"      # runs the local legs at N = 1
+    if ((world > 1 and plan.has_halo) or selftest) and not plan.is_i64:
+        try:
+            breakdown = step_breakdown(hp, torch, dist, world, plan, A, x, y, barrier)
+        except Exception as exc:        # identical code and call order on every rank: all ranks land here together
+            breakdown = {"error": f"{type(exc).__name__}: {exc}"}
+
     # ---- opt-in packed copy (3 B per stored entry instead of 12; same bits), reported separately --------
     packed = None
     if not args.no_packed:
@@ -342,6 +393,8 @@ def main():
         "verified_vs_closed_form": verified, "setup_s": round(setup_s, 2),
         "packed_csr_opt_in": packed,
     }
+    if breakdown is not None:
+        result["step_breakdown_ms_max_over_ranks"] = breakdown
     if rank == 0 and not args.no_cpu_baseline:
         xg = x.local_values()
         ghost = np.zeros(0)

@@ -95,6 +95,21 @@ def main():
         torch.cuda.synchronize()
         print(f"{name:30s} {np.median(res):8.4f} ms/step (min {np.min(res):.4f})   host enqueue {host:.4f} ms/step")
     print(f"interior blocks {interior.numel()}, boundary blocks {boundary.numel()}")
+    # bench.py's N > 1 diagnostic (step_breakdown) on the same self-exchanging slab: stand-ins for the
+    # host-layer objects it reads
+    import json
+    from types import SimpleNamespace as NS
+    import bench
+    fplan = NS(has_halo=True, halo=plan, colval_split=d_cv, n_own=nloc, interior=interior, boundary=boundary,
+               n_interior=int(interior.numel()), n_boundary=int(boundary.numel()), is_i64=False)
+    fA = NS(rowptr_target=d_rp, nzval=d_nz, nrows_local=nloc, nnz=len(vals))
+    fx, fy = NS(v=x), NS(v=y)
+    real_mul = hp.mul_
+    hp.mul_ = lambda yy, AA, xx: dist()              # the fused step of this harness
+    try:
+        print("step_breakdown:", json.dumps(bench.step_breakdown(hp, torch, None, 1, fplan, fA, fx, fy, torch.cuda.synchronize)))
+    finally:
+        hp.mul_ = real_mul
     capi.call("hpcla_halo_plan_destroy", plan)
 
 
