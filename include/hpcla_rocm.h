@@ -264,9 +264,15 @@ int hpcla_halo_ghost_ptr(hpcla_halo_plan_t *plan, double **ghost, int64_t *n_gho
 int hpcla_halo_begin(hpcla_halo_plan_t *plan, const double *x, void *stream);
 int hpcla_halo_end(hpcla_halo_plan_t *plan, void *stream);
 
-/* Fused distributed SpMV  y = A*x  (Base.:*(A,x), src/sparse.jl:2096-2128; mul!, :2019-2037):
- * halo_begin -> interior blocks -> halo_end -> boundary blocks.  block lists from
- * hpcla_classify_blocks_*; with plan==NULL or no neighbours it is a plain split SpMV. */
+/* Fused distributed SpMV  y = A*x  (Base.:*(A,x), src/sparse.jl:2096-2128; mul!, :2019-2037).
+ * Two orderings, chosen by the environment variable HPCLA_HALO_MODE when the library is first used:
+ *   "serial" (default)  the send/recv group on `stream`, then ONE launch over all row blocks;
+ *   "overlap"           exchange + boundary blocks on the plan's side stream, interior blocks on
+ *                       `stream`, joined by events (block lists from hpcla_classify_blocks_*).
+ * On MI355X the SpMV kernel fills every wave slot of every CU, so a side-stream RCCL kernel only runs
+ * once the interior grid drains; measured "overlap" = +29..32 us, "serial" = +13..14 us per 4096^2 step
+ * (profiles/r01_halo_mode_experiments.log).  Both give the same bits.  With plan==NULL or no
+ * neighbours it is a plain split SpMV. */
 int hpcla_spmv_dist_f64_i32(hpcla_halo_plan_t *plan, const int32_t *rowptr,
                             const int32_t *colval_split, const double *nzval, const double *x,
                             int64_t n_own, double *y, int64_t nrows, int64_t nnz, int index_base,

@@ -4,9 +4,11 @@
 // there every SpMV copies x to the host, packs send buffers on the CPU, runs MPI Isend/Irecv on host
 // memory, unpacks and copies the gathered vector back to the device, strictly before the kernel.
 // Here the exchange never leaves the GPUs: a pack kernel (skipped when a neighbour's indices are one
-// contiguous run, as for stencil slabs) and one ncclGroup of ncclSend/ncclRecv over xGMI run on the
-// plan's side stream while the interior row blocks are computed on the caller's stream; receives
-// land directly in the ghost segment the boundary row blocks read (no unpack, no local copy).
+// contiguous run, as for stencil slabs) and one ncclGroup of ncclSend/ncclRecv over xGMI; receives
+// land directly in the ghost segment the row blocks read (no unpack, no local copy).  The group runs
+// either on the caller's stream ahead of one fused launch, or on the plan's side stream while the
+// interior row blocks are computed on the caller's stream (spmv_dist_impl has the measurements that
+// decide the default); the SpMM path and hpcla_halo_begin/end always use the side stream.
 //
 // librccl is loaded lazily with dlopen so the single-GPU path has no RCCL dependency; inside a
 // PyTorch process the already-loaded librccl.so.1 is reused (same SONAME).
@@ -416,7 +418,8 @@ HPCLA_API int hpcla_halo_ghost_ptr(hpcla_halo_plan_t *plan, double **ghost, int6
     return HPCLA_OK;
 }
 
-static int halo_post(hpcla_halo_plan_t *plan, const double *x, void *stream, bool record_done);
+static int halo_post(hpcla_halo_plan_t *plan, const double *x, void *stream, bool record_done,
+                     bool inline_on_main = false);
 
 HPCLA_API int hpcla_halo_begin(hpcla_halo_plan_t *plan, const double *x, void *stream)
 {
@@ -425,7 +428,8 @@ HPCLA_API int hpcla_halo_begin(hpcla_halo_plan_t *plan, const double *x, void *s
 
 // posts the exchange on the plan's side stream; with record_done == false the caller enqueues more
 // work on the side stream (the boundary row blocks) and records ev_done itself
-static int halo_post(hpcla_halo_plan_t *plan, const double *x, void *stream, bool record_done)
+static int halo_post(hpcla_halo_plan_t *plan, const double *x, void *stream, bool record_done,
+                     bool inline_on_main)
 {
     if (!plan) return set_error(HPCLA_ERR_INVALID, "halo_begin: null plan");
     if (plan->send_ranks.empty() && plan->recv_ranks.empty()) return HPCLA_OK;
@@ -434,17 +438,20 @@ static int halo_post(hpcla_halo_plan_t *plan, const double *x, void *stream, boo
     const int w = plan->width;
     // the exchange may start once everything enqueued on the caller's stream (the producer of x, and
     // the previous consumer of the ghost segment) has finished
-    HPCLA_CHECK_HIP(hipEventRecord(plan->ev_ready, main));
-    HPCLA_CHECK_HIP(hipStreamWaitEvent(plan->side, plan->ev_ready, 0));
+    hipStream_t cs = inline_on_main ? main : plan->side;      // stream that carries the exchange
+    if (!inline_on_main) {
+        HPCLA_CHECK_HIP(hipEventRecord(plan->ev_ready, main));
+        HPCLA_CHECK_HIP(hipStreamWaitEvent(plan->side, plan->ev_ready, 0));
+    }
     if (plan->need_pack) {
         const int64_t total = plan->n_send_total * w;
         int64_t g = (total + 255) / 256;
         if (g > 4096) g = 4096;
         if (plan->idx_is_i64)
-            pack_kernel<int64_t><<<(uint32_t)g, 256, 0, plan->side>>>(
+            pack_kernel<int64_t><<<(uint32_t)g, 256, 0, cs>>>(
                 x, (const int64_t *)plan->send_idx, plan->send_buf, plan->n_send_total, w);
         else
-            pack_kernel<int32_t><<<(uint32_t)g, 256, 0, plan->side>>>(
+            pack_kernel<int32_t><<<(uint32_t)g, 256, 0, cs>>>(
                 x, (const int32_t *)plan->send_idx, plan->send_buf, plan->n_send_total, w);
         HPCLA_CHECK_LAUNCH();
     }
@@ -454,17 +461,17 @@ static int halo_post(hpcla_halo_plan_t *plan, const double *x, void *stream, boo
         if (plan->recv_counts[i] == 0) continue;
         HPCLA_CHECK_RCCL(g_rccl.Recv(plan->ghost + plan->recv_off[i] * w,
                                      (size_t)(plan->recv_counts[i] * w), ncclDouble,
-                                     plan->recv_ranks[i], nc, plan->side));
+                                     plan->recv_ranks[i], nc, cs));
     }
     for (size_t i = 0; i < plan->send_ranks.size(); ++i) {
         if (plan->send_counts[i] == 0) continue;
         const double *src = plan->send_contig[i] ? x + plan->send_first[i] * w
                                                  : plan->send_buf + plan->send_off[i] * w;
         HPCLA_CHECK_RCCL(g_rccl.Send(src, (size_t)(plan->send_counts[i] * w), ncclDouble,
-                                     plan->send_ranks[i], nc, plan->side));
+                                     plan->send_ranks[i], nc, cs));
     }
     HPCLA_CHECK_RCCL(g_rccl.GroupEnd());
-    if (record_done) HPCLA_CHECK_HIP(hipEventRecord(plan->ev_done, plan->side));
+    if (record_done && !inline_on_main) HPCLA_CHECK_HIP(hipEventRecord(plan->ev_done, plan->side));
     return HPCLA_OK;
 }
 
@@ -494,6 +501,25 @@ static int spmv_dist_impl(F split_fn, hpcla_halo_plan_t *plan, const I *rowptr, 
     // side stream: exchange, then the boundary row blocks (they need the ghosts); caller's stream:
     // the interior row blocks, concurrently.  Both write disjoint rows of y; the caller's stream
     // joins the side stream at the end.
+    // Two ways to order the step (HPCLA_HALO_MODE, default "serial"):
+    //  serial   exchange on the CALLER's stream, then one launch over all row blocks.  No side stream, no
+    //           events, no interior/boundary split.
+    //  overlap  exchange + boundary blocks on the plan's side stream, interior blocks on the caller's.
+    // Measured on MI355X (profiles/r01_halo_mode_experiments.log): the SpMV kernel keeps 8 workgroups =
+    // all 32 wave slots of every CU busy, so a side-stream RCCL kernel only becomes resident when the
+    // interior grid drains -- "overlap" then costs interior + exchange + boundary + two cross-stream hops
+    // (+32 us per 4096^2 step) against exchange + kernel (+13 us) for "serial".  Overlap pays only next
+    // to kernels that leave CU room (the SpMM path, 6 workgroups per CU, keeps it).
+    static const bool serial_mode = [] {
+        const char *e = getenv("HPCLA_HALO_MODE");
+        return !(e && e[0] == 'o');
+    }();
+    if (serial_mode) {
+        int rc0 = halo_post(plan, x, stream, false, true);
+        if (rc0) return rc0;
+        return split_fn(rowptr, colval, nzval, x, plan->ghost, n_own, y, nrows, nnz, index_base, nullptr, 0,
+                        stream, dot_partial, -1);
+    }
     int rc = halo_post(plan, x, stream, false);
     if (rc) return rc;
     if (n_boundary > 0) {

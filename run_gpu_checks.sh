@@ -26,6 +26,7 @@ for st in $STEPS; do
       tail -3 gpurun_out/${TAG}_prof.log;;
     spgemm) run 600 gpurun_out/${TAG}_spgemm.log python benchmarks/bench_spgemm.py; tail -5 gpurun_out/${TAG}_spgemm.log;;
     halo)   run 600 gpurun_out/${TAG}_halo.log python benchmarks/bench_halo_overhead.py; tail -5 gpurun_out/${TAG}_halo.log;;
+    halo_modes) for mode in serial overlap; do HPCLA_HALO_MODE=$mode run 600 gpurun_out/${TAG}_halo_${mode}.log python benchmarks/bench_halo_overhead.py; echo "$mode: $(grep -E 'plain split|halo \+ interior' gpurun_out/${TAG}_halo_${mode}.log | sed 's/host enqueue.*//' | tr '\n' ' ')"; done;;
     halo_ch) for ch in 4 16; do NCCL_MIN_P2P_NCHANNELS=$ch run 600 gpurun_out/${TAG}_halo_ch$ch.log python benchmarks/bench_halo_overhead.py; grep -E 'plain split|halo \+ interior|exchange only' gpurun_out/${TAG}_halo_ch$ch.log; done;;
     halotrace)
       run 600 gpurun_out/${TAG}_halotrace.log rocprofv3 --kernel-trace --output-format csv -d gpurun_out/${TAG}_halotrace -- python3 benchmarks/bench_halo_overhead.py

@@ -304,10 +304,13 @@ def test_execute_plan_gathered_serial(hp, orc, gpu_backend_i32):
     assert A.ncols_compressed < n
 
 
-def test_rccl_halo_self_exchange_subprocess():
-    """The RCCL send/recv + side-stream + event code of hpcla_halo_begin/end, exercised on one GPU
-    with a one-rank RCCL communicator sending to itself (HPCLA_FORCE_RCCL=1)."""
-    env = dict(os.environ, HPCLA_FORCE_RCCL="1")
+@pytest.mark.parametrize("mode", ["serial", "overlap"])
+def test_rccl_halo_self_exchange_subprocess(mode):
+    """The RCCL send/recv + side-stream + event code of hpcla_halo_begin/end and both orderings of the
+    fused distributed SpMV (HPCLA_HALO_MODE: exchange on the caller's stream then one launch / exchange
+    and boundary blocks on the side stream next to the interior blocks), exercised on one GPU with a
+    one-rank RCCL communicator sending to itself (HPCLA_FORCE_RCCL=1)."""
+    env = dict(os.environ, HPCLA_FORCE_RCCL="1", HPCLA_HALO_MODE=mode)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_halo_self_worker.py")],
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
