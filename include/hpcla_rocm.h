@@ -202,8 +202,9 @@ int hpcla_gemv_t_rowmajor_f64(const double *A, int64_t lda, int64_t nrows, int64
 
 
 /* ---- gather: replaces _gather_kernel! (src/vectors.jl:174-194) --------------------------------
- * out[dst[i]] = x[src[i]] (dst may be NULL = identity).  Kept for API parity
- * (execute_plan! returning `gathered`); the SpMV hot path does not need it. */
+ * out[dst[i]] = x[src[i]] (dst may be NULL = identity).  The SpMV hot path does not need it (split
+ * column space); used for execute_plan! returning `gathered`, the SpGEMM value gather and the value
+ * permutations of the TransposePlan (src/sparse.jl:1702-1845). */
 int hpcla_gather_f64_i32(const double *x, const int32_t *src, const int32_t *dst, double *out,
                          int64_t n, int index_base, void *stream);
 int hpcla_gather_f64_i64(const double *x, const int64_t *src, const int64_t *dst, double *out,

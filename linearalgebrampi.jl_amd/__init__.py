@@ -31,8 +31,8 @@ from .dense import (HPCMatrix, HPCMatrix_local, TransposedHPCMatrix, clear_dense
                     dense_matvec, dense_matvec_t, spmm)
 from .matmat import clear_matrix_plan_cache, get_matrix_plan, spgemm
 from .cg import cg_fixed_iterations
-from .transpose import (TransposedHPCSparseMatrix, TransposedHPCVector, adjoint, transpose,
-                        transpose_local_rows)
+from .transpose import (HostTransposeStructure, TransposedHPCSparseMatrix, TransposedHPCVector, TransposePlan,
+                        adjoint, clear_transpose_plan_cache, get_transpose_plan, transpose)
 from .addition import sparse_add
 from .repartition import (RangePlan, SparseRepartitionPlan, clear_repartition_cache, exchange_ranges,
                           get_sparse_repartition_plan, get_vector_repartition_plan, repartition)

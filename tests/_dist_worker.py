@@ -93,7 +93,14 @@ def main():
     Ag = sp.csr_matrix((glob.vals, glob.colidx, glob.rowptr), shape=(m, ncol))
     rp, cp = orc.uniform_partition(m, nranks), orc.uniform_partition(ncol, nranks)
     loc = Ag[rp[rank]:rp[rank + 1], :]
-    trp, tci, tv = hp.transpose_local_rows(loc.indptr, loc.indices, loc.data, rp, cp, comm)
+    st = hp.HostTransposeStructure(loc.indptr, loc.indices, rp, cp, comm)
+    # emulate TransposePlan.execute on the host: gather into send order, range exchange, gather into result order
+    send = loc.data[st.send_order]
+    got = B.comm_exchange_arrays(comm, st.peers_out, [send[st.bounds[r]:st.bounds[r + 1]] for r in st.peers_out],
+                                 st.peers_in, st.recv_counts, np.float64)
+    recv = np.concatenate([send[st.bounds[rank]:st.bounds[rank + 1]]] + got)
+    assert len(recv) == st.n_total and st.n_own_segment == st.bounds[rank + 1] - st.bounds[rank]
+    trp, tci, tv = st.rowptr_t, st.col_t, recv[st.final_order]
     AT = Ag.T.tocsr()
     AT.sort_indices()
     want = AT[cp[rank]:cp[rank + 1], :]
