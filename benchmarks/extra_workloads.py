@@ -159,6 +159,32 @@ def run(args, backend, rank, world):
         vals = rng.random(nnz)
         A = hp.HPCSparseMatrix_local(rowptr, cols, vals, ncols, backend)
         del cols, vals
+        if os.environ.get("HPCLA_SPRAND_SPMV", "") == "1":
+            # the same unstructured matrix times ONE vector (single GPU only): the x gather is one
+            # 64-byte sector per stored entry, far from the each-value-once algorithmic count
+            xv = hp.HPCVector.zeros(np.array([0, ncols]), backend)
+            hp._capi.call("hpcla_fill_uniform_f64", xv.v.data_ptr(), 0, ncols, wl.SEED_X,
+                          torch.cuda.current_stream().cuda_stream)
+            yv = A @ xv
+            for _ in range(args.warmup):
+                hp.mul_(yv, A, xv)
+            _sync_barrier(torch, dist, world)
+            steps = min(args.steps, 50)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                hp.mul_(yv, A, xv)
+            _sync_barrier(torch, dist, world)
+            ms = (time.perf_counter() - t0) / steps * 1e3
+            b_alg = wl.spmv_algorithmic_bytes(A.nnz, A.nrows_local, A.ncols_compressed, 4)
+            b_sect = A.nnz * (12 + 64) + 12 * A.nrows_local
+            print(json.dumps({"metric": "SpMV GFLOP/s, sprand ~29.8 nnz/row", "value": round(2.0 * A.nnz / (ms * 1e-3) / 1e9, 1),
+                              "ms_per_step": round(ms, 4), "nnz": A.nnz, "ncols_compressed": A.ncols_compressed,
+                              "algorithmic_gbs": round(b_alg / (ms * 1e-3) / 1e9, 1),
+                              "frac_of_peak_algorithmic": round(b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                              "sector_gather_gbs": round(b_sect / (ms * 1e-3) / 1e9, 1),
+                              "note": "sector_gather = 12 B + one 64-byte sector of x per stored entry"}), flush=True)
+            hp.clear_plan_cache()
+            return
         b_rows = rows_loc * mult
         Bl = torch.empty((b_rows, k), dtype=torch.float64, device=dev)
         hp._capi.call("hpcla_fill_uniform_f64", Bl.data_ptr(), rank * b_rows * k, b_rows * k, wl.SEED_X,
