@@ -147,6 +147,16 @@ bool halo_active(const hpcla_halo_plan_t *plan)
     return plan && !(plan->send_ranks.empty() && plan->recv_ranks.empty());
 }
 
+// HPCLA_HALO_MODE: "serial" (default) or "overlap" -- see spmv_dist_impl
+bool halo_serial_mode()
+{
+    static const bool serial = [] {
+        const char *e = getenv("HPCLA_HALO_MODE");
+        return !(e && e[0] == 'o');
+    }();
+    return serial;
+}
+
 }  // namespace hpcla
 
 using namespace hpcla;
@@ -387,10 +397,8 @@ HPCLA_API int hpcla_halo_plan_create(hpcla_halo_plan_t **plan, hpcla_comm_t *com
         HALO_HIP(hipMemset(p->ghost, 0, p->n_ghost * width * sizeof(double)));
     }
     {
-        // highest stream priority: the exchange (and the boundary row blocks behind it) must be
-        // dispatched AHEAD of the interior kernel's ~65 000 queued workgroups; at equal priority the
-        // side-stream work only starts when the interior grid has drained (measured: exchange time
-        // added to, instead of hidden under, the interior kernel)
+        // highest stream priority, so that side-stream work is dispatched ahead of the caller's queued
+        // workgroups wherever a CU has room for it (next to the SpMV kernel none has: spmv_dist_impl)
         int prio_least = 0, prio_greatest = 0;
         HALO_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
         HALO_HIP(hipStreamCreateWithPriority(&p->side, hipStreamNonBlocking, prio_greatest));
@@ -475,6 +483,14 @@ static int halo_post(hpcla_halo_plan_t *plan, const double *x, void *stream, boo
     return HPCLA_OK;
 }
 
+namespace hpcla {
+// the exchange on the caller's stream itself (serial mode), for packed.hip
+int halo_exchange_inline(hpcla_halo_plan_t *plan, const double *x, void *stream)
+{
+    return halo_post(plan, x, stream, false, true);
+}
+}  // namespace hpcla
+
 HPCLA_API int hpcla_halo_end(hpcla_halo_plan_t *plan, void *stream)
 {
     if (!plan) return set_error(HPCLA_ERR_INVALID, "halo_end: null plan");
@@ -510,11 +526,7 @@ static int spmv_dist_impl(F split_fn, hpcla_halo_plan_t *plan, const I *rowptr, 
     // interior grid drains -- "overlap" then costs interior + exchange + boundary + two cross-stream hops
     // (+32 us per 4096^2 step) against exchange + kernel (+13 us) for "serial".  Overlap pays only next
     // to kernels that leave CU room (the SpMM path, 6 workgroups per CU, keeps it).
-    static const bool serial_mode = [] {
-        const char *e = getenv("HPCLA_HALO_MODE");
-        return !(e && e[0] == 'o');
-    }();
-    if (serial_mode) {
+    if (halo_serial_mode()) {
         int rc0 = halo_post(plan, x, stream, false, true);
         if (rc0) return rc0;
         return split_fn(rowptr, colval, nzval, x, plan->ghost, n_own, y, nrows, nnz, index_base, nullptr, 0,
