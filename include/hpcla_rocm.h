@@ -345,6 +345,10 @@ int hpcla_asum_f64(hpcla_comm_t *comm, const double *x, int64_t n, double *out_d
                    void *stream);
 int hpcla_amax_f64(hpcla_comm_t *comm, const double *x, int64_t n, double *out_dev, void *work,
                    void *stream);
+/* general p-norm, p > 0 finite: out = sum |x_i|^p over all ranks; the caller takes the 1/p power
+ * (norm(v, p), src/vectors.jl:774-779) */
+int hpcla_powsum_f64(hpcla_comm_t *comm, const double *x, int64_t n, double p, double *out_dev, void *work,
+                     void *stream);
 
 /* ---- vector updates: replace u+v, a*v and fused broadcast (src/vectors.jl:868-903, 944-964,
  * 1203-1226).  The scalar is alpha_host * (num_dev ? *num_dev : 1) / (den_dev ? *den_dev : 1),

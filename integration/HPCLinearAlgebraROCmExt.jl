@@ -219,7 +219,10 @@ function LinearAlgebra.norm(v::HPCVector{T,B}, p::Real=2) where {T<:Float64,B<:R
                _ptr(work)::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_amax_f64")
         return Array(out)[1]
     else
-        return invoke(LinearAlgebra.norm, Tuple{HPCVector,Real}, v, p)      # generic path of the parent
+        p > 0 || return invoke(LinearAlgebra.norm, Tuple{HPCVector,Real}, v, p)     # generic path of the parent
+        _check(@ccall(LIB.hpcla_powsum_f64(c::Ptr{Cvoid}, _ptr(v.v)::Ptr{Cvoid}, n::Int64, Float64(p)::Cdouble,
+               _ptr(out)::Ptr{Cvoid}, _ptr(work)::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_powsum_f64")
+        return Array(out)[1]^(1 / p)
     end
 end
 

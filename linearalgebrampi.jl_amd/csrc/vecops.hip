@@ -13,11 +13,12 @@ namespace hpcla {
 constexpr int RT = 256;            // threads per reduction block
 constexpr int MAX_PARTIALS = 2048; // upper bound of stage-1 blocks
 
-enum RedOp { RED_DOT = 0, RED_SQ = 1, RED_ABS = 2, RED_MAX = 3, RED_SUM = 4 };
+enum RedOp { RED_DOT = 0, RED_SQ = 1, RED_ABS = 2, RED_MAX = 3, RED_SUM = 4, RED_POW = 5 };
 
 template <int OP>
-__device__ __forceinline__ double red_map(double a, double b)
+__device__ __forceinline__ double red_map(double a, double b, double p = 0.0)
 {
+    if (OP == RED_POW) return pow(fabs(a), p);
     if (OP == RED_DOT) return a * b;
     if (OP == RED_SQ) return a * a;
     if (OP == RED_SUM) return a;
@@ -51,7 +52,7 @@ __device__ __forceinline__ double block_reduce(double v)
 template <int OP>
 __global__ __launch_bounds__(RT) void reduce_stage1(const double *__restrict__ x,
                                                     const double *__restrict__ y, int64_t n,
-                                                    double *__restrict__ partial)
+                                                    double *__restrict__ partial, double p = 0.0)
 {
     // 16-byte loads on the aligned body, scalar tail
     double acc = 0.0;
@@ -64,11 +65,11 @@ __global__ __launch_bounds__(RT) void reduce_stage1(const double *__restrict__ x
         const double2 a = x2[i];
         double2 b = a;
         if (OP == RED_DOT) b = y2[i];
-        acc = red_comb<OP>(acc, red_map<OP>(a.x, b.x));
-        acc = red_comb<OP>(acc, red_map<OP>(a.y, b.y));
+        acc = red_comb<OP>(acc, red_map<OP>(a.x, b.x, p));
+        acc = red_comb<OP>(acc, red_map<OP>(a.y, b.y, p));
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0)
-        acc = red_comb<OP>(acc, red_map<OP>(x[n - 1], OP == RED_DOT ? y[n - 1] : x[n - 1]));
+        acc = red_comb<OP>(acc, red_map<OP>(x[n - 1], OP == RED_DOT ? y[n - 1] : x[n - 1], p));
     const double r = block_reduce<OP>(acc);
     if (threadIdx.x == 0) partial[blockIdx.x] = r;
 }
@@ -95,7 +96,7 @@ int allreduce_on(hpcla_comm_t *comm, double *buf, int64_t count, int op, void *s
 
 template <int OP>
 static int reduce_impl(hpcla_comm_t *comm, const double *x, const double *y, int64_t n,
-                       double *out_dev, void *work, void *stream)
+                       double *out_dev, void *work, void *stream, double p = 0.0)
 {
     if (n < 0) return set_error(HPCLA_ERR_INVALID, "reduce: negative size");
     if (!out_dev || !work) return set_error(HPCLA_ERR_INVALID, "reduce: null out/work");
@@ -106,9 +107,9 @@ static int reduce_impl(hpcla_comm_t *comm, const double *x, const double *y, int
     hipStream_t s = as_stream(stream);
     double *partial = reinterpret_cast<double *>(work);
     const int g = reduce_grid(n);
-    reduce_stage1<OP><<<g, RT, 0, s>>>(x, y, n, partial);
+    reduce_stage1<OP><<<g, RT, 0, s>>>(x, y, n, partial, p);
     HPCLA_CHECK_LAUNCH();
-    reduce_stage2<OP><<<1, RT, 0, s>>>(partial, g, out_dev);
+    reduce_stage2<OP == RED_POW ? RED_SUM : OP><<<1, RT, 0, s>>>(partial, g, out_dev);
     HPCLA_CHECK_LAUNCH();
     if (comm) return allreduce_on(comm, out_dev, 1, OP == RED_MAX ? 1 : 0, stream);
     return HPCLA_OK;
@@ -288,6 +289,13 @@ HPCLA_API int hpcla_amax_f64(hpcla_comm_t *comm, const double *x, int64_t n, dou
                              void *work, void *stream)
 {
     return reduce_impl<RED_MAX>(comm, x, nullptr, n, out_dev, work, stream);
+}
+
+HPCLA_API int hpcla_powsum_f64(hpcla_comm_t *comm, const double *x, int64_t n, double p, double *out_dev,
+                               void *work, void *stream)
+{
+    if (!(p > 0.0)) return set_error(HPCLA_ERR_INVALID, "powsum: p must be positive");
+    return reduce_impl<RED_POW>(comm, x, nullptr, n, out_dev, work, stream, p);
 }
 
 HPCLA_API int hpcla_axpy_f64(double alpha_host, const double *num_dev, const double *den_dev,

@@ -246,7 +246,7 @@ def norm(v: HPCVector, p: float = 2, out=None):
     """``norm(v, p)`` (src/vectors.jl:758-780): p=2 sums squares then sqrt, p=1 asum, p=Inf max.
     With ``out`` (1-element device tensor) nothing is read back: ``out`` receives the all-reduced
     quantity the reference feeds to its final step -- for p=2 that is the SUM OF SQUARES (the sqrt is
-    the caller's), for p=1 / Inf the norm itself."""
+    the caller's), for p=1 / Inf the norm itself, for any other p the sum of |x|^p."""
     if p == 2:
         r = _reduce("nrm2sq", v, None, out)
         return r if out is not None else math.sqrt(float(r.item()))
@@ -256,4 +256,10 @@ def norm(v: HPCVector, p: float = 2, out=None):
     if p == math.inf:
         r = _reduce("amax", v, None, out)
         return r if out is not None else float(r.item())
-    raise NotImplementedError("general p-norms are outside the SpMV/CG hot path (SURVEY.md section 8)")
+    if not (p > 0):
+        raise ValueError("norm: p must be positive")
+    work, scal = _Scratch.get(v.v.device)                                        # general p (:774-779)
+    r = out if out is not None else scal[:1]
+    _capi.call("hpcla_powsum_f64", v.backend.rccl, dptr(v.v), v.local_length, float(p), dptr(r), dptr(work),
+               current_stream_ptr())
+    return r if out is not None else float(r.item()) ** (1.0 / p)

@@ -330,6 +330,9 @@ def test_dot_norm_golden_and_random(hp, orc, golden, gpu_backend_i32):
     assert abs(hp.norm(v) - nm["norm2"]) < TOL_REF
     assert abs(hp.norm(v, 1) - nm["norm1"]) < TOL_REF
     assert abs(hp.norm(v, math.inf) - nm["norminf"]) < TOL_REF
+    assert abs(hp.norm(v, 3) - nm["norm3"]) < TOL_REF and abs(hp.norm(v, 1.5) - nm["norm1p5"]) < TOL_REF
+    with pytest.raises(ValueError):
+        hp.norm(v, -1)
     for n in (1, 2, 3, 511, 512, 513, 100_003, 4_000_001):
         xg, yg = orc.fill_uniform(0, n, 1) - 0.5, orc.fill_uniform(0, n, 2) - 0.25
         xv, yv = hp.HPCVector.from_global(xg, b), hp.HPCVector.from_global(yg, b)
@@ -338,6 +341,8 @@ def test_dot_norm_golden_and_random(hp, orc, golden, gpu_backend_i32):
         assert abs(hp.norm(xv) - orc.norm([xg], 2)) <= RTOL_RED * orc.norm([xg], 2)
         assert abs(hp.norm(xv, 1) - orc.norm([xg], 1)) <= RTOL_RED * orc.norm([xg], 1)
         assert hp.norm(xv, math.inf) == orc.norm([xg], math.inf)
+        want3 = float(np.sum(np.abs(xg) ** 3.0)) ** (1.0 / 3.0)                      # general p (src/vectors.jl:774-779)
+        assert abs(hp.norm(xv, 3) - want3) <= 1e-11 * want3
     # deterministic: two runs give the same bits
     assert hp.dot(xv, yv) == hp.dot(xv, yv)
 
