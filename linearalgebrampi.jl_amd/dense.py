@@ -53,6 +53,18 @@ class HPCMatrix:
 
     __mul__ = __matmul__
 
+    def __getitem__(self, key):
+        """``A[:, k]`` (src/indexing.jl:385-393): column k (0-based here) as an HPCVector on A's row
+        partition -- the operand of the reference's SpMM column loop.  Stays on the device."""
+        from .vectors import HPCVector
+        if not (isinstance(key, tuple) and len(key) == 2 and key[0] == slice(None) and isinstance(key[1], (int, np.integer))):
+            raise TypeError("HPCMatrix indexing supports A[:, k] only")
+        k, n = int(key[1]), int(self.A.shape[1])
+        if k < 0 or k >= n:
+            raise IndexError(f"HPCMatrix column index out of bounds: k={k}, ncols={n}")
+        return HPCVector(compute_partition_hash(self.row_partition), self.row_partition,
+                         self.A[:, k].contiguous(), self.backend)
+
     def local_values(self) -> np.ndarray:
         return self.A.detach().cpu().numpy()
 

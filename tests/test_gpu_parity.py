@@ -222,7 +222,8 @@ def test_large_spmm_columns_equal_spmv_bitwise(hp, orc, gpu_backend_i32):
     B = hp.HPCMatrix.from_global(Bg, gpu_backend_i32)
     C = hp.spmm(A, B)
     for j in (0, 7, 15):
-        xj = hp.HPCVector.from_global(np.ascontiguousarray(Bg[:, j]), gpu_backend_i32)
+        xj = B[:, j]                                                # getindex(::HPCMatrix, :, k), src/indexing.jl:385-393
+        np.testing.assert_array_equal(xj.local_values(), Bg[:, j])
         yj = A @ xj
         assert torch.equal(C.A[:, j].contiguous(), yj.v), f"column {j}"
     want0 = orc.spmv(rp.astype(np.int32), ci.astype(np.int32), va, np.ascontiguousarray(Bg[:, 0]))
