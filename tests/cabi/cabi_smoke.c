@@ -27,8 +27,59 @@
         if (_e != hipSuccess) { fprintf(stderr, "%s: %s\n", #call, hipGetErrorString(_e)); return 1; } \
     } while (0)
 
-int main(void)
+/* `cabi_smoke N` : time y = A*x on the N x N 5-point matrix through the C ABI alone (HIP events), the
+ * headline workload without any Python in the process. */
+static int bench(int64_t N)
 {
+    const int64_t n = N * N, nnz = hpcla_poisson2d_nnz(N, N, 0, n);
+    int64_t *rp64, *colg, *col_indices;
+    int32_t *rowptr, *colval;
+    double *vals, *x, *y;
+    void *work;
+    HIPCHECK(hipMalloc((void **)&rp64, (n + 1) * 8));
+    HIPCHECK(hipMalloc((void **)&colg, nnz * 8));
+    HIPCHECK(hipMalloc((void **)&vals, nnz * 8));
+    CHECK(hpcla_gen_poisson2d(N, N, 0, n, rp64, colg, vals, NULL));
+    HIPCHECK(hipMalloc(&work, hpcla_colspace_work_bytes(n)));
+    HIPCHECK(hipMalloc((void **)&colval, nnz * 4));
+    HIPCHECK(hipMalloc((void **)&col_indices, n * 8));
+    int64_t ncomp = 0;
+    CHECK(hpcla_compress_columns_i32(colg, nnz, 0, n, colval, 0, col_indices, &ncomp, work, NULL));
+    int64_t *h_rp = (int64_t *)malloc((n + 1) * 8);
+    int32_t *h_rp32 = (int32_t *)malloc((n + 1) * 4);
+    HIPCHECK(hipMemcpy(h_rp, rp64, (n + 1) * 8, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i <= n; ++i) h_rp32[i] = (int32_t)h_rp[i];
+    HIPCHECK(hipMalloc((void **)&rowptr, (n + 1) * 4));
+    HIPCHECK(hipMemcpy(rowptr, h_rp32, (n + 1) * 4, hipMemcpyHostToDevice));
+    HIPCHECK(hipFree(rp64)); HIPCHECK(hipFree(colg)); HIPCHECK(hipFree(work)); HIPCHECK(hipFree(col_indices));
+    HIPCHECK(hipMalloc((void **)&x, n * 8));
+    HIPCHECK(hipMalloc((void **)&y, n * 8));
+    CHECK(hpcla_fill_uniform_f64(x, 0, n, 0xC0FFEEULL, NULL));
+    for (int i = 0; i < 20; ++i) CHECK(hpcla_spmv_csr_f64_i32(rowptr, colval, vals, x, y, n, nnz, 0, NULL));
+    hipEvent_t e0, e1;
+    HIPCHECK(hipEventCreate(&e0)); HIPCHECK(hipEventCreate(&e1));
+    const int steps = 200;
+    HIPCHECK(hipDeviceSynchronize());
+    HIPCHECK(hipEventRecord(e0, NULL));
+    for (int i = 0; i < steps; ++i) CHECK(hpcla_spmv_csr_f64_i32(rowptr, colval, vals, x, y, n, nnz, 0, NULL));
+    HIPCHECK(hipEventRecord(e1, NULL));
+    HIPCHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
+    const double t = ms / steps * 1e-3;
+    const double b_alg = 12.0 * nnz + 4.0 * (n + 1) + 8.0 * n + 8.0 * n;
+    printf("C-ABI bench: N=%lld n=%lld nnz=%lld  %.4f ms/SpMV  %.1f GFLOP/s  %.1f GB/s algorithmic = %.3f of 8 TB/s\n",
+           (long long)N, (long long)n, (long long)nnz, t * 1e3, 2.0 * nnz / t / 1e9, b_alg / t / 1e9,
+           b_alg / t / 1e9 / 8000.0);
+    return 0;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc > 1) {
+        CHECK(hpcla_set_device(0));
+        return bench(atoll(argv[1]));
+    }
     const int64_t nx = 300, ny = 200, n = nx * ny;
     int ndev = 0;
     CHECK(hpcla_device_count(&ndev));

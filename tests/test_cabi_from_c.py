@@ -33,3 +33,15 @@ def test_cabi_program_runs_without_python_runtime():
     out = subprocess.run([EXE], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "C-ABI smoke PASS" in out.stdout
+
+
+@pytest.mark.gpu
+def test_cabi_program_benchmarks_the_headline_workload_without_python():
+    """Same kernel, same workload (4096^2 Poisson), no Python in the process: the rate must reach the
+    BASELINE target (>= 0.60 of the 8 TB/s HBM peak by algorithmic bytes)."""
+    if not os.path.exists(EXE):
+        _build()
+    out = subprocess.run([EXE, "4096"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    frac = float(out.stdout.strip().split("=")[-1].split("of")[0])
+    assert frac >= 0.60, out.stdout
