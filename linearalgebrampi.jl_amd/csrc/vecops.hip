@@ -107,10 +107,16 @@ static int reduce_impl(hpcla_comm_t *comm, const double *x, const double *y, int
     hipStream_t s = as_stream(stream);
     double *partial = reinterpret_cast<double *>(work);
     const int g = reduce_grid(n);
-    reduce_stage1<OP><<<g, RT, 0, s>>>(x, y, n, partial, p);
-    HPCLA_CHECK_LAUNCH();
-    reduce_stage2<OP == RED_POW ? RED_SUM : OP><<<1, RT, 0, s>>>(partial, g, out_dev);
-    HPCLA_CHECK_LAUNCH();
+    if (g == 1) {
+        // short vectors: the single stage-1 workgroup's partial IS the result (one launch, not two)
+        reduce_stage1<OP><<<1, RT, 0, s>>>(x, y, n, out_dev, p);
+        HPCLA_CHECK_LAUNCH();
+    } else {
+        reduce_stage1<OP><<<g, RT, 0, s>>>(x, y, n, partial, p);
+        HPCLA_CHECK_LAUNCH();
+        reduce_stage2<OP == RED_POW ? RED_SUM : OP><<<1, RT, 0, s>>>(partial, g, out_dev);
+        HPCLA_CHECK_LAUNCH();
+    }
     if (comm) return allreduce_on(comm, out_dev, 1, OP == RED_MAX ? 1 : 0, stream);
     return HPCLA_OK;
 }
@@ -289,6 +295,12 @@ HPCLA_API int hpcla_amax_f64(hpcla_comm_t *comm, const double *x, int64_t n, dou
                              void *work, void *stream)
 {
     return reduce_impl<RED_MAX>(comm, x, nullptr, n, out_dev, work, stream);
+}
+
+HPCLA_API int hpcla_sum_f64(hpcla_comm_t *comm, const double *x, int64_t n, double *out_dev, void *work,
+                            void *stream)
+{
+    return reduce_impl<RED_SUM>(comm, x, nullptr, n, out_dev, work, stream);
 }
 
 HPCLA_API int hpcla_powsum_f64(hpcla_comm_t *comm, const double *x, int64_t n, double p, double *out_dev,

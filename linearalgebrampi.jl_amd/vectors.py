@@ -234,6 +234,14 @@ def _reduce(kind: str, x: HPCVector, y: Optional[HPCVector], out=None):
     return out
 
 
+def vsum(v: HPCVector, out=None):
+    """``sum(v)`` (src/vectors.jl:838-845)."""
+    work, scal = _Scratch.get(v.v.device)
+    r = out if out is not None else scal[:1]
+    _capi.call("hpcla_sum_f64", v.backend.rccl, dptr(v.v), v.local_length, dptr(r), dptr(work), current_stream_ptr())
+    return r if out is not None else float(r.item())
+
+
 def dot(x: HPCVector, y: HPCVector, out=None):
     """``dot(x, y)`` (src/vectors.jl:798-812).  Returns a Python float (host sync), or, when ``out``
     (1-element device tensor) is given, leaves the result on the device and returns ``out``."""

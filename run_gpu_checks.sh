@@ -39,6 +39,7 @@ for st in $STEPS; do
     spmm2d) run 900 gpurun_out/${TAG}_spmm2d.log python bench.py --workload poisson2d_spmm --steps 30 --warmup 3; tail -1 gpurun_out/${TAG}_spmm2d.log;;
     rank4) run 600 gpurun_out/${TAG}_rank4.log python benchmarks/bench_rank4.py; tail -14 gpurun_out/${TAG}_rank4.log;;
     sprand_spmv) for m in 1 8; do HPCLA_SPRAND_SPMV=1 HPCLA_SPMM_COLS_MULT=$m run 900 gpurun_out/${TAG}_sprand_spmv$m.log python bench.py --workload sprand_spmm --steps 30 --warmup 3; tail -1 gpurun_out/${TAG}_sprand_spmv$m.log; done;;
+    single) run 900 gpurun_out/${TAG}_single.log python benchmarks/bench_single_rank.py; tail -40 gpurun_out/${TAG}_single.log;;
     spmm8)  HPCLA_SPMM_COLS_MULT=8 run 900 gpurun_out/${TAG}_spmm8.log python bench.py --workload sprand_spmm --steps 20 --warmup 3; tail -2 gpurun_out/${TAG}_spmm8.log;;
     spmm)   run 900 gpurun_out/${TAG}_spmm.log python bench.py --workload sprand_spmm --steps 20 --warmup 3; tail -2 gpurun_out/${TAG}_spmm.log;;
     pmc_sq)
