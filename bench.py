@@ -5,8 +5,9 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one y = A*x (``mul!(y, A, x)``) over the resident matrix: halo exchange (N > 1, RCCL on a
-side stream, overlapped with the interior row blocks) + SpMV.  Workload at N = 1: BASELINE
+A "step" is one y = A*x (``mul!(y, A, x)``) over the resident matrix: halo exchange (N > 1: RCCL
+send/recv group, ahead of one fused launch by default or overlapped with the interior row blocks on a
+side stream with HPCLA_HALO_MODE=overlap) + SpMV.  Workload at N = 1: BASELINE
 configs[1], the 4096^2 Poisson matrix (n = 16 777 216, nnz = 83 869 696, Int32 indices).  N > 1:
 weak scaling -- every GPU owns one 4096 x 4096 slab of a 4096 x (4096*N) grid (same per-GPU work as
 N = 1, two 32 KiB halo lines per interior GPU).

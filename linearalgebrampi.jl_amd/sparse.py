@@ -6,7 +6,7 @@ local column space ``col_indices`` (sorted unique global columns, src/sparse.jl:
 memoization key ``(hash(A), hash(x.partition), T, Ti, array type)`` (src/sparse.jl:1992-2001).
 
 Replaced (device side, libhpcla_rocm through the C ABI): the execute half of the plan
-(src/vectors.jl:394-463 -> GPU-resident RCCL halo on a side stream), the kernel
+(src/vectors.jl:394-463 -> GPU-resident RCCL halo, ordering chosen by HPCLA_HALO_MODE), the kernel
 (src/sparse.jl:2055-2084 -> row-block stream SpMV), and the CPU ``mul!`` (src/sparse.jl:2019-2037 ->
 the same device kernel writing ``y.v`` in place).
 
