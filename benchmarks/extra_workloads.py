@@ -177,14 +177,14 @@ def run(args, backend, rank, world):
             ms = (time.perf_counter() - t0) / steps * 1e3
             b_alg = wl.spmv_algorithmic_bytes(A.nnz, A.nrows_local, A.ncols_compressed, 4)
             b_sect = A.nnz * (12 + 64) + 12 * A.nrows_local
-            print(json.dumps({"metric": "SpMV GFLOP/s, sprand ~29.8 nnz/row", "value": round(2.0 * A.nnz / (ms * 1e-3) / 1e9, 1),
+            line = json.dumps({"metric": "SpMV GFLOP/s, sprand ~29.8 nnz/row", "value": round(2.0 * A.nnz / (ms * 1e-3) / 1e9, 1),
                               "ms_per_step": round(ms, 4), "nnz": A.nnz, "ncols_compressed": A.ncols_compressed,
                               "algorithmic_gbs": round(b_alg / (ms * 1e-3) / 1e9, 1),
                               "frac_of_peak_algorithmic": round(b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                               "sector_gather_gbs": round(b_sect / (ms * 1e-3) / 1e9, 1),
-                              "note": "sector_gather = 12 B + one 64-byte sector of x per stored entry"}), flush=True)
+                              "note": "sector_gather = 12 B + one 64-byte sector of x per stored entry"})
             hp.clear_plan_cache()
-            return
+            return line
         b_rows = rows_loc * mult
         Bl = torch.empty((b_rows, k), dtype=torch.float64, device=dev)
         hp._capi.call("hpcla_fill_uniform_f64", Bl.data_ptr(), rank * b_rows * k, b_rows * k, wl.SEED_X,
@@ -196,9 +196,8 @@ def run(args, backend, rank, world):
                             f"sprand-like {rows_loc} rows per GPU x {ncols} cols, nnz/GPU={A.nnz}, k={k}, C = A*B")
     if world > 1:
         _device_barrier(torch, dist)
-    if rank == 0:
-        print(json.dumps(out), flush=True)
     hp.clear_plan_cache()
     hp.clear_spmm_cache()
     if world > 1:
         dist.destroy_process_group()
+    return json.dumps(out) if rank == 0 else None
