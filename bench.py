@@ -193,9 +193,25 @@ def main():
         out = _run()
     line, verified = out if isinstance(out, tuple) else (out, True)
     if line is not None:
-        print(line, flush=True)
+        print(line, flush=True)            # the result is out before any teardown can go wrong
+    with _StdoutToStderr():
+        _teardown()
     if not verified:
         raise SystemExit(1)
+
+
+def _teardown():
+    """Collective teardown after the result line is printed: plans, then the process group.  The library's
+    RCCL communicator is left to process exit on purpose (like the reference's NCCL communicator,
+    ext/HPCLinearAlgebraCUDAExt.jl:373, 384-386: no destroy that could block behind a straggler)."""
+    try:
+        import torch.distributed as dist
+        import hpcla_amd as hp
+        hp.clear_plan_cache()
+        if dist.is_available() and dist.is_initialized():
+            dist.destroy_process_group()
+    except Exception as exc:                 # teardown problems must not turn a finished run into a failure
+        sys.stderr.write(f"bench: teardown: {type(exc).__name__}: {exc}\n")
 
 
 def _run():
@@ -437,9 +453,6 @@ def _run():
         result["cpu_baseline"] = cpu_baseline_spmv(A.rowptr, A.colval, vals, xfull, args.cpu_seconds)
     if world > 1:
         _device_barrier(torch, dist)
-    hp.clear_plan_cache()
-    if world > 1:
-        dist.destroy_process_group()
     if not verified:
         sys.stderr.write("bench: result verification FAILED\n")
     return (json.dumps(result) if rank == 0 else None), verified
