@@ -45,6 +45,11 @@ for st in $STEPS; do
     pmc_sq)
       run 600 gpurun_out/${TAG}_pmc_sq.log rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d gpurun_out/${TAG}_pmc_sq -- python3 benchmarks/tune_spmv.py --variants 100,5,20,0 --rounds 1 --reps 2
       tail -2 gpurun_out/${TAG}_pmc_sq.log;;
+    pmc_spmm)
+      run 600 gpurun_out/${TAG}_pmc_spmm_sq.log rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_BUSY_CYCLES --output-format csv -d gpurun_out/${TAG}_pmc_spmm_sq -- python3 bench.py --workload poisson2d_spmm --steps 5 --warmup 2
+      run 600 gpurun_out/${TAG}_pmc_spmm_tcc.log rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum --output-format csv -d gpurun_out/${TAG}_pmc_spmm_tcc -- python3 bench.py --workload poisson2d_spmm --steps 5 --warmup 2
+      run 600 gpurun_out/${TAG}_pmc_spmm_fs.log rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/${TAG}_pmc_spmm_fs -- python3 bench.py --workload poisson2d_spmm --steps 5 --warmup 2
+      tail -1 gpurun_out/${TAG}_pmc_spmm_fs.log;;
     pmc_tcc)
       run 600 gpurun_out/${TAG}_pmc_tcc.log rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum --output-format csv -d gpurun_out/${TAG}_pmc_tcc -- python3 benchmarks/tune_spmv.py --variants 100,5,20,0 --rounds 1 --reps 2
       tail -2 gpurun_out/${TAG}_pmc_tcc.log;;
