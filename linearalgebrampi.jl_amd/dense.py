@@ -274,53 +274,75 @@ def spmm(A, B: HPCMatrix) -> HPCMatrix:
     s = current_stream_ptr()
     sfx = "i64" if plan.is_i64 else "i32"
     Bc = B.A.contiguous()
-    if not plan.has_halo:
+    nranks = comm_size(backend.comm)
+    if nranks == 1:
         # every column owned: split indices == offsets into B's local rows
         _capi.call(f"hpcla_spmm_csr_f64_{sfx}", dptr(A.rowptr_target), dptr(plan.colval_split),
                    dptr(A.nzval), dptr(Bc), k, _capi.LAYOUT_ROW, dptr(C), k, _capi.LAYOUT_ROW,
                    A.nrows_local, A.nnz, k, 0, s)
         return out
-    if plan.is_i64:
-        raise NotImplementedError("distributed SpMM is implemented for Int32 indices")
     key = (A._ensure_hash(), probe.structural_hash, k)
     ent = _spmm_halo_cache.get(key)
     if ent is None:
+        # plan time, collective (every rank, with or without neighbours): who gets whole slices
+        from .backends import comm_alltoall_counts
+        from .sparse import whole_slice_lists, whole_slice_wishes
         h = plan.host
-        n_send, n_recv = len(h.send_rank_ids), len(h.recv_rank_ids)
-        send_ranks = (ctypes.c_int32 * max(n_send, 1))(*h.send_rank_ids)
-        send_counts = (ctypes.c_int64 * max(n_send, 1))(*[len(i) for i in h.send_indices])
-        recv_ranks = (ctypes.c_int32 * max(n_recv, 1))(*h.recv_rank_ids)
-        recv_counts = (ctypes.c_int64 * max(n_recv, 1))(*[len(p) for p in h.recv_perm])
-        send_idx = (torch.from_numpy(np.concatenate(h.send_indices).astype(np.int32)).to(dev)
-                    if n_send else None)
-        halo = ctypes.c_void_p()
-        torch.cuda.current_stream().synchronize()
-        _capi.check("hpcla_halo_plan_create", _capi.load().hpcla_halo_plan_create(
-            ctypes.byref(halo), backend.rccl, n_send, send_ranks, send_counts, dptr(send_idx), 0,
-            n_recv, recv_ranks, recv_counts, k))
-        # SpMM row blocks are smaller than SpMV row blocks: classify at SpMM granularity
-        rpb = _capi.load().hpcla_spmm_rows_per_block()
-        nblk = (A.nrows_local + rpb - 1) // rpb
-        flags_i = torch.empty(nblk, dtype=torch.int32, device=dev)
-        _capi.call("hpcla_classify_blocks_i32", dptr(A.rowptr_target), dptr(plan.colval_split),
-                   A.nrows_local, 0, plan.n_own, rpb, dptr(flags_i), s)
-        flags = flags_i != 0
-        interior = torch.nonzero(~flags).flatten().to(torch.int32).contiguous()
-        boundary = torch.nonzero(flags).flatten().to(torch.int32).contiguous()
-        ent = (halo, interior, boundary, send_idx)
-        _spmm_halo_cache[key] = ent
-    halo, interior, boundary, _ = ent
+        wish = whole_slice_wishes(h, B.row_partition, nranks)
+        granted = comm_alltoall_counts(backend.comm, wish)
+        if not plan.has_halo:
+            ent = _spmm_halo_cache[key] = (None, None, None, None, plan.colval_split)
+        else:
+            if plan.is_i64:
+                raise NotImplementedError("distributed SpMM is implemented for Int32 indices")
+            send_indices, recv_counts_l, cmap = whole_slice_lists(h, A.col_indices, B.row_partition, wish, granted)
+            n_send, n_recv = len(h.send_rank_ids), len(h.recv_rank_ids)
+            send_ranks = (ctypes.c_int32 * max(n_send, 1))(*h.send_rank_ids)
+            send_counts = (ctypes.c_int64 * max(n_send, 1))(*[len(i) for i in send_indices])
+            recv_ranks = (ctypes.c_int32 * max(n_recv, 1))(*h.recv_rank_ids)
+            recv_counts = (ctypes.c_int64 * max(n_recv, 1))(*recv_counts_l)
+            send_idx = (torch.from_numpy(np.concatenate(send_indices).astype(np.int32)).to(dev)
+                        if n_send else None)
+            if wish.any():
+                # ghost positions differ from the vector plan's: a split colval copy of its own
+                cmap_dev = torch.from_numpy(cmap.astype(np.int32)).to(dev)
+                colval_split = torch.empty(A.nnz, dtype=torch.int32, device=dev)
+                _capi.call("hpcla_remap_i32", dptr(A.colval_target()), dptr(cmap_dev), dptr(colval_split), A.nnz, 0, s)
+            else:
+                colval_split = plan.colval_split
+            halo = ctypes.c_void_p()
+            torch.cuda.current_stream().synchronize()
+            _capi.check("hpcla_halo_plan_create", _capi.load().hpcla_halo_plan_create(
+                ctypes.byref(halo), backend.rccl, n_send, send_ranks, send_counts, dptr(send_idx), 0,
+                n_recv, recv_ranks, recv_counts, k))
+            # SpMM row blocks are smaller than SpMV row blocks: classify at SpMM granularity
+            rpb = _capi.load().hpcla_spmm_rows_per_block()
+            nblk = (A.nrows_local + rpb - 1) // rpb
+            flags_i = torch.empty(nblk, dtype=torch.int32, device=dev)
+            _capi.call("hpcla_classify_blocks_i32", dptr(A.rowptr_target), dptr(colval_split),
+                       A.nrows_local, 0, plan.n_own, rpb, dptr(flags_i), s)
+            flags = flags_i != 0
+            interior = torch.nonzero(~flags).flatten().to(torch.int32).contiguous()
+            boundary = torch.nonzero(flags).flatten().to(torch.int32).contiguous()
+            ent = (halo, interior, boundary, send_idx, colval_split)
+            _spmm_halo_cache[key] = ent
+    if ent[0] is None:
+        _capi.call(f"hpcla_spmm_csr_f64_{sfx}", dptr(A.rowptr_target), dptr(plan.colval_split),
+                   dptr(A.nzval), dptr(Bc), k, _capi.LAYOUT_ROW, dptr(C), k, _capi.LAYOUT_ROW,
+                   A.nrows_local, A.nnz, k, 0, s)
+        return out
+    halo, interior, boundary, _, colval_split = ent
     ghost = ctypes.c_void_p()
     ng = ctypes.c_int64()
     _capi.call("hpcla_halo_ghost_ptr", halo, ctypes.byref(ghost), ctypes.byref(ng))
     _capi.call("hpcla_halo_begin", halo, dptr(Bc), s)
     if interior.numel():
-        _capi.call("hpcla_spmm_split_f64_i32", dptr(A.rowptr_target), dptr(plan.colval_split),
+        _capi.call("hpcla_spmm_split_f64_i32", dptr(A.rowptr_target), dptr(colval_split),
                    dptr(A.nzval), dptr(Bc), k, ghost, k, plan.n_own, dptr(C), k, A.nrows_local,
                    A.nnz, k, 0, dptr(interior), int(interior.numel()), s)
     _capi.call("hpcla_halo_end", halo, s)
     if boundary.numel():
-        _capi.call("hpcla_spmm_split_f64_i32", dptr(A.rowptr_target), dptr(plan.colval_split),
+        _capi.call("hpcla_spmm_split_f64_i32", dptr(A.rowptr_target), dptr(colval_split),
                    dptr(A.nzval), dptr(Bc), k, ghost, k, plan.n_own, dptr(C), k, A.nrows_local,
                    A.nnz, k, 0, dptr(boundary), int(boundary.numel()), s)
     return out

@@ -113,6 +113,42 @@ def split_column_map(plan: HostVectorPlan) -> np.ndarray:
     return m
 
 
+WHOLE_SLICE_FRACTION = 0.5     # a neighbour that needs more than this share of my rows gets all of them
+
+
+def whole_slice_wishes(plan: HostVectorPlan, x_partition: np.ndarray, nranks: int) -> np.ndarray:
+    """Per owner rank r: 1 if this rank wants r's WHOLE slice instead of the requested rows (it needs
+    more than WHOLE_SLICE_FRACTION of them).  SURVEY 8e(3): an unstructured A (config 5) touches ~98 % of
+    all rows of B, where a gather-and-pack of the requested rows costs a full extra pass over them and
+    a send buffer as large as the slice; whole slices go out of B in place (contiguous, no pack)."""
+    sizes = np.diff(np.asarray(x_partition, dtype=np.int64))
+    wish = np.zeros(nranks, dtype=np.int64)
+    for r, perm in zip(plan.recv_rank_ids, plan.recv_perm):
+        if len(perm) > WHOLE_SLICE_FRACTION * sizes[r]:
+            wish[r] = 1
+    return wish
+
+
+def whole_slice_lists(plan: HostVectorPlan, col_indices: np.ndarray, x_partition: np.ndarray,
+                      wish: np.ndarray, granted: np.ndarray):
+    """Exchange lists with whole slices where wished.  ``wish[r]``: I receive r's whole slice;
+    ``granted[q]``: q receives my whole slice (= q's wish, learnt through an Alltoall of the wishes).
+    Returns (send_indices, recv_counts, split column map): the ghost segment of a whole-slice
+    neighbour r holds ALL of r's rows in order, so column g sits at ``g - x_partition[r]`` in it."""
+    x_partition = np.asarray(x_partition, dtype=np.int64)
+    send_indices = [np.arange(plan.n_own, dtype=np.int64) if granted[q] else idx
+                    for q, idx in zip(plan.send_rank_ids, plan.send_indices)]
+    recv_counts = [int(x_partition[r + 1] - x_partition[r]) if wish[r] else len(perm)
+                   for r, perm in zip(plan.recv_rank_ids, plan.recv_perm)]
+    m = np.empty(plan.n_gathered, dtype=np.int64)
+    m[plan.local_dst_indices] = plan.local_src_indices
+    off = plan.n_own
+    for r, perm, cnt in zip(plan.recv_rank_ids, plan.recv_perm, recv_counts):
+        m[perm] = off + (col_indices[perm] - x_partition[r] if wish[r] else np.arange(len(perm), dtype=np.int64))
+        off += cnt
+    return send_indices, recv_counts, m
+
+
 # =====================================================================================================
 # device plan
 # =====================================================================================================

@@ -209,3 +209,44 @@ def test_check_partition_rejects_malformed_targets():
     for bad in ([0, 5], [1, 3, 10], [0, 7, 5, 10], [0, 3, 9]):
         with pytest.raises(ValueError):
             check_partition(np.array(bad), 10, 2 if len(bad) == 3 else len(bad) - 1 if bad != [0, 5] else 2)
+
+
+# ---- whole-slice exchange lists for SpMM ("switch to all-gather of B") -----------------
+@pytest.mark.parametrize("nranks", [2, 4])
+def test_whole_slice_lists_reproduce_the_gathered_rows(hp, orc, nranks):
+    """All ranks simulated in one process: wishes -> Alltoall -> lists; the emulated exchange must put
+    every needed row of B where the SpMM's split column map expects it, whole-slice and requested-rows
+    neighbours mixed; message sizes agree on both ends; whole-slice sends are contiguous (no pack)."""
+    from hpcla_amd.sparse import whole_slice_lists, whole_slice_wishes
+    rng = np.random.default_rng(nranks)
+    n = 120 * nranks
+    xp = orc.uniform_partition(n, nranks)
+    # rank r touches ~90 % of rank (r+1)'s columns (-> whole slice), ~10 % of the others (-> requested rows)
+    cis = []
+    for r in range(nranks):
+        sel = []
+        for o in range(nranks):
+            frac = 1.0 if o == r else (0.9 if o == (r + 1) % nranks else 0.1)
+            cols = np.arange(xp[o], xp[o + 1])
+            sel.append(cols[rng.random(len(cols)) < frac])
+        cis.append(np.sort(np.concatenate(sel)).astype(np.int64))
+    oplans = orc.vector_plans(cis, xp)
+    plans = [hp.HostVectorPlan(p.send_rank_ids, p.send_indices, p.recv_rank_ids, p.recv_perm, p.local_src_indices,
+                               p.local_dst_indices, p.n_gathered, int(xp[r + 1] - xp[r])) for r, p in enumerate(oplans)]
+    wishes = [whole_slice_wishes(p, xp, nranks) for p in plans]
+    assert all(w[(r + 1) % nranks] == 1 and w.sum() == 1 for r, w in enumerate(wishes)) or nranks == 2
+    granted = [np.array([wishes[q][r] for q in range(nranks)]) for r in range(nranks)]      # the Alltoall
+    lists = [whole_slice_lists(plans[r], cis[r], xp, wishes[r], granted[r]) for r in range(nranks)]
+    Bg = rng.random((n, 3))
+    for r in range(nranks):
+        send_idx_r, recv_counts, cmap = lists[r]
+        segs = []
+        for src, cnt in zip(plans[r].recv_rank_ids, recv_counts):
+            j = plans[src].send_rank_ids.index(r)
+            idx = lists[src][0][j]
+            assert len(idx) == cnt                                   # both ends agree on the size
+            if wishes[r][src]:
+                np.testing.assert_array_equal(idx, np.arange(xp[src + 1] - xp[src]))   # contiguous: sent in place
+            segs.append(Bg[xp[src]:xp[src + 1]][idx])
+        ext = np.concatenate([Bg[xp[r]:xp[r + 1]]] + segs)
+        np.testing.assert_array_equal(ext[cmap], Bg[cis[r]])
