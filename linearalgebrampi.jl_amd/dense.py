@@ -269,7 +269,7 @@ def spmm(A, B: HPCMatrix) -> HPCMatrix:
         raise ValueError("A*B: B's local rows do not match its row partition")
     C = torch.empty((A.nrows_local, k), dtype=torch.float64, device=dev)
     out = HPCMatrix(plan.result_partition, uniform_partition(k, comm_size(backend.comm)), C, backend)
-    if k == 0 or A.nrows_local == 0:
+    if k == 0:                       # (a rank without local rows still takes part in the exchange below)
         return out
     s = current_stream_ptr()
     sfx = "i64" if plan.is_i64 else "i32"
@@ -303,6 +303,8 @@ def spmm(A, B: HPCMatrix) -> HPCMatrix:
             recv_counts = (ctypes.c_int64 * max(n_recv, 1))(*recv_counts_l)
             send_idx = (torch.from_numpy(np.concatenate(send_indices).astype(np.int32)).to(dev)
                         if n_send else None)
+            if plan.n_own + sum(recv_counts_l) > np.iinfo(np.int32).max:
+                raise OverflowError("split column space does not fit Int32")
             if wish.any():
                 # ghost positions differ from the vector plan's: a split colval copy of its own
                 cmap_dev = torch.from_numpy(cmap.astype(np.int32)).to(dev)
