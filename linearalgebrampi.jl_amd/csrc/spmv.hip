@@ -256,7 +256,7 @@ __global__ __launch_bounds__(RPB) void classify_blocks_kernel(const I *__restric
     const int64_t p0 = (int64_t)rowptr[r0] - base;
     const int64_t p1 = (int64_t)rowptr[r0 + nr] - base;
     int any = 0;
-    for (int64_t j = p0 + threadIdx.x; j < p1; j += RPB) any |= ((int64_t)colval[j] >= n_own);
+    for (int64_t j = p0 + threadIdx.x; j < p1; j += RPB) any |= ((int64_t)colval[j] - base >= n_own);
     any = __syncthreads_or(any);
     if (threadIdx.x == 0) flags[blockIdx.x] = any ? 1 : 0;
 }
