@@ -51,7 +51,36 @@ class HPCMatrix:
             return dense_matvec(self, x)
         return NotImplemented
 
-    __mul__ = __matmul__
+    def __mul__(self, other):
+        """``A * x`` or ``A * a`` (scalar: src/dense.jl:1317-1327, 1818-1838), on the device."""
+        if isinstance(other, (int, float, np.floating, np.integer)):
+            return self._scaled(float(other), divide=False)
+        return self.__matmul__(other)
+
+    def __rmul__(self, a):
+        if isinstance(a, (int, float, np.floating, np.integer)):
+            return self._scaled(float(a), divide=False)
+        return NotImplemented
+
+    def __truediv__(self, a):
+        return self._scaled(float(a), divide=True)
+
+    def _scaled(self, a: float, divide: bool) -> "HPCMatrix":
+        src = self.A if self.A.is_contiguous() else self.A.contiguous()
+        out = _torch().empty_like(src)
+        if divide:
+            _capi.call("hpcla_divide_f64", dptr(src), a, dptr(out), src.numel(), current_stream_ptr())
+        else:
+            _capi.call("hpcla_scale_f64", a, dptr(src), dptr(out), src.numel(), current_stream_ptr())
+        return HPCMatrix(self.row_partition, self.col_partition, out, self.backend)
+
+    def norm(self, p: float = 2) -> float:
+        """``norm(A, p)`` (src/dense.jl:1399-1420): the entries as one long vector (p = 2: Frobenius)."""
+        from .vectors import HPCVector, norm as vnorm
+        flat = (self.A if self.A.is_contiguous() else self.A.contiguous()).view(-1)
+        sizes = comm_allgather(self.backend.comm, np.array([flat.numel()], dtype=np.int64))
+        part = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        return vnorm(HPCVector(compute_partition_hash(part), part, flat, self.backend), p)
 
     def __getitem__(self, key):
         """``A[:, k]`` (src/indexing.jl:385-393): column k (0-based here) as an HPCVector on A's row

@@ -1025,6 +1025,25 @@ def test_dense_transpose_matvec(hp, orc, gpu_backend_i32, shape):
         hp.transpose(A) @ hp.HPCVector.from_global(np.ones(m + 1), b)
 
 
+def test_dense_scalar_ops_and_norms(hp, orc, golden, gpu_backend_i32):
+    """a*A, A*a, A/a (src/dense.jl:1317-1327, 1818-1838) and norm(A, p) (src/dense.jl:1399-1420); the SpMM
+    fixture's Frobenius norm (test/test_new_operations.jl:79-82) closes the loop on a reference value."""
+    import math
+    b = gpu_backend_i32
+    Mg = orc.fill_uniform(0, 300 * 7, 9).reshape(300, 7) - 0.5
+    M = hp.HPCMatrix.from_global(Mg, b)
+    np.testing.assert_array_equal((2.5 * M).local_values(), 2.5 * Mg)
+    np.testing.assert_array_equal((M * 2.5).local_values(), Mg * 2.5)
+    np.testing.assert_array_equal((M / 3.0).local_values(), Mg / 3.0)
+    assert abs(M.norm() - np.linalg.norm(Mg)) <= RTOL_RED * np.linalg.norm(Mg)
+    assert abs(M.norm(1) - np.abs(Mg).sum()) <= RTOL_RED * np.abs(Mg).sum()
+    assert M.norm(math.inf) == np.abs(Mg).max()
+    c = golden["spmm_sym"]
+    A = _from_coo(hp, c["I"], c["J"], c["V"], c["m"], c["n"], b)
+    C = A @ hp.HPCMatrix.from_global(np.array(c["B"]), b)
+    assert abs(C.norm() - c["C_fro"]) < TOL_REF
+
+
 def test_row_vector_algebra(hp, orc, gpu_backend_i32):
     """transpose(v) * A, a*vt, vt*a, vt/a, vt +/- wt (src/sparse.jl:2136-2142, src/vectors.jl:909-987,
     test/test_vector_multiplication.jl:141-160, 291-309)."""
