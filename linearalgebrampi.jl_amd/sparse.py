@@ -412,9 +412,46 @@ class HPCSparseMatrix:
         if isinstance(other, HPCSparseMatrix):
             from .matmat import spgemm
             return spgemm(self, other)
+        from .transpose import TransposedHPCSparseMatrix
+        if isinstance(other, TransposedHPCSparseMatrix):            # A * transpose(B), src/sparse.jl:2364-2368
+            return self.__matmul__(other.materialize())
         return NotImplemented
 
-    __mul__ = __matmul__
+    def __mul__(self, other):
+        if isinstance(other, (int, float, np.floating, np.integer)):
+            return self._scaled(float(other))
+        return self.__matmul__(other)
+
+    def __rmul__(self, a):
+        """``a * A`` (src/sparse.jl:2289-2308): new values, the structure arrays (and hash) are shared."""
+        if isinstance(a, (int, float, np.floating, np.integer)):
+            return self._scaled(float(a))
+        return NotImplemented
+
+    def __neg__(self):                                               # src/sparse.jl:2315
+        return self._scaled(-1.0)
+
+    def _with_values(self, nzval) -> "HPCSparseMatrix":
+        out = HPCSparseMatrix(self.row_partition, self.col_partition, self.col_indices, self._rowptr,
+                              self._colval, nzval, self.rowptr_target, self.backend)
+        out._colval_target = self._colval_target
+        out.structural_hash = self.structural_hash
+        return out
+
+    def _scaled(self, a: float) -> "HPCSparseMatrix":
+        out = _torch().empty_like(self.nzval)
+        _capi.call("hpcla_scale_f64", a, dptr(self.nzval), dptr(out), self.nnz, current_stream_ptr())
+        return self._with_values(out)
+
+    def copy(self) -> "HPCSparseMatrix":                             # src/sparse.jl:2458
+        return self._with_values(self.nzval.clone())
+
+    def norm(self, p: float = 2) -> float:
+        """``norm(A, p)`` (src/sparse.jl:2172-2195): over the stored entries (p = 2: Frobenius)."""
+        from .vectors import norm as vnorm
+        sizes = comm_allgather(self.backend.comm, np.array([self.nnz], dtype=np.int64))
+        part = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        return vnorm(HPCVector(compute_partition_hash(part), part, self.nzval, self.backend), p)
 
     def __add__(self, other):
         if isinstance(other, HPCSparseMatrix):

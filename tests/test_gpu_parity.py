@@ -1044,6 +1044,33 @@ def test_dense_scalar_ops_and_norms(hp, orc, golden, gpu_backend_i32):
     assert abs(C.norm() - c["C_fro"]) < TOL_REF
 
 
+def test_sparse_scalar_ops_norm_and_transposed_products(hp, orc, gpu_backend_i32):
+    """a*A, A*a, -A, copy (src/sparse.jl:2289-2315, 2458), norm(A, p) (:2172-2195) and the products with
+    lazily transposed operands (:2342-2368): the structure arrays are shared, values exact."""
+    import math
+    import scipy.sparse as sp
+    b = gpu_backend_i32
+    Ar, Br = orc.sprand_rows(500, 0.02, 0, 400), orc.sprand_rows(500, 0.03, 0, 300, seed_struct=5, seed_vals=6)
+    A = hp.HPCSparseMatrix_local(Ar.rowptr, Ar.colidx, Ar.vals, 500, b)          # 400 x 500
+    Bm = hp.HPCSparseMatrix_local(Br.rowptr, Br.colidx, Br.vals, 500, b)         # 300 x 500
+    As = sp.csr_matrix((Ar.vals, Ar.colidx, Ar.rowptr), shape=(400, 500))
+    Bs = sp.csr_matrix((Br.vals, Br.colidx, Br.rowptr), shape=(300, 500))
+    for M, want in ((2.5 * A, 2.5 * Ar.vals), (A * 2.5, Ar.vals * 2.5), (-A, -Ar.vals), (A.copy(), Ar.vals)):
+        rp, col, val = _csr_of(M)
+        np.testing.assert_array_equal(rp, Ar.rowptr); np.testing.assert_array_equal(col, Ar.colidx)
+        np.testing.assert_array_equal(val, want)
+        assert M._ensure_hash() == A._ensure_hash()
+    nv = Ar.vals
+    assert abs(A.norm() - np.linalg.norm(nv)) <= RTOL_RED * np.linalg.norm(nv)
+    assert abs(A.norm(1) - np.abs(nv).sum()) <= RTOL_RED * np.abs(nv).sum() and A.norm(math.inf) == np.abs(nv).max()
+    for got, want in ((A @ hp.transpose(Bm), As @ Bs.T), (hp.transpose(A) @ A, As.T @ As)):
+        want = want.tocsr(); want.sort_indices()
+        d = _dense_of(got, want.shape)
+        assert np.max(np.abs(d - want.toarray())) <= 1e-12 * max(1.0, np.abs(want.toarray()).max())
+    from hpcla_amd.matmat import clear_matrix_plan_cache
+    clear_matrix_plan_cache(); hp.clear_transpose_plan_cache(); hp.clear_plan_cache()
+
+
 def test_row_vector_algebra(hp, orc, gpu_backend_i32):
     """transpose(v) * A, a*vt, vt*a, vt/a, vt +/- wt (src/sparse.jl:2136-2142, src/vectors.jl:909-987,
     test/test_vector_multiplication.jl:141-160, 291-309)."""
