@@ -33,7 +33,7 @@ from .matmat import clear_matrix_plan_cache, get_matrix_plan, spgemm
 from .cg import cg_fixed_iterations
 from .transpose import (HostTransposeStructure, TransposedHPCSparseMatrix, TransposedHPCVector, TransposePlan,
                         adjoint, clear_transpose_plan_cache, get_transpose_plan, transpose)
-from .addition import sparse_add
+from .addition import add_scaled_identity, sparse_add
 from .repartition import (RangePlan, SparseRepartitionPlan, clear_repartition_cache, exchange_ranges,
                           get_sparse_repartition_plan, get_vector_repartition_plan, repartition)
 

@@ -103,3 +103,33 @@ def sparse_add(A, B, subtract: bool = False):
     C = HPCSparseMatrix(A.row_partition, A.col_partition, plan.col_indices, plan.rowptr_ti, plan.colval, nzval,
                         plan.rowptr_dev, A.backend)
     return C
+
+
+# ---- A + lambda*I / A - lambda*I (src/sparse.jl:3925-4015) ---------------------------------------------
+_identity_cache: Dict[tuple, object] = {}
+
+
+def add_scaled_identity(A, lam: float, subtract: bool = False):
+    """``A + lam*I`` (``A + J::UniformScaling``, src/sparse.jl:3925-3985; ``A - J`` :3987-3995).  The
+    reference walks the entries on the CPU with scalar indexing (its comment: "not efficient on GPU");
+    here the identity is an ordinary HPCSparseMatrix on A's row partition (unit diagonal, cached per
+    structure), scaled on the device and merged by the same one-pass AdditionPlan as ``A + B`` -- diagonal
+    entries missing from A are added structurally, exactly as in the reference's IdentityAdditionPlan."""
+    from .backends import comm_rank
+    from .sparse import HPCSparseMatrix_local
+    m, n = A.shape
+    if m != n:
+        raise ValueError(f"A + lambda*I needs a square matrix, got {A.shape}")
+    key = (A.backend.torch_device, tuple(A.row_partition.tolist()), tuple(A.col_partition.tolist()), str(A.Ti))
+    eye = _identity_cache.get(key)
+    if eye is None:
+        r = comm_rank(A.backend.comm)
+        lo, hi = int(A.row_partition[r]), int(A.row_partition[r + 1])
+        eye = HPCSparseMatrix_local(np.arange(hi - lo + 1, dtype=np.int64), np.arange(lo, hi, dtype=np.int64),
+                                    np.ones(hi - lo), n, A.backend, col_partition=A.col_partition)
+        _identity_cache[key] = eye
+    return sparse_add(A, float(lam) * eye, subtract=subtract)
+
+
+def clear_identity_cache() -> None:
+    _identity_cache.clear()

@@ -1067,6 +1067,15 @@ def test_sparse_scalar_ops_norm_and_transposed_products(hp, orc, gpu_backend_i32
         want = want.tocsr(); want.sort_indices()
         d = _dense_of(got, want.shape)
         assert np.max(np.abs(d - want.toarray())) <= 1e-12 * max(1.0, np.abs(want.toarray()).max())
+    # A + lambda*I, A - lambda*I (src/sparse.jl:3925-3995): missing diagonal entries appear structurally
+    Sq = orc.sprand_rows(300, 0.02, 0, 300, seed_struct=8, seed_vals=9)
+    S = hp.HPCSparseMatrix_local(Sq.rowptr, Sq.colidx, Sq.vals, 300, b)
+    Ss = sp.csr_matrix((Sq.vals, Sq.colidx, Sq.rowptr), shape=(300, 300))
+    np.testing.assert_array_equal(_dense_of(hp.add_scaled_identity(S, 2.5), (300, 300)), (Ss + 2.5 * sp.identity(300)).toarray())
+    np.testing.assert_array_equal(_dense_of(hp.add_scaled_identity(S, 2.5, subtract=True), (300, 300)),
+                                  (Ss - 2.5 * sp.identity(300)).toarray())
+    assert hp.add_scaled_identity(S, 1.0).nnz == len(np.unique(np.concatenate([Sq.colidx + 300 * np.repeat(np.arange(300), np.diff(Sq.rowptr)),
+                                                                                  301 * np.arange(300)])))
     from hpcla_amd.matmat import clear_matrix_plan_cache
     clear_matrix_plan_cache(); hp.clear_transpose_plan_cache(); hp.clear_plan_cache()
 
