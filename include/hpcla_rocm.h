@@ -345,6 +345,10 @@ int hpcla_asum_f64(hpcla_comm_t *comm, const double *x, int64_t n, double *out_d
                    void *stream);
 int hpcla_amax_f64(hpcla_comm_t *comm, const double *x, int64_t n, double *out_dev, void *work,
                    void *stream);
+/* maximum(v) (negate = 0) / minimum(v) (negate = 1: out = max(-x), the caller flips the sign)
+ * (src/vectors.jl:815-836); an empty vector contributes -inf like typemin in the reference */
+int hpcla_maxval_f64(hpcla_comm_t *comm, const double *x, int64_t n, int negate, double *out_dev, void *work,
+                     void *stream);
 /* sum(v) (src/vectors.jl:838-845): out = sum of all elements over all ranks */
 int hpcla_sum_f64(hpcla_comm_t *comm, const double *x, int64_t n, double *out_dev, void *work, void *stream);
 /* general p-norm, p > 0 finite: out = sum |x_i|^p over all ranks; the caller takes the 1/p power

@@ -99,6 +99,7 @@ _SIGNATURES = {
     "hpcla_nrm2sq_f64": [_vp, _vp, _i64, _vp, _vp, _vp],
     "hpcla_asum_f64": [_vp, _vp, _i64, _vp, _vp, _vp],
     "hpcla_amax_f64": [_vp, _vp, _i64, _vp, _vp, _vp],
+    "hpcla_maxval_f64": [_vp, _vp, _i64, _i32, _vp, _vp, _vp],
     "hpcla_sum_f64": [_vp, _vp, _i64, _vp, _vp, _vp],
     "hpcla_powsum_f64": [_vp, _vp, _i64, _f64, _vp, _vp, _vp],
     "hpcla_axpy_f64": [_f64, _vp, _vp, _vp, _vp, _i64, _vp],

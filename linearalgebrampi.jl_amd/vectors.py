@@ -242,6 +242,23 @@ def vsum(v: HPCVector, out=None):
     return r if out is not None else float(r.item())
 
 
+def _maxval(v: HPCVector, negate: int) -> float:
+    work, scal = _Scratch.get(v.v.device)
+    _capi.call("hpcla_maxval_f64", v.backend.rccl, dptr(v.v), v.local_length, negate, dptr(scal[:1]), dptr(work),
+               current_stream_ptr())
+    return float(scal[:1].item())
+
+
+def maximum(v: HPCVector) -> float:
+    """``maximum(v)`` (src/vectors.jl:815-824)."""
+    return _maxval(v, 0)
+
+
+def minimum(v: HPCVector) -> float:
+    """``minimum(v)`` (src/vectors.jl:826-836)."""
+    return -_maxval(v, 1)
+
+
 def dot(x: HPCVector, y: HPCVector, out=None):
     """``dot(x, y)`` (src/vectors.jl:798-812).  Returns a Python float (host sync), or, when ``out``
     (1-element device tensor) is given, leaves the result on the device and returns ``out``."""

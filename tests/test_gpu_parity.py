@@ -342,6 +342,8 @@ def test_dot_norm_golden_and_random(hp, orc, golden, gpu_backend_i32):
         assert abs(hp.norm(xv) - orc.norm([xg], 2)) <= RTOL_RED * orc.norm([xg], 2)
         assert abs(hp.norm(xv, 1) - orc.norm([xg], 1)) <= RTOL_RED * orc.norm([xg], 1)
         assert hp.norm(xv, math.inf) == orc.norm([xg], math.inf)
+        assert hp.maximum(xv) == xg.max() and hp.minimum(xv) == xg.min()            # src/vectors.jl:815-836
+        assert abs(hp.vsum(xv) - xg.sum()) <= RTOL_RED * np.abs(xg).sum()           # src/vectors.jl:838-845
         want3 = float(np.sum(np.abs(xg) ** 3.0)) ** (1.0 / 3.0)                      # general p (src/vectors.jl:774-779)
         assert abs(hp.norm(xv, 3) - want3) <= 1e-11 * want3
     # deterministic: two runs give the same bits
