@@ -309,6 +309,10 @@ def _run():
         want = np.where(ok, want + term, want)
     got = y.v[torch.from_numpy(samp).cuda()].cpu().numpy()
     verified = bool(np.array_equal(got, want))
+    if not verified:                     # say where, for whoever reads the log of a failed multi-GPU run
+        bad = np.flatnonzero(got != want)
+        sys.stderr.write(f"bench: rank {rank}: {len(bad)} of {len(g)} sampled rows differ; first global rows "
+                         f"{g[bad[:8]].tolist()} got {got[bad[:8]].tolist()} want {want[bad[:8]].tolist()}\n")
     if world > 1:
         flag = torch.tensor([1 if verified else 0], device="cuda")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
