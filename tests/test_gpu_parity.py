@@ -1152,6 +1152,18 @@ def test_widened_rows_on_reference_fixtures(hp, golden, gpu_backend_i32):
     clear_addition_plan_cache(); clear_matrix_plan_cache(); hp.clear_plan_cache()
 
 
+def test_host_collectives_on_mixed_gloo_nccl_group():
+    """bench.py --gpus N initialises torch.distributed with "cpu:gloo,cuda:nccl" (that needs a GPU to be
+    constructed, hence the gpu mark).  Two processes: comm_* primitives, index/value exchanges and
+    build_host_vector_plan must work on that mixed group exactly as on the gloo-only group of the CPU tests."""
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", "29733", os.path.join(ROOT, "tests", "_mixed_pg_worker.py")]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert out.stdout.count("mixed-backend host collectives OK") == 2
+
+
 def test_graft_entry_smoke():
     import __graft_entry__ as g
     g.smoke()
