@@ -28,6 +28,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--dim", type=int, default=2)
+    ap.add_argument("--nz", type=int, default=0, help="dim 3: number of planes (default: size), e.g. 64 for config 4's per-GPU slab")
     ap.add_argument("--variants", default="0,1,2,3,4,5,6,7,10,11,12,13,14,15,20")
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--reps", type=int, default=20)
@@ -46,7 +47,8 @@ def main():
     if args.dim == 2:
         rowptr, colidx, vals = wl.poisson2d_rows(N, N, 0, N * N); n = N * N
     else:
-        rowptr, colidx, vals = wl.poisson3d_rows(N, N, N, 0, N ** 3); n = N ** 3
+        nz = args.nz or N
+        rowptr, colidx, vals = wl.poisson3d_rows(N, N, nz, 0, N * N * nz); n = N * N * nz
     A = hp.HPCSparseMatrix_local(rowptr, colidx, vals, n, backend)
     x = hp.HPCVector.zeros(A.row_partition, backend)
     s = torch.cuda.current_stream().cuda_stream
@@ -63,19 +65,27 @@ def main():
     rp_h = A.rowptr.astype(np.int64)
     rowid = np.repeat(np.arange(n, dtype=np.int64), np.diff(rp_h))
     d = A.colval.astype(np.int64) - (rowid // 256) * 256
-    assert d.min() >= -32768 and d.max() <= 32767, "not packable with 16-bit block-relative columns"
-    dv, inv = np.unique(A.nzval.cpu().numpy(), return_inverse=True)
-    assert len(dv) <= 256
-    pad = (-nnz) % 8 + 8
-    dcol = torch.from_numpy(np.concatenate([d.astype(np.int16), np.zeros(pad, np.int16)])).cuda()
-    code = torch.from_numpy(np.concatenate([inv.astype(np.uint8), np.zeros(pad, np.uint8)])).cuda()
-    dictv = torch.from_numpy(dv).cuda()
-    mk = lambda R: torch.from_numpy(np.concatenate([(A.colval.astype(np.int64) - (rowid // R) * R).astype(np.int16),
-                                                    np.zeros(pad, np.int16)])).cuda()
-    dcol512, dcol1024 = mk(512), mk(1024)
-    del rowid, d, inv
+    packable = d.min() >= -32768 and d.max() <= 32767          # 16-bit block-relative columns (2-D stencils)
+    if packable:
+        dv, inv = np.unique(A.nzval.cpu().numpy(), return_inverse=True)
+        assert len(dv) <= 256
+        pad = (-nnz) % 8 + 8
+        dcol = torch.from_numpy(np.concatenate([d.astype(np.int16), np.zeros(pad, np.int16)])).cuda()
+        code = torch.from_numpy(np.concatenate([inv.astype(np.uint8), np.zeros(pad, np.uint8)])).cuda()
+        dictv = torch.from_numpy(dv).cuda()
+        mk = lambda R: torch.from_numpy(np.concatenate([(A.colval.astype(np.int64) - (rowid // R) * R).astype(np.int16),
+                                                        np.zeros(pad, np.int16)])).cuda()
+        dcol512, dcol1024 = mk(512), mk(1024)
+        del inv
+    else:                                                       # packed variants (80-86) unavailable
+        dcol = dcol512 = dcol1024 = torch.zeros(8, dtype=torch.int16, device="cuda")
+        code = torch.zeros(8, dtype=torch.uint8, device="cuda")
+        dictv = torch.zeros(1, dtype=torch.float64, device="cuda")
+    del rowid, d
     yvec = hp.HPCVector.zeros(A.row_partition, backend)
     plan = hp.get_vector_plan(A, x)
+    dot_out = torch.zeros(1, dtype=torch.float64, device="cuda")
+    dot_work = torch.empty(hp._capi.load().hpcla_spmv_dot_work_bytes(n) // 8 + 1, dtype=torch.float64, device="cuda")
 
     def launch(v):
         if v == 100:     # production library, plain kernel
@@ -88,6 +98,10 @@ def main():
             return hp._capi.load().hpcla_spmv_dist_f64_i32(None, A.rowptr_target.data_ptr(), plan.colval_split.data_ptr(),
                                                           A.nzval.data_ptr(), x.v.data_ptr(), n, yvec.v.data_ptr(), n, nnz, 0,
                                                           None, 0, None, 0, s)
+        if v == 104:     # fused SpMV + x.y epilogue (CG's p.Ap), partials reduced, no communicator
+            return hp._capi.load().hpcla_spmv_dist_dot_f64_i32(None, None, A.rowptr_target.data_ptr(), plan.colval_split.data_ptr(),
+                                                              A.nzval.data_ptr(), x.v.data_ptr(), n, yvec.v.data_ptr(), n, nnz, 0,
+                                                              None, 0, None, 0, dot_out.data_ptr(), dot_work.data_ptr(), s)
         if v == 101:     # production library, split-column kernel (ghost select per entry)
             return hp._capi.load().hpcla_spmv_split_f64_i32(A.rowptr_target.data_ptr(), cv.data_ptr(), A.nzval.data_ptr(),
                                                            x.v.data_ptr(), ghost.data_ptr(), n, y.data_ptr(), n, nnz, 0,
@@ -101,7 +115,7 @@ def main():
         rc = launch(v)
         assert rc == 0, (v, rc)
         torch.cuda.synchronize()
-        exact[v] = bool(torch.equal(yvec.v if v in (102, 103) else y, y_ref))
+        exact[v] = bool(torch.equal(yvec.v if v in (102, 103, 104) else y, y_ref))
     for rnd in range(args.rounds):
         for v in variants:
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -102,6 +102,11 @@ __global__ __launch_bounds__(RPB) void spmv_rowblock_quad_kernel(
         hi = (int)((int64_t)rowptr[r0 + tid + 1] - base - pa);
     }
 
+    // fused x.y epilogue: fetch x at this lane's row NOW, so the load rides along with the stream instead of
+    // adding a dependent memory round trip at the tail of every workgroup (CG iteration kernel 352 -> 348 us)
+    double x_row = 0.0;
+    if (dot_partial && tid < nr) x_row = x_own[r0 + tid];
+
     double acc = 0.0;
     for (int64_t c = 0; c < total; c += CHUNK) {
         const int n = (int)((total - c) < CHUNK ? (total - c) : CHUNK);
@@ -172,7 +177,7 @@ __global__ __launch_bounds__(RPB) void spmv_rowblock_quad_kernel(
         __syncthreads();
     }
     if (tid < nr) y[r0 + tid] = acc;
-    if (dot_partial) block_dot_epilogue(s_prod, dot_partial, blk, tid < nr ? acc * x_own[r0 + tid] : 0.0);
+    if (dot_partial) block_dot_epilogue(s_prod, dot_partial, blk, tid < nr ? acc * x_row : 0.0);
 }
 
 // ---- fallback kernel: element-per-lane loads, no alignment requirement --------------------------------

@@ -19,6 +19,7 @@ for st in $STEPS; do
     bench)  run 600 gpurun_out/${TAG}_bench.log python bench.py --steps 100 --warmup 10; tail -3 gpurun_out/${TAG}_bench.log;;
     tune)   run 600 gpurun_out/${TAG}_tune.log python benchmarks/tune_spmv.py ${TUNE_ARGS}; tail -25 gpurun_out/${TAG}_tune.log;;
     tune8k) run 900 gpurun_out/${TAG}_tune8k.log python benchmarks/tune_spmv.py --size 8192 --variants 16,100,101,102,20 --rounds 5 --reps 10; tail -8 gpurun_out/${TAG}_tune8k.log;;
+    tune3dslab) run 900 gpurun_out/${TAG}_tune3dslab.log python benchmarks/tune_spmv.py --dim 3 --size 512 --nz 64 --variants ${TUNE3D_VARIANTS:-16,10,12,19,15,100} --rounds 5 --reps 10; tail -9 gpurun_out/${TAG}_tune3dslab.log;;
     tune3d) run 600 gpurun_out/${TAG}_tune3d.log python benchmarks/tune_spmv.py --dim 3 --size 256 ${TUNE_ARGS}; tail -25 gpurun_out/${TAG}_tune3d.log;;
     prof)
       cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
@@ -50,6 +51,9 @@ for st in $STEPS; do
       run 600 gpurun_out/${TAG}_pmc_spmm_tcc.log rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum --output-format csv -d gpurun_out/${TAG}_pmc_spmm_tcc -- python3 bench.py --workload poisson2d_spmm --steps 5 --warmup 2
       run 600 gpurun_out/${TAG}_pmc_spmm_fs.log rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/${TAG}_pmc_spmm_fs -- python3 bench.py --workload poisson2d_spmm --steps 5 --warmup 2
       tail -1 gpurun_out/${TAG}_pmc_spmm_fs.log;;
+    profcg)
+      run 600 gpurun_out/${TAG}_profcg.log rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_profcg -- python3 bench.py --workload poisson3d_cg --steps 50 --warmup 8
+      tail -2 gpurun_out/${TAG}_profcg.log;;
     pmc_tcc)
       run 600 gpurun_out/${TAG}_pmc_tcc.log rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum --output-format csv -d gpurun_out/${TAG}_pmc_tcc -- python3 benchmarks/tune_spmv.py --variants 100,5,20,0 --rounds 1 --reps 2
       tail -2 gpurun_out/${TAG}_pmc_tcc.log;;
