@@ -13,6 +13,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """A fresh checkout has no built artefacts (they are git-ignored): build the HIP library (hipcc
+    cross-compiles gfx950 without a GPU, a few seconds) and the oracle before the first test needs them --
+    the same two `make` calls as __graft_entry__.build()."""
+    import subprocess
+    lib = os.path.join(ROOT, "linearalgebrampi.jl_amd", "libhpcla_rocm.so")
+    if not os.path.exists(lib):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "linearalgebrampi.jl_amd", "csrc")],
+                              stdout=subprocess.DEVNULL)
+    if not any(f.endswith(".so") for f in os.listdir(os.path.join(ROOT, "oracle"))):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+
+
 @pytest.fixture(scope="session")
 def golden():
     with open(os.path.join(ROOT, "tests", "golden", "hotpath_golden.json")) as f:
