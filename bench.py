@@ -5,12 +5,18 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one y = A*x (``mul!(y, A, x)``) over the resident matrix: halo exchange (N > 1: RCCL
-send/recv group, ahead of one fused launch by default or overlapped with the interior row blocks on a
-side stream with HPCLA_HALO_MODE=overlap) + SpMV.  Workload at N = 1: BASELINE
-configs[1], the 4096^2 Poisson matrix (n = 16 777 216, nnz = 83 869 696, Int32 indices).  N > 1:
-weak scaling -- every GPU owns one 4096 x 4096 slab of a 4096 x (4096*N) grid (same per-GPU work as
-N = 1, two 32 KiB halo lines per interior GPU).
+`python bench.py --gpus N` starts its own N ranks (one process per GPU; the parent spawns them before it
+touches the GPU runtime); under torch.distributed.run it uses the ranks it is given.
+
+A "step" is one y = A*x (``mul!(y, A, x)``) over the resident matrix: halo exchange + SpMV.  At N > 1 the
+default exchange is the peer-window push over xGMI (a small kernel stores the boundary values straight
+into the neighbours' ghost windows; the SpMV's own boundary workgroups wait for them -- DESIGN.md
+section 4); HPCLA_HALO_MODE=serial|overlap selects the RCCL send/recv orderings instead, and the line's
+`step_breakdown_ms_max_over_ranks` times every ordering.  Workload at N = 1: BASELINE configs[1], the 4096^2
+Poisson matrix (n = 16 777 216, nnz = 83 869 696, Int32 indices).  N > 1: weak scaling -- every GPU owns one
+4096 x 4096 slab of a 4096 x (4096*N) grid (same per-GPU work as N = 1, two 32 KiB halo lines per interior
+GPU); the sub-record `strong_scaling` is BASELINE configs[2], the fixed 8192^2 problem over the N GPUs, with
+the same problem on rank 0 alone beside it (speed-up measured inside one run).
 
 Output: ONE JSON line on rank 0 (contract in the task statement) with `roofline` (HBM, algorithmic
 bytes / per-launch time measured with HIP events on the launch stream) and `cpu_baseline` (the
@@ -44,15 +50,9 @@ def parse():
     ap.add_argument("--no-packed", action="store_true", help="skip the extra opt-in packed-copy measurement")
     ap.add_argument("--host-setup", action="store_true", help="generate/compress the matrix on the host (numpy) instead of on the device")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--strong-size", type=int, default=8192, help="grid edge of the strong-scaling sub-record (BASELINE configs[2])")
+    ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling sub-record")
     return ap.parse_args()
-
-
-def _device_barrier(torch, dist):
-    """Barrier through the device collective path (a 1-element all-reduce on the NCCL/RCCL group):
-    unambiguous for mixed gloo+nccl process groups."""
-    t = torch.zeros(1, device="cuda")
-    dist.all_reduce(t)
-    torch.cuda.synchronize()
 
 
 def usable_cores() -> int:
@@ -132,46 +132,96 @@ def cpu_baseline_spmv(rowptr, colval, vals, x_gathered, budget_s):
     }
 
 
-def step_breakdown(hp, torch, dist, world, plan, A, x, y, barrier):
-    """Device time per call (HIP events, max over ranks) of the pieces of one distributed step."""
+class Job:
+    """Host-side collectives of the benchmark itself (barrier, max / sum / min over ranks): gloo on CPU
+    scalars, so they work whatever the data path is -- RCCL, or peer windows with ranks sharing a GPU."""
+
+    def __init__(self, torch, dist, world, rank):
+        self.torch, self.dist, self.world, self.rank = torch, dist, world, rank
+
+    def barrier(self):
+        self.torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def _reduce(self, value, op):
+        if self.world == 1:
+            return float(value)
+        t = self.torch.tensor([float(value)], dtype=self.torch.float64)
+        self.dist.all_reduce(t, op=op)
+        return float(t.item())
+
+    def max(self, v):
+        return self._reduce(v, self.dist.ReduceOp.MAX if self.world > 1 else None)
+
+    def min(self, v):
+        return self._reduce(v, self.dist.ReduceOp.MIN if self.world > 1 else None)
+
+    def sum(self, v):
+        return self._reduce(v, self.dist.ReduceOp.SUM if self.world > 1 else None)
+
+
+HALO_MODES = {"serial": 0, "overlap": 1, "push": 2}
+
+
+def step_breakdown(hp, job, backend, plan, A, x, y):
+    """Device time per call (HIP events, max over ranks) of one distributed step in EVERY ordering this job
+    can run (push: peer windows attached; serial / overlap: an RCCL communicator exists), plus the pieces of
+    the step.  Every rank makes the same calls in the same order; the only communication is the step's own
+    halo exchange."""
     import ctypes
+    torch = job.torch
     capi = hp._capi
     sp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
     cur = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    gp, gn = ctypes.c_void_p(), ctypes.c_int64(0)
-    if plan.has_halo:
-        capi.call("hpcla_halo_ghost_ptr", plan.halo, ctypes.byref(gp), ctypes.byref(gn))
+    sfx = "i64" if plan.is_i64 else "i32"
+
+    def ghost():
+        gp, gn = ctypes.c_void_p(), ctypes.c_int64(0)
+        if plan.has_halo:
+            capi.call("hpcla_halo_ghost_ptr", plan.halo, ctypes.byref(gp), ctypes.byref(gn))
+        return (gp if gp.value else None), int(gn.value)
 
     def split(blocks, nb):
-        capi.call("hpcla_spmv_split_f64_i32", sp(A.rowptr_target), sp(plan.colval_split), sp(A.nzval), sp(x.v),
-                  gp if gp.value else None, plan.n_own, sp(y.v), A.nrows_local, A.nnz, 0, sp(blocks), nb, cur())
+        capi.call(f"hpcla_spmv_split_f64_{sfx}", sp(A.rowptr_target), sp(plan.colval_split), sp(A.nzval), sp(x.v),
+                  ghost()[0], plan.n_own, sp(y.v), A.nrows_local, A.nnz, 0, sp(blocks), nb, cur())
 
     def exchange():
         # the step's own exchange and nothing else: the fused entry point over ZERO rows (same stream, same
-        # RCCL group, same HPCLA_HALO_MODE as the timed loop -- no communication pattern the loop did not use)
-        capi.call("hpcla_spmv_dist_f64_i32", plan.halo, sp(A.rowptr_target), sp(plan.colval_split), sp(A.nzval),
+        # transport and ordering as the timed loop -- no communication pattern the loop did not use)
+        capi.call(f"hpcla_spmv_dist_f64_{sfx}", plan.halo, sp(A.rowptr_target), sp(plan.colval_split), sp(A.nzval),
                   sp(x.v), plan.n_own, sp(y.v), 0, 0, 0, None, 0, None, 0, cur())
 
-    legs = [("all_row_blocks_no_exchange", lambda: split(None, 0))]
-    if plan.has_halo:
-        legs += [("interior_blocks", lambda: split(plan.interior, plan.n_interior)),
-                 ("boundary_blocks", lambda: split(plan.boundary, plan.n_boundary)),
-                 ("exchange_only", exchange)]
-    legs.append(("full_step", lambda: hp.mul_(y, A, x)))
-    out = {"n_interior_blocks": plan.n_interior, "n_boundary_blocks": plan.n_boundary, "ghost_values": int(gn.value)}
-    for name, fn in legs:
+    def timed(fn, reps=50):
         fn()
-        barrier()
+        job.barrier()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(50):
+        for _ in range(reps):
             fn()
         e1.record()
-        barrier()
-        t = torch.tensor([e0.elapsed_time(e1) / 50], dtype=torch.float64, device="cuda")
-        if world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        out[name + "_ms"] = round(float(t.item()), 5)
+        job.barrier()
+        return round(job.max(e0.elapsed_time(e1) / reps), 5)
+
+    out = {"n_interior_blocks": plan.n_interior, "n_boundary_blocks": plan.n_boundary, "ghost_values": ghost()[1]}
+    out["all_row_blocks_no_exchange_ms"] = timed(lambda: split(None, 0))
+    if plan.has_halo:
+        out["interior_blocks_ms"] = timed(lambda: split(plan.interior, plan.n_interior))
+        out["boundary_blocks_ms"] = timed(lambda: split(plan.boundary, plan.n_boundary))
+    modes = []
+    if getattr(plan, "push", False):
+        modes.append("push")
+    if backend.has_rccl:
+        modes += ["serial", "overlap"]
+    per_mode = {}
+    for m in modes:
+        capi.call("hpcla_set_halo_mode", HALO_MODES[m])
+        per_mode[m] = {"full_step_ms": timed(lambda: hp.mul_(y, A, x)),
+                       "exchange_only_ms": timed(exchange) if plan.has_halo else None}
+    capi.call("hpcla_set_halo_mode", -1)
+    out["modes"] = per_mode
+    out["timed_out"] = bool(job.max(1.0 if plan.timed_out() else 0.0))
     return out
 
 
@@ -192,9 +242,28 @@ class _StdoutToStderr:
         return False
 
 
+def _load_launcher():
+    """linearalgebrampi.jl_amd/launch.py loaded BY PATH: importing the package would import torch, and the
+    launching parent must never touch the GPU runtime."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("hpcla_launch", os.path.join(ROOT, "linearalgebrampi.jl_amd", "launch.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def main():
+    args = parse()
+    launch = _load_launcher()
+    if args.gpus > 1 and not launch.already_launched():
+        # `python bench.py --gpus N` with no launcher around it: start the N ranks ourselves (the reference's
+        # distributed entry does the same with mpiexec, test/runtests.jl:16-35).  Nothing GPU-related has
+        # been imported in this process.
+        sys.stderr.write(f"bench: launching {args.gpus} ranks (one process per GPU)\n")
+        raise SystemExit(launch.spawn_ranks([os.path.abspath(__file__)] + sys.argv[1:], args.gpus,
+                                            timeout=float(os.environ.get("HPCLA_BENCH_TIMEOUT_S", "1500"))))
     with _StdoutToStderr():
-        out = _run()
+        out = _run(args)
     line, verified = out if isinstance(out, tuple) else (out, True)
     if line is not None:
         print(line, flush=True)            # the result is out before any teardown can go wrong
@@ -211,92 +280,19 @@ def _teardown():
     try:
         import torch.distributed as dist
         import hpcla_amd as hp
+        hp.clear_spmm_cache()
         hp.clear_plan_cache()
         if dist.is_available() and dist.is_initialized():
+            dist.barrier()
             dist.destroy_process_group()
     except Exception as exc:                 # teardown problems must not turn a finished run into a failure
         sys.stderr.write(f"bench: teardown: {type(exc).__name__}: {exc}\n")
 
 
-def _run():
-    args = parse()
-    import torch
-    import torch.distributed as dist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-        args.gpus = world
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
-    torch.cuda.set_device(local_rank % torch.cuda.device_count())
-
-    import hpcla_amd as hp
-    from hpcla_amd import workloads as wl
-
-    Ti = np.int32 if args.index == "i32" else np.int64
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("cpu:gloo,cuda:nccl")
-        backend = hp.backend_rocm_mpi(np.float64, Ti)
-    else:
-        backend = hp.backend_rocm_serial(np.float64, Ti, device_index=torch.cuda.current_device())
-
-    if args.workload not in ("poisson2d", "poisson2d_strong"):
-        from benchmarks import extra_workloads          # configs 4/5: separate harness
-        return extra_workloads.run(args, backend, rank, world)       # its JSON line (rank 0) or None
-
-    # ---- build the workload ------------------------------------------------------------------------
-    strong = args.workload == "poisson2d_strong"      # BASELINE configs[2]: fixed 8192^2 grid over N GPUs
-    N = args.size or (8192 if strong else 4096)
-    if strong:
-        nx, ny = N, N
-        ny_loc = (N + world - 1) // world
-        part0 = hp.uniform_partition(nx * ny, world)
-        lo, hi = int(part0[rank]), int(part0[rank + 1])
-    else:
-        nx, ny_loc = N, N
-        ny = ny_loc * world
-        lo, hi = rank * nx * ny_loc, (rank + 1) * nx * ny_loc
-    n_glob = nx * ny
-    t0 = time.perf_counter()
-    if args.host_setup:
-        rowptr, colidx, vals = wl.poisson2d_rows(nx, ny, lo, hi)
-        A = hp.HPCSparseMatrix_local(rowptr, colidx, vals, n_glob, backend)
-        del colidx
-    else:
-        # device-side construction: generator kernel + bitmap/scan column compression
-        s0 = torch.cuda.current_stream().cuda_stream
-        nnz_gen = hp._capi.load().hpcla_poisson2d_nnz(nx, ny, lo, hi)
-        rp_d = torch.empty(hi - lo + 1, dtype=torch.int64, device="cuda")
-        ci_d = torch.empty(nnz_gen, dtype=torch.int64, device="cuda")
-        va_d = torch.empty(nnz_gen, dtype=torch.float64, device="cuda")
-        hp._capi.call("hpcla_gen_poisson2d", nx, ny, lo, hi, rp_d.data_ptr(), ci_d.data_ptr(), va_d.data_ptr(), s0)
-        A = hp.HPCSparseMatrix_local_device(rp_d, ci_d, va_d, n_glob, backend,
-                                            col_window=(max(lo - nx, 0), min(hi + nx, n_glob) - 1))
-        del ci_d, rp_d
-        vals = None
-    part = A.row_partition
-    x = hp.HPCVector.zeros(part, backend)
-    hp._capi.call("hpcla_fill_uniform_f64", x.v.data_ptr(), lo, hi - lo, wl.SEED_X,
-                  torch.cuda.current_stream().cuda_stream)
-    y = hp.HPCVector.zeros(part, backend)
-    plan = hp.get_vector_plan(A, x)
-    setup_s = time.perf_counter() - t0
-    nnz_loc, nrows_loc = A.nnz, A.nrows_local
-    b_alg_loc = wl.spmv_algorithmic_bytes(nnz_loc, nrows_loc, A.ncols_compressed, np.dtype(Ti).itemsize)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            _device_barrier(torch, dist)
-        torch.cuda.synchronize()
-
-    # ---- verification of this rank's result on sampled rows (incl. halo-adjacent rows) -----------------
-    hp.mul_(y, A, x)
-    torch.cuda.synchronize()
+def closed_form_check(wl, torch, y, nx, ny, lo, nrows_loc, rank):
+    """This rank's result on sampled rows (incl. the halo-adjacent first / last grid lines) against the
+    closed form of the 5-point matrix: same order and rounding as the kernel (ascending column, multiply
+    then add), so the comparison is bit-exact."""
     samp = np.unique(np.concatenate([np.arange(0, min(3 * nx, nrows_loc)),
                                      np.arange(max(0, nrows_loc - 3 * nx), nrows_loc),
                                      np.random.default_rng(rank).integers(0, nrows_loc, 4096)]))
@@ -304,44 +300,181 @@ def _run():
     gi, gj = g % nx, g // nx
     xs = lambda idx: wl.u01(wl.SEED_X, idx)
     want = np.zeros(len(g))
-    # same order and rounding as the kernel: ascending column, mul then add
     for col, ok, coef in ((g - nx, gj > 0, -1.0), (g - 1, gi > 0, -1.0), (g, np.ones_like(g, bool), 4.0),
                           (g + 1, gi < nx - 1, -1.0), (g + nx, gj < ny - 1, -1.0)):
         term = coef * xs(np.where(ok, col, 0))
         want = np.where(ok, want + term, want)
     got = y.v[torch.from_numpy(samp).cuda()].cpu().numpy()
-    verified = bool(np.array_equal(got, want))
-    if not verified:                     # say where, for whoever reads the log of a failed multi-GPU run
+    ok = bool(np.array_equal(got, want))
+    if not ok:                     # say where, for whoever reads the log of a failed multi-GPU run
         bad = np.flatnonzero(got != want)
         sys.stderr.write(f"bench: rank {rank}: {len(bad)} of {len(g)} sampled rows differ; first global rows "
                          f"{g[bad[:8]].tolist()} got {got[bad[:8]].tolist()} want {want[bad[:8]].tolist()}\n")
-    if world > 1:
-        flag = torch.tensor([1 if verified else 0], device="cuda")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        verified = bool(flag.item())
+    return ok, samp, want
 
-    # ---- warm-up, then EXACTLY K timed steps -----------------------------------------------------------
-    for _ in range(args.warmup):
-        hp.mul_(y, A, x)
-    ev_t0, ev_t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    barrier()
-    t0 = time.perf_counter()
-    ev_t0.record()                       # HIP events on the launch stream, bracketing the timed region itself
-    for _ in range(args.steps):
-        hp.mul_(y, A, x)
-    ev_t1.record()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    timed_region_launch_ms = ev_t0.elapsed_time(ev_t1) / args.steps
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
-    # ---- per-launch duration with HIP events on the launch stream (roofline.achieved) ----------------
+class PoissonRun:
+    """One resident 2-D Poisson problem (matrix, x, y, plan) of `world` ranks and the timing of K steps."""
+
+    def __init__(self, hp, wl, job, backend, args, N, strong, world, rank):
+        torch = job.torch
+        self.hp, self.wl, self.job, self.backend = hp, wl, job, backend
+        Ti = np.int32 if args.index == "i32" else np.int64
+        if strong:                                  # BASELINE configs[2]: ONE N x N grid over all ranks
+            nx, ny = N, N
+            part0 = hp.uniform_partition(nx * ny, world)
+            lo, hi = int(part0[rank]), int(part0[rank + 1])
+            ny_loc = (hi - lo) // nx
+        else:                                       # weak: one N x N slab per rank
+            nx, ny_loc = N, N
+            ny = ny_loc * world
+            lo, hi = rank * nx * ny_loc, (rank + 1) * nx * ny_loc
+        self.nx, self.ny, self.ny_loc, self.lo, self.hi, self.n_glob = nx, ny, ny_loc, lo, hi, nx * ny
+        t0 = time.perf_counter()
+        self.vals = None
+        if args.host_setup:
+            rowptr, colidx, vals = wl.poisson2d_rows(nx, ny, lo, hi)
+            self.A = hp.HPCSparseMatrix_local(rowptr, colidx, vals, self.n_glob, backend)
+            self.vals = vals
+            del colidx
+        else:
+            # device-side construction (SURVEY 8f rank 2): generator kernel + bitmap/scan column compression
+            s0 = torch.cuda.current_stream().cuda_stream
+            nnz_gen = hp._capi.load().hpcla_poisson2d_nnz(nx, ny, lo, hi)
+            rp_d = torch.empty(hi - lo + 1, dtype=torch.int64, device="cuda")
+            ci_d = torch.empty(nnz_gen, dtype=torch.int64, device="cuda")
+            va_d = torch.empty(nnz_gen, dtype=torch.float64, device="cuda")
+            hp._capi.call("hpcla_gen_poisson2d", nx, ny, lo, hi, rp_d.data_ptr(), ci_d.data_ptr(), va_d.data_ptr(), s0)
+            self.A = hp.HPCSparseMatrix_local_device(rp_d, ci_d, va_d, self.n_glob, backend,
+                                                     col_window=(max(lo - nx, 0), min(hi + nx, self.n_glob) - 1))
+            del ci_d, rp_d
+        A = self.A
+        self.x = hp.HPCVector.zeros(A.row_partition, backend)
+        hp._capi.call("hpcla_fill_uniform_f64", self.x.v.data_ptr(), lo, hi - lo, wl.SEED_X,
+                      torch.cuda.current_stream().cuda_stream)
+        self.y = hp.HPCVector.zeros(A.row_partition, backend)
+        self.plan = hp.get_vector_plan(A, self.x)
+        torch.cuda.synchronize()
+        self.setup_s = time.perf_counter() - t0
+        self.nnz_loc, self.nrows_loc = A.nnz, A.nrows_local
+        self.b_alg_loc = wl.spmv_algorithmic_bytes(A.nnz, A.nrows_local, A.ncols_compressed, np.dtype(Ti).itemsize)
+        hp.mul_(self.y, A, self.x)
+        torch.cuda.synchronize()
+        ok, self.samp, self.want = closed_form_check(wl, torch, self.y, nx, ny, lo, self.nrows_loc, rank)
+        self.collective = world == job.world          # False: rank 0 alone inside a multi-rank job
+        self.verified = bool(job.min(1.0 if ok else 0.0)) if self.collective else ok
+
+    def time_steps(self, steps, warmup):
+        """warm-up, then EXACTLY `steps` timed steps bracketed by barrier + synchronize on both sides; returns
+        (wall seconds, max over ranks; device ms per launch between two HIP events on the launch stream)."""
+        torch, hp, job = self.job.torch, self.hp, self.job
+        collective = self.collective
+        sync = job.barrier if collective else torch.cuda.synchronize
+        for _ in range(warmup):
+            hp.mul_(self.y, self.A, self.x)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        sync()
+        t0 = time.perf_counter()
+        ev0.record()                       # HIP events on the launch stream, bracketing the timed region itself
+        for _ in range(steps):
+            hp.mul_(self.y, self.A, self.x)
+        ev1.record()
+        sync()
+        elapsed = time.perf_counter() - t0
+        if collective:
+            elapsed = job.max(elapsed)
+        return elapsed, ev0.elapsed_time(ev1) / steps
+
+    def release(self):
+        self.A = self.x = self.y = self.plan = None
+
+
+def strong_scaling_record(hp, wl, job, backend, args, world, rank):
+    """BASELINE configs[2]: ONE 8192^2 Poisson problem row-partitioned over all ranks (strong scaling), and --
+    on rank 0 alone, same box, same run -- the whole problem on one GPU, so the record carries its own
+    speed-up.  The N = 1 job reports just the single-GPU point."""
+    torch = job.torch
+    N = args.strong_size
+    steps, warmup = min(args.steps, 50), min(args.warmup, 10)
+    rec = {"workload": f"poisson2d 5-pt {N}x{N} global over {world} GPU(s), CSR SpMV y=A*x, index={args.index}"}
+    run = PoissonRun(hp, wl, job, backend, args, N, True, world, rank)
+    el, launch_ms = run.time_steps(steps, warmup)
+    nnz_tot = int(job.sum(run.nnz_loc))
+    b_tot = job.sum(run.b_alg_loc)
+    ms = el / steps * 1e3
+    rec.update({"n_gpus": world, "steps": steps, "ms_per_step": round(ms, 5),
+                "gflops": round(2.0 * nnz_tot / (ms * 1e-3) / 1e9, 2), "nnz": nnz_tot,
+                "hbm_frac_of_peak_whole_job": round(b_tot / (ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), 4),
+                "verified_vs_closed_form": run.verified, "timed_out": bool(job.max(1.0 if run.plan.timed_out() else 0.0)),
+                "halo_mode": "push" if getattr(run.plan, "push", False) else os.environ.get("HPCLA_HALO_MODE", "serial")})
+    verified = run.verified
+    run.release()
+    hp.clear_plan_cache()
+    torch.cuda.empty_cache()
+    if world > 1:
+        n1 = None
+        if rank == 0:                                # the other ranks wait at the barrier below
+            b1 = hp.backend_rocm_serial(np.float64, np.int32 if args.index == "i32" else np.int64,
+                                        device_index=torch.cuda.current_device())
+            one = PoissonRun(hp, wl, job, b1, args, N, True, 1, 0)
+            el1, _ = one.time_steps(steps, warmup)
+            n1 = el1 / steps * 1e3
+            verified = verified and one.verified
+            one.release()
+            torch.cuda.empty_cache()
+        job.barrier()
+        n1 = job.max(n1 if n1 is not None else 0.0)
+        rec["n1_ms_per_step_rank0_alone"] = round(n1, 5)
+        rec["speedup_vs_n1"] = round(n1 / ms, 3)
+    return rec, verified
+
+
+def _run(args):
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
+    ndev = torch.cuda.device_count()
+    if world > ndev and os.environ.get("HPCLA_ALLOW_SHARED_GPU", "") != "1":
+        raise SystemExit(f"bench.py --gpus {world}: only {ndev} GPU(s) visible (HPCLA_ALLOW_SHARED_GPU=1 lets ranks "
+                         "share a device for a functional rehearsal; its timings mean nothing)")
+    torch.cuda.set_device(local_rank % ndev)
+
+    import hpcla_amd as hp
+    from hpcla_amd import workloads as wl
+
+    Ti = np.int32 if args.index == "i32" else np.int64
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # host-side collectives (plan construction, this script's barriers and maxima) run over gloo; the
+        # data path is the library's own: peer windows over xGMI and/or its RCCL communicator
+        dist.init_process_group("gloo")
+        backend = hp.backend_rocm_mpi(np.float64, Ti)
+    else:
+        backend = hp.backend_rocm_serial(np.float64, Ti, device_index=torch.cuda.current_device())
+    job = Job(torch, dist, world, rank)
+
+    if args.workload not in ("poisson2d", "poisson2d_strong"):
+        from benchmarks import extra_workloads          # configs 4/5: separate harness
+        return extra_workloads.run(args, backend, rank, world, job)     # its JSON line (rank 0) or None
+
+    # ---- headline: weak scaling, one 4096^2 slab per GPU (N = 1: BASELINE configs[1]) ------------------
+    strong = args.workload == "poisson2d_strong"      # whole line on the fixed 8192^2 grid instead
+    N = args.size or (args.strong_size if strong else 4096)
+    run = PoissonRun(hp, wl, job, backend, args, N, strong, world, rank)
+    A, x, y, plan = run.A, run.x, run.y, run.plan
+    verified = run.verified
+    nnz_loc, nrows_loc, b_alg_loc = run.nnz_loc, run.nrows_loc, run.b_alg_loc
+    elapsed, timed_region_launch_ms = run.time_steps(args.steps, args.warmup)
+
+    # ---- per-launch duration with HIP events on the launch stream (cross-check of roofline.achieved) ----
     reps = min(max(args.steps, 20), 200)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-    barrier()
+    job.barrier()
     for a, b in evs:
         a.record()
         hp.mul_(y, A, x)
@@ -349,49 +482,32 @@ def _run():
     torch.cuda.synchronize()
     per_launch_ms = np.array([a.elapsed_time(b) for a, b in evs])
     launch_ms = float(np.mean(per_launch_ms))
-    # back-to-back launches between ONE event pair (no per-launch event overhead)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
-    for _ in range(reps):
+    for _ in range(reps):                # back-to-back launches between ONE event pair
         hp.mul_(y, A, x)
     b.record()
     torch.cuda.synchronize()
     stream_ms = a.elapsed_time(b) / reps
+    timed_out = bool(job.max(1.0 if plan.timed_out() else 0.0))
 
-    # ---- N > 1: where a distributed step spends its time (device time per call, HIP events; every rank makes
-    #      the same calls in the same order, and the only communication is the step's own halo exchange) ----
+    # ---- N > 1: every ordering of the distributed step + its pieces (max over ranks) -----------------
     breakdown = None
     selftest = os.environ.get("HPCLA_BENCH_BREAKDOWN_SELFTEST", "") == "1"      # runs the local legs at N = 1
-    if ((world > 1 and plan.has_halo) or selftest) and not plan.is_i64:
+    if (world > 1 and bool(job.max(1.0 if plan.has_halo else 0.0))) or selftest:
         try:
-            breakdown = step_breakdown(hp, torch, dist, world, plan, A, x, y, barrier)
+            breakdown = step_breakdown(hp, job, backend, plan, A, x, y)
         except Exception as exc:        # identical code and call order on every rank: all ranks land here together
             breakdown = {"error": f"{type(exc).__name__}: {exc}"}
 
     # ---- opt-in packed copy (3 B per stored entry instead of 12; same bits), reported separately --------
     packed = None
     if not args.no_packed and world == 1:        # an optional extra must not stand between an N > 1 run and its result line
-        ok = A.enable_packed(x)
-        if world > 1:
-            f = torch.tensor([1 if ok else 0], device="cuda")
-            dist.all_reduce(f, op=dist.ReduceOp.MIN)
-            ok = bool(f.item())
-        if ok:
+        if A.enable_packed(x):
             hp.mul_(y, A, x)
             torch.cuda.synchronize()
-            same = bool(np.array_equal(y.v[torch.from_numpy(samp).cuda()].cpu().numpy(), want))
-            for _ in range(args.warmup):
-                hp.mul_(y, A, x)
-            barrier()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                hp.mul_(y, A, x)
-            barrier()
-            el = time.perf_counter() - t1
-            if world > 1:
-                t = torch.tensor([el], dtype=torch.float64, device="cuda")
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                el = float(t.item())
+            same = bool(np.array_equal(y.v[torch.from_numpy(run.samp).cuda()].cpu().numpy(), run.want))
+            el, _ = run.time_steps(args.steps, args.warmup)
             pk_bytes = 3 * nnz_loc + 4 * (nrows_loc + 1) + 8 * nrows_loc + 8 * A.ncols_compressed
             packed = {"ms_per_step": round(el / args.steps * 1e3, 5),
                       "speedup_vs_csr": round((elapsed / args.steps) / (el / args.steps), 3),
@@ -403,27 +519,29 @@ def _run():
                               "NOT the CSR headline: fewer bytes are moved, results bit-identical"}
         A.disable_packed()
 
-    nnz_tot = nnz_loc * world            # slabs differ by <= 2*nx nonzeros; rank 0 reports its own * N
-    if world > 1:
-        t = torch.tensor([float(nnz_loc), float(b_alg_loc)], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t)
-        nnz_tot, b_alg_tot = int(t[0].item()), int(t[1].item())
-    else:
-        b_alg_tot = b_alg_loc
+    nnz_tot = int(job.sum(nnz_loc))
+    b_alg_tot = job.sum(b_alg_loc)
     ms_per_step = elapsed / args.steps * 1e3
     gflops = 2.0 * nnz_tot / (elapsed / args.steps) / 1e9
     # roofline.achieved: algorithmic bytes of one launch / average launch duration over the TIMED region
-    # (device time between the two events / K; the per-launch event pairs below it are a cross-check)
+    # (device time between the two events / K; the per-launch event pairs are a cross-check)
     achieved = b_alg_loc / (timed_region_launch_ms * 1e-3) / 1e9
 
-    traffic = None
+    traffic = traffic_source = None
     tj = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if os.path.exists(tj) and args.index == "i32" and N == 4096 and not strong:     # measured for that launch only
+    if os.path.exists(tj) and args.index == "i32" and N == 4096 and not strong and world == 1:
         try:
-            traffic = json.load(open(tj)).get("hbm_bytes_per_launch")
+            rec = json.load(open(tj))
+            traffic = rec.get("hbm_bytes_per_launch")
+            traffic_source = ("NOT measured by this run: PMC counters cannot be read from inside the process; value "
+                              "stored by the builder's rocprofv3 passes of this same command -- " + rec.get("source", tj))
         except Exception:
-            traffic = None
+            traffic = traffic_source = None
 
+    kernel = "hpcla::spmv_rowblock_quad_kernel<%s, %s, %s>" % (
+        "int" if args.index == "i32" else "long", "true" if plan.has_halo else "false",
+        "true" if getattr(plan, "push", False) else "false")
+    nx, ny, ny_loc, n_glob = run.nx, run.ny, run.ny_loc, run.n_glob
     result = {
         "metric": "SpMV GFLOP/s (2*nnz/t), 2-D 5-pt Poisson, fp64",
         "value": round(gflops, 2), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps,
@@ -432,35 +550,51 @@ def _run():
         "config": {"workload": f"poisson2d 5-pt, {nx}x{ny_loc} slab per GPU ({nx}x{ny} global), "
                                f"n={n_glob}, nnz={nnz_tot}, index={args.index}, CSR SpMV y=A*x",
                    "global_rows": n_glob, "nnz": nnz_tot, "index_type": args.index,
-                   "parallelism": f"row-slab x{world}, RCCL halo" if world > 1 else "single GPU"},
+                   "parallelism": (f"row-slab x{world}, halo: " + ("peer-window push over xGMI" if getattr(plan, "push", False)
+                                                                   else "RCCL send/recv")) if world > 1 else "single GPU"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "kernel": "hpcla::spmv_rowblock_quad_kernel", "algorithmic_bytes_per_launch": b_alg_loc,
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                     "kernel": kernel, "algorithmic_bytes_per_launch": b_alg_loc,
                      "launch_ms_timed_region": round(timed_region_launch_ms, 5),
                      "launch_ms_event_pairs": round(launch_ms, 5), "launch_ms_back_to_back": round(stream_ms, 5),
                      "launch_ms_min": round(float(per_launch_ms.min()), 5),
                      "launch_ms_median": round(float(np.median(per_launch_ms)), 5)},
         "hbm_gbs_whole_job": round(b_alg_tot / (elapsed / args.steps) / 1e9, 1),
         "hbm_frac_of_peak_whole_job": round(b_alg_tot / (elapsed / args.steps) / 1e9 / (HBM_PEAK_GBS * world), 4),
-        "verified_vs_closed_form": verified, "setup_s": round(setup_s, 2),
+        "verified_vs_closed_form": verified, "exchange_timed_out": timed_out, "setup_s": round(run.setup_s, 2),
         "packed_csr_opt_in": packed,
     }
     if breakdown is not None:
         result["step_breakdown_ms_max_over_ranks"] = breakdown
     if rank == 0 and not args.no_cpu_baseline:
+        lo, hi = run.lo, run.hi
         xg = x.local_values()
-        ghost = np.zeros(0)
         if plan.has_halo:
             ghost_idx = A.col_indices[A.col_indices >= hi]
             ghost_lo = A.col_indices[A.col_indices < lo]
             xfull = np.concatenate([wl.u01(wl.SEED_X, ghost_lo), xg, wl.u01(wl.SEED_X, ghost_idx)])
         else:
             xfull = xg
-        if vals is None:
-            vals = A.nzval.cpu().numpy()
+        vals = run.vals if run.vals is not None else A.nzval.cpu().numpy()
         result["cpu_baseline"] = cpu_baseline_spmv(A.rowptr, A.colval, vals, xfull, args.cpu_seconds)
-    if world > 1:
-        _device_barrier(torch, dist)
+        del vals, xfull
+
+    # ---- BASELINE configs[2], the strong-scaling problem, as a sub-record of the same line ----------------
+    if not strong and not args.no_strong:
+        run.release()
+        del A, x, y, plan
+        hp.clear_plan_cache()
+        torch.cuda.empty_cache()
+        job.barrier()
+        try:
+            rec, ok = strong_scaling_record(hp, wl, job, backend, args, world, rank)
+            verified = verified and ok and not rec.get("timed_out", False)
+        except Exception as exc:                     # same code on every rank: all ranks land here together
+            rec = {"error": f"{type(exc).__name__}: {exc}"}
+        result["strong_scaling"] = rec
+    verified = verified and not timed_out
+    result["verified_vs_closed_form"] = verified
+    job.barrier()
     if not verified:
         sys.stderr.write("bench: result verification FAILED\n")
     return (json.dumps(result) if rank == 0 else None), verified

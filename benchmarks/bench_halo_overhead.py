@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Overhead of the distributed step on ONE GPU: a 4096 x 4096 Poisson slab whose upper and lower
-ghost lines are exchanged with ITSELF through a one-rank RCCL communicator (HPCLA_FORCE_RCCL=1), i.e.
-the exact launch sequence of an interior rank in bench.py --gpus N (event, side stream, ncclGroup of
-2 sends + 2 recvs of 32 KiB, interior kernel, event wait, boundary kernel) versus the plain kernel."""
+ghost lines (2 x 32 KiB) are exchanged with ITSELF through a one-rank communicator (HPCLA_FORCE_RCCL=1),
+i.e. the launch sequence of an interior rank in bench.py --gpus N, in every ordering of the step
+(hpcla_set_halo_mode): push (peer-window push kernel + ONE fused launch whose boundary workgroups wait
+in-kernel), serial (RCCL group, then one launch) and overlap (RCCL group + boundary blocks on a side
+stream), each against the plain kernel."""
 import ctypes
 import os
 import sys
@@ -38,14 +40,18 @@ def main():
     capi.call("hpcla_classify_blocks_i32", d_rp.data_ptr(), d_cv.data_ptr(), nloc, 0, nloc, rpb, flags.data_ptr(), s)
     interior = torch.nonzero(flags == 0).flatten().to(torch.int32)
     boundary = torch.nonzero(flags != 0).flatten().to(torch.int32)
-    # "neighbours": rank 0 twice (lower ghost = my last line, upper ghost = my first line)
+    # one "neighbour", rank 0 itself: lower ghost = my last line, upper ghost = my first line (a rank appears
+    # once per list in a real plan; the two lines travel as one 64 KiB message here)
     send_idx = torch.cat([torch.arange(nloc - nx, nloc), torch.arange(0, nx)]).to(torch.int32).cuda()
     plan = ctypes.c_void_p()
-    ranks = (ctypes.c_int32 * 2)(0, 0)
-    counts = (ctypes.c_int64 * 2)(nx, nx)
+    ranks = (ctypes.c_int32 * 1)(0)
+    counts = (ctypes.c_int64 * 1)(2 * nx)
     torch.cuda.synchronize()
-    capi.check("create", lib.hpcla_halo_plan_create(ctypes.byref(plan), backend.rccl, 2, ranks, counts,
-                                                   send_idx.data_ptr(), 0, 2, ranks, counts, 1))
+    capi.check("create", lib.hpcla_halo_plan_create(ctypes.byref(plan), backend.rccl, 1, ranks, counts,
+                                                   send_idx.data_ptr(), 0, 1, ranks, counts, 1))
+    from hpcla_amd.backends import attach_halo_windows
+    pushable = attach_halo_windows(backend, plan)
+    modes = (["push"] if pushable else []) + ["serial", "overlap"]
 
     def dist():
         capi.call("hpcla_spmv_dist_f64_i32", plan, d_rp.data_ptr(), d_cv.data_ptr(), d_nz.data_ptr(), x.data_ptr(),
@@ -75,9 +81,8 @@ def main():
         boundary_only()
 
     import time
-    for name, fn in (("plain split kernel", plain), ("halo + interior + boundary", dist), ("halo exchange only", halo_only),
-                     ("interior blocks only (list)", interior_only), ("boundary blocks only", boundary_only),
-                     ("interior + boundary, no halo", interior_then_boundary)):
+
+    def measure(name, fn):
         for _ in range(20):
             fn()
         torch.cuda.synchronize()
@@ -93,23 +98,26 @@ def main():
             fn()
         host = (time.perf_counter() - t0) / 200 * 1e3
         torch.cuda.synchronize()
-        print(f"{name:30s} {np.median(res):8.4f} ms/step (min {np.min(res):.4f})   host enqueue {host:.4f} ms/step")
-    print(f"interior blocks {interior.numel()}, boundary blocks {boundary.numel()}")
-    # bench.py's N > 1 diagnostic (step_breakdown) on the same self-exchanging slab: stand-ins for the
-    # host-layer objects it reads
-    import json
-    from types import SimpleNamespace as NS
-    import bench
-    fplan = NS(has_halo=True, halo=plan, colval_split=d_cv, n_own=nloc, interior=interior, boundary=boundary,
-               n_interior=int(interior.numel()), n_boundary=int(boundary.numel()), is_i64=False)
-    fA = NS(rowptr_target=d_rp, nzval=d_nz, nrows_local=nloc, nnz=len(vals))
-    fx, fy = NS(v=x), NS(v=y)
-    real_mul = hp.mul_
-    hp.mul_ = lambda yy, AA, xx: dist()              # the fused step of this harness
-    try:
-        print("step_breakdown:", json.dumps(bench.step_breakdown(hp, torch, None, 1, fplan, fA, fx, fy, torch.cuda.synchronize)))
-    finally:
-        hp.mul_ = real_mul
+        print(f"{name:44s} {np.median(res):8.4f} ms/step (min {np.min(res):.4f})   host enqueue {host:.4f} ms/step", flush=True)
+        return float(np.median(res))
+
+    base = measure("plain split kernel", plain)
+    measure("interior blocks only (list)", interior_only)
+    measure("boundary blocks only", boundary_only)
+    measure("interior + boundary, no halo", interior_then_boundary)
+    MODE = {"serial": 0, "overlap": 1, "push": 2}
+    for rnd in range(2):                                   # two interleaved rounds: box drift shows up as disagreement
+        for m in modes:
+            capi.call("hpcla_set_halo_mode", MODE[m])
+            t = measure(f"[{m}] halo + interior + boundary", dist)
+            measure(f"[{m}] halo exchange only", halo_only)
+            print(f"    -> [{m}] overhead vs plain kernel: {1e3 * (t - base):+.1f} us", flush=True)
+        base = measure("plain split kernel (again)", plain)
+    capi.call("hpcla_set_halo_mode", -1)
+    st = ctypes.c_int(0)
+    capi.call("hpcla_halo_status", plan, ctypes.byref(st))
+    print(f"interior blocks {interior.numel()}, boundary blocks {boundary.numel()}, timed_out={st.value}")
+    torch.cuda.synchronize()
     capi.call("hpcla_halo_plan_destroy", plan)
 
 

@@ -16,34 +16,22 @@ import numpy as np
 HBM_PEAK_GBS = 8000.0
 
 
-def _device_barrier(torch, dist):
-    t = torch.zeros(1, device="cuda")
-    dist.all_reduce(t)
-    torch.cuda.synchronize()
+def _sync_barrier(job):
+    job.barrier()
 
 
-def _sync_barrier(torch, dist, world):
-    torch.cuda.synchronize()
-    if world > 1:
-        _device_barrier(torch, dist)
-    torch.cuda.synchronize()
-
-
-def _measure_spmm(args, torch, dist, hp, wl, A, B, k, world, dev, setup_s, metric, workload):
+def _measure_spmm(args, job, hp, wl, A, B, k, world, dev, setup_s, metric, workload):
     C = A @ B
     for _ in range(args.warmup):
         C = A @ B
-    _sync_barrier(torch, dist, world)
+    _sync_barrier(job)
     steps = min(args.steps, 50)
     t0 = time.perf_counter()
     for _ in range(steps):
         C = A @ B
-    _sync_barrier(torch, dist, world)
+    _sync_barrier(job)
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = job.max(elapsed)
     ms = elapsed / steps * 1e3
     b_alg = wl.spmm_algorithmic_bytes(A.nnz, A.nrows_local, A.ncols_compressed, k, 4)
     b_gather = A.nnz * (12 + 8 * k) + 4 * A.nrows_local + 8 * k * A.nrows_local    # every B row read per entry
@@ -65,9 +53,8 @@ def _measure_spmm(args, torch, dist, hp, wl, A, B, k, world, dev, setup_s, metri
     return out
 
 
-def run(args, backend, rank, world):
+def run(args, backend, rank, world, job):
     import torch
-    import torch.distributed as dist
     import hpcla_amd as hp
     from hpcla_amd import workloads as wl
     dev = backend.torch_device
@@ -90,15 +77,12 @@ def run(args, backend, rank, world):
         fused = os.environ.get("HPCLA_CG_UNFUSED", "") != "1"
         graph = os.environ.get("HPCLA_CG_GRAPH", "") == "1"     # replay a captured pair of iterations
         hp.cg_fixed_iterations(A, b, max(args.warmup // 4, 2), record_history=False, fused=fused)   # warm-up
-        _sync_barrier(torch, dist, world)
+        _sync_barrier(job)
         t0 = time.perf_counter()
         x, hist = hp.cg_fixed_iterations(A, b, iters, record_history=True, fused=fused, graph=graph)
-        _sync_barrier(torch, dist, world)
+        _sync_barrier(job)
         elapsed = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+        elapsed = job.max(elapsed)
         n_loc, nnz_loc = A.nrows_local, A.nnz
         b_spmv = wl.spmv_algorithmic_bytes(nnz_loc, n_loc, A.ncols_compressed, 4)
         b_iter = b_spmv + 96 * n_loc        # textbook unfused CG = SpMV + 96 n bytes
@@ -135,7 +119,7 @@ def run(args, backend, rank, world):
                       torch.cuda.current_stream().cuda_stream)
         B = hp.HPCMatrix_local(Bl, backend)
         setup_s = time.perf_counter() - t0
-        out = _measure_spmm(args, torch, dist, hp, wl, A, B, k, world, dev, setup_s,
+        out = _measure_spmm(args, job, hp, wl, A, B, k, world, dev, setup_s,
                             "SpMM GFLOP/s (2*k*nnz/t), 2-D 5-pt Poisson, k=16, fp64",
                             f"poisson2d 5-pt {nx}x{ny_loc} slab per GPU, nnz/GPU={A.nnz}, k={k}, C = A*B")
     elif args.workload == "sprand_spmm":
@@ -168,12 +152,12 @@ def run(args, backend, rank, world):
             yv = A @ xv
             for _ in range(args.warmup):
                 hp.mul_(yv, A, xv)
-            _sync_barrier(torch, dist, world)
+            _sync_barrier(job)
             steps = min(args.steps, 50)
             t0 = time.perf_counter()
             for _ in range(steps):
                 hp.mul_(yv, A, xv)
-            _sync_barrier(torch, dist, world)
+            _sync_barrier(job)
             ms = (time.perf_counter() - t0) / steps * 1e3
             b_alg = wl.spmv_algorithmic_bytes(A.nnz, A.nrows_local, A.ncols_compressed, 4)
             b_sect = A.nnz * (12 + 64) + 12 * A.nrows_local
@@ -191,10 +175,9 @@ def run(args, backend, rank, world):
                       torch.cuda.current_stream().cuda_stream)
         B = hp.HPCMatrix_local(Bl, backend)
         setup_s = time.perf_counter() - t0
-        out = _measure_spmm(args, torch, dist, hp, wl, A, B, k, world, dev, setup_s,
+        out = _measure_spmm(args, job, hp, wl, A, B, k, world, dev, setup_s,
                             "SpMM GFLOP/s (2*k*nnz/t), sprand ~29.8 nnz/row, k=16, fp64",
                             f"sprand-like {rows_loc} rows per GPU x {ncols} cols, nnz/GPU={A.nnz}, k={k}, C = A*B")
-    if world > 1:
-        _device_barrier(torch, dist)
+    job.barrier()
     hp.clear_spmm_cache()
     return json.dumps(out) if rank == 0 else None          # bench.py prints it, then tears down

@@ -178,6 +178,11 @@ int hpcla_spmm_split_f64_i32(const int32_t *rowptr, const int32_t *colval_split,
                              const double *B_ghost, int64_t ldb_ghost, int64_t n_own, double *C,
                              int64_t ldc, int64_t nrows, int64_t nnz, int k, int index_base,
                              const int32_t *block_list, int64_t n_blocks, void *stream);
+int hpcla_spmm_split_f64_i64(const int64_t *rowptr, const int64_t *colval_split,
+                             const double *nzval, const double *B_own, int64_t ldb_own,
+                             const double *B_ghost, int64_t ldb_ghost, int64_t n_own, double *C,
+                             int64_t ldc, int64_t nrows, int64_t nnz, int k, int index_base,
+                             const int32_t *block_list, int64_t n_blocks, void *stream);
 /* layout conversion for column-major callers (Julia Matrix): dst(row-major, ld=k) <- src */
 int hpcla_transpose_f64(const double *src, int64_t ld_src, int src_layout, double *dst,
                         int64_t ld_dst, int dst_layout, int64_t rows, int64_t cols, void *stream);
@@ -218,12 +223,39 @@ int hpcla_gather_f64_i64(const double *x, const int64_t *src, const int64_t *dst
 #define HPCLA_UNIQUE_ID_BYTES 128
 int hpcla_comm_get_unique_id(uint8_t *id_host /* 128 bytes */);
 int hpcla_comm_init_rank(hpcla_comm_t **comm, const uint8_t *id_host, int nranks, int rank);
+/* flags: HPCLA_COMM_NO_RCCL = no RCCL communicator is created (id_host may be NULL); every data-path
+ * collective of this communicator then goes through the peer windows below.  Needed where RCCL cannot
+ * start -- it refuses two ranks on one GPU ("Duplicate GPU detected"), which is how the multi-rank GPU
+ * tests run on a single-GPU box. */
+#define HPCLA_COMM_NO_RCCL 1
+int hpcla_comm_init_rank_ex(hpcla_comm_t **comm, const uint8_t *id_host, int nranks, int rank, int flags);
 int hpcla_comm_rank(const hpcla_comm_t *comm, int *rank);
 int hpcla_comm_size(const hpcla_comm_t *comm, int *nranks);
 int hpcla_comm_destroy(hpcla_comm_t *comm);
 /* in-place all-reduce of `count` doubles on `stream`: op 0 = sum, 1 = max
  * (comm_allreduce(comm, x, + | max), src/backends.jl:264-277). */
 int hpcla_allreduce_f64(hpcla_comm_t *comm, double *buf, int64_t count, int op, void *stream);
+
+/* ---- peer windows: one-sided transport over xGMI for the ranks of ONE node (csrc/window.hip) --------
+ * Replaces, on the hot path, the MPI Isend/Irecv of execute_plan! (src/vectors.jl:431-455) and the scalar
+ * comm_allreduce (src/backends.jl:264-277) -- and the RCCL group/all-reduce this library uses otherwise.
+ * A window is a fine-grained device allocation that the other ranks map (hipIpcOpenMemHandle) and store
+ * into directly; flags/acks in its control lines order producer and consumer, all spins are bounded.
+ * Bootstrap is the unique-id pattern again (ext/HPCLinearAlgebraCUDAExt.jl:411-443): every rank EXPORTS a
+ * HPCLA_WINDOW_DESC_BYTES descriptor, the host runtime all-gathers them (MPI.Allgather /
+ * torch.distributed), every rank ATTACHES.  All ranks must be on one node (descriptor bytes 64..71 hold a
+ * node identity the host layer compares before attaching).
+ *   communicator window: all-reduce of <= 8 doubles in ONE kernel (each rank stores its partial into its
+ *     slot of every window, then sums its own window's slots in rank order: the same bits on every rank);
+ *   halo plan window:    see hpcla_halo_plan_export below. */
+#define HPCLA_WINDOW_DESC_BYTES 128
+int hpcla_comm_window_export(hpcla_comm_t *comm, uint8_t *desc_host /* 128 bytes out */);
+int hpcla_comm_window_attach(hpcla_comm_t *comm, const uint8_t *all_descs_host /* nranks x 128 bytes */);
+/* 1 in *timed_out if a window all-reduce gave up waiting for a peer (HPCLA_PUSH_TIMEOUT_S, default 20 s);
+ * synchronises a 4-byte device read. */
+int hpcla_comm_status(hpcla_comm_t *comm, int *timed_out);
+/* 64-bit identity of (node, physical device): two ranks with equal identities share one GPU. */
+int hpcla_device_identity(int device, uint64_t *id);
 
 /* Contiguous-range exchange: device form of execute_plan!(::VectorRepartitionPlan)
  * (src/vectors.jl:624-671; plan lists :511-620), of the dense row repartition (src/dense.jl:1711-1760)
@@ -256,6 +288,19 @@ int hpcla_halo_plan_create(hpcla_halo_plan_t **plan, hpcla_comm_t *comm, int n_s
                            const int32_t *recv_ranks_host, const int64_t *recv_counts_host,
                            int width);
 int hpcla_halo_plan_destroy(hpcla_halo_plan_t *plan);
+/* Push transport for this plan.  When the communicator's window is attached, create() places the ghost
+ * segment (double-buffered up to 64 MiB) inside a peer-mappable window.  export: this rank's descriptor
+ * plus a table of HPCLA_WINDOW_TABLE_ROWS x nranks int64 (row 0: flag line of source rank r, row 1: offset
+ * of r's segment in my ghost, row 2: ack line of consumer rank r, row 3: entries expected from r; -1 =
+ * none).  The host runtime all-gathers descriptors and tables; attach maps the neighbours' windows and
+ * builds the push lists.  Collective: ranks without neighbours pass a zeroed descriptor / -1 table.
+ * After attach, HPCLA_HALO_MODE unset or "push" selects the push transport for this plan. */
+#define HPCLA_WINDOW_TABLE_ROWS 4
+int hpcla_halo_plan_export(hpcla_halo_plan_t *plan, uint8_t *desc_host, int64_t *table_host);
+int hpcla_halo_plan_attach(hpcla_halo_plan_t *plan, const uint8_t *all_descs_host,
+                           const int64_t *all_tables_host);
+/* 1 in *timed_out if a push or wait of this plan gave up (result invalid); synchronising 4-byte read. */
+int hpcla_halo_status(hpcla_halo_plan_t *plan, int *timed_out);
 /* device pointer of the ghost buffer (n_ghost*width doubles) and its length in indices */
 int hpcla_halo_ghost_ptr(hpcla_halo_plan_t *plan, double **ghost, int64_t *n_ghost);
 /* begin: after everything already enqueued on `stream`, pack x[send_idx] and post the
@@ -266,14 +311,22 @@ int hpcla_halo_begin(hpcla_halo_plan_t *plan, const double *x, void *stream);
 int hpcla_halo_end(hpcla_halo_plan_t *plan, void *stream);
 
 /* Fused distributed SpMV  y = A*x  (Base.:*(A,x), src/sparse.jl:2096-2128; mul!, :2019-2037).
- * Two orderings, chosen by the environment variable HPCLA_HALO_MODE when the library is first used:
- *   "serial" (default)  the send/recv group on `stream`, then ONE launch over all row blocks;
+ * Three orderings, chosen by the environment variable HPCLA_HALO_MODE when the library is first used:
+ *   "push"   (default when the plan's peer windows are attached) a push kernel stores the boundary
+ *                       values into the neighbours' ghost windows, then ONE launch = interior blocks
+ *                       followed by the boundary blocks, which wait in-kernel for the neighbours' flags;
+ *                       interior_blocks + boundary_blocks must cover every row block;
+ *   "serial" (default otherwise) the RCCL send/recv group on `stream`, then ONE launch over all row blocks;
  *   "overlap"           exchange + boundary blocks on the plan's side stream, interior blocks on
  *                       `stream`, joined by events (block lists from hpcla_classify_blocks_*).
  * On MI355X the SpMV kernel fills every wave slot of every CU, so a side-stream RCCL kernel only runs
  * once the interior grid drains; measured "overlap" = +29..32 us, "serial" = +13..14 us per 4096^2 step
  * (profiles/r01_halo_mode_experiments.log).  Both give the same bits.  With plan==NULL or no
  * neighbours it is a plain split SpMV. */
+/* Run-time override of HPCLA_HALO_MODE for plans used from now on: -1 automatic (push where attached,
+ * else serial), 0 serial, 1 overlap, 2 push.  Must be called with the same value on every rank, between
+ * steps (used by bench.py to time every ordering in one run). */
+int hpcla_set_halo_mode(int mode);
 int hpcla_spmv_dist_f64_i32(hpcla_halo_plan_t *plan, const int32_t *rowptr,
                             const int32_t *colval_split, const double *nzval, const double *x,
                             int64_t n_own, double *y, int64_t nrows, int64_t nnz, int index_base,

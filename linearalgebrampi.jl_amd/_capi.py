@@ -17,6 +17,9 @@ OK = 0
 LAYOUT_ROW = 0
 LAYOUT_COL = 1
 UNIQUE_ID_BYTES = 128
+WINDOW_DESC_BYTES = 128
+WINDOW_TABLE_ROWS = 4
+COMM_NO_RCCL = 1
 
 
 class HPCLAError(RuntimeError):
@@ -53,11 +56,21 @@ _SIGNATURES = {
     "hpcla_spmm_csr_f64_i32": [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _i64, _i32, _i64, _i64, _i32, _i32, _vp],
     "hpcla_spmm_csr_f64_i64": [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _i64, _i32, _i64, _i64, _i32, _i32, _vp],
     "hpcla_spmm_split_f64_i32": [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _i64, _vp],
+    "hpcla_spmm_split_f64_i64": [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _i64, _vp],
     "hpcla_transpose_f64": [_vp, _i64, _i32, _vp, _i64, _i32, _i64, _i64, _vp],
     "hpcla_gather_f64_i32": [_vp, _vp, _vp, _vp, _i64, _i32, _vp],
     "hpcla_gather_f64_i64": [_vp, _vp, _vp, _vp, _i64, _i32, _vp],
     "hpcla_comm_get_unique_id": [_vp],
     "hpcla_comm_init_rank": [_vp, _vp, _i32, _i32],
+    "hpcla_comm_init_rank_ex": [_vp, _vp, _i32, _i32, _i32],
+    "hpcla_comm_window_export": [_vp, _vp],
+    "hpcla_comm_window_attach": [_vp, _vp],
+    "hpcla_comm_status": [_vp, _vp],
+    "hpcla_device_identity": [_i32, _vp],
+    "hpcla_halo_plan_export": [_vp, _vp, _vp],
+    "hpcla_halo_plan_attach": [_vp, _vp, _vp],
+    "hpcla_halo_status": [_vp, _vp],
+    "hpcla_set_halo_mode": [_i32],
     "hpcla_comm_rank": [_vp, _vp],
     "hpcla_comm_size": [_vp, _vp],
     "hpcla_comm_destroy": [_vp],

@@ -255,7 +255,7 @@ class HPCBackend:
     ext/HPCLinearAlgebraCUDAExt.jl:384-386)."""
 
     def __init__(self, T, Ti, device: AbstractDevice, comm: AbstractComm, solver: AbstractSolver,
-                 rccl=None):
+                 rccl=None, peer_windows: bool = False, has_rccl: bool = False):
         self.T = np.dtype(T)
         self.Ti = np.dtype(Ti)
         if self.T != np.dtype(np.float64):
@@ -266,6 +266,8 @@ class HPCBackend:
         self.comm = comm
         self.solver = solver
         self.rccl = rccl           # ctypes.c_void_p handle of hpcla_comm_t
+        self.peer_windows = bool(peer_windows)   # communicator window attached (same on every rank)
+        self.has_rccl = bool(has_rccl)           # an RCCL communicator exists (not when ranks share a GPU)
 
     def __repr__(self):
         return (f"HPCBackend{{{self.T},{self.Ti},{type(self.device).__name__},"
@@ -313,12 +315,40 @@ def _require_gpu(index: int) -> None:
     _capi.call("hpcla_set_device", index)
 
 
-def _make_rccl(comm: AbstractComm):
+def _windows_enabled() -> bool:
+    """Peer windows (the xGMI push transport, csrc/window.hip) are attached whenever all ranks share a
+    node; HPCLA_WINDOWS=0 keeps a pure-RCCL data path."""
+    return os.environ.get("HPCLA_WINDOWS", "1") != "0"
+
+
+def allgather_window_descs(comm: AbstractComm, desc: bytes):
+    """All-gather of the 128-byte window descriptors -> (list of descriptors, all on one node?).
+    Bytes 64..71 of a descriptor carry the exporting rank's node identity."""
+    descs = comm_allgather_bytes(comm, desc)
+    hosts = {d[64:72] for d in descs}
+    return descs, len(hosts) == 1
+
+
+def _make_rccl(comm: AbstractComm, device_index: int = 0):
+    """The library communicator of this backend: RCCL over xGMI bootstrapped like the reference's NCCL
+    communicator (ext/HPCLinearAlgebraCUDAExt.jl:411-443: rank 0 makes the unique id, the host runtime
+    broadcasts it), plus -- when all ranks share a node -- the communicator's peer window (scalar
+    all-reduce by direct stores, and the precondition for push-mode halo plans).  RCCL refuses two ranks
+    on one physical GPU; ranks that share a device (multi-rank tests on a one-GPU box) therefore get a
+    window-only communicator."""
     from . import _capi
     lib = _capi.load()
     nranks, rank = comm_size(comm), comm_rank(comm)
     handle = ctypes.c_void_p()
-    need_id = nranks > 1 or os.environ.get("HPCLA_FORCE_RCCL", "") == "1"
+    forced = os.environ.get("HPCLA_FORCE_RCCL", "") == "1"
+    flags = 0
+    if nranks > 1:
+        ident = ctypes.c_uint64(0)
+        _capi.call("hpcla_device_identity", int(device_index), ctypes.byref(ident))
+        ids = comm_allgather(comm, np.array([ident.value], dtype=np.uint64).view(np.int64))
+        if len(set(ids.tolist())) < nranks or os.environ.get("HPCLA_NO_RCCL", "") == "1":
+            flags |= _capi.COMM_NO_RCCL
+    need_id = (nranks > 1 or forced) and not (flags & _capi.COMM_NO_RCCL)
     uid = None
     if need_id:
         if rank == 0:
@@ -327,12 +357,47 @@ def _make_rccl(comm: AbstractComm):
             uid = bytes(buf)
         uid = comm_bcast_bytes(comm, uid, _capi.UNIQUE_ID_BYTES, root=0)
         idbuf = (ctypes.c_uint8 * _capi.UNIQUE_ID_BYTES).from_buffer_copy(uid)
-        _capi.check("hpcla_comm_init_rank",
-                    lib.hpcla_comm_init_rank(ctypes.byref(handle), idbuf, nranks, rank))
+        _capi.check("hpcla_comm_init_rank_ex",
+                    lib.hpcla_comm_init_rank_ex(ctypes.byref(handle), idbuf, nranks, rank, flags))
     else:
-        _capi.check("hpcla_comm_init_rank",
-                    lib.hpcla_comm_init_rank(ctypes.byref(handle), None, 1, 0))
-    return handle
+        _capi.check("hpcla_comm_init_rank_ex",
+                    lib.hpcla_comm_init_rank_ex(ctypes.byref(handle), None, nranks, rank, flags))
+    if (nranks > 1 or forced) and (_windows_enabled() or (flags & _capi.COMM_NO_RCCL)):
+        desc = (ctypes.c_uint8 * _capi.WINDOW_DESC_BYTES)()
+        _capi.call("hpcla_comm_window_export", handle, desc)
+        descs, one_node = allgather_window_descs(comm, bytes(desc))
+        if one_node:
+            blob = (ctypes.c_uint8 * (_capi.WINDOW_DESC_BYTES * nranks)).from_buffer_copy(b"".join(descs))
+            _capi.call("hpcla_comm_window_attach", handle, blob)
+            return handle, True, need_id
+        if flags & _capi.COMM_NO_RCCL:
+            raise RuntimeError("ranks span several nodes and RCCL is disabled: no data-path transport left")
+    return handle, False, need_id
+
+
+def attach_halo_windows(backend: "HPCBackend", halo) -> bool:
+    """Plan-time, COLLECTIVE over the backend's communicator (every rank calls it, with ``halo=None`` when
+    it has no neighbours): all-gather the plans' window descriptors and slot tables and map the
+    neighbours' ghost windows, after which the plan exchanges by direct peer stores
+    (``hpcla_halo_plan_export`` / ``_attach``, csrc/window.hip).  No-op unless the communicator's own
+    window is attached (all ranks on one node).  Returns whether this rank's plan is attached."""
+    from . import _capi
+    if not backend.peer_windows:
+        return False
+    comm = backend.comm
+    n = comm_size(comm)
+    desc = (ctypes.c_uint8 * _capi.WINDOW_DESC_BYTES)()
+    table = (ctypes.c_int64 * (_capi.WINDOW_TABLE_ROWS * n))(*([-1] * (_capi.WINDOW_TABLE_ROWS * n)))
+    if halo:
+        _capi.call("hpcla_halo_plan_export", halo, desc, table)
+    descs = comm_allgather_bytes(comm, bytes(desc))
+    tables = comm_allgather(comm, np.frombuffer(bytes(table), dtype=np.int64))
+    if not halo or int.from_bytes(bytes(desc)[80:88], "little") == 0:      # this rank exported no window
+        return False
+    blob = (ctypes.c_uint8 * (_capi.WINDOW_DESC_BYTES * n)).from_buffer_copy(b"".join(descs))
+    tab = (ctypes.c_int64 * len(tables))(*tables.tolist())
+    _capi.call("hpcla_halo_plan_attach", halo, blob, tab)
+    return True
 
 
 def backend_rocm_serial(T=np.float64, Ti=np.int64, device_index: int = 0) -> HPCBackend:
@@ -341,7 +406,9 @@ def backend_rocm_serial(T=np.float64, Ti=np.int64, device_index: int = 0) -> HPC
     reference (`Ti=Int`); the headline benchmark uses Int32."""
     _require_gpu(device_index)
     comm = CommSerial()
-    return HPCBackend(T, Ti, DeviceROCm(device_index), comm, SolverNone(), rccl=_make_rccl(comm))
+    handle, windows, has_rccl = _make_rccl(comm, device_index)
+    return HPCBackend(T, Ti, DeviceROCm(device_index), comm, SolverNone(), rccl=handle, peer_windows=windows,
+                      has_rccl=has_rccl)
 
 
 def backend_rocm_mpi(T=np.float64, Ti=np.int64, group=None, device_index: Optional[int] = None) -> HPCBackend:
@@ -354,4 +421,6 @@ def backend_rocm_mpi(T=np.float64, Ti=np.int64, group=None, device_index: Option
         ndev = max(torch.cuda.device_count(), 1)
         device_index = local_rank % ndev
     _require_gpu(device_index)
-    return HPCBackend(T, Ti, DeviceROCm(device_index), comm, SolverNone(), rccl=_make_rccl(comm))
+    handle, windows, has_rccl = _make_rccl(comm, device_index)
+    return HPCBackend(T, Ti, DeviceROCm(device_index), comm, SolverNone(), rccl=handle, peer_windows=windows,
+                      has_rccl=has_rccl)

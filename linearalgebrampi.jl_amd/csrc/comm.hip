@@ -12,14 +12,18 @@
 //
 // librccl is loaded lazily with dlopen so the single-GPU path has no RCCL dependency; inside a
 // PyTorch process the already-loaded librccl.so.1 is reused (same SONAME).
+//
+// Second transport (window.hip): on one node the halo and the scalar all-reduce can bypass RCCL
+// altogether -- peers map each other's ghost windows and push into them directly over xGMI, and the
+// SpMV's own boundary workgroups wait for the data (HPCLA_HALO_MODE=push, the default once a plan's
+// windows are attached).  This file dispatches between the two.
 #include <dlfcn.h>
-#include <rccl/rccl.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include <vector>
 
-#include "common.h"
+#include "comm_internal.h"
 
 namespace hpcla {
 
@@ -29,23 +33,16 @@ int spmv_split_i32(const int32_t *, const int32_t *, const double *, const doubl
 int spmv_split_i64(const int64_t *, const int64_t *, const double *, const double *, const double *,
                    int64_t, double *, int64_t, int64_t, int, const int32_t *, int64_t, void *,
                    double *, int64_t);
+int spmv_fused_i32(const int32_t *, const int32_t *, const double *, const double *, const double *, int64_t,
+                   double *, int64_t, int64_t, int, const int32_t *, int64_t, int64_t, const int32_t *, int64_t,
+                   const HaloWait &, const PushArgs &, void *, double *);
+int spmv_fused_i64(const int64_t *, const int64_t *, const double *, const double *, const double *, int64_t,
+                   double *, int64_t, int64_t, int, const int32_t *, int64_t, int64_t, const int32_t *, int64_t,
+                   const HaloWait &, const PushArgs &, void *, double *);
 int reduce_partials_sum(const double *partial, int64_t np, double *scratch, double *out,
                         void *stream);   // vecops.hip
 
-// ---- RCCL entry points, resolved at first use ------------------------------------------------
-struct RcclApi {
-    void *handle = nullptr;
-    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
-    decltype(&ncclCommInitRank) CommInitRank = nullptr;
-    decltype(&ncclCommDestroy) CommDestroy = nullptr;
-    decltype(&ncclSend) Send = nullptr;
-    decltype(&ncclRecv) Recv = nullptr;
-    decltype(&ncclGroupStart) GroupStart = nullptr;
-    decltype(&ncclGroupEnd) GroupEnd = nullptr;
-    decltype(&ncclAllReduce) AllReduce = nullptr;
-    decltype(&ncclGetErrorString) GetErrorString = nullptr;
-};
-
+// ---- RCCL entry points, resolved at first use (RcclApi: comm_internal.h) ----------------------
 static RcclApi g_rccl;
 
 static int rccl_load()
@@ -85,33 +82,6 @@ static int rccl_load()
 
 }  // namespace hpcla
 
-struct hpcla_comm {
-    int nranks = 1;
-    int rank = 0;
-    ncclComm_t nccl = nullptr;   // null for the serial communicator
-};
-
-struct hpcla_halo_plan {
-    hpcla_comm *comm = nullptr;
-    int width = 1;
-    std::vector<int> send_ranks, recv_ranks;
-    std::vector<int64_t> send_counts, recv_counts, send_off, recv_off;
-    std::vector<int64_t> send_first;   // first index of neighbour i when its run is contiguous
-    std::vector<char> send_contig;
-    bool need_pack = false;
-    int64_t n_send_total = 0, n_ghost = 0;
-    void *send_idx = nullptr;   // device copy of the concatenated send indices
-    int idx_is_i64 = 0;
-    double *send_buf = nullptr; // device, n_send_total * width
-    double *ghost = nullptr;    // device, n_ghost * width
-    hipStream_t side = nullptr;
-    hipEvent_t ev_ready = nullptr, ev_done = nullptr;
-    // contiguity of the caller's (ascending) interior block list, probed once per list
-    const int32_t *probed_list = nullptr;
-    int64_t probed_n = -1, probed_first = -1;
-    bool probed_contig = false;
-};
-
 namespace hpcla {
 
 // pack: buf[(off+i)*w + c] = x[idx[off+i]*w + c]
@@ -135,8 +105,14 @@ int allreduce_on(hpcla_comm_t *comm, double *buf, int64_t count, int op, void *s
     if (!comm) return set_error(HPCLA_ERR_INVALID, "allreduce: null communicator");
     if (count < 0) return set_error(HPCLA_ERR_INVALID, "allreduce: negative count");
     if (op != 0 && op != 1) return set_error(HPCLA_ERR_INVALID, "allreduce: op must be 0 or 1");
-    if (comm->nranks == 1 || !comm->nccl || count == 0) return HPCLA_OK;
+    if (count == 0) return HPCLA_OK;
+    if (comm->nranks == 1 && !comm->nccl) return HPCLA_OK;
     if (!buf) return set_error(HPCLA_ERR_INVALID, "allreduce: null buffer");
+    // scalars (dot / norm / CG's rr): one-hop peer-window kernel, identical bits on every rank;
+    // long vectors (the dense transposed mat-vec): RCCL's ring, unless this communicator has none
+    if (comm->win_attached && (count <= AR_MAX || !comm->nccl)) return window_allreduce(comm, buf, count, op, stream);
+    if (!comm->nccl)
+        return set_error(HPCLA_ERR_INVALID, "allreduce: communicator has neither RCCL nor an attached window");
     HPCLA_CHECK_RCCL(g_rccl.AllReduce(buf, buf, (size_t)count, ncclDouble,
                                       op == 0 ? ncclSum : ncclMax, comm->nccl, as_stream(stream)));
     return HPCLA_OK;
@@ -147,19 +123,45 @@ bool halo_active(const hpcla_halo_plan_t *plan)
     return plan && !(plan->send_ranks.empty() && plan->recv_ranks.empty());
 }
 
-// HPCLA_HALO_MODE: "serial" (default) or "overlap" -- see spmv_dist_impl
-bool halo_serial_mode()
+// HPCLA_HALO_MODE: "push" | "serial" | "overlap"; unset = push where the plan's peer windows are
+// attached (one node), else serial -- see spmv_dist_impl
+static int g_halo_mode_override = -2;          // -2: not set -> environment
+static int halo_mode_env()
 {
-    static const bool serial = [] {
+    static const int m = [] {
         const char *e = getenv("HPCLA_HALO_MODE");
-        return !(e && e[0] == 'o');
+        if (!e || !e[0]) return -1;
+        if (e[0] == 'o') return (int)HALO_OVERLAP;
+        if (e[0] == 'p') return (int)HALO_PUSH;
+        return (int)HALO_SERIAL;
     }();
-    return serial;
+    return g_halo_mode_override != -2 ? g_halo_mode_override : m;
+}
+
+HaloMode halo_mode_of(const hpcla_halo_plan *plan)
+{
+    const int m = halo_mode_env();
+    if (plan && plan->attached && (m < 0 || m == (int)HALO_PUSH)) return HALO_PUSH;
+    if (plan && plan->comm && !plan->comm->nccl && plan->attached) return HALO_PUSH;   // no RCCL to fall back on
+    return m == (int)HALO_OVERLAP ? HALO_OVERLAP : HALO_SERIAL;
+}
+
+bool halo_want_window()
+{
+    const int m = halo_mode_env();
+    return m < 0 || m == (int)HALO_PUSH;
 }
 
 }  // namespace hpcla
 
 using namespace hpcla;
+
+HPCLA_API int hpcla_set_halo_mode(int mode)
+{
+    if (mode < -1 || mode > 2) return set_error(HPCLA_ERR_INVALID, "set_halo_mode: mode must be -1 (auto), 0, 1 or 2");
+    g_halo_mode_override = mode;
+    return HPCLA_OK;
+}
 
 HPCLA_API int hpcla_comm_get_unique_id(uint8_t *id_host)
 {
@@ -176,6 +178,12 @@ HPCLA_API int hpcla_comm_get_unique_id(uint8_t *id_host)
 HPCLA_API int hpcla_comm_init_rank(hpcla_comm_t **comm, const uint8_t *id_host, int nranks,
                                    int rank)
 {
+    return hpcla_comm_init_rank_ex(comm, id_host, nranks, rank, 0);
+}
+
+HPCLA_API int hpcla_comm_init_rank_ex(hpcla_comm_t **comm, const uint8_t *id_host, int nranks,
+                                      int rank, int flags)
+{
     if (!comm) return set_error(HPCLA_ERR_INVALID, "comm_init_rank: null output");
     if (nranks < 1 || rank < 0 || rank >= nranks)
         return set_error(HPCLA_ERR_INVALID, "comm_init_rank: bad rank %d of %d", rank, nranks);
@@ -186,7 +194,7 @@ HPCLA_API int hpcla_comm_init_rank(hpcla_comm_t **comm, const uint8_t *id_host, 
     // nranks == 1: serial communicator (CommSerial, src/backends.jl:63).  HPCLA_FORCE_RCCL=1 makes
     // a real one-rank RCCL communicator, used by the self-send test of the exchange code.
     const char *force = getenv("HPCLA_FORCE_RCCL");
-    if (nranks > 1 || (force && force[0] == '1')) {
+    if ((flags & HPCLA_COMM_NO_RCCL) == 0 && (nranks > 1 || (force && force[0] == '1'))) {
         if (!id_host) { delete c; return set_error(HPCLA_ERR_INVALID, "comm_init_rank: null id"); }
         int rc = rccl_load();
         if (rc) { delete c; return rc; }
@@ -219,6 +227,7 @@ HPCLA_API int hpcla_comm_size(const hpcla_comm_t *comm, int *nranks)
 HPCLA_API int hpcla_comm_destroy(hpcla_comm_t *comm)
 {
     if (!comm) return HPCLA_OK;
+    comm_window_free(comm);
     if (comm->nccl) {
         ncclResult_t r = g_rccl.CommDestroy(comm->nccl);
         comm->nccl = nullptr;
@@ -299,6 +308,7 @@ static void halo_free(hpcla_halo_plan *p)
     if (!p) return;
     if (p->send_idx) (void)hipFree(p->send_idx);
     if (p->send_buf) (void)hipFree(p->send_buf);
+    push_free(p);                                  // peer mappings + the window (which holds the ghost)
     if (p->ghost) (void)hipFree(p->ghost);
     if (p->ev_ready) (void)hipEventDestroy(p->ev_ready);
     if (p->ev_done) (void)hipEventDestroy(p->ev_done);
@@ -333,7 +343,7 @@ HPCLA_API int hpcla_halo_plan_create(hpcla_halo_plan_t **plan, hpcla_comm_t *com
     if ((n_send > 0 && (!send_ranks_host || !send_counts_host)) ||
         (n_recv > 0 && (!recv_ranks_host || !recv_counts_host)))
         return set_error(HPCLA_ERR_INVALID, "halo_plan_create: null rank/count lists");
-    if ((n_send > 0 || n_recv > 0) && !comm->nccl)
+    if ((n_send > 0 || n_recv > 0) && !comm->nccl && !comm->win_attached)
         return set_error(HPCLA_ERR_INVALID,
                          "halo_plan_create: neighbours given but the communicator is serial");
     hpcla_halo_plan *p = new (std::nothrow) hpcla_halo_plan();
@@ -389,10 +399,16 @@ HPCLA_API int hpcla_halo_plan_create(hpcla_halo_plan_t **plan, hpcla_comm_t *com
             HALO_HIP(hipMemcpy(h.data(), p->send_idx, p->n_send_total * isz, hipMemcpyDeviceToHost));
             scan_contiguous(p, h);
         }
-        if (p->need_pack)
+        if (p->need_pack && comm->nccl)
             HALO_HIP(hipMalloc((void **)&p->send_buf, p->n_send_total * width * sizeof(double)));
     }
-    if (p->n_ghost > 0) {
+    // ghost segment: inside a peer-mappable window when the push transport may serve this plan (the
+    // communicator's own window is attached, i.e. all ranks share a node, and HPCLA_HALO_MODE does not
+    // name an RCCL mode), else a plain allocation that RCCL receives into
+    if (comm->win_attached && (n_send > 0 || n_recv > 0) && (halo_want_window() || !comm->nccl)) {
+        int rcw = push_plan_alloc(p);
+        if (rcw) { halo_free(p); return rcw; }
+    } else if (p->n_ghost > 0) {
         HALO_HIP(hipMalloc((void **)&p->ghost, p->n_ghost * width * sizeof(double)));
         HALO_HIP(hipMemset(p->ghost, 0, p->n_ghost * width * sizeof(double)));
     }
@@ -421,7 +437,8 @@ HPCLA_API int hpcla_halo_plan_destroy(hpcla_halo_plan_t *plan)
 HPCLA_API int hpcla_halo_ghost_ptr(hpcla_halo_plan_t *plan, double **ghost, int64_t *n_ghost)
 {
     if (!plan) return set_error(HPCLA_ERR_INVALID, "halo_ghost_ptr: null plan");
-    if (ghost) *ghost = plan->ghost;
+    // push transport: the buffer of the exchange posted last (double-buffered window)
+    if (ghost) *ghost = plan->attached ? push_ghost_ptr(plan) : plan->ghost;
     if (n_ghost) *n_ghost = plan->n_ghost;
     return HPCLA_OK;
 }
@@ -431,6 +448,17 @@ static int halo_post(hpcla_halo_plan_t *plan, const double *x, void *stream, boo
 
 HPCLA_API int hpcla_halo_begin(hpcla_halo_plan_t *plan, const double *x, void *stream)
 {
+    if (plan && halo_active(plan) && halo_mode_of(plan) == HALO_PUSH) {
+        // the push kernel IS the copy engine: run it on the side stream (after everything enqueued on the
+        // caller's stream) so that a large payload (SpMM ghost rows) overlaps the caller's interior work
+        if (plan->n_send_total > 0 && !x) return set_error(HPCLA_ERR_INVALID, "halo_begin: null x");
+        HPCLA_CHECK_HIP(hipEventRecord(plan->ev_ready, as_stream(stream)));
+        HPCLA_CHECK_HIP(hipStreamWaitEvent(plan->side, plan->ev_ready, 0));
+        int rc = push_post(plan, x, plan->side);
+        if (rc) return rc;
+        HPCLA_CHECK_HIP(hipEventRecord(plan->ev_done, plan->side));
+        return HPCLA_OK;
+    }
     return halo_post(plan, x, stream, true);
 }
 
@@ -464,21 +492,36 @@ static int halo_post(hpcla_halo_plan_t *plan, const double *x, void *stream, boo
         HPCLA_CHECK_LAUNCH();
     }
     ncclComm_t nc = plan->comm->nccl;
+    if (!nc) return set_error(HPCLA_ERR_INVALID, "halo exchange: this communicator has no RCCL transport");
+    // a failed Send/Recv must not leave the thread inside an open group (later RCCL calls would be
+    // queued into it), and once the side stream carries work the caller's stream must still be joined
+    // to it: close the group, record ev_done, make the caller wait, then report
+    ncclResult_t bad = ncclSuccess;
+    const char *what = "";
     HPCLA_CHECK_RCCL(g_rccl.GroupStart());
-    for (size_t i = 0; i < plan->recv_ranks.size(); ++i) {
+    for (size_t i = 0; i < plan->recv_ranks.size() && bad == ncclSuccess; ++i) {
         if (plan->recv_counts[i] == 0) continue;
-        HPCLA_CHECK_RCCL(g_rccl.Recv(plan->ghost + plan->recv_off[i] * w,
-                                     (size_t)(plan->recv_counts[i] * w), ncclDouble,
-                                     plan->recv_ranks[i], nc, cs));
+        bad = g_rccl.Recv(plan->ghost + plan->recv_off[i] * w, (size_t)(plan->recv_counts[i] * w), ncclDouble,
+                          plan->recv_ranks[i], nc, cs);
+        what = "ncclRecv";
     }
-    for (size_t i = 0; i < plan->send_ranks.size(); ++i) {
+    for (size_t i = 0; i < plan->send_ranks.size() && bad == ncclSuccess; ++i) {
         if (plan->send_counts[i] == 0) continue;
         const double *src = plan->send_contig[i] ? x + plan->send_first[i] * w
                                                  : plan->send_buf + plan->send_off[i] * w;
-        HPCLA_CHECK_RCCL(g_rccl.Send(src, (size_t)(plan->send_counts[i] * w), ncclDouble,
-                                     plan->send_ranks[i], nc, cs));
+        bad = g_rccl.Send(src, (size_t)(plan->send_counts[i] * w), ncclDouble, plan->send_ranks[i], nc, cs);
+        what = "ncclSend";
     }
-    HPCLA_CHECK_RCCL(g_rccl.GroupEnd());
+    const ncclResult_t endr = g_rccl.GroupEnd();
+    if (bad != ncclSuccess || endr != ncclSuccess) {
+        if (!inline_on_main) {
+            (void)hipEventRecord(plan->ev_done, plan->side);
+            (void)hipStreamWaitEvent(main, plan->ev_done, 0);
+        }
+        if (bad != ncclSuccess)
+            return set_error(HPCLA_ERR_RCCL, "%s failed: %s", what, g_rccl.GetErrorString(bad));
+        return set_error(HPCLA_ERR_RCCL, "ncclGroupEnd failed: %s", g_rccl.GetErrorString(endr));
+    }
     if (record_done && !inline_on_main) HPCLA_CHECK_HIP(hipEventRecord(plan->ev_done, plan->side));
     return HPCLA_OK;
 }
@@ -487,20 +530,47 @@ namespace hpcla {
 // the exchange on the caller's stream itself (serial mode), for packed.hip
 int halo_exchange_inline(hpcla_halo_plan_t *plan, const double *x, void *stream)
 {
+    if (plan && halo_active(plan) && halo_mode_of(plan) == HALO_PUSH) return push_post(plan, x, stream);
     return halo_post(plan, x, stream, false, true);
 }
+// ... and what must precede the first ghost read on that stream (push: the device-side flag wait)
+int halo_exchange_inline_finish(hpcla_halo_plan_t *plan, void *stream)
+{
+    if (plan && halo_active(plan) && halo_mode_of(plan) == HALO_PUSH) return push_wait_kernel_launch(plan, stream);
+    return HPCLA_OK;
+}
+
+bool halo_serial_mode(const hpcla_halo_plan_t *plan) { return halo_mode_of(plan) != HALO_OVERLAP; }
 }  // namespace hpcla
 
 HPCLA_API int hpcla_halo_end(hpcla_halo_plan_t *plan, void *stream)
 {
     if (!plan) return set_error(HPCLA_ERR_INVALID, "halo_end: null plan");
     if (plan->send_ranks.empty() && plan->recv_ranks.empty()) return HPCLA_OK;
-    HPCLA_CHECK_HIP(hipStreamWaitEvent(as_stream(stream), plan->ev_done, 0));
+    HPCLA_CHECK_HIP(hipStreamWaitEvent(as_stream(stream), plan->ev_done, 0));   // my own exchange work is done
+    // push transport: additionally wait (on the device) until every neighbour has published this epoch
+    if (halo_mode_of(plan) == HALO_PUSH) return push_wait_kernel_launch(plan, stream);
     return HPCLA_OK;
 }
 
-template <typename I, typename F>
-static int spmv_dist_impl(F split_fn, hpcla_halo_plan_t *plan, const I *rowptr, const I *colval,
+// contiguity of the (ascending) interior block list, probed once per list: a contiguous run is addressed
+// by its base, because a per-workgroup list load would sit on the critical path of every workgroup
+// (measured: +30 us per 4096^2 SpMV)
+static int probe_interior(hpcla_halo_plan_t *plan, const int32_t *interior, int64_t n_interior)
+{
+    if (plan->probed_list == interior && plan->probed_n == n_interior) return HPCLA_OK;
+    int32_t ends[2] = {0, 0};
+    HPCLA_CHECK_HIP(hipMemcpy(&ends[0], interior, sizeof(int32_t), hipMemcpyDeviceToHost));
+    HPCLA_CHECK_HIP(hipMemcpy(&ends[1], interior + (n_interior - 1), sizeof(int32_t), hipMemcpyDeviceToHost));
+    plan->probed_list = interior;
+    plan->probed_n = n_interior;
+    plan->probed_first = ends[0];
+    plan->probed_contig = ((int64_t)ends[1] - (int64_t)ends[0] + 1 == n_interior);
+    return HPCLA_OK;
+}
+
+template <typename I, typename F, typename G>
+static int spmv_dist_impl(F split_fn, G fused_fn, hpcla_halo_plan_t *plan, const I *rowptr, const I *colval,
                           const double *nzval, const double *x, int64_t n_own, double *y,
                           int64_t nrows, int64_t nnz, int index_base, const int32_t *interior,
                           int64_t n_interior, const int32_t *boundary, int64_t n_boundary,
@@ -526,7 +596,32 @@ static int spmv_dist_impl(F split_fn, hpcla_halo_plan_t *plan, const I *rowptr, 
     // interior grid drains -- "overlap" then costs interior + exchange + boundary + two cross-stream hops
     // (+32 us per 4096^2 step) against exchange + kernel (+13 us) for "serial".  Overlap pays only next
     // to kernels that leave CU room (the SpMM path, 6 workgroups per CU, keeps it).
-    if (halo_serial_mode()) {
+    const HaloMode mode = halo_mode_of(plan);
+    if (mode == HALO_PUSH) {
+        //  push     (default on one node) ONE launch: its leading workgroups store this rank's boundary values
+        //           straight into the neighbours' ghost windows and publish the step's epoch; the interior blocks
+        //           follow; the boundary blocks come last and poll the local flag lines before their first ghost
+        //           gather (window.hip, halo_wait.h, spmv.hip).  No RCCL kernel, no side stream, no events, no
+        //           extra launch; the exchange overlaps all interior blocks.
+        if (n_interior > 0) {
+            int rcq = probe_interior(plan, interior, n_interior);
+            if (rcq) return rcq;
+        }
+        PushArgs pa;
+        int rcp;
+        if ((plan->idx_is_i64 != 0) == (sizeof(I) == 8)) {
+            rcp = push_begin(plan, x, stream, &pa);        // the push rides in the leading workgroups of the launch
+        } else {                                           // send lists typed unlike the matrix: push kernel of its own
+            rcp = push_post(plan, x, stream);
+            memset(&pa, 0, sizeof(pa));
+        }
+        if (rcp) return rcp;
+        const bool contig = n_interior > 0 && plan->probed_contig;
+        return fused_fn(rowptr, colval, nzval, x, push_ghost_ptr(plan), n_own, y, nrows, nnz, index_base,
+                        contig ? nullptr : interior, contig ? plan->probed_first : 0, n_interior, boundary,
+                        n_boundary, push_wait_args(plan), pa, stream, dot_partial);
+    }
+    if (mode == HALO_SERIAL) {
         int rc0 = halo_post(plan, x, stream, false, true);
         if (rc0) return rc0;
         return split_fn(rowptr, colval, nzval, x, plan->ghost, n_own, y, nrows, nnz, index_base, nullptr, 0,
@@ -541,18 +636,8 @@ static int spmv_dist_impl(F split_fn, hpcla_halo_plan_t *plan, const I *rowptr, 
     }
     HPCLA_CHECK_HIP(hipEventRecord(plan->ev_done, plan->side));
     if (n_interior > 0) {
-        // The interior list is ascending (classify order).  When it is one contiguous run -- every
-        // slab partition -- address the blocks by base: the per-workgroup list load would sit on the
-        // critical path of every workgroup (measured: +30 us per 4096^2 SpMV).  Probed once per list.
-        if (plan->probed_list != interior || plan->probed_n != n_interior) {
-            int32_t ends[2] = {0, 0};
-            HPCLA_CHECK_HIP(hipMemcpy(&ends[0], interior, sizeof(int32_t), hipMemcpyDeviceToHost));
-            HPCLA_CHECK_HIP(hipMemcpy(&ends[1], interior + (n_interior - 1), sizeof(int32_t), hipMemcpyDeviceToHost));
-            plan->probed_list = interior;
-            plan->probed_n = n_interior;
-            plan->probed_first = ends[0];
-            plan->probed_contig = ((int64_t)ends[1] - (int64_t)ends[0] + 1 == n_interior);
-        }
+        rc = probe_interior(plan, interior, n_interior);
+        if (rc) return rc;
         if (plan->probed_contig)
             rc = split_fn(rowptr, colval, nzval, x, plan->ghost, n_own, y, nrows, nnz, index_base,
                           nullptr, n_interior, stream, dot_partial, plan->probed_first);
@@ -567,8 +652,8 @@ static int spmv_dist_impl(F split_fn, hpcla_halo_plan_t *plan, const I *rowptr, 
 // y = A*x and out = x.y in one pass over A (CG's p.Ap): the SpMV workgroups leave per-row-block
 // partials in `work`, summed in index order afterwards, then all-reduced.  Needs x partitioned like
 // A's rows (n_own == nrows) and interior+boundary lists that cover every row block exactly once.
-template <typename I, typename F>
-static int spmv_dist_dot_impl(F split_fn, hpcla_halo_plan_t *plan, hpcla_comm_t *comm, const I *rowptr,
+template <typename I, typename F, typename G>
+static int spmv_dist_dot_impl(F split_fn, G fused_fn, hpcla_halo_plan_t *plan, hpcla_comm_t *comm, const I *rowptr,
                               const I *colval, const double *nzval, const double *x, int64_t n_own,
                               double *y, int64_t nrows, int64_t nnz, int index_base,
                               const int32_t *interior, int64_t n_interior, const int32_t *boundary,
@@ -584,7 +669,7 @@ static int spmv_dist_dot_impl(F split_fn, hpcla_halo_plan_t *plan, hpcla_comm_t 
         return set_error(HPCLA_ERR_INVALID, "spmv_dist_dot: block lists must cover every row block");
     double *scratch = reinterpret_cast<double *>(work);          // 2048 doubles of stage-1 scratch
     double *partial = scratch + 2048;                            // then one double per row block
-    int rc = spmv_dist_impl<I>(split_fn, plan, rowptr, colval, nzval, x, n_own, y, nrows, nnz, index_base,
+    int rc = spmv_dist_impl<I>(split_fn, fused_fn, plan, rowptr, colval, nzval, x, n_own, y, nrows, nnz, index_base,
                                interior, n_interior, boundary, n_boundary, stream, partial);
     if (rc) return rc;
     rc = reduce_partials_sum(partial, all_blocks, scratch, dot_out_dev, stream);
@@ -607,7 +692,7 @@ HPCLA_API int hpcla_spmv_dist_dot_f64_i32(hpcla_halo_plan_t *plan, hpcla_comm_t 
                                           const int32_t *boundary_blocks, int64_t n_boundary,
                                           double *dot_out_dev, void *work, void *stream)
 {
-    return spmv_dist_dot_impl<int32_t>(spmv_split_i32, plan, comm, rowptr, colval_split, nzval, x, n_own,
+    return spmv_dist_dot_impl<int32_t>(spmv_split_i32, spmv_fused_i32, plan, comm, rowptr, colval_split, nzval, x, n_own,
                                        y, nrows, nnz, index_base, interior_blocks, n_interior,
                                        boundary_blocks, n_boundary, dot_out_dev, work, stream);
 }
@@ -620,7 +705,7 @@ HPCLA_API int hpcla_spmv_dist_dot_f64_i64(hpcla_halo_plan_t *plan, hpcla_comm_t 
                                           const int32_t *boundary_blocks, int64_t n_boundary,
                                           double *dot_out_dev, void *work, void *stream)
 {
-    return spmv_dist_dot_impl<int64_t>(spmv_split_i64, plan, comm, rowptr, colval_split, nzval, x, n_own,
+    return spmv_dist_dot_impl<int64_t>(spmv_split_i64, spmv_fused_i64, plan, comm, rowptr, colval_split, nzval, x, n_own,
                                        y, nrows, nnz, index_base, interior_blocks, n_interior,
                                        boundary_blocks, n_boundary, dot_out_dev, work, stream);
 }
@@ -632,7 +717,7 @@ HPCLA_API int hpcla_spmv_dist_f64_i32(hpcla_halo_plan_t *plan, const int32_t *ro
                                       int64_t n_interior, const int32_t *boundary_blocks,
                                       int64_t n_boundary, void *stream)
 {
-    return spmv_dist_impl<int32_t>(spmv_split_i32, plan, rowptr, colval_split, nzval, x, n_own, y,
+    return spmv_dist_impl<int32_t>(spmv_split_i32, spmv_fused_i32, plan, rowptr, colval_split, nzval, x, n_own, y,
                                    nrows, nnz, index_base, interior_blocks, n_interior,
                                    boundary_blocks, n_boundary, stream);
 }
@@ -644,7 +729,7 @@ HPCLA_API int hpcla_spmv_dist_f64_i64(hpcla_halo_plan_t *plan, const int64_t *ro
                                       int64_t n_interior, const int32_t *boundary_blocks,
                                       int64_t n_boundary, void *stream)
 {
-    return spmv_dist_impl<int64_t>(spmv_split_i64, plan, rowptr, colval_split, nzval, x, n_own, y,
+    return spmv_dist_impl<int64_t>(spmv_split_i64, spmv_fused_i64, plan, rowptr, colval_split, nzval, x, n_own, y,
                                    nrows, nnz, index_base, interior_blocks, n_interior,
                                    boundary_blocks, n_boundary, stream);
 }

@@ -1,0 +1,143 @@
+// halo_wait.h -- consumer side of the peer-window push transport (window.hip): wait inside a kernel
+// until every recv neighbour has published the step's epoch, then make its payload visible.
+#pragma once
+#include "common.h"
+
+namespace hpcla {
+
+constexpr int WIN_FLAG_STRIDE_U64 = 16;        // one polled word per 128-byte line
+
+// what a consuming launch needs: the plan's LOCAL flag lines and the epoch of this step
+struct HaloWait {
+    const uint64_t *flags;                     // n_flags lines, stride WIN_FLAG_STRIDE_U64
+    int n_flags;
+    uint64_t epoch;
+    uint32_t *status;                          // set to 1 when a spin timed out (the grid still drains)
+    int64_t timeout_ticks;                     // wall_clock64 ticks (100 MHz)
+};
+
+// Called by EVERY thread of a workgroup (it contains a barrier).  One lane polls with relaxed
+// system-scope loads (no fence per poll), then ONE system-scope acquire drops this CU's stale lines;
+// the other waves read the ghosts only after the barrier (MI355X visibility rules: the acquire is per
+// CU, the barrier holds the other waves until it has completed).
+__device__ __forceinline__ void halo_wait_block(const HaloWait &w)
+{
+    if (threadIdx.x == 0) {
+        const int64_t t0 = (int64_t)wall_clock64();
+        bool ok = true;
+        for (int i = 0; i < w.n_flags && ok; ++i) {
+            const uint64_t *f = w.flags + (int64_t)i * WIN_FLAG_STRIDE_U64;
+            while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < w.epoch) {
+                __builtin_amdgcn_s_sleep(2);
+                if ((int64_t)wall_clock64() - t0 > w.timeout_ticks) {
+                    __hip_atomic_store(w.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = false;
+                    break;
+                }
+            }
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);           // system scope
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+}
+
+// ---- producer side -----------------------------------------------------------------------------
+// One send neighbour of a plan, as the push code sees it (built at attach time, window.hip).
+struct PushTarget {
+    double *ghost;          // peer's ghost buffer 0 at my segment (peer memory, mapped here)
+    int64_t buf_stride;     // doubles between the peer's two buffers
+    uint64_t *flag;         // peer's flag line for me
+    const uint64_t *ack;    // LOCAL ack line this peer writes: last epoch it has finished reading
+    int64_t count;          // entries (x width doubles)
+    int64_t src_off;        // offset of this neighbour's run in send_idx
+    int64_t first;          // first index of x when the run is contiguous, else -1
+    int32_t nbuf;           // the peer's ghost buffer count
+    int32_t nchunks;        // workgroups that push to this peer
+};
+
+struct PushArgs {
+    const double *x;
+    const void *idx;                    // send indices (int32 or int64, the plan's type)
+    const PushTarget *targets;
+    const int32_t *map;                 // [n_blocks][2]: (target or -1, chunk)
+    uint64_t *const *ack_out;           // where this rank's acks go (peer memory), one per recv neighbour
+    int n_ack_out;
+    uint64_t *arrive;                   // local arrival counters, one per send neighbour
+    uint32_t *status;
+    uint64_t epoch;
+    int w;                              // doubles per index
+    int64_t timeout_ticks;
+    int n_blocks;                       // push workgroups (>= 1 whenever the plan has neighbours)
+};
+
+__device__ __forceinline__ bool spin_until_ge(const uint64_t *word, uint64_t want, int64_t t0, int64_t timeout,
+                                              uint32_t *status)
+{
+    while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
+        __builtin_amdgcn_s_sleep(2);
+        if ((int64_t)wall_clock64() - t0 > timeout) {
+            __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+    }
+    return true;
+}
+
+// Work of push workgroup `b` (all threads of the workgroup call it; NT = threads per workgroup).
+// Block 0 first publishes this rank's acks ("I have finished reading epoch-1": true in stream order, the
+// consumer of epoch-1 precedes this launch).  Then: wait until the peer has released the buffer of this
+// epoch, store the chunk with system-scope write-through stores, drain, and let the LAST chunk of the
+// neighbour publish the epoch in the peer's flag line.
+template <typename I, int NT>
+__device__ __forceinline__ void halo_push_block(const PushArgs &a, int b)
+{
+    if (b == 0)
+        for (int j = threadIdx.x; j < a.n_ack_out; j += NT)
+            __hip_atomic_store(a.ack_out[j], a.epoch - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const int t = a.map[2 * b], c = a.map[2 * b + 1];
+    if (t < 0) return;
+    const PushTarget T = a.targets[t];
+    if (threadIdx.x == 0 && a.epoch > (uint64_t)T.nbuf)
+        spin_until_ge(T.ack, a.epoch - (uint64_t)T.nbuf, (int64_t)wall_clock64(), a.timeout_ticks, a.status);
+    __syncthreads();
+    double *dst = T.ghost + (int64_t)(a.epoch % (uint64_t)T.nbuf) * T.buf_stride;
+    const I *idx = reinterpret_cast<const I *>(a.idx);
+    const int w = a.w;
+    const int64_t total = T.count * w;
+    const int64_t per = (total + T.nchunks - 1) / T.nchunks;
+    const int64_t lo = (int64_t)c * per;
+    const int64_t hi = lo + per < total ? lo + per : total;
+    if (T.first >= 0) {
+        const double *src = a.x + T.first * w;
+        for (int64_t i = lo + threadIdx.x; i < hi; i += NT)
+            __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    } else if (w == 1) {
+        for (int64_t i = lo + threadIdx.x; i < hi; i += NT)
+            __hip_atomic_store(dst + i, a.x[(int64_t)idx[T.src_off + i]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    } else {
+        for (int64_t i = lo + threadIdx.x; i < hi; i += NT) {
+            const int64_t e = i / w;
+            const int cc = (int)(i - e * w);
+            __hip_atomic_store(dst + i, a.x[(int64_t)idx[T.src_off + e] * w + cc], __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    // every storing wave drains its write-through stores, then ONE lane publishes
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        bool last = true;
+        if (T.nchunks > 1) {
+            const uint64_t old = __hip_atomic_fetch_add(a.arrive + t, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = (old + 1 == a.epoch * (uint64_t)T.nchunks);
+        }
+        if (last) {
+            __atomic_thread_fence(__ATOMIC_RELEASE);             // system scope
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(T.flag, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+}  // namespace hpcla

@@ -6,6 +6,8 @@
 
 namespace hpcla {
 
+uint64_t host_identity();   // window.hip
+
 char *err_buf()
 {
     static thread_local char buf[512] = "";
@@ -45,6 +47,17 @@ HPCLA_API int hpcla_device_count(int *count)
 HPCLA_API int hpcla_set_device(int device)
 {
     HPCLA_CHECK_HIP(hipSetDevice(device));
+    return HPCLA_OK;
+}
+
+HPCLA_API int hpcla_device_identity(int device, uint64_t *id)
+{
+    if (!id) return set_error(HPCLA_ERR_INVALID, "device_identity: null pointer");
+    char bus[64] = "";
+    HPCLA_CHECK_HIP(hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device));
+    uint64_t h = host_identity();
+    for (const char *c = bus; *c; ++c) { h ^= (uint8_t)*c; h *= 0x100000001b3ull; }
+    *id = h;
     return HPCLA_OK;
 }
 

@@ -38,7 +38,8 @@ int reduce_partials_sum(const double *partial, int64_t np, double *scratch, doub
                         void *stream);
 int allreduce_on(hpcla_comm_t *comm, double *buf, int64_t count, int op, void *stream);
 bool halo_active(const hpcla_halo_plan_t *plan);   // comm.hip
-bool halo_serial_mode();                            // comm.hip (HPCLA_HALO_MODE)
+bool halo_serial_mode(const hpcla_halo_plan_t *plan);   // comm.hip (HPCLA_HALO_MODE; push counts as serial)
+int halo_exchange_inline_finish(hpcla_halo_plan_t *plan, void *stream);
 int halo_exchange_inline(hpcla_halo_plan_t *plan, const double *x, void *stream);   // comm.hip
 
 }  // namespace hpcla
@@ -373,17 +374,15 @@ HPCLA_API int hpcla_spmv_dist_packed_f64_i32(hpcla_halo_plan_t *plan, hpcla_comm
             return set_error(HPCLA_ERR_INVALID, "spmv_dist_packed: block lists must cover every row block");
         // same two orderings as the CSR step (comm.hip, spmv_dist_impl): exchange first on the caller's
         // stream, or on the side stream next to the interior blocks
-        const bool serial = halo_serial_mode();
+        const bool serial = halo_serial_mode(plan);
         rc = serial ? halo_exchange_inline(plan, x, stream) : hpcla_halo_begin(plan, x, stream);
         if (rc) return rc;
         if (n_interior > 0) {
             rc = hpcla_spmv_packed_f64_i32(p, rowptr, x, y, index_base, interior_blocks, n_interior, partial, stream);
             if (rc) return rc;
         }
-        if (!serial) {
-            rc = hpcla_halo_end(plan, stream);
-            if (rc) return rc;
-        }
+        rc = serial ? halo_exchange_inline_finish(plan, stream) : hpcla_halo_end(plan, stream);
+        if (rc) return rc;
         if (n_boundary > 0) {
             double *ghost = nullptr;
             rc = hpcla_halo_ghost_ptr(plan, &ghost, nullptr);

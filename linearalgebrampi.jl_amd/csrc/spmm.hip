@@ -378,6 +378,18 @@ HPCLA_API int hpcla_spmm_split_f64_i32(const int32_t *rowptr, const int32_t *col
                                 n_blocks, stream);
 }
 
+HPCLA_API int hpcla_spmm_split_f64_i64(const int64_t *rowptr, const int64_t *colval_split,
+                                       const double *nzval, const double *B_own, int64_t ldb_own,
+                                       const double *B_ghost, int64_t ldb_ghost, int64_t n_own,
+                                       double *C, int64_t ldc, int64_t nrows, int64_t nnz, int k,
+                                       int index_base, const int32_t *block_list,
+                                       int64_t n_blocks, void *stream)
+{
+    return spmm_launch<int64_t>(rowptr, colval_split, nzval, B_own, ldb_own, 1, B_ghost, ldb_ghost,
+                                n_own, true, C, ldc, 1, nrows, nnz, k, index_base, block_list,
+                                n_blocks, stream);
+}
+
 HPCLA_API int hpcla_transpose_f64(const double *src, int64_t ld_src, int src_layout, double *dst,
                                   int64_t ld_dst, int dst_layout, int64_t rows, int64_t cols,
                                   void *stream)

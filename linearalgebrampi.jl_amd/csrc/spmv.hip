@@ -26,7 +26,10 @@
 // 8 XCDs through the 256 MiB Infinity Cache); a software-pipelined persistent variant and a
 // branch-free variant (idle lanes re-reading quad 0) both lose to plain high occupancy
 // (8 workgroups per CU) with whole waves skipping the quads past the end of a row block.
+#include <string.h>
+
 #include "common.h"
+#include "halo_wait.h"
 
 namespace hpcla {
 
@@ -59,6 +62,31 @@ __device__ __forceinline__ double gather_x(const double *__restrict__ x_own,
     return x_own[col];
 }
 
+// Which row block a workgroup owns.  Plain launches: list[b] or base + b.  Fused distributed launches
+// (WAIT, peer-window transport): the first n_first workgroups take the INTERIOR blocks and never wait;
+// the rest take the BOUNDARY blocks -- dispatched last, so the neighbours' pushes have long landed --
+// and poll the plan's flag lines once before their first ghost gather (halo_wait.h).
+struct BlockSel {
+    const int32_t *list;         // blocks of this launch (plain) / boundary blocks (WAIT); null: base + b
+    int64_t base;
+    const int32_t *first_list;   // WAIT only: interior blocks; null: first_base + b
+    int64_t first_base;
+    int64_t n_first;
+};
+
+template <bool WAIT>
+__device__ __forceinline__ int64_t select_block(const BlockSel &bs, bool &wait, int lead)
+{
+    const int64_t b = (int64_t)blockIdx.x - lead;     // `lead` push workgroups come first in a fused launch
+    wait = false;
+    if (WAIT) {
+        if (b < bs.n_first) return bs.first_list ? (int64_t)bs.first_list[b] : bs.first_base + b;
+        wait = true;
+        return bs.list ? (int64_t)bs.list[b - bs.n_first] : bs.base + (b - bs.n_first);
+    }
+    return bs.list ? (int64_t)bs.list[b] : bs.base + b;
+}
+
 // Fused x.y epilogue (CG's p.Ap): every workgroup leaves the
 // deterministic tree sum of x[r]*y[r] over its rows in dot_partial[row block]; hpcla_spmv_dot_finish
 // sums the partials in index order.  Valid when x is partitioned like A's rows (x_own[r] is x at row r).
@@ -74,19 +102,26 @@ __device__ __forceinline__ void block_dot_epilogue(double *s_scratch, double *__
 }
 
 // ---- primary kernel: aligned quads (needs colval 4*sizeof(I)- and nzval 32-byte aligned) -----------
-template <typename I, bool SPLIT>
-__global__ __launch_bounds__(RPB) void spmv_rowblock_quad_kernel(
+template <typename I, bool SPLIT, bool WAIT>
+__global__ __launch_bounds__(RPB) __attribute__((amdgpu_num_sgpr(80), amdgpu_num_vgpr(64))) void spmv_rowblock_quad_kernel(
     const I *__restrict__ rowptr, const I *__restrict__ colval, const double *__restrict__ nzval,
     const double *__restrict__ x_own, const double *__restrict__ x_ghost, int64_t n_own,
     double *__restrict__ y, int64_t nrows, int64_t nnz, int base,
-    const int32_t *__restrict__ block_list, double *__restrict__ dot_partial, int64_t block_base)
+    BlockSel bs, double *__restrict__ dot_partial, HaloWait hw, PushArgs push)
 {
     __shared__ double s_prod[CHUNK];
 
+    // fused distributed launch: the leading workgroups ARE the halo push (this rank's boundary values go
+    // straight into the neighbours' ghost windows while the interior blocks below already stream)
+    if (WAIT && (int)blockIdx.x < push.n_blocks) {
+        halo_push_block<I, RPB>(push, (int)blockIdx.x);
+        return;
+    }
     const int tid = threadIdx.x;
     // a contiguous run of row blocks is addressed by its base (no per-workgroup list load on the
     // critical path rowptr -> A -> x); arbitrary subsets go through the list
-    const int64_t blk = block_list ? (int64_t)block_list[blockIdx.x] : block_base + (int64_t)blockIdx.x;
+    bool wait_ghosts;
+    const int64_t blk = select_block<WAIT>(bs, wait_ghosts, WAIT ? push.n_blocks : 0);
     const int64_t r0 = blk * RPB;
     const int nr = (int)((nrows - r0) < RPB ? (nrows - r0) : RPB);
 
@@ -133,6 +168,9 @@ __global__ __launch_bounds__(RPB) void spmv_rowblock_quad_kernel(
                 }
             }
         }
+        // boundary workgroup of a fused distributed launch: the A stream above is already in flight;
+        // the ghosts may be read once every neighbour has published this step (workgroup-uniform branch)
+        if (WAIT && wait_ghosts && c == 0) halo_wait_block(hw);
         // gather phase: all x loads of the pass issued back to back (addresses first, then loads, then
         // the multiplies -- written as separate loops so hipcc clusters the loads instead of waiting
         // for each gather before issuing the next)
@@ -181,19 +219,22 @@ __global__ __launch_bounds__(RPB) void spmv_rowblock_quad_kernel(
 }
 
 // ---- fallback kernel: element-per-lane loads, no alignment requirement --------------------------------
-template <typename I, bool SPLIT>
-__global__ __launch_bounds__(RPB) void spmv_rowblock_kernel(
+template <typename I, bool SPLIT, bool WAIT>
+__global__ __launch_bounds__(RPB) __attribute__((amdgpu_num_sgpr(80), amdgpu_num_vgpr(64))) void spmv_rowblock_kernel(
     const I *__restrict__ rowptr, const I *__restrict__ colval, const double *__restrict__ nzval,
     const double *__restrict__ x_own, const double *__restrict__ x_ghost, int64_t n_own,
-    double *__restrict__ y, int64_t nrows, int base, const int32_t *__restrict__ block_list,
-    double *__restrict__ dot_partial, int64_t block_base)
+    double *__restrict__ y, int64_t nrows, int base, BlockSel bs,
+    double *__restrict__ dot_partial, HaloWait hw, PushArgs push)
 {
     __shared__ double s_prod[CHUNK];
 
+    if (WAIT && (int)blockIdx.x < push.n_blocks) {
+        halo_push_block<I, RPB>(push, (int)blockIdx.x);
+        return;
+    }
     const int tid = threadIdx.x;
-    // a contiguous run of row blocks is addressed by its base (no per-workgroup list load on the
-    // critical path rowptr -> A -> x); arbitrary subsets go through the list
-    const int64_t blk = block_list ? (int64_t)block_list[blockIdx.x] : block_base + (int64_t)blockIdx.x;
+    bool wait_ghosts;
+    const int64_t blk = select_block<WAIT>(bs, wait_ghosts, WAIT ? push.n_blocks : 0);
     const int64_t r0 = blk * RPB;
     const int nr = (int)((nrows - r0) < RPB ? (nrows - r0) : RPB);
 
@@ -222,6 +263,7 @@ __global__ __launch_bounds__(RPB) void spmv_rowblock_kernel(
                 val[u] = nv[i];
             }
         }
+        if (WAIT && wait_ghosts && c == 0) halo_wait_block(hw);
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             const int i = tid + u * RPB;
@@ -324,27 +366,90 @@ static int spmv_launch(const I *rowptr, const I *colval, const double *nzval, co
     // quad kernel: a 4-entry quad must never straddle a page -> colval 4*sizeof(I)-, nzval 32-byte aligned
     const bool aligned = (reinterpret_cast<uintptr_t>(colval) % (4 * sizeof(I)) == 0) &&
                          (reinterpret_cast<uintptr_t>(nzval) % 32 == 0);
+    const BlockSel bs{block_list, block_base, nullptr, 0, 0};
+    const HaloWait nowait{nullptr, 0, 0, nullptr, 0};
+    PushArgs nopush;
+    memset(&nopush, 0, sizeof(nopush));
     if (aligned) {
         if (split)
-            spmv_rowblock_quad_kernel<I, true><<<grid, block, 0, s>>>(
-                rowptr, colval, nzval, x_own, x_ghost, n_own, y, nrows, nnz, index_base, block_list,
-                dot_partial, block_base);
+            spmv_rowblock_quad_kernel<I, true, false><<<grid, block, 0, s>>>(
+                rowptr, colval, nzval, x_own, x_ghost, n_own, y, nrows, nnz, index_base, bs, dot_partial, nowait, nopush);
         else
-            spmv_rowblock_quad_kernel<I, false><<<grid, block, 0, s>>>(
-                rowptr, colval, nzval, x_own, nullptr, 0, y, nrows, nnz, index_base, block_list,
-                dot_partial, block_base);
+            spmv_rowblock_quad_kernel<I, false, false><<<grid, block, 0, s>>>(
+                rowptr, colval, nzval, x_own, nullptr, 0, y, nrows, nnz, index_base, bs, dot_partial, nowait, nopush);
     } else {
         if (split)
-            spmv_rowblock_kernel<I, true><<<grid, block, 0, s>>>(
-                rowptr, colval, nzval, x_own, x_ghost, n_own, y, nrows, index_base, block_list,
-                dot_partial, block_base);
+            spmv_rowblock_kernel<I, true, false><<<grid, block, 0, s>>>(
+                rowptr, colval, nzval, x_own, x_ghost, n_own, y, nrows, index_base, bs, dot_partial, nowait, nopush);
         else
-            spmv_rowblock_kernel<I, false><<<grid, block, 0, s>>>(
-                rowptr, colval, nzval, x_own, nullptr, 0, y, nrows, index_base, block_list, dot_partial,
-                block_base);
+            spmv_rowblock_kernel<I, false, false><<<grid, block, 0, s>>>(
+                rowptr, colval, nzval, x_own, nullptr, 0, y, nrows, index_base, bs, dot_partial, nowait, nopush);
     }
     HPCLA_CHECK_LAUNCH();
     return HPCLA_OK;
+}
+
+// Fused distributed launch (peer-window transport, comm.hip): ONE grid = interior blocks (a contiguous
+// run from interior_base, or interior_list) followed by the boundary blocks, whose workgroups wait for
+// the neighbours' flags before their first ghost gather.  The exchange overlaps every interior block
+// without a second stream or a second launch.
+template <typename I>
+static int spmv_launch_fused(const I *rowptr, const I *colval, const double *nzval, const double *x_own,
+                             const double *x_ghost, int64_t n_own, double *y, int64_t nrows, int64_t nnz,
+                             int index_base, const int32_t *interior_list, int64_t interior_base,
+                             int64_t n_interior, const int32_t *boundary_list, int64_t n_boundary,
+                             const HaloWait &hw, const PushArgs &pa, void *stream, double *dot_partial)
+{
+    if (nrows < 0 || nnz < 0) return set_error(HPCLA_ERR_INVALID, "spmv: negative size");
+    if (index_base != 0 && index_base != 1)
+        return set_error(HPCLA_ERR_INVALID, "spmv: index_base must be 0 or 1");
+    if (nrows > 0 && (!rowptr || !y)) return set_error(HPCLA_ERR_INVALID, "spmv: null rowptr/y");
+    if (nnz > 0 && (!colval || !nzval || !x_own))
+        return set_error(HPCLA_ERR_INVALID, "spmv: null colval/nzval/x with nnz > 0");
+    const int64_t all_blocks = (nrows + RPB - 1) / RPB;
+    if (n_interior < 0 || n_boundary < 0 || n_interior + n_boundary > all_blocks)
+        return set_error(HPCLA_ERR_INVALID, "spmv: block counts out of range");
+    if (n_boundary > 0 && !boundary_list) return set_error(HPCLA_ERR_INVALID, "spmv: null boundary list");
+    if (n_boundary > 0 && !x_ghost) return set_error(HPCLA_ERR_INVALID, "spmv: boundary blocks without a ghost segment");
+    if (!interior_list && n_interior > 0 && (interior_base < 0 || interior_base + n_interior > all_blocks))
+        return set_error(HPCLA_ERR_INVALID, "spmv: interior run out of bounds");
+    const int64_t launch_blocks = pa.n_blocks + n_interior + n_boundary;   // push workgroups lead the grid
+    if (launch_blocks == 0) return HPCLA_OK;
+    if (launch_blocks > 0x7fffffffLL) return set_error(HPCLA_ERR_INVALID, "spmv: too many blocks");
+    dim3 grid((uint32_t)launch_blocks), block(RPB);
+    hipStream_t s = as_stream(stream);
+    const bool aligned = (reinterpret_cast<uintptr_t>(colval) % (4 * sizeof(I)) == 0) &&
+                         (reinterpret_cast<uintptr_t>(nzval) % 32 == 0);
+    const BlockSel bs{boundary_list, 0, interior_list, interior_base, n_interior};
+    if (aligned)
+        spmv_rowblock_quad_kernel<I, true, true><<<grid, block, 0, s>>>(
+            rowptr, colval, nzval, x_own, x_ghost, n_own, y, nrows, nnz, index_base, bs, dot_partial, hw, pa);
+    else
+        spmv_rowblock_kernel<I, true, true><<<grid, block, 0, s>>>(
+            rowptr, colval, nzval, x_own, x_ghost, n_own, y, nrows, index_base, bs, dot_partial, hw, pa);
+    HPCLA_CHECK_LAUNCH();
+    return HPCLA_OK;
+}
+
+int spmv_fused_i32(const int32_t *rowptr, const int32_t *colval, const double *nzval, const double *x_own,
+                   const double *x_ghost, int64_t n_own, double *y, int64_t nrows, int64_t nnz, int index_base,
+                   const int32_t *interior_list, int64_t interior_base, int64_t n_interior,
+                   const int32_t *boundary_list, int64_t n_boundary, const HaloWait &hw, const PushArgs &pa,
+                   void *stream, double *dot_partial)
+{
+    return spmv_launch_fused<int32_t>(rowptr, colval, nzval, x_own, x_ghost, n_own, y, nrows, nnz, index_base,
+                                      interior_list, interior_base, n_interior, boundary_list, n_boundary, hw,
+                                      pa, stream, dot_partial);
+}
+int spmv_fused_i64(const int64_t *rowptr, const int64_t *colval, const double *nzval, const double *x_own,
+                   const double *x_ghost, int64_t n_own, double *y, int64_t nrows, int64_t nnz, int index_base,
+                   const int32_t *interior_list, int64_t interior_base, int64_t n_interior,
+                   const int32_t *boundary_list, int64_t n_boundary, const HaloWait &hw, const PushArgs &pa,
+                   void *stream, double *dot_partial)
+{
+    return spmv_launch_fused<int64_t>(rowptr, colval, nzval, x_own, x_ghost, n_own, y, nrows, nnz, index_base,
+                                      interior_list, interior_base, n_interior, boundary_list, n_boundary, hw,
+                                      pa, stream, dot_partial);
 }
 
 // exported to comm.hip (spmv_dist)

@@ -1,0 +1,528 @@
+// window.hip -- peer-window push transport: halo exchange and scalar all-reduce by DIRECT stores into
+// the neighbours' memory over xGMI, no RCCL kernel and no side stream.
+//
+// Replaces the exchange half of execute_plan! (MPI Isend/Irecv on host buffers, src/vectors.jl:431-455)
+// and comm_allreduce of a scalar (src/backends.jl:264-277) on one node.  Why not RCCL here: measured on
+// MI355X (profiles/r01_halo_mode_experiments.log), the ncclSend/ncclRecv group of a 2 x 32 KiB stencil
+// halo costs ~13 us on the caller's stream and cannot overlap the SpMV kernel, which occupies every
+// wave slot of every CU.  xGMI is point-to-point and peer memory is mappable, so the natural MI355X
+// form is one-sided:
+//
+//   * every plan owns a WINDOW (fine-grained allocation: control lines + ghost buffers) that its
+//     neighbours map once, at plan time, through hipIpcOpenMemHandle (handles travel through the host
+//     runtime exactly like the RCCL unique id, ext/HPCLinearAlgebraCUDAExt.jl:411-443);
+//   * per SpMV, a small PUSH kernel on the caller's stream stores x[send_indices] straight into each
+//     neighbour's ghost buffer (system-scope write-through stores), drains them, and publishes the
+//     step's epoch in the neighbour's flag line;
+//   * the consumer is the SpMV launch itself: its boundary workgroups are dispatched LAST and poll the
+//     flag lines (one lane, relaxed system-scope loads, one acquire) before their first ghost gather
+//     (spmv.hip), so the exchange overlaps all interior row blocks without a second stream;
+//   * ghost buffers are double-buffered and guarded by ACK lines (the consumer's next push publishes
+//     "I have finished reading epoch e-1" before it waits for anything), so a fast rank can never
+//     overwrite values a slow neighbour is still reading, for symmetric and asymmetric patterns alike.
+//
+// Every spin is bounded (HPCLA_PUSH_TIMEOUT_S, default 20 s): on expiry the kernel sets the plan's
+// status word and carries on, so a grid always drains; hpcla_halo_status reports it.
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+#include "comm_internal.h"
+#include "halo_wait.h"
+
+namespace hpcla {
+
+// ---- host helpers ----------------------------------------------------------------------------
+uint64_t host_identity()
+{
+    // boot id (one per running kernel) + host name: equal for all processes that can share IPC handles
+    uint64_t h = 0xcbf29ce484222325ull;
+    auto mix = [&h](const char *s, size_t n) {
+        for (size_t i = 0; i < n; ++i) { h ^= (uint8_t)s[i]; h *= 0x100000001b3ull; }
+    };
+    char buf[256];
+    FILE *f = fopen("/proc/sys/kernel/random/boot_id", "r");
+    if (f) {
+        size_t n = fread(buf, 1, sizeof(buf), f);
+        fclose(f);
+        mix(buf, n);
+    }
+    if (gethostname(buf, sizeof(buf)) == 0) mix(buf, strnlen(buf, sizeof(buf)));
+    return h ? h : 1;
+}
+
+int64_t spin_timeout_ticks()
+{
+    static const int64_t ticks = [] {
+        const char *e = getenv("HPCLA_PUSH_TIMEOUT_S");
+        double s = e ? atof(e) : 20.0;
+        if (!(s > 0.0)) s = 20.0;
+        return (int64_t)(s * 1.0e8);           // wall_clock64 runs at 100 MHz
+    }();
+    return ticks;
+}
+
+int window_alloc(void **p, size_t bytes)
+{
+    // fine-grained: coherent for stores arriving from peers while kernels of this device read it
+    HPCLA_CHECK_HIP(hipExtMallocWithFlags(p, bytes, hipDeviceMallocFinegrained));
+    hipError_t e = hipMemset(*p, 0, bytes);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        (void)hipFree(*p);
+        *p = nullptr;
+        return set_error(HPCLA_ERR_HIP, "window memset failed: %s", hipGetErrorString(e));
+    }
+    return HPCLA_OK;
+}
+
+int window_open(const WindowDesc &d, int peer_rank, int my_rank, void *my_base, PeerMap *out)
+{
+    if (d.bytes == 0) return set_error(HPCLA_ERR_INVALID, "window_open: rank %d exported no window", peer_rank);
+    if (peer_rank == my_rank && d.pid == (uint64_t)getpid()) {
+        out->base = my_base;                   // a handle cannot be opened in the process that made it
+        out->opened = false;
+        return HPCLA_OK;
+    }
+    if (d.host_id != host_identity())
+        return set_error(HPCLA_ERR_UNSUPPORTED, "window_open: rank %d is on another node (push transport is per node)",
+                         peer_rank);
+    hipIpcMemHandle_t h;
+    static_assert(sizeof(h) == 64, "hipIpcMemHandle_t size");
+    memcpy(&h, d.ipc, sizeof(h));
+    void *p = nullptr;
+    hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess)
+        return set_error(HPCLA_ERR_HIP, "hipIpcOpenMemHandle(rank %d) failed: %s", peer_rank, hipGetErrorString(e));
+    out->base = p;
+    out->opened = true;
+    return HPCLA_OK;
+}
+
+void window_close(PeerMap *m)
+{
+    if (m->opened && m->base) (void)hipIpcCloseMemHandle(m->base);
+    m->base = nullptr;
+    m->opened = false;
+}
+
+static void fill_desc(WindowDesc *d, void *win, size_t bytes)
+{
+    memset(d, 0, sizeof(*d));
+    d->host_id = host_identity();
+    d->pid = (uint64_t)getpid();
+    d->bytes = bytes;
+    if (win) {
+        hipIpcMemHandle_t h;
+        if (hipIpcGetMemHandle(&h, win) == hipSuccess) memcpy(d->ipc, &h, sizeof(h));
+        else d->bytes = 0;
+    }
+}
+
+// ---- halo plan window ------------------------------------------------------------------------
+static inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static size_t halo_ctrl_bytes(uint32_t n_flags, uint32_t n_acks)
+{
+    return round_up((size_t)(n_flags + n_acks + 1) * WIN_LINE, 256);
+}
+static size_t halo_buf_bytes(uint64_t n_ghost, uint32_t width)
+{
+    return round_up((size_t)n_ghost * width * sizeof(double), 256);
+}
+
+int push_plan_alloc(hpcla_halo_plan *p)
+{
+    const uint32_t nf = (uint32_t)p->recv_ranks.size(), na = (uint32_t)p->send_ranks.size();
+    const size_t ctrl = halo_ctrl_bytes(nf, na);
+    const size_t buf = halo_buf_bytes((uint64_t)p->n_ghost, (uint32_t)p->width);
+    p->nbuf = (int64_t)buf <= WIN_DOUBLE_BUFFER_MAX ? 2 : 1;
+    p->win_bytes = ctrl + buf * p->nbuf;
+    int rc = window_alloc(&p->win, p->win_bytes);
+    if (rc) return rc;
+    uint8_t *base = reinterpret_cast<uint8_t *>(p->win);
+    p->flags = reinterpret_cast<uint64_t *>(base);
+    p->acks = reinterpret_cast<uint64_t *>(base + (size_t)nf * WIN_LINE);
+    p->status = reinterpret_cast<uint32_t *>(base + (size_t)(nf + na) * WIN_LINE);
+    p->ghost = reinterpret_cast<double *>(base + ctrl);
+    return HPCLA_OK;
+}
+
+constexpr int PUSH_THREADS = 256;
+constexpr int64_t PUSH_CHUNK_DOUBLES = 4096;    // 32 KiB per workgroup
+constexpr int PUSH_MAX_CHUNKS = 64;
+
+// standalone producer (hpcla_halo_begin, packed path): the same per-workgroup code the fused SpMV launch
+// runs in its leading workgroups (halo_wait.h)
+template <typename I>
+__global__ __launch_bounds__(PUSH_THREADS) void halo_push_kernel(PushArgs a)
+{
+    halo_push_block<I, PUSH_THREADS>(a, (int)blockIdx.x);
+}
+
+// standalone consumer (hpcla_halo_end, SpMM boundary blocks): kernels launched after it on the same
+// stream start behind its acquire
+__global__ __launch_bounds__(64) void halo_wait_kernel(HaloWait w)
+{
+    halo_wait_block(w);
+}
+
+HaloWait push_wait_args(const hpcla_halo_plan *p)
+{
+    HaloWait w;
+    w.flags = p->flags;
+    w.n_flags = (int)p->recv_ranks.size();
+    w.epoch = p->epoch;
+    w.status = p->status;
+    w.timeout_ticks = spin_timeout_ticks();
+    return w;
+}
+
+double *push_ghost_ptr(const hpcla_halo_plan *p)
+{
+    if (!p->win || p->nbuf < 2) return p->ghost;
+    const size_t buf = halo_buf_bytes((uint64_t)p->n_ghost, (uint32_t)p->width);
+    return p->ghost + (p->epoch % 2) * (buf / sizeof(double));
+}
+
+// next epoch of the plan + the launch arguments of its push workgroups (the caller launches them: either
+// halo_push_kernel or the leading workgroups of the fused SpMV)
+int push_begin(hpcla_halo_plan *p, const double *x, void *stream, PushArgs *out)
+{
+    if (!p->attached) return set_error(HPCLA_ERR_INVALID, "halo push: plan has no attached peer windows");
+    if (p->n_send_total > 0 && !x) return set_error(HPCLA_ERR_INVALID, "halo push: null x");
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(as_stream(stream), &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+        return set_error(HPCLA_ERR_UNSUPPORTED,
+                         "halo push: the step epoch is a launch argument, so a push-mode exchange cannot be "
+                         "captured into a HIP graph (use HPCLA_HALO_MODE=serial for graph capture)");
+    p->epoch += 1;
+    out->x = x;
+    out->idx = p->send_idx;
+    out->targets = (const PushTarget *)p->push_desc_dev;
+    out->map = (const int32_t *)p->push_block_map_dev;
+    out->ack_out = (uint64_t *const *)p->ack_desc_dev;
+    out->n_ack_out = (int)p->recv_ranks.size();
+    out->arrive = p->arrive;
+    out->status = p->status;
+    out->epoch = p->epoch;
+    out->w = p->width;
+    out->timeout_ticks = spin_timeout_ticks();
+    out->n_blocks = (int)p->push_blocks;
+    return HPCLA_OK;
+}
+
+int push_post(hpcla_halo_plan *p, const double *x, void *stream)
+{
+    PushArgs a;
+    int rc = push_begin(p, x, stream, &a);
+    if (rc) return rc;
+    if (p->idx_is_i64)
+        halo_push_kernel<int64_t><<<(uint32_t)a.n_blocks, PUSH_THREADS, 0, as_stream(stream)>>>(a);
+    else
+        halo_push_kernel<int32_t><<<(uint32_t)a.n_blocks, PUSH_THREADS, 0, as_stream(stream)>>>(a);
+    HPCLA_CHECK_LAUNCH();
+    return HPCLA_OK;
+}
+
+int push_wait_kernel_launch(hpcla_halo_plan *p, void *stream)
+{
+    if (p->recv_ranks.empty()) return HPCLA_OK;
+    halo_wait_kernel<<<1, 64, 0, as_stream(stream)>>>(push_wait_args(p));
+    HPCLA_CHECK_LAUNCH();
+    return HPCLA_OK;
+}
+
+void push_free(hpcla_halo_plan *p)
+{
+    for (auto &m : p->send_peer) window_close(&m);
+    for (auto &m : p->recv_peer) window_close(&m);
+    p->send_peer.clear();
+    p->recv_peer.clear();
+    if (p->push_desc_dev) (void)hipFree(p->push_desc_dev);
+    if (p->ack_desc_dev) (void)hipFree(p->ack_desc_dev);
+    if (p->push_block_map_dev) (void)hipFree(p->push_block_map_dev);
+    if (p->arrive) (void)hipFree(p->arrive);
+    p->push_desc_dev = p->ack_desc_dev = p->push_block_map_dev = nullptr;
+    p->arrive = nullptr;
+    if (p->win) {
+        (void)hipFree(p->win);
+        p->win = nullptr;
+        p->ghost = nullptr;                    // lived inside the window
+    }
+    p->attached = false;
+}
+
+// ---- scalar all-reduce through the communicator window ---------------------------------------------
+// slot (parity, rank): one 128-byte line {u64 epoch; double value[AR_MAX]} inside every rank's window.
+// Each rank stores its partial into its slot of EVERY window, then sums the nranks slots of its own
+// window in rank order: one kernel, one xGMI hop, and every rank adds the same numbers in the same
+// order, so the result is bit-identical on all ranks (the reference asserts uniformity,
+// test/test_utils.jl).
+__global__ __launch_bounds__(64) void window_allreduce_kernel(uint64_t *const *__restrict__ peer_slots,
+                                                              uint64_t *my_slots, uint32_t *status,
+                                                              double *buf, int count, int op, int nranks,
+                                                              int my_rank, uint64_t epoch, int64_t timeout)
+{
+    __shared__ double s_val[64][AR_MAX];
+    const int j = threadIdx.x;
+    const uint64_t parity = epoch & 1;
+    if (j < nranks) {
+        uint64_t *dst = peer_slots[j] + (parity * (uint64_t)nranks + (uint64_t)my_rank) * WIN_LINE_U64;
+        for (int c = 0; c < count; ++c)
+            __hip_atomic_store(reinterpret_cast<double *>(dst + 1 + c), buf[c], __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __atomic_thread_fence(__ATOMIC_RELEASE);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(dst, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const uint64_t *src = my_slots + (parity * (uint64_t)nranks + (uint64_t)j) * WIN_LINE_U64;
+        spin_until_ge(src, epoch, (int64_t)wall_clock64(), timeout, status);
+        for (int c = 0; c < count; ++c)
+            s_val[j][c] = __hip_atomic_load(reinterpret_cast<const double *>(src + 1 + c), __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __syncthreads();
+    if (j < count) {
+        double acc = s_val[0][j];
+        for (int r = 1; r < nranks; ++r) acc = op == 0 ? acc + s_val[r][j] : (s_val[r][j] > acc ? s_val[r][j] : acc);
+        buf[j] = acc;
+    }
+}
+
+int window_allreduce(hpcla_comm *comm, double *buf, int64_t count, int op, void *stream)
+{
+    hipStream_t s = as_stream(stream);
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+        return set_error(HPCLA_ERR_UNSUPPORTED, "window all-reduce cannot be captured into a HIP graph");
+    uint64_t *my_slots = reinterpret_cast<uint64_t *>(reinterpret_cast<uint8_t *>(comm->win) + WIN_LINE);
+    uint32_t *status = reinterpret_cast<uint32_t *>(comm->win);
+    for (int64_t off = 0; off < count; off += AR_MAX) {
+        const int n = (int)((count - off) < AR_MAX ? (count - off) : AR_MAX);
+        comm->ar_epoch += 1;
+        window_allreduce_kernel<<<1, 64, 0, s>>>((uint64_t *const *)comm->peer_slots_dev, my_slots, status,
+                                                 buf + off, n, op, comm->nranks, comm->rank, comm->ar_epoch,
+                                                 spin_timeout_ticks());
+        HPCLA_CHECK_LAUNCH();
+    }
+    return HPCLA_OK;
+}
+
+void comm_window_free(hpcla_comm *comm)
+{
+    for (auto &m : comm->peers) window_close(&m);
+    comm->peers.clear();
+    if (comm->peer_slots_dev) (void)hipFree(comm->peer_slots_dev);
+    comm->peer_slots_dev = nullptr;
+    if (comm->win) (void)hipFree(comm->win);
+    comm->win = nullptr;
+    comm->win_attached = false;
+}
+
+}  // namespace hpcla
+
+using namespace hpcla;
+
+// ---- C ABI: communicator window ---------------------------------------------------------------------
+HPCLA_API int hpcla_comm_window_export(hpcla_comm_t *comm, uint8_t *desc_host)
+{
+    if (!comm || !desc_host) return set_error(HPCLA_ERR_INVALID, "comm_window_export: null pointer");
+    if (comm->nranks > 64)
+        return set_error(HPCLA_ERR_UNSUPPORTED, "comm_window_export: the window all-reduce supports <= 64 ranks");
+    if (!comm->win) {
+        comm->win_bytes = (size_t)WIN_LINE * (1 + 2 * (size_t)comm->nranks);
+        int rc = window_alloc(&comm->win, comm->win_bytes);
+        if (rc) return rc;
+    }
+    WindowDesc d;
+    fill_desc(&d, comm->win, comm->win_bytes);
+    if (d.bytes == 0) return set_error(HPCLA_ERR_HIP, "comm_window_export: hipIpcGetMemHandle failed");
+    memcpy(desc_host, &d, sizeof(d));
+    return HPCLA_OK;
+}
+
+HPCLA_API int hpcla_comm_window_attach(hpcla_comm_t *comm, const uint8_t *all_descs_host)
+{
+    if (!comm || !all_descs_host) return set_error(HPCLA_ERR_INVALID, "comm_window_attach: null pointer");
+    if (!comm->win) return set_error(HPCLA_ERR_INVALID, "comm_window_attach: export first");
+    if (comm->win_attached) return HPCLA_OK;
+    const int n = comm->nranks;
+    comm->peers.assign(n, PeerMap());
+    std::vector<void *> slots(n);
+    for (int r = 0; r < n; ++r) {
+        WindowDesc d;
+        memcpy(&d, all_descs_host + (size_t)r * sizeof(WindowDesc), sizeof(d));
+        if (d.bytes != comm->win_bytes) {
+            comm_window_free(comm);
+            return set_error(HPCLA_ERR_INVALID, "comm_window_attach: rank %d exported %llu bytes, expected %zu", r,
+                             (unsigned long long)d.bytes, comm->win_bytes);
+        }
+        int rc = window_open(d, r, comm->rank, comm->win, &comm->peers[r]);
+        if (rc) { comm_window_free(comm); return rc; }
+        slots[r] = reinterpret_cast<uint8_t *>(comm->peers[r].base) + WIN_LINE;
+    }
+    hipError_t e = hipMalloc((void **)&comm->peer_slots_dev, sizeof(void *) * n);
+    if (e == hipSuccess) e = hipMemcpy(comm->peer_slots_dev, slots.data(), sizeof(void *) * n, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        comm_window_free(comm);
+        return set_error(HPCLA_ERR_HIP, "comm_window_attach: %s", hipGetErrorString(e));
+    }
+    comm->win_attached = true;
+    return HPCLA_OK;
+}
+
+HPCLA_API int hpcla_comm_status(hpcla_comm_t *comm, int *timed_out)
+{
+    if (!comm || !timed_out) return set_error(HPCLA_ERR_INVALID, "comm_status: null pointer");
+    *timed_out = 0;
+    if (!comm->win) return HPCLA_OK;
+    uint32_t v = 0;
+    HPCLA_CHECK_HIP(hipMemcpy(&v, comm->win, sizeof(v), hipMemcpyDeviceToHost));
+    *timed_out = v ? 1 : 0;
+    return HPCLA_OK;
+}
+
+// ---- C ABI: halo plan window ------------------------------------------------------------------------
+HPCLA_API int hpcla_halo_plan_export(hpcla_halo_plan_t *plan, uint8_t *desc_host, int64_t *table_host)
+{
+    if (!plan || !desc_host || !table_host) return set_error(HPCLA_ERR_INVALID, "halo_plan_export: null pointer");
+    const int n = plan->comm->nranks;
+    for (int i = 0; i < HPCLA_WINDOW_TABLE_ROWS * n; ++i) table_host[i] = -1;
+    WindowDesc d;
+    fill_desc(&d, plan->win, plan->win ? plan->win_bytes : 0);
+    d.n_ghost = (uint64_t)plan->n_ghost;
+    d.nbuf = (uint32_t)plan->nbuf;
+    d.width = (uint32_t)plan->width;
+    d.n_flags = (uint32_t)plan->recv_ranks.size();
+    d.n_acks = (uint32_t)plan->send_ranks.size();
+    memcpy(desc_host, &d, sizeof(d));
+    if (!plan->win) return HPCLA_OK;           // RCCL-only plan: exports an empty descriptor
+    for (size_t j = 0; j < plan->recv_ranks.size(); ++j) {
+        const int r = plan->recv_ranks[j];
+        table_host[0 * n + r] = (int64_t)j;                    // flag line of source rank r
+        table_host[1 * n + r] = plan->recv_off[j];             // where r's segment starts in my ghost
+        table_host[3 * n + r] = plan->recv_counts[j];
+    }
+    for (size_t i = 0; i < plan->send_ranks.size(); ++i)
+        table_host[2 * n + plan->send_ranks[i]] = (int64_t)i;  // ack line of consumer rank
+    return HPCLA_OK;
+}
+
+HPCLA_API int hpcla_halo_plan_attach(hpcla_halo_plan_t *plan, const uint8_t *all_descs_host,
+                                     const int64_t *all_tables_host)
+{
+    if (!plan || !all_descs_host || !all_tables_host)
+        return set_error(HPCLA_ERR_INVALID, "halo_plan_attach: null pointer");
+    if (!plan->win) return set_error(HPCLA_ERR_INVALID, "halo_plan_attach: the plan was created without a window");
+    if (plan->attached) return HPCLA_OK;
+    hpcla_halo_plan *p = plan;
+    const int n = p->comm->nranks, me = p->comm->rank;
+    const size_t ns = p->send_ranks.size(), nr = p->recv_ranks.size();
+    auto desc_of = [&](int r) {
+        WindowDesc d;
+        memcpy(&d, all_descs_host + (size_t)r * sizeof(WindowDesc), sizeof(d));
+        return d;
+    };
+    auto table_of = [&](int r) { return all_tables_host + (size_t)r * HPCLA_WINDOW_TABLE_ROWS * n; };
+    // one mapping per distinct peer rank (a rank may be both a send and a recv neighbour)
+    std::vector<PeerMap> by_rank(n);
+    std::vector<char> have(n, 0);
+    auto map_rank = [&](int r) -> int {
+        if (have[r]) return HPCLA_OK;
+        int rc = window_open(desc_of(r), r, me, p->win, &by_rank[r]);
+        if (rc == HPCLA_OK) have[r] = 1;
+        return rc;
+    };
+    auto fail = [&](int rc) {
+        for (int r = 0; r < n; ++r)
+            if (have[r]) window_close(&by_rank[r]);
+        return rc;
+    };
+    std::vector<PushTarget> targets(ns);
+    std::vector<int32_t> bmap;
+    for (size_t i = 0; i < ns; ++i) {
+        const int q = p->send_ranks[i];
+        int rc = map_rank(q);
+        if (rc) return fail(rc);
+        const WindowDesc d = desc_of(q);
+        const int64_t *T = table_of(q);
+        const int64_t fs = T[0 * n + me], go = T[1 * n + me], cnt = T[3 * n + me];
+        if (fs < 0 || go < 0 || cnt != p->send_counts[i] || (int)d.width != p->width)
+            return fail(set_error(HPCLA_ERR_INVALID,
+                                  "halo_plan_attach: rank %d does not expect %lld entries from rank %d (has %lld)", q,
+                                  (long long)p->send_counts[i], me, (long long)cnt));
+        uint8_t *base = reinterpret_cast<uint8_t *>(by_rank[q].base);
+        const size_t ctrl = halo_ctrl_bytes(d.n_flags, d.n_acks);
+        const size_t buf = halo_buf_bytes(d.n_ghost, d.width);
+        PushTarget &t = targets[i];
+        t.ghost = reinterpret_cast<double *>(base + ctrl) + go * p->width;
+        t.buf_stride = (int64_t)(buf / sizeof(double));
+        t.flag = reinterpret_cast<uint64_t *>(base + (size_t)fs * WIN_LINE);
+        t.ack = p->acks + i * WIN_LINE_U64;
+        t.count = p->send_counts[i];
+        t.src_off = p->send_off[i];
+        t.first = p->send_contig[i] ? p->send_first[i] : -1;
+        t.nbuf = (int32_t)d.nbuf;
+        int64_t ch = (t.count * p->width + PUSH_CHUNK_DOUBLES - 1) / PUSH_CHUNK_DOUBLES;
+        if (ch < 1) ch = 1;
+        if (ch > PUSH_MAX_CHUNKS) ch = PUSH_MAX_CHUNKS;
+        t.nchunks = (int32_t)ch;
+        for (int32_t c = 0; c < t.nchunks; ++c) { bmap.push_back((int32_t)i); bmap.push_back(c); }
+    }
+    if (bmap.empty()) { bmap.push_back(-1); bmap.push_back(0); }   // acks only
+    std::vector<uint64_t *> ack_out(nr);
+    for (size_t j = 0; j < nr; ++j) {
+        const int r = p->recv_ranks[j];
+        int rc = map_rank(r);
+        if (rc) return fail(rc);
+        const WindowDesc d = desc_of(r);
+        const int64_t as = table_of(r)[2 * n + me];
+        if (as < 0)
+            return fail(set_error(HPCLA_ERR_INVALID, "halo_plan_attach: rank %d does not send to rank %d", r, me));
+        ack_out[j] = reinterpret_cast<uint64_t *>(reinterpret_cast<uint8_t *>(by_rank[r].base) +
+                                                  ((size_t)d.n_flags + (size_t)as) * WIN_LINE);
+    }
+#define ATT_HIP(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) {                                                                    \
+            push_free_device_tables(p);                                                            \
+            return fail(set_error(HPCLA_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)));  \
+        }                                                                                          \
+    } while (0)
+    auto push_free_device_tables = [](hpcla_halo_plan *q) {
+        if (q->push_desc_dev) (void)hipFree(q->push_desc_dev);
+        if (q->ack_desc_dev) (void)hipFree(q->ack_desc_dev);
+        if (q->push_block_map_dev) (void)hipFree(q->push_block_map_dev);
+        if (q->arrive) (void)hipFree(q->arrive);
+        q->push_desc_dev = q->ack_desc_dev = q->push_block_map_dev = nullptr;
+        q->arrive = nullptr;
+    };
+    ATT_HIP(hipMalloc(&p->push_desc_dev, sizeof(PushTarget) * (ns ? ns : 1)));
+    if (ns) ATT_HIP(hipMemcpy(p->push_desc_dev, targets.data(), sizeof(PushTarget) * ns, hipMemcpyHostToDevice));
+    ATT_HIP(hipMalloc(&p->ack_desc_dev, sizeof(uint64_t *) * (nr ? nr : 1)));
+    if (nr) ATT_HIP(hipMemcpy(p->ack_desc_dev, ack_out.data(), sizeof(uint64_t *) * nr, hipMemcpyHostToDevice));
+    ATT_HIP(hipMalloc(&p->push_block_map_dev, sizeof(int32_t) * bmap.size()));
+    ATT_HIP(hipMemcpy(p->push_block_map_dev, bmap.data(), sizeof(int32_t) * bmap.size(), hipMemcpyHostToDevice));
+    ATT_HIP(hipMalloc((void **)&p->arrive, sizeof(uint64_t) * (ns ? ns : 1)));
+    ATT_HIP(hipMemset(p->arrive, 0, sizeof(uint64_t) * (ns ? ns : 1)));
+#undef ATT_HIP
+    p->push_blocks = (int64_t)(bmap.size() / 2);
+    // keep the mappings (closed at destroy)
+    for (int r = 0; r < n; ++r)
+        if (have[r]) p->send_peer.push_back(by_rank[r]);
+    p->attached = true;
+    return HPCLA_OK;
+}
+
+HPCLA_API int hpcla_halo_status(hpcla_halo_plan_t *plan, int *timed_out)
+{
+    if (!plan || !timed_out) return set_error(HPCLA_ERR_INVALID, "halo_status: null pointer");
+    *timed_out = 0;
+    if (!plan->status) return HPCLA_OK;
+    uint32_t v = 0;
+    HPCLA_CHECK_HIP(hipMemcpy(&v, plan->status, sizeof(v), hipMemcpyDeviceToHost));
+    *timed_out = v ? 1 : 0;
+    return HPCLA_OK;
+}

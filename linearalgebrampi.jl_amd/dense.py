@@ -20,7 +20,8 @@ from typing import Dict, Optional
 import numpy as np
 
 from . import _capi
-from .backends import HPCBackend, assert_backends_compatible, comm_allgather, comm_rank, comm_size
+from .backends import (HPCBackend, assert_backends_compatible, attach_halo_windows, comm_allgather, comm_rank,
+                       comm_size)
 from .partition import compute_partition_hash, uniform_partition
 from .vectors import current_stream_ptr, dptr
 
@@ -274,7 +275,14 @@ def dense_matvec_t(A: HPCMatrix, x):
 _spmm_halo_cache: Dict[tuple, object] = {}
 
 
+_spmm_backends: Dict[int, HPCBackend] = {}
+
+
 def clear_spmm_cache() -> None:
+    """Collective, like clear_plan_cache! (the ranks meet before ghost windows are unmapped)."""
+    from .sparse import _quiesce
+    _quiesce(list(_spmm_backends.values()))
+    _spmm_backends.clear()
     for h in _spmm_halo_cache.values():
         if h[0]:
             _capi.call("hpcla_halo_plan_destroy", h[0])
@@ -311,6 +319,7 @@ def spmm(A, B: HPCMatrix) -> HPCMatrix:
                    A.nrows_local, A.nnz, k, 0, s)
         return out
     key = (A._ensure_hash(), probe.structural_hash, k)
+    _spmm_backends[id(backend)] = backend
     ent = _spmm_halo_cache.get(key)
     if ent is None:
         # plan time, collective (every rank, with or without neighbours): who gets whole slices
@@ -319,38 +328,40 @@ def spmm(A, B: HPCMatrix) -> HPCMatrix:
         h = plan.host
         wish = whole_slice_wishes(h, B.row_partition, nranks)
         granted = comm_alltoall_counts(backend.comm, wish)
+        Ti = np.int64 if plan.is_i64 else np.int32
+        tdt = torch.int64 if plan.is_i64 else torch.int32
         if not plan.has_halo:
+            attach_halo_windows(backend, None)          # collective: the other ranks' plans are attaching
             ent = _spmm_halo_cache[key] = (None, None, None, None, plan.colval_split)
         else:
-            if plan.is_i64:
-                raise NotImplementedError("distributed SpMM is implemented for Int32 indices")
             send_indices, recv_counts_l, cmap = whole_slice_lists(h, A.col_indices, B.row_partition, wish, granted)
             n_send, n_recv = len(h.send_rank_ids), len(h.recv_rank_ids)
             send_ranks = (ctypes.c_int32 * max(n_send, 1))(*h.send_rank_ids)
             send_counts = (ctypes.c_int64 * max(n_send, 1))(*[len(i) for i in send_indices])
             recv_ranks = (ctypes.c_int32 * max(n_recv, 1))(*h.recv_rank_ids)
             recv_counts = (ctypes.c_int64 * max(n_recv, 1))(*recv_counts_l)
-            send_idx = (torch.from_numpy(np.concatenate(send_indices).astype(np.int32)).to(dev)
+            send_idx = (torch.from_numpy(np.concatenate(send_indices).astype(Ti)).to(dev)
                         if n_send else None)
-            if plan.n_own + sum(recv_counts_l) > np.iinfo(np.int32).max:
-                raise OverflowError("split column space does not fit Int32")
+            if plan.n_own + sum(recv_counts_l) > np.iinfo(Ti).max:
+                raise OverflowError("split column space does not fit the index type")
             if wish.any():
                 # ghost positions differ from the vector plan's: a split colval copy of its own
-                cmap_dev = torch.from_numpy(cmap.astype(np.int32)).to(dev)
-                colval_split = torch.empty(A.nnz, dtype=torch.int32, device=dev)
-                _capi.call("hpcla_remap_i32", dptr(A.colval_target()), dptr(cmap_dev), dptr(colval_split), A.nnz, 0, s)
+                cmap_dev = torch.from_numpy(cmap.astype(Ti)).to(dev)
+                colval_split = torch.empty(A.nnz, dtype=tdt, device=dev)
+                _capi.call(f"hpcla_remap_{sfx}", dptr(A.colval_target()), dptr(cmap_dev), dptr(colval_split), A.nnz, 0, s)
             else:
                 colval_split = plan.colval_split
             halo = ctypes.c_void_p()
             torch.cuda.current_stream().synchronize()
             _capi.check("hpcla_halo_plan_create", _capi.load().hpcla_halo_plan_create(
-                ctypes.byref(halo), backend.rccl, n_send, send_ranks, send_counts, dptr(send_idx), 0,
-                n_recv, recv_ranks, recv_counts, k))
+                ctypes.byref(halo), backend.rccl, n_send, send_ranks, send_counts, dptr(send_idx),
+                1 if plan.is_i64 else 0, n_recv, recv_ranks, recv_counts, k))
+            attach_halo_windows(backend, halo)          # collective: push transport when all ranks share a node
             # SpMM row blocks are smaller than SpMV row blocks: classify at SpMM granularity
             rpb = _capi.load().hpcla_spmm_rows_per_block()
             nblk = (A.nrows_local + rpb - 1) // rpb
             flags_i = torch.empty(nblk, dtype=torch.int32, device=dev)
-            _capi.call("hpcla_classify_blocks_i32", dptr(A.rowptr_target), dptr(colval_split),
+            _capi.call(f"hpcla_classify_blocks_{sfx}", dptr(A.rowptr_target), dptr(colval_split),
                        A.nrows_local, 0, plan.n_own, rpb, dptr(flags_i), s)
             flags = flags_i != 0
             interior = torch.nonzero(~flags).flatten().to(torch.int32).contiguous()
@@ -365,15 +376,16 @@ def spmm(A, B: HPCMatrix) -> HPCMatrix:
     halo, interior, boundary, _, colval_split = ent
     ghost = ctypes.c_void_p()
     ng = ctypes.c_int64()
-    _capi.call("hpcla_halo_ghost_ptr", halo, ctypes.byref(ghost), ctypes.byref(ng))
     _capi.call("hpcla_halo_begin", halo, dptr(Bc), s)
+    # after begin: with the push transport the ghost window is double-buffered per exchange
+    _capi.call("hpcla_halo_ghost_ptr", halo, ctypes.byref(ghost), ctypes.byref(ng))
     if interior.numel():
-        _capi.call("hpcla_spmm_split_f64_i32", dptr(A.rowptr_target), dptr(colval_split),
+        _capi.call(f"hpcla_spmm_split_f64_{sfx}", dptr(A.rowptr_target), dptr(colval_split),
                    dptr(A.nzval), dptr(Bc), k, ghost, k, plan.n_own, dptr(C), k, A.nrows_local,
                    A.nnz, k, 0, dptr(interior), int(interior.numel()), s)
     _capi.call("hpcla_halo_end", halo, s)
     if boundary.numel():
-        _capi.call("hpcla_spmm_split_f64_i32", dptr(A.rowptr_target), dptr(colval_split),
+        _capi.call(f"hpcla_spmm_split_f64_{sfx}", dptr(A.rowptr_target), dptr(colval_split),
                    dptr(A.nzval), dptr(Bc), k, ghost, k, plan.n_own, dptr(C), k, A.nrows_local,
                    A.nnz, k, 0, dptr(boundary), int(boundary.numel()), s)
     return out

@@ -22,8 +22,8 @@ from typing import Dict, List, Optional, Tuple
 import numpy as np
 
 from . import _capi
-from .backends import (CommSerial, HPCBackend, assert_backends_compatible, comm_allgather,
-                       comm_alltoall_counts, comm_exchange_indices, comm_rank, comm_size)
+from .backends import (CommSerial, HPCBackend, assert_backends_compatible, attach_halo_windows, comm_allgather,
+                       comm_alltoall_counts, comm_barrier, comm_exchange_indices, comm_rank, comm_size)
 from .partition import (compute_partition_hash, compute_structural_hash, owner_of,
                         uniform_partition)
 from .vectors import HPCVector, current_stream_ptr, dptr
@@ -203,6 +203,9 @@ class VectorPlan:
             _capi.check("hpcla_halo_plan_create", _capi.load().hpcla_halo_plan_create(
                 ctypes.byref(self.halo), backend.rccl, n_send, send_ranks, send_counts,
                 dptr(send_idx), 1 if self.is_i64 else 0, n_recv, recv_ranks, recv_counts, 1))
+        # collective (ranks without neighbours take part with an empty descriptor): map the neighbours'
+        # ghost windows -> push transport for this plan (csrc/window.hip)
+        self.push = attach_halo_windows(backend, self.halo if self.has_halo else None)
 
         # interior / boundary row blocks
         self.interior = self.boundary = None
@@ -225,6 +228,14 @@ class VectorPlan:
         if self.has_halo:
             _capi.call("hpcla_halo_ghost_ptr", self.halo, ctypes.byref(g), ctypes.byref(n))
         return g, n.value
+
+    def timed_out(self) -> bool:
+        """True if a push-mode exchange of this plan gave up waiting for a neighbour (results invalid)."""
+        if not self.halo:
+            return False
+        flag = ctypes.c_int(0)
+        _capi.call("hpcla_halo_status", self.halo, ctypes.byref(flag))
+        return bool(flag.value)
 
     def destroy(self) -> None:
         if self.halo:
@@ -250,9 +261,24 @@ def get_vector_plan(A: "HPCSparseMatrix", x: HPCVector) -> VectorPlan:
 def clear_plan_cache() -> None:
     """``clear_plan_cache!`` (src/HPCLinearAlgebra.jl:181-201): plans are freed only here, never
     by a finaliser (a finaliser must not issue device/collective work)."""
+    _quiesce([p.backend for p in _vector_plan_cache.values()])
     for p in _vector_plan_cache.values():
         p.destroy()
     _vector_plan_cache.clear()
+
+
+def _quiesce(backends) -> None:
+    """Before plans are freed: drain this device and meet the other ranks, so that no peer is still
+    storing into (or polling) a ghost window that is about to be unmapped.  Collective, like
+    clear_plan_cache! itself."""
+    seen = set()
+    for b in backends:
+        if id(b.comm) in seen:
+            continue
+        seen.add(id(b.comm))
+        _torch().cuda.synchronize()
+        if b.peer_windows and comm_size(b.comm) > 1:
+            comm_barrier(b.comm)
 
 
 def cache_sizes() -> Dict[str, int]:

@@ -1,6 +1,8 @@
-"""GPU worker: drives hpcla_halo_* with a ONE-rank RCCL communicator that sends to itself
+"""GPU worker: drives hpcla_halo_* with a ONE-rank communicator that sends to itself
 (HPCLA_FORCE_RCCL=1), so the ncclGroup send/recv, pack kernel, side stream and event ordering of the
-multi-GPU path run on a single MI355X.  Also runs the fused hpcla_spmv_dist with that plan."""
+multi-GPU path -- or, with HPCLA_HALO_MODE=push, the peer-window push kernel, flags, acks and the
+in-kernel wait (the "peer" window being this rank's own) -- run on a single MI355X.  Also runs the fused
+hpcla_spmv_dist with that plan.  Real two-process exchanges: tests/test_gpu_multirank.py."""
 import ctypes
 import os
 import sys
@@ -17,7 +19,10 @@ def main():
     from oracle import oracle as orc
 
     assert os.environ.get("HPCLA_FORCE_RCCL") == "1"
+    from hpcla_amd.backends import attach_halo_windows
+    push = os.environ.get("HPCLA_HALO_MODE", "") == "push"
     backend = hp.backend_rocm_serial(np.float64, np.int32)
+    assert backend.peer_windows
     capi = hp._capi
     lib = capi.load()
     s = torch.cuda.current_stream().cuda_stream
@@ -32,14 +37,15 @@ def main():
         torch.cuda.synchronize()
         capi.check("create", lib.hpcla_halo_plan_create(ctypes.byref(plan), backend.rccl, 1, ranks, counts,
                                                        idx.data_ptr(), 0, 1, ranks, counts, width))
+        assert attach_halo_windows(backend, plan) == push
         ghost = ctypes.c_void_p(); ng = ctypes.c_int64()
-        capi.call("hpcla_halo_ghost_ptr", plan, ctypes.byref(ghost), ctypes.byref(ng))
-        assert ng.value == len(idx_np)
-        for rep in range(3):                       # repeated use: WAR ordering of the ghost buffer
+        for rep in range(5):                       # repeated use: WAR ordering of the ghost buffer(s)
             xs = xsrc * (rep + 1.0)
             capi.call("hpcla_halo_begin", plan, xs.data_ptr(), s)
             busy = torch.ones(1 << 20, device="cuda").cumsum(0)      # overlapping work on the main stream
             capi.call("hpcla_halo_end", plan, s)
+            capi.call("hpcla_halo_ghost_ptr", plan, ctypes.byref(ghost), ctypes.byref(ng))   # buffer of THIS exchange
+            assert ng.value == len(idx_np)
             # read the ghost buffer on the main stream (ordered after halo_end)
             tmp = torch.empty(len(idx_np) * width, dtype=torch.float64, device="cuda")
             ident = torch.arange(len(idx_np) * width, dtype=torch.int64, device="cuda")
@@ -47,6 +53,9 @@ def main():
             torch.cuda.synchronize()
             want = xs.view(-1, width)[torch.from_numpy(idx_np).cuda()].reshape(-1)
             assert torch.equal(tmp, want), f"ghost mismatch (width={width}, rep={rep})"
+        st = ctypes.c_int(0)
+        capi.call("hpcla_halo_status", plan, ctypes.byref(st))
+        assert st.value == 0, "push/wait timed out"
         capi.call("hpcla_halo_plan_destroy", plan)
 
     rng = np.random.default_rng(0)
@@ -84,6 +93,7 @@ def main():
     torch.cuda.synchronize()
     capi.check("create", lib.hpcla_halo_plan_create(ctypes.byref(plan), backend.rccl, 1, ranks, counts,
                                                    d_idx.data_ptr(), 0, 1, ranks, counts, 1))
+    assert attach_halo_windows(backend, plan) == push
     d_rp = torch.from_numpy(rows.rowptr.astype(np.int32)).cuda()
     d_cv = torch.from_numpy(ci[cv].astype(np.int32)).cuda()    # split columns: own < nloc, ghosts nloc+g
     d_nz = torch.from_numpy(rows.vals).cuda()
@@ -96,7 +106,7 @@ def main():
     boundary = torch.nonzero(flags != 0).flatten().to(torch.int32)
     assert boundary.numel() == nx // rpb and interior.numel() == nblk - nx // rpb
     y = torch.full((nloc,), float("nan"), dtype=torch.float64, device="cuda")
-    for rep in range(3):
+    for rep in range(5):
         capi.call("hpcla_spmv_dist_f64_i32", plan, d_rp.data_ptr(), d_cv.data_ptr(), d_nz.data_ptr(),
                   d_x.data_ptr(), nloc, y.data_ptr(), nloc, rows.nnz, 0, interior.data_ptr(), interior.numel(),
                   boundary.data_ptr(), boundary.numel(), s)

@@ -1,0 +1,162 @@
+"""Worker for tests/test_gpu_multirank.py: ONE process per rank (started by hpcla_amd launch.spawn_ranks),
+every rank on GPU ``LOCAL_RANK % device_count`` -- with fewer GPUs than ranks the ranks SHARE a GPU, which
+the peer-window transport supports (RCCL does not: "Duplicate GPU detected").
+
+Checks, each against the CPU oracle on identical inputs and therefore against the 1-rank result too
+(the 1-rank GPU product is bit-equal to the oracle, tests/test_gpu_parity.py):
+  * y = A*x distributed, bit-exact, for a stencil slab (contiguous sends), an unstructured matrix
+    (scattered sends, asymmetric neighbour sets) and x partitioned differently from A's rows;
+  * 40 dependent steps x <- A*x/8 (free-running: exercises epochs, double buffering and acks);
+  * dot / norm: 1e-12 relative to the oracle AND bit-identical on all ranks;
+  * CG, 12 iterations, fused and unfused, residual history vs the oracle;
+  * A*B with k = 16 and k = 3 dense columns (distributed SpMM), Int32 and Int64;
+  * mul_dot_ (fused SpMV + p.Ap);
+  * no push/wait timed out.
+Exit code 0 = all passed on this rank."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+    import hpcla_amd as hp
+    from hpcla_amd import backends as B
+    from oracle import oracle as orc
+
+    dist.init_process_group("gloo")
+    rank, nranks = dist.get_rank(), dist.get_world_size()
+    ndev = torch.cuda.device_count()
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", rank)) % ndev)
+    mode = os.environ.get("HPCLA_HALO_MODE", "(default)")
+
+    def allgather_f64(v):
+        flat = B.comm_allgather(comm, np.ascontiguousarray(v, dtype=np.float64).view(np.int64))
+        return flat.view(np.float64)
+
+    for Ti in (np.int32, np.int64):
+        backend = hp.backend_rocm_mpi(np.float64, Ti)
+        comm = backend.comm
+        tag = f"[rank {rank}/{nranks} {np.dtype(Ti).name} mode={mode} windows={backend.peer_windows}]"
+
+        cases = []
+        # stencil slab: rows partitioned uniformly, 2 boundary lines per interior rank
+        nx, ny = 512, 6 * nranks + 3
+        n = nx * ny
+        cases.append(("poisson2d", n, lambda lo, hi: orc.poisson2d_rows(nx, ny, lo, hi),
+                      orc.uniform_partition(n, nranks), orc.uniform_partition(n, nranks)))
+        # unstructured: every rank talks to every rank, scattered indices
+        n2 = 30000
+        cases.append(("sprand", n2, lambda lo, hi: orc.sprand_rows(n2, 0.0015, lo, hi),
+                      orc.uniform_partition(n2, nranks), orc.uniform_partition(n2, nranks)))
+        # x partitioned differently from the rows (A*x accepts any partition of x, src/sparse.jl:2096-2128)
+        n3 = 20000
+        xp3 = np.array([0] + [min(n3, 700 + (n3 * r) // nranks) for r in range(1, nranks)] + [n3])
+        cases.append(("sprand_xpart", n3, lambda lo, hi: orc.sprand_rows(n3, 0.002, lo, hi),
+                      orc.uniform_partition(n3, nranks), xp3))
+
+        for name, ng, gen, rp, xp in cases:
+            lo, hi = int(rp[rank]), int(rp[rank + 1])
+            rows = gen(lo, hi)
+            A = hp.HPCSparseMatrix_local(rows.rowptr, rows.colidx, rows.vals, ng, backend)
+            assert np.array_equal(A.row_partition, rp)
+            xg = orc.fill_uniform(0, ng, orc.SEED_X)
+            x = hp.HPCVector.from_global(xg, backend, partition=xp)
+            ci, cv = orc.compress_columns(rows)
+            want = orc.spmv(rows.rowptr.astype(Ti), cv.astype(Ti), rows.vals, xg[ci])
+            y = A @ x
+            torch.cuda.synchronize()
+            got = y.local_values()
+            assert np.array_equal(got, want), f"{tag} {name}: A*x differs, max err {np.abs(got - want).max()}"
+            plan = hp.get_vector_plan(A, x)
+            if nranks > 1 and mode in ("(default)", "push") and backend.peer_windows:
+                assert plan.push or not plan.has_halo, f"{tag} {name}: push transport not attached"
+            # repeated in-place products (same x): ghost buffers are reused / double-buffered
+            for _ in range(5):
+                hp.mul_(y, A, x)
+            torch.cuda.synchronize()
+            assert np.array_equal(y.local_values(), want), f"{tag} {name}: repeated mul! differs"
+            assert not plan.timed_out(), f"{tag} {name}: a push/wait timed out"
+
+            if name == "sprand_xpart":
+                continue
+            # dependent steps: x_{k+1} = A x_k / 8, no host sync in between
+            xs = hp.HPCVector.from_global(xg, backend, partition=rp)
+            ys = xs.similar()
+            steps = 40
+            for _ in range(steps):
+                hp.mul_(ys, A, xs)
+                xs.v.copy_(ys.v)
+                xs.v.mul_(0.125)
+            torch.cuda.synchronize()
+            assert not hp.get_vector_plan(A, xs).timed_out(), f"{tag} {name}: timed out in the dependent loop"
+            # oracle: the same recurrence on the GLOBAL vector (every rank can afford it at this size)
+            rows_all = gen(0, ng)
+            ci_all, cv_all = orc.compress_columns(rows_all)
+            xr = xg.copy()
+            for _ in range(steps):
+                xr = orc.spmv(rows_all.rowptr.astype(Ti), cv_all.astype(Ti), rows_all.vals, xr[ci_all]) * 0.125
+            assert np.array_equal(xs.local_values(), xr[lo:hi]), f"{tag} {name}: dependent steps differ"
+
+            # dot / norm: tolerance vs the oracle, identical bits across ranks
+            yv = hp.HPCVector.from_global(orc.fill_uniform(0, ng, orc.SEED_RHS), backend, partition=rp)
+            xv = hp.HPCVector.from_global(xg, backend, partition=rp)
+            d = hp.dot(xv, yv)
+            nr = hp.norm(xv)
+            yg = orc.fill_uniform(0, ng, orc.SEED_RHS)
+            d_ref = orc.dot([xg], [yg])
+            n_ref = orc.norm([xg])
+            assert abs(d - d_ref) <= 1e-12 * abs(d_ref), (tag, name, d, d_ref)
+            assert abs(nr - n_ref) <= 1e-12 * abs(n_ref), (tag, name, nr, n_ref)
+            alld = allgather_f64(np.array([d, nr]))
+            assert all(alld[2 * r] == d and alld[2 * r + 1] == nr for r in range(nranks)), \
+                f"{tag} {name}: dot/norm not uniform across ranks: {alld}"
+
+            if name == "poisson2d":
+                # CG (SPD matrix): 12 iterations, both forms, vs the oracle's restatement
+                bg = orc.fill_uniform(0, ng, orc.SEED_RHS)
+                b = hp.HPCVector.from_global(bg, backend, partition=rp)
+                _, hist_ref = orc.cg(rows_all.rowptr.astype(Ti), cv_all.astype(Ti), rows_all.vals, bg, 12)
+                for fused in (True, False):
+                    xc, hist = hp.cg_fixed_iterations(A, b, 12, fused=fused)
+                    assert np.allclose(hist, hist_ref, rtol=1e-9, atol=0), (tag, fused, hist, hist_ref)
+                # fused SpMV + p.Ap
+                out = torch.zeros(1, dtype=torch.float64, device="cuda")
+                yy = xv.similar()
+                hp.mul_dot_(yy, A, xv, out)
+                torch.cuda.synchronize()
+                y_all = orc.spmv(rows_all.rowptr.astype(Ti), cv_all.astype(Ti), rows_all.vals, xg[ci_all])
+                assert np.array_equal(yy.local_values(), y_all[lo:hi])
+                pAp_ref = orc.dot([xg], [y_all])
+                assert abs(out.item() - pAp_ref) <= 1e-12 * float(np.abs(xg) @ np.abs(y_all)), (out.item(), pAp_ref)
+
+            # distributed SpMM: k dense columns, row-major on the device
+            for k in (16, 3):
+                Bg = orc.fill_uniform(0, ng * k, 4711).reshape(ng, k)
+                Bl = torch.from_numpy(np.ascontiguousarray(Bg[lo:hi])).cuda()
+                Bm = hp.HPCMatrix_local(Bl, backend)
+                C = A @ Bm
+                torch.cuda.synchronize()
+                Cw = orc.spmm(rows.rowptr.astype(Ti), cv.astype(Ti), rows.vals, np.ascontiguousarray(Bg[ci]))
+                assert np.array_equal(C.A.cpu().numpy(), Cw), f"{tag} {name}: A*B (k={k}) differs"
+                C2 = A @ Bm                                      # cached plan, second exchange
+                torch.cuda.synchronize()
+                assert np.array_equal(C2.A.cpu().numpy(), Cw), f"{tag} {name}: second A*B (k={k}) differs"
+        flag = __import__("ctypes").c_int(0)
+        hp._capi.call("hpcla_comm_status", backend.rccl, __import__("ctypes").byref(flag))
+        assert flag.value == 0, f"{tag}: a window all-reduce timed out"
+        hp.clear_spmm_cache()
+        hp.clear_plan_cache()
+        print(f"{tag} OK", flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

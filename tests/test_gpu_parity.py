@@ -305,7 +305,7 @@ def test_execute_plan_gathered_serial(hp, orc, gpu_backend_i32):
     assert A.ncols_compressed < n
 
 
-@pytest.mark.parametrize("mode", ["serial", "overlap"])
+@pytest.mark.parametrize("mode", ["serial", "overlap", "push"])
 def test_rccl_halo_self_exchange_subprocess(mode):
     """The RCCL send/recv + side-stream + event code of hpcla_halo_begin/end and both orderings of the
     fused distributed SpMV (HPCLA_HALO_MODE: exchange on the caller's stream then one launch / exchange
