@@ -251,6 +251,11 @@ int hpcla_allreduce_f64(hpcla_comm_t *comm, double *buf, int64_t count, int op, 
 #define HPCLA_WINDOW_DESC_BYTES 128
 int hpcla_comm_window_export(hpcla_comm_t *comm, uint8_t *desc_host /* 128 bytes out */);
 int hpcla_comm_window_attach(hpcla_comm_t *comm, const uint8_t *all_descs_host /* nranks x 128 bytes */);
+/* Connection test after attach: all-reduce of (rank+1) through the windows with its own timeout;
+ * *ok = 1 iff it arrived complete.  The host layer all-gathers `ok`; unless every rank passed, every rank
+ * calls hpcla_comm_window_detach and the data path stays on RCCL.  Synchronises the device. */
+int hpcla_comm_window_selftest(hpcla_comm_t *comm, double timeout_s, int *ok);
+int hpcla_comm_window_detach(hpcla_comm_t *comm);
 /* 1 in *timed_out if a window all-reduce gave up waiting for a peer (HPCLA_PUSH_TIMEOUT_S, default 20 s);
  * synchronises a 4-byte device read. */
 int hpcla_comm_status(hpcla_comm_t *comm, int *timed_out);
@@ -299,6 +304,8 @@ int hpcla_halo_plan_destroy(hpcla_halo_plan_t *plan);
 int hpcla_halo_plan_export(hpcla_halo_plan_t *plan, uint8_t *desc_host, int64_t *table_host);
 int hpcla_halo_plan_attach(hpcla_halo_plan_t *plan, const uint8_t *all_descs_host,
                            const int64_t *all_tables_host);
+/* give up the push transport of this plan (some rank failed to attach): RCCL receives into the ghost */
+int hpcla_halo_plan_detach(hpcla_halo_plan_t *plan);
 /* 1 in *timed_out if a push or wait of this plan gave up (result invalid); synchronising 4-byte read. */
 int hpcla_halo_status(hpcla_halo_plan_t *plan, int *timed_out);
 /* device pointer of the ghost buffer (n_ghost*width doubles) and its length in indices */

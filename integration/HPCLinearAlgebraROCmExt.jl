@@ -84,7 +84,42 @@ function _rccl(comm::AbstractComm)
     h = Ref{Ptr{Cvoid}}(C_NULL)
     _check(@ccall(LIB.hpcla_comm_init_rank(h::Ptr{Ptr{Cvoid}}, id::Ptr{UInt8}, nranks::Cint, rank::Cint)::Cint),
            "hpcla_comm_init_rank")
+    nranks > 1 && _attach_comm_window(h[], comm.comm, nranks)
     return _comms[key] = h[]
+end
+
+# ---- peer windows (push transport over xGMI, csrc/window.hip): same bootstrap pattern as the unique id --
+# every rank exports a 128-byte descriptor, MPI all-gathers them, every rank attaches; then a connection
+# test whose verdict is all-gathered too, so that either every rank uses the windows or none does.
+const _windows_ok = Dict{Ptr{Cvoid},Bool}()
+function _attach_comm_window(h::Ptr{Cvoid}, mpicomm::MPI.Comm, nranks::Int)
+    desc = zeros(UInt8, 128)
+    _check(@ccall(LIB.hpcla_comm_window_export(h::Ptr{Cvoid}, desc::Ptr{UInt8})::Cint), "hpcla_comm_window_export")
+    descs = MPI.Allgather(desc, mpicomm)
+    one_node = all(i -> descs[65 + 128*(i-1) : 72 + 128*(i-1)] == descs[65:72], 1:nranks)   # bytes 64..71: node identity
+    ok = Ref{Cint}(0)
+    if one_node && (@ccall LIB.hpcla_comm_window_attach(h::Ptr{Cvoid}, descs::Ptr{UInt8})::Cint) == 0
+        @ccall LIB.hpcla_comm_window_selftest(h::Ptr{Cvoid}, 10.0::Cdouble, ok::Ptr{Cint})::Cint
+    end
+    good = minimum(MPI.Allgather(Int32[ok[]], mpicomm)) == 1
+    good || _check(@ccall(LIB.hpcla_comm_window_detach(h::Ptr{Cvoid})::Cint), "hpcla_comm_window_detach")
+    return _windows_ok[h] = good
+end
+
+# plan-time, collective over the communicator (ranks without neighbours pass halo == C_NULL)
+function _attach_halo_window(h::Ptr{Cvoid}, halo::Ptr{Cvoid}, mpicomm::MPI.Comm, nranks::Int)
+    get(_windows_ok, h, false) || return false
+    desc = zeros(UInt8, 128); table = fill(Int64(-1), 4 * nranks)
+    halo == C_NULL || _check(@ccall(LIB.hpcla_halo_plan_export(halo::Ptr{Cvoid}, desc::Ptr{UInt8}, table::Ptr{Int64})::Cint),
+                             "hpcla_halo_plan_export")
+    descs = MPI.Allgather(desc, mpicomm); tables = MPI.Allgather(table, mpicomm)
+    mine = halo != C_NULL && any(!=(0x00), desc[81:88])            # bytes 80..87: window size
+    ok = !mine || (@ccall LIB.hpcla_halo_plan_attach(halo::Ptr{Cvoid}, descs::Ptr{UInt8}, tables::Ptr{Int64})::Cint) == 0
+    if minimum(MPI.Allgather(Int32[ok ? 1 : 0], mpicomm)) == 0
+        mine && ok && _check(@ccall(LIB.hpcla_halo_plan_detach(halo::Ptr{Cvoid})::Cint), "hpcla_halo_plan_detach")
+        return false
+    end
+    return mine
 end
 
 # ---- device half of the VectorPlan, cached next to the reference plan -----------------------------------
@@ -131,18 +166,25 @@ function _device_plan(A::HPCSparseMatrix{T,Ti,B}, x::HPCVector{T,B}, plan) where
                    1::Cint)::Cint), "hpcla_halo_plan_create")
             rpb = @ccall LIB.hpcla_spmv_rows_per_block()::Cint
             flags = AMDGPU.zeros(Int32, cld(A.nrows_local, rpb))
+            # `split` is 0-based (hpcla_remap output) while A.rowptr_target is 1-based: the classifier applies
+            # ONE index_base to both arrays, so it gets the 0-based rowptr copy and index_base = 0 -- with
+            # base 1 the first ghost column (== n_own) would count as owned and its row block as interior
+            rp0 = _rowptr0(A)
             if Ti === Int32
-                _check(@ccall(LIB.hpcla_classify_blocks_i32(_ptr(A.rowptr_target)::Ptr{Cvoid}, _ptr(split)::Ptr{Cvoid},
-                       A.nrows_local::Int64, 1::Cint, n_own::Int64, rpb::Cint, _ptr(flags)::Ptr{Cvoid},
+                _check(@ccall(LIB.hpcla_classify_blocks_i32(_ptr(rp0)::Ptr{Cvoid}, _ptr(split)::Ptr{Cvoid},
+                       A.nrows_local::Int64, 0::Cint, n_own::Int64, rpb::Cint, _ptr(flags)::Ptr{Cvoid},
                        _stream()::Ptr{Cvoid})::Cint), "hpcla_classify_blocks_i32")
             else
-                _check(@ccall(LIB.hpcla_classify_blocks_i64(_ptr(A.rowptr_target)::Ptr{Cvoid}, _ptr(split)::Ptr{Cvoid},
-                       A.nrows_local::Int64, 1::Cint, n_own::Int64, rpb::Cint, _ptr(flags)::Ptr{Cvoid},
+                _check(@ccall(LIB.hpcla_classify_blocks_i64(_ptr(rp0)::Ptr{Cvoid}, _ptr(split)::Ptr{Cvoid},
+                       A.nrows_local::Int64, 0::Cint, n_own::Int64, rpb::Cint, _ptr(flags)::Ptr{Cvoid},
                        _stream()::Ptr{Cvoid})::Cint), "hpcla_classify_blocks_i64")
             end
             f = Array(flags)
             interior = ROCVector(Int32.(findall(==(0), f) .- 1)); boundary = ROCVector(Int32.(findall(!=(0), f) .- 1))
         end
+        # collective: map the neighbours' ghost windows (push transport); a no-op without attached windows
+        A.backend.comm isa CommMPI &&
+            _attach_halo_window(_rccl(A.backend.comm), halo[], A.backend.comm.comm, comm_size(A.backend.comm))
         ROCVectorPlan{Ti}(halo[], split, interior, boundary, n_own)
     end
 end

@@ -66,6 +66,9 @@ _SIGNATURES = {
     "hpcla_comm_window_export": [_vp, _vp],
     "hpcla_comm_window_attach": [_vp, _vp],
     "hpcla_comm_status": [_vp, _vp],
+    "hpcla_comm_window_selftest": [_vp, _f64, _vp],
+    "hpcla_comm_window_detach": [_vp],
+    "hpcla_halo_plan_detach": [_vp],
     "hpcla_device_identity": [_i32, _vp],
     "hpcla_halo_plan_export": [_vp, _vp, _vp],
     "hpcla_halo_plan_attach": [_vp, _vp, _vp],

@@ -367,11 +367,33 @@ def _make_rccl(comm: AbstractComm, device_index: int = 0):
         _capi.call("hpcla_comm_window_export", handle, desc)
         descs, one_node = allgather_window_descs(comm, bytes(desc))
         if one_node:
+            # map every rank's window, then prove the path: an all-reduce of (rank+1) through the windows.
+            # Every rank learns every rank's verdict; unless all passed, all detach and stay on RCCL.
             blob = (ctypes.c_uint8 * (_capi.WINDOW_DESC_BYTES * nranks)).from_buffer_copy(b"".join(descs))
-            _capi.call("hpcla_comm_window_attach", handle, blob)
-            return handle, True, need_id
+            ok = ctypes.c_int(0)
+            why = ""
+            try:
+                _capi.call("hpcla_comm_window_attach", handle, blob)
+                attached = True
+            except _capi.HPCLAError as exc:
+                attached, why = False, str(exc)
+            if bool(comm_allgather(comm, np.array([1 if attached else 0])).min()):
+                try:
+                    _capi.call("hpcla_comm_window_selftest", handle, 10.0, ctypes.byref(ok))
+                except _capi.HPCLAError as exc:
+                    why = str(exc)
+            verdicts = comm_allgather(comm, np.array([ok.value], dtype=np.int64))
+            if bool(verdicts.min()):
+                return handle, True, need_id
+            _capi.call("hpcla_comm_window_detach", handle)
+            if rank == 0:
+                import sys
+                sys.stderr.write("hpcla: peer windows unavailable (ranks that failed: "
+                                 f"{np.flatnonzero(verdicts == 0).tolist()}{'; ' + why if why else ''}); "
+                                 "the data path stays on RCCL\n")
         if flags & _capi.COMM_NO_RCCL:
-            raise RuntimeError("ranks span several nodes and RCCL is disabled: no data-path transport left")
+            raise RuntimeError("no data-path transport left: RCCL is disabled (ranks share a GPU or HPCLA_NO_RCCL=1) "
+                               "and the peer windows could not be attached")
     return handle, False, need_id
 
 
@@ -392,12 +414,26 @@ def attach_halo_windows(backend: "HPCBackend", halo) -> bool:
         _capi.call("hpcla_halo_plan_export", halo, desc, table)
     descs = comm_allgather_bytes(comm, bytes(desc))
     tables = comm_allgather(comm, np.frombuffer(bytes(table), dtype=np.int64))
-    if not halo or int.from_bytes(bytes(desc)[80:88], "little") == 0:      # this rank exported no window
+    mine = bool(halo) and int.from_bytes(bytes(desc)[80:88], "little") != 0     # this rank exported a window
+    ok, why = True, ""
+    if mine:
+        blob = (ctypes.c_uint8 * (_capi.WINDOW_DESC_BYTES * n)).from_buffer_copy(b"".join(descs))
+        tab = (ctypes.c_int64 * len(tables))(*tables.tolist())
+        try:
+            _capi.call("hpcla_halo_plan_attach", halo, blob, tab)
+        except _capi.HPCLAError as exc:
+            ok, why = False, str(exc)
+    # every rank learns whether every rank attached: a plan is pushed into by ALL its neighbours or by none
+    if not bool(comm_allgather(comm, np.array([1 if ok else 0])).min()):
+        if mine and ok:
+            _capi.call("hpcla_halo_plan_detach", halo)
+        if not backend.has_rccl:
+            raise RuntimeError(f"halo windows could not be attached and there is no RCCL transport: {why}")
+        if why:
+            import sys
+            sys.stderr.write(f"hpcla: halo plan stays on RCCL: {why}\n")
         return False
-    blob = (ctypes.c_uint8 * (_capi.WINDOW_DESC_BYTES * n)).from_buffer_copy(b"".join(descs))
-    tab = (ctypes.c_int64 * len(tables))(*tables.tolist())
-    _capi.call("hpcla_halo_plan_attach", halo, blob, tab)
-    return True
+    return mine
 
 
 def backend_rocm_serial(T=np.float64, Ti=np.int64, device_index: int = 0) -> HPCBackend:

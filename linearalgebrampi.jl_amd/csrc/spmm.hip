@@ -14,6 +14,8 @@
 //
 // Generic strides are accepted for B and C (column-major = Julia Matrix), the row-major form is
 // the fast one.  Algorithmic bytes: 12 B/nnz + 4 B/row + 8k B/row (C) + 8k B per B row touched.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace hpcla {
@@ -143,32 +145,42 @@ __global__ __launch_bounds__(TPB_MM) void spmm_rowblock_kernel(
 
 // Vector form for the device-native layout (row-major B and C, k a multiple of 4, 16-byte aligned):
 // FOUR lanes share a matrix row, each owns four adjacent output columns and reads its 32-byte slice of
-// a B row with two 16-byte loads.  Per stored entry a lane now issues 2 loads and 8 flops instead of
-// 1 load and 2 flops behind the same address / predicate arithmetic -- the 8-byte-per-lane form above
-// is bound by instruction issue (~11 instructions per multiply-add), not by memory.  A workgroup still
-// owns 64 rows (one lane-group each), entries staged through LDS as 32-bit column ids; the entry loop
-// advances two entries per step (4 independent 16-byte loads per lane).  Deeper unrolling was slower:
-// 60 registers keep 7-8 wavefronts per SIMD resident, 96 (four entries per step) only 5.  Measured on
-// one box (profiles/r01_spmm_variants.log), 8-byte form -> this form: 5-point matrix x 16 columns
-// 1.043 -> 0.643 ms; config 5's random pattern with the 2.1 GB gather set 1.622 -> 1.516 ms; random with
-// B inside the Infinity Cache 1.247 -> 1.275 ms.  Also tried and dropped: no LDS staging (entries handed
-// round a lane-group with shuffles: 0.99 / 1.34 / 1.56 ms) and an XCD-sliced block order (1.03 / 1.24 /
-// 1.63 ms).  Each output column is still accumulated entry by entry in stored order: same bits.
+// a B row with two 16-byte loads: per stored entry a lane issues 2 loads and 8 flops.  A workgroup owns 64
+// rows (one lane-group each).
+//
+// Instruction diet (round 2).  The round-1 form of this kernel staged 32-bit column ids and let every one
+// of a row's four lanes redo, per entry, the own/ghost select, the 64-bit row-stride multiply and the
+// pointer add, next to per-element tail predicates: 1.06e8 VALU wave-instructions on the 5-point matrix x 16
+// columns where the arithmetic needs 2.1e7 (profiles/r01_pmc_spmm_vec_stencil.txt), 0.52 of the HBM
+// roofline.  Now the staging pass -- which touches every entry ONCE -- resolves it to the ADDRESS of its
+// B row and parks {address, value} as one 16-byte LDS record; a lane's inner step is then: one
+// ds_read_b128, one 64-bit add of its (loop-invariant) column byte offset, two 16-byte loads, eight
+// flops.  Tail handling is outside the loop (pairs, then at most one single), so there are no per-element
+// predicates.  Each output column is still accumulated entry by entry in stored order: same bits.
+// Also tried in round 1 and dropped: no LDS staging (entries handed round a lane-group with shuffles) and an
+// XCD-sliced block order.
 constexpr int VG = 4;                        // lanes per row
 constexpr int VCPL = KT / VG;                // 4 columns per lane
-constexpr int VU = 2;                        // entries per step: 4 independent 16-byte loads per lane
+// records staged per pass (template CH): 1536 * 16 B = 24 KiB (6 workgroups per CU), or 512 * 16 B = 8 KiB
+// for matrices with <= 8 entries per row on average, whose 64-row blocks fit one small pass (8 per CU)
 
 typedef double vdouble2 __attribute__((ext_vector_type(2)));
 
-template <typename I, bool SPLIT>
+struct __attribute__((aligned(16))) SpmmEntry {
+    const double *row;                       // start of the entry's B row (own block or ghost segment)
+    double val;
+};
+
+typedef const vdouble2 __attribute__((address_space(1))) *gvec2_ptr;   // global address space: global_load, not flat_load
+
+template <typename I, bool SPLIT, int VU, int CHUNK_V>
 __global__ __launch_bounds__(TPB_MM) void spmm_rowblock_vec_kernel(
     const I *__restrict__ rowptr, const I *__restrict__ colval, const double *__restrict__ nzval,
     const double *__restrict__ B_own, int64_t b_rs, const double *__restrict__ B_ghost, int64_t bg_rs,
     int64_t n_own, double *__restrict__ C, int64_t c_rs, int64_t nrows, int k, int base,
     const int32_t *__restrict__ block_list, uint32_t nblocks)
 {
-    __shared__ double s_val[CHUNK_MM];
-    __shared__ int32_t s_col[CHUNK_MM];     // own: row of B; ghost: -(1 + ghost row)
+    __shared__ SpmmEntry s_ent[CHUNK_V];
 
     const int tid = threadIdx.x;
     const int g = tid / VG, l = tid % VG;   // g = row of the block (0..63)
@@ -188,55 +200,54 @@ __global__ __launch_bounds__(TPB_MM) void spmm_rowblock_vec_kernel(
     for (int kt = 0; kt < k; kt += KT) {
         const int c = kt + VCPL * l;
         const bool col_ok = c < k;
+        const int64_t lane_bytes = (int64_t)c * (int64_t)sizeof(double);   // this lane's slice of every B row
         double acc[VCPL];
 #pragma unroll
         for (int q = 0; q < VCPL; ++q) acc[q] = 0.0;
 
-        for (int64_t ch = 0; ch < total; ch += CHUNK_MM) {
-            const int n = (int)((total - ch) < CHUNK_MM ? (total - ch) : CHUNK_MM);
+        for (int64_t ch = 0; ch < total; ch += CHUNK_V) {
+            const int n = (int)((total - ch) < CHUNK_V ? (total - ch) : CHUNK_V);
             __syncthreads();   // previous pass finished reading LDS
             for (int i = tid; i < n; i += TPB_MM) {
                 const int64_t col = (int64_t)__builtin_nontemporal_load(colval + p0 + ch + i) - base;
-                s_val[i] = __builtin_nontemporal_load(nzval + p0 + ch + i);
-                s_col[i] = (SPLIT && col >= n_own) ? (int32_t)(-(1 + (col - n_own))) : (int32_t)col;
+                SpmmEntry e;
+                e.val = __builtin_nontemporal_load(nzval + p0 + ch + i);
+                e.row = (SPLIT && col >= n_own) ? B_ghost + (col - n_own) * bg_rs : B_own + col * b_rs;
+                s_ent[i] = e;
             }
             __syncthreads();
             if (!col_ok) continue;
-            const int a = (int)((lo > ch ? lo : ch) - ch);
+            int j = (int)((lo > ch ? lo : ch) - ch);
             const int e = (int)((hi < ch + n ? hi : ch + n) - ch);
-            for (int j = a; j < e; j += VU) {
-                int32_t cj[VU];
-                double v[VU];
-                bool ok[VU];
+            // VU entries per step: 2*VU independent 16-byte loads in flight per lane
+            for (; j + VU <= e; j += VU) {
+                SpmmEntry en[VU];
                 vdouble2 b0[VU], b1[VU];
 #pragma unroll
+                for (int u = 0; u < VU; ++u) en[u] = s_ent[j + u];
+#pragma unroll
                 for (int u = 0; u < VU; ++u) {
-                    ok[u] = j + u < e;
-                    const int idx = ok[u] ? j + u : j;
-                    cj[u] = s_col[idx];
-                    v[u] = s_val[idx];
+                    const char *src = reinterpret_cast<const char *>(en[u].row) + lane_bytes;
+                    b0[u] = *(gvec2_ptr)(src);
+                    b1[u] = *(gvec2_ptr)(src + 16);
                 }
 #pragma unroll
                 for (int u = 0; u < VU; ++u) {
-                    b0[u] = (vdouble2)(0.0);
-                    b1[u] = (vdouble2)(0.0);
-                    if (ok[u]) {
-                        const double *src = (SPLIT && cj[u] < 0)
-                                                ? B_ghost + (int64_t)(-cj[u] - 1) * bg_rs + c
-                                                : B_own + (int64_t)cj[u] * b_rs + c;
-                        b0[u] = *reinterpret_cast<const vdouble2 *>(src);
-                        b1[u] = *reinterpret_cast<const vdouble2 *>(src + 2);
-                    }
+                    acc[0] += en[u].val * b0[u].x;
+                    acc[1] += en[u].val * b0[u].y;
+                    acc[2] += en[u].val * b1[u].x;
+                    acc[3] += en[u].val * b1[u].y;
                 }
-#pragma unroll
-                for (int u = 0; u < VU; ++u) {
-                    if (ok[u]) {
-                        acc[0] += v[u] * b0[u].x;
-                        acc[1] += v[u] * b0[u].y;
-                        acc[2] += v[u] * b1[u].x;
-                        acc[3] += v[u] * b1[u].y;
-                    }
-                }
+            }
+            for (; j < e; ++j) {              // at most VU-1 leftovers
+                const SpmmEntry en = s_ent[j];
+                const char *src = reinterpret_cast<const char *>(en.row) + lane_bytes;
+                const vdouble2 b0 = *(gvec2_ptr)(src);
+                const vdouble2 b1 = *(gvec2_ptr)(src + 16);
+                acc[0] += en.val * b0.x;
+                acc[1] += en.val * b0.y;
+                acc[2] += en.val * b1.x;
+                acc[3] += en.val * b1.y;
             }
         }
         if (g < nr && col_ok) {
@@ -311,17 +322,31 @@ static int spmm_launch(const I *rowptr, const I *colval, const double *nzval, co
     const bool vec_ok = b_cs == 1 && c_cs == 1 && (k % 4) == 0 && (b_rs % 2) == 0 && (c_rs % 2) == 0 &&
                         (!split || (bg_rs % 2) == 0) &&
                         ((reinterpret_cast<uintptr_t>(B_own) | reinterpret_cast<uintptr_t>(C) |
-                          (split ? reinterpret_cast<uintptr_t>(B_ghost) : 0)) & 15) == 0 &&
-                        sizeof(I) == 4;
+                          (split ? reinterpret_cast<uintptr_t>(B_ghost) : 0)) & 15) == 0;
     if (vec_ok) {
-        if (split)
-            spmm_rowblock_vec_kernel<I, true><<<grid, block, 0, s>>>(
-                rowptr, colval, nzval, B_own, b_rs, B_ghost, bg_rs, n_own, C, c_rs, nrows, k, index_base,
-                block_list, (uint32_t)launch_blocks);
-        else
-            spmm_rowblock_vec_kernel<I, false><<<grid, block, 0, s>>>(
-                rowptr, colval, nzval, B_own, b_rs, nullptr, 0, 0, C, c_rs, nrows, k, index_base,
-                block_list, (uint32_t)launch_blocks);
+        // tuning knobs: entries per inner step (HPCLA_SPMM_VU = 2 | 4) and records per LDS pass
+        // (HPCLA_SPMM_CHUNK = 512 | 1536; default by density: short rows fit the small pass)
+        static const int vu = [] {
+            const char *e = getenv("HPCLA_SPMM_VU");
+            return (e && atoi(e) == 4) ? 4 : 2;
+        }();
+        static const int chunk_env = [] {
+            const char *e = getenv("HPCLA_SPMM_CHUNK");
+            return e ? atoi(e) : 0;
+        }();
+        const bool small = chunk_env ? chunk_env == 512 : nnz <= 8 * nrows;
+#define HPCLA_SPMM_VEC(SP, VUU, CH)                                                                     \
+    spmm_rowblock_vec_kernel<I, SP, VUU, CH><<<grid, block, 0, s>>>(                                     \
+        rowptr, colval, nzval, B_own, b_rs, SP ? B_ghost : nullptr, SP ? bg_rs : 0, SP ? n_own : 0, C, c_rs, \
+        nrows, k, index_base, block_list, (uint32_t)launch_blocks)
+#define HPCLA_SPMM_VEC2(SP)                                                                             \
+    do {                                                                                                \
+        if (small) { if (vu == 4) HPCLA_SPMM_VEC(SP, 4, 512); else HPCLA_SPMM_VEC(SP, 2, 512); }        \
+        else { if (vu == 4) HPCLA_SPMM_VEC(SP, 4, 1536); else HPCLA_SPMM_VEC(SP, 2, 1536); }            \
+    } while (0)
+        if (split) HPCLA_SPMM_VEC2(true); else HPCLA_SPMM_VEC2(false);
+#undef HPCLA_SPMM_VEC2
+#undef HPCLA_SPMM_VEC
     } else if (split)
         spmm_rowblock_kernel<I, true><<<grid, block, 0, s>>>(
             rowptr, colval, nzval, B_own, b_rs, b_cs, B_ghost, bg_rs, n_own, C, c_rs, c_cs, nrows,

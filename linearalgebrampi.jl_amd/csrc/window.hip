@@ -372,6 +372,58 @@ HPCLA_API int hpcla_comm_window_attach(hpcla_comm_t *comm, const uint8_t *all_de
     return HPCLA_OK;
 }
 
+// Connection test, run once after attach: an all-reduce of (rank + 1) through the windows with its own
+// (short) timeout.  *ok = 1 iff every peer's store arrived here and the sum is n(n+1)/2.  The host layer
+// all-gathers `ok` and, unless every rank passed, detaches the windows everywhere and stays on RCCL.
+HPCLA_API int hpcla_comm_window_selftest(hpcla_comm_t *comm, double timeout_s, int *ok)
+{
+    if (!comm || !ok) return set_error(HPCLA_ERR_INVALID, "comm_window_selftest: null pointer");
+    *ok = 0;
+    if (!comm->win_attached) return set_error(HPCLA_ERR_INVALID, "comm_window_selftest: no attached window");
+    double *buf = nullptr;
+    HPCLA_CHECK_HIP(hipMalloc((void **)&buf, sizeof(double)));
+    const double mine = (double)(comm->rank + 1);
+    hipError_t e = hipMemcpy(buf, &mine, sizeof(double), hipMemcpyHostToDevice);
+    double got = 0.0;
+    uint32_t st = 1;
+    if (e == hipSuccess) {
+        uint64_t *my_slots = reinterpret_cast<uint64_t *>(reinterpret_cast<uint8_t *>(comm->win) + WIN_LINE);
+        comm->ar_epoch += 1;
+        window_allreduce_kernel<<<1, 64, 0, nullptr>>>((uint64_t *const *)comm->peer_slots_dev, my_slots,
+                                                       reinterpret_cast<uint32_t *>(comm->win), buf, 1, 0,
+                                                       comm->nranks, comm->rank, comm->ar_epoch,
+                                                       (int64_t)((timeout_s > 0 ? timeout_s : 5.0) * 1.0e8));
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e == hipSuccess) e = hipMemcpy(&got, buf, sizeof(double), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(&st, comm->win, sizeof(st), hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(buf);
+    if (e != hipSuccess) return set_error(HPCLA_ERR_HIP, "comm_window_selftest: %s", hipGetErrorString(e));
+    const double want = 0.5 * comm->nranks * (comm->nranks + 1.0);
+    *ok = (st == 0 && got == want) ? 1 : 0;
+    return HPCLA_OK;
+}
+
+// give up the communicator window (after a failed connection test): back to RCCL for everything
+HPCLA_API int hpcla_comm_window_detach(hpcla_comm_t *comm)
+{
+    if (!comm) return set_error(HPCLA_ERR_INVALID, "comm_window_detach: null communicator");
+    comm_window_free(comm);
+    return HPCLA_OK;
+}
+
+// give up the push transport of one plan (a neighbour could not be mapped): the ghost segment stays where
+// it is and RCCL receives into it
+HPCLA_API int hpcla_halo_plan_detach(hpcla_halo_plan_t *plan)
+{
+    if (!plan) return set_error(HPCLA_ERR_INVALID, "halo_plan_detach: null plan");
+    for (auto &m : plan->send_peer) window_close(&m);
+    plan->send_peer.clear();
+    plan->attached = false;
+    return HPCLA_OK;
+}
+
 HPCLA_API int hpcla_comm_status(hpcla_comm_t *comm, int *timed_out)
 {
     if (!comm || !timed_out) return set_error(HPCLA_ERR_INVALID, "comm_status: null pointer");
