@@ -18,3 +18,4 @@ for vu in 2 4; do for ch in 512 1536; do
 done; done
 unset HPCLA_SPMM_VU HPCLA_SPMM_CHUNK
 step 600 gpurun_out/r02e_pytest_spmm.log python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "spmm or SpMM"; tail -3 gpurun_out/r02e_pytest_spmm.log
+step 900 gpurun_out/r02e_pytest_new.log python -m pytest tests/test_gpu_full_size.py tests/test_gpu_parity.py -x -q -m gpu -s -k "full_size or config3 or config4 or packed or to_backend or golden_host_layer or device_side or widened"; tail -12 gpurun_out/r02e_pytest_new.log

@@ -119,6 +119,12 @@ int hpcla_classify_blocks_i64(const int64_t *rowptr, const int64_t *colval_split
  * col_indices_out (device int64, capacity `window`; first *ncols_compressed_host entries valid,
  * ascending).  `work`: hpcla_colspace_work_bytes(window) device bytes.  Synchronises the stream. */
 int64_t hpcla_colspace_work_bytes(int64_t window);
+/* 256-bit order-sensitive digest of a device index array (the local pass of compute_structural_hash,
+ * src/sparse.jl:97-121, without a D2H copy of colval): out_host[k] = sum_i mix(a[i]*P1 + (i+1)*P2 + S_k)
+ * mod 2^64, k = 0..3.  Memoization keys only -- compared for equality, like the reference's Blake3
+ * digests.  Synchronises the stream. */
+int hpcla_digest_i32(const int32_t *a, int64_t n, uint64_t *out_host /* 4 words */, void *stream);
+int hpcla_digest_i64(const int64_t *a, int64_t n, uint64_t *out_host /* 4 words */, void *stream);
 int hpcla_compress_columns_i32(const int64_t *colidx_global, int64_t nnz, int64_t col_lo, int64_t window,
                                int32_t *colval_out, int index_base, int64_t *col_indices_out,
                                int64_t *ncols_compressed_host, void *work, void *stream);

@@ -16,10 +16,10 @@ The directory name contains a dot, so it is imported through the top-level alias
 ``hpcla_amd`` (``import hpcla_amd as hp``).
 """
 from . import _capi
-from .backends import (AbstractComm, AbstractDevice, CommSerial, CommTorch, DeviceROCm, HPCBackend,
+from .backends import (AbstractComm, AbstractDevice, CommSerial, CommTorch, DeviceCPU, DeviceROCm, HPCBackend,
                        SolverNone, assert_backends_compatible, backend_rocm_mpi,
                        backend_rocm_serial, backends_compatible, comm_exchange_arrays, comm_rank, comm_size,
-                       eltype_backend, indextype_backend)
+                       cpu_version, eltype_backend, indextype_backend)
 from .partition import (compute_partition_hash, compute_structural_hash, owner_of,
                         uniform_partition)
 from .vectors import HPCVector, HPCVector_local, cg_update_, dot, maximum, minimum, norm, vsum
@@ -31,6 +31,7 @@ from .dense import (HPCMatrix, HPCMatrix_local, TransposedHPCMatrix, clear_dense
                     dense_matvec, dense_matvec_t, spmm)
 from .matmat import clear_matrix_plan_cache, get_matrix_plan, spgemm
 from .cg import cg_fixed_iterations
+from .convert import to_backend
 from .transpose import (HostTransposeStructure, TransposedHPCSparseMatrix, TransposedHPCVector, TransposePlan,
                         adjoint, clear_transpose_plan_cache, get_transpose_plan, transpose)
 from .addition import add_scaled_identity, sparse_add

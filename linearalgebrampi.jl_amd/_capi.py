@@ -93,6 +93,8 @@ _SIGNATURES = {
     "hpcla_colspace_work_bytes": [_i64],
     "hpcla_compress_columns_i32": [_vp, _i64, _i64, _i64, _vp, _i32, _vp, _vp, _vp, _vp],
     "hpcla_compress_columns_i64": [_vp, _i64, _i64, _i64, _vp, _i32, _vp, _vp, _vp, _vp],
+    "hpcla_digest_i32": [_vp, _i64, _vp, _vp],
+    "hpcla_digest_i64": [_vp, _i64, _vp, _vp],
     "hpcla_poisson2d_nnz": [_i64, _i64, _i64, _i64],
     "hpcla_gen_poisson2d": [_i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp],
     "hpcla_gemv_rowmajor_f64": [_vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp],

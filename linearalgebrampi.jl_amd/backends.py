@@ -36,6 +36,16 @@ class DeviceROCm(AbstractDevice):
         return f"DeviceROCm({self.index})"
 
 
+class DeviceCPU(AbstractDevice):
+    """Host memory (src/backends.jl:29).  In this build a DeviceCPU backend only HOLDS data -- the result of
+    ``to_backend(x, cpu_version(backend))``, which the reference's GPU tests compare on
+    (test/test_utils.jl:203-207); every operator of the package computes in the HIP library and refuses
+    CPU-resident operands (there is no CPU compute path here; the reference package has one)."""
+
+    def __repr__(self):
+        return "DeviceCPU()"
+
+
 # ---- solvers: out of scope for this path, tag kept so the 5-parameter shape matches ---------------
 class AbstractSolver:
     pass
@@ -259,7 +269,7 @@ class HPCBackend:
         self.T = np.dtype(T)
         self.Ti = np.dtype(Ti)
         if self.T != np.dtype(np.float64):
-            raise TypeError(f"DeviceROCm backend implements Float64 only, got {self.T}")
+            raise TypeError(f"this build implements Float64 only, got {self.T}")
         if self.Ti not in _INDEX_TYPES:
             raise TypeError(f"index type must be int32 or int64, got {self.Ti}")
         self.device = device
@@ -276,7 +286,25 @@ class HPCBackend:
     @property
     def torch_device(self):
         import torch
+        if isinstance(self.device, DeviceCPU):
+            return torch.device("cpu")
         return torch.device("cuda", self.device.index)
+
+    @property
+    def on_device(self) -> bool:
+        return isinstance(self.device, DeviceROCm)
+
+
+def cpu_version(b: "HPCBackend") -> "HPCBackend":
+    """``cpu_version(backend)`` (test/test_utils.jl:203-207): same T / Ti / comm, DeviceCPU."""
+    return HPCBackend(b.T, b.Ti, DeviceCPU(), b.comm, b.solver)
+
+
+def require_device(b: "HPCBackend", what: str) -> None:
+    """Operators compute in the HIP library only; a CPU-resident operand is an error, not a fallback."""
+    if not b.on_device:
+        raise TypeError(f"{what}: operand lives on {b.device!r}; this build has no CPU compute path "
+                        "(move it with to_backend(x, rocm_backend), or use the reference package on the CPU)")
 
 
 def eltype_backend(b: HPCBackend):        # src/backends.jl:153-154

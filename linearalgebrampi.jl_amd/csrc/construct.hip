@@ -239,6 +239,75 @@ HPCLA_API int hpcla_compress_columns_i64(const int64_t *colidx_global, int64_t n
 }
 
 // nnz of rows [row_start,row_end) of the nx*ny 5-point Laplacian (closed form, host)
+// ---- structure digest: the device form of compute_structural_hash's local pass ---------------------
+// The reference hashes rowptr / colval / col_indices on the host with Blake3 (src/sparse.jl:97-121) purely
+// as a memoization key: digests are compared for equality, never against constants.  For a device-resident
+// structure that would mean a D2H copy of colval (250 MB at config 5) plus a host hash per matrix; here a
+// kernel folds the array into four 64-bit words, word k = sum_i mix(a[i]*P1 + (i+1)*P2 + S_k) mod 2^64.
+// The position enters every term, so the digest is order-sensitive; integer addition is exact and
+// commutative, so atomics give the same words on every run.  The host twin (partition.py) applies the
+// same formula with numpy -- host-built and device-built structures hash alike.
+namespace hpcla {
+__device__ __forceinline__ uint64_t digest_mix(uint64_t z)
+{
+    z ^= z >> 29;
+    z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 32;
+    return z;
+}
+template <typename I>
+__global__ __launch_bounds__(256) void digest_kernel(const I *__restrict__ a, int64_t n, uint64_t *__restrict__ out)
+{
+    const uint64_t P1 = 0x9E3779B97F4A7C15ull, P2 = 0xD1B54A32D192ED03ull;
+    const uint64_t S[4] = {0x243F6A8885A308D3ull, 0x13198A2E03707344ull, 0xA4093822299F31D0ull, 0x082EFA98EC4E6C89ull};
+    uint64_t h[4] = {0, 0, 0, 0};
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t t = (uint64_t)(int64_t)a[i] * P1 + (uint64_t)(i + 1) * P2;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) h[k] += digest_mix(t + S[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint64_t v = h[k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd((unsigned long long *)(out + k), (unsigned long long)v);
+    }
+}
+template <typename I>
+static int digest_impl(const I *a, int64_t n, uint64_t *out_host, void *stream)
+{
+    if (n < 0 || !out_host) return set_error(HPCLA_ERR_INVALID, "digest: bad arguments");
+    for (int k = 0; k < 4; ++k) out_host[k] = 0;
+    if (n == 0) return HPCLA_OK;
+    if (!a) return set_error(HPCLA_ERR_INVALID, "digest: null array");
+    uint64_t *d = nullptr;
+    HPCLA_CHECK_HIP(hipMalloc((void **)&d, 4 * sizeof(uint64_t)));
+    hipStream_t s = as_stream(stream);
+    hipError_t e = hipMemsetAsync(d, 0, 4 * sizeof(uint64_t), s);
+    if (e == hipSuccess) {
+        int64_t g = (n + 255) / 256;
+        if (g > 4096) g = 4096;
+        digest_kernel<I><<<(uint32_t)g, 256, 0, s>>>(a, n, d);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out_host, d, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d);
+    if (e != hipSuccess) return set_error(HPCLA_ERR_HIP, "digest: %s", hipGetErrorString(e));
+    return HPCLA_OK;
+}
+}  // namespace hpcla
+
+HPCLA_API int hpcla_digest_i32(const int32_t *a, int64_t n, uint64_t *out_host, void *stream)
+{
+    return digest_impl<int32_t>(a, n, out_host, stream);
+}
+HPCLA_API int hpcla_digest_i64(const int64_t *a, int64_t n, uint64_t *out_host, void *stream)
+{
+    return digest_impl<int64_t>(a, n, out_host, stream);
+}
+
 HPCLA_API int64_t hpcla_poisson2d_nnz(int64_t nx, int64_t ny, int64_t row_start, int64_t row_end)
 {
     return poisson2d_prefix(row_end, nx, ny) - poisson2d_prefix(row_start, nx, ny);

@@ -23,7 +23,8 @@ import numpy as np
 
 from . import _capi
 from .backends import (CommSerial, HPCBackend, assert_backends_compatible, attach_halo_windows, comm_allgather,
-                       comm_alltoall_counts, comm_barrier, comm_exchange_indices, comm_rank, comm_size)
+                       comm_alltoall_counts, comm_barrier, comm_exchange_indices, comm_rank, comm_size,
+                       require_device)
 from .partition import (compute_partition_hash, compute_structural_hash, owner_of,
                         uniform_partition)
 from .vectors import HPCVector, current_stream_ptr, dptr
@@ -66,11 +67,12 @@ def build_host_vector_plan(col_indices: np.ndarray, x_partition: np.ndarray, com
     col_indices = np.asarray(col_indices, dtype=np.int64)
     my_x_start = int(x_partition[rank])
 
-    # step 1: group col_indices by owner rank in x's partition (:1888-1896)
-    owners = owner_of(x_partition, col_indices)
-    # col_indices is sorted and owners are contiguous rank ranges, so each owner's entries are one
-    # contiguous run: boundaries by searchsorted instead of per-element push!
-    bounds = np.searchsorted(owners, np.arange(nranks + 1), side="left")
+    # step 1: group col_indices by owner rank in x's partition (:1888-1896).  col_indices is sorted and
+    # owners are contiguous rank ranges (owner(g) = min(searchsortedlast(partition, g) - 1, nranks - 1)), so
+    # each owner's entries are one contiguous run whose ends are found by nranks - 1 binary searches in
+    # col_indices -- no per-element owner array, no per-element push! (1.6e7 columns at config 5)
+    cuts = np.asarray(x_partition[1:nranks], dtype=np.int64)
+    bounds = np.concatenate([[0], np.searchsorted(col_indices, cuts, side="left"), [len(col_indices)]]).astype(np.int64)
     send_counts = np.diff(bounds)                                           # :1899 (what I need)
 
     # step 2: Alltoall of counts (:1899-1900)
@@ -160,6 +162,7 @@ class VectorPlan:
 
     def __init__(self, A: "HPCSparseMatrix", x: HPCVector):
         assert_backends_compatible(A.backend, x.backend)
+        require_device(A.backend, "VectorPlan(A, x)")
         torch = _torch()
         backend = A.backend
         dev = backend.torch_device
@@ -418,9 +421,33 @@ class HPCSparseMatrix:
         return self._colval_target
 
     def _ensure_hash(self) -> bytes:                     # src/HPCLinearAlgebra.jl:759-764
+        """Structural hash (memoization key, src/sparse.jl:97-121).  The array passes run where the arrays
+        live: rowptr / colval are digested ON THE DEVICE (``hpcla_digest_*``) when their device copies exist
+        -- a device-built matrix never copies colval to the host for this -- else by the numpy twin; both give
+        the same words."""
         if self.structural_hash is None:
-            self.structural_hash = compute_structural_hash(
-                self.row_partition, self.col_indices, self.rowptr, self.colval, self.backend.comm)
+            from .partition import array_digest, structural_hash_from_digests
+
+            def dig(dev_t, host_a):
+                if dev_t is not None and dev_t.is_cuda:
+                    out = (ctypes.c_uint64 * 4)()
+                    sfx = "i64" if dev_t.dtype == _torch().int64 else "i32"
+                    _capi.call(f"hpcla_digest_{sfx}", dptr(dev_t), int(dev_t.numel()), out, current_stream_ptr())
+                    return int(dev_t.numel()), bytes(out)
+                return int(len(host_a)), array_digest(host_a)
+
+            ci = getattr(self, "_col_indices_dev", None)
+            cv = self._colval_target
+            if self.backend.on_device:               # host-built matrix: the plan needs colval on the device anyway
+                cv = self.colval_target()
+                if ci is None and len(self.col_indices) > (1 << 16):
+                    ci = _torch().from_numpy(self.col_indices).to(self.backend.torch_device)
+            self.structural_hash = structural_hash_from_digests(
+                self.row_partition,
+                [dig(ci, self.col_indices),
+                 dig(self.rowptr_target, None if self.rowptr_target.is_cuda else self.rowptr),
+                 dig(cv, None if cv is not None and cv.is_cuda else self.colval)],
+                self.backend.comm)
         return self.structural_hash
 
     # -- A * x (src/sparse.jl:2096-2128) and A * B (src/sparse.jl:2391-2413) ---------------------------
@@ -644,6 +671,7 @@ def HPCSparseMatrix_local_device(rowptr_dev, colidx_global_dev, vals_dev, ncols_
     A = HPCSparseMatrix(row_partition, col_partition, col_indices, None, None, vals_dev,
                         rowptr_dev.to(tdt), backend)
     A._colval_target = colval_dev
+    A._col_indices_dev = col_indices_dev[:ncomp.value]
     return A
 
 

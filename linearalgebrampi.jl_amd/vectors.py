@@ -34,6 +34,11 @@ def dptr(t) -> ctypes.c_void_p:
     """Raw device pointer of a torch tensor (None -> NULL)."""
     if t is None:
         return ctypes.c_void_p(0)
+    if t.device.type != "cuda":
+        # every operator computes in the HIP library; a CPU-resident operand (the result of
+        # to_backend(x, cpu_version(b))) is an error, never a silent host fallback
+        raise TypeError("operand lives in host memory; this build has no CPU compute path "
+                        "(move it with to_backend(x, rocm_backend), or use the reference package on the CPU)")
     return ctypes.c_void_p(t.data_ptr())
 
 

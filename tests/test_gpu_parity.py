@@ -73,7 +73,12 @@ def test_spmv_golden_host_layer(hp, golden, gpu_backend_i32, gpu_backend_i64, na
     ydist = Adist @ xdist
     assert isinstance(ydist, hp.HPCVector) and ydist.backend is backend
     np.testing.assert_array_equal(ydist.partition, Adist.row_partition)
-    assert np.max(np.abs(ydist.local_values() - np.array(case["y"]))) < TOL_REF
+    # compared the way the reference's GPU tests compare (test/test_utils.jl:203-207): after
+    # to_backend(y, cpu_version(backend)), on the host copy
+    y_cpu = hp.to_backend(ydist, hp.cpu_version(backend))
+    assert isinstance(y_cpu.backend.device, hp.DeviceCPU) and y_cpu.v.device.type == "cpu"
+    assert y_cpu.structural_hash == ydist.structural_hash
+    assert np.max(np.abs(y_cpu.v.numpy() - np.array(case["y"]))) < TOL_REF
     # mul!(y, A, x)  (test/test_vector_multiplication.jl:70-92)
     y2 = hp.HPCVector.zeros(Adist.row_partition, backend)
     hp.mul_(y2, Adist, xdist)
@@ -396,9 +401,44 @@ def test_spmm_golden_host_layer(hp, golden, gpu_backend_i32):
     Bd = hp.HPCMatrix.from_global(np.array(case["B"]), gpu_backend_i32)
     Cd = Ad @ Bd
     assert isinstance(Cd, hp.HPCMatrix)
-    C = Cd.local_values()
+    C = hp.to_backend(Cd, hp.cpu_version(gpu_backend_i32)).A.numpy()       # test/test_utils.jl:203-207
     assert np.max(np.abs(C - np.array(case["C"]))) < TOL_REF
     assert abs(np.linalg.norm(C) - case["C_fro"]) < TOL_REF
+
+
+def test_to_backend_round_trip(hp, orc, gpu_backend_i32):
+    """to_backend (src/HPCLinearAlgebra.jl:337-378): device -> CPU -> device keeps every bit and the
+    structure; the CPU copy shares partitions / hashes / host structure arrays, drops cached_transpose, and is
+    refused by the operators (no CPU compute path in this build, by design)."""
+    b = gpu_backend_i32
+    cpu = hp.cpu_version(b)
+    n = 3000
+    rows = orc.sprand_rows(n, 0.01, 0, n)
+    A = hp.HPCSparseMatrix_local(rows.rowptr, rows.colidx, rows.vals, n, b)
+    xg = orc.fill_uniform(0, n, orc.SEED_X)
+    x = hp.HPCVector.from_global(xg, b)
+    y = A @ x
+    A.cached_transpose = object()                                  # pretend transpose(A) was materialised
+    Ac, xc = hp.to_backend(A, cpu), hp.to_backend(x, cpu)
+    assert Ac.backend is cpu and Ac.nzval.device.type == "cpu" and Ac.rowptr_target.device.type == "cpu"
+    assert Ac.cached_transpose is None and Ac.col_indices is A.col_indices and Ac.structural_hash == A.structural_hash
+    np.testing.assert_array_equal(Ac.nzval.numpy(), rows.vals)
+    np.testing.assert_array_equal(xc.v.numpy(), xg)
+    with pytest.raises((TypeError, ValueError)):
+        Ac @ xc                                                    # CPU operands: an error, not a fallback
+    with pytest.raises((TypeError, ValueError)):
+        A @ xc                                                     # mixed backends (src/backends.jl:444-464)
+    with pytest.raises(TypeError):
+        hp.dot(xc, xc)
+    A2, x2 = hp.to_backend(Ac, b), hp.to_backend(xc, b)
+    assert A2.backend is b and A2.nzval.is_cuda and A2.rowptr_target.is_cuda
+    np.testing.assert_array_equal((A2 @ x2).local_values(), y.local_values())
+    M = hp.HPCMatrix.from_global(orc.fill_uniform(0, n * 4, 5).reshape(n, 4), b)
+    Mc = hp.to_backend(M, cpu)
+    assert Mc.A.device.type == "cpu"
+    np.testing.assert_array_equal(hp.to_backend(Mc, b).local_values(), M.local_values())
+    A.cached_transpose = None
+    hp.clear_plan_cache()
 
 
 @pytest.mark.parametrize("k", [1, 3, 16, 17, 40])
