@@ -178,13 +178,23 @@ __global__ __launch_bounds__(TPB_MM) void spmm_rowblock_vec_kernel(
     const I *__restrict__ rowptr, const I *__restrict__ colval, const double *__restrict__ nzval,
     const double *__restrict__ B_own, int64_t b_rs, const double *__restrict__ B_ghost, int64_t bg_rs,
     int64_t n_own, double *__restrict__ C, int64_t c_rs, int64_t nrows, int k, int base,
-    const int32_t *__restrict__ block_list, uint32_t nblocks)
+    const int32_t *__restrict__ block_list, uint32_t nblocks, uint32_t xcd_group)
 {
     __shared__ SpmmEntry s_ent[CHUNK_V];
 
     const int tid = threadIdx.x;
     const int g = tid / VG, l = tid % VG;   // g = row of the block (0..63)
-    const uint32_t b = blockIdx.x;
+    // XCD-grouped order (xcd_group = G > 0): workgroups b, b+8, b+16, ... share an XCD (= one L2); give each
+    // XCD runs of G CONSECUTIVE row blocks, the 8 XCDs working on 8 neighbouring runs, so that a B row needed
+    // again a few thousand matrix rows later (the +-nx neighbours of a stencil) is still in THAT L2 instead of
+    // being fetched over the fabric by two or three different XCDs.  The window of all XCDs still moves
+    // through the matrix as one (8G blocks wide), unlike an XCD-sliced order.
+    uint32_t b = blockIdx.x;
+    if (xcd_group) {
+        const uint32_t xcd = b & 7u, slot = b >> 3;
+        b = ((slot / xcd_group) * 8u + xcd) * xcd_group + slot % xcd_group;
+        if (b >= nblocks) return;             // the grid is rounded up to a multiple of 8G
+    }
     const int64_t blk = block_list ? (int64_t)block_list[b] : (int64_t)b;
     const int64_t r0 = blk * RPB_MM;
     const int nr = (int)((nrows - r0) < RPB_MM ? (nrows - r0) : RPB_MM);
@@ -335,10 +345,18 @@ static int spmm_launch(const I *rowptr, const I *colval, const double *nzval, co
             return e ? atoi(e) : 0;
         }();
         const bool small = chunk_env ? chunk_env == 512 : nnz <= 8 * nrows;
+        // XCD-grouped block order: HPCLA_SPMM_XCD_GROUP = G (0 = natural order)
+        static const int xg_env = [] {
+            const char *e = getenv("HPCLA_SPMM_XCD_GROUP");
+            return e ? atoi(e) : 0;
+        }();
+        const uint32_t xg = xg_env > 0 ? (uint32_t)xg_env : 0u;
+        dim3 vgrid = grid;
+        if (xg) vgrid = dim3((uint32_t)(((launch_blocks + 8ll * xg - 1) / (8ll * xg)) * 8ll * xg));
 #define HPCLA_SPMM_VEC(SP, VUU, CH)                                                                     \
-    spmm_rowblock_vec_kernel<I, SP, VUU, CH><<<grid, block, 0, s>>>(                                     \
+    spmm_rowblock_vec_kernel<I, SP, VUU, CH><<<vgrid, block, 0, s>>>(                                    \
         rowptr, colval, nzval, B_own, b_rs, SP ? B_ghost : nullptr, SP ? bg_rs : 0, SP ? n_own : 0, C, c_rs, \
-        nrows, k, index_base, block_list, (uint32_t)launch_blocks)
+        nrows, k, index_base, block_list, (uint32_t)launch_blocks, xg)
 #define HPCLA_SPMM_VEC2(SP)                                                                             \
     do {                                                                                                \
         if (small) { if (vu == 4) HPCLA_SPMM_VEC(SP, 4, 512); else HPCLA_SPMM_VEC(SP, 2, 512); }        \

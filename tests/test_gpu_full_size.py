@@ -17,11 +17,13 @@ pytestmark = pytest.mark.gpu
 
 # CG: two CG runs that differ only in the summation order of their dot products (tree on the GPU,
 # sequential in the oracle: ~1e-16 relative per dot) drift apart through the recurrence -- alpha and beta
-# feed back into every later iterate.  Observed on this problem (printed by the test): the residual
-# histories agree to <= 4e-12 relative at every one of the 100 iterations and x to <= 2e-12 of max|x|;
-# the bounds asserted leave a factor ~25 for other boxes / reduction widths.
-CG_HIST_RTOL = 1e-10
-CG_X_RTOL = 5e-11
+# feed back into every later iterate.  MEASURED on this problem (the test prints it; gpurun_out/r02e_pytest_new.log):
+# the residual histories agree to 2.4e-15 relative at every one of the 100 iterations and x to 2.2e-15 of
+# max|x| (fused and unfused alike) -- the matrix is far from converged after 100 iterations (||r|| 2366 ->
+# 502), so the recurrence has not amplified the rounding differences.  The bound asserted is BASELINE's own
+# 1e-12 relative, per iteration, with a factor 400 of margin over what was observed.
+CG_HIST_RTOL = 1e-12
+CG_X_RTOL = 1e-12
 
 
 def test_config3_poisson8192_whole_problem_one_gpu(hp, orc, gpu_backend_i32):
