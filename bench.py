@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--strong-size", type=int, default=8192, help="grid edge of the strong-scaling sub-record (BASELINE configs[2])")
     ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling sub-record")
+    ap.add_argument("--no-extras", action="store_true", help="skip the CG / SpMM sub-records (BASELINE configs[3], [4])")
     return ap.parse_args()
 
 
@@ -592,6 +593,20 @@ def _run(args):
         except Exception as exc:                     # same code on every rank: all ranks land here together
             rec = {"error": f"{type(exc).__name__}: {exc}"}
         result["strong_scaling"] = rec
+    # ---- the other BASELINE configs as sub-records of the same line (driver-timed): configs[3]'s per-GPU share
+    #      (3-D Poisson, 100 CG iterations) and configs[4] (SpMM, k = 16) in its two regimes -------------------
+    if not strong and not args.no_extras:
+        import copy
+        from benchmarks import extra_workloads
+        extras = {}
+        for name, wsteps in (("poisson3d_cg", 100), ("poisson2d_spmm", 20), ("sprand_spmm", 10)):
+            a2 = copy.copy(args)
+            a2.workload, a2.steps, a2.warmup, a2.size = name, wsteps, 4, 0
+            try:
+                extras[name] = extra_workloads.run_record(a2, backend, rank, world, job)
+            except Exception as exc:                 # same code on every rank: all ranks land here together
+                extras[name] = {"error": f"{type(exc).__name__}: {exc}"}
+        result["other_configs"] = extras
     verified = verified and not timed_out
     result["verified_vs_closed_form"] = verified
     job.barrier()

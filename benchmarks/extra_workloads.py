@@ -53,7 +53,36 @@ def _measure_spmm(args, job, hp, wl, A, B, k, world, dev, setup_s, metric, workl
     return out
 
 
+def device_stencil(hp, torch, backend, dims, lo, hi):
+    """Rows [lo, hi) of the 5-point (dims = (nx, ny)) or 7-point (dims = (nx, ny, nz)) Laplacian, generated and
+    column-compressed ON THE DEVICE (hpcla_gen_poisson2d/3d + hpcla_compress_columns_*)."""
+    s0 = torch.cuda.current_stream().cuda_stream
+    lib = hp._capi.load()
+    n_glob = int(np.prod(dims))
+    if len(dims) == 2:
+        nnz = lib.hpcla_poisson2d_nnz(dims[0], dims[1], lo, hi)
+        reach = dims[0]
+    else:
+        nnz = lib.hpcla_poisson3d_nnz(dims[0], dims[1], dims[2], lo, hi)
+        reach = dims[0] * dims[1]
+    rp = torch.empty(hi - lo + 1, dtype=torch.int64, device="cuda")
+    ci = torch.empty(nnz, dtype=torch.int64, device="cuda")
+    va = torch.empty(nnz, dtype=torch.float64, device="cuda")
+    if len(dims) == 2:
+        hp._capi.call("hpcla_gen_poisson2d", dims[0], dims[1], lo, hi, rp.data_ptr(), ci.data_ptr(), va.data_ptr(), s0)
+    else:
+        hp._capi.call("hpcla_gen_poisson3d", dims[0], dims[1], dims[2], lo, hi, rp.data_ptr(), ci.data_ptr(),
+                      va.data_ptr(), s0)
+    return hp.HPCSparseMatrix_local_device(rp, ci, va, n_glob, backend,
+                                           col_window=(max(lo - reach, 0), min(hi + reach, n_glob) - 1))
+
+
 def run(args, backend, rank, world, job):
+    out = run_record(args, backend, rank, world, job)
+    return json.dumps(out) if rank == 0 else None          # bench.py prints it, then tears down
+
+
+def run_record(args, backend, rank, world, job):
     import torch
     import hpcla_amd as hp
     from hpcla_amd import workloads as wl
@@ -66,9 +95,7 @@ def run(args, backend, rank, world, job):
         n_glob = N * N * nz
         lo, hi = rank * N * N * planes, (rank + 1) * N * N * planes
         t0 = time.perf_counter()
-        rowptr, colidx, vals = wl.poisson3d_rows(N, N, nz, lo, hi)
-        A = hp.HPCSparseMatrix_local(rowptr, colidx, vals, n_glob, backend)
-        del rowptr, colidx, vals
+        A = device_stencil(hp, torch, backend, (N, N, nz), lo, hi)
         b = hp.HPCVector.zeros(A.row_partition, backend)
         hp._capi.call("hpcla_fill_uniform_f64", b.v.data_ptr(), lo, hi - lo, wl.SEED_RHS,
                       torch.cuda.current_stream().cuda_stream)
@@ -99,6 +126,7 @@ def run(args, backend, rank, world, job):
                          "unit": "GB/s", "frac": round(b_iter / (ms_iter * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
                          "algorithmic_bytes_per_iteration": b_iter, "note": "whole iteration (SpMV + 2 reductions + 3 updates), wall clock"},
             "residual_first": hist[0], "residual_last": hist[-1], "setup_s": round(setup_s, 2),
+            "exchange_timed_out": bool(job.max(1.0 if hp.get_vector_plan(A, b).timed_out() else 0.0)),
         }
     elif args.workload == "poisson2d_spmm":
         # structured counterpart of config 5: the 5-point matrix times 16 dense columns.  Every B row is
@@ -110,9 +138,7 @@ def run(args, backend, rank, world, job):
         ny = ny_loc * world
         lo, hi = rank * nx * ny_loc, (rank + 1) * nx * ny_loc
         t0 = time.perf_counter()
-        rowptr, colidx, vals = wl.poisson2d_rows(nx, ny, lo, hi)
-        A = hp.HPCSparseMatrix_local(rowptr, colidx, vals, nx * ny, backend)
-        del rowptr, colidx, vals
+        A = device_stencil(hp, torch, backend, (nx, ny), lo, hi)
         b_rows = hi - lo
         Bl = torch.empty((b_rows, k), dtype=torch.float64, device=dev)
         hp._capi.call("hpcla_fill_uniform_f64", Bl.data_ptr(), lo * k, b_rows * k, wl.SEED_X,
@@ -173,7 +199,7 @@ def run(args, backend, rank, world, job):
                               "sector_gather_gbs": round(b_sect / (ms * 1e-3) / 1e9, 1),
                               "note": "sector_gather = 12 B + one 64-byte sector of x per stored entry"})
             hp.clear_plan_cache()
-            return line
+            return json.loads(line)
         b_rows = rows_loc * mult
         Bl = torch.empty((b_rows, k), dtype=torch.float64, device=dev)
         hp._capi.call("hpcla_fill_uniform_f64", Bl.data_ptr(), rank * b_rows * k, b_rows * k, wl.SEED_X,
@@ -185,4 +211,6 @@ def run(args, backend, rank, world, job):
                             f"sprand-like {rows_loc} rows per GPU x {ncols} cols, nnz/GPU={A.nnz}, k={k}, C = A*B")
     job.barrier()
     hp.clear_spmm_cache()
-    return json.dumps(out) if rank == 0 else None          # bench.py prints it, then tears down
+    hp.clear_plan_cache()
+    torch.cuda.empty_cache()
+    return out

@@ -137,6 +137,10 @@ int hpcla_compress_columns_i64(const int64_t *colidx_global, int64_t nnz, int64_
 int64_t hpcla_poisson2d_nnz(int64_t nx, int64_t ny, int64_t row_start, int64_t row_end);
 int hpcla_gen_poisson2d(int64_t nx, int64_t ny, int64_t row_start, int64_t row_end, int64_t *rowptr_out,
                         int64_t *colidx_out, double *vals_out, void *stream);
+/* the 7-point analogue of BASELINE configs[3] (idx = (k*ny + j)*nx + i, diagonal 6) */
+int64_t hpcla_poisson3d_nnz(int64_t nx, int64_t ny, int64_t nz, int64_t row_start, int64_t row_end);
+int hpcla_gen_poisson3d(int64_t nx, int64_t ny, int64_t nz, int64_t row_start, int64_t row_end,
+                        int64_t *rowptr_out, int64_t *colidx_out, double *vals_out, void *stream);
 
 /* ---- SpGEMM local product (sparse x sparse): replaces the CPU SparseArrays multiply inside
  * Base.:*(A::HPCSparseMatrix, B::HPCSparseMatrix) (`CT = plan.AT * A_csc`, src/sparse.jl:991-1059).

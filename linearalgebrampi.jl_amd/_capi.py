@@ -97,6 +97,8 @@ _SIGNATURES = {
     "hpcla_digest_i64": [_vp, _i64, _vp, _vp],
     "hpcla_poisson2d_nnz": [_i64, _i64, _i64, _i64],
     "hpcla_gen_poisson2d": [_i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp],
+    "hpcla_poisson3d_nnz": [_i64, _i64, _i64, _i64, _i64],
+    "hpcla_gen_poisson3d": [_i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp],
     "hpcla_gemv_rowmajor_f64": [_vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp],
     "hpcla_gemv_t_work_bytes": [_i64, _i64],
     "hpcla_gemv_t_rowmajor_f64": [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp],
@@ -135,6 +137,7 @@ _RESTYPES = {
     "hpcla_spmv_dot_work_bytes": _i64,
     "hpcla_colspace_work_bytes": _i64,
     "hpcla_poisson2d_nnz": _i64,
+    "hpcla_poisson3d_nnz": _i64,
     "hpcla_spgemm_bin_cap": _i64,
     "hpcla_gemv_t_work_bytes": _i64,
 }

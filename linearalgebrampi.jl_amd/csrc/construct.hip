@@ -134,6 +134,46 @@ __host__ __device__ __forceinline__ int64_t poisson2d_prefix(int64_t idx, int64_
     return 5 * idx - west - east - south - north;
 }
 
+// 7-point analogue, idx = (k*ny + j)*nx + i: 7*idx minus the missing neighbours of the rows before idx
+__host__ __device__ __forceinline__ int64_t poisson3d_prefix(int64_t idx, int64_t nx, int64_t ny, int64_t nz)
+{
+    const int64_t nxy = nx * ny;
+    const int64_t kk = idx / nxy, rem = idx % nxy;
+    const int64_t lines = idx / nx, i = idx % nx;
+    const int64_t west = lines + (i > 0 ? 1 : 0);
+    const int64_t east = lines;
+    const int64_t south = kk * nx + (rem < nx ? rem : nx);                                   // rows with j == 0
+    const int64_t north = kk * nx + (rem > (ny - 1) * nx ? rem - (ny - 1) * nx : 0);           // rows with j == ny-1
+    const int64_t down = idx < nxy ? idx : nxy;                                               // rows with k == 0
+    const int64_t up = idx > (nz - 1) * nxy ? idx - (nz - 1) * nxy : 0;                        // rows with k == nz-1
+    return 7 * idx - west - east - south - north - down - up;
+}
+
+__global__ __launch_bounds__(256) void gen_poisson3d_kernel(int64_t nx, int64_t ny, int64_t nz, int64_t row_start,
+                                                            int64_t nloc, int64_t *__restrict__ rowptr,
+                                                            int64_t *__restrict__ colidx,
+                                                            double *__restrict__ vals)
+{
+    const int64_t nxy = nx * ny;
+    const int64_t base = poisson3d_prefix(row_start, nx, ny, nz);
+    int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (; r <= nloc; r += stride) {
+        const int64_t idx = row_start + r;
+        int64_t p = poisson3d_prefix(idx, nx, ny, nz) - base;
+        rowptr[r] = p;
+        if (r == nloc) break;
+        const int64_t i = idx % nx, j = (idx / nx) % ny, k = idx / nxy;
+        if (k > 0)      { colidx[p] = idx - nxy; vals[p++] = -1.0; }
+        if (j > 0)      { colidx[p] = idx - nx;  vals[p++] = -1.0; }
+        if (i > 0)      { colidx[p] = idx - 1;   vals[p++] = -1.0; }
+        colidx[p] = idx; vals[p++] = 6.0;
+        if (i < nx - 1) { colidx[p] = idx + 1;   vals[p++] = -1.0; }
+        if (j < ny - 1) { colidx[p] = idx + nx;  vals[p++] = -1.0; }
+        if (k < nz - 1) { colidx[p] = idx + nxy; vals[p++] = -1.0; }
+    }
+}
+
 __global__ __launch_bounds__(256) void gen_poisson2d_kernel(int64_t nx, int64_t ny, int64_t row_start,
                                                             int64_t nloc, int64_t *__restrict__ rowptr,
                                                             int64_t *__restrict__ colidx,
@@ -311,6 +351,24 @@ HPCLA_API int hpcla_digest_i64(const int64_t *a, int64_t n, uint64_t *out_host, 
 HPCLA_API int64_t hpcla_poisson2d_nnz(int64_t nx, int64_t ny, int64_t row_start, int64_t row_end)
 {
     return poisson2d_prefix(row_end, nx, ny) - poisson2d_prefix(row_start, nx, ny);
+}
+
+HPCLA_API int64_t hpcla_poisson3d_nnz(int64_t nx, int64_t ny, int64_t nz, int64_t row_start, int64_t row_end)
+{
+    return poisson3d_prefix(row_end, nx, ny, nz) - poisson3d_prefix(row_start, nx, ny, nz);
+}
+
+HPCLA_API int hpcla_gen_poisson3d(int64_t nx, int64_t ny, int64_t nz, int64_t row_start, int64_t row_end,
+                                  int64_t *rowptr_out, int64_t *colidx_out, double *vals_out, void *stream)
+{
+    if (nx < 1 || ny < 1 || nz < 1 || row_start < 0 || row_end < row_start || row_end > nx * ny * nz)
+        return set_error(HPCLA_ERR_INVALID, "gen_poisson3d: bad range");
+    if (!rowptr_out || !colidx_out || !vals_out) return set_error(HPCLA_ERR_INVALID, "gen_poisson3d: null output");
+    const int64_t nloc = row_end - row_start;
+    gen_poisson3d_kernel<<<grid_for(nloc + 1), 256, 0, as_stream(stream)>>>(nx, ny, nz, row_start, nloc, rowptr_out,
+                                                                          colidx_out, vals_out);
+    HPCLA_CHECK_LAUNCH();
+    return HPCLA_OK;
 }
 
 HPCLA_API int hpcla_gen_poisson2d(int64_t nx, int64_t ny, int64_t row_start, int64_t row_end,

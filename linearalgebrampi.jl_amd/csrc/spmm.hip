@@ -157,6 +157,18 @@ __global__ __launch_bounds__(TPB_MM) void spmm_rowblock_kernel(
 // ds_read_b128, one 64-bit add of its (loop-invariant) column byte offset, two 16-byte loads, eight
 // flops.  Tail handling is outside the loop (pairs, then at most one single), so there are no per-element
 // predicates.  Each output column is still accumulated entry by entry in stored order: same bits.
+// Measured after the diet (profiles/r02_pmc_spmm_vec_stencil.txt): VALU instructions -26 %, LDS instructions
+// -54 %, time -5 % (0.643 -> 0.61 ms on the 5-point matrix x 16): the kernel is not issue-bound.  Its L2 misses
+// are exactly the compulsory lines (A + B + C once), so there is no redundant fabric traffic either.  Tried on
+// top of it and dropped, with the numbers (profiles/r02_spmm_*.log): an XCD-grouped block order (runs of G
+// consecutive row blocks per XCD, G = 16..2048: 0.6185..0.659 ms vs 0.6138 natural -- nothing to win when
+// the misses are compulsory); software-pipelined tiles (a workgroup owning T = 2/4/8 tiles, rowptr slices
+// up front, next pass's A entries requested before the current pass's B gathers, double-buffered LDS
+// records: 0.583 / 0.587 / 0.592 vs 0.595 ms on the stencil, and 1.44 / 1.50 / 1.80 vs 1.38 ms on config 5's
+// random pattern -- the dependent chain is not the limit); kept: the HALF64 lane mapping below (+1.5 %).  For
+// scale: on the same box a device copy B -> C runs at 4.8 TB/s, a read-only pass at 5.9, a fill at 6.3
+// (profiles/r02_stream_mix_ceiling.log); this kernel's byte mix (40 % writes) moved as separate ideal streams
+// takes 0.544 ms there, the kernel 0.612.
 // Also tried in round 1 and dropped: no LDS staging (entries handed round a lane-group with shuffles) and an
 // XCD-sliced block order.
 constexpr int VG = 4;                        // lanes per row
@@ -178,23 +190,13 @@ __global__ __launch_bounds__(TPB_MM) void spmm_rowblock_vec_kernel(
     const I *__restrict__ rowptr, const I *__restrict__ colval, const double *__restrict__ nzval,
     const double *__restrict__ B_own, int64_t b_rs, const double *__restrict__ B_ghost, int64_t bg_rs,
     int64_t n_own, double *__restrict__ C, int64_t c_rs, int64_t nrows, int k, int base,
-    const int32_t *__restrict__ block_list, uint32_t nblocks, uint32_t xcd_group)
+    const int32_t *__restrict__ block_list, uint32_t nblocks)
 {
     __shared__ SpmmEntry s_ent[CHUNK_V];
 
     const int tid = threadIdx.x;
     const int g = tid / VG, l = tid % VG;   // g = row of the block (0..63)
-    // XCD-grouped order (xcd_group = G > 0): workgroups b, b+8, b+16, ... share an XCD (= one L2); give each
-    // XCD runs of G CONSECUTIVE row blocks, the 8 XCDs working on 8 neighbouring runs, so that a B row needed
-    // again a few thousand matrix rows later (the +-nx neighbours of a stencil) is still in THAT L2 instead of
-    // being fetched over the fabric by two or three different XCDs.  The window of all XCDs still moves
-    // through the matrix as one (8G blocks wide), unlike an XCD-sliced order.
-    uint32_t b = blockIdx.x;
-    if (xcd_group) {
-        const uint32_t xcd = b & 7u, slot = b >> 3;
-        b = ((slot / xcd_group) * 8u + xcd) * xcd_group + slot % xcd_group;
-        if (b >= nblocks) return;             // the grid is rounded up to a multiple of 8G
-    }
+    const uint32_t b = blockIdx.x;
     const int64_t blk = block_list ? (int64_t)block_list[b] : (int64_t)b;
     const int64_t r0 = blk * RPB_MM;
     const int nr = (int)((nrows - r0) < RPB_MM ? (nrows - r0) : RPB_MM);
@@ -275,152 +277,6 @@ __global__ __launch_bounds__(TPB_MM) void spmm_rowblock_vec_kernel(
     }
 }
 
-// Software-pipelined form of the vector kernel.  The kernel above is latency-bound, not issue- or
-// bandwidth-bound (profiles/r02_pmc_spmm_vec_stencil.txt: 74 % of wave cycles waiting at compulsory L2
-// misses): a workgroup moves ~20 KB behind a chain of three dependent memory round trips (rowptr -> A
-// entries -> B rows -> store).  Here a workgroup owns T consecutive 64-row tiles and
-//   * reads the rowptr slices of ALL its tiles up front (one round trip per workgroup, parked in LDS);
-//   * keeps the A entries of the NEXT pass in registers: they are requested before the B gathers of the
-//     current pass are issued, so the A stream of pass i+1 and the B gathers of pass i are in flight together
-//     and the per-pass chain is one round trip, not two;
-//   * double-buffers the {address, value} records in LDS, one barrier per pass.
-// A "pass" is <= CH entries of one tile (a tile with more entries takes several passes; the accumulators
-// carry over), so rows of any length work.  Same per-(row, column) order of additions: same bits.
-template <typename I, bool SPLIT, int VU, int CH, int T>
-__global__ __launch_bounds__(TPB_MM) void spmm_rowblock_pipe_kernel(
-    const I *__restrict__ rowptr, const I *__restrict__ colval, const double *__restrict__ nzval,
-    const double *__restrict__ B_own, int64_t b_rs, const double *__restrict__ B_ghost, int64_t bg_rs,
-    int64_t n_own, double *__restrict__ C, int64_t c_rs, int64_t nrows, int k, int base,
-    const int32_t *__restrict__ block_list, uint32_t nblocks)
-{
-    constexpr int EPT = CH / TPB_MM;                 // entries per thread per pass
-    static_assert(CH % TPB_MM == 0, "CH must be a multiple of the workgroup size");
-    __shared__ SpmmEntry s_ent[2][CH];
-    __shared__ int64_t s_rp[T][RPB_MM + 1];          // rowptr (0-based) of the workgroup's tiles
-
-    const int tid = threadIdx.x;
-    const int g = tid / VG, l = tid % VG;            // g = row of the tile (0..63)
-    const uint32_t t0 = blockIdx.x * T;
-    const int ntiles = (int)((nblocks - t0) < (uint32_t)T ? (nblocks - t0) : (uint32_t)T);
-
-    for (int idx = tid; idx < ntiles * (RPB_MM + 1); idx += TPB_MM) {
-        const int t = idx / (RPB_MM + 1), i = idx - t * (RPB_MM + 1);
-        const int64_t blk = block_list ? (int64_t)block_list[t0 + t] : (int64_t)(t0 + t);
-        int64_t r = blk * RPB_MM + i;
-        if (r > nrows) r = nrows;                    // rows past the end: empty
-        s_rp[t][i] = (int64_t)rowptr[r] - base;
-    }
-    __syncthreads();
-
-    for (int kt = 0; kt < k; kt += KT) {
-        const int c = kt + VCPL * l;
-        const bool col_ok = c < k;
-        const int64_t lane_bytes = (int64_t)c * (int64_t)sizeof(double);
-        double acc[VCPL];
-#pragma unroll
-        for (int q = 0; q < VCPL; ++q) acc[q] = 0.0;
-
-        // registers holding the entries of the pass that is loaded ahead
-        I pcol[EPT];
-        double pval[EPT];
-        int t = 0;                                   // current tile, pass offset within it
-        int64_t ch = 0;
-        // skip leading empty tiles so that the prologue loads something real
-        auto tile_total = [&](int tt) { return s_rp[tt][RPB_MM] - s_rp[tt][0]; };
-        auto issue = [&](int tt, int64_t cc) {
-            const int64_t p = s_rp[tt][0] + cc;
-            const int64_t left = tile_total(tt) - cc;
-            const int n = (int)(left < CH ? left : CH);
-#pragma unroll
-            for (int u = 0; u < EPT; ++u) {
-                const int i = tid + u * TPB_MM;
-                if (i < n) {
-                    pcol[u] = __builtin_nontemporal_load(colval + p + i);
-                    pval[u] = __builtin_nontemporal_load(nzval + p + i);
-                }
-            }
-        };
-        issue(0, 0);
-        int buf = 0;
-        while (t < ntiles) {
-            const int64_t total = tile_total(t);
-            const int64_t left = total - ch;
-            const int n = (int)(left < CH ? left : CH);
-            // park the loaded pass as {B-row address, value} records
-#pragma unroll
-            for (int u = 0; u < EPT; ++u) {
-                const int i = tid + u * TPB_MM;
-                if (i < n) {
-                    const int64_t col = (int64_t)pcol[u] - base;
-                    SpmmEntry e;
-                    e.val = pval[u];
-                    e.row = (SPLIT && col >= n_own) ? B_ghost + (col - n_own) * bg_rs : B_own + col * b_rs;
-                    s_ent[buf][i] = e;
-                }
-            }
-            __syncthreads();
-            // request the next pass now: its A loads travel together with this pass's B gathers
-            int tn = t;
-            int64_t chn = ch + CH;
-            if (chn >= total) { tn = t + 1; chn = 0; }
-            if (tn < ntiles) issue(tn, chn);
-            // compute this pass
-            if (col_ok) {
-                const int64_t lo = s_rp[t][g] - s_rp[t][0], hi = s_rp[t][g + 1] - s_rp[t][0];
-                int j = (int)((lo > ch ? lo : ch) - ch);
-                const int e = (int)((hi < ch + n ? hi : ch + n) - ch);
-                const SpmmEntry *ent = s_ent[buf];
-                for (; j + VU <= e; j += VU) {
-                    SpmmEntry en[VU];
-                    vdouble2 b0[VU], b1[VU];
-#pragma unroll
-                    for (int u = 0; u < VU; ++u) en[u] = ent[j + u];
-#pragma unroll
-                    for (int u = 0; u < VU; ++u) {
-                        const char *src = reinterpret_cast<const char *>(en[u].row) + lane_bytes;
-                        b0[u] = *(gvec2_ptr)(src);
-                        b1[u] = *(gvec2_ptr)(src + 16);
-                    }
-#pragma unroll
-                    for (int u = 0; u < VU; ++u) {
-                        acc[0] += en[u].val * b0[u].x;
-                        acc[1] += en[u].val * b0[u].y;
-                        acc[2] += en[u].val * b1[u].x;
-                        acc[3] += en[u].val * b1[u].y;
-                    }
-                }
-                for (; j < e; ++j) {
-                    const SpmmEntry en = ent[j];
-                    const char *src = reinterpret_cast<const char *>(en.row) + lane_bytes;
-                    const vdouble2 b0 = *(gvec2_ptr)(src);
-                    const vdouble2 b1 = *(gvec2_ptr)(src + 16);
-                    acc[0] += en.val * b0.x;
-                    acc[1] += en.val * b0.y;
-                    acc[2] += en.val * b1.x;
-                    acc[3] += en.val * b1.y;
-                }
-            }
-            if (tn != t) {                            // last pass of tile t: write its C rows
-                const int64_t blk = block_list ? (int64_t)block_list[t0 + t] : (int64_t)(t0 + t);
-                const int64_t r = blk * RPB_MM + g;
-                if (r < nrows && col_ok) {
-                    double *dst = C + r * c_rs + c;
-                    vdouble2 o0, o1;
-                    o0.x = acc[0]; o0.y = acc[1]; o1.x = acc[2]; o1.y = acc[3];
-                    *reinterpret_cast<vdouble2 *>(dst) = o0;
-                    *reinterpret_cast<vdouble2 *>(dst + 2) = o1;
-                }
-#pragma unroll
-                for (int q = 0; q < VCPL; ++q) acc[q] = 0.0;
-            }
-            t = tn;
-            ch = chn;
-            buf ^= 1;
-        }
-        __syncthreads();                              // LDS buffers are reused by the next column tile
-    }
-}
-
 // tiled transpose / layout conversion: dst(i,c) = src(i,c), arbitrary (row,col) strides
 __global__ __launch_bounds__(256) void relayout_kernel(const double *__restrict__ src,
                                                        int64_t s_rs, int64_t s_cs,
@@ -496,22 +352,14 @@ static int spmm_launch(const I *rowptr, const I *colval, const double *nzval, co
             return e ? atoi(e) : 0;
         }();
         const bool small = chunk_env ? chunk_env == 512 : nnz <= 8 * nrows;
-        // XCD-grouped block order: HPCLA_SPMM_XCD_GROUP = G (0 = natural order)
-        static const int xg_env = [] {
-            const char *e = getenv("HPCLA_SPMM_XCD_GROUP");
-            return e ? atoi(e) : 0;
-        }();
-        const uint32_t xg = xg_env > 0 ? (uint32_t)xg_env : 0u;
-        dim3 vgrid = grid;
-        if (xg) vgrid = dim3((uint32_t)(((launch_blocks + 8ll * xg - 1) / (8ll * xg)) * 8ll * xg));
 #define HPCLA_SPMM_VEC(SP, VUU, CH, H64)                                                                \
-    spmm_rowblock_vec_kernel<I, SP, VUU, CH, H64><<<vgrid, block, 0, s>>>(                               \
+    spmm_rowblock_vec_kernel<I, SP, VUU, CH, H64><<<grid, block, 0, s>>>(                                \
         rowptr, colval, nzval, B_own, b_rs, SP ? B_ghost : nullptr, SP ? bg_rs : 0, SP ? n_own : 0, C, c_rs, \
-        nrows, k, index_base, block_list, (uint32_t)launch_blocks, xg)
-        // lane->column mapping (HPCLA_SPMM_HALF64 = 1: 64 contiguous bytes per row per load; needs k % 16 == 0)
+        nrows, k, index_base, block_list, (uint32_t)launch_blocks)
+        // lane->column mapping: 64 contiguous bytes per row per load when k % 16 == 0 (HPCLA_SPMM_HALF64=0: off)
         static const int h64_env = [] {
             const char *e = getenv("HPCLA_SPMM_HALF64");
-            return e ? atoi(e) : 0;
+            return e ? atoi(e) : 1;
         }();
         const bool h64 = h64_env != 0 && (k % 16) == 0;
 #define HPCLA_SPMM_VEC2(SP)                                                                             \
@@ -521,27 +369,7 @@ static int spmm_launch(const I *rowptr, const I *colval, const double *nzval, co
         } else if (small) { if (vu == 4) HPCLA_SPMM_VEC(SP, 4, 512, false); else HPCLA_SPMM_VEC(SP, 2, 512, false); } \
         else { if (vu == 4) HPCLA_SPMM_VEC(SP, 4, 1536, false); else HPCLA_SPMM_VEC(SP, 2, 1536, false); } \
     } while (0)
-        // software-pipelined tiles: HPCLA_SPMM_PIPE = T (tiles per workgroup: 0 = off, 2, 4 or 8)
-        static const int pipe_env = [] {
-            const char *e = getenv("HPCLA_SPMM_PIPE");
-            return e ? atoi(e) : 0;
-        }();
-        if (pipe_env > 0 && !xg && !h64) {
-            const int T = pipe_env >= 8 ? 8 : (pipe_env >= 4 ? 4 : 2);
-            dim3 pgrid((uint32_t)((launch_blocks + T - 1) / T));
-#define HPCLA_SPMM_PIPE(SP, CH, TT)                                                                     \
-    spmm_rowblock_pipe_kernel<I, SP, 2, CH, TT><<<pgrid, block, 0, s>>>(                                 \
-        rowptr, colval, nzval, B_own, b_rs, SP ? B_ghost : nullptr, SP ? bg_rs : 0, SP ? n_own : 0, C, c_rs, \
-        nrows, k, index_base, block_list, (uint32_t)launch_blocks)
-#define HPCLA_SPMM_PIPE2(SP)                                                                            \
-    do {                                                                                                \
-        if (small) { if (T == 8) HPCLA_SPMM_PIPE(SP, 512, 8); else if (T == 4) HPCLA_SPMM_PIPE(SP, 512, 4); else HPCLA_SPMM_PIPE(SP, 512, 2); } \
-        else { if (T == 8) HPCLA_SPMM_PIPE(SP, 768, 8); else if (T == 4) HPCLA_SPMM_PIPE(SP, 768, 4); else HPCLA_SPMM_PIPE(SP, 768, 2); } \
-    } while (0)
-            if (split) HPCLA_SPMM_PIPE2(true); else HPCLA_SPMM_PIPE2(false);
-#undef HPCLA_SPMM_PIPE2
-#undef HPCLA_SPMM_PIPE
-        } else if (split) HPCLA_SPMM_VEC2(true); else HPCLA_SPMM_VEC2(false);
+        if (split) HPCLA_SPMM_VEC2(true); else HPCLA_SPMM_VEC2(false);
 #undef HPCLA_SPMM_VEC2
 #undef HPCLA_SPMM_VEC
     } else if (split)

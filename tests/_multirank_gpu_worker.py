@@ -4,8 +4,9 @@ the peer-window transport supports (RCCL does not: "Duplicate GPU detected").
 
 Checks, each against the CPU oracle on identical inputs and therefore against the 1-rank result too
 (the 1-rank GPU product is bit-equal to the oracle, tests/test_gpu_parity.py):
-  * y = A*x distributed, bit-exact, for a stencil slab (contiguous sends), an unstructured matrix
-    (scattered sends, asymmetric neighbour sets) and x partitioned differently from A's rows;
+  * y = A*x distributed, bit-exact, for a 2-D stencil slab (contiguous sends), a 3-D slab whose halo planes
+    take several push chunks each, an unstructured matrix (scattered sends, asymmetric neighbour sets) and x
+    partitioned differently from A's rows;
   * 40 dependent steps x <- A*x/8 (free-running: exercises epochs, double buffering and acks);
   * dot / norm: 1e-12 relative to the oracle AND bit-identical on all ranks;
   * CG, 12 iterations, fused and unfused, residual history vs the oracle;
@@ -51,6 +52,12 @@ def main():
         n = nx * ny
         cases.append(("poisson2d", n, lambda lo, hi: orc.poisson2d_rows(nx, ny, lo, hi),
                       orc.uniform_partition(n, nranks), orc.uniform_partition(n, nranks)))
+        # 3-D slab: one 96 x 96 plane (9216 doubles = 72 KiB) per neighbour, i.e. a push of SEVERAL 32 KiB
+        # chunks per neighbour (arrival counter, last chunk publishes) -- config 4's shape in small
+        mx, my, mz = 96, 96, 5 * nranks + 1
+        n3d = mx * my * mz
+        cases.append(("poisson3d", n3d, lambda lo, hi: orc.poisson3d_rows(mx, my, mz, lo, hi),
+                      orc.uniform_partition(n3d, nranks), orc.uniform_partition(n3d, nranks)))
         # unstructured: every rank talks to every rank, scattered indices
         n2 = 30000
         cases.append(("sprand", n2, lambda lo, hi: orc.sprand_rows(n2, 0.0015, lo, hi),
@@ -118,7 +125,7 @@ def main():
             assert all(alld[2 * r] == d and alld[2 * r + 1] == nr for r in range(nranks)), \
                 f"{tag} {name}: dot/norm not uniform across ranks: {alld}"
 
-            if name == "poisson2d":
+            if name in ("poisson2d", "poisson3d"):
                 # CG (SPD matrix): 12 iterations, both forms, vs the oracle's restatement
                 bg = orc.fill_uniform(0, ng, orc.SEED_RHS)
                 b = hp.HPCVector.from_global(bg, backend, partition=rp)

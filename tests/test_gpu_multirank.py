@@ -63,7 +63,7 @@ def test_bench_launches_its_own_ranks():
     if _device_count() < 2:
         env["HPCLA_ALLOW_SHARED_GPU"] = "1"           # rehearsal: both ranks on the one GPU
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5",
-                          "--warmup", "2", "--size", "1024", "--strong-size", "1024", "--no-cpu-baseline"],
+                          "--warmup", "2", "--size", "1024", "--strong-size", "1024", "--no-cpu-baseline", "--no-extras"],
                          env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]

@@ -406,6 +406,25 @@ def test_spmm_golden_host_layer(hp, golden, gpu_backend_i32):
     assert abs(np.linalg.norm(C) - case["C_fro"]) < TOL_REF
 
 
+@pytest.mark.parametrize("dims,lo,hi", [((7, 5, 4), 0, 140), ((7, 5, 4), 33, 101), ((16, 16, 16), 1000, 4096),
+                                        ((1, 1, 5), 0, 5), ((3, 1, 1), 0, 3), ((40, 30, 20), 11111, 24000)])
+def test_device_poisson3d_generator_matches_oracle(hp, orc, dims, lo, hi):
+    """hpcla_gen_poisson3d (closed-form rowptr, 7-point rows) against the oracle's C generator, any row range."""
+    import torch
+    nx, ny, nz = dims
+    want = orc.poisson3d_rows(nx, ny, nz, lo, hi)
+    assert hp._capi.load().hpcla_poisson3d_nnz(nx, ny, nz, lo, hi) == want.nnz
+    rp = torch.empty(hi - lo + 1, dtype=torch.int64, device="cuda")
+    ci = torch.full((max(want.nnz, 1),), -7, dtype=torch.int64, device="cuda")
+    va = torch.full((max(want.nnz, 1),), float("nan"), dtype=torch.float64, device="cuda")
+    hp._capi.call("hpcla_gen_poisson3d", nx, ny, nz, lo, hi, rp.data_ptr(), ci.data_ptr(), va.data_ptr(),
+                  torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(rp.cpu().numpy(), want.rowptr)
+    np.testing.assert_array_equal(ci.cpu().numpy()[:want.nnz], want.colidx)
+    np.testing.assert_array_equal(va.cpu().numpy()[:want.nnz], want.vals)
+
+
 def test_to_backend_round_trip(hp, orc, gpu_backend_i32):
     """to_backend (src/HPCLinearAlgebra.jl:337-378): device -> CPU -> device keeps every bit and the
     structure; the CPU copy shares partitions / hashes / host structure arrays, drops cached_transpose, and is
