@@ -5,7 +5,7 @@ profiles/traffic_latest.json (HBM bytes per launch of the dominant kernel, corre
 /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE counts 128-byte requests as
 64 bytes -> doubled; WRITE_SIZE is exact; both are reported in KiB).
 
-usage: python benchmarks/collect_profiles.py TAG [ROUND]      (ROUND defaults to r01)
+usage: python benchmarks/collect_profiles.py TAG [ROUND]      (ROUND defaults to r02)
 """
 import csv
 import glob
@@ -15,7 +15,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL = "spmv_rowblock_quad_kernel<int, false>"
+KERNEL = "spmv_rowblock_quad_kernel<int, false, false>"     # <index type, SPLIT, WAIT>: the single-GPU headline kernel
 B_ALG = 1_341_980_676          # config 2, Int32
 
 
@@ -39,7 +39,7 @@ def counter_mean(path, name):
 
 def main():
     tag = sys.argv[1]
-    rnd = sys.argv[2] if len(sys.argv) > 2 else "r01"
+    rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
     prof = os.path.join(ROOT, "profiles")
     shutil.copy(find(tag, "prof", "kernel_stats.csv"), os.path.join(prof, f"{rnd}_bench_kernel_stats.csv"))
     # the trace is large: keep the SpMV launches only
@@ -63,7 +63,7 @@ def main():
     out = {
         "kernel": "hpcla::" + KERNEL,
         "source": f"profiles/{rnd}_bench_pmc_FETCH_SIZE.csv + profiles/{rnd}_bench_pmc_WRITE_SIZE.csv (separate rocprofv3 "
-                  f"--pmc passes over `python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline`; {nf} / {nw} launches)",
+                  f"--pmc passes over `python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-strong --no-extras --no-packed`; {nf} / {nw} launches)",
         "FETCH_SIZE_KB_mean": round(fetch_kb, 1), "WRITE_SIZE_KB_mean": round(write_kb, 1),
         "correction": "gfx950: FETCH_SIZE counts 128-B requests at 64 B -> doubled (MI355X_MICROARCH.md, HBM); WRITE_SIZE exact",
         "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": B_ALG,

@@ -103,7 +103,7 @@ __device__ __forceinline__ void block_dot_epilogue(double *s_scratch, double *__
 
 // ---- primary kernel: aligned quads (needs colval 4*sizeof(I)- and nzval 32-byte aligned) -----------
 template <typename I, bool SPLIT, bool WAIT>
-__global__ __launch_bounds__(RPB) __attribute__((amdgpu_num_sgpr(80), amdgpu_num_vgpr(64))) void spmv_rowblock_quad_kernel(
+__global__ __launch_bounds__(RPB) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8))) void spmv_rowblock_quad_kernel(
     const I *__restrict__ rowptr, const I *__restrict__ colval, const double *__restrict__ nzval,
     const double *__restrict__ x_own, const double *__restrict__ x_ghost, int64_t n_own,
     double *__restrict__ y, int64_t nrows, int64_t nnz, int base,
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(RPB) __attribute__((amdgpu_num_sgpr(80), amdgpu_num
 
 // ---- fallback kernel: element-per-lane loads, no alignment requirement --------------------------------
 template <typename I, bool SPLIT, bool WAIT>
-__global__ __launch_bounds__(RPB) __attribute__((amdgpu_num_sgpr(80), amdgpu_num_vgpr(64))) void spmv_rowblock_kernel(
+__global__ __launch_bounds__(RPB) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8))) void spmv_rowblock_kernel(
     const I *__restrict__ rowptr, const I *__restrict__ colval, const double *__restrict__ nzval,
     const double *__restrict__ x_own, const double *__restrict__ x_ghost, int64_t n_own,
     double *__restrict__ y, int64_t nrows, int base, BlockSel bs,

@@ -23,7 +23,7 @@ for st in $STEPS; do
     tune3d) run 600 gpurun_out/${TAG}_tune3d.log python benchmarks/tune_spmv.py --dim 3 --size 256 ${TUNE_ARGS}; tail -25 gpurun_out/${TAG}_tune3d.log;;
     prof)
       cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-      run 600 gpurun_out/${TAG}_prof.log rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_prof -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline
+      run 600 gpurun_out/${TAG}_prof.log rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_prof -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-strong --no-extras --no-packed
       tail -3 gpurun_out/${TAG}_prof.log;;
     spgemm) run 600 gpurun_out/${TAG}_spgemm.log python benchmarks/bench_spgemm.py; tail -5 gpurun_out/${TAG}_spgemm.log;;
     halo)   run 600 gpurun_out/${TAG}_halo.log python benchmarks/bench_halo_overhead.py; tail -5 gpurun_out/${TAG}_halo.log;;
@@ -67,10 +67,10 @@ for st in $STEPS; do
       run 600 gpurun_out/${TAG}_pmc_tune_wr.log rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/${TAG}_pmc_tune_wr -- python3 benchmarks/tune_spmv.py --variants 20,100,101 --rounds 1 --reps 3
       tail -2 gpurun_out/${TAG}_pmc_tune_wr.log;;
     pmc_rd)
-      run 600 gpurun_out/${TAG}_pmc_rd.log rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/${TAG}_pmc_rd -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline
+      run 600 gpurun_out/${TAG}_pmc_rd.log rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/${TAG}_pmc_rd -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-strong --no-extras --no-packed
       tail -2 gpurun_out/${TAG}_pmc_rd.log;;
     pmc_wr)
-      run 600 gpurun_out/${TAG}_pmc_wr.log rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/${TAG}_pmc_wr -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline
+      run 600 gpurun_out/${TAG}_pmc_wr.log rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/${TAG}_pmc_wr -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-strong --no-extras --no-packed
       tail -2 gpurun_out/${TAG}_pmc_wr.log;;
   esac
 done
