@@ -101,9 +101,8 @@ def _dist():
 
 def _host_device(comm: "CommTorch"):
     """Device on which host-side collectives stage their tensors: CPU when the group has a CPU
-    backend (gloo), else the current GPU (NCCL/RCCL-only groups).  Decided once per communicator
-    by the backend name, falling back to a one-element probe collective (every rank takes the same
-    branch, so the probe cannot desynchronise ranks)."""
+    backend (gloo / mpi), else the current GPU (NCCL/RCCL-only groups).  Decided once per communicator
+    from the backend name alone (the same string on every rank)."""
     import torch
     if getattr(comm, "_host_dev", None) is not None:
         return comm._host_dev
@@ -114,12 +113,7 @@ def _host_device(comm: "CommTorch"):
     elif name == "nccl":
         dev = torch.device("cuda", torch.cuda.current_device())
     else:
-        try:
-            t = torch.zeros(1, dtype=torch.int64)
-            dist.all_reduce(t, group=comm.group)
-            dev = torch.device("cpu")
-        except Exception:
-            dev = torch.device("cuda", torch.cuda.current_device())
+        raise ValueError(f"CommTorch: process-group backend {name!r} is neither a CPU backend (gloo, mpi) nor nccl")
     comm._host_dev = dev
     return dev
 

@@ -209,8 +209,12 @@ def spgemm_local(A, g_rowptr, g_col, g_val, ncols_global: int, col_partition, ca
         caps = []
         while lib.hpcla_spgemm_bin_cap(len(caps)) >= 0:          # bins are the library's to define
             caps.append(lib.hpcla_spgemm_bin_cap(len(caps)))
-        if nrows and ub_h.max() > caps[-1]:
-            raise NotImplementedError(f"SpGEMM: an output row has up to {int(ub_h.max())} candidate entries; "
+        # the limit is checked COLLECTIVELY (A*B is collective): every rank learns the worst row of any rank and
+        # all raise together -- a rank raising alone would leave the others waiting in the next collective
+        from .backends import comm_allgather
+        worst = int(comm_allgather(A.backend.comm, np.array([int(ub_h.max()) if nrows else 0], dtype=np.int64)).max())
+        if worst > caps[-1]:
+            raise NotImplementedError(f"SpGEMM: an output row has up to {worst} candidate entries; "
                                       f"this build handles {caps[-1]}")
         ub_prefix_h = np.concatenate([[0], np.cumsum(ub_h)]).astype(np.int64)
         bins, lo = [], -1

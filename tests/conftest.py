@@ -22,7 +22,8 @@ def pytest_sessionstart(session):
     if not os.path.exists(lib):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "linearalgebrampi.jl_amd", "csrc")],
                               stdout=subprocess.DEVNULL)
-    if not any(f.endswith(".so") for f in os.listdir(os.path.join(ROOT, "oracle"))):
+    built = os.path.join(ROOT, "oracle", "_build")               # where oracle/Makefile puts liborc.so
+    if not (os.path.isdir(built) and any(f.endswith(".so") for f in os.listdir(built))):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
 
 

@@ -6,12 +6,15 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import hpcla_amd  # noqa: E402,F401  (makes hpcla_amd.launch importable)
 
 
 @pytest.mark.parametrize("nranks", [2, 3])
 def test_vector_plan_across_processes_gloo(nranks):
     env = dict(os.environ, OMP_NUM_THREADS="1")
-    port = 29600 + nranks
+    from hpcla_amd.launch import free_port
+    port = free_port()                       # picked at run time: fixed ports collide when sessions share a host
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nranks}",
            "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "tests", "_dist_worker.py")]

@@ -23,6 +23,11 @@ TOL_REF = 1e-10      # reference absolute tolerance on its O(10) fixtures
 RTOL_RED = 1e-12     # BASELINE.json: 1e-12 relative for fp64
 
 
+def _free_port():
+    from hpcla_amd.launch import free_port
+    return free_port()
+
+
 def _t(a, dev="cuda"):
     import torch
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -1217,7 +1222,7 @@ def test_host_collectives_on_mixed_gloo_nccl_group():
     build_host_vector_plan must work on that mixed group exactly as on the gloo-only group of the CPU tests."""
     env = dict(os.environ, OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-           "--master-addr", "127.0.0.1", "--master-port", "29733", os.path.join(ROOT, "tests", "_mixed_pg_worker.py")]
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_mixed_pg_worker.py")]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert out.stdout.count("mixed-backend host collectives OK") == 2
