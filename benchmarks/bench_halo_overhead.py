@@ -23,10 +23,19 @@ def main():
     backend = hp.backend_rocm_serial(np.float64, np.int32)
     capi, lib = hp._capi, hp._capi.load()
     s = torch.cuda.current_stream().cuda_stream
-    nx = ny = 4096
-    nloc = nx * ny
-    # middle slab of a 3-slab grid: ghosts below (nx) and above (nx)
-    rowptr, colidx, vals = wl.poisson2d_rows(nx, 3 * ny, nloc, 2 * nloc)
+    dim3 = len(sys.argv) > 1 and sys.argv[1] == "--dim3"
+    if dim3:
+        # config 4's per-GPU share: 512 x 512 x 64 slab of the 7-point matrix, ghost PLANES of 262 144 values (2 MiB)
+        N, planes = 512, 64
+        nx = N * N                                           # "reach": one plane
+        nloc = nx * planes
+        rowptr, colidx, vals = wl.poisson3d_rows(N, N, 3 * planes, nloc, 2 * nloc)
+        print(f"3-D slab {N}x{N}x{planes}: ghost planes of {nx} values ({nx * 8 / 2**20:.1f} MiB each)")
+    else:
+        nx = ny = 4096
+        nloc = nx * ny
+        # middle slab of a 3-slab grid: ghosts below (nx) and above (nx)
+        rowptr, colidx, vals = wl.poisson2d_rows(nx, 3 * ny, nloc, 2 * nloc)
     colidx = colidx - nloc                                   # own columns 0..nloc-1, ghosts <0 and >= nloc
     split = np.where(colidx < 0, nloc + (colidx + nx), np.where(colidx >= nloc, nloc + nx + (colidx - nloc), colidx))
     d_rp = torch.from_numpy(rowptr.astype(np.int32)).cuda()

@@ -110,8 +110,27 @@ __device__ __forceinline__ void halo_push_block(const PushArgs &a, int b)
     const int64_t hi = lo + per < total ? lo + per : total;
     if (T.first >= 0) {
         const double *src = a.x + T.first * w;
-        for (int64_t i = lo + threadIdx.x; i < hi; i += NT)
-            __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // contiguous run (every slab partition): 16-byte write-through stores where source and destination
+        // are 16-byte aligned TOGETHER (an 8-byte store is one fabric write per lane and costs ~2.7x per byte,
+        // MI355X_MICROARCH.md visibility table); the ragged ends and the misaligned case go 8 bytes at a time
+        const bool pair = (((reinterpret_cast<uintptr_t>(src + lo) ^ reinterpret_cast<uintptr_t>(dst + lo)) & 15) == 0);
+        int64_t i0 = lo, i1 = hi;
+        if (pair) {
+            if ((reinterpret_cast<uintptr_t>(dst + lo) & 15) != 0 && lo < hi) i0 = lo + 1;     // one leading double
+            i1 = i0 + ((hi - i0) & ~(int64_t)1);
+            if (threadIdx.x == 0 && i0 > lo)
+                __hip_atomic_store(dst + lo, src[lo], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            for (int64_t i = i0 + 2 * (int64_t)threadIdx.x; i < i1; i += 2 * NT) {
+                typedef double v2d __attribute__((ext_vector_type(2)));
+                const v2d v = *reinterpret_cast<const v2d *>(src + i);
+                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst + i), "v"(v) : "memory");
+            }
+            if (threadIdx.x == 0 && i1 < hi)
+                __hip_atomic_store(dst + i1, src[i1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        } else {
+            for (int64_t i = lo + threadIdx.x; i < hi; i += NT)
+                __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     } else if (w == 1) {
         for (int64_t i = lo + threadIdx.x; i < hi; i += NT)
             __hip_atomic_store(dst + i, a.x[(int64_t)idx[T.src_off + i]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -165,7 +165,9 @@ __global__ __launch_bounds__(TPB_MM) void spmm_rowblock_kernel(
 // the misses are compulsory); software-pipelined tiles (a workgroup owning T = 2/4/8 tiles, rowptr slices
 // up front, next pass's A entries requested before the current pass's B gathers, double-buffered LDS
 // records: 0.583 / 0.587 / 0.592 vs 0.595 ms on the stencil, and 1.44 / 1.50 / 1.80 vs 1.38 ms on config 5's
-// random pattern -- the dependent chain is not the limit); kept: the HALF64 lane mapping below (+1.5 %).  For
+// random pattern -- the dependent chain is not the limit); eight lanes per row, one 16-byte load per entry,
+// a whole 5-entry row's gathers issued in ONE round trip (62 VGPRs, 8 waves/SIMD: 0.626 vs 0.589 ms, slower --
+// the number of gather rounds is not the limit either); kept: the HALF64 lane mapping below (+1.5 %).  For
 // scale: on the same box a device copy B -> C runs at 4.8 TB/s, a read-only pass at 5.9, a fill at 6.3
 // (profiles/r02_stream_mix_ceiling.log); this kernel's byte mix (40 % writes) moved as separate ideal streams
 // takes 0.544 ms there, the kernel 0.612.
@@ -277,85 +279,6 @@ __global__ __launch_bounds__(TPB_MM) void spmm_rowblock_vec_kernel(
     }
 }
 
-// Eight lanes per row (full 16-column tiles): lane l owns columns {2l, 2l+1}, so ONE 16-byte load per entry
-// per lane and the eight lanes of a row read its whole 128-byte B row in one instruction (a wave: 8 rows x 8
-// lanes = 8 full lines per instruction, instead of 16 half lines twice).  With 4 registers of B data per
-// entry instead of 8, VU8 entries are in flight at once inside the 64-VGPR budget: a 5-point row issues ALL
-// its gathers in one round trip where the 4-lane form needs three (two pairs and a single).  A workgroup
-// still owns RPB_MM = 64 rows (the granularity the host classifies interior / boundary blocks at), with
-// 512 threads.
-constexpr int TPB8 = RPB_MM * 8;
-
-template <typename I, bool SPLIT, int VU8, int CHUNK_V>
-__global__ __launch_bounds__(TPB8) __attribute__((amdgpu_waves_per_eu(8, 8))) void spmm_rowblock_vec8_kernel(
-    const I *__restrict__ rowptr, const I *__restrict__ colval, const double *__restrict__ nzval,
-    const double *__restrict__ B_own, int64_t b_rs, const double *__restrict__ B_ghost, int64_t bg_rs,
-    int64_t n_own, double *__restrict__ C, int64_t c_rs, int64_t nrows, int k, int base,
-    const int32_t *__restrict__ block_list, uint32_t nblocks)
-{
-    __shared__ SpmmEntry s_ent[CHUNK_V];
-
-    const int tid = threadIdx.x;
-    const int g = tid >> 3, l = tid & 7;    // g = row of the block (0..63), l = lane of the row
-    const uint32_t b = blockIdx.x;
-    const int64_t blk = block_list ? (int64_t)block_list[b] : (int64_t)b;
-    const int64_t r0 = blk * RPB_MM;
-    const int nr = (int)((nrows - r0) < RPB_MM ? (nrows - r0) : RPB_MM);
-    const int64_t p0 = (int64_t)rowptr[r0] - base;
-    const int64_t p1 = (int64_t)rowptr[r0 + nr] - base;
-    const int64_t total = p1 - p0;
-    int64_t lo = 0, hi = 0;
-    if (g < nr) {
-        lo = (int64_t)rowptr[r0 + g] - base - p0;
-        hi = (int64_t)rowptr[r0 + g + 1] - base - p0;
-    }
-
-    for (int kt = 0; kt < k; kt += KT) {
-        const int c = kt + 2 * l;
-        const int64_t lane_bytes = (int64_t)c * (int64_t)sizeof(double);
-        double acc0 = 0.0, acc1 = 0.0;
-
-        for (int64_t ch = 0; ch < total; ch += CHUNK_V) {
-            const int n = (int)((total - ch) < CHUNK_V ? (total - ch) : CHUNK_V);
-            __syncthreads();   // previous pass finished reading LDS
-            for (int i = tid; i < n; i += TPB8) {
-                const int64_t col = (int64_t)__builtin_nontemporal_load(colval + p0 + ch + i) - base;
-                SpmmEntry e;
-                e.val = __builtin_nontemporal_load(nzval + p0 + ch + i);
-                e.row = (SPLIT && col >= n_own) ? B_ghost + (col - n_own) * bg_rs : B_own + col * b_rs;
-                s_ent[i] = e;
-            }
-            __syncthreads();
-            int j = (int)((lo > ch ? lo : ch) - ch);
-            const int e = (int)((hi < ch + n ? hi : ch + n) - ch);
-            // up to VU8 entries per step, all requested before the first is used; a short row is ONE step.
-            // Loads are unconditional (a step's missing tail entries re-read its last entry: an L1 hit), only the
-            // additions are predicated -- straight-line code, no per-entry branches around the loads.
-            for (; j < e; j += VU8) {
-                const int last = e - 1 - j;                  // >= 0
-                SpmmEntry en[VU8];
-                vdouble2 bv[VU8];
-#pragma unroll
-                for (int u = 0; u < VU8; ++u) en[u] = s_ent[j + (u < last ? u : last)];
-#pragma unroll
-                for (int u = 0; u < VU8; ++u)
-                    bv[u] = *(gvec2_ptr)(reinterpret_cast<const char *>(en[u].row) + lane_bytes);
-#pragma unroll
-                for (int u = 0; u < VU8; ++u)
-                    if (u <= last) {
-                        acc0 += en[u].val * bv[u].x;
-                        acc1 += en[u].val * bv[u].y;
-                    }
-            }
-        }
-        if (g < nr) {
-            vdouble2 o;
-            o.x = acc0; o.y = acc1;
-            *reinterpret_cast<vdouble2 *>(C + (r0 + g) * c_rs + c) = o;
-        }
-    }
-}
-
 // tiled transpose / layout conversion: dst(i,c) = src(i,c), arbitrary (row,col) strides
 __global__ __launch_bounds__(256) void relayout_kernel(const double *__restrict__ src,
                                                        int64_t s_rs, int64_t s_cs,
@@ -448,21 +371,7 @@ static int spmm_launch(const I *rowptr, const I *colval, const double *nzval, co
         } else if (small) { if (vu == 4) HPCLA_SPMM_VEC(SP, 4, 512, false); else HPCLA_SPMM_VEC(SP, 2, 512, false); } \
         else { if (vu == 4) HPCLA_SPMM_VEC(SP, 4, 1536, false); else HPCLA_SPMM_VEC(SP, 2, 1536, false); } \
     } while (0)
-        // eight lanes per row (k % 16 == 0): HPCLA_SPMM_LANES8 = 1 / 0 (default on), entries in flight VU8 = 5
-        static const int lanes8_env = [] {
-            const char *e = getenv("HPCLA_SPMM_LANES8");
-            return e ? atoi(e) : 1;
-        }();
-        if (lanes8_env != 0 && (k % 16) == 0) {
-            dim3 block8(TPB8);
-#define HPCLA_SPMM_VEC8(SP, CH)                                                                         \
-    spmm_rowblock_vec8_kernel<I, SP, 5, CH><<<grid, block8, 0, s>>>(                                     \
-        rowptr, colval, nzval, B_own, b_rs, SP ? B_ghost : nullptr, SP ? bg_rs : 0, SP ? n_own : 0, C, c_rs, \
-        nrows, k, index_base, block_list, (uint32_t)launch_blocks)
-            if (split) { if (small) HPCLA_SPMM_VEC8(true, 512); else HPCLA_SPMM_VEC8(true, 1536); }
-            else { if (small) HPCLA_SPMM_VEC8(false, 512); else HPCLA_SPMM_VEC8(false, 1536); }
-#undef HPCLA_SPMM_VEC8
-        } else if (split) HPCLA_SPMM_VEC2(true); else HPCLA_SPMM_VEC2(false);
+        if (split) HPCLA_SPMM_VEC2(true); else HPCLA_SPMM_VEC2(false);
 #undef HPCLA_SPMM_VEC2
 #undef HPCLA_SPMM_VEC
     } else if (split)
