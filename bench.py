@@ -567,7 +567,7 @@ def _run(args):
     }
     if breakdown is not None:
         result["step_breakdown_ms_max_over_ranks"] = breakdown
-    if rank == 0 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline:      # the contract: rank 0 at N = 1 only
         lo, hi = run.lo, run.hi
         xg = x.local_values()
         if plan.has_halo:
