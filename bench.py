@@ -178,11 +178,15 @@ def step_breakdown(hp, job, backend, plan, A, x, y):
     cur = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     sfx = "i64" if plan.is_i64 else "i32"
 
-    def ghost():
-        gp, gn = ctypes.c_void_p(), ctypes.c_int64(0)
-        if plan.has_halo:
-            capi.call("hpcla_halo_ghost_ptr", plan.halo, ctypes.byref(gp), ctypes.byref(gn))
-        return (gp if gp.value else None), int(gn.value)
+    _g = []
+
+    def ghost():                         # fetched ONCE: for a double-buffered plan the call reads the device step counter
+        if not _g:
+            gp, gn = ctypes.c_void_p(), ctypes.c_int64(0)
+            if plan.has_halo:
+                capi.call("hpcla_halo_ghost_ptr", plan.halo, ctypes.byref(gp), ctypes.byref(gn))
+            _g.append(((gp if gp.value else None), int(gn.value)))
+        return _g[0]
 
     def split(blocks, nb):
         capi.call(f"hpcla_spmv_split_f64_{sfx}", sp(A.rowptr_target), sp(plan.colval_split), sp(A.nzval), sp(x.v),

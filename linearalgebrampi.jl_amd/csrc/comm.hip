@@ -454,7 +454,7 @@ HPCLA_API int hpcla_halo_begin(hpcla_halo_plan_t *plan, const double *x, void *s
         if (plan->n_send_total > 0 && !x) return set_error(HPCLA_ERR_INVALID, "halo_begin: null x");
         HPCLA_CHECK_HIP(hipEventRecord(plan->ev_ready, as_stream(stream)));
         HPCLA_CHECK_HIP(hipStreamWaitEvent(plan->side, plan->ev_ready, 0));
-        int rc = push_post(plan, x, plan->side);
+        int rc = push_post(plan, x, 1, plan->side);          // readers: the push workgroups + halo_end's wait kernel
         if (rc) return rc;
         HPCLA_CHECK_HIP(hipEventRecord(plan->ev_done, plan->side));
         return HPCLA_OK;
@@ -530,14 +530,7 @@ namespace hpcla {
 // the exchange on the caller's stream itself (serial mode), for packed.hip
 int halo_exchange_inline(hpcla_halo_plan_t *plan, const double *x, void *stream)
 {
-    if (plan && halo_active(plan) && halo_mode_of(plan) == HALO_PUSH) return push_post(plan, x, stream);
     return halo_post(plan, x, stream, false, true);
-}
-// ... and what must precede the first ghost read on that stream (push: the device-side flag wait)
-int halo_exchange_inline_finish(hpcla_halo_plan_t *plan, void *stream)
-{
-    if (plan && halo_active(plan) && halo_mode_of(plan) == HALO_PUSH) return push_wait_kernel_launch(plan, stream);
-    return HPCLA_OK;
 }
 
 bool halo_serial_mode(const hpcla_halo_plan_t *plan) { return halo_mode_of(plan) != HALO_OVERLAP; }
@@ -610,16 +603,17 @@ static int spmv_dist_impl(F split_fn, G fused_fn, hpcla_halo_plan_t *plan, const
         PushArgs pa;
         int rcp;
         if ((plan->idx_is_i64 != 0) == (sizeof(I) == 8)) {
-            rcp = push_begin(plan, x, stream, &pa);        // the push rides in the leading workgroups of the launch
+            rcp = push_begin(plan, x, n_boundary, &pa);    // the push rides in the leading workgroups of the launch
         } else {                                           // send lists typed unlike the matrix: push kernel of its own
-            rcp = push_post(plan, x, stream);
+            rcp = push_post(plan, x, n_boundary, stream);
             memset(&pa, 0, sizeof(pa));
         }
         if (rcp) return rcp;
         const bool contig = n_interior > 0 && plan->probed_contig;
-        return fused_fn(rowptr, colval, nzval, x, push_ghost_ptr(plan), n_own, y, nrows, nnz, index_base,
+        // (the ghost argument is buffer 0; a boundary workgroup computes the buffer of its epoch after its wait)
+        return fused_fn(rowptr, colval, nzval, x, plan->ghost, n_own, y, nrows, nnz, index_base,
                         contig ? nullptr : interior, contig ? plan->probed_first : 0, n_interior, boundary,
-                        n_boundary, push_wait_args(plan), pa, stream, dot_partial);
+                        n_boundary, push_wait_args(plan, n_boundary), pa, stream, dot_partial);
     }
     if (mode == HALO_SERIAL) {
         int rc0 = halo_post(plan, x, stream, false, true);

@@ -63,7 +63,7 @@ struct hpcla_comm {
     std::vector<hpcla::PeerMap> peers;         // [nranks]
     void **peer_slots_dev = nullptr;           // device array [nranks]: base of every rank's slot area
     bool win_attached = false;
-    uint64_t ar_epoch = 0;
+    uint64_t *ar_done_dev = nullptr;           // device: window all-reduces completed (read + bumped by the kernel)
 };
 
 struct hpcla_halo_plan {
@@ -99,7 +99,7 @@ struct hpcla_halo_plan {
     void *push_block_map_dev = nullptr;        // device int32[push_blocks][2]: (neighbour, chunk)
     uint64_t *arrive = nullptr;                // device, local: arrival counters, one per send neighbour
     bool attached = false;
-    uint64_t epoch = 0;                        // exchanges posted so far
+    uint64_t *epoch_dev = nullptr;             // device {done (u64), ticket (u32)}: the plan's step counter (halo_wait.h)
 };
 
 namespace hpcla {
@@ -125,11 +125,12 @@ HaloMode halo_mode_of(const hpcla_halo_plan *plan);
 bool halo_want_window();                       // false when HPCLA_HALO_MODE names an RCCL mode
 
 // window.hip
-int push_begin(hpcla_halo_plan *plan, const double *x, void *stream, PushArgs *out);   // next epoch + launch args
-int push_post(hpcla_halo_plan *plan, const double *x, void *stream);       // acks + payload + flags (own kernel)
+// n_wait_readers = waiting workgroups of the exchange (boundary blocks of a fused launch; 1 for the wait kernel)
+int push_begin(hpcla_halo_plan *plan, const double *x, int64_t n_wait_readers, PushArgs *out);   // launch args
+int push_post(hpcla_halo_plan *plan, const double *x, int64_t n_wait_readers, void *stream);     // own kernel
 int push_wait_kernel_launch(hpcla_halo_plan *plan, void *stream);          // standalone wait (halo_end)
-double *push_ghost_ptr(const hpcla_halo_plan *plan);                       // buffer of the current epoch
-HaloWait push_wait_args(const hpcla_halo_plan *plan);
+double *push_ghost_ptr(const hpcla_halo_plan *plan);                       // host view (may synchronise)
+HaloWait push_wait_args(const hpcla_halo_plan *plan, int64_t n_wait_readers);
 void push_free(hpcla_halo_plan *plan);
 int push_plan_alloc(hpcla_halo_plan *plan);                                // window instead of a plain ghost
 int window_allreduce(hpcla_comm *comm, double *buf, int64_t count, int op, void *stream);

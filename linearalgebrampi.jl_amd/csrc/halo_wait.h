@@ -7,27 +7,61 @@ namespace hpcla {
 
 constexpr int WIN_FLAG_STRIDE_U64 = 16;        // one polled word per 128-byte line
 
-// what a consuming launch needs: the plan's LOCAL flag lines and the epoch of this step
+// The step counter of a plan lives in DEVICE memory: `done` = exchanges completed, `ticket` = workgroups of
+// the exchange in flight that no longer need its number.  Every workgroup that takes part in an exchange
+// (push workgroups, waiting workgroups: its `n_readers`, possibly spread over two kernels) reads
+// e = done + 1 when it starts and releases it once; the LAST release stores done = e.  Nobody writes `done`
+// while a reader can still read it, and no launch argument changes from step to step -- so a step can be
+// captured into a HIP graph and replayed.
+struct EpochRef {
+    uint64_t *done;
+    uint32_t *ticket;
+    uint32_t n_readers;
+};
+
+__device__ __forceinline__ uint64_t epoch_current(const EpochRef &r)
+{
+    return __hip_atomic_load(r.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+}
+
+__device__ __forceinline__ void epoch_release(const EpochRef &r, uint64_t e)     // ONE lane per reader workgroup
+{
+    const uint32_t old = __hip_atomic_fetch_add(r.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old + 1 == r.n_readers) {
+        __hip_atomic_store(r.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(r.done, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// what a consuming launch needs: the plan's LOCAL flag lines, its step counter, and where the ghost buffer of
+// a given epoch is
 struct HaloWait {
     const uint64_t *flags;                     // n_flags lines, stride WIN_FLAG_STRIDE_U64
     int n_flags;
-    uint64_t epoch;
+    EpochRef er;
     uint32_t *status;                          // set to 1 when a spin timed out (the grid still drains)
     int64_t timeout_ticks;                     // wall_clock64 ticks (100 MHz)
+    const double *ghost0;                      // ghost buffer 0; buffer of epoch e = ghost0 + (e % nbuf) * stride
+    int64_t buf_stride;
+    int nbuf;
 };
 
 // Called by EVERY thread of a workgroup (it contains a barrier).  One lane polls with relaxed
 // system-scope loads (no fence per poll), then ONE system-scope acquire drops this CU's stale lines;
 // the other waves read the ghosts only after the barrier (MI355X visibility rules: the acquire is per
 // CU, the barrier holds the other waves until it has completed).
-__device__ __forceinline__ void halo_wait_block(const HaloWait &w)
+// Returns the INDEX of the ghost buffer of the exchange waited for (epoch % nbuf), as a wave-uniform value
+// (readfirstlane: the caller's pointer arithmetic then stays in scalar registers).
+__device__ __forceinline__ uint32_t halo_wait_block(const HaloWait &w)
 {
+    __shared__ uint32_t s_buf;
     if (threadIdx.x == 0) {
+        const uint64_t epoch = epoch_current(w.er);
         const int64_t t0 = (int64_t)wall_clock64();
         bool ok = true;
         for (int i = 0; i < w.n_flags && ok; ++i) {
             const uint64_t *f = w.flags + (int64_t)i * WIN_FLAG_STRIDE_U64;
-            while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < w.epoch) {
+            while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
                 __builtin_amdgcn_s_sleep(2);
                 if ((int64_t)wall_clock64() - t0 > w.timeout_ticks) {
                     __hip_atomic_store(w.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -38,8 +72,11 @@ __device__ __forceinline__ void halo_wait_block(const HaloWait &w)
         }
         __atomic_thread_fence(__ATOMIC_ACQUIRE);           // system scope
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+        s_buf = (uint32_t)(epoch % (uint64_t)w.nbuf);
+        epoch_release(w.er, epoch);                        // the number is not needed any more (the DATA is:
+    }                                                      // the producers learn that from the next step's acks)
     __syncthreads();
+    return __builtin_amdgcn_readfirstlane(s_buf);
 }
 
 // ---- producer side -----------------------------------------------------------------------------
@@ -65,7 +102,7 @@ struct PushArgs {
     int n_ack_out;
     uint64_t *arrive;                   // local arrival counters, one per send neighbour
     uint32_t *status;
-    uint64_t epoch;
+    EpochRef er;                        // the plan's step counter (device memory)
     int w;                              // doubles per index
     int64_t timeout_ticks;
     int n_blocks;                       // push workgroups (>= 1 whenever the plan has neighbours)
@@ -92,16 +129,21 @@ __device__ __forceinline__ bool spin_until_ge(const uint64_t *word, uint64_t wan
 template <typename I, int NT>
 __device__ __forceinline__ void halo_push_block(const PushArgs &a, int b)
 {
+    const uint64_t epoch = epoch_current(a.er);        // every lane reads it (one request per wave); released below
     if (b == 0)
         for (int j = threadIdx.x; j < a.n_ack_out; j += NT)
-            __hip_atomic_store(a.ack_out[j], a.epoch - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(a.ack_out[j], epoch - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const int t = a.map[2 * b], c = a.map[2 * b + 1];
-    if (t < 0) return;
+    if (t < 0) {                                       // acks only (no send neighbour)
+        __syncthreads();
+        if (threadIdx.x == 0) epoch_release(a.er, epoch);
+        return;
+    }
     const PushTarget T = a.targets[t];
-    if (threadIdx.x == 0 && a.epoch > (uint64_t)T.nbuf)
-        spin_until_ge(T.ack, a.epoch - (uint64_t)T.nbuf, (int64_t)wall_clock64(), a.timeout_ticks, a.status);
+    if (threadIdx.x == 0 && epoch > (uint64_t)T.nbuf)
+        spin_until_ge(T.ack, epoch - (uint64_t)T.nbuf, (int64_t)wall_clock64(), a.timeout_ticks, a.status);
     __syncthreads();
-    double *dst = T.ghost + (int64_t)(a.epoch % (uint64_t)T.nbuf) * T.buf_stride;
+    double *dst = T.ghost + (int64_t)(epoch % (uint64_t)T.nbuf) * T.buf_stride;
     const I *idx = reinterpret_cast<const I *>(a.idx);
     const int w = a.w;
     const int64_t total = T.count * w;
@@ -149,13 +191,14 @@ __device__ __forceinline__ void halo_push_block(const PushArgs &a, int b)
         bool last = true;
         if (T.nchunks > 1) {
             const uint64_t old = __hip_atomic_fetch_add(a.arrive + t, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            last = (old + 1 == a.epoch * (uint64_t)T.nchunks);
+            last = (old + 1 == epoch * (uint64_t)T.nchunks);
         }
         if (last) {
             __atomic_thread_fence(__ATOMIC_RELEASE);             // system scope
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(T.flag, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(T.flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
+        epoch_release(a.er, epoch);
     }
 }
 

@@ -22,7 +22,9 @@
 #include <new>
 #include <vector>
 
-#include "common.h"
+#include <string.h>
+
+#include "comm_internal.h"
 
 namespace hpcla {
 
@@ -39,7 +41,9 @@ int reduce_partials_sum(const double *partial, int64_t np, double *scratch, doub
 int allreduce_on(hpcla_comm_t *comm, double *buf, int64_t count, int op, void *stream);
 bool halo_active(const hpcla_halo_plan_t *plan);   // comm.hip
 bool halo_serial_mode(const hpcla_halo_plan_t *plan);   // comm.hip (HPCLA_HALO_MODE; push counts as serial)
-int halo_exchange_inline_finish(hpcla_halo_plan_t *plan, void *stream);
+int spmv_fused_i32(const int32_t *, const int32_t *, const double *, const double *, const double *, int64_t,
+                   double *, int64_t, int64_t, int, const int32_t *, int64_t, int64_t, const int32_t *, int64_t,
+                   const HaloWait &, const PushArgs &, void *, double *);     // spmv.hip
 int halo_exchange_inline(hpcla_halo_plan_t *plan, const double *x, void *stream);   // comm.hip
 
 }  // namespace hpcla
@@ -374,6 +378,30 @@ HPCLA_API int hpcla_spmv_dist_packed_f64_i32(hpcla_halo_plan_t *plan, hpcla_comm
             return set_error(HPCLA_ERR_INVALID, "spmv_dist_packed: block lists must cover every row block");
         // same two orderings as the CSR step (comm.hip, spmv_dist_impl): exchange first on the caller's
         // stream, or on the side stream next to the interior blocks
+        if (halo_mode_of(plan) == HALO_PUSH) {
+            // push transport: the push kernel, the packed interior blocks, then the boundary blocks through the
+            // CSR kernel's waiting form (they poll the flags themselves and find the ghost buffer of the epoch)
+            rc = push_post(plan, x, n_boundary, stream);
+            if (rc) return rc;
+            if (n_interior > 0) {
+                rc = hpcla_spmv_packed_f64_i32(p, rowptr, x, y, index_base, interior_blocks, n_interior, partial, stream);
+                if (rc) return rc;
+            }
+            if (n_boundary > 0) {
+                PushArgs nopush;
+                memset(&nopush, 0, sizeof(nopush));
+                rc = spmv_fused_i32(rowptr, colval_split, nzval, x, plan->ghost, n_own, y, nrows, nnz, index_base,
+                                    nullptr, 0, 0, boundary_blocks, n_boundary, push_wait_args(plan, n_boundary),
+                                    nopush, stream, partial);
+                if (rc) return rc;
+            }
+            if (dot_out_dev) {
+                rc = reduce_partials_sum(partial, all_blocks, scratch, dot_out_dev, stream);
+                if (rc) return rc;
+                if (comm) return allreduce_on(comm, dot_out_dev, 1, 0, stream);
+            }
+            return HPCLA_OK;
+        }
         const bool serial = halo_serial_mode(plan);
         rc = serial ? halo_exchange_inline(plan, x, stream) : hpcla_halo_begin(plan, x, stream);
         if (rc) return rc;
@@ -381,8 +409,10 @@ HPCLA_API int hpcla_spmv_dist_packed_f64_i32(hpcla_halo_plan_t *plan, hpcla_comm
             rc = hpcla_spmv_packed_f64_i32(p, rowptr, x, y, index_base, interior_blocks, n_interior, partial, stream);
             if (rc) return rc;
         }
-        rc = serial ? halo_exchange_inline_finish(plan, stream) : hpcla_halo_end(plan, stream);
-        if (rc) return rc;
+        if (!serial) {
+            rc = hpcla_halo_end(plan, stream);
+            if (rc) return rc;
+        }
         if (n_boundary > 0) {
             double *ghost = nullptr;
             rc = hpcla_halo_ghost_ptr(plan, &ghost, nullptr);

@@ -105,7 +105,7 @@ __device__ __forceinline__ void block_dot_epilogue(double *s_scratch, double *__
 template <typename I, bool SPLIT, bool WAIT>
 __global__ __launch_bounds__(RPB) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8))) void spmv_rowblock_quad_kernel(
     const I *__restrict__ rowptr, const I *__restrict__ colval, const double *__restrict__ nzval,
-    const double *__restrict__ x_own, const double *__restrict__ x_ghost, int64_t n_own,
+    const double *__restrict__ x_own, const double *x_ghost, int64_t n_own,
     double *__restrict__ y, int64_t nrows, int64_t nnz, int base,
     BlockSel bs, double *__restrict__ dot_partial, HaloWait hw, PushArgs push)
 {
@@ -122,6 +122,10 @@ __global__ __launch_bounds__(RPB) __attribute__((amdgpu_num_sgpr(80), amdgpu_wav
     // critical path rowptr -> A -> x); arbitrary subsets go through the list
     bool wait_ghosts;
     const int64_t blk = select_block<WAIT>(bs, wait_ghosts, WAIT ? push.n_blocks : 0);
+    // boundary workgroup of a fused distributed launch (workgroup-uniform branch): the ghosts may be read once
+    // every neighbour has published this step; the buffer of the step's epoch is computed here, uniformly, so
+    // the loop below is the same code as in the plain kernel
+    if (WAIT && wait_ghosts) x_ghost = hw.ghost0 + (int64_t)halo_wait_block(hw) * hw.buf_stride;
     const int64_t r0 = blk * RPB;
     const int nr = (int)((nrows - r0) < RPB ? (nrows - r0) : RPB);
 
@@ -168,9 +172,6 @@ __global__ __launch_bounds__(RPB) __attribute__((amdgpu_num_sgpr(80), amdgpu_wav
                 }
             }
         }
-        // boundary workgroup of a fused distributed launch: the A stream above is already in flight;
-        // the ghosts may be read once every neighbour has published this step (workgroup-uniform branch)
-        if (WAIT && wait_ghosts && c == 0) halo_wait_block(hw);
         // gather phase: all x loads of the pass issued back to back (addresses first, then loads, then
         // the multiplies -- written as separate loops so hipcc clusters the loads instead of waiting
         // for each gather before issuing the next)
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(RPB) __attribute__((amdgpu_num_sgpr(80), amdgpu_wav
 template <typename I, bool SPLIT, bool WAIT>
 __global__ __launch_bounds__(RPB) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8))) void spmv_rowblock_kernel(
     const I *__restrict__ rowptr, const I *__restrict__ colval, const double *__restrict__ nzval,
-    const double *__restrict__ x_own, const double *__restrict__ x_ghost, int64_t n_own,
+    const double *__restrict__ x_own, const double *x_ghost, int64_t n_own,
     double *__restrict__ y, int64_t nrows, int base, BlockSel bs,
     double *__restrict__ dot_partial, HaloWait hw, PushArgs push)
 {
@@ -235,6 +236,10 @@ __global__ __launch_bounds__(RPB) __attribute__((amdgpu_num_sgpr(80), amdgpu_wav
     const int tid = threadIdx.x;
     bool wait_ghosts;
     const int64_t blk = select_block<WAIT>(bs, wait_ghosts, WAIT ? push.n_blocks : 0);
+    // boundary workgroup of a fused distributed launch (workgroup-uniform branch): the ghosts may be read once
+    // every neighbour has published this step; the buffer of the step's epoch is computed here, uniformly, so
+    // the loop below is the same code as in the plain kernel
+    if (WAIT && wait_ghosts) x_ghost = hw.ghost0 + (int64_t)halo_wait_block(hw) * hw.buf_stride;
     const int64_t r0 = blk * RPB;
     const int nr = (int)((nrows - r0) < RPB ? (nrows - r0) : RPB);
 
@@ -263,7 +268,6 @@ __global__ __launch_bounds__(RPB) __attribute__((amdgpu_num_sgpr(80), amdgpu_wav
                 val[u] = nv[i];
             }
         }
-        if (WAIT && wait_ghosts && c == 0) halo_wait_block(hw);
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             const int i = tid + u * RPB;
@@ -367,7 +371,8 @@ static int spmv_launch(const I *rowptr, const I *colval, const double *nzval, co
     const bool aligned = (reinterpret_cast<uintptr_t>(colval) % (4 * sizeof(I)) == 0) &&
                          (reinterpret_cast<uintptr_t>(nzval) % 32 == 0);
     const BlockSel bs{block_list, block_base, nullptr, 0, 0};
-    const HaloWait nowait{nullptr, 0, 0, nullptr, 0};
+    HaloWait nowait;
+    memset(&nowait, 0, sizeof(nowait));
     PushArgs nopush;
     memset(&nopush, 0, sizeof(nopush));
     if (aligned) {

@@ -21,6 +21,7 @@
 //     "I have finished reading epoch e-1" before it waits for anything), so a fast rank can never
 //     overwrite values a slow neighbour is still reading, for symmetric and asymmetric patterns alike.
 //
+// The step epochs live in device memory (halo_wait.h), so distributed steps are HIP-graph capturable.
 // Every spin is bounded (HPCLA_PUSH_TIMEOUT_S, default 20 s): on expiry the kernel sets the plan's
 // status word and carries on, so a grid always drains; hpcla_halo_status reports it.
 #include <stdlib.h>
@@ -136,7 +137,10 @@ int push_plan_alloc(hpcla_halo_plan *p)
     const uint32_t nf = (uint32_t)p->recv_ranks.size(), na = (uint32_t)p->send_ranks.size();
     const size_t ctrl = halo_ctrl_bytes(nf, na);
     const size_t buf = halo_buf_bytes((uint64_t)p->n_ghost, (uint32_t)p->width);
-    p->nbuf = (int64_t)buf <= WIN_DOUBLE_BUFFER_MAX ? 2 : 1;
+    // vectors (the fused SpMV computes the buffer of its epoch in the kernel): two buffers, one step of slack
+    // between neighbours; dense ghost rows (their consumers take the ghost pointer from the host): one buffer,
+    // the ack wait orders producer and consumer strictly
+    p->nbuf = (p->width == 1 && (int64_t)buf <= WIN_DOUBLE_BUFFER_MAX) ? 2 : 1;
     p->win_bytes = ctrl + buf * p->nbuf;
     int rc = window_alloc(&p->win, p->win_bytes);
     if (rc) return rc;
@@ -145,7 +149,20 @@ int push_plan_alloc(hpcla_halo_plan *p)
     p->acks = reinterpret_cast<uint64_t *>(base + (size_t)nf * WIN_LINE);
     p->status = reinterpret_cast<uint32_t *>(base + (size_t)(nf + na) * WIN_LINE);
     p->ghost = reinterpret_cast<double *>(base + ctrl);
+    // step counter {done, ticket}: ordinary device memory, only this rank's kernels touch it
+    hipError_t e = hipMalloc((void **)&p->epoch_dev, 16);
+    if (e == hipSuccess) e = hipMemset(p->epoch_dev, 0, 16);
+    if (e != hipSuccess) return set_error(HPCLA_ERR_HIP, "window step counter: %s", hipGetErrorString(e));
     return HPCLA_OK;
+}
+
+static EpochRef epoch_ref(const hpcla_halo_plan *p, int64_t n_wait_readers)
+{
+    EpochRef r;
+    r.done = p->epoch_dev;
+    r.ticket = reinterpret_cast<uint32_t *>(p->epoch_dev + 1);
+    r.n_readers = (uint32_t)(p->push_blocks + n_wait_readers);
+    return r;
 }
 
 constexpr int PUSH_THREADS = 256;
@@ -167,36 +184,43 @@ __global__ __launch_bounds__(64) void halo_wait_kernel(HaloWait w)
     halo_wait_block(w);
 }
 
-HaloWait push_wait_args(const hpcla_halo_plan *p)
+// n_wait_readers: waiting workgroups of the exchange (boundary blocks of the fused launch, or 1 for the
+// standalone wait kernel); together with the plan's push workgroups they are the exchange's epoch readers
+HaloWait push_wait_args(const hpcla_halo_plan *p, int64_t n_wait_readers)
 {
     HaloWait w;
     w.flags = p->flags;
     w.n_flags = (int)p->recv_ranks.size();
-    w.epoch = p->epoch;
+    w.er = epoch_ref(p, n_wait_readers);
     w.status = p->status;
     w.timeout_ticks = spin_timeout_ticks();
+    w.ghost0 = p->ghost;
+    w.buf_stride = (int64_t)(halo_buf_bytes((uint64_t)p->n_ghost, (uint32_t)p->width) / sizeof(double));
+    w.nbuf = p->nbuf;
     return w;
 }
 
+// Host view of "the ghost buffer of the exchange completed last".  Single-buffered plans (dense ghost rows):
+// a constant.  Double-buffered plans: reads the device step counter, i.e. SYNCHRONISES the device -- only the
+// API-parity path (execute_plan) asks; the fused SpMV computes its buffer in the kernel.
 double *push_ghost_ptr(const hpcla_halo_plan *p)
 {
     if (!p->win || p->nbuf < 2) return p->ghost;
+    uint64_t done = 0;
+    if (hipDeviceSynchronize() != hipSuccess ||
+        hipMemcpy(&done, p->epoch_dev, sizeof(done), hipMemcpyDeviceToHost) != hipSuccess)
+        return p->ghost;
     const size_t buf = halo_buf_bytes((uint64_t)p->n_ghost, (uint32_t)p->width);
-    return p->ghost + (p->epoch % 2) * (buf / sizeof(double));
+    return p->ghost + (done % 2) * (buf / sizeof(double));
 }
 
-// next epoch of the plan + the launch arguments of its push workgroups (the caller launches them: either
-// halo_push_kernel or the leading workgroups of the fused SpMV)
-int push_begin(hpcla_halo_plan *p, const double *x, void *stream, PushArgs *out)
+// launch arguments of the plan's push workgroups (the caller launches them: halo_push_kernel, or the leading
+// workgroups of the fused SpMV).  Nothing in them changes from step to step: the epoch is read from the plan's
+// device-resident step counter, so the step is capturable into a HIP graph.
+int push_begin(hpcla_halo_plan *p, const double *x, int64_t n_wait_readers, PushArgs *out)
 {
     if (!p->attached) return set_error(HPCLA_ERR_INVALID, "halo push: plan has no attached peer windows");
     if (p->n_send_total > 0 && !x) return set_error(HPCLA_ERR_INVALID, "halo push: null x");
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(as_stream(stream), &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
-        return set_error(HPCLA_ERR_UNSUPPORTED,
-                         "halo push: the step epoch is a launch argument, so a push-mode exchange cannot be "
-                         "captured into a HIP graph (use HPCLA_HALO_MODE=serial for graph capture)");
-    p->epoch += 1;
     out->x = x;
     out->idx = p->send_idx;
     out->targets = (const PushTarget *)p->push_desc_dev;
@@ -205,17 +229,17 @@ int push_begin(hpcla_halo_plan *p, const double *x, void *stream, PushArgs *out)
     out->n_ack_out = (int)p->recv_ranks.size();
     out->arrive = p->arrive;
     out->status = p->status;
-    out->epoch = p->epoch;
+    out->er = epoch_ref(p, n_wait_readers);
     out->w = p->width;
     out->timeout_ticks = spin_timeout_ticks();
     out->n_blocks = (int)p->push_blocks;
     return HPCLA_OK;
 }
 
-int push_post(hpcla_halo_plan *p, const double *x, void *stream)
+int push_post(hpcla_halo_plan *p, const double *x, int64_t n_wait_readers, void *stream)
 {
     PushArgs a;
-    int rc = push_begin(p, x, stream, &a);
+    int rc = push_begin(p, x, n_wait_readers, &a);
     if (rc) return rc;
     if (p->idx_is_i64)
         halo_push_kernel<int64_t><<<(uint32_t)a.n_blocks, PUSH_THREADS, 0, as_stream(stream)>>>(a);
@@ -225,10 +249,11 @@ int push_post(hpcla_halo_plan *p, const double *x, void *stream)
     return HPCLA_OK;
 }
 
+// the standalone consumer: ONE waiting workgroup (launched even without recv neighbours: it is one of the
+// exchange's epoch readers)
 int push_wait_kernel_launch(hpcla_halo_plan *p, void *stream)
 {
-    if (p->recv_ranks.empty()) return HPCLA_OK;
-    halo_wait_kernel<<<1, 64, 0, as_stream(stream)>>>(push_wait_args(p));
+    halo_wait_kernel<<<1, 64, 0, as_stream(stream)>>>(push_wait_args(p, 1));
     HPCLA_CHECK_LAUNCH();
     return HPCLA_OK;
 }
@@ -243,8 +268,10 @@ void push_free(hpcla_halo_plan *p)
     if (p->ack_desc_dev) (void)hipFree(p->ack_desc_dev);
     if (p->push_block_map_dev) (void)hipFree(p->push_block_map_dev);
     if (p->arrive) (void)hipFree(p->arrive);
+    if (p->epoch_dev) (void)hipFree(p->epoch_dev);
     p->push_desc_dev = p->ack_desc_dev = p->push_block_map_dev = nullptr;
     p->arrive = nullptr;
+    p->epoch_dev = nullptr;
     if (p->win) {
         (void)hipFree(p->win);
         p->win = nullptr;
@@ -262,10 +289,12 @@ void push_free(hpcla_halo_plan *p)
 __global__ __launch_bounds__(64) void window_allreduce_kernel(uint64_t *const *__restrict__ peer_slots,
                                                               uint64_t *my_slots, uint32_t *status,
                                                               double *buf, int count, int op, int nranks,
-                                                              int my_rank, uint64_t epoch, int64_t timeout)
+                                                              int my_rank, uint64_t *done, int64_t timeout)
 {
     __shared__ double s_val[64][AR_MAX];
     const int j = threadIdx.x;
+    // the all-reduce counter lives in device memory (graph-capturable): this kernel is its only reader/writer
+    const uint64_t epoch = __hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
     const uint64_t parity = epoch & 1;
     if (j < nranks) {
         uint64_t *dst = peer_slots[j] + (parity * (uint64_t)nranks + (uint64_t)my_rank) * WIN_LINE_U64;
@@ -288,21 +317,18 @@ __global__ __launch_bounds__(64) void window_allreduce_kernel(uint64_t *const *_
         for (int r = 1; r < nranks; ++r) acc = op == 0 ? acc + s_val[r][j] : (s_val[r][j] > acc ? s_val[r][j] : acc);
         buf[j] = acc;
     }
+    if (j == 0) __hip_atomic_store(done, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every lane has read it (barrier above)
 }
 
 int window_allreduce(hpcla_comm *comm, double *buf, int64_t count, int op, void *stream)
 {
     hipStream_t s = as_stream(stream);
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
-        return set_error(HPCLA_ERR_UNSUPPORTED, "window all-reduce cannot be captured into a HIP graph");
     uint64_t *my_slots = reinterpret_cast<uint64_t *>(reinterpret_cast<uint8_t *>(comm->win) + WIN_LINE);
     uint32_t *status = reinterpret_cast<uint32_t *>(comm->win);
     for (int64_t off = 0; off < count; off += AR_MAX) {
         const int n = (int)((count - off) < AR_MAX ? (count - off) : AR_MAX);
-        comm->ar_epoch += 1;
         window_allreduce_kernel<<<1, 64, 0, s>>>((uint64_t *const *)comm->peer_slots_dev, my_slots, status,
-                                                 buf + off, n, op, comm->nranks, comm->rank, comm->ar_epoch,
+                                                 buf + off, n, op, comm->nranks, comm->rank, comm->ar_done_dev,
                                                  spin_timeout_ticks());
         HPCLA_CHECK_LAUNCH();
     }
@@ -315,6 +341,8 @@ void comm_window_free(hpcla_comm *comm)
     comm->peers.clear();
     if (comm->peer_slots_dev) (void)hipFree(comm->peer_slots_dev);
     comm->peer_slots_dev = nullptr;
+    if (comm->ar_done_dev) (void)hipFree(comm->ar_done_dev);
+    comm->ar_done_dev = nullptr;
     if (comm->win) (void)hipFree(comm->win);
     comm->win = nullptr;
     comm->win_attached = false;
@@ -364,6 +392,8 @@ HPCLA_API int hpcla_comm_window_attach(hpcla_comm_t *comm, const uint8_t *all_de
     }
     hipError_t e = hipMalloc((void **)&comm->peer_slots_dev, sizeof(void *) * n);
     if (e == hipSuccess) e = hipMemcpy(comm->peer_slots_dev, slots.data(), sizeof(void *) * n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void **)&comm->ar_done_dev, sizeof(uint64_t));
+    if (e == hipSuccess) e = hipMemset(comm->ar_done_dev, 0, sizeof(uint64_t));
     if (e != hipSuccess) {
         comm_window_free(comm);
         return set_error(HPCLA_ERR_HIP, "comm_window_attach: %s", hipGetErrorString(e));
@@ -388,10 +418,9 @@ HPCLA_API int hpcla_comm_window_selftest(hpcla_comm_t *comm, double timeout_s, i
     uint32_t st = 1;
     if (e == hipSuccess) {
         uint64_t *my_slots = reinterpret_cast<uint64_t *>(reinterpret_cast<uint8_t *>(comm->win) + WIN_LINE);
-        comm->ar_epoch += 1;
         window_allreduce_kernel<<<1, 64, 0, nullptr>>>((uint64_t *const *)comm->peer_slots_dev, my_slots,
                                                        reinterpret_cast<uint32_t *>(comm->win), buf, 1, 0,
-                                                       comm->nranks, comm->rank, comm->ar_epoch,
+                                                       comm->nranks, comm->rank, comm->ar_done_dev,
                                                        (int64_t)((timeout_s > 0 ? timeout_s : 5.0) * 1.0e8));
         e = hipGetLastError();
         if (e == hipSuccess) e = hipDeviceSynchronize();

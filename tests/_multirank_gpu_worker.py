@@ -9,7 +9,8 @@ Checks, each against the CPU oracle on identical inputs and therefore against th
     partitioned differently from A's rows;
   * 40 dependent steps x <- A*x/8 (free-running: exercises epochs, double buffering and acks);
   * dot / norm: 1e-12 relative to the oracle AND bit-identical on all ranks;
-  * CG, 12 iterations, fused and unfused, residual history vs the oracle;
+  * CG, 12 iterations, fused and unfused, residual history vs the oracle -- eagerly and replayed from a captured
+    HIP graph (bit-identical);
   * A*B with k = 16 and k = 3 dense columns (distributed SpMM), Int32 and Int64;
   * mul_dot_ (fused SpMV + p.Ap);
   * no push/wait timed out.
@@ -133,6 +134,12 @@ def main():
                 for fused in (True, False):
                     xc, hist = hp.cg_fixed_iterations(A, b, 12, fused=fused)
                     assert np.allclose(hist, hist_ref, rtol=1e-9, atol=0), (tag, fused, hist, hist_ref)
+                    # the same iterations replayed from a captured HIP graph: the push-mode step keeps its epoch
+                    # in device memory, so a distributed step is capturable; bit-identical to the eager loop
+                    xg2, hist_g = hp.cg_fixed_iterations(A, b, 12, fused=fused, graph=True)
+                    assert hist_g == hist, (tag, fused, "graph replay differs", hist_g, hist)
+                    assert np.array_equal(xg2.local_values(), xc.local_values())
+                    assert not hp.get_vector_plan(A, b).timed_out()
                 # fused SpMV + p.Ap
                 out = torch.zeros(1, dtype=torch.float64, device="cuda")
                 yy = xv.similar()
