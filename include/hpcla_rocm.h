@@ -318,7 +318,10 @@ int hpcla_halo_plan_attach(hpcla_halo_plan_t *plan, const uint8_t *all_descs_hos
 int hpcla_halo_plan_detach(hpcla_halo_plan_t *plan);
 /* 1 in *timed_out if a push or wait of this plan gave up (result invalid); synchronising 4-byte read. */
 int hpcla_halo_status(hpcla_halo_plan_t *plan, int *timed_out);
-/* device pointer of the ghost buffer (n_ghost*width doubles) and its length in indices */
+/* device pointer of the ghost buffer of the exchange completed last (n_ghost*width doubles) and its length in
+ * indices.  Constant for RCCL plans and for dense (width > 1) push plans; a double-buffered vector push plan
+ * reads its device step counter here, i.e. the call SYNCHRONISES the device -- only the API-parity path
+ * (execute_plan!'s `gathered`) asks, the fused SpMV finds its buffer in the kernel. */
 int hpcla_halo_ghost_ptr(hpcla_halo_plan_t *plan, double **ghost, int64_t *n_ghost);
 /* begin: after everything already enqueued on `stream`, pack x[send_idx] and post the
  * ncclSend/ncclRecv group on the plan's side stream (tag-21 exchange, src/vectors.jl:431-446).
