@@ -99,7 +99,7 @@ struct hpcla_halo_plan {
     void *push_block_map_dev = nullptr;        // device int32[push_blocks][2]: (neighbour, chunk)
     uint64_t *arrive = nullptr;                // device, local: arrival counters, one per send neighbour
     bool attached = false;
-    uint64_t *epoch_dev = nullptr;             // device {done (u64), ticket (u32)}: the plan's step counter (halo_wait.h)
+    uint64_t *epoch_dev = nullptr;             // device {done, top, shard counters}: the plan's step counter (halo_wait.h)
 };
 
 namespace hpcla {

@@ -13,9 +13,16 @@ constexpr int WIN_FLAG_STRIDE_U64 = 16;        // one polled word per 128-byte l
 // e = done + 1 when it starts and releases it once; the LAST release stores done = e.  Nobody writes `done`
 // while a reader can still read it, and no launch argument changes from step to step -- so a step can be
 // captured into a HIP graph and replayed.
+//
+// The releases are counted in TWO levels (EPOCH_SHARDS counters on lines of their own, then one top counter):
+// a 3-D slab has thousands of waiting workgroups, and read-modify-write atomics on ONE address serialise at
+// ~40 ns each (2048 boundary blocks on a single ticket cost +84 us per step; sharded: back to +10).
+constexpr uint32_t EPOCH_SHARDS = 64;
+constexpr uint32_t EPOCH_SHARD_STRIDE = 16;          // u32 words between shard counters (64 bytes)
+constexpr size_t EPOCH_BYTES = 64 + 64 + (size_t)EPOCH_SHARDS * EPOCH_SHARD_STRIDE * 4;   // done | top | shards
+
 struct EpochRef {
-    uint64_t *done;
-    uint32_t *ticket;
+    uint64_t *done;          // + 16 u32 words: the top counter; + 32 words: the shard counters
     uint32_t n_readers;
 };
 
@@ -24,13 +31,20 @@ __device__ __forceinline__ uint64_t epoch_current(const EpochRef &r)
     return __hip_atomic_load(r.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
 }
 
-__device__ __forceinline__ void epoch_release(const EpochRef &r, uint64_t e)     // ONE lane per reader workgroup
+// ONE lane per reader workgroup; `reader` = this workgroup's index among the exchange's readers (0..n_readers-1)
+__device__ __forceinline__ void epoch_release(const EpochRef &r, uint64_t e, uint32_t reader)
 {
-    const uint32_t old = __hip_atomic_fetch_add(r.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (old + 1 == r.n_readers) {
-        __hip_atomic_store(r.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(r.done, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    uint32_t *top = reinterpret_cast<uint32_t *>(r.done) + 16;
+    uint32_t *shards = reinterpret_cast<uint32_t *>(r.done) + 32;
+    const uint32_t sh = reader % EPOCH_SHARDS;
+    const uint32_t in_shard = (r.n_readers - sh + EPOCH_SHARDS - 1) / EPOCH_SHARDS;     // readers with this residue
+    uint32_t *cnt = shards + sh * EPOCH_SHARD_STRIDE;
+    if (__hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 != in_shard) return;
+    __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t active = r.n_readers < EPOCH_SHARDS ? r.n_readers : EPOCH_SHARDS;
+    if (__hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 != active) return;
+    __hip_atomic_store(top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(r.done, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // what a consuming launch needs: the plan's LOCAL flag lines, its step counter, and where the ghost buffer of
@@ -44,6 +58,7 @@ struct HaloWait {
     const double *ghost0;                      // ghost buffer 0; buffer of epoch e = ghost0 + (e % nbuf) * stride
     int64_t buf_stride;
     int nbuf;
+    uint32_t first_wait_reader;                // reader index of the first waiting workgroup (= the plan's push blocks)
 };
 
 // Called by EVERY thread of a workgroup (it contains a barrier).  One lane polls with relaxed
@@ -51,8 +66,9 @@ struct HaloWait {
 // the other waves read the ghosts only after the barrier (MI355X visibility rules: the acquire is per
 // CU, the barrier holds the other waves until it has completed).
 // Returns the INDEX of the ghost buffer of the exchange waited for (epoch % nbuf), as a wave-uniform value
-// (readfirstlane: the caller's pointer arithmetic then stays in scalar registers).
-__device__ __forceinline__ uint32_t halo_wait_block(const HaloWait &w)
+// (readfirstlane: the caller's pointer arithmetic then stays in scalar registers).  `reader` = this workgroup's
+// index among the exchange's epoch readers.
+__device__ __forceinline__ uint32_t halo_wait_block(const HaloWait &w, uint32_t reader)
 {
     __shared__ uint32_t s_buf;
     if (threadIdx.x == 0) {
@@ -73,7 +89,7 @@ __device__ __forceinline__ uint32_t halo_wait_block(const HaloWait &w)
         __atomic_thread_fence(__ATOMIC_ACQUIRE);           // system scope
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         s_buf = (uint32_t)(epoch % (uint64_t)w.nbuf);
-        epoch_release(w.er, epoch);                        // the number is not needed any more (the DATA is:
+        epoch_release(w.er, epoch, reader);                // the number is not needed any more (the DATA is:
     }                                                      // the producers learn that from the next step's acks)
     __syncthreads();
     return __builtin_amdgcn_readfirstlane(s_buf);
@@ -136,7 +152,7 @@ __device__ __forceinline__ void halo_push_block(const PushArgs &a, int b)
     const int t = a.map[2 * b], c = a.map[2 * b + 1];
     if (t < 0) {                                       // acks only (no send neighbour)
         __syncthreads();
-        if (threadIdx.x == 0) epoch_release(a.er, epoch);
+        if (threadIdx.x == 0) epoch_release(a.er, epoch, (uint32_t)b);
         return;
     }
     const PushTarget T = a.targets[t];
@@ -198,7 +214,7 @@ __device__ __forceinline__ void halo_push_block(const PushArgs &a, int b)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_store(T.flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
-        epoch_release(a.er, epoch);
+        epoch_release(a.er, epoch, (uint32_t)b);           // push workgroups are readers 0 .. n_blocks-1
     }
 }
 

@@ -125,7 +125,8 @@ __global__ __launch_bounds__(RPB) __attribute__((amdgpu_num_sgpr(80), amdgpu_wav
     // boundary workgroup of a fused distributed launch (workgroup-uniform branch): the ghosts may be read once
     // every neighbour has published this step; the buffer of the step's epoch is computed here, uniformly, so
     // the loop below is the same code as in the plain kernel
-    if (WAIT && wait_ghosts) x_ghost = hw.ghost0 + (int64_t)halo_wait_block(hw) * hw.buf_stride;
+    if (WAIT && wait_ghosts)       // reader index: the plan's push workgroups come first (window.hip), then the boundary blocks
+        x_ghost = hw.ghost0 + (int64_t)halo_wait_block(hw, hw.first_wait_reader + (uint32_t)(blockIdx.x - push.n_blocks - bs.n_first)) * hw.buf_stride;
     const int64_t r0 = blk * RPB;
     const int nr = (int)((nrows - r0) < RPB ? (nrows - r0) : RPB);
 
@@ -239,7 +240,8 @@ __global__ __launch_bounds__(RPB) __attribute__((amdgpu_num_sgpr(80), amdgpu_wav
     // boundary workgroup of a fused distributed launch (workgroup-uniform branch): the ghosts may be read once
     // every neighbour has published this step; the buffer of the step's epoch is computed here, uniformly, so
     // the loop below is the same code as in the plain kernel
-    if (WAIT && wait_ghosts) x_ghost = hw.ghost0 + (int64_t)halo_wait_block(hw) * hw.buf_stride;
+    if (WAIT && wait_ghosts)       // reader index: the plan's push workgroups come first (window.hip), then the boundary blocks
+        x_ghost = hw.ghost0 + (int64_t)halo_wait_block(hw, hw.first_wait_reader + (uint32_t)(blockIdx.x - push.n_blocks - bs.n_first)) * hw.buf_stride;
     const int64_t r0 = blk * RPB;
     const int nr = (int)((nrows - r0) < RPB ? (nrows - r0) : RPB);
 

@@ -150,8 +150,8 @@ int push_plan_alloc(hpcla_halo_plan *p)
     p->status = reinterpret_cast<uint32_t *>(base + (size_t)(nf + na) * WIN_LINE);
     p->ghost = reinterpret_cast<double *>(base + ctrl);
     // step counter {done, ticket}: ordinary device memory, only this rank's kernels touch it
-    hipError_t e = hipMalloc((void **)&p->epoch_dev, 16);
-    if (e == hipSuccess) e = hipMemset(p->epoch_dev, 0, 16);
+    hipError_t e = hipMalloc((void **)&p->epoch_dev, EPOCH_BYTES);
+    if (e == hipSuccess) e = hipMemset(p->epoch_dev, 0, EPOCH_BYTES);
     if (e != hipSuccess) return set_error(HPCLA_ERR_HIP, "window step counter: %s", hipGetErrorString(e));
     return HPCLA_OK;
 }
@@ -160,7 +160,6 @@ static EpochRef epoch_ref(const hpcla_halo_plan *p, int64_t n_wait_readers)
 {
     EpochRef r;
     r.done = p->epoch_dev;
-    r.ticket = reinterpret_cast<uint32_t *>(p->epoch_dev + 1);
     r.n_readers = (uint32_t)(p->push_blocks + n_wait_readers);
     return r;
 }
@@ -181,7 +180,7 @@ __global__ __launch_bounds__(PUSH_THREADS) void halo_push_kernel(PushArgs a)
 // stream start behind its acquire
 __global__ __launch_bounds__(64) void halo_wait_kernel(HaloWait w)
 {
-    halo_wait_block(w);
+    halo_wait_block(w, w.first_wait_reader);
 }
 
 // n_wait_readers: waiting workgroups of the exchange (boundary blocks of the fused launch, or 1 for the
@@ -197,6 +196,7 @@ HaloWait push_wait_args(const hpcla_halo_plan *p, int64_t n_wait_readers)
     w.ghost0 = p->ghost;
     w.buf_stride = (int64_t)(halo_buf_bytes((uint64_t)p->n_ghost, (uint32_t)p->width) / sizeof(double));
     w.nbuf = p->nbuf;
+    w.first_wait_reader = (uint32_t)p->push_blocks;
     return w;
 }
 

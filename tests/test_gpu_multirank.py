@@ -31,7 +31,7 @@ def _spawn(nranks, env_extra, timeout=600):
     return spawn_ranks([WORKER], nranks, env_extra=env_extra, timeout=timeout, forward_rank0_stdout=False)
 
 
-@pytest.mark.parametrize("nranks", [2, 3])
+@pytest.mark.parametrize("nranks", [2, 3, 4])
 def test_push_transport_ranks_exchange(nranks):
     """Default mode (push): halo by direct peer stores, scalar all-reduce through the communicator window."""
     env = {"HPCLA_PUSH_TIMEOUT_S": "30"}
