@@ -46,7 +46,7 @@ struct PeerMap {                               // a peer's window mapped into th
 };
 
 uint64_t host_identity();
-int window_alloc(void **p, size_t bytes);
+int window_alloc(void **p, size_t bytes, bool uncached);
 int window_open(const WindowDesc &d, int peer_rank, int my_rank, void *my_base, PeerMap *out);
 void window_close(PeerMap *m);
 int64_t spin_timeout_ticks();                  // HPCLA_PUSH_TIMEOUT_S (default 20 s) in wall_clock64 ticks

@@ -63,10 +63,20 @@ int64_t spin_timeout_ticks()
     return ticks;
 }
 
-int window_alloc(void **p, size_t bytes)
+int window_alloc(void **p, size_t bytes, bool uncached)
 {
-    // fine-grained: coherent for stores arriving from peers while kernels of this device read it
-    HPCLA_CHECK_HIP(hipExtMallocWithFlags(p, bytes, hipDeviceMallocFinegrained));
+    // Memory that PEERS store into while kernels of this device read it.  Control lines and vector ghost
+    // segments (KiB..MiB, each value read once or twice per step): UNCACHED -- never held in this device's L2s,
+    // so a value stored by a peer cannot be shadowed by a stale line whatever the acquire does or does not
+    // invalidate.  Dense ghost rows (config 5: 1.9 GB gathered ~30x per row): FINE-GRAINED -- cacheable, kept
+    // coherent by the system-scope acquire in front of the consumer (and a kernel boundary).
+    // HPCLA_WINDOW_ALLOC=finegrained|uncached overrides both.
+    static const int forced = [] {
+        const char *e = getenv("HPCLA_WINDOW_ALLOC");
+        return !e ? -1 : (e[0] == 'u' ? 1 : 0);
+    }();
+    if (forced >= 0) uncached = forced == 1;
+    HPCLA_CHECK_HIP(hipExtMallocWithFlags(p, bytes, uncached ? hipDeviceMallocUncached : hipDeviceMallocFinegrained));
     hipError_t e = hipMemset(*p, 0, bytes);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
@@ -142,7 +152,7 @@ int push_plan_alloc(hpcla_halo_plan *p)
     // the ack wait orders producer and consumer strictly
     p->nbuf = (p->width == 1 && (int64_t)buf <= WIN_DOUBLE_BUFFER_MAX) ? 2 : 1;
     p->win_bytes = ctrl + buf * p->nbuf;
-    int rc = window_alloc(&p->win, p->win_bytes);
+    int rc = window_alloc(&p->win, p->win_bytes, p->width == 1);
     if (rc) return rc;
     uint8_t *base = reinterpret_cast<uint8_t *>(p->win);
     p->flags = reinterpret_cast<uint64_t *>(base);
@@ -360,7 +370,7 @@ HPCLA_API int hpcla_comm_window_export(hpcla_comm_t *comm, uint8_t *desc_host)
         return set_error(HPCLA_ERR_UNSUPPORTED, "comm_window_export: the window all-reduce supports <= 64 ranks");
     if (!comm->win) {
         comm->win_bytes = (size_t)WIN_LINE * (1 + 2 * (size_t)comm->nranks);
-        int rc = window_alloc(&comm->win, comm->win_bytes);
+        int rc = window_alloc(&comm->win, comm->win_bytes, true);
         if (rc) return rc;
     }
     WindowDesc d;
