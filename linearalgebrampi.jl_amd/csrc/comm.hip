@@ -623,22 +623,29 @@ static int spmv_dist_impl(F split_fn, G fused_fn, hpcla_halo_plan_t *plan, const
     }
     int rc = halo_post(plan, x, stream, false);
     if (rc) return rc;
+    // from here on the side stream carries work that writes the ghost segment / y: whatever fails below, the
+    // caller's stream is joined to it before the error is reported
+    auto join_and_fail = [&](int code) {
+        (void)hipEventRecord(plan->ev_done, plan->side);
+        (void)hipStreamWaitEvent(as_stream(stream), plan->ev_done, 0);
+        return code;
+    };
     if (n_boundary > 0) {
         rc = split_fn(rowptr, colval, nzval, x, plan->ghost, n_own, y, nrows, nnz, index_base,
                       boundary, n_boundary, plan->side, dot_partial, -1);
-        if (rc) return rc;
+        if (rc) return join_and_fail(rc);
     }
     HPCLA_CHECK_HIP(hipEventRecord(plan->ev_done, plan->side));
     if (n_interior > 0) {
         rc = probe_interior(plan, interior, n_interior);
-        if (rc) return rc;
+        if (rc) return join_and_fail(rc);
         if (plan->probed_contig)
             rc = split_fn(rowptr, colval, nzval, x, plan->ghost, n_own, y, nrows, nnz, index_base,
                           nullptr, n_interior, stream, dot_partial, plan->probed_first);
         else
             rc = split_fn(rowptr, colval, nzval, x, plan->ghost, n_own, y, nrows, nnz, index_base,
                           interior, n_interior, stream, dot_partial, -1);
-        if (rc) return rc;
+        if (rc) return join_and_fail(rc);
     }
     return hpcla_halo_end(plan, stream);
 }
