@@ -271,18 +271,80 @@ end
 # ---- A * B, B::HPCMatrix  (replaces the column loop of src/sparse.jl:2391-2413) ---------------------------
 # Julia's Matrix is column-major; the kernel's fast layout is row-major (one 128-byte line per B row at
 # k = 16), so B is converted once with hpcla_transpose_f64 and C converted back.
-function Base.:*(A::HPCSparseMatrix{T,Ti,B}, M::HPCMatrix{T,B}) where {T<:Float64,Ti<:Int32,B<:ROCBackend}
-    comm_size(A.backend.comm) == 1 || error("multi-rank SpMM: bind hpcla_spmm_split_f64_i32 + a width-k halo plan (see linearalgebrampi.jl_amd/dense.py)")
+const _spmm_plans = IdDict{Any,Any}()     # (reference plan, k) -> (halo handle, interior, boundary); freed with the plan cache
+
+# width-k halo plan for the ghost ROWS of B: the reference VectorPlan's own lists, `width = k` values per index
+# (row-major rows travel as contiguous k-doubles).  The Python twin additionally swaps a neighbour's requested
+# rows for its WHOLE slice when more than half of it is needed (config 5; linearalgebrampi.jl_amd/sparse.py
+# whole_slice_lists) -- an optimisation of the lists, not of this binding.
+function _spmm_halo(A::HPCSparseMatrix{T,Ti,B}, plan, d::ROCVectorPlan{Ti}, k::Int) where {T,Ti,B<:ROCBackend}
+    get!(_spmm_plans, (plan, k)) do
+        halo = Ref{Ptr{Cvoid}}(C_NULL)
+        send_idx = ROCVector(Ti.(reduce(vcat, plan.send_indices; init=Ti[]) .- one(Ti)))
+        AMDGPU.synchronize()
+        _check(@ccall(LIB.hpcla_halo_plan_create(halo::Ptr{Ptr{Cvoid}}, _rccl(A.backend.comm)::Ptr{Cvoid},
+               length(plan.send_rank_ids)::Cint, Int32.(plan.send_rank_ids)::Ptr{Int32},
+               Int64.(length.(plan.send_indices))::Ptr{Int64}, _ptr(send_idx)::Ptr{Cvoid},
+               (Ti === Int64 ? 1 : 0)::Cint, length(plan.recv_rank_ids)::Cint,
+               Int32.(plan.recv_rank_ids)::Ptr{Int32}, Int64.(length.(plan.recv_perm))::Ptr{Int64},
+               k::Cint)::Cint), "hpcla_halo_plan_create")
+        A.backend.comm isa CommMPI &&
+            _attach_halo_window(_rccl(A.backend.comm), halo[], A.backend.comm.comm, comm_size(A.backend.comm))
+        rpb = @ccall LIB.hpcla_spmm_rows_per_block()::Cint          # SpMM row blocks are smaller than SpMV's
+        flags = AMDGPU.zeros(Int32, cld(A.nrows_local, rpb))
+        rp0 = _rowptr0(A)
+        if Ti === Int32
+            _check(@ccall(LIB.hpcla_classify_blocks_i32(_ptr(rp0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
+                   A.nrows_local::Int64, 0::Cint, d.n_own::Int64, rpb::Cint, _ptr(flags)::Ptr{Cvoid},
+                   _stream()::Ptr{Cvoid})::Cint), "hpcla_classify_blocks_i32")
+        else
+            _check(@ccall(LIB.hpcla_classify_blocks_i64(_ptr(rp0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
+                   A.nrows_local::Int64, 0::Cint, d.n_own::Int64, rpb::Cint, _ptr(flags)::Ptr{Cvoid},
+                   _stream()::Ptr{Cvoid})::Cint), "hpcla_classify_blocks_i64")
+        end
+        f = Array(flags)
+        (halo[], ROCVector(Int32.(findall(==(0), f) .- 1)), ROCVector(Int32.(findall(!=(0), f) .- 1)), send_idx)
+    end
+end
+
+function _spmm_split!(Crow, A::HPCSparseMatrix{T,Ti,B}, d, Brow, ghost::Ptr{Cvoid}, k::Int, blocks) where {T,Ti,B}
+    isempty(blocks) && return
+    rp0 = _rowptr0(A); nnz = length(A.nzval)
+    if Ti === Int32
+        _check(@ccall(LIB.hpcla_spmm_split_f64_i32(_ptr(rp0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
+               _ptr(A.nzval)::Ptr{Cvoid}, _ptr(Brow)::Ptr{Cvoid}, k::Int64, ghost::Ptr{Cvoid}, k::Int64, d.n_own::Int64,
+               _ptr(Crow)::Ptr{Cvoid}, k::Int64, A.nrows_local::Int64, nnz::Int64, k::Cint, 0::Cint,
+               _ptr(blocks)::Ptr{Cvoid}, length(blocks)::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_spmm_split_f64_i32")
+    else
+        _check(@ccall(LIB.hpcla_spmm_split_f64_i64(_ptr(rp0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
+               _ptr(A.nzval)::Ptr{Cvoid}, _ptr(Brow)::Ptr{Cvoid}, k::Int64, ghost::Ptr{Cvoid}, k::Int64, d.n_own::Int64,
+               _ptr(Crow)::Ptr{Cvoid}, k::Int64, A.nrows_local::Int64, nnz::Int64, k::Cint, 0::Cint,
+               _ptr(blocks)::Ptr{Cvoid}, length(blocks)::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_spmm_split_f64_i64")
+    end
+end
+
+function Base.:*(A::HPCSparseMatrix{T,Ti,B}, M::HPCMatrix{T,B}) where {T<:Float64,Ti,B<:ROCBackend}
+    assert_backends_compatible(A.backend, M.backend)
     nloc, k = size(M.A)
     Brow = AMDGPU.zeros(T, k, nloc)                 # k x nloc column-major == nloc x k row-major
     _check(@ccall(LIB.hpcla_transpose_f64(_ptr(M.A)::Ptr{Cvoid}, nloc::Int64, 1::Cint, _ptr(Brow)::Ptr{Cvoid}, k::Int64,
            0::Cint, nloc::Int64, k::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_transpose_f64")
-    gathered = Brow                                  # 1 rank and col_indices == 1:n (else gather rows first)
     Crow = AMDGPU.zeros(T, k, A.nrows_local)
-    _check(@ccall(LIB.hpcla_spmm_csr_f64_i32(_ptr(A.rowptr_target)::Ptr{Cvoid}, _ptr(A.colval_target)::Ptr{Cvoid},
-           _ptr(A.nzval)::Ptr{Cvoid}, _ptr(gathered)::Ptr{Cvoid}, k::Int64, 0::Cint, _ptr(Crow)::Ptr{Cvoid}, k::Int64,
-           0::Cint, A.nrows_local::Int64, length(A.nzval)::Int64, k::Cint, 1::Cint, _stream()::Ptr{Cvoid})::Cint),
-           "hpcla_spmm_csr_f64_i32")
+    # the vector plan for (A, B's row partition) provides neighbour lists and the split column space
+    probe = HPCVector{T,B}(compute_partition_hash(M.row_partition), M.row_partition, view(Brow, 1, :), A.backend)
+    plan = get_vector_plan(A, probe)
+    d = _device_plan(A, probe, plan)
+    if isempty(plan.send_rank_ids) && isempty(plan.recv_rank_ids)
+        _spmm_split!(Crow, A, d, Brow, C_NULL, k, ROCVector(Int32.(0:cld(A.nrows_local, (@ccall LIB.hpcla_spmm_rows_per_block()::Cint))-1)))
+    else
+        halo, interior, boundary, _ = _spmm_halo(A, plan, d, k)
+        ghost = Ref{Ptr{Cvoid}}(C_NULL); ng = Ref{Int64}(0)
+        _check(@ccall(LIB.hpcla_halo_begin(halo::Ptr{Cvoid}, _ptr(Brow)::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_halo_begin")
+        _check(@ccall(LIB.hpcla_halo_ghost_ptr(halo::Ptr{Cvoid}, ghost::Ptr{Ptr{Cvoid}}, ng::Ptr{Int64})::Cint), "hpcla_halo_ghost_ptr")
+        _spmm_split!(Crow, A, d, Brow, ghost[], k, interior)       # rows without ghost columns overlap the exchange
+        _check(@ccall(LIB.hpcla_halo_end(halo::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_halo_end")
+        _spmm_split!(Crow, A, d, Brow, ghost[], k, boundary)
+    end
     C = AMDGPU.zeros(T, A.nrows_local, k)
     _check(@ccall(LIB.hpcla_transpose_f64(_ptr(Crow)::Ptr{Cvoid}, k::Int64, 0::Cint, _ptr(C)::Ptr{Cvoid},
            A.nrows_local::Int64, 1::Cint, A.nrows_local::Int64, k::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_transpose_f64")
