@@ -5,8 +5,10 @@ the peer-window transport supports (RCCL does not: "Duplicate GPU detected").
 Checks, each against the CPU oracle on identical inputs and therefore against the 1-rank result too
 (the 1-rank GPU product is bit-equal to the oracle, tests/test_gpu_parity.py):
   * y = A*x distributed, bit-exact, for a 2-D stencil slab (contiguous sends), a 3-D slab whose halo planes
-    take several push chunks each, an unstructured matrix (scattered sends, asymmetric neighbour sets) and x
-    partitioned differently from A's rows;
+    take several push chunks each, an unstructured matrix (scattered sends, all-to-all neighbour sets), a
+    one-directional band (each rank receives from the next and sends to the previous one only: push targets and
+    wait sources differ), a matrix with fewer rows than ranks (an empty rank) and x partitioned differently
+    from A's rows;
   * 40 dependent steps x <- A*x/8 (free-running: exercises epochs, double buffering and acks);
   * dot / norm: 1e-12 relative to the oracle AND bit-identical on all ranks;
   * CG, 12 iterations, fused and unfused, residual history vs the oracle -- eagerly and replayed from a captured
@@ -63,6 +65,32 @@ def main():
         n2 = 30000
         cases.append(("sprand", n2, lambda lo, hi: orc.sprand_rows(n2, 0.0015, lo, hi),
                       orc.uniform_partition(n2, nranks), orc.uniform_partition(n2, nranks)))
+        # one-directional dependencies: row i needs columns i and i + K with K ~ one rank's rows, so rank r
+        # RECEIVES from rank r+1 only and SENDS to rank r-1 only -- push targets and wait sources differ, the
+        # last rank only sends, the first only receives (the ack lines, not a symmetric handshake, protect the
+        # ghost buffers here)
+        n4 = 4000 * nranks
+        K4 = 4000 - 37
+
+        def upper_rows(lo, hi, n4=n4, K4=K4):
+            import scipy.sparse as sp
+            i = np.arange(n4)
+            M = sp.csr_matrix((np.concatenate([2.0 + (i % 7), -1.0 - (i[:n4 - K4] % 3)]),
+                               (np.concatenate([i, i[:n4 - K4]]), np.concatenate([i, i[:n4 - K4] + K4]))), shape=(n4, n4))
+            M.sort_indices()
+            loc = M[lo:hi]
+            return orc.LocalRows(loc.indptr.astype(np.int64), loc.indices.astype(np.int64), loc.data.astype(np.float64), n4)
+        cases.append(("upper", n4, upper_rows, orc.uniform_partition(n4, nranks), orc.uniform_partition(n4, nranks)))
+        # fewer rows than ranks: the last rank owns nothing (empty local matrix, no plan of its own, still collective)
+        n5 = max(nranks - 1, 1)
+
+        def tiny_rows(lo, hi, n5=n5):
+            import scipy.sparse as sp
+            M = (sp.identity(n5, format="csr") * 3.0 + sp.diags([np.ones(max(n5 - 1, 0))], [1], shape=(n5, n5), format="csr")).tocsr()
+            M.sort_indices()
+            loc = M[lo:hi]
+            return orc.LocalRows(loc.indptr.astype(np.int64), loc.indices.astype(np.int64), loc.data.astype(np.float64), n5)
+        cases.append(("tiny", n5, tiny_rows, orc.uniform_partition(n5, nranks), orc.uniform_partition(n5, nranks)))
         # x partitioned differently from the rows (A*x accepts any partition of x, src/sparse.jl:2096-2128)
         n3 = 20000
         xp3 = np.array([0] + [min(n3, 700 + (n3 * r) // nranks) for r in range(1, nranks)] + [n3])
@@ -92,7 +120,7 @@ def main():
             assert np.array_equal(y.local_values(), want), f"{tag} {name}: repeated mul! differs"
             assert not plan.timed_out(), f"{tag} {name}: a push/wait timed out"
 
-            if name == "sprand_xpart":
+            if name in ("sprand_xpart", "tiny"):
                 continue
             # dependent steps: x_{k+1} = A x_k / 8, no host sync in between
             xs = hp.HPCVector.from_global(xg, backend, partition=rp)
