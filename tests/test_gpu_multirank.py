@@ -33,8 +33,10 @@ def _spawn(nranks, env_extra, timeout=600):
 
 @pytest.mark.parametrize("nranks", [2, 3, 4])
 def test_push_transport_ranks_exchange(nranks):
-    """Default mode (push): halo by direct peer stores, scalar all-reduce through the communicator window."""
-    env = {"HPCLA_PUSH_TIMEOUT_S": "30"}
+    """Default mode (push): halo by direct peer stores, scalar all-reduce through the communicator window.
+    2 ranks run both index types; 3 ranks Int64 (the reference's default Ti), 4 ranks Int32 -- the ranks share the
+    one GPU of the box by time-slicing, so wall time grows with ranks x cases."""
+    env = {"HPCLA_PUSH_TIMEOUT_S": "30", "HPCLA_MR_TYPES": {2: "i32,i64", 3: "i64", 4: "i32"}[nranks]}
     env.pop("HPCLA_HALO_MODE", None)
     os.environ.pop("HPCLA_HALO_MODE", None)
     assert _spawn(nranks, env) == 0
