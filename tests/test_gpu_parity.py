@@ -567,11 +567,13 @@ def test_spmv_unaligned_pointers_take_fallback_kernel(hp, orc, gpu_backend_i32, 
     np.testing.assert_array_equal(y.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("Ti", [np.int32, np.int64])
 @pytest.mark.parametrize("nranks,k", [(2, 16), (3, 5)])
-def test_split_spmm_per_rank_matches_reference_pipeline(hp, orc, gpu_backend_i32, nranks, k):
-    """hpcla_spmm_split_f64_i32 (own rows of B + ghost rows, interior/boundary block lists at SpMM
+def test_split_spmm_per_rank_matches_reference_pipeline(hp, orc, gpu_backend_i32, nranks, k, Ti):
+    """hpcla_spmm_split_f64_{i32,i64} (Int64 is the reference's default Ti, src/backends.jl:348) (own rows of B + ghost rows, interior/boundary block lists at SpMM
     granularity) == the reference's column loop over gathered B, for every simulated rank."""
     import torch
+    sfx = "i32" if Ti == np.int32 else "i64"
     n = 4000
     rp = orc.uniform_partition(n, nranks)
     Bg = orc.fill_uniform(0, n * k, 21).reshape(n, k)
@@ -582,18 +584,18 @@ def test_split_spmm_per_rank_matches_reference_pipeline(hp, orc, gpu_backend_i32
     s = torch.cuda.current_stream().cuda_stream
     for r in range(nranks):
         rows, (ci, cv), pl = locs[r], comp[r], plans[r]
-        want = orc.spmm(rows.rowptr.astype(np.int32), cv.astype(np.int32), rows.vals, Bg[ci])
+        want = orc.spmm(rows.rowptr.astype(Ti), cv.astype(Ti), rows.vals, Bg[ci])
         n_own = int(rp[r + 1] - rp[r])
         hplan = hp.HostVectorPlan(pl.send_rank_ids, pl.send_indices, pl.recv_rank_ids, pl.recv_perm,
                                   pl.local_src_indices, pl.local_dst_indices, pl.n_gathered, n_own)
         cmap = hp.split_column_map(hplan)
         ghost_rows = np.concatenate([ci[p] for p in pl.recv_perm]) if pl.recv_perm else np.zeros(0, dtype=np.int64)
-        d_rp, d_split = _t(rows.rowptr.astype(np.int32)), _t(cmap[cv].astype(np.int32))
+        d_rp, d_split = _t(rows.rowptr.astype(Ti)), _t(cmap[cv].astype(Ti))
         d_nz = _t(rows.vals)
         d_B, d_G = _t(Bg[rp[r]:rp[r + 1]]), _t(Bg[ghost_rows] if len(ghost_rows) else np.zeros((1, k)))
         nblk = (rows.nrows + rpb - 1) // rpb
         flags = torch.empty(nblk, dtype=torch.int32, device="cuda")
-        hp._capi.call("hpcla_classify_blocks_i32", d_rp.data_ptr(), d_split.data_ptr(), rows.nrows, 0, n_own, rpb,
+        hp._capi.call(f"hpcla_classify_blocks_{sfx}", d_rp.data_ptr(), d_split.data_ptr(), rows.nrows, 0, n_own, rpb,
                       flags.data_ptr(), s)
         f = flags.cpu().numpy()
         C = torch.full((rows.nrows, k), float("nan"), dtype=torch.float64, device="cuda")
@@ -601,7 +603,7 @@ def test_split_spmm_per_rank_matches_reference_pipeline(hp, orc, gpu_backend_i32
             lst = _t(sel.astype(np.int32))
             if lst.numel() == 0:
                 continue
-            hp._capi.call("hpcla_spmm_split_f64_i32", d_rp.data_ptr(), d_split.data_ptr(), d_nz.data_ptr(),
+            hp._capi.call(f"hpcla_spmm_split_f64_{sfx}", d_rp.data_ptr(), d_split.data_ptr(), d_nz.data_ptr(),
                           d_B.data_ptr(), k, d_G.data_ptr(), k, n_own, C.data_ptr(), k, rows.nrows, rows.nnz, k, 0,
                           lst.data_ptr(), lst.numel(), s)
         torch.cuda.synchronize()
