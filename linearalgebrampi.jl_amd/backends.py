@@ -143,6 +143,8 @@ def comm_allgather(comm: AbstractComm, values: np.ndarray) -> np.ndarray:
         return values.copy()
     import torch
     dev = _host_device(comm)
+    if not values.flags.writeable:                     # e.g. a view of a bytes object: torch wants a writable buffer
+        values = values.copy()
     t = torch.from_numpy(values).to(dev)
     out = [torch.empty_like(t) for _ in range(comm_size(comm))]
     _dist().all_gather(out, t, group=comm.group)
