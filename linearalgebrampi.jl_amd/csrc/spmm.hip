@@ -14,7 +14,6 @@
 //
 // Generic strides are accepted for B and C (column-major = Julia Matrix), the row-major form is
 // the fast one.  Algorithmic bytes: 12 B/nnz + 4 B/row + 8k B/row (C) + 8k B per B row touched.
-#include <limits.h>
 #include <stdlib.h>
 
 #include "common.h"
@@ -168,7 +167,12 @@ __global__ __launch_bounds__(TPB_MM) void spmm_rowblock_kernel(
 // records: 0.583 / 0.587 / 0.592 vs 0.595 ms on the stencil, and 1.44 / 1.50 / 1.80 vs 1.38 ms on config 5's
 // random pattern -- the dependent chain is not the limit); eight lanes per row, one 16-byte load per entry,
 // a whole 5-entry row's gathers issued in ONE round trip (62 VGPRs, 8 waves/SIMD: 0.626 vs 0.589 ms, slower --
-// the number of gather rounds is not the limit either); kept: the HALF64 lane mapping below (+1.5 %).  For
+// the number of gather rounds is not the limit either); an LDS-tiled form that finds a block's distinct B rows
+// on the fly (presence bitmap + popcount scan in LDS) and streams them into LDS once: bit-exact, 1.15 ms (five
+// barriers and 16 waves per CU per 64-row block; profiles/r02_spmm_lds_tile_on_the_fly.log).  What DID pay is
+// the SHAPE of the accesses: the HALF64 lane mapping (+1.5 %) and C written through LDS in whole lines
+// (CSTAGE, 0.608 -> 0.573 ms, profiles/r02_spmm_cstage.log).  A hand-written pure stream of the same byte mix
+// at the same 64-row granularity runs in 0.438 ms on the same box (benchmarks/tune/stream_mix.hip).  For
 // scale: on the same box a device copy B -> C runs at 4.8 TB/s, a read-only pass at 5.9, a fill at 6.3
 // (profiles/r02_stream_mix_ceiling.log); this kernel's byte mix (40 % writes) moved as separate ideal streams
 // takes 0.544 ms there, the kernel 0.612.
@@ -188,7 +192,7 @@ struct __attribute__((aligned(16))) SpmmEntry {
 
 typedef const vdouble2 __attribute__((address_space(1))) *gvec2_ptr;   // global address space: global_load, not flat_load
 
-template <typename I, bool SPLIT, int VU, int CHUNK_V, bool HALF64>
+template <typename I, bool SPLIT, int VU, int CHUNK_V, bool HALF64, bool CSTAGE>
 __global__ __launch_bounds__(TPB_MM) void spmm_rowblock_vec_kernel(
     const I *__restrict__ rowptr, const I *__restrict__ colval, const double *__restrict__ nzval,
     const double *__restrict__ B_own, int64_t b_rs, const double *__restrict__ B_ghost, int64_t bg_rs,
@@ -270,6 +274,26 @@ __global__ __launch_bounds__(TPB_MM) void spmm_rowblock_vec_kernel(
                 acc[3] += en.val * b1.y;
             }
         }
+        if (CSTAGE) {
+            // C through LDS (k == 16, C rows contiguous): the block's 64 x 16 results form ONE contiguous 8 KiB
+            // region of C; written from the accumulators, a store instruction covers 16 half lines, written from
+            // LDS in linear order it covers 8 whole lines
+            __syncthreads();                               // every lane has finished reading the records
+            double *s_c = reinterpret_cast<double *>(s_ent);
+            static_assert(sizeof(SpmmEntry) * CHUNK_V >= sizeof(double) * RPB_MM * KT, "C tile fits the record area");
+            vdouble2 o0, o1;
+            o0.x = acc[0]; o0.y = acc[1]; o1.x = acc[2]; o1.y = acc[3];
+            *reinterpret_cast<vdouble2 *>(s_c + g * KT + c) = o0;
+            *reinterpret_cast<vdouble2 *>(s_c + g * KT + c + SECOND / 8) = o1;
+            __syncthreads();
+            vdouble2 *dst = reinterpret_cast<vdouble2 *>(C + r0 * c_rs);
+            const vdouble2 *src = reinterpret_cast<const vdouble2 *>(s_c);
+#pragma unroll
+            for (int u = 0; u < (RPB_MM * KT / 2) / TPB_MM; ++u) {
+                const int i = tid + u * TPB_MM;
+                if (i < nr * (KT / 2)) dst[i] = src[i];
+            }
+        } else
         if (g < nr && col_ok) {
             double *dst = C + (r0 + g) * c_rs + c;
             vdouble2 o0, o1;
@@ -277,217 +301,6 @@ __global__ __launch_bounds__(TPB_MM) void spmm_rowblock_vec_kernel(
             *reinterpret_cast<vdouble2 *>(dst) = o0;
             *reinterpret_cast<vdouble2 *>(dst + SECOND / 8) = o1;
         }
-    }
-}
-
-// LDS-tiled form for banded / stencil-like matrices, k = 16 (north star: "LDS-staged tiles").  A pure
-// streaming kernel moves this workload's byte mix at 6.1 TB/s with the same 64-row granularity
-// (benchmarks/tune/stream_mix.hip: 0.438 ms) while the gather form above takes 0.60 ms: what separates them is
-// the 5x re-read of B rows through L1/L2 as dependent 16-byte gathers (7.1e7 L2 requests where a stream needs
-// 2.1e7).  Here a workgroup finds the DISTINCT B rows its 64 matrix rows touch ON THE FLY -- no plan-time
-// preprocessing, no extra arrays: a presence bitmap over the block's column window in LDS, a popcount scan,
-// and every entry gets the slot of its column -- then streams exactly those rows into LDS ONCE, whole
-// 128-byte rows, all loads in flight together, and computes from LDS.  A 5-point block touches 194 distinct
-// rows (64 own-line, 2 edge, 2 x 64 neighbour-line) instead of issuing 320 gathers in three dependent rounds.
-// Blocks that do not qualify (more than T_CH entries, a column window wider than T_W, more than T_MAX
-// distinct rows: random patterns, 3-D planes) take the gather loop inside the same kernel.  Per (row,
-// column) the products are still added entry by entry in stored order: same bits.
-constexpr int T_CH = 512;                    // entries of a block handled by the tile path
-constexpr int T_W = 16384;                   // column window (bits of the presence bitmap)
-constexpr int T_WORDS = T_W / 32;
-constexpr int T_MAX = 200;                   // distinct B rows held in LDS
-constexpr int T_STRIDE = KT + 2;             // doubles per tile row: 144 bytes, so consecutive slots shift by 4 banks
-
-template <typename I, bool SPLIT>
-__global__ __launch_bounds__(TPB_MM) __attribute__((amdgpu_waves_per_eu(4, 8))) void spmm_rowblock_tile_kernel(
-    const I *__restrict__ rowptr, const I *__restrict__ colval, const double *__restrict__ nzval,
-    const double *__restrict__ B_own, int64_t b_rs, const double *__restrict__ B_ghost, int64_t bg_rs,
-    int64_t n_own, double *__restrict__ C, int64_t c_rs, int64_t nrows, int base,
-    const int32_t *__restrict__ block_list, uint32_t nblocks)
-{
-    // LDS: tile | values | slots | bitmap | prefix | list | scratch.  The gather fallback re-uses the tile area for
-    // its {address, value} records.
-    __shared__ __attribute__((aligned(16))) double s_tile[T_MAX * T_STRIDE];       // 28 800 B
-    __shared__ double s_val[T_CH];                                                   //  4 096 B
-    __shared__ uint16_t s_slot[T_CH];                                                //  1 024 B
-    __shared__ uint32_t s_bits[T_WORDS];                                             //  2 048 B
-    __shared__ uint16_t s_pref[T_WORDS];                                             //  1 024 B
-    __shared__ int32_t s_list[T_MAX];                                                //    800 B
-    __shared__ int64_t s_red[8];                                                     // min / max per wave
-    __shared__ int32_t s_wsum[4];
-    static_assert(sizeof(SpmmEntry) * T_CH <= sizeof(double) * T_MAX * T_STRIDE, "fallback records alias the tile");
-
-    const int tid = threadIdx.x;
-    const int g = tid / VG, l = tid % VG;   // g = row of the block (0..63)
-    const uint32_t b = blockIdx.x;
-    const int64_t blk = block_list ? (int64_t)block_list[b] : (int64_t)b;
-    const int64_t r0 = blk * RPB_MM;
-    const int nr = (int)((nrows - r0) < RPB_MM ? (nrows - r0) : RPB_MM);
-    const int64_t p0 = (int64_t)rowptr[r0] - base;
-    const int64_t p1 = (int64_t)rowptr[r0 + nr] - base;
-    const int64_t total = p1 - p0;
-    int64_t lo = 0, hi = 0;
-    if (g < nr) {
-        lo = (int64_t)rowptr[r0 + g] - base - p0;
-        hi = (int64_t)rowptr[r0 + g + 1] - base - p0;
-    }
-    const int c = 2 * l;                                   // HALF64 mapping: columns {2l, 2l+1} and {8+2l, 9+2l}
-    double acc[VCPL] = {0.0, 0.0, 0.0, 0.0};
-
-    bool tiled = total <= T_CH;                            // workgroup-uniform from here on
-    int64_t col[2] = {0, 0};
-    double val[2] = {0.0, 0.0};
-    int64_t cmin = 0;
-    int D = 0;
-    if (tiled) {
-        // ---- entries (<= 2 per thread) and the block's column window ---------------------------------------
-        int64_t mn = INT64_MAX, mx = INT64_MIN;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int i = tid + u * TPB_MM;
-            if (i < total) {
-                col[u] = (int64_t)__builtin_nontemporal_load(colval + p0 + i) - base;
-                val[u] = __builtin_nontemporal_load(nzval + p0 + i);
-                mn = col[u] < mn ? col[u] : mn;
-                mx = col[u] > mx ? col[u] : mx;
-            }
-        }
-        for (int i = tid; i < T_WORDS; i += TPB_MM) s_bits[i] = 0u;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const int64_t a = __shfl_xor(mn, off, 64), bb = __shfl_xor(mx, off, 64);
-            mn = a < mn ? a : mn;
-            mx = bb > mx ? bb : mx;
-        }
-        if ((tid & 63) == 0) { s_red[tid >> 6] = mn; s_red[4 + (tid >> 6)] = mx; }
-        __syncthreads();
-        int64_t cmax = s_red[4];
-        cmin = s_red[0];
-#pragma unroll
-        for (int w = 1; w < 4; ++w) {
-            cmin = s_red[w] < cmin ? s_red[w] : cmin;
-            cmax = s_red[4 + w] > cmax ? s_red[4 + w] : cmax;
-        }
-        tiled = total > 0 && cmax - cmin < T_W;
-        if (tiled) {
-            // ---- presence bitmap -> popcount scan -> slot of every column -------------------------------------
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int i = tid + u * TPB_MM;
-                if (i < total) {
-                    const uint32_t rel = (uint32_t)(col[u] - cmin);
-                    atomicOr(&s_bits[rel >> 5], 1u << (rel & 31));
-                }
-            }
-            __syncthreads();
-            const uint32_t w0 = s_bits[2 * tid], w1 = s_bits[2 * tid + 1];
-            const int c0 = __popc(w0), c1 = __popc(w1);
-            int incl = c0 + c1;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int up = __shfl_up(incl, off, 64);
-                if ((tid & 63) >= off) incl += up;
-            }
-            if ((tid & 63) == 63) s_wsum[tid >> 6] = incl;
-            __syncthreads();
-            int wbase = 0;
-            for (int w = 0; w < (tid >> 6); ++w) wbase += s_wsum[w];
-            D = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
-            const int excl = wbase + incl - (c0 + c1);
-            s_pref[2 * tid] = (uint16_t)excl;
-            s_pref[2 * tid + 1] = (uint16_t)(excl + c0);
-            tiled = D <= T_MAX;
-            if (tiled) {
-                int pos = excl;
-                uint32_t w = w0;
-                while (w) { s_list[pos++] = (2 * tid) * 32 + __builtin_ctz(w); w &= w - 1; }
-                w = w1;
-                while (w) { s_list[pos++] = (2 * tid + 1) * 32 + __builtin_ctz(w); w &= w - 1; }
-            }
-            __syncthreads();
-        }
-    }
-
-    if (tiled) {
-        // ---- park {slot, value}; stream the D distinct B rows into LDS, all loads in flight together ---------
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int i = tid + u * TPB_MM;
-            if (i < total) {
-                const uint32_t rel = (uint32_t)(col[u] - cmin);
-                const uint32_t word = rel >> 5, bit = rel & 31;
-                s_slot[i] = (uint16_t)(s_pref[word] + __popc(s_bits[word] & ((1u << bit) - 1u)));
-                s_val[i] = val[u];
-            }
-        }
-        constexpr int FILL = (T_MAX * 8 + TPB_MM - 1) / TPB_MM;       // 16-byte pieces per thread (7)
-        vdouble2 piece[FILL];
-#pragma unroll
-        for (int f = 0; f < FILL; ++f) {
-            const int i = tid + f * TPB_MM;
-            if (i < D * 8) {
-                const int64_t cc = cmin + s_list[i >> 3];
-                const double *src = (SPLIT && cc >= n_own) ? B_ghost + (cc - n_own) * bg_rs : B_own + cc * b_rs;
-                piece[f] = *(gvec2_ptr)(src + 2 * (i & 7));
-            }
-        }
-#pragma unroll
-        for (int f = 0; f < FILL; ++f) {
-            const int i = tid + f * TPB_MM;
-            if (i < D * 8) *reinterpret_cast<vdouble2 *>(&s_tile[(i >> 3) * T_STRIDE + 2 * (i & 7)]) = piece[f];
-        }
-        __syncthreads();
-        // ---- compute from LDS ---------------------------------------------------------------------------------
-        for (int j = (int)lo; j < (int)hi; ++j) {
-            const double v = s_val[j];
-            const double *row = &s_tile[(int)s_slot[j] * T_STRIDE];
-            const vdouble2 b0 = *reinterpret_cast<const vdouble2 *>(row + c);
-            const vdouble2 b1 = *reinterpret_cast<const vdouble2 *>(row + 8 + c);
-            acc[0] += v * b0.x;
-            acc[1] += v * b0.y;
-            acc[2] += v * b1.x;
-            acc[3] += v * b1.y;
-        }
-    } else {
-        // ---- gather fallback (the vector kernel's loop; its records alias the tile area) ----------------------
-        SpmmEntry *s_ent = reinterpret_cast<SpmmEntry *>(s_tile);
-        const int64_t lane_bytes = (int64_t)c * (int64_t)sizeof(double);
-        for (int64_t ch = 0; ch < total; ch += T_CH) {
-            const int n = (int)((total - ch) < T_CH ? (total - ch) : T_CH);
-            __syncthreads();
-            for (int i = tid; i < n; i += TPB_MM) {
-                const int64_t cc = (int64_t)__builtin_nontemporal_load(colval + p0 + ch + i) - base;
-                SpmmEntry e;
-                e.val = __builtin_nontemporal_load(nzval + p0 + ch + i);
-                e.row = (SPLIT && cc >= n_own) ? B_ghost + (cc - n_own) * bg_rs : B_own + cc * b_rs;
-                s_ent[i] = e;
-            }
-            __syncthreads();
-            int j = (int)((lo > ch ? lo : ch) - ch);
-            const int e = (int)((hi < ch + n ? hi : ch + n) - ch);
-            for (; j + 2 <= e; j += 2) {
-                const SpmmEntry e0 = s_ent[j], e1 = s_ent[j + 1];
-                const char *s0 = reinterpret_cast<const char *>(e0.row) + lane_bytes;
-                const char *s1 = reinterpret_cast<const char *>(e1.row) + lane_bytes;
-                const vdouble2 a0 = *(gvec2_ptr)(s0), a1 = *(gvec2_ptr)(s0 + 64);
-                const vdouble2 q0 = *(gvec2_ptr)(s1), q1 = *(gvec2_ptr)(s1 + 64);
-                acc[0] += e0.val * a0.x; acc[1] += e0.val * a0.y; acc[2] += e0.val * a1.x; acc[3] += e0.val * a1.y;
-                acc[0] += e1.val * q0.x; acc[1] += e1.val * q0.y; acc[2] += e1.val * q1.x; acc[3] += e1.val * q1.y;
-            }
-            if (j < e) {
-                const SpmmEntry e0 = s_ent[j];
-                const char *s0 = reinterpret_cast<const char *>(e0.row) + lane_bytes;
-                const vdouble2 a0 = *(gvec2_ptr)(s0), a1 = *(gvec2_ptr)(s0 + 64);
-                acc[0] += e0.val * a0.x; acc[1] += e0.val * a0.y; acc[2] += e0.val * a1.x; acc[3] += e0.val * a1.y;
-            }
-        }
-    }
-    if (g < nr) {
-        double *dst = C + (r0 + g) * c_rs + c;
-        vdouble2 o0, o1;
-        o0.x = acc[0]; o0.y = acc[1]; o1.x = acc[2]; o1.y = acc[3];
-        *reinterpret_cast<vdouble2 *>(dst) = o0;
-        *reinterpret_cast<vdouble2 *>(dst + 8) = o1;
     }
 }
 
@@ -566,8 +379,8 @@ static int spmm_launch(const I *rowptr, const I *colval, const double *nzval, co
             return e ? atoi(e) : 0;
         }();
         const bool small = chunk_env ? chunk_env == 512 : nnz <= 8 * nrows;
-#define HPCLA_SPMM_VEC(SP, VUU, CH, H64)                                                                \
-    spmm_rowblock_vec_kernel<I, SP, VUU, CH, H64><<<grid, block, 0, s>>>(                                \
+#define HPCLA_SPMM_VEC(SP, VUU, CH, H64, CST)                                                           \
+    spmm_rowblock_vec_kernel<I, SP, VUU, CH, H64, CST><<<grid, block, 0, s>>>(                           \
         rowptr, colval, nzval, B_own, b_rs, SP ? B_ghost : nullptr, SP ? bg_rs : 0, SP ? n_own : 0, C, c_rs, \
         nrows, k, index_base, block_list, (uint32_t)launch_blocks)
         // lane->column mapping: 64 contiguous bytes per row per load when k % 16 == 0 (HPCLA_SPMM_HALF64=0: off)
@@ -576,28 +389,22 @@ static int spmm_launch(const I *rowptr, const I *colval, const double *nzval, co
             return e ? atoi(e) : 1;
         }();
         const bool h64 = h64_env != 0 && (k % 16) == 0;
-#define HPCLA_SPMM_VEC2(SP)                                                                             \
-    do {                                                                                                \
-        if (h64) {                                                                                      \
-            if (small) HPCLA_SPMM_VEC(SP, 2, 512, true); else HPCLA_SPMM_VEC(SP, 2, 1536, true);        \
-        } else if (small) { if (vu == 4) HPCLA_SPMM_VEC(SP, 4, 512, false); else HPCLA_SPMM_VEC(SP, 2, 512, false); } \
-        else { if (vu == 4) HPCLA_SPMM_VEC(SP, 4, 1536, false); else HPCLA_SPMM_VEC(SP, 2, 1536, false); } \
-    } while (0)
-        // LDS-tiled kernel for short-row matrices at k = 16 (HPCLA_SPMM_TILE=0: off)
-        static const int tile_env = [] {
-            const char *e = getenv("HPCLA_SPMM_TILE");
+        // C through LDS when the block's C rows are one contiguous region (HPCLA_SPMM_CSTAGE=0: off)
+        static const int cst_env = [] {
+            const char *e = getenv("HPCLA_SPMM_CSTAGE");
             return e ? atoi(e) : 1;
         }();
-        if (tile_env != 0 && k == KT && small) {
-            if (split)
-                spmm_rowblock_tile_kernel<I, true><<<grid, block, 0, s>>>(rowptr, colval, nzval, B_own, b_rs, B_ghost, bg_rs,
-                                                                        n_own, C, c_rs, nrows, index_base, block_list,
-                                                                        (uint32_t)launch_blocks);
-            else
-                spmm_rowblock_tile_kernel<I, false><<<grid, block, 0, s>>>(rowptr, colval, nzval, B_own, b_rs, nullptr, 0, 0,
-                                                                         C, c_rs, nrows, index_base, block_list,
-                                                                         (uint32_t)launch_blocks);
-        } else if (split) HPCLA_SPMM_VEC2(true); else HPCLA_SPMM_VEC2(false);
+        const bool cstage = cst_env != 0 && k == KT && c_rs == KT;
+#define HPCLA_SPMM_VEC2(SP)                                                                             \
+    do {                                                                                                \
+        if (h64 && cstage) {                                                                            \
+            if (small) HPCLA_SPMM_VEC(SP, 2, 512, true, true); else HPCLA_SPMM_VEC(SP, 2, 1536, true, true); \
+        } else if (h64) {                                                                               \
+            if (small) HPCLA_SPMM_VEC(SP, 2, 512, true, false); else HPCLA_SPMM_VEC(SP, 2, 1536, true, false); \
+        } else if (small) { if (vu == 4) HPCLA_SPMM_VEC(SP, 4, 512, false, false); else HPCLA_SPMM_VEC(SP, 2, 512, false, false); } \
+        else { if (vu == 4) HPCLA_SPMM_VEC(SP, 4, 1536, false, false); else HPCLA_SPMM_VEC(SP, 2, 1536, false, false); } \
+    } while (0)
+        if (split) HPCLA_SPMM_VEC2(true); else HPCLA_SPMM_VEC2(false);
 #undef HPCLA_SPMM_VEC2
 #undef HPCLA_SPMM_VEC
     } else if (split)
