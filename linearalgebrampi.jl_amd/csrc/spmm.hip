@@ -171,7 +171,9 @@ __global__ __launch_bounds__(TPB_MM) void spmm_rowblock_kernel(
 // on the fly (presence bitmap + popcount scan in LDS) and streams them into LDS once: bit-exact, 1.15 ms (five
 // barriers and 16 waves per CU per 64-row block; profiles/r02_spmm_lds_tile_on_the_fly.log).  What DID pay is
 // the SHAPE of the accesses: the HALF64 lane mapping (+1.5 %) and C written through LDS in whole lines
-// (CSTAGE, 0.608 -> 0.573 ms, profiles/r02_spmm_cstage.log).  A hand-written pure stream of the same byte mix
+// (CSTAGE, 0.608 -> 0.573 ms, profiles/r02_spmm_cstage.log) -- for the STORES only: reading B in whole lines
+// (eight lanes per row, two rows per lane-group at 256 threads) measured 0.66-0.69 ms
+// (profiles/r02_spmm_whole_line_form.log).  A hand-written pure stream of the same byte mix
 // at the same 64-row granularity runs in 0.438 ms on the same box (benchmarks/tune/stream_mix.hip).  For
 // scale: on the same box a device copy B -> C runs at 4.8 TB/s, a read-only pass at 5.9, a fill at 6.3
 // (profiles/r02_stream_mix_ceiling.log); this kernel's byte mix (40 % writes) moved as separate ideal streams
@@ -304,88 +306,6 @@ __global__ __launch_bounds__(TPB_MM) void spmm_rowblock_vec_kernel(
     }
 }
 
-// Whole-line form (full 16-column tiles): eight lanes share a row and each owns TWO adjacent columns, so one
-// 16-byte load per entry per lane and a wave instruction reads the whole 128-byte B rows of 8 matrix rows
-// (for a stencil: 1 KiB contiguous); every lane-group serves TWO rows of the block (r and r + 8 of its wave's
-// 16), which keeps the workgroup at 256 threads / 64 rows and the accumulators at four per lane.  C rows are
-// stored as whole lines straight from the accumulators.  Loads are unconditional (a step's missing tail
-// entries re-read the row's last entry: an L1 hit), only the additions are predicated.
-template <typename I, bool SPLIT, int VU, int CHUNK_V>
-__global__ __launch_bounds__(TPB_MM) void spmm_rowblock_line_kernel(
-    const I *__restrict__ rowptr, const I *__restrict__ colval, const double *__restrict__ nzval,
-    const double *__restrict__ B_own, int64_t b_rs, const double *__restrict__ B_ghost, int64_t bg_rs,
-    int64_t n_own, double *__restrict__ C, int64_t c_rs, int64_t nrows, int k, int base,
-    const int32_t *__restrict__ block_list, uint32_t nblocks)
-{
-    __shared__ SpmmEntry s_ent[CHUNK_V];
-
-    const int tid = threadIdx.x;
-    const int wave = tid >> 6, sub = (tid >> 3) & 7, m = tid & 7;
-    const int ga = wave * 16 + sub, gb = ga + 8;          // the two rows of this lane-group
-    const uint32_t b = blockIdx.x;
-    const int64_t blk = block_list ? (int64_t)block_list[b] : (int64_t)b;
-    const int64_t r0 = blk * RPB_MM;
-    const int nr = (int)((nrows - r0) < RPB_MM ? (nrows - r0) : RPB_MM);
-    const int64_t p0 = (int64_t)rowptr[r0] - base;
-    const int64_t p1 = (int64_t)rowptr[r0 + nr] - base;
-    const int64_t total = p1 - p0;
-    int64_t loa = 0, hia = 0, lob = 0, hib = 0;
-    if (ga < nr) {
-        loa = (int64_t)rowptr[r0 + ga] - base - p0;
-        hia = (int64_t)rowptr[r0 + ga + 1] - base - p0;
-    }
-    if (gb < nr) {
-        lob = (int64_t)rowptr[r0 + gb] - base - p0;
-        hib = (int64_t)rowptr[r0 + gb + 1] - base - p0;
-    }
-
-    for (int kt = 0; kt < k; kt += KT) {
-        const int64_t lane_bytes = (int64_t)(kt + 2 * m) * (int64_t)sizeof(double);
-        double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
-
-        for (int64_t ch = 0; ch < total; ch += CHUNK_V) {
-            const int n = (int)((total - ch) < CHUNK_V ? (total - ch) : CHUNK_V);
-            __syncthreads();   // previous pass finished reading LDS
-            for (int i = tid; i < n; i += TPB_MM) {
-                const int64_t col = (int64_t)__builtin_nontemporal_load(colval + p0 + ch + i) - base;
-                SpmmEntry e;
-                e.val = __builtin_nontemporal_load(nzval + p0 + ch + i);
-                e.row = (SPLIT && col >= n_own) ? B_ghost + (col - n_own) * bg_rs : B_own + col * b_rs;
-                s_ent[i] = e;
-            }
-            __syncthreads();
-            int ja = (int)((loa > ch ? loa : ch) - ch), jb = (int)((lob > ch ? lob : ch) - ch);
-            const int ea = (int)((hia < ch + n ? hia : ch + n) - ch), eb = (int)((hib < ch + n ? hib : ch + n) - ch);
-            while (ja < ea || jb < eb) {
-                const int lasta = ea - 1 - ja, lastb = eb - 1 - jb;      // < 0: that row has nothing left in this pass
-                SpmmEntry xa[VU], xb[VU];
-                vdouble2 va[VU], vb[VU];
-#pragma unroll
-                for (int u = 0; u < VU; ++u) {
-                    xa[u] = s_ent[lasta >= 0 ? ja + (u < lasta ? u : lasta) : 0];
-                    xb[u] = s_ent[lastb >= 0 ? jb + (u < lastb ? u : lastb) : 0];
-                }
-#pragma unroll
-                for (int u = 0; u < VU; ++u) {
-                    va[u] = *(gvec2_ptr)(reinterpret_cast<const char *>(xa[u].row) + lane_bytes);
-                    vb[u] = *(gvec2_ptr)(reinterpret_cast<const char *>(xb[u].row) + lane_bytes);
-                }
-#pragma unroll
-                for (int u = 0; u < VU; ++u) {
-                    if (u <= lasta) { a0 += xa[u].val * va[u].x; a1 += xa[u].val * va[u].y; }
-                    if (u <= lastb) { b0 += xb[u].val * vb[u].x; b1 += xb[u].val * vb[u].y; }
-                }
-                ja += VU;
-                jb += VU;
-            }
-        }
-        vdouble2 oa, ob;
-        oa.x = a0; oa.y = a1; ob.x = b0; ob.y = b1;
-        if (ga < nr) *reinterpret_cast<vdouble2 *>(C + (r0 + ga) * c_rs + kt + 2 * m) = oa;
-        if (gb < nr) *reinterpret_cast<vdouble2 *>(C + (r0 + gb) * c_rs + kt + 2 * m) = ob;
-    }
-}
-
 // tiled transpose / layout conversion: dst(i,c) = src(i,c), arbitrary (row,col) strides
 __global__ __launch_bounds__(256) void relayout_kernel(const double *__restrict__ src,
                                                        int64_t s_rs, int64_t s_cs,
@@ -486,25 +406,7 @@ static int spmm_launch(const I *rowptr, const I *colval, const double *nzval, co
         } else if (small) { if (vu == 4) HPCLA_SPMM_VEC(SP, 4, 512, false, false); else HPCLA_SPMM_VEC(SP, 2, 512, false, false); } \
         else { if (vu == 4) HPCLA_SPMM_VEC(SP, 4, 1536, false, false); else HPCLA_SPMM_VEC(SP, 2, 1536, false, false); } \
     } while (0)
-        // whole-line form (k % 16 == 0): HPCLA_SPMM_LINE = 0 | 2 | 3 (entries per row per step; 0 = off)
-        static const int line_env = [] {
-            const char *e = getenv("HPCLA_SPMM_LINE");
-            return e ? atoi(e) : 0;
-        }();
-        if (line_env > 0 && (k % KT) == 0) {
-#define HPCLA_SPMM_LINE(SP, VUU, CH)                                                                    \
-    spmm_rowblock_line_kernel<I, SP, VUU, CH><<<grid, block, 0, s>>>(                                    \
-        rowptr, colval, nzval, B_own, b_rs, SP ? B_ghost : nullptr, SP ? bg_rs : 0, SP ? n_own : 0, C, c_rs, \
-        nrows, k, index_base, block_list, (uint32_t)launch_blocks)
-#define HPCLA_SPMM_LINE2(SP)                                                                            \
-    do {                                                                                                \
-        if (line_env >= 3) { if (small) HPCLA_SPMM_LINE(SP, 3, 512); else HPCLA_SPMM_LINE(SP, 3, 1536); } \
-        else { if (small) HPCLA_SPMM_LINE(SP, 2, 512); else HPCLA_SPMM_LINE(SP, 2, 1536); }             \
-    } while (0)
-            if (split) HPCLA_SPMM_LINE2(true); else HPCLA_SPMM_LINE2(false);
-#undef HPCLA_SPMM_LINE2
-#undef HPCLA_SPMM_LINE
-        } else if (split) HPCLA_SPMM_VEC2(true); else HPCLA_SPMM_VEC2(false);
+        if (split) HPCLA_SPMM_VEC2(true); else HPCLA_SPMM_VEC2(false);
 #undef HPCLA_SPMM_VEC2
 #undef HPCLA_SPMM_VEC
     } else if (split)
