@@ -388,8 +388,12 @@ def _make_rccl(comm: AbstractComm, device_index: int = 0):
                     lib.hpcla_comm_init_rank_ex(ctypes.byref(handle), None, nranks, rank, flags))
     if (nranks > 1 or forced) and (_windows_enabled() or (flags & _capi.COMM_NO_RCCL)):
         desc = (ctypes.c_uint8 * _capi.WINDOW_DESC_BYTES)()
-        _capi.call("hpcla_comm_window_export", handle, desc)
+        try:
+            _capi.call("hpcla_comm_window_export", handle, desc)
+        except _capi.HPCLAError:                      # e.g. more than 64 ranks: this rank exports nothing,
+            desc = (ctypes.c_uint8 * _capi.WINDOW_DESC_BYTES)()     # and then NO rank attaches (decided below)
         descs, one_node = allgather_window_descs(comm, bytes(desc))
+        one_node = one_node and all(int.from_bytes(d[80:88], "little") != 0 for d in descs)
         if one_node:
             # map every rank's window, then prove the path: an all-reduce of (rank+1) through the windows.
             # Every rank learns every rank's verdict; unless all passed, all detach and stay on RCCL.
