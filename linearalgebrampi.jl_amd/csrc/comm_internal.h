@@ -92,7 +92,7 @@ struct hpcla_halo_plan {
     int nbuf = 1;                              // ghost buffers in the window
     uint64_t *flags = nullptr, *acks = nullptr;      // local control lines (stride WIN_LINE_U64)
     uint32_t *status = nullptr;                // local: nonzero after a spin timed out
-    std::vector<hpcla::PeerMap> send_peer, recv_peer;   // mapped windows of my send / recv neighbours
+    std::vector<hpcla::PeerMap> peer_maps;     // mapped windows of my neighbours (one per distinct rank)
     void *push_desc_dev = nullptr;             // device array of PushTarget, one per send neighbour
     void *ack_desc_dev = nullptr;              // device array of uint64_t* : where my acks go, one per recv neighbour
     int64_t push_blocks = 0;                   // grid of the push kernel

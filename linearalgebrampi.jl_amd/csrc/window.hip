@@ -270,10 +270,8 @@ int push_wait_kernel_launch(hpcla_halo_plan *p, void *stream)
 
 void push_free(hpcla_halo_plan *p)
 {
-    for (auto &m : p->send_peer) window_close(&m);
-    for (auto &m : p->recv_peer) window_close(&m);
-    p->send_peer.clear();
-    p->recv_peer.clear();
+    for (auto &m : p->peer_maps) window_close(&m);
+    p->peer_maps.clear();
     if (p->push_desc_dev) (void)hipFree(p->push_desc_dev);
     if (p->ack_desc_dev) (void)hipFree(p->ack_desc_dev);
     if (p->push_block_map_dev) (void)hipFree(p->push_block_map_dev);
@@ -457,8 +455,8 @@ HPCLA_API int hpcla_comm_window_detach(hpcla_comm_t *comm)
 HPCLA_API int hpcla_halo_plan_detach(hpcla_halo_plan_t *plan)
 {
     if (!plan) return set_error(HPCLA_ERR_INVALID, "halo_plan_detach: null plan");
-    for (auto &m : plan->send_peer) window_close(&m);
-    plan->send_peer.clear();
+    for (auto &m : plan->peer_maps) window_close(&m);
+    plan->peer_maps.clear();
     plan->attached = false;
     return HPCLA_OK;
 }
@@ -602,7 +600,7 @@ HPCLA_API int hpcla_halo_plan_attach(hpcla_halo_plan_t *plan, const uint8_t *all
     p->push_blocks = (int64_t)(bmap.size() / 2);
     // keep the mappings (closed at destroy)
     for (int r = 0; r < n; ++r)
-        if (have[r]) p->send_peer.push_back(by_rank[r]);
+        if (have[r]) p->peer_maps.push_back(by_rank[r]);
     p->attached = true;
     return HPCLA_OK;
 }
