@@ -143,6 +143,30 @@ def main():
         assert torch.equal(dv[0:900], sv[100:1000]) and torch.equal(dv[900:1600], sv[1000:1700]) \
             and torch.equal(dv[1600:2600], sv[2000:3000]), f"exchange_ranges mismatch (width={width})"
 
+    if push:
+        # bounded spins: a wait whose producer never comes must give up after HPCLA_PUSH_TIMEOUT_S, flag the plan and
+        # let the grid drain (the test sets 2 s) -- never hang the GPU
+        import time
+        plan = ctypes.c_void_p()
+        idx = torch.arange(64, dtype=torch.int32, device="cuda")
+        ranks = (ctypes.c_int32 * 1)(0)
+        counts = (ctypes.c_int64 * 1)(64)
+        torch.cuda.synchronize()
+        capi.check("create", lib.hpcla_halo_plan_create(ctypes.byref(plan), backend.rccl, 1, ranks, counts,
+                                                       idx.data_ptr(), 0, 1, ranks, counts, 1))
+        assert attach_halo_windows(backend, plan)
+        t0 = time.perf_counter()
+        capi.call("hpcla_halo_end", plan, s)                 # a wait with no push before it
+        torch.cuda.synchronize()
+        waited = time.perf_counter() - t0
+        st = ctypes.c_int(0)
+        capi.call("hpcla_halo_status", plan, ctypes.byref(st))
+        limit = float(os.environ.get("HPCLA_PUSH_TIMEOUT_S", "20"))
+        assert st.value == 1, "the orphan wait did not report a timeout"
+        assert 0.5 * limit <= waited <= limit + 5.0, f"orphan wait took {waited:.2f} s (limit {limit} s)"
+        capi.call("hpcla_halo_plan_destroy", plan)
+        print(f"orphan wait gave up after {waited:.2f} s, status flagged")
+
     print("halo self-exchange OK")
 
 

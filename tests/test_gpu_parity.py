@@ -322,7 +322,7 @@ def test_rccl_halo_self_exchange_subprocess(mode):
     fused distributed SpMV (HPCLA_HALO_MODE: exchange on the caller's stream then one launch / exchange
     and boundary blocks on the side stream next to the interior blocks), exercised on one GPU with a
     one-rank RCCL communicator sending to itself (HPCLA_FORCE_RCCL=1)."""
-    env = dict(os.environ, HPCLA_FORCE_RCCL="1", HPCLA_HALO_MODE=mode)
+    env = dict(os.environ, HPCLA_FORCE_RCCL="1", HPCLA_HALO_MODE=mode, HPCLA_PUSH_TIMEOUT_S="2")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_halo_self_worker.py")],
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
