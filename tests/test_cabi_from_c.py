@@ -11,19 +11,39 @@ EXE = os.path.join(ROOT, "tests", "cabi", "_build", "cabi_smoke")
 LIBDIR = os.path.join(ROOT, "linearalgebrampi.jl_amd")
 
 
-def _build():
-    os.makedirs(os.path.dirname(EXE), exist_ok=True)
+SRC_PAIR = os.path.join(ROOT, "tests", "cabi", "cabi_window_pair.c")
+EXE_PAIR = os.path.join(ROOT, "tests", "cabi", "_build", "cabi_window_pair")
+
+
+def _build(src=SRC, exe=EXE):
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
     # plain gcc: the header must be valid C; HIP enters only as the runtime API for hipMalloc/hipMemcpy
-    subprocess.check_call(["gcc", "-std=c11", "-O2", "-Wall", "-Werror=implicit-function-declaration",
-                           "-D__HIP_PLATFORM_AMD__", SRC, "-I", os.path.join(ROOT, "include"),
+    subprocess.check_call(["gcc", "-std=c11", "-D_POSIX_C_SOURCE=200809L", "-O2", "-Wall",
+                           "-Werror=implicit-function-declaration",
+                           "-D__HIP_PLATFORM_AMD__", src, "-I", os.path.join(ROOT, "include"),
                            "-I", "/opt/rocm/include", "-L", LIBDIR, "-lhpcla_rocm", "-L", "/opt/rocm/lib",
-                           "-lamdhip64", f"-Wl,-rpath,{LIBDIR}", "-Wl,-rpath,/opt/rocm/lib", "-lm", "-o", EXE])
+                           "-lamdhip64", f"-Wl,-rpath,{LIBDIR}", "-Wl,-rpath,/opt/rocm/lib", "-lm", "-o", exe])
 
 
 def test_cabi_program_builds():
     """CPU: the header is valid C and every symbol the program uses links."""
     _build()
     assert os.path.exists(EXE)
+    _build(SRC_PAIR, EXE_PAIR)
+    assert os.path.exists(EXE_PAIR)
+
+
+@pytest.mark.gpu
+def test_cabi_two_processes_push_transport_without_python():
+    """Two plain-C processes (fork before any HIP call) bootstrap the peer windows over a socket pair -- the place
+    of MPI.Allgather in the Julia extension -- and run distributed SpMVs + window all-reduces through the header
+    alone: bit-exact against the closed form, identical dot bits on both ranks."""
+    if not os.path.exists(EXE_PAIR):
+        _build(SRC_PAIR, EXE_PAIR)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([EXE_PAIR], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "C-ABI window pair PASS" in out.stdout
 
 
 @pytest.mark.gpu
