@@ -100,3 +100,16 @@ def test_array_digest_is_order_sensitive_and_width_agnostic():
     big = np.arange(5_000_000, dtype=np.int64)                              # crosses the blocking boundary
     assert array_digest(big) == array_digest(big.copy())
     assert len(array_digest(a)) == 32
+
+
+def test_window_descriptor_helpers_on_the_host():
+    """Host-side halves of the window bootstrap that need no GPU: the same-node decision from the gathered
+    descriptors (bytes 64..71 = node identity) and the no-op path of attach_halo_windows without windows."""
+    import types
+    from hpcla_amd import backends as B
+    comm = B.CommSerial()
+    d = bytes(64) + (1234).to_bytes(8, "little") + bytes(56)
+    descs, one = B.allgather_window_descs(comm, d)
+    assert descs == [d] and one is True
+    fake = types.SimpleNamespace(peer_windows=False, comm=comm, has_rccl=False)
+    assert B.attach_halo_windows(fake, None) is False            # nothing to attach, no collective issued
