@@ -356,7 +356,10 @@ def spmm(A, B: HPCMatrix) -> HPCMatrix:
             _capi.check("hpcla_halo_plan_create", _capi.load().hpcla_halo_plan_create(
                 ctypes.byref(halo), backend.rccl, n_send, send_ranks, send_counts, dptr(send_idx),
                 1 if plan.is_i64 else 0, n_recv, recv_ranks, recv_counts, k))
-            attach_halo_windows(backend, halo)          # collective: push transport when all ranks share a node
+            bp = np.asarray(B.row_partition, dtype=np.int64)
+            wprobe = (plan.n_own, k, [(r, np.arange(bp[r + 1] - bp[r]) if wish[r] else A.col_indices[perm] - bp[r])
+                                     for r, perm in zip(h.recv_rank_ids, h.recv_perm)])
+            attach_halo_windows(backend, halo, wprobe)  # collective: push transport when all ranks share a node
             # SpMM row blocks are smaller than SpMV row blocks: classify at SpMM granularity
             rpb = _capi.load().hpcla_spmm_rows_per_block()
             nblk = (A.nrows_local + rpb - 1) // rpb

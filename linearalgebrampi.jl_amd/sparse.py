@@ -208,7 +208,9 @@ class VectorPlan:
                 dptr(send_idx), 1 if self.is_i64 else 0, n_recv, recv_ranks, recv_counts, 1))
         # collective (ranks without neighbours take part with an empty descriptor): map the neighbours'
         # ghost windows -> push transport for this plan (csrc/window.hip)
-        self.push = attach_halo_windows(backend, self.halo if self.has_halo else None)
+        xp = np.asarray(x.partition, dtype=np.int64)
+        probe = (self.n_own, 1, [(r, A.col_indices[perm] - xp[r]) for r, perm in zip(h.recv_rank_ids, h.recv_perm)])
+        self.push = attach_halo_windows(backend, self.halo if self.has_halo else None, probe)
 
         # interior / boundary row blocks
         self.interior = self.boundary = None

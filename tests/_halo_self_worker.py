@@ -29,7 +29,7 @@ def main():
     n = 100_000
     x = torch.from_numpy(orc.fill_uniform(0, n, 42)).cuda()
 
-    def run(idx_np, width, xsrc):
+    def run(idx_np, width, xsrc, bad_probe=False):
         plan = ctypes.c_void_p()
         idx = torch.from_numpy(idx_np.astype(np.int32)).cuda()
         ranks = (ctypes.c_int32 * 1)(0)
@@ -37,7 +37,10 @@ def main():
         torch.cuda.synchronize()
         capi.check("create", lib.hpcla_halo_plan_create(ctypes.byref(plan), backend.rccl, 1, ranks, counts,
                                                        idx.data_ptr(), 0, 1, ranks, counts, width))
-        assert attach_halo_windows(backend, plan) == push
+        # the attach ends with the plan's connection test (two real exchanges checked against these lists); a
+        # plan whose test fails is detached and exchanges over RCCL instead
+        probe = (xsrc.numel() // width, width, [(0, idx_np + (1 if bad_probe else 0))])
+        assert attach_halo_windows(backend, plan, probe) == (push and not bad_probe)
         ghost = ctypes.c_void_p(); ng = ctypes.c_int64()
         for rep in range(5):                       # repeated use: WAR ordering of the ghost buffer(s)
             xs = xsrc * (rep + 1.0)
@@ -65,6 +68,8 @@ def main():
     xk = torch.from_numpy(orc.fill_uniform(0, 4096 * k, 43)).cuda()
     run(np.sort(rng.choice(4096, size=300, replace=False)), k, xk)       # SpMM ghost rows, width 16
     run(np.arange(100, 400), k, xk)
+    if push:
+        run(np.arange(50, 900), 1, x, bad_probe=True)                      # failed connection test -> RCCL, same values
 
     # all-reduce on the one-rank communicator is the identity
     t = torch.tensor([3.25, -1.0], dtype=torch.float64, device="cuda")
