@@ -316,6 +316,16 @@ int hpcla_halo_plan_attach(hpcla_halo_plan_t *plan, const uint8_t *all_descs_hos
                            const int64_t *all_tables_host);
 /* give up the push transport of this plan (some rank failed to attach): RCCL receives into the ghost */
 int hpcla_halo_plan_detach(hpcla_halo_plan_t *plan);
+/* Connection test of one plan on the real topology, run by the host runtime right after attach (collective
+ * among the ranks that hold a plan: each makes the same TWO exchanges, one per ghost buffer of a
+ * double-buffered plan).  The exchanged vector is x[i*width + j] = rank * 2^40 + i*width + j (+ 0.25 in
+ * round two; `n_local_rows` rows); afterwards ghost slot check_slots[t] must hold row check_rows[t] of the
+ * rank whose segment the slot lies in (the host knows both from the reference plan: recv_perm and the
+ * x partition, src/sparse.jl:1938-1953).  *ok = 1: every checked value arrived and nothing timed out;
+ * *ok = 0: hpcla_last_error() says what failed -- the runtime then all-gathers the verdicts and detaches
+ * the plan on every rank (hpcla_halo_plan_detach), leaving it on RCCL.  Works for RCCL plans too. */
+int hpcla_halo_plan_probe(hpcla_halo_plan_t *plan, int64_t n_local_rows, const int64_t *check_slots_host,
+                          const int64_t *check_rows_host, int64_t n_check, void *stream, int *ok);
 /* 1 in *timed_out if a push or wait of this plan gave up (result invalid); synchronising 4-byte read. */
 int hpcla_halo_status(hpcla_halo_plan_t *plan, int *timed_out);
 /* device pointer of the ghost buffer of the exchange completed last (n_ghost*width doubles) and its length in

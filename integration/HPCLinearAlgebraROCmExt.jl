@@ -107,7 +107,9 @@ function _attach_comm_window(h::Ptr{Cvoid}, mpicomm::MPI.Comm, nranks::Int)
 end
 
 # plan-time, collective over the communicator (ranks without neighbours pass halo == C_NULL)
-function _attach_halo_window(h::Ptr{Cvoid}, halo::Ptr{Cvoid}, mpicomm::MPI.Comm, nranks::Int)
+# `probe = (n_local_rows, segments)`: segments[i] = 0-based rows of neighbour recv_rank_ids[i] that fill its ghost
+# segment, in ghost order -- the plan's connection test (hpcla_halo_plan_probe) checks a sample of them
+function _attach_halo_window(h::Ptr{Cvoid}, halo::Ptr{Cvoid}, mpicomm::MPI.Comm, nranks::Int, probe=nothing)
     get(_windows_ok, h, false) || return false
     desc = zeros(UInt8, 128); table = fill(Int64(-1), 4 * nranks)
     halo == C_NULL || _check(@ccall(LIB.hpcla_halo_plan_export(halo::Ptr{Cvoid}, desc::Ptr{UInt8}, table::Ptr{Int64})::Cint),
@@ -115,8 +117,26 @@ function _attach_halo_window(h::Ptr{Cvoid}, halo::Ptr{Cvoid}, mpicomm::MPI.Comm,
     descs = MPI.Allgather(desc, mpicomm); tables = MPI.Allgather(table, mpicomm)
     mine = halo != C_NULL && any(!=(0x00), desc[81:88])            # bytes 80..87: window size
     ok = !mine || (@ccall LIB.hpcla_halo_plan_attach(halo::Ptr{Cvoid}, descs::Ptr{UInt8}, tables::Ptr{Int64})::Cint) == 0
-    if minimum(MPI.Allgather(Int32[ok ? 1 : 0], mpicomm)) == 0
-        mine && ok && _check(@ccall(LIB.hpcla_halo_plan_detach(halo::Ptr{Cvoid})::Cint), "hpcla_halo_plan_detach")
+    attached = minimum(MPI.Allgather(Int32[ok ? 1 : 0], mpicomm)) == 1
+    if attached
+        # connection test of THIS plan on the real topology: two checked exchanges; verdict all-gathered
+        if mine && probe !== nothing
+            n_local, segments = probe
+            slots = Int64[]; rows = Int64[]; off = 0
+            for seg in segments
+                cnt = length(seg)
+                pick = unique(vcat(1:min(cnt, 2048), max(cnt - 2047, 1):cnt, cnt > 0 ? rand(1:cnt, 8192) : Int[]))
+                append!(slots, off .+ pick .- 1); append!(rows, Int64.(seg[pick])); off += cnt
+            end
+            good = Ref{Cint}(0)
+            rc = @ccall LIB.hpcla_halo_plan_probe(halo::Ptr{Cvoid}, Int64(n_local)::Int64, slots::Ptr{Int64}, rows::Ptr{Int64},
+                                                  length(slots)::Int64, _stream()::Ptr{Cvoid}, good::Ptr{Cint})::Cint
+            ok = rc == 0 && good[] == 1
+        end
+        attached = minimum(MPI.Allgather(Int32[ok ? 1 : 0], mpicomm)) == 1
+    end
+    if !attached
+        mine && _check(@ccall(LIB.hpcla_halo_plan_detach(halo::Ptr{Cvoid})::Cint), "hpcla_halo_plan_detach")
         return false
     end
     return mine
@@ -129,6 +149,7 @@ mutable struct ROCVectorPlan{Ti}
     interior::ROCVector{Int32}
     boundary::ROCVector{Int32}
     n_own::Int
+    segments::Vector{Vector{Int}}    # per recv neighbour: 0-based rows (in their owner) that fill its ghost segment
 end
 const _rocm_plans = IdDict{Any,Any}()    # reference plan object -> ROCVectorPlan (cleared with clear_plan_cache!)
 
@@ -154,6 +175,8 @@ function _device_plan(A::HPCSparseMatrix{T,Ti,B}, x::HPCVector{T,B}, plan) where
                    _ptr(split)::Ptr{Cvoid}, nnz::Int64, 1::Cint, _stream()::Ptr{Cvoid})::Cint), "hpcla_remap_i64")
         end
         halo = Ref{Ptr{Cvoid}}(C_NULL)
+        segments = [Int.(A.col_indices[perm] .- x.partition[r + 1])       # 0-based row in its owner (rank r, 0-based)
+                    for (r, perm) in zip(plan.recv_rank_ids, plan.recv_perm)]
         interior = ROCVector{Int32}(undef, 0); boundary = ROCVector{Int32}(undef, 0)
         if !isempty(plan.send_rank_ids) || !isempty(plan.recv_rank_ids)
             send_idx = ROCVector(Ti.(reduce(vcat, plan.send_indices; init=Ti[]) .- one(Ti)))   # 0-based
@@ -184,8 +207,9 @@ function _device_plan(A::HPCSparseMatrix{T,Ti,B}, x::HPCVector{T,B}, plan) where
         end
         # collective: map the neighbours' ghost windows (push transport); a no-op without attached windows
         A.backend.comm isa CommMPI &&
-            _attach_halo_window(_rccl(A.backend.comm), halo[], A.backend.comm.comm, comm_size(A.backend.comm))
-        ROCVectorPlan{Ti}(halo[], split, interior, boundary, n_own)
+            _attach_halo_window(_rccl(A.backend.comm), halo[], A.backend.comm.comm, comm_size(A.backend.comm),
+                                (n_own, segments))
+        ROCVectorPlan{Ti}(halo[], split, interior, boundary, n_own, segments)
     end
 end
 
@@ -289,7 +313,8 @@ function _spmm_halo(A::HPCSparseMatrix{T,Ti,B}, plan, d::ROCVectorPlan{Ti}, k::I
                Int32.(plan.recv_rank_ids)::Ptr{Int32}, Int64.(length.(plan.recv_perm))::Ptr{Int64},
                k::Cint)::Cint), "hpcla_halo_plan_create")
         A.backend.comm isa CommMPI &&
-            _attach_halo_window(_rccl(A.backend.comm), halo[], A.backend.comm.comm, comm_size(A.backend.comm))
+            _attach_halo_window(_rccl(A.backend.comm), halo[], A.backend.comm.comm, comm_size(A.backend.comm),
+                                (d.n_own, d.segments))
         rpb = @ccall LIB.hpcla_spmm_rows_per_block()::Cint          # SpMM row blocks are smaller than SpMV's
         flags = AMDGPU.zeros(Int32, cld(A.nrows_local, rpb))
         rp0 = _rowptr0(A)

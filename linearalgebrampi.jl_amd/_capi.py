@@ -73,6 +73,7 @@ _SIGNATURES = {
     "hpcla_halo_plan_export": [_vp, _vp, _vp],
     "hpcla_halo_plan_attach": [_vp, _vp, _vp],
     "hpcla_halo_status": [_vp, _vp],
+    "hpcla_halo_plan_probe": [_vp, _i64, _vp, _vp, _i64, _vp, _vp],
     "hpcla_set_halo_mode": [_i32],
     "hpcla_comm_rank": [_vp, _vp],
     "hpcla_comm_size": [_vp, _vp],

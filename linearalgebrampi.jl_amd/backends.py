@@ -426,61 +426,31 @@ def _make_rccl(comm: AbstractComm, device_index: int = 0):
 
 
 def _probe_halo_plan(backend: "HPCBackend", halo, probe) -> str:
-    """Two push exchanges of ``x[i*width + j] = rank * 2**40 + i*width + j (+ 0.25 in round two)`` through
-    the plan's own begin / end, then the ghost buffer against what the neighbours must have stored (sampled:
-    both ends of every neighbour's segment plus random slots).  Every rank with a plan runs the same two
-    exchanges, so the plans' step epochs stay in lockstep.  Returns "" or the reason of the failure."""
+    """The plan's connection test (``hpcla_halo_plan_probe``, csrc/comm.hip): two real exchanges of a vector
+    whose entries encode (rank, position), then sampled ghost slots -- both ends of every neighbour's segment
+    plus random slots -- against the rows the neighbours must have stored there.  Every rank with a plan
+    calls it, so the plans' step epochs stay in lockstep.  Returns "" or the reason of the failure."""
     import torch
     from . import _capi
     n_local, width, segments = probe
-    dev = backend.torch_device
-    s = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-    me = comm_rank(backend.comm)
-    rng = np.random.default_rng(12345 + me)
-    slots, owners, rows, off = [], [], [], 0
-    for r, seg_rows in segments:                   # ghost order = recv order, one contiguous segment per neighbour
+    rng = np.random.default_rng(12345 + comm_rank(backend.comm))
+    slots, rows, off = [], [], 0
+    for _r, seg_rows in segments:                  # ghost order = recv order, one contiguous segment per neighbour
         seg_rows = np.asarray(seg_rows, dtype=np.int64)
         cnt = len(seg_rows)
-        pick = np.unique(np.concatenate([np.arange(min(cnt, 2048)), np.arange(max(cnt - 2048, 0), cnt),
-                                         rng.integers(0, max(cnt, 1), 8192) if cnt else np.empty(0, np.int64)]))
-        slots.append(off + pick)
-        owners.append(np.full(len(pick), r, dtype=np.int64))
-        rows.append(seg_rows[pick])
+        if cnt:
+            pick = np.unique(np.concatenate([np.arange(min(cnt, 2048)), np.arange(max(cnt - 2048, 0), cnt),
+                                             rng.integers(0, cnt, 8192)]))
+            slots.append(off + pick)
+            rows.append(seg_rows[pick])
         off += cnt
-    slots = np.concatenate(slots) if slots else np.empty(0, np.int64)
-    owners = np.concatenate(owners) if owners else np.empty(0, np.int64)
-    rows = np.concatenate(rows) if rows else np.empty(0, np.int64)
-    j = np.arange(width, dtype=np.int64)
-    elem = (slots[:, None] * width + j[None, :]).ravel()
-    want0 = (owners[:, None] * float(2 ** 40) + (rows[:, None] * width + j[None, :])).ravel().astype(np.float64)
-    elem_dev = torch.from_numpy(elem).to(dev)
-    got_dev = torch.empty(len(elem), dtype=torch.float64, device=dev)
-    x = torch.arange(max(n_local * width, 1), dtype=torch.float64, device=dev) + float(me) * float(2 ** 40)
-    ptr = lambda t: ctypes.c_void_p(t.data_ptr())
-    for shift in (0.0, 0.25):
-        if shift:
-            x += shift
-        _capi.call("hpcla_halo_begin", halo, ptr(x), s)
-        _capi.call("hpcla_halo_end", halo, s)
-        ghost, ng = ctypes.c_void_p(), ctypes.c_int64()
-        _capi.call("hpcla_halo_ghost_ptr", halo, ctypes.byref(ghost), ctypes.byref(ng))
-        if int(ng.value) != off:
-            return f"plan probe: ghost holds {int(ng.value)} indices, the plan's lists say {off}"
-        if len(elem):
-            _capi.call("hpcla_gather_f64_i64", ghost, ptr(elem_dev), None, ptr(got_dev), len(elem), 0, s)
-        torch.cuda.current_stream(dev).synchronize()
-        st = ctypes.c_int()
-        _capi.call("hpcla_halo_status", halo, ctypes.byref(st))
-        if st.value:
-            return "plan probe: a push or a wait timed out"
-        if len(elem):
-            got = got_dev.cpu().numpy()
-            bad = np.flatnonzero(got != want0 + shift)
-            if len(bad):
-                b = int(bad[0])
-                return (f"plan probe: {len(bad)} of {len(elem)} sampled ghost values wrong; ghost element {int(elem[b])} "
-                        f"holds {got[b]!r}, expected {want0[b] + shift!r}")
-    return ""
+    slots = np.ascontiguousarray(np.concatenate(slots) if slots else np.empty(0, np.int64), dtype=np.int64)
+    rows = np.ascontiguousarray(np.concatenate(rows) if rows else np.empty(0, np.int64), dtype=np.int64)
+    ok = ctypes.c_int(0)
+    s = ctypes.c_void_p(torch.cuda.current_stream(backend.torch_device).cuda_stream)
+    _capi.call("hpcla_halo_plan_probe", halo, int(n_local), slots.ctypes.data_as(ctypes.c_void_p),
+               rows.ctypes.data_as(ctypes.c_void_p), len(slots), s, ctypes.byref(ok))
+    return "" if ok.value else _capi.last_error()
 
 
 def attach_halo_windows(backend: "HPCBackend", halo, probe=None) -> bool:

@@ -18,6 +18,7 @@
 // SpMV's own boundary workgroups wait for the data (HPCLA_HALO_MODE=push, the default once a plan's
 // windows are attached).  This file dispatches between the two.
 #include <dlfcn.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -543,6 +544,118 @@ HPCLA_API int hpcla_halo_end(hpcla_halo_plan_t *plan, void *stream)
     HPCLA_CHECK_HIP(hipStreamWaitEvent(as_stream(stream), plan->ev_done, 0));   // my own exchange work is done
     // push transport: additionally wait (on the device) until every neighbour has published this epoch
     if (halo_mode_of(plan) == HALO_PUSH) return push_wait_kernel_launch(plan, stream);
+    return HPCLA_OK;
+}
+
+// ---- connection test of ONE plan on the real topology ---------------------------------------------------
+// x[e] = rank * 2^40 + e (+ shift): a ghost slot filled by rank r from its row i holds r * 2^40 + i*w + j.
+__global__ void probe_fill_kernel(double *x, int64_t n, double base, double shift)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        x[i] = base + (double)i + shift;
+}
+
+__global__ void probe_check_kernel(const double *ghost, const int64_t *slots, const int64_t *rows,
+                                   const int32_t *owners, int64_t n_check, int w, double shift,
+                                   unsigned long long *bad)      // bad[0] = count, bad[1] = first wrong element
+{
+    const int64_t total = n_check * w;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t t = e / w;
+        const int j = (int)(e % w);
+        const double want = (double)owners[t] * 1099511627776.0 + (double)(rows[t] * w + j) + shift;
+        const int64_t at = slots[t] * w + j;
+        if (ghost[at] != want) {
+            atomicAdd(&bad[0], 1ULL);
+            atomicMin(&bad[1], (unsigned long long)at);
+        }
+    }
+}
+
+HPCLA_API int hpcla_halo_plan_probe(hpcla_halo_plan_t *plan, int64_t n_local_rows, const int64_t *check_slots_host,
+                                    const int64_t *check_rows_host, int64_t n_check, void *stream, int *ok)
+{
+    if (!plan || !ok) return set_error(HPCLA_ERR_INVALID, "halo_plan_probe: null pointer");
+    *ok = 0;
+    if (n_local_rows < 0 || n_check < 0 || (n_check > 0 && (!check_slots_host || !check_rows_host)))
+        return set_error(HPCLA_ERR_INVALID, "halo_plan_probe: bad arguments");
+    if (plan->send_ranks.empty() && plan->recv_ranks.empty()) { *ok = 1; return HPCLA_OK; }
+    const int w = plan->width;
+    // owner of every checked slot, from the plan's own segment table
+    std::vector<int32_t> owners((size_t)n_check);
+    for (int64_t t = 0; t < n_check; ++t) {
+        const int64_t sl = check_slots_host[t];
+        if (sl < 0 || sl >= plan->n_ghost || check_rows_host[t] < 0)
+            return set_error(HPCLA_ERR_INVALID, "halo_plan_probe: slot %lld outside the ghost (%lld indices)",
+                             (long long)sl, (long long)plan->n_ghost);
+        int32_t who = -1;
+        for (size_t j = 0; j < plan->recv_ranks.size(); ++j)
+            if (sl >= plan->recv_off[j] && sl < plan->recv_off[j] + plan->recv_counts[j]) { who = plan->recv_ranks[j]; break; }
+        if (who < 0) return set_error(HPCLA_ERR_INVALID, "halo_plan_probe: slot %lld lies in no segment", (long long)sl);
+        owners[(size_t)t] = who;
+    }
+    hipStream_t s = as_stream(stream);
+    const int64_t nx = n_local_rows * w > 0 ? n_local_rows * w : 1;
+    double *x = nullptr;
+    int64_t *d_slots = nullptr, *d_rows = nullptr;
+    int32_t *d_own = nullptr;
+    unsigned long long *d_bad = nullptr;
+    hipError_t e = hipMalloc((void **)&x, (size_t)nx * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_bad, 2 * sizeof(unsigned long long));
+    if (e == hipSuccess && n_check) {
+        e = hipMalloc((void **)&d_slots, (size_t)n_check * sizeof(int64_t));
+        if (e == hipSuccess) e = hipMalloc((void **)&d_rows, (size_t)n_check * sizeof(int64_t));
+        if (e == hipSuccess) e = hipMalloc((void **)&d_own, (size_t)n_check * sizeof(int32_t));
+        if (e == hipSuccess) e = hipMemcpy(d_slots, check_slots_host, (size_t)n_check * sizeof(int64_t), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(d_rows, check_rows_host, (size_t)n_check * sizeof(int64_t), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(d_own, owners.data(), (size_t)n_check * sizeof(int32_t), hipMemcpyHostToDevice);
+    }
+    int rc = HPCLA_OK;
+    bool good = (e == hipSuccess);
+    char why[256] = "";
+    // two exchanges: one per ghost buffer of a double-buffered plan, and round two's values differ from round
+    // one's, so a stale buffer cannot pass.  Every rank with a plan makes the same two exchanges.
+    for (int round = 0; round < 2 && e == hipSuccess && rc == HPCLA_OK; ++round) {
+        const double shift = round ? 0.25 : 0.0;
+        const unsigned long long init[2] = {0ULL, ~0ULL};
+        e = hipMemcpyAsync(d_bad, init, sizeof(init), hipMemcpyHostToDevice, s);
+        if (e != hipSuccess) break;
+        int64_t g = (nx + 255) / 256;
+        probe_fill_kernel<<<(uint32_t)(g > 4096 ? 4096 : g), 256, 0, s>>>(x, nx, (double)plan->comm->rank * 1099511627776.0, shift);
+        rc = hpcla_halo_begin(plan, x, stream);
+        if (rc == HPCLA_OK) rc = hpcla_halo_end(plan, stream);
+        double *ghost = nullptr;
+        if (rc == HPCLA_OK) rc = hpcla_halo_ghost_ptr(plan, &ghost, nullptr);
+        if (rc != HPCLA_OK) break;
+        if (n_check) {
+            g = (n_check * w + 255) / 256;
+            probe_check_kernel<<<(uint32_t)(g > 4096 ? 4096 : g), 256, 0, s>>>(ghost, d_slots, d_rows, d_own, n_check, w, shift, d_bad);
+        }
+        unsigned long long bad[2] = {0, 0};
+        e = hipMemcpyAsync(bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) break;
+        int timed_out = 0;
+        rc = hpcla_halo_status(plan, &timed_out);
+        if (rc != HPCLA_OK) break;
+        if (timed_out) {
+            good = false;
+            snprintf(why, sizeof(why), "halo_plan_probe: a push or a wait timed out in round %d", round);
+            break;
+        }
+        if (bad[0]) {
+            good = false;
+            snprintf(why, sizeof(why), "halo_plan_probe: round %d: %llu of %lld checked ghost values wrong, first at ghost element %llu",
+                     round, bad[0], (long long)(n_check * w), bad[1]);
+            break;
+        }
+    }
+    (void)hipFree(x); (void)hipFree(d_bad); (void)hipFree(d_slots); (void)hipFree(d_rows); (void)hipFree(d_own);
+    if (e != hipSuccess) return set_error(HPCLA_ERR_HIP, "halo_plan_probe: %s", hipGetErrorString(e));
+    if (rc != HPCLA_OK) return rc;
+    if (!good) (void)set_error(HPCLA_ERR_INVALID, "%s", why);        // the reason, for hpcla_last_error()
+    *ok = good ? 1 : 0;
     return HPCLA_OK;
 }
 

@@ -125,6 +125,21 @@ static int run_rank(int rank, int fd)
     if (xfer(fd, ptab + rank * HPCLA_WINDOW_TABLE_ROWS * 2, ptab + peer * HPCLA_WINDOW_TABLE_ROWS * 2,
              sizeof(int64_t) * HPCLA_WINDOW_TABLE_ROWS * 2)) return 1;
     CHECK(hpcla_halo_plan_attach(plan, pdesc, ptab));
+    /* the plan's connection test: my ghost slot i must hold the peer's row h (its last grid line for rank 1's
+     * lower ghosts, its first grid line for rank 0's upper ghosts); both ranks run the same two exchanges */
+    {
+        int64_t *slots = (int64_t *)malloc(nx * 8), *prow = (int64_t *)malloc(nx * 8);
+        for (int64_t i = 0; i < nx; ++i) { slots[i] = i; prow[i] = rank == 0 ? i : n_own - nx + i; }
+        int probe_ok = 0, peer_ok = 0;
+        CHECK(hpcla_halo_plan_probe(plan, n_own, slots, prow, nx, NULL, &probe_ok));
+        if (xfer(fd, &probe_ok, &peer_ok, sizeof(int))) return 1;
+        if (!probe_ok || !peer_ok) { fprintf(stderr, "rank %d: plan probe failed: %s\n", rank, hpcla_last_error()); return 1; }
+        /* a wrong expectation must be caught (and costs two more exchanges on BOTH ranks) */
+        prow[nx / 2] += 1;
+        CHECK(hpcla_halo_plan_probe(plan, n_own, slots, prow, nx, NULL, &probe_ok));
+        if (probe_ok) { fprintf(stderr, "rank %d: plan probe accepted a wrong row\n", rank); return 1; }
+        free(slots); free(prow);
+    }
     /* interior / boundary row blocks */
     const int rpb = hpcla_spmv_rows_per_block();
     const int64_t nblk = (n_own + rpb - 1) / rpb;
