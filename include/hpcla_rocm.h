@@ -456,6 +456,16 @@ int hpcla_scale_f64(double alpha_host, const double *x, double *y, int64_t n, vo
 int hpcla_cg_update_f64(hpcla_comm_t *comm, double alpha_host, const double *num_dev,
                         const double *den_dev, const double *p, const double *Ap, double *x, double *r,
                         int64_t n, double *rr_out_dev, void *work, void *stream);
+/* The same iteration with the x update deferred to the direction update (p is then read once per iteration
+ * instead of twice; identical operations per element, identical bits):
+ *   residual:  a = alpha_host * *num_dev / *den_dev;  r -= a*Ap;  rr_out_dev[0] = allreduce(sum r^2)
+ *   direction: a = alpha_host * *a_num_dev / *a_den_dev, b = beta_host * *b_num_dev / *b_den_dev;
+ *              x += a*p;  p = r + b*p      (null num/den pointers count as 1) */
+int hpcla_cg_residual_f64(hpcla_comm_t *comm, double alpha_host, const double *num_dev, const double *den_dev,
+                          const double *Ap, double *r, int64_t n, double *rr_out_dev, void *work, void *stream);
+int hpcla_cg_direction_f64(double alpha_host, const double *a_num_dev, const double *a_den_dev, double beta_host,
+                           const double *b_num_dev, const double *b_den_dev, const double *r, double *x,
+                           double *p, int64_t n, void *stream);
 int hpcla_divide_f64(const double *x, double a_host, double *y, int64_t n, void *stream);
 int hpcla_axpby_f64(double a, const double *x, double b, const double *y, double *z, int64_t n,
                     void *stream);

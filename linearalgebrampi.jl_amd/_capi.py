@@ -91,6 +91,8 @@ _SIGNATURES = {
     "hpcla_spmv_dist_dot_f64_i32": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp],
     "hpcla_spmv_dist_dot_f64_i64": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp],
     "hpcla_cg_update_f64": [_vp, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp],
+    "hpcla_cg_residual_f64": [_vp, _f64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp],
+    "hpcla_cg_direction_f64": [_f64, _vp, _vp, _f64, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "hpcla_colspace_work_bytes": [_i64],
     "hpcla_compress_columns_i32": [_vp, _i64, _i64, _i64, _vp, _i32, _vp, _vp, _vp, _vp],
     "hpcla_compress_columns_i64": [_vp, _i64, _i64, _i64, _vp, _i32, _vp, _vp, _vp, _vp],

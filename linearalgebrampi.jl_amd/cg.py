@@ -10,15 +10,16 @@ Two forms, identical arithmetic per element (only the reduction trees differ):
 
 * ``fused=False``  one library call per reference operator: SpMV, dot, axpy, axpy, norm, xpay
   (8 kernel launches, SpMV + 96 B/row of vector traffic -- the "textbook unfused" count of SURVEY 8d);
-* ``fused=True``   SpMV with the p.Ap partials in its epilogue, one update kernel for
-  x += a p / r -= a Ap / sum r^2, then xpay: 5 launches, SpMV + ~72 B/row.
+* ``fused=True``   SpMV with the p.Ap partials in its epilogue, one kernel for r -= a Ap / sum r^2, one for
+  x += a p / p = r + b p (the x update is deferred to where p is read anyway): 5 launches,
+  SpMV + 64 B/row.
 """
 from __future__ import annotations
 
 from typing import List, Tuple
 
 from .sparse import get_vector_plan, mul_, mul_dot_
-from .vectors import HPCVector, cg_update_, dot, norm
+from .vectors import HPCVector, cg_direction_, cg_residual_, dot, norm
 
 
 def _torch():
@@ -29,13 +30,14 @@ def _torch():
 def _cg_iteration(A, x, r, p, Ap, rr_cur, rr_nxt, pAp, fused: bool) -> None:
     if fused:
         mul_dot_(Ap, A, p, pAp)                                 # Ap = A*p, pAp = p.Ap
-        cg_update_(x, r, p, Ap, 1.0, rr_cur, pAp, rr_nxt)       # x += a p; r -= a Ap; rr_new
-    else:
-        mul_(Ap, A, p)                                          # Ap = A*p
-        dot(p, Ap, out=pAp)                                     # pAp
-        x.axpy_(1.0, p, num=rr_cur, den=pAp)                    # x += (rr/pAp) p
-        r.axpy_(-1.0, Ap, num=rr_cur, den=pAp)                  # r -= (rr/pAp) Ap
-        norm(r, 2, out=rr_nxt)                                  # rr_new = sum(r^2)
+        cg_residual_(r, Ap, 1.0, rr_cur, pAp, rr_nxt)           # r -= a Ap; rr_new        (a = rr/pAp)
+        cg_direction_(x, p, r, 1.0, rr_cur, pAp, 1.0, rr_nxt, rr_cur)   # x += a p; p = r + (rr_new/rr) p
+        return
+    mul_(Ap, A, p)                                              # Ap = A*p
+    dot(p, Ap, out=pAp)                                         # pAp
+    x.axpy_(1.0, p, num=rr_cur, den=pAp)                        # x += (rr/pAp) p
+    r.axpy_(-1.0, Ap, num=rr_cur, den=pAp)                      # r -= (rr/pAp) Ap
+    norm(r, 2, out=rr_nxt)                                      # rr_new = sum(r^2)
     p.xpay_(r, 1.0, num=rr_nxt, den=rr_cur)                     # p = r + (rr_new/rr) p
 
 

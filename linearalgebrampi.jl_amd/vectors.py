@@ -207,6 +207,23 @@ def cg_update_(x: HPCVector, r: HPCVector, p: HPCVector, Ap: HPCVector, a: float
     return rr_out
 
 
+def cg_residual_(r: HPCVector, Ap: HPCVector, a: float, num, den, rr_out):
+    """``r .-= s .* Ap ; rr_out = sum(r.^2)``, ``s = a*num/den`` from device scalars (24 B/elt)."""
+    r._same_partition(Ap)
+    work, _ = _Scratch.get(r.v.device)
+    _capi.call("hpcla_cg_residual_f64", r.backend.rccl, float(a), dptr(num), dptr(den), dptr(Ap.v), dptr(r.v),
+               r.local_length, dptr(rr_out), dptr(work), current_stream_ptr())
+    return rr_out
+
+
+def cg_direction_(x: HPCVector, p: HPCVector, r: HPCVector, a: float, a_num, a_den, b: float, b_num, b_den):
+    """``x .+= s .* p ; p .= r .+ t .* p`` with ``s = a*a_num/a_den``, ``t = b*b_num/b_den`` (40 B/elt): the
+    deferred x update of a CG iteration rides on the direction update, which reads the same p."""
+    x._same_partition(p), x._same_partition(r)
+    _capi.call("hpcla_cg_direction_f64", float(a), dptr(a_num), dptr(a_den), float(b), dptr(b_num), dptr(b_den),
+               dptr(r.v), dptr(x.v), dptr(p.v), x.local_length, current_stream_ptr())
+
+
 def HPCVector_local(v_local, backend: HPCBackend) -> HPCVector:
     """src/vectors.jl:76-94: partition inferred by an Allgather of the local sizes."""
     torch = _torch()

@@ -656,6 +656,20 @@ def test_fused_spmv_dot_and_cg_update(hp, orc, gpu_backend_i32):
         np.testing.assert_array_equal(X.local_values(), wx)
         np.testing.assert_array_equal(R.local_values(), wr)
         assert abs(rr.item() - orc.dot([wr], [wr])) <= RTOL_RED * orc.dot([wr], [wr])
+        # the deferred-x form: cg_residual_ (r -= s Ap ; rr) then cg_direction_ (x += s p ; p = r + t p) -- the
+        # same per-element operations, so x / r / p must carry the same bits as the three separate updates
+        X2, R2 = hp.HPCVector.from_global(xx, b), hp.HPCVector.from_global(rrv, b)
+        P2 = hp.HPCVector.from_global(pg, b)
+        rr2 = torch.zeros(1, dtype=torch.float64, device="cuda")
+        hp.cg_residual_(R2, AP, 1.0, num, den, rr2)
+        np.testing.assert_array_equal(R2.local_values(), wr)
+        assert rr2.item() == rr.item()                                    # same reduction tree as cg_update_
+        bnum = torch.tensor([0.3], dtype=torch.float64, device="cuda")
+        bden = torch.tensor([0.7], dtype=torch.float64, device="cuda")
+        hp.cg_direction_(X2, P2, R2, 1.0, num, den, 1.0, bnum, bden)
+        np.testing.assert_array_equal(X2.local_values(), wx)
+        wp = pg.copy(); orc.xpay(wr, 1.0 * 0.3 / 0.7, wp)                 # p = r + t p
+        np.testing.assert_array_equal(P2.local_values(), wp)
 
 
 def test_cg_fused_equals_unfused(hp, orc, gpu_backend_i32):
