@@ -163,8 +163,9 @@ __device__ __forceinline__ void halo_push_block(const PushArgs &a, int b)
     const I *idx = reinterpret_cast<const I *>(a.idx);
     const int w = a.w;
     const int64_t total = T.count * w;
-    const int64_t per = (total + T.nchunks - 1) / T.nchunks;
-    const int64_t lo = (int64_t)c * per;
+    int64_t per = (total + T.nchunks - 1) / T.nchunks;
+    per += per & 1;                                    // even chunk starts: a 16-byte pair never straddles two chunks
+    const int64_t lo = (int64_t)c * per < total ? (int64_t)c * per : total;
     const int64_t hi = lo + per < total ? lo + per : total;
     if (T.first >= 0) {
         const double *src = a.x + T.first * w;
@@ -192,6 +193,16 @@ __device__ __forceinline__ void halo_push_block(const PushArgs &a, int b)
     } else if (w == 1) {
         for (int64_t i = lo + threadIdx.x; i < hi; i += NT)
             __hip_atomic_store(dst + i, a.x[(int64_t)idx[T.src_off + i]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    } else if ((w & 1) == 0 && ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(a.x)) & 15) == 0) {
+        // gathered ROWS of an even number of doubles (SpMM ghost rows): a row is contiguous on both sides and
+        // 16-byte aligned, so it travels as 16-byte write-through stores like a contiguous run
+        for (int64_t i = lo + 2 * (int64_t)threadIdx.x; i < hi; i += 2 * NT) {
+            typedef double v2d __attribute__((ext_vector_type(2)));
+            const int64_t e = i / w;
+            const int cc = (int)(i - e * w);
+            const v2d v = *reinterpret_cast<const v2d *>(a.x + (int64_t)idx[T.src_off + e] * w + cc);
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst + i), "v"(v) : "memory");
+        }
     } else {
         for (int64_t i = lo + threadIdx.x; i < hi; i += NT) {
             const int64_t e = i / w;
