@@ -191,8 +191,25 @@ __device__ __forceinline__ void halo_push_block(const PushArgs &a, int b)
                 __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     } else if (w == 1) {
-        for (int64_t i = lo + threadIdx.x; i < hi; i += NT)
-            __hip_atomic_store(dst + i, a.x[(int64_t)idx[T.src_off + i]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // gathered values: the DESTINATION is contiguous, so two gathered values leave as one 16-byte store
+        // (chunk starts are even; only a misaligned ghost segment falls back to 8-byte stores)
+        if ((reinterpret_cast<uintptr_t>(dst + lo) & 15) == 0) {
+            typedef double v2d __attribute__((ext_vector_type(2)));
+            const int64_t hi2 = lo + ((hi - lo) & ~(int64_t)1);
+            for (int64_t i = lo + 2 * (int64_t)threadIdx.x; i < hi2; i += 2 * NT) {
+                v2d v;
+                v.x = a.x[(int64_t)idx[T.src_off + i]];
+                v.y = a.x[(int64_t)idx[T.src_off + i + 1]];
+                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst + i), "v"(v) : "memory");
+            }
+            if (threadIdx.x == 0 && hi2 < hi)
+                __hip_atomic_store(dst + hi2, a.x[(int64_t)idx[T.src_off + hi2]], __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_SYSTEM);
+        } else {
+            for (int64_t i = lo + threadIdx.x; i < hi; i += NT)
+                __hip_atomic_store(dst + i, a.x[(int64_t)idx[T.src_off + i]], __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     } else if ((w & 1) == 0 && ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(a.x)) & 15) == 0) {
         // gathered ROWS of an even number of doubles (SpMM ghost rows): a row is contiguous on both sides and
         // 16-byte aligned, so it travels as 16-byte write-through stores like a contiguous run
