@@ -77,7 +77,11 @@ def cg_fixed_iterations(A, b: HPCVector, iters: int, record_history: bool = True
                 hist[first + k + 1:first + k + 2].copy_(rr[nxt:nxt + 1])
             cur = nxt
 
-    if not graph or iters < 4:
+    if (not graph or iters < 4) and record_history:
+        # eager loop: the history array IS the rr storage (sum r_k^2 lives in hist[k]), so recording costs no copies
+        for k in range(iters):
+            _cg_iteration(A, x, r, p, Ap, hist[k:k + 1], hist[k + 1:k + 2], pAp, fused)
+    elif not graph or iters < 4:
         pair(0, iters)
     else:
         pair(0, 2)                                                   # eager: allocations, plan probes
