@@ -411,7 +411,8 @@ def strong_scaling_record(hp, wl, job, backend, args, world, rank):
                 "gflops": round(2.0 * nnz_tot / (ms * 1e-3) / 1e9, 2), "nnz": nnz_tot,
                 "hbm_frac_of_peak_whole_job": round(b_tot / (ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), 4),
                 "verified_vs_closed_form": run.verified, "timed_out": bool(job.max(1.0 if run.plan.timed_out() else 0.0)),
-                "halo_mode": "push" if getattr(run.plan, "push", False) else os.environ.get("HPCLA_HALO_MODE", "serial")})
+                "halo_mode": ("push" if getattr(run.plan, "push", False) else
+                              os.environ.get("HPCLA_HALO_MODE", "serial") if run.plan.has_halo else "none (no neighbours)")})
     verified = run.verified
     run.release()
     hp.clear_plan_cache()
