@@ -151,7 +151,7 @@ mutable struct ROCVectorPlan{Ti}
     n_own::Int
     segments::Vector{Vector{Int}}    # per recv neighbour: 0-based rows (in their owner) that fill its ghost segment
 end
-const _rocm_plans = IdDict{Any,Any}()    # reference plan object -> ROCVectorPlan (cleared with clear_plan_cache!)
+const _rocm_plans = IdDict{Any,Any}()    # reference plan object -> ROCVectorPlan (freed by clear_rocm_plan_cache!)
 
 function _device_plan(A::HPCSparseMatrix{T,Ti,B}, x::HPCVector{T,B}, plan) where {T,Ti,B<:ROCBackend}
     get!(_rocm_plans, plan) do
@@ -295,7 +295,7 @@ end
 # ---- A * B, B::HPCMatrix  (replaces the column loop of src/sparse.jl:2391-2413) ---------------------------
 # Julia's Matrix is column-major; the kernel's fast layout is row-major (one 128-byte line per B row at
 # k = 16), so B is converted once with hpcla_transpose_f64 and C converted back.
-const _spmm_plans = IdDict{Any,Any}()     # (reference plan, k) -> (halo handle, interior, boundary); freed with the plan cache
+const _spmm_plans = IdDict{Any,Any}()     # (reference plan, k) -> (halo handle, interior, boundary); freed by clear_rocm_plan_cache!
 
 # width-k halo plan for the ghost ROWS of B: the reference VectorPlan's own lists, `width = k` values per index
 # (row-major rows travel as contiguous k-doubles).  The Python twin additionally swaps a neighbour's requested
@@ -374,6 +374,65 @@ function Base.:*(A::HPCSparseMatrix{T,Ti,B}, M::HPCMatrix{T,B}) where {T<:Float6
     _check(@ccall(LIB.hpcla_transpose_f64(_ptr(Crow)::Ptr{Cvoid}, k::Int64, 0::Cint, _ptr(C)::Ptr{Cvoid},
            A.nrows_local::Int64, 1::Cint, A.nrows_local::Int64, k::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_transpose_f64")
     return HPCLinearAlgebra.HPCMatrix_local(C, A.backend)
+end
+
+# ---- execute_plan!(::VectorPlan, x) on the device  (replaces src/vectors.jl:394-463 for every OTHER caller of
+# the plan: vector operands with different partitions :870-876, dense A*x, ...; A*x above never needs `gathered`)
+# gathered[local_dst] = x[local_src] and gathered[recv_perm[i]] = what neighbour i sent, GPU to GPU; the CPU
+# staging buffer `gathered_cpu` is never touched.  Collective like the reference's.
+const _rocm_exec = IdDict{Any,Any}()      # reference plan -> (halo handle, device index lists); freed by clear_rocm_plan_cache!
+function HPCLinearAlgebra.execute_plan!(plan::HPCLinearAlgebra.VectorPlan{T,Ti,<:ROCVector},
+                                        x::HPCVector{T,B}) where {T<:Float64,Ti,B<:ROCBackend}
+    st = get!(_rocm_exec, plan) do
+        halo = Ref{Ptr{Cvoid}}(C_NULL)
+        send_idx = ROCVector(Int64.(reduce(vcat, plan.send_indices; init=Ti[])) .- 1)      # 0-based, kept alive with the plan
+        if !isempty(plan.send_rank_ids) || !isempty(plan.recv_rank_ids)
+            AMDGPU.synchronize()
+            _check(@ccall(LIB.hpcla_halo_plan_create(halo::Ptr{Ptr{Cvoid}}, _rccl(x.backend.comm)::Ptr{Cvoid},
+                   length(plan.send_rank_ids)::Cint, Int32.(plan.send_rank_ids)::Ptr{Int32},
+                   Int64.(length.(plan.send_indices))::Ptr{Int64}, _ptr(send_idx)::Ptr{Cvoid}, 1::Cint,
+                   length(plan.recv_rank_ids)::Cint, Int32.(plan.recv_rank_ids)::Ptr{Int32},
+                   Int64.(length.(plan.recv_perm))::Ptr{Int64}, 1::Cint)::Cint), "hpcla_halo_plan_create")
+        end
+        x.backend.comm isa CommMPI &&
+            _attach_halo_window(_rccl(x.backend.comm), halo[], x.backend.comm.comm, comm_size(x.backend.comm))
+        perm = Int64.(reduce(vcat, plan.recv_perm; init=Ti[]))
+        (halo[], ROCVector(Int64.(plan.local_src_indices)), ROCVector(Int64.(plan.local_dst_indices)),
+         ROCVector(perm), ROCVector(collect(Int64, 1:length(perm))), send_idx)
+    end
+    halo, src, dst, perm, ident, _ = st
+    s = _stream()
+    halo == C_NULL || _check(@ccall(LIB.hpcla_halo_begin(halo::Ptr{Cvoid}, _ptr(x.v)::Ptr{Cvoid}, s::Ptr{Cvoid})::Cint),
+                             "hpcla_halo_begin")
+    # the own part, under the exchange: 1-based lists as they stand (index_base = 1)
+    isempty(src) || _check(@ccall(LIB.hpcla_gather_f64_i64(_ptr(x.v)::Ptr{Cvoid}, _ptr(src)::Ptr{Cvoid}, _ptr(dst)::Ptr{Cvoid},
+                           _ptr(plan.gathered)::Ptr{Cvoid}, length(src)::Int64, 1::Cint, s::Ptr{Cvoid})::Cint),
+                           "hpcla_gather_f64_i64")
+    if halo != C_NULL
+        _check(@ccall(LIB.hpcla_halo_end(halo::Ptr{Cvoid}, s::Ptr{Cvoid})::Cint), "hpcla_halo_end")
+        ghost = Ref{Ptr{Cvoid}}(C_NULL); ng = Ref{Int64}(0)
+        _check(@ccall(LIB.hpcla_halo_ghost_ptr(halo::Ptr{Cvoid}, ghost::Ptr{Ptr{Cvoid}}, ng::Ptr{Int64})::Cint),
+               "hpcla_halo_ghost_ptr")
+        isempty(perm) || _check(@ccall(LIB.hpcla_gather_f64_i64(ghost[]::Ptr{Cvoid}, _ptr(ident)::Ptr{Cvoid},
+                                _ptr(perm)::Ptr{Cvoid}, _ptr(plan.gathered)::Ptr{Cvoid}, length(perm)::Int64, 1::Cint,
+                                s::Ptr{Cvoid})::Cint), "hpcla_gather_f64_i64")
+    end
+    return plan.gathered
+end
+
+# ---- freeing the device halves of the plans ------------------------------------------------------------------
+# Explicit and collective, never from a finalizer (the handles own device memory, IPC mappings and a stream; the
+# CUDA extension states the same rule for its communicators, ext/HPCLinearAlgebraCUDAExt.jl:9-10, 384-386).
+# Call it wherever clear_plan_cache!() is called (src/HPCLinearAlgebra.jl:181-201 empties the reference plans
+# these entries are keyed on); INTEGRATION.md shows the one-line hook for the parent.
+function clear_rocm_plan_cache!()
+    destroy(h) = h == C_NULL || @ccall LIB.hpcla_halo_plan_destroy(h::Ptr{Cvoid})::Cint
+    AMDGPU.synchronize()
+    for d in values(_rocm_plans); d isa ROCVectorPlan && destroy(d.halo); end
+    for st in values(_spmm_plans); destroy(st[1]); end
+    for st in values(_rocm_exec); destroy(st[1]); end
+    empty!(_rocm_plans); empty!(_spmm_plans); empty!(_rocm_exec); empty!(_merge_lists)
+    return nothing
 end
 
 # ---- repartition(x, p)  (replaces the CPU-staged execute_plan! of src/vectors.jl:624-671) ---------------
