@@ -356,7 +356,7 @@ function Base.:*(A::HPCSparseMatrix{T,Ti,B}, M::HPCMatrix{T,B}) where {T<:Float6
            0::Cint, nloc::Int64, k::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_transpose_f64")
     Crow = AMDGPU.zeros(T, k, A.nrows_local)
     # the vector plan for (A, B's row partition) provides neighbour lists and the split column space
-    probe = HPCVector{T,B}(compute_partition_hash(M.row_partition), M.row_partition, view(Brow, 1, :), A.backend)
+    probe = HPCVector{T,B}(compute_partition_hash(M.row_partition), M.row_partition, similar(A.nzval, nloc), A.backend)   # plan key only
     plan = get_vector_plan(A, probe)
     d = _device_plan(A, probe, plan)
     if isempty(plan.send_rank_ids) && isempty(plan.recv_rank_ids)
