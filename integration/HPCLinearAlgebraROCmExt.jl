@@ -491,7 +491,9 @@ HPCLinearAlgebra.execute_subtraction!(nzval::ROCVector{Float64}, plan::HPCLinear
 # (n x nloc) block of its transpose, so the two entry points swap roles -- A*x reads A.A through the
 # column-sum kernel and transpose(A)*x through the row-dot kernel; no relayout.
 function Base.:*(A::HPCMatrix{T,B}, x::HPCVector{T,B}) where {T<:Float64,B<:ROCBackend}
-    comm_size(A.backend.comm) == 1 || error("multi-rank dense A*x: gather x with a halo plan first (see linearalgebrampi.jl_amd/dense.py)")
+    # several ranks: the parent's method (src/dense.jl:614-658) gathers x through execute_plan!(::VectorPlan, x) --
+    # the device exchange above -- and multiplies the local block with the array package's gemv
+    comm_size(A.backend.comm) == 1 || return invoke(Base.:*, Tuple{HPCMatrix,HPCVector}, A, x)
     nloc, n = size(A.A)
     y = AMDGPU.zeros(T, nloc)
     work = AMDGPU.zeros(UInt8, @ccall LIB.hpcla_gemv_t_work_bytes(n::Int64, nloc::Int64)::Int64)
