@@ -15,6 +15,7 @@ Checks, each against the CPU oracle on identical inputs and therefore against th
     HIP graph (bit-identical);
   * A*B with k = 16 and k = 3 dense columns (distributed SpMM), Int32 and Int64;
   * mul_dot_ (fused SpMV + p.Ap);
+  * products of all the matrices interleaved (several cached plans in flight, no host sync in between);
   * no push/wait timed out.
 Exit code 0 = all passed on this rank."""
 import os
@@ -100,6 +101,7 @@ def main():
         cases.append(("sprand_xpart", n3, lambda lo, hi: orc.sprand_rows(n3, 0.002, lo, hi),
                       orc.uniform_partition(n3, nranks), xp3))
 
+        kept = []                                   # (name, A, x, y, want): for the interleaved-plans check below
         for name, ng, gen, rp, xp in cases:
             lo, hi = int(rp[rank]), int(rp[rank + 1])
             rows = gen(lo, hi)
@@ -122,6 +124,7 @@ def main():
             torch.cuda.synchronize()
             assert np.array_equal(y.local_values(), want), f"{tag} {name}: repeated mul! differs"
             assert not plan.timed_out(), f"{tag} {name}: a push/wait timed out"
+            kept.append((name, A, x, y, want))
 
             if name in ("sprand_xpart", "tiny"):
                 continue
@@ -193,6 +196,17 @@ def main():
                 C2 = A @ Bm                                      # cached plan, second exchange
                 torch.cuda.synchronize()
                 assert np.array_equal(C2.A.cpu().numpy(), Cw), f"{tag} {name}: second A*B (k={k}) differs"
+        # several cached plans in flight at once: products of DIFFERENT matrices interleaved without a host sync
+        # (every plan has its own windows, epochs and acks; their pushes and waits must not disturb each other)
+        for _ in range(4):
+            for name, A, x, y, want in kept:
+                y.v.zero_()
+                hp.mul_(y, A, x)
+        torch.cuda.synchronize()
+        for name, A, x, y, want in kept:
+            assert np.array_equal(y.local_values(), want), f"{tag} {name}: interleaved products differ"
+            assert not hp.get_vector_plan(A, x).timed_out(), f"{tag} {name}: timed out in the interleaved loop"
+        del kept
         flag = __import__("ctypes").c_int(0)
         hp._capi.call("hpcla_comm_status", backend.rccl, __import__("ctypes").byref(flag))
         assert flag.value == 0, f"{tag}: a window all-reduce timed out"
