@@ -381,8 +381,21 @@ def _make_rccl(comm: AbstractComm, device_index: int = 0):
             uid = bytes(buf)
         uid = comm_bcast_bytes(comm, uid, _capi.UNIQUE_ID_BYTES, root=0)
         idbuf = (ctypes.c_uint8 * _capi.UNIQUE_ID_BYTES).from_buffer_copy(uid)
-        _capi.check("hpcla_comm_init_rank_ex",
-                    lib.hpcla_comm_init_rank_ex(ctypes.byref(handle), idbuf, nranks, rank, flags))
+        why = _init_rccl_guarded(lib, handle, idbuf, nranks, rank, flags, device_index)
+        # collective verdict: RCCL for every rank or for none (ncclCommInitRank is itself a collective that can
+        # fail -- or hang in its socket bootstrap -- on SOME ranks)
+        if nranks > 1 and not bool(comm_allgather(comm, np.array([0 if why else 1])).min()):
+            import sys
+            if why:
+                sys.stderr.write(f"hpcla: rank {rank}: no RCCL communicator ({why}); trying the peer windows alone\n")
+            # the half-made communicator is abandoned, not destroyed: a destroy could block behind the failure
+            handle = ctypes.c_void_p()
+            flags |= _capi.COMM_NO_RCCL
+            need_id = False
+            _capi.check("hpcla_comm_init_rank_ex",
+                        lib.hpcla_comm_init_rank_ex(ctypes.byref(handle), None, nranks, rank, flags))
+        elif why:
+            raise _capi.HPCLAError("hpcla_comm_init_rank_ex", -1, why)
     else:
         _capi.check("hpcla_comm_init_rank_ex",
                     lib.hpcla_comm_init_rank_ex(ctypes.byref(handle), None, nranks, rank, flags))
@@ -420,9 +433,34 @@ def _make_rccl(comm: AbstractComm, device_index: int = 0):
                                  f"{np.flatnonzero(verdicts == 0).tolist()}{'; ' + why if why else ''}); "
                                  "the data path stays on RCCL\n")
         if flags & _capi.COMM_NO_RCCL:
-            raise RuntimeError("no data-path transport left: RCCL is disabled (ranks share a GPU or HPCLA_NO_RCCL=1) "
-                               "and the peer windows could not be attached")
+            raise RuntimeError("no data-path transport left: RCCL is unavailable (ranks share a GPU, HPCLA_NO_RCCL=1, "
+                               "or its initialisation failed) and the peer windows could not be attached")
     return handle, False, need_id
+
+
+def _init_rccl_guarded(lib, handle, idbuf, nranks: int, rank: int, flags: int, device_index: int) -> str:
+    """``hpcla_comm_init_rank_ex`` on a helper thread with a deadline (HPCLA_RCCL_INIT_TIMEOUT_S, default 180 s):
+    ncclCommInitRank bootstraps over sockets and waits for every rank without a timeout of its own.  Returns ""
+    or the reason this rank has no RCCL communicator; a thread that never returns is left behind (daemon)."""
+    import threading
+    from . import _capi
+    limit = float(os.environ.get("HPCLA_RCCL_INIT_TIMEOUT_S", "180"))
+    box = {}
+
+    def work():
+        try:
+            lib.hpcla_set_device(int(device_index))          # the current device is a per-thread setting
+            st = lib.hpcla_comm_init_rank_ex(ctypes.byref(handle), idbuf, nranks, rank, flags)
+            box["why"] = "" if st == _capi.OK else f"status {st}: {_capi.last_error()}"
+        except Exception as exc:                             # pragma: no cover
+            box["why"] = f"{type(exc).__name__}: {exc}"
+
+    t = threading.Thread(target=work, name="hpcla-rccl-init", daemon=True)
+    t.start()
+    t.join(limit)
+    if t.is_alive():
+        return f"ncclCommInitRank did not return within {limit:.0f} s"
+    return box.get("why", "no result")
 
 
 def _probe_halo_plan(backend: "HPCBackend", halo, probe) -> str:

@@ -43,3 +43,29 @@ def test_usable_cores_respects_override(monkeypatch):
     assert bench.usable_cores() == 3
     monkeypatch.delenv("HPCLA_CPU_THREADS")
     assert 1 <= bench.usable_cores() <= 64
+
+
+def test_guarded_breakdown_watchdog_prints_the_result_and_exits():
+    """The optional transport comparison runs under a watchdog: if it hangs, the finished result line is still
+    printed (once, on the real stdout) and the process exits with the verification's code."""
+    import subprocess
+    code = ("import os, sys, time, json\n"
+            f"sys.path.insert(0, {ROOT!r})\n"
+            "import bench\n"
+            "res = {'metric': 'm', 'value': 1.0}\n"
+            "bench._guarded_breakdown(lambda: time.sleep(30), res, True, 1)\n"
+            "print('not reached')\n")
+    env = dict(os.environ, HPCLA_BENCH_BREAKDOWN_TIMEOUT_S="0.3")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60, env=env)
+    assert out.returncode == 0, out.stderr[-500:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and "not reached" not in out.stdout
+    rec = json.loads(lines[0])
+    assert rec["value"] == 1.0 and "error" in rec["step_breakdown_ms_max_over_ranks"]
+    # and the ordinary case: the comparison's record comes back, nothing is printed by the guard
+    code2 = ("import sys\n"
+             f"sys.path.insert(0, {ROOT!r})\n"
+             "import bench\n"
+             "print(bench._guarded_breakdown(lambda: {'modes': {}}, {'value': 2.0}, True, 1))\n")
+    out2 = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, timeout=60)
+    assert out2.returncode == 0 and out2.stdout.strip() == "{'modes': {}}", (out2.stdout, out2.stderr[-300:])
