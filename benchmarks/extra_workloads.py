@@ -16,8 +16,8 @@ import numpy as np
 HBM_PEAK_GBS = 8000.0
 
 
-def _sync_barrier(job):
-    job.barrier()
+def _sync_barrier(job, closing=False):
+    job.barrier(device_only=closing)      # closing bracket of a timed region: device rendezvous only (bench.py Job)
 
 
 def _measure_spmm(args, job, hp, wl, A, B, k, world, dev, setup_s, metric, workload):
@@ -29,7 +29,7 @@ def _measure_spmm(args, job, hp, wl, A, B, k, world, dev, setup_s, metric, workl
     t0 = time.perf_counter()
     for _ in range(steps):
         C = A @ B
-    _sync_barrier(job)
+    _sync_barrier(job, closing=True)
     elapsed = time.perf_counter() - t0
     elapsed = job.max(elapsed)
     ms = elapsed / steps * 1e3
@@ -107,7 +107,7 @@ def run_record(args, backend, rank, world, job):
         _sync_barrier(job)
         t0 = time.perf_counter()
         x, hist = hp.cg_fixed_iterations(A, b, iters, record_history=True, fused=fused, graph=graph)
-        _sync_barrier(job)
+        _sync_barrier(job, closing=True)
         elapsed = time.perf_counter() - t0
         elapsed = job.max(elapsed)
         n_loc, nnz_loc = A.nrows_local, A.nnz
