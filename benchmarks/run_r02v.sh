@@ -1,17 +1,10 @@
 #!/bin/bash
-set -o pipefail
-mkdir -p gpurun_out
-step() { local t=$1 log=$2; shift 2
-  timeout -k 10 "$t" "$@" > "$log" 2>&1; local rc=$?
-  if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "timed out -- stopping: $*"; tail -20 "$log"; exit $rc; fi
-  return $rc; }
-step 600 gpurun_out/r02v_pytest.log python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "spmm or SpMM" || { tail -40 gpurun_out/r02v_pytest.log; exit 1; }
-tail -2 gpurun_out/r02v_pytest.log
-OUT=gpurun_out/r02v_spmm_cstage.log; : > $OUT
-for T in 0 1 0 1; do
-  export HPCLA_SPMM_CSTAGE=$T
-  step 300 gpurun_out/r02v_tmp.log python bench.py --workload poisson2d_spmm --steps 30 --warmup 3 || { tail -5 gpurun_out/r02v_tmp.log; exit 1; }
-  echo "CSTAGE=$T poisson2d_spmm: $(tail -1 gpurun_out/r02v_tmp.log | python -c 'import sys,json; r=json.loads(sys.stdin.read()); print(r["ms_per_step"], "ms", r["value"], "GFLOP/s frac", r["roofline"]["frac"])')" | tee -a $OUT
-  HPCLA_SPMM_COLS_MULT=8 step 300 gpurun_out/r02v_tmp.log python bench.py --workload sprand_spmm --steps 20 --warmup 3 || { tail -5 gpurun_out/r02v_tmp.log; exit 1; }
-  echo "CSTAGE=$T sprand_spmm x8:  $(tail -1 gpurun_out/r02v_tmp.log | python -c 'import sys,json; r=json.loads(sys.stdin.read()); print(r["ms_per_step"], "ms frac", r["roofline"]["frac"], "gather GB/s", r["roofline"]["gather_gbs"])')" | tee -a $OUT
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+for n in 2 4; do
+  export STRESS_STEPS=$([ $n = 2 ] && echo 3000 || echo 1200)
+  timeout -k 10 500 python -c "
+import sys, importlib.util
+spec = importlib.util.spec_from_file_location('l', 'linearalgebrampi.jl_amd/launch.py'); m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+sys.exit(m.spawn_ranks(['benchmarks/stress_push_epochs.py'], $n, timeout=450))" > gpurun_out/r02v_stress_$n.log 2>&1
+  echo "ranks=$n rc=$?"; grep -E "OK|Error|assert|differ" gpurun_out/r02v_stress_$n.log | tail -10
 done
