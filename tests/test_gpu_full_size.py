@@ -6,6 +6,10 @@ size or through their pieces ("parity caveats"):
 * config 4's per-GPU share (512 x 512 x 64 planes of the 7-point Laplacian), the contract item of
   SURVEY 8d C4: EXACTLY 100 CG iterations, final ||r||_2 and x against the oracle's restatement, with the
   tolerance that is actually met written here;
+* config 5's per-GPU share at its own size: 2 097 152 rows x ~29.8 stored entries with columns uniform over
+  2^24, times B = 2^24 x 16 (2.1 GB, the gather set one GPU of the 8-GPU job sees): two columns of A*B bit-equal
+  to the SpMV of that column (the reference's definition, src/sparse.jl:2391-2413) and 4096 sampled rows
+  bit-equal to the sequential row sum;
 * the packed copy with nnz % 8 != 0, arrays followed by NaN / wrong-column guard entries, so an octet
   load that strays past the end changes the result instead of faulting (the r01q fault's tail case,
   DESIGN.md section 9).
@@ -89,6 +93,59 @@ def test_config4_share_100_cg_iterations_vs_oracle(hp, orc, gpu_backend_i32):
         assert abs(hp.norm(res) - hist[-1]) <= 1e-9 * hist[0]
     del A, b, x, res
     hp.clear_plan_cache()
+    torch.cuda.empty_cache()
+
+
+def test_config5_share_spmm_full_size(hp, orc, gpu_backend_i32):
+    """BASELINE configs[4] (SpMM, k = 16), one GPU's share at full size, B as large as the 8-GPU job's gather
+    set.  The matrix is generated on the device like the bench's (counts ~ Poisson(29.8), columns uniform)."""
+    import torch
+    dev = "cuda"
+    rows_loc, ncols, k = 2_097_152, 1 << 24, 16
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0xA11CE)
+    counts = torch.poisson(torch.full((rows_loc,), 29.8, dtype=torch.float64, device=dev), generator=gen).to(torch.int64)
+    rowptr = torch.zeros(rows_loc + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(counts, 0, out=rowptr[1:])
+    nnz = int(rowptr[-1].item())
+    assert 6.2e7 < nnz < 6.3e7
+    cols = torch.randint(0, ncols, (nnz,), generator=gen, device=dev, dtype=torch.int64)
+    rowid = torch.repeat_interleave(torch.arange(rows_loc, device=dev, dtype=torch.int64), counts)
+    key = torch.sort(rowid * ncols + cols).values
+    cols = key - rowid * ncols                                   # ascending within each row
+    del key, rowid, counts
+    vals = torch.rand(nnz, generator=gen, device=dev, dtype=torch.float64)
+    # sampled rows for the sequential check: their entries, kept before the library compresses the columns
+    rng = np.random.default_rng(11)
+    samp = np.unique(np.concatenate([np.arange(64), np.arange(rows_loc - 64, rows_loc), rng.integers(0, rows_loc, 4096)]))
+    rp_h = rowptr.cpu().numpy()
+    ent = np.concatenate([np.arange(rp_h[r], rp_h[r + 1]) for r in samp])
+    ent_d = torch.from_numpy(ent).to(dev)
+    s_cols, s_vals = cols[ent_d].cpu().numpy(), vals[ent_d].cpu().numpy()
+    A = hp.HPCSparseMatrix_local_device(rowptr, cols, vals, ncols, gpu_backend_i32, col_window=(0, ncols - 1))
+    del cols
+    Bl = torch.empty((ncols, k), dtype=torch.float64, device=dev)
+    hp._capi.call("hpcla_fill_uniform_f64", Bl.data_ptr(), 0, ncols * k, orc.SEED_X, torch.cuda.current_stream().cuda_stream)
+    B = hp.HPCMatrix_local(Bl, gpu_backend_i32)
+    C = hp.spmm(A, B)
+    torch.cuda.synchronize()
+    assert tuple(C.A.shape) == (rows_loc, k)
+    # (a) the reference's definition: column j of A*B is the SpMV of column j, bit for bit
+    for j in (3, 12):
+        yj = A @ B[:, j]
+        assert torch.equal(C.A[:, j].contiguous(), yj.v), f"column {j} differs from A*B[:, {j}]"
+    # (b) sequential row sums in stored order (multiply, then add: src/sparse.jl:2060-2064) on the sampled rows
+    b_rows = Bl[torch.from_numpy(s_cols).to(dev)].cpu().numpy()             # B row of every sampled entry
+    got = C.A[torch.from_numpy(samp).to(dev)].cpu().numpy()
+    pos = 0
+    for i, r in enumerate(samp):
+        acc = np.zeros(k)
+        for e in range(int(rp_h[r + 1] - rp_h[r])):
+            acc = acc + s_vals[pos] * b_rows[pos]
+            pos += 1
+        assert np.array_equal(got[i], acc), f"row {r}"
+    del A, B, C, Bl, vals
+    hp.clear_plan_cache(); hp.clear_spmm_cache()
     torch.cuda.empty_cache()
 
 
