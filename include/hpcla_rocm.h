@@ -242,8 +242,8 @@ int hpcla_comm_init_rank_ex(hpcla_comm_t **comm, const uint8_t *id_host, int nra
 int hpcla_comm_rank(const hpcla_comm_t *comm, int *rank);
 int hpcla_comm_size(const hpcla_comm_t *comm, int *nranks);
 int hpcla_comm_destroy(hpcla_comm_t *comm);
-/* in-place all-reduce of `count` doubles on `stream`: op 0 = sum, 1 = max
- * (comm_allreduce(comm, x, + | max), src/backends.jl:264-277). */
+/* in-place all-reduce of `count` doubles on `stream`: op 0 = sum, 1 = max, 2 = product
+ * (comm_allreduce(comm, x, + | max | *), src/backends.jl:264-277). */
 int hpcla_allreduce_f64(hpcla_comm_t *comm, double *buf, int64_t count, int op, void *stream);
 
 /* ---- peer windows: one-sided transport over xGMI for the ranks of ONE node (csrc/window.hip) --------
@@ -434,6 +434,8 @@ int hpcla_maxval_f64(hpcla_comm_t *comm, const double *x, int64_t n, int negate,
                      void *stream);
 /* sum(v) (src/vectors.jl:838-845): out = sum of all elements over all ranks */
 int hpcla_sum_f64(hpcla_comm_t *comm, const double *x, int64_t n, double *out_dev, void *work, void *stream);
+/* prod(v), src/vectors.jl:853-858 (an empty local part contributes 1) */
+int hpcla_prod_f64(hpcla_comm_t *comm, const double *x, int64_t n, double *out_dev, void *work, void *stream);
 /* general p-norm, p > 0 finite: out = sum |x_i|^p over all ranks; the caller takes the 1/p power
  * (norm(v, p), src/vectors.jl:774-779) */
 int hpcla_powsum_f64(hpcla_comm_t *comm, const double *x, int64_t n, double p, double *out_dev, void *work,

@@ -292,6 +292,26 @@ function LinearAlgebra.norm(v::HPCVector{T,B}, p::Real=2) where {T<:Float64,B<:R
     end
 end
 
+# sum / prod / maximum / minimum (src/vectors.jl:815-858): same two-stage device reduction + scalar all-reduce
+function _reduce_scalar(sym::Symbol, v::HPCVector, negate::Int=0)
+    work, out = _scratch(); c = _rccl(v.backend.comm); n = length(v.v)
+    if sym === :sum
+        _check(@ccall(LIB.hpcla_sum_f64(c::Ptr{Cvoid}, _ptr(v.v)::Ptr{Cvoid}, n::Int64, _ptr(out)::Ptr{Cvoid},
+               _ptr(work)::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_sum_f64")
+    elseif sym === :prod
+        _check(@ccall(LIB.hpcla_prod_f64(c::Ptr{Cvoid}, _ptr(v.v)::Ptr{Cvoid}, n::Int64, _ptr(out)::Ptr{Cvoid},
+               _ptr(work)::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_prod_f64")
+    else
+        _check(@ccall(LIB.hpcla_maxval_f64(c::Ptr{Cvoid}, _ptr(v.v)::Ptr{Cvoid}, n::Int64, negate::Cint, _ptr(out)::Ptr{Cvoid},
+               _ptr(work)::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_maxval_f64")
+    end
+    return Array(out)[1]
+end
+Base.sum(v::HPCVector{T,B}) where {T<:Float64,B<:ROCBackend} = _reduce_scalar(:sum, v)
+Base.prod(v::HPCVector{T,B}) where {T<:Float64,B<:ROCBackend} = _reduce_scalar(:prod, v)
+Base.maximum(v::HPCVector{T,B}) where {T<:Float64,B<:ROCBackend} = _reduce_scalar(:max, v, 0)
+Base.minimum(v::HPCVector{T,B}) where {T<:Float64,B<:ROCBackend} = -_reduce_scalar(:max, v, 1)      # min x = -max(-x)
+
 # ---- A * B, B::HPCMatrix  (replaces the column loop of src/sparse.jl:2391-2413) ---------------------------
 # Julia's Matrix is column-major; the kernel's fast layout is row-major (one 128-byte line per B row at
 # k = 16), so B is converted once with hpcla_transpose_f64 and C converted back.

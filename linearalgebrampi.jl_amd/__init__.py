@@ -22,7 +22,7 @@ from .backends import (AbstractComm, AbstractDevice, CommSerial, CommTorch, Devi
                        cpu_version, eltype_backend, indextype_backend)
 from .partition import (compute_partition_hash, compute_structural_hash, owner_of,
                         uniform_partition)
-from .vectors import HPCVector, HPCVector_local, cg_direction_, cg_residual_, cg_update_, dot, maximum, minimum, norm, vsum
+from .vectors import HPCVector, HPCVector_local, cg_direction_, cg_residual_, cg_update_, dot, maximum, minimum, norm, prod, vsum
 from .sparse import (HPCSparseMatrix, HPCSparseMatrix_from_global, HPCSparseMatrix_local,
                      HPCSparseMatrix_local_device,
                      HostVectorPlan, VectorPlan, build_host_vector_plan, cache_sizes,

@@ -124,6 +124,7 @@ _SIGNATURES = {
     "hpcla_amax_f64": [_vp, _vp, _i64, _vp, _vp, _vp],
     "hpcla_maxval_f64": [_vp, _vp, _i64, _i32, _vp, _vp, _vp],
     "hpcla_sum_f64": [_vp, _vp, _i64, _vp, _vp, _vp],
+    "hpcla_prod_f64": [_vp, _vp, _i64, _vp, _vp, _vp],
     "hpcla_powsum_f64": [_vp, _vp, _i64, _f64, _vp, _vp, _vp],
     "hpcla_axpy_f64": [_f64, _vp, _vp, _vp, _vp, _i64, _vp],
     "hpcla_xpay_f64": [_vp, _f64, _vp, _vp, _vp, _i64, _vp],

@@ -105,7 +105,7 @@ int allreduce_on(hpcla_comm_t *comm, double *buf, int64_t count, int op, void *s
 {
     if (!comm) return set_error(HPCLA_ERR_INVALID, "allreduce: null communicator");
     if (count < 0) return set_error(HPCLA_ERR_INVALID, "allreduce: negative count");
-    if (op != 0 && op != 1) return set_error(HPCLA_ERR_INVALID, "allreduce: op must be 0 or 1");
+    if (op < 0 || op > 2) return set_error(HPCLA_ERR_INVALID, "allreduce: op must be 0 (sum), 1 (max) or 2 (product)");
     if (count == 0) return HPCLA_OK;
     if (comm->nranks == 1 && !comm->nccl) return HPCLA_OK;
     if (!buf) return set_error(HPCLA_ERR_INVALID, "allreduce: null buffer");
@@ -115,7 +115,7 @@ int allreduce_on(hpcla_comm_t *comm, double *buf, int64_t count, int op, void *s
     if (!comm->nccl)
         return set_error(HPCLA_ERR_INVALID, "allreduce: communicator has neither RCCL nor an attached window");
     HPCLA_CHECK_RCCL(g_rccl.AllReduce(buf, buf, (size_t)count, ncclDouble,
-                                      op == 0 ? ncclSum : ncclMax, comm->nccl, as_stream(stream)));
+                                      op == 0 ? ncclSum : (op == 1 ? ncclMax : ncclProd), comm->nccl, as_stream(stream)));
     return HPCLA_OK;
 }
 

@@ -13,8 +13,9 @@ namespace hpcla {
 constexpr int RT = 256;            // threads per reduction block
 constexpr int MAX_PARTIALS = 2048; // upper bound of stage-1 blocks
 
-enum RedOp { RED_DOT = 0, RED_SQ = 1, RED_ABS = 2, RED_MAX = 3, RED_SUM = 4, RED_POW = 5, RED_MAXV = 6 };
-// RED_MAX: max |x| (identity 0);  RED_MAXV: max x (identity -inf; min x = -max(-x) with negate = 1)
+enum RedOp { RED_DOT = 0, RED_SQ = 1, RED_ABS = 2, RED_MAX = 3, RED_SUM = 4, RED_POW = 5, RED_MAXV = 6, RED_PROD = 7 };
+// RED_MAX: max |x| (identity 0);  RED_MAXV: max x (identity -inf; min x = -max(-x) with negate = 1);
+// RED_PROD: product (identity 1)
 
 template <int OP>
 __device__ __forceinline__ double red_map(double a, double b, double p = 0.0)
@@ -23,13 +24,14 @@ __device__ __forceinline__ double red_map(double a, double b, double p = 0.0)
     if (OP == RED_MAXV) return p != 0.0 ? -a : a;          // p doubles as the "negate" flag
     if (OP == RED_DOT) return a * b;
     if (OP == RED_SQ) return a * a;
-    if (OP == RED_SUM) return a;
+    if (OP == RED_SUM || OP == RED_PROD) return a;
     return fabs(a);
 }
 template <int OP>
 __device__ __forceinline__ double red_comb(double s, double v)
 {
     if (OP == RED_MAX || OP == RED_MAXV) return v > s ? v : s;
+    if (OP == RED_PROD) return s * v;
     return s + v;
 }
 
@@ -57,7 +59,7 @@ __global__ __launch_bounds__(RT) void reduce_stage1(const double *__restrict__ x
                                                     double *__restrict__ partial, double p = 0.0)
 {
     // 16-byte loads on the aligned body, scalar tail
-    double acc = OP == RED_MAXV ? -__builtin_huge_val() : 0.0;
+    double acc = OP == RED_MAXV ? -__builtin_huge_val() : (OP == RED_PROD ? 1.0 : 0.0);
     const int64_t n2 = n / 2;
     const double2 *x2 = reinterpret_cast<const double2 *>(x);
     const double2 *y2 = reinterpret_cast<const double2 *>(OP == RED_DOT ? y : x);
@@ -80,7 +82,7 @@ template <int OP>
 __global__ __launch_bounds__(RT) void reduce_stage2(const double *__restrict__ partial, int np,
                                                     double *__restrict__ out)
 {
-    double acc = OP == RED_MAXV ? -__builtin_huge_val() : 0.0;
+    double acc = OP == RED_MAXV ? -__builtin_huge_val() : (OP == RED_PROD ? 1.0 : 0.0);
     for (int i = threadIdx.x; i < np; i += RT) acc = red_comb<OP>(acc, partial[i]);
     const double r = block_reduce<OP>(acc);
     if (threadIdx.x == 0) out[0] = r;
@@ -119,7 +121,7 @@ static int reduce_impl(hpcla_comm_t *comm, const double *x, const double *y, int
         reduce_stage2<OP == RED_POW ? RED_SUM : OP><<<1, RT, 0, s>>>(partial, g, out_dev);
         HPCLA_CHECK_LAUNCH();
     }
-    if (comm) return allreduce_on(comm, out_dev, 1, (OP == RED_MAX || OP == RED_MAXV) ? 1 : 0, stream);
+    if (comm) return allreduce_on(comm, out_dev, 1, (OP == RED_MAX || OP == RED_MAXV) ? 1 : (OP == RED_PROD ? 2 : 0), stream);
     return HPCLA_OK;
 }
 
@@ -380,6 +382,13 @@ HPCLA_API int hpcla_sum_f64(hpcla_comm_t *comm, const double *x, int64_t n, doub
                             void *stream)
 {
     return reduce_impl<RED_SUM>(comm, x, nullptr, n, out_dev, work, stream);
+}
+
+// prod(v) (src/vectors.jl:853-858; an empty local part contributes one(T))
+HPCLA_API int hpcla_prod_f64(hpcla_comm_t *comm, const double *x, int64_t n, double *out_dev, void *work,
+                             void *stream)
+{
+    return reduce_impl<RED_PROD>(comm, x, nullptr, n, out_dev, work, stream);
 }
 
 HPCLA_API int hpcla_powsum_f64(hpcla_comm_t *comm, const double *x, int64_t n, double p, double *out_dev,

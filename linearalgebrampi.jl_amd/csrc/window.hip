@@ -322,7 +322,8 @@ __global__ __launch_bounds__(64) void window_allreduce_kernel(uint64_t *const *_
     __syncthreads();
     if (j < count) {
         double acc = s_val[0][j];
-        for (int r = 1; r < nranks; ++r) acc = op == 0 ? acc + s_val[r][j] : (s_val[r][j] > acc ? s_val[r][j] : acc);
+        for (int r = 1; r < nranks; ++r)
+            acc = op == 0 ? acc + s_val[r][j] : (op == 2 ? acc * s_val[r][j] : (s_val[r][j] > acc ? s_val[r][j] : acc));
         buf[j] = acc;
     }
     if (j == 0) __hip_atomic_store(done, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every lane has read it (barrier above)

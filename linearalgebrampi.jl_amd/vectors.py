@@ -264,6 +264,13 @@ def vsum(v: HPCVector, out=None):
     return r if out is not None else float(r.item())
 
 
+def prod(v: HPCVector) -> float:
+    """``prod(v)`` (src/vectors.jl:853-858): local product (1 for an empty part), then an all-reduce with ``*``."""
+    work, scal = _Scratch.get(v.v.device)
+    _capi.call("hpcla_prod_f64", v.backend.rccl, dptr(v.v), v.local_length, dptr(scal[:1]), dptr(work), current_stream_ptr())
+    return float(scal[:1].item())
+
+
 def _maxval(v: HPCVector, negate: int) -> float:
     work, scal = _Scratch.get(v.v.device)
     _capi.call("hpcla_maxval_f64", v.backend.rccl, dptr(v.v), v.local_length, negate, dptr(scal[:1]), dptr(work),

@@ -156,6 +156,9 @@ def main():
             n_ref = orc.norm([xg])
             assert abs(d - d_ref) <= 1e-12 * abs(d_ref), (tag, name, d, d_ref)
             assert abs(nr - n_ref) <= 1e-12 * abs(n_ref), (tag, name, nr, n_ref)
+            pg = 1.0 + 1e-3 * xg                               # prod: the all-reduce with op = product
+            pr = hp.prod(hp.HPCVector.from_global(pg, backend, partition=rp))
+            assert abs(pr - np.exp(np.sum(np.log(pg)))) <= 1e-9 * abs(pr), (tag, name, pr)
             alld = allgather_f64(np.array([d, nr]))
             assert all(alld[2 * r] == d and alld[2 * r + 1] == nr for r in range(nranks)), \
                 f"{tag} {name}: dot/norm not uniform across ranks: {alld}"

@@ -357,6 +357,12 @@ def test_dot_norm_golden_and_random(hp, orc, golden, gpu_backend_i32):
         assert abs(hp.vsum(xv) - xg.sum()) <= RTOL_RED * np.abs(xg).sum()           # src/vectors.jl:838-845
         want3 = float(np.sum(np.abs(xg) ** 3.0)) ** (1.0 / 3.0)                      # general p (src/vectors.jl:774-779)
         assert abs(hp.norm(xv, 3) - want3) <= 1e-11 * want3
+        pg = 1.0 + 1e-3 * xg                                                          # prod(v), src/vectors.jl:853-858
+        want_p = float(np.exp(np.sum(np.log(pg)))) if n > 64 else float(np.prod(pg))
+        assert abs(hp.prod(hp.HPCVector.from_global(pg, b)) - want_p) <= (1e-9 if n > 64 else RTOL_RED) * abs(want_p)
+    # the reference's own reductions case (test/test_vector_multiplication.jl:198-225): x = 1..8
+    r8 = hp.HPCVector.from_global(np.arange(1.0, 9.0), b)
+    assert hp.vsum(r8) == 36.0 and hp.prod(r8) == 40320.0 and hp.maximum(r8) == 8.0 and hp.minimum(r8) == 1.0
     # deterministic: two runs give the same bits
     assert hp.dot(xv, yv) == hp.dot(xv, yv)
 
