@@ -408,6 +408,16 @@ HPCLA_API int hpcla_halo_plan_create(hpcla_halo_plan_t **plan, hpcla_comm_t *com
     // name an RCCL mode), else a plain allocation that RCCL receives into
     if (comm->win_attached && (n_send > 0 || n_recv > 0) && (halo_want_window() || !comm->nccl)) {
         int rcw = push_plan_alloc(p);
+        if (rcw && comm->nccl) {
+            // no peer-mappable window to be had: this plan stays an RCCL plan (it exports an empty descriptor, so
+            // the collective attach step keeps every rank's copy of it on RCCL)
+            push_free(p);
+            rcw = HPCLA_OK;
+            if (p->n_ghost > 0) {
+                HALO_HIP(hipMalloc((void **)&p->ghost, p->n_ghost * width * sizeof(double)));
+                HALO_HIP(hipMemset(p->ghost, 0, p->n_ghost * width * sizeof(double)));
+            }
+        }
         if (rcw) { halo_free(p); return rcw; }
     } else if (p->n_ghost > 0) {
         HALO_HIP(hipMalloc((void **)&p->ghost, p->n_ghost * width * sizeof(double)));

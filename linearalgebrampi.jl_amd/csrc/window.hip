@@ -76,7 +76,17 @@ int window_alloc(void **p, size_t bytes, bool uncached)
         return !e ? -1 : (e[0] == 'u' ? 1 : 0);
     }();
     if (forced >= 0) uncached = forced == 1;
-    HPCLA_CHECK_HIP(hipExtMallocWithFlags(p, bytes, uncached ? hipDeviceMallocUncached : hipDeviceMallocFinegrained));
+    // either flavour is correct for either use (they differ in speed: DESIGN.md section 4); if the preferred one
+    // cannot be had on this system, take the other before giving the transport up
+    hipError_t ea = hipExtMallocWithFlags(p, bytes, uncached ? hipDeviceMallocUncached : hipDeviceMallocFinegrained);
+    if (ea != hipSuccess) {
+        (void)hipGetLastError();
+        ea = hipExtMallocWithFlags(p, bytes, uncached ? hipDeviceMallocFinegrained : hipDeviceMallocUncached);
+    }
+    if (ea != hipSuccess) {
+        *p = nullptr;
+        return set_error(HPCLA_ERR_HIP, "window allocation of %zu bytes failed: %s", bytes, hipGetErrorString(ea));
+    }
     hipError_t e = hipMemset(*p, 0, bytes);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
