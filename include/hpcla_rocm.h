@@ -254,7 +254,9 @@ int hpcla_allreduce_f64(hpcla_comm_t *comm, double *buf, int64_t count, int op, 
  * Bootstrap is the unique-id pattern again (ext/HPCLinearAlgebraCUDAExt.jl:411-443): every rank EXPORTS a
  * HPCLA_WINDOW_DESC_BYTES descriptor, the host runtime all-gathers them (MPI.Allgather /
  * torch.distributed), every rank ATTACHES.  All ranks must be on one node (descriptor bytes 64..71 hold a
- * node identity the host layer compares before attaching).
+ * node identity the host layer compares before attaching; bytes 112..119 the identity of the GPU that holds
+ * the window: attach refuses a peer whose device the runtime reports as not peer-accessible, instead of
+ * mapping memory that would fault on the first store).
  *   communicator window: all-reduce of <= 8 doubles in ONE kernel (each rank stores its partial into its
  *     slot of every window, then sums its own window's slots in rank order: the same bits on every rank);
  *   halo plan window:    see hpcla_halo_plan_export below. */

@@ -36,7 +36,8 @@ struct WindowDesc {                            // HPCLA_WINDOW_DESC_BYTES, excha
     uint32_t nbuf;                             // halo: 1 or 2 ghost buffers
     uint32_t width;
     uint32_t n_flags, n_acks;
-    uint8_t pad[16];
+    uint64_t device_id;                        // identity of the GPU holding the window (hpcla_device_identity): peer-access check
+    uint8_t pad[8];
 };
 static_assert(sizeof(WindowDesc) == HPCLA_WINDOW_DESC_BYTES, "WindowDesc size");
 

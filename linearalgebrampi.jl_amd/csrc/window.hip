@@ -63,6 +63,12 @@ int64_t spin_timeout_ticks()
     return ticks;
 }
 
+static uint64_t device_identity_of(int device)
+{
+    uint64_t id = 0;
+    return hpcla_device_identity(device, &id) == HPCLA_OK ? id : 0;
+}
+
 int window_alloc(void **p, size_t bytes, bool uncached)
 {
     // Memory that PEERS store into while kernels of this device read it.  Control lines and vector ghost
@@ -108,6 +114,21 @@ int window_open(const WindowDesc &d, int peer_rank, int my_rank, void *my_base, 
     if (d.host_id != host_identity())
         return set_error(HPCLA_ERR_UNSUPPORTED, "window_open: rank %d is on another node (push transport is per node)",
                          peer_rank);
+    // The peer's GPU, if this process can see it: refuse the mapping when the runtime reports no peer access
+    // between the two devices (stores through such a mapping would fault the GPU instead of returning an error).
+    // An invisible peer device (HIP_VISIBLE_DEVICES per rank) cannot be asked about; the IPC open then decides.
+    int cur = 0, ndev = 0;
+    if (d.device_id != 0 && hipGetDevice(&cur) == hipSuccess && hipGetDeviceCount(&ndev) == hipSuccess &&
+        d.device_id != device_identity_of(cur)) {
+        for (int dev = 0; dev < ndev; ++dev) {
+            if (dev == cur || device_identity_of(dev) != d.device_id) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, cur, dev) == hipSuccess && !can)
+                return set_error(HPCLA_ERR_UNSUPPORTED, "window_open: device %d has no peer access to rank %d's device %d",
+                                 cur, peer_rank, dev);
+            break;
+        }
+    }
     hipIpcMemHandle_t h;
     static_assert(sizeof(h) == 64, "hipIpcMemHandle_t size");
     memcpy(&h, d.ipc, sizeof(h));
@@ -133,6 +154,8 @@ static void fill_desc(WindowDesc *d, void *win, size_t bytes)
     d->host_id = host_identity();
     d->pid = (uint64_t)getpid();
     d->bytes = bytes;
+    int cur = 0;
+    if (hipGetDevice(&cur) == hipSuccess) d->device_id = device_identity_of(cur);
     if (win) {
         hipIpcMemHandle_t h;
         if (hipIpcGetMemHandle(&h, win) == hipSuccess) memcpy(d->ipc, &h, sizeof(h));
