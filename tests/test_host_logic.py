@@ -250,3 +250,34 @@ def test_whole_slice_lists_reproduce_the_gathered_rows(hp, orc, nranks):
             segs.append(Bg[xp[src]:xp[src + 1]][idx])
         ext = np.concatenate([Bg[xp[r]:xp[r + 1]]] + segs)
         np.testing.assert_array_equal(ext[cmap], Bg[cis[r]])
+
+
+def test_rccl_init_guard_reports_failure_and_deadline(hp, monkeypatch):
+    """backends._init_rccl_guarded: ncclCommInitRank runs on a helper thread with a deadline; a failing or a
+    hanging initialisation becomes a REASON (all-gathered by the caller, who then continues on the peer
+    windows alone) instead of an exception on some ranks or a hang."""
+    import ctypes
+    import time
+    from hpcla_amd import backends
+
+    class FakeLib:
+        def __init__(self, status, delay=0.0):
+            self.status, self.delay, self.device = status, delay, None
+
+        def hpcla_set_device(self, d):
+            self.device = d
+            return 0
+
+        def hpcla_comm_init_rank_ex(self, handle_ref, idbuf, nranks, rank, flags):
+            time.sleep(self.delay)
+            return self.status
+
+    h = ctypes.c_void_p()
+    ok = FakeLib(0)
+    assert backends._init_rccl_guarded(ok, h, None, 2, 0, 0, 3) == "" and ok.device == 3
+    why = backends._init_rccl_guarded(FakeLib(-3), h, None, 2, 0, 0, 0)
+    assert why.startswith("status -3")
+    monkeypatch.setenv("HPCLA_RCCL_INIT_TIMEOUT_S", "0.2")
+    t0 = time.perf_counter()
+    why = backends._init_rccl_guarded(FakeLib(0, delay=5.0), h, None, 2, 0, 0, 0)
+    assert "did not return" in why and time.perf_counter() - t0 < 3.0
