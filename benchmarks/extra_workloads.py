@@ -119,12 +119,12 @@ def run_record(args, backend, rank, world, job):
             "n_gpus": world, "steps": iters, "warmup": args.warmup, "ms_per_step": round(ms_iter, 4),
             "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"poisson3d 7-pt {N}x{N}x{planes} per GPU ({N}x{N}x{nz} global), {iters} CG iterations, "
-                                   f"{'fused SpMV+dot / update' if fused else 'one kernel per reference operator'}"
+                                   f"{'fused: SpMV+p.Ap, r-update+r.r, x/p-update' if fused else 'one kernel per reference operator'}"
                                    f"{', HIP graph replay' if graph else ''}",
                        "global_rows": n_glob, "nnz_per_gpu": nnz_loc},
             "roofline": {"bound": "hbm", "achieved": round(b_iter / (ms_iter * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(b_iter / (ms_iter * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
-                         "algorithmic_bytes_per_iteration": b_iter, "note": "whole iteration (SpMV + 2 reductions + 3 updates), wall clock"},
+                         "algorithmic_bytes_per_iteration": b_iter, "note": "whole iteration (SpMV, 2 reductions, the x / r / p updates), wall clock; bytes = the textbook unfused count of SURVEY 8d (SpMV + 96 n), the fused form moves SpMV + 64 n"},
             "residual_first": hist[0], "residual_last": hist[-1], "setup_s": round(setup_s, 2),
             "exchange_timed_out": bool(job.max(1.0 if hp.get_vector_plan(A, b).timed_out() else 0.0)),
         }
