@@ -124,7 +124,10 @@ def run_record(args, backend, rank, world, job):
                        "global_rows": n_glob, "nnz_per_gpu": nnz_loc},
             "roofline": {"bound": "hbm", "achieved": round(b_iter / (ms_iter * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(b_iter / (ms_iter * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
-                         "algorithmic_bytes_per_iteration": b_iter, "note": "whole iteration (SpMV, 2 reductions, the x / r / p updates), wall clock; bytes = the textbook unfused count of SURVEY 8d (SpMV + 96 n), the fused form moves SpMV + 64 n"},
+                         "algorithmic_bytes_per_iteration": b_iter,
+                         "moved_bytes_per_iteration": b_spmv + (64 if fused else 96) * n_loc,
+                         "moved_gbs": round((b_spmv + (64 if fused else 96) * n_loc) / (ms_iter * 1e-3) / 1e9, 1),
+                         "note": "whole iteration (SpMV, 2 reductions, the x / r / p updates), wall clock; bytes = the textbook unfused count of SURVEY 8d (SpMV + 96 n), the fused form moves SpMV + 64 n"},
             "residual_first": hist[0], "residual_last": hist[-1], "setup_s": round(setup_s, 2),
             "exchange_timed_out": bool(job.max(1.0 if hp.get_vector_plan(A, b).timed_out() else 0.0)),
         }
