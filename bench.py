@@ -182,6 +182,11 @@ class Job:
     def sum(self, v):
         return self._reduce(v, self.dist.ReduceOp.SUM if self.world > 1 else None)
 
+    def agree(self, flag) -> bool:
+        """Collective yes/no (every rank must say yes): budget decisions are taken by all ranks together, so no
+        rank starts a collective stage another rank has skipped."""
+        return bool(self.min(1.0 if flag else 0.0))
+
 
 HALO_MODES = {"serial": 0, "overlap": 1, "push": 2}
 
@@ -275,14 +280,13 @@ class Outcome:
         self.result, self.verified, self.breakdown_fn = result, verified, breakdown_fn
 
 
-def _guarded_breakdown(fn, result, verified, stdout_fd):
+def _guarded_breakdown(fn, result, verified, stdout_fd, limit):
     """Run the transport comparison under a watchdog.  It exercises orderings the timed loop did not use (the
-    RCCL send/recv modes next to the peer-window push); if it does not come back within
-    HPCLA_BENCH_BREAKDOWN_TIMEOUT_S (default 240 s) every rank gives up on its own timer: rank 0 prints the
-    finished result line without the comparison and the process exits -- an optional diagnostic must not be
-    able to cost the measurement."""
+    RCCL send/recv modes next to the peer-window push); if it does not come back within `limit` seconds (what is
+    left of the run's budget, at most 90 s -- benchmarks/budget.py; HPCLA_BENCH_BREAKDOWN_TIMEOUT_S overrides)
+    every rank gives up on its own timer: rank 0 prints the finished result line without the comparison and the
+    process exits -- an optional diagnostic must not be able to cost the measurement."""
     import threading
-    limit = float(os.environ.get("HPCLA_BENCH_BREAKDOWN_TIMEOUT_S", "240"))
     lock, state = threading.Lock(), {"over": False}
 
     def bail():
@@ -312,6 +316,15 @@ def _guarded_breakdown(fn, result, verified, stdout_fd):
     return bd
 
 
+def _load_budget():
+    """benchmarks/budget.py loaded BY PATH (stdlib only; the launching parent imports nothing else)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("hpcla_budget", os.path.join(ROOT, "benchmarks", "budget.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def _load_launcher():
     """linearalgebrampi.jl_amd/launch.py loaded BY PATH: importing the package would import torch, and the
     launching parent must never touch the GPU runtime."""
@@ -325,20 +338,26 @@ def _load_launcher():
 def main():
     args = parse()
     launch = _load_launcher()
+    budget = _load_budget().Budget()                 # origin: HPCLA_BENCH_T0 if a parent set it, else now
+    budget.export_guards()                           # the ranks inherit the origin and the derived guard defaults
     if args.gpus > 1 and not launch.already_launched():
         # `python bench.py --gpus N` with no launcher around it: start the N ranks ourselves (the reference's
         # distributed entry does the same with mpiexec, test/runtests.jl:16-35).  Nothing GPU-related has
         # been imported in this process.
         sys.stderr.write(f"bench: launching {args.gpus} ranks (one process per GPU)\n")
+        # the launcher's own limit is derived from the driver's (outer - 30 s), never larger than it
         raise SystemExit(launch.spawn_ranks([os.path.abspath(__file__)] + sys.argv[1:], args.gpus,
-                                            timeout=float(os.environ.get("HPCLA_BENCH_TIMEOUT_S", "1500"))))
+                                            timeout=float(os.environ.get("HPCLA_BENCH_TIMEOUT_S", budget.launcher_timeout()))))
     with _StdoutToStderr() as redirected:
-        out = _run(args)
+        out = _run(args, budget)
         if isinstance(out, Outcome):
             if out.breakdown_fn is not None:
-                bd = _guarded_breakdown(out.breakdown_fn, out.result, out.verified, redirected.saved)
+                limit = float(os.environ.get("HPCLA_BENCH_BREAKDOWN_TIMEOUT_S", budget.comparison_timeout()))
+                budget.stage(f"transport comparison (watchdog {limit:.0f} s)")
+                bd = _guarded_breakdown(out.breakdown_fn, out.result, out.verified, redirected.saved, limit)
                 if out.result is not None:
                     out.result["step_breakdown_ms_max_over_ranks"] = bd
+                budget.stage("transport comparison done")
             out = (json.dumps(out.result) if out.result is not None else None), out.verified
     line, verified = out if isinstance(out, tuple) else (out, True)
     if line is not None:
@@ -468,7 +487,7 @@ class PoissonRun:
         self.A = self.x = self.y = self.plan = None
 
 
-def strong_scaling_record(hp, wl, job, backend, args, world, rank):
+def strong_scaling_record(hp, wl, job, backend, args, world, rank, budget=None):
     """BASELINE configs[2]: ONE 8192^2 Poisson problem row-partitioned over all ranks (strong scaling), and --
     on rank 0 alone, same box, same run -- the whole problem on one GPU, so the record carries its own
     speed-up.  The N = 1 job reports just the single-GPU point."""
@@ -491,7 +510,10 @@ def strong_scaling_record(hp, wl, job, backend, args, world, rank):
     run.release()
     hp.clear_plan_cache()
     torch.cuda.empty_cache()
-    if world > 1:
+    if world > 1 and budget is not None and not job.agree(budget.allows("strong_scaling_n1")):
+        rec["n1_ms_per_step_rank0_alone"] = rec["speedup_vs_n1"] = None
+        rec["n1_skipped"] = "budget"
+    elif world > 1:
         n1 = None
         if rank == 0:                                # the other ranks wait at the barrier below
             b1 = hp.backend_rocm_serial(np.float64, np.int32 if args.index == "i32" else np.int64,
@@ -509,7 +531,37 @@ def strong_scaling_record(hp, wl, job, backend, args, world, rank):
     return rec, verified
 
 
-def _run(args):
+def int64_record(hp, wl, job, args, N, steps, warmup):
+    """The headline matrix with Int64 indices -- the reference's default `Ti = Int` (src/backends.jl:348, 369) -- as a
+    driver-timed sub-record (N = 1): same kernel template, 16 B per stored entry instead of 12; its own algorithmic
+    byte count (1 744 568 328 B at 4096^2), never mixed with the Int32 headline."""
+    import copy
+    torch = job.torch
+    a2 = copy.copy(args)
+    a2.index = "i64"
+    b64 = hp.backend_rocm_serial(np.float64, np.int64, device_index=torch.cuda.current_device())
+    run = PoissonRun(hp, wl, job, b64, a2, N, False, 1, 0)
+    el, launch_ms = run.time_steps(steps, warmup)
+    ms = el / steps * 1e3
+    from benchmarks.extra_workloads import stored_traffic
+    traffic, traffic_source = stored_traffic("poisson2d_spmv_int64", N == 4096)
+    rec = {"workload": f"poisson2d 5-pt {N}x{N}, CSR SpMV y=A*x, index=i64 (reference default Ti=Int)",
+           "steps": steps, "warmup": warmup, "ms_per_step": round(ms, 5),
+           "gflops": round(2.0 * run.nnz_loc / (ms * 1e-3) / 1e9, 2),
+           "roofline": {"bound": "hbm", "achieved": round(run.b_alg_loc / (launch_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(run.b_alg_loc / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        "traffic": traffic, "traffic_source": traffic_source,
+                        "kernel": "hpcla::spmv_rowblock_quad_kernel<long, false, false>",
+                        "algorithmic_bytes_per_launch": run.b_alg_loc, "launch_ms_timed_region": round(launch_ms, 5)},
+           "verified_vs_closed_form": run.verified}
+    ok = run.verified
+    run.release()
+    hp.clear_plan_cache()
+    torch.cuda.empty_cache()
+    return rec, ok
+
+
+def _run(args, budget):
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -523,6 +575,7 @@ def _run(args):
         raise SystemExit(f"bench.py --gpus {world}: only {ndev} GPU(s) visible (HPCLA_ALLOW_SHARED_GPU=1 lets ranks "
                          "share a device for a functional rehearsal; its timings mean nothing)")
     torch.cuda.set_device(local_rank % ndev)
+    budget.stage(f"rank {rank}/{world}: torch imported, device set")
 
     import hpcla_amd as hp
     from hpcla_amd import workloads as wl
@@ -538,6 +591,8 @@ def _run(args):
         backend = hp.backend_rocm_serial(np.float64, Ti, device_index=torch.cuda.current_device())
     job = Job(torch, dist, world, rank)
     job.attach_data_path(hp, backend)
+    stage = budget.stage if rank == 0 else (lambda _name: None)
+    stage(f"backend ready (rccl={'yes' if backend.has_rccl else 'no'}, peer windows={'yes' if backend.peer_windows else 'no'})")
 
     if args.workload not in ("poisson2d", "poisson2d_strong"):
         from benchmarks import extra_workloads          # configs 4/5: separate harness
@@ -550,7 +605,9 @@ def _run(args):
     A, x, y, plan = run.A, run.x, run.y, run.plan
     verified = run.verified
     nnz_loc, nrows_loc, b_alg_loc = run.nnz_loc, run.nrows_loc, run.b_alg_loc
+    stage("headline problem built and verified")
     elapsed, timed_region_launch_ms = run.time_steps(args.steps, args.warmup)
+    stage("headline timed")
 
     # ---- per-launch duration with HIP events on the launch stream (cross-check of roofline.achieved) ----
     reps = min(max(args.steps, 20), 200)
@@ -579,7 +636,7 @@ def _run(args):
 
     # ---- opt-in packed copy (3 B per stored entry instead of 12; same bits), reported separately --------
     packed = None
-    if not args.no_packed and world == 1:        # an optional extra must not stand between an N > 1 run and its result line
+    if not args.no_packed and world == 1 and budget.allows("packed"):   # an optional extra must not stand between an N > 1 run and its result line
         if A.enable_packed(x):
             hp.mul_(y, A, x)
             torch.cuda.synchronize()
@@ -641,7 +698,14 @@ def _run(args):
         "verified_vs_closed_form": verified, "exchange_timed_out": timed_out, "setup_s": round(run.setup_s, 2),
         "packed_csr_opt_in": packed,
     }
-    if world == 1 and not args.no_cpu_baseline:      # the contract: rank 0 at N = 1 only
+    if world > 1:
+        # the strong-scaling speed-up (BASELINE: ">= 6x at 8 GPUs over 1") is filled in below; placed at the TOP level
+        # next to the transport facts so a reader of `value` (weak scaling) cannot miss it
+        result["halo_mode"] = ("push" if getattr(plan, "push", False) else os.environ.get("HPCLA_HALO_MODE", "serial"))
+        result["n_ranks_rccl"] = world if backend.has_rccl else 0
+        result["peer_windows"] = bool(backend.peer_windows)
+        result["strong_scaling_speedup_vs_n1"] = None
+    if world == 1 and not args.no_cpu_baseline and budget.allows("cpu_baseline", args.cpu_seconds + 18):   # the contract: rank 0 at N = 1 only
         lo, hi = run.lo, run.hi
         xg = x.local_values()
         if plan.has_halo:
@@ -653,33 +717,63 @@ def _run(args):
         vals = run.vals if run.vals is not None else A.nzval.cpu().numpy()
         result["cpu_baseline"] = cpu_baseline_spmv(A.rowptr, A.colval, vals, xfull, args.cpu_seconds)
         del vals, xfull
+        stage("cpu baseline timed")
 
     # ---- BASELINE configs[2], the strong-scaling problem, as a sub-record of the same line ----------------
+    # Optional stages run in order of value and only while the budget covers them (benchmarks/budget.py): a stage
+    # that would not fit is recorded as {"skipped": "budget"}, decided by all ranks together.
+    from benchmarks.budget import SKIPPED
     if not strong and not args.no_strong:
         run.release()
         del A, x, y, plan
         hp.clear_plan_cache()
         torch.cuda.empty_cache()
         job.barrier()
-        try:
-            rec, ok = strong_scaling_record(hp, wl, job, backend, args, world, rank)
-            verified = verified and ok and not rec.get("timed_out", False)
-        except Exception as exc:                     # same code on every rank: all ranks land here together
-            rec = {"error": f"{type(exc).__name__}: {exc}"}
+        if job.agree(budget.allows("strong_scaling")):
+            try:
+                rec, ok = strong_scaling_record(hp, wl, job, backend, args, world, rank, budget)
+                verified = verified and ok and not rec.get("timed_out", False)
+            except Exception as exc:                     # same code on every rank: all ranks land here together
+                rec = {"error": f"{type(exc).__name__}: {exc}"}
+        else:
+            rec = dict(SKIPPED)
         result["strong_scaling"] = rec
+        if world > 1:
+            result["strong_scaling_speedup_vs_n1"] = rec.get("speedup_vs_n1")
+        stage("strong-scaling sub-record done")
     # ---- the other BASELINE configs as sub-records of the same line (driver-timed): configs[3]'s per-GPU share
-    #      (3-D Poisson, 100 CG iterations) and configs[4] (SpMM, k = 16) in its two regimes -------------------
+    #      (3-D Poisson, 100 CG iterations) and configs[4] (SpMM, k = 16): config 5 at its own gather set (B = 2^24 x 16
+    #      rows whatever N is: at N = 1 all of it local -- the HBM side of the 8-GPU job), the 5-point matrix x 16
+    #      (the kernel's own efficiency), and the Infinity-Cache-sized B of round 2 labelled as such ----------------
     if not strong and not args.no_extras:
         import copy
         from benchmarks import extra_workloads
         extras = {}
-        for name, wsteps in (("poisson3d_cg", 100), ("poisson2d_spmm", 20), ("sprand_spmm", 10)):
+        if world == 1:
+            if budget.allows("int64"):
+                try:
+                    extras["int64"], ok = int64_record(hp, wl, job, args, N, min(args.steps, 50), min(args.warmup, 10))
+                    verified = verified and ok
+                except Exception as exc:
+                    extras["int64"] = {"error": f"{type(exc).__name__}: {exc}"}
+            else:
+                extras["int64"] = dict(SKIPPED)
+            stage("int64 sub-record done")
+        todo = [("poisson3d_cg", "poisson3d_cg", 100, 0), ("sprand_spmm", "sprand_spmm", 10, max(1, 8 // world)),
+                ("poisson2d_spmm", "poisson2d_spmm", 20, 0)]
+        if world == 1:
+            todo.append(("sprand_spmm_mall_sized", "sprand_spmm", 10, 1))
+        for name, workload, wsteps, mult in todo:
             a2 = copy.copy(args)
-            a2.workload, a2.steps, a2.warmup, a2.size = name, wsteps, 4, 0
+            a2.workload, a2.steps, a2.warmup, a2.size, a2.cols_mult = workload, wsteps, 5, 0, mult
+            if not job.agree(budget.allows(name)):
+                extras[name] = dict(SKIPPED)
+                continue
             try:
                 extras[name] = extra_workloads.run_record(a2, backend, rank, world, job)
             except Exception as exc:                 # same code on every rank: all ranks land here together
                 extras[name] = {"error": f"{type(exc).__name__}: {exc}"}
+            stage(f"{name} sub-record done")
         result["other_configs"] = extras
     verified = verified and not timed_out
     result["verified_vs_closed_form"] = verified
@@ -687,6 +781,11 @@ def _run(args):
     if not verified:
         sys.stderr.write("bench: result verification FAILED\n")
     breakdown_fn = None
+    if want_breakdown and not job.agree(budget.allows("comparison")):
+        if rank == 0:
+            result["step_breakdown_ms_max_over_ranks"] = dict(SKIPPED)
+        want_breakdown = False
+    result["budget"] = {"outer_limit_s": budget.outer, "elapsed_s": round(budget.elapsed(), 1), "skipped": list(budget.skipped)}
     if want_breakdown:
         def breakdown_fn():              # on a fresh copy of the headline problem (the plan caches were cleared above)
             hp.clear_plan_cache()

@@ -16,40 +16,89 @@ import numpy as np
 HBM_PEAK_GBS = 8000.0
 
 
+def stored_traffic(key, applicable=True):
+    """HBM bytes per launch / iteration measured by the builder's separate rocprofv3 --pmc passes of the same
+    workload (profiles/traffic_latest.json, written by benchmarks/collect_profiles.py; corrected for gfx950 as
+    MI355X_MICROARCH.md prescribes).  PMC counters cannot be read from inside the process, so the value is a
+    stored measurement and labelled as such; (None, reason) when this run's shape differs from the stored one."""
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic_latest.json")
+    try:
+        rec = json.load(open(path)).get("workloads", {}).get(key)
+    except Exception:
+        rec = None
+    if not applicable or not rec:
+        return None, "no stored PMC measurement for this shape (profiles/traffic_latest.json)"
+    return rec["hbm_bytes"], ("NOT measured by this run: PMC counters cannot be read from inside the process; value stored by "
+                              "the builder's rocprofv3 passes of this workload -- " + rec.get("source", path))
+
+
 def _sync_barrier(job, closing=False):
     job.barrier(device_only=closing)      # closing bracket of a timed region: device rendezvous only (bench.py Job)
 
 
-def _measure_spmm(args, job, hp, wl, A, B, k, world, dev, setup_s, metric, workload):
+XGMI_LINK_GBS = 153.0        # MI355X_MICROARCH.md / SURVEY 5: 7 xGMI links per GPU x ~153 GB/s each way, point to point
+XGMI_LINKS = 7
+
+
+def _measure_spmm(args, job, hp, wl, A, B, k, world, dev, setup_s, metric, workload, traffic_key=None):
+    import torch
     C = A @ B
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 5)):
         C = A @ B
-    _sync_barrier(job)
     steps = min(args.steps, 50)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    _sync_barrier(job)
     t0 = time.perf_counter()
+    ev0.record()
     for _ in range(steps):
         C = A @ B
+    ev1.record()
     _sync_barrier(job, closing=True)
     elapsed = time.perf_counter() - t0
     elapsed = job.max(elapsed)
+    device_ms = job.max(ev0.elapsed_time(ev1) / steps)
     ms = elapsed / steps * 1e3
     b_alg = wl.spmm_algorithmic_bytes(A.nnz, A.nrows_local, A.ncols_compressed, k, 4)
     b_gather = A.nnz * (12 + 8 * k) + 4 * A.nrows_local + 8 * k * A.nrows_local    # every B row read per entry
+    traffic, traffic_source = stored_traffic(traffic_key, traffic_key is not None and world == 1)
     out = {
         "metric": metric, "value": round(2.0 * k * A.nnz * world / (ms * 1e-3) / 1e9, 1),
-        "unit": "GFLOP/s", "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+        "unit": "GFLOP/s", "n_gpus": world, "steps": steps, "warmup": max(args.warmup, 5), "ms_per_step": round(ms, 4),
+        "device_ms_per_step": round(device_ms, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": workload,
-                   "ncols_compressed": A.ncols_compressed},
-        "roofline": {"bound": "hbm", "achieved": round(b_alg / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                   "ncols_compressed": A.ncols_compressed, "ncols": int(B.row_partition[-1])},
+        "roofline": {"bound": "hbm", "achieved": round(b_alg / (device_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(b_alg / (device_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "traffic": traffic, "traffic_source": traffic_source,
                      "algorithmic_bytes_per_launch": b_alg,
                      "gather_bytes_per_launch": b_gather,
-                     "gather_gbs": round(b_gather / (ms * 1e-3) / 1e9, 1),
-                     "note": "algorithmic bytes count each touched B row once; a random-column matrix re-reads B rows "
+                     "gather_gbs": round(b_gather / (device_ms * 1e-3) / 1e9, 1),
+                     "note": "achieved = algorithmic bytes / device time per step (HIP events on the launch stream); algorithmic "
+                             "bytes count each touched B row once; a random-column matrix re-reads B rows "
                              "(gather_bytes = one 128-byte line per stored entry), which is what HBM actually serves"},
         "setup_s": round(setup_s, 2),
     }
+    if world > 1:
+        # the exchange side of the step (BASELINE.md section 2: "report against both HBM and xGMI rooflines"):
+        # ghost rows of B that cross xGMI per step, against 7 point-to-point links of ~153 GB/s per direction
+        xin, xout, n_peers_in, n_peers_out = hp.spmm_exchange_bytes(A, B)
+        peak_in = XGMI_LINK_GBS * max(min(n_peers_in, XGMI_LINKS), 1)
+        t_comm_bound = job.max(max(xin / (XGMI_LINK_GBS * max(min(n_peers_in, XGMI_LINKS), 1)),
+                                   xout / (XGMI_LINK_GBS * max(min(n_peers_out, XGMI_LINKS), 1))) / 1e9 * 1e3)    # ms
+        t_hbm_bound = job.max(b_alg / (HBM_PEAK_GBS * 1e9) * 1e3)
+        out["roofline_xgmi"] = {
+            "bound": "xgmi", "bytes_in_per_gpu_per_step": int(job.max(xin)), "bytes_out_per_gpu_per_step": int(job.max(xout)),
+            "peers_in": int(job.max(n_peers_in)), "peers_out": int(job.max(n_peers_out)),
+            "achieved_in_gbs": round(job.max(xin) / (ms * 1e-3) / 1e9, 1), "link_gbs": XGMI_LINK_GBS, "links": XGMI_LINKS,
+            "peak_in_gbs": round(job.max(peak_in), 1),
+            "frac": round(job.max(xin) / (ms * 1e-3) / 1e9 / job.max(peak_in), 4) if xin or world > 1 else None,
+            "comm_bound_ms": round(t_comm_bound, 4), "hbm_bound_ms": round(t_hbm_bound, 4),
+            "step_sits_on": "xgmi" if t_comm_bound > t_hbm_bound else "hbm",
+            "order": os.environ.get("HPCLA_SPMM_ORDER", "sequential"),
+            "note": "bytes = ghost rows of B (8k bytes each) received / sent by the busiest rank per step; peak = one xGMI link "
+                    "per peer (point to point), at most 7; frac = achieved ingress / that peak over the WALL time of a step "
+                    "(exchange and kernel together); comm_bound / hbm_bound = the step's two lower bounds"}
     return out
 
 
@@ -103,34 +152,75 @@ def run_record(args, backend, rank, world, job):
         iters = args.steps if args.steps != 200 else 100
         fused = os.environ.get("HPCLA_CG_UNFUSED", "") != "1"
         graph = os.environ.get("HPCLA_CG_GRAPH", "") == "1"     # replay a captured pair of iterations
-        hp.cg_fixed_iterations(A, b, max(args.warmup // 4, 2), record_history=False, fused=fused)   # warm-up
+        native = os.environ.get("HPCLA_CG_PYTHON_LOOP", "") != "1"   # default: hpcla_cg_iterations_* (one host call)
+        # Everything that is not an iteration stays OUTSIDE the timed region: the workspace (x, r, p, Ap, history),
+        # the plan, x0 = 0 / r0 = p0 = b / sum r0^2 (cg_setup), and the history read-back.  Warm-up: >= 5
+        # iterations through the SAME code path that is then timed.
+        ws = hp.CGWorkspace(b, max(iters, 8) + 2)
+        plan, fused_eff = hp.cg_setup(A, b, ws, fused)
+        n_warm = max(args.warmup, 5)
+        gp = None
+        if graph:
+            hp.cg_iterate(A, ws, plan, fused_eff, 2, native_loop=False)
+            gp = hp.CGGraphPair(A, ws, plan, fused_eff)
+            gp.replay(max(n_warm // 2, 3))
+        else:
+            hp.cg_iterate(A, ws, plan, fused_eff, n_warm, native_loop=native)
+        torch.cuda.synchronize()
+        plan, fused_eff = hp.cg_setup(A, b, ws, fused)          # restart from x0 = 0
+        if graph:
+            hp.cg_iterate(A, ws, plan, fused_eff, 2, native_loop=False)
+            iters_timed = (iters - 2) // 2 * 2
+        else:
+            iters_timed = iters
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         _sync_barrier(job)
         t0 = time.perf_counter()
-        x, hist = hp.cg_fixed_iterations(A, b, iters, record_history=True, fused=fused, graph=graph)
+        ev0.record()                       # HIP events on the launch stream, bracketing the iterations themselves
+        if graph:
+            gp.replay(iters_timed // 2)
+        else:
+            hp.cg_iterate(A, ws, plan, fused_eff, iters_timed, native_loop=native)
+        ev1.record()
+        t_enqueued = time.perf_counter() - t0          # host time to enqueue all iterations (nothing waited for)
         _sync_barrier(job, closing=True)
         elapsed = time.perf_counter() - t0
         elapsed = job.max(elapsed)
+        device_ms_iter = job.max(ev0.elapsed_time(ev1) / iters_timed)
+        host_enqueue_ms_iter = job.max(t_enqueued / iters_timed * 1e3)
+        if ws.done < iters:                                     # graph mode: the odd remainder, untimed
+            hp.cg_iterate(A, ws, plan, fused_eff, iters - ws.done, native_loop=False)
+        hist = ws.hist[:iters + 1].sqrt().cpu().tolist()       # read-back after the timed region
         n_loc, nnz_loc = A.nrows_local, A.nnz
         b_spmv = wl.spmv_algorithmic_bytes(nnz_loc, n_loc, A.ncols_compressed, 4)
         b_iter = b_spmv + 96 * n_loc        # textbook unfused CG = SpMV + 96 n bytes
-        ms_iter = elapsed / iters * 1e3
+        b_moved = b_spmv + (64 if fused_eff else 96) * n_loc
+        ms_iter = elapsed / iters_timed * 1e3
+        traffic, traffic_source = stored_traffic("poisson3d_cg_iteration", N == 512 and world == 1 and fused_eff)
         out = {
             "metric": "CG ms/iteration, 3-D 7-pt Poisson, fp64", "value": round(ms_iter, 4), "unit": "ms/iter",
-            "n_gpus": world, "steps": iters, "warmup": args.warmup, "ms_per_step": round(ms_iter, 4),
+            "n_gpus": world, "steps": iters_timed, "warmup": n_warm, "ms_per_step": round(ms_iter, 4),
+            "wall_ms_per_iter": round(ms_iter, 4), "device_ms_per_iter": round(device_ms_iter, 4),
+            "host_enqueue_ms_per_iter": round(host_enqueue_ms_iter, 5),
             "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"poisson3d 7-pt {N}x{N}x{planes} per GPU ({N}x{N}x{nz} global), {iters} CG iterations, "
-                                   f"{'fused: SpMV+p.Ap, r-update+r.r, x/p-update' if fused else 'one kernel per reference operator'}"
-                                   f"{', HIP graph replay' if graph else ''}",
+            "config": {"workload": f"poisson3d 7-pt {N}x{N}x{planes} per GPU ({N}x{N}x{nz} global), {iters_timed} CG iterations, "
+                                   f"{'fused: SpMV+p.Ap, r-update+r.r, x/p-update' if fused_eff else 'one kernel per reference operator'}"
+                                   f"{', HIP graph replay' if graph else (', one host call for all iterations (hpcla_cg_iterations)' if native and fused_eff else ', one host call per kernel')}",
                        "global_rows": n_glob, "nnz_per_gpu": nnz_loc},
             "roofline": {"bound": "hbm", "achieved": round(b_iter / (ms_iter * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(b_iter / (ms_iter * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                         "unit": "GB/s", "frac": round(b_iter / (ms_iter * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_iteration": b_iter,
-                         "moved_bytes_per_iteration": b_spmv + (64 if fused else 96) * n_loc,
-                         "moved_gbs": round((b_spmv + (64 if fused else 96) * n_loc) / (ms_iter * 1e-3) / 1e9, 1),
-                         "note": "whole iteration (SpMV, 2 reductions, the x / r / p updates), wall clock; bytes = the textbook unfused count of SURVEY 8d (SpMV + 96 n), the fused form moves SpMV + 64 n"},
+                         "moved_bytes_per_iteration": b_moved,
+                         "moved_gbs": round(b_moved / (ms_iter * 1e-3) / 1e9, 1),
+                         "frac_moved_bytes": round(b_moved / (ms_iter * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "note": "whole iteration (SpMV, 2 reductions, the x / r / p updates); achieved = bytes / WALL clock per iteration "
+                                 "(max over ranks); device_ms_per_iter = HIP events on the launch stream around the same iterations; "
+                                 "bytes = the textbook unfused count of SURVEY 8d (SpMV + 96 n), the fused form moves SpMV + 64 n"},
             "residual_first": hist[0], "residual_last": hist[-1], "setup_s": round(setup_s, 2),
             "exchange_timed_out": bool(job.max(1.0 if hp.get_vector_plan(A, b).timed_out() else 0.0)),
         }
+        del ws, gp
     elif args.workload == "poisson2d_spmm":
         # structured counterpart of config 5: the 5-point matrix times 16 dense columns.  Every B row is
         # needed by <= 5 matrix rows that sit close together, so the algorithmic byte count (each B row
@@ -150,13 +240,14 @@ def run_record(args, backend, rank, world, job):
         setup_s = time.perf_counter() - t0
         out = _measure_spmm(args, job, hp, wl, A, B, k, world, dev, setup_s,
                             "SpMM GFLOP/s (2*k*nnz/t), 2-D 5-pt Poisson, k=16, fp64",
-                            f"poisson2d 5-pt {nx}x{ny_loc} slab per GPU, nnz/GPU={A.nnz}, k={k}, C = A*B")
+                            f"poisson2d 5-pt {nx}x{ny_loc} slab per GPU, nnz/GPU={A.nnz}, k={k}, C = A*B",
+                            traffic_key="poisson2d_spmm" if N == 4096 else None)
     elif args.workload == "sprand_spmm":
         k = 16
         rows_loc = args.size or 2_097_152
         # HPCLA_SPMM_COLS_MULT=8 on ONE GPU reproduces config 5's per-GPU access pattern (B has
         # 8 x 2 097 152 rows = 2.1 GB, far beyond the 256 MiB Infinity Cache) without the exchange
-        mult = int(os.environ.get("HPCLA_SPMM_COLS_MULT", "1"))
+        mult = int(getattr(args, "cols_mult", 0) or os.environ.get("HPCLA_SPMM_COLS_MULT", "1"))
         ncols = rows_loc * world * mult
         mean_nnz = 29.8
         # generated ON THE DEVICE (torch is plumbing here): counts ~ Poisson(29.8) (= Binomial(ncols, 29.8/ncols)
@@ -209,9 +300,14 @@ def run_record(args, backend, rank, world, job):
                       torch.cuda.current_stream().cuda_stream)
         B = hp.HPCMatrix_local(Bl, backend)
         setup_s = time.perf_counter() - t0
+        regime = ("B = %d rows x 16 = %.2f GB: config 5's gather set, far beyond the 256 MiB Infinity Cache" % (ncols, ncols * 128 / 1e9)
+                  if ncols * 128 > (1 << 29) else
+                  "B = %d rows x 16 = %.0f MB: Infinity-Cache-sized B (MALL-assisted gathers), NOT config 5's regime" % (ncols, ncols * 128 / 1e6))
         out = _measure_spmm(args, job, hp, wl, A, B, k, world, dev, setup_s,
                             "SpMM GFLOP/s (2*k*nnz/t), sprand ~29.8 nnz/row, k=16, fp64",
-                            f"sprand-like {rows_loc} rows per GPU x {ncols} cols, nnz/GPU={A.nnz}, k={k}, C = A*B")
+                            f"sprand-like {rows_loc} rows per GPU x {ncols} cols, nnz/GPU={A.nnz}, k={k}, C = A*B; {regime}",
+                            traffic_key=("sprand_spmm_b2e24" if (rows_loc, ncols) == (2_097_152, 16_777_216) else
+                                         "sprand_spmm_mall_sized" if (rows_loc, ncols) == (2_097_152, 2_097_152) else None))
     job.barrier()
     hp.clear_spmm_cache()
     hp.clear_plan_cache()

@@ -268,8 +268,10 @@ int hpcla_comm_window_attach(hpcla_comm_t *comm, const uint8_t *all_descs_host /
  * calls hpcla_comm_window_detach and the data path stays on RCCL.  Synchronises the device. */
 int hpcla_comm_window_selftest(hpcla_comm_t *comm, double timeout_s, int *ok);
 int hpcla_comm_window_detach(hpcla_comm_t *comm);
-/* 1 in *timed_out if a window all-reduce gave up waiting for a peer (HPCLA_PUSH_TIMEOUT_S, default 20 s);
- * synchronises a 4-byte device read. */
+/* 1 in *timed_out if a window all-reduce gave up waiting for a peer (HPCLA_PUSH_TIMEOUT_S, default 300 s: a
+ * slow peer is waited for like a blocking MPI_Allreduce, src/backends.jl:264-277; the bound only lets the grid
+ * drain when a peer has died).  The result of an expired all-reduce is NaN on this rank.  Synchronises a
+ * 4-byte device read. */
 int hpcla_comm_status(hpcla_comm_t *comm, int *timed_out);
 /* 64-bit identity of (node, physical device): two ranks with equal identities share one GPU. */
 int hpcla_device_identity(int device, uint64_t *id);
@@ -304,6 +306,17 @@ int hpcla_halo_plan_create(hpcla_halo_plan_t **plan, hpcla_comm_t *comm, int n_s
                            const void *send_idx, int idx_is_i64, int n_recv,
                            const int32_t *recv_ranks_host, const int64_t *recv_counts_host,
                            int width);
+/* flags: HPCLA_HALO_SINGLE_BUFFER -- never double-buffer the ghost window.  Required for every plan that is
+ * driven through hpcla_halo_begin / hpcla_halo_end with the ghost pointer taken from the host in between
+ * (SpMM ghost rows: the interior launch is enqueued before the exchange has completed, so "the buffer of the
+ * exchange completed last" is not yet this exchange's buffer); width > 1 plans are single-buffered anyway, the
+ * flag matters for a one-column B (width 1).  Vector plans of the fused SpMV keep the default (0). */
+#define HPCLA_HALO_SINGLE_BUFFER 1
+int hpcla_halo_plan_create_ex(hpcla_halo_plan_t **plan, hpcla_comm_t *comm, int n_send,
+                              const int32_t *send_ranks_host, const int64_t *send_counts_host,
+                              const void *send_idx, int idx_is_i64, int n_recv,
+                              const int32_t *recv_ranks_host, const int64_t *recv_counts_host,
+                              int width, int flags);
 int hpcla_halo_plan_destroy(hpcla_halo_plan_t *plan);
 /* Push transport for this plan.  When the communicator's window is attached, create() places the ghost
  * segment (double-buffered up to 64 MiB) inside a peer-mappable window.  export: this rank's descriptor
@@ -328,11 +341,16 @@ int hpcla_halo_plan_detach(hpcla_halo_plan_t *plan);
  * the plan on every rank (hpcla_halo_plan_detach), leaving it on RCCL.  Works for RCCL plans too. */
 int hpcla_halo_plan_probe(hpcla_halo_plan_t *plan, int64_t n_local_rows, const int64_t *check_slots_host,
                           const int64_t *check_rows_host, int64_t n_check, void *stream, int *ok);
-/* 1 in *timed_out if a push or wait of this plan gave up (result invalid); synchronising 4-byte read. */
+/* 1 in *timed_out if a push or wait of this plan gave up; synchronising 4-byte read.  An expired WAIT poisons
+ * what it would have fed: the waiting row blocks' y entries and dot partials (fused SpMV) or the whole ghost
+ * buffer (hpcla_halo_end) become NaN, so the failure cannot pass as a result; an expired ack wait of a PUSH
+ * stores nothing and publishes nothing (the consumer may still be reading the buffer).  The status is sticky:
+ * the plan is dead afterwards. */
 int hpcla_halo_status(hpcla_halo_plan_t *plan, int *timed_out);
 /* device pointer of the ghost buffer of the exchange completed last (n_ghost*width doubles) and its length in
- * indices.  Constant for RCCL plans and for dense (width > 1) push plans; a double-buffered vector push plan
- * reads its device step counter here, i.e. the call SYNCHRONISES the device -- only the API-parity path
+ * indices.  Constant for RCCL plans, for dense (width > 1) push plans and for HPCLA_HALO_SINGLE_BUFFER plans;
+ * a double-buffered vector push plan reads its device step counter here, i.e. the call SYNCHRONISES the device
+ * and is only meaningful AFTER hpcla_halo_end of the exchange in question -- only the API-parity path
  * (execute_plan!'s `gathered`) asks, the fused SpMV finds its buffer in the kernel. */
 int hpcla_halo_ghost_ptr(hpcla_halo_plan_t *plan, double **ghost, int64_t *n_ghost);
 /* begin: after everything already enqueued on `stream`, pack x[send_idx] and post the
@@ -470,6 +488,27 @@ int hpcla_cg_residual_f64(hpcla_comm_t *comm, double alpha_host, const double *n
 int hpcla_cg_direction_f64(double alpha_host, const double *a_num_dev, const double *a_den_dev, double beta_host,
                            const double *b_num_dev, const double *b_den_dev, const double *r, double *x,
                            double *p, int64_t n, void *stream);
+/* `iters` fused CG iterations enqueued by ONE host call (no reference counterpart: the reference has no
+ * Krylov solver, a caller composes the iteration from A*p src/sparse.jl:2096-2128, dot src/vectors.jl:798-812,
+ * the broadcasts :1203-1226 and norm :758-765 -- SURVEY 3.4).  Per iteration exactly the launches of
+ * hpcla_spmv_dist_dot_* (Ap = A*p, pAp), hpcla_cg_residual_f64 and hpcla_cg_direction_f64, with the same
+ * arguments, so the same bits as the three separate calls; neither Python nor Julia sits in the loop.
+ * rr_hist_dev: iters + 1 doubles, [0] = sum r_0^2 on entry, [j] = sum r_j^2 on return (device memory; the
+ * caller takes the square roots).  pAp_dev: 1 double.  dot_work: hpcla_spmv_dot_work_bytes(nrows) bytes,
+ * reduce_work: hpcla_reduce_work_bytes() bytes.  x, r, p, Ap partitioned like A's rows (nrows entries,
+ * 16-byte aligned); plan / comm / block lists as for hpcla_spmv_dist_dot_*.  Only enqueues: capturable. */
+int hpcla_cg_iterations_f64_i32(hpcla_halo_plan_t *plan, hpcla_comm_t *comm, const int32_t *rowptr,
+                                const int32_t *colval_split, const double *nzval, int64_t nrows, int64_t nnz,
+                                int index_base, const int32_t *interior_blocks, int64_t n_interior,
+                                const int32_t *boundary_blocks, int64_t n_boundary, double *x, double *r,
+                                double *p, double *Ap, double *rr_hist_dev, double *pAp_dev, void *dot_work,
+                                void *reduce_work, int iters, void *stream);
+int hpcla_cg_iterations_f64_i64(hpcla_halo_plan_t *plan, hpcla_comm_t *comm, const int64_t *rowptr,
+                                const int64_t *colval_split, const double *nzval, int64_t nrows, int64_t nnz,
+                                int index_base, const int32_t *interior_blocks, int64_t n_interior,
+                                const int32_t *boundary_blocks, int64_t n_boundary, double *x, double *r,
+                                double *p, double *Ap, double *rr_hist_dev, double *pAp_dev, void *dot_work,
+                                void *reduce_work, int iters, void *stream);
 int hpcla_divide_f64(const double *x, double a_host, double *y, int64_t n, void *stream);
 int hpcla_axpby_f64(double a, const double *x, double b, const double *y, double *z, int64_t n,
                     void *stream);

@@ -315,7 +315,7 @@ Base.minimum(v::HPCVector{T,B}) where {T<:Float64,B<:ROCBackend} = -_reduce_scal
 # ---- A * B, B::HPCMatrix  (replaces the column loop of src/sparse.jl:2391-2413) ---------------------------
 # Julia's Matrix is column-major; the kernel's fast layout is row-major (one 128-byte line per B row at
 # k = 16), so B is converted once with hpcla_transpose_f64 and C converted back.
-const _spmm_plans = IdDict{Any,Any}()     # (reference plan, k) -> (halo handle, interior, boundary); freed by clear_rocm_plan_cache!
+const _spmm_plans = IdDict{Any,Any}()     # (reference plan, k) -> (halo handle, interior, boundary, send_idx, ghost pointer); freed by clear_rocm_plan_cache!
 
 # width-k halo plan for the ghost ROWS of B: the reference VectorPlan's own lists, `width = k` values per index
 # (row-major rows travel as contiguous k-doubles).  The Python twin additionally swaps a neighbour's requested
@@ -326,12 +326,15 @@ function _spmm_halo(A::HPCSparseMatrix{T,Ti,B}, plan, d::ROCVectorPlan{Ti}, k::I
         halo = Ref{Ptr{Cvoid}}(C_NULL)
         send_idx = ROCVector(Ti.(reduce(vcat, plan.send_indices; init=Ti[]) .- one(Ti)))
         AMDGPU.synchronize()
-        _check(@ccall(LIB.hpcla_halo_plan_create(halo::Ptr{Ptr{Cvoid}}, _rccl(A.backend.comm)::Ptr{Cvoid},
+        # flags = 1 (HPCLA_HALO_SINGLE_BUFFER): this plan is driven through halo_begin / halo_end and its consumers
+        # take the ghost pointer from the host while the exchange is in flight, so a one-column B (width 1) must
+        # not be double-buffered like the fused SpMV's vector plans
+        _check(@ccall(LIB.hpcla_halo_plan_create_ex(halo::Ptr{Ptr{Cvoid}}, _rccl(A.backend.comm)::Ptr{Cvoid},
                length(plan.send_rank_ids)::Cint, Int32.(plan.send_rank_ids)::Ptr{Int32},
                Int64.(length.(plan.send_indices))::Ptr{Int64}, _ptr(send_idx)::Ptr{Cvoid},
                (Ti === Int64 ? 1 : 0)::Cint, length(plan.recv_rank_ids)::Cint,
                Int32.(plan.recv_rank_ids)::Ptr{Int32}, Int64.(length.(plan.recv_perm))::Ptr{Int64},
-               k::Cint)::Cint), "hpcla_halo_plan_create")
+               k::Cint, 1::Cint)::Cint), "hpcla_halo_plan_create_ex")
         A.backend.comm isa CommMPI &&
             _attach_halo_window(_rccl(A.backend.comm), halo[], A.backend.comm.comm, comm_size(A.backend.comm),
                                 (d.n_own, d.segments))
@@ -348,7 +351,10 @@ function _spmm_halo(A::HPCSparseMatrix{T,Ti,B}, plan, d::ROCVectorPlan{Ti}, k::I
                    _stream()::Ptr{Cvoid})::Cint), "hpcla_classify_blocks_i64")
         end
         f = Array(flags)
-        (halo[], ROCVector(Int32.(findall(==(0), f) .- 1)), ROCVector(Int32.(findall(!=(0), f) .- 1)), send_idx)
+        # the ghost buffer of a single-buffered plan is a constant: fetched once, at plan time
+        ghost = Ref{Ptr{Cvoid}}(C_NULL); ng = Ref{Int64}(0)
+        _check(@ccall(LIB.hpcla_halo_ghost_ptr(halo[]::Ptr{Cvoid}, ghost::Ptr{Ptr{Cvoid}}, ng::Ptr{Int64})::Cint), "hpcla_halo_ghost_ptr")
+        (halo[], ROCVector(Int32.(findall(==(0), f) .- 1)), ROCVector(Int32.(findall(!=(0), f) .- 1)), send_idx, ghost[])
     end
 end
 
@@ -382,13 +388,11 @@ function Base.:*(A::HPCSparseMatrix{T,Ti,B}, M::HPCMatrix{T,B}) where {T<:Float6
     if isempty(plan.send_rank_ids) && isempty(plan.recv_rank_ids)
         _spmm_split!(Crow, A, d, Brow, C_NULL, k, ROCVector(Int32.(0:cld(A.nrows_local, (@ccall LIB.hpcla_spmm_rows_per_block()::Cint))-1)))
     else
-        halo, interior, boundary, _ = _spmm_halo(A, plan, d, k)
-        ghost = Ref{Ptr{Cvoid}}(C_NULL); ng = Ref{Int64}(0)
+        halo, interior, boundary, _, ghost = _spmm_halo(A, plan, d, k)
         _check(@ccall(LIB.hpcla_halo_begin(halo::Ptr{Cvoid}, _ptr(Brow)::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_halo_begin")
-        _check(@ccall(LIB.hpcla_halo_ghost_ptr(halo::Ptr{Cvoid}, ghost::Ptr{Ptr{Cvoid}}, ng::Ptr{Int64})::Cint), "hpcla_halo_ghost_ptr")
-        _spmm_split!(Crow, A, d, Brow, ghost[], k, interior)       # rows without ghost columns overlap the exchange
+        _spmm_split!(Crow, A, d, Brow, ghost, k, interior)         # rows without ghost columns overlap the exchange
         _check(@ccall(LIB.hpcla_halo_end(halo::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_halo_end")
-        _spmm_split!(Crow, A, d, Brow, ghost[], k, boundary)
+        _spmm_split!(Crow, A, d, Brow, ghost, k, boundary)
     end
     C = AMDGPU.zeros(T, A.nrows_local, k)
     _check(@ccall(LIB.hpcla_transpose_f64(_ptr(Crow)::Ptr{Cvoid}, k::Int64, 0::Cint, _ptr(C)::Ptr{Cvoid},

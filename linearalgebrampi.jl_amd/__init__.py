@@ -26,11 +26,12 @@ from .vectors import HPCVector, HPCVector_local, cg_direction_, cg_residual_, cg
 from .sparse import (HPCSparseMatrix, HPCSparseMatrix_from_global, HPCSparseMatrix_local,
                      HPCSparseMatrix_local_device,
                      HostVectorPlan, VectorPlan, build_host_vector_plan, cache_sizes,
+                     ExchangeTimeout, check_exchange_health,
                      clear_plan_cache, execute_plan, get_vector_plan, mul_, mul_dot_, split_column_map)
 from .dense import (HPCMatrix, HPCMatrix_local, TransposedHPCMatrix, clear_dense_plan_cache, clear_spmm_cache,
-                    dense_matvec, dense_matvec_t, spmm)
+                    dense_matvec, dense_matvec_t, spmm, spmm_exchange_bytes)
 from .matmat import clear_matrix_plan_cache, get_matrix_plan, spgemm
-from .cg import cg_fixed_iterations
+from .cg import CGGraphPair, CGWorkspace, cg_fixed_iterations, cg_iterate, cg_setup
 from .convert import to_backend
 from .transpose import (HostTransposeStructure, TransposedHPCSparseMatrix, TransposedHPCVector, TransposePlan,
                         adjoint, clear_transpose_plan_cache, get_transpose_plan, transpose)

@@ -20,6 +20,7 @@ UNIQUE_ID_BYTES = 128
 WINDOW_DESC_BYTES = 128
 WINDOW_TABLE_ROWS = 4
 COMM_NO_RCCL = 1
+HALO_SINGLE_BUFFER = 1
 
 
 class HPCLAError(RuntimeError):
@@ -81,6 +82,7 @@ _SIGNATURES = {
     "hpcla_allreduce_f64": [_vp, _vp, _i64, _i32, _vp],
     "hpcla_exchange_ranges_f64": [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp],
     "hpcla_halo_plan_create": [_vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32],
+    "hpcla_halo_plan_create_ex": [_vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32],
     "hpcla_halo_plan_destroy": [_vp],
     "hpcla_halo_ghost_ptr": [_vp, _vp, _vp],
     "hpcla_halo_begin": [_vp, _vp, _vp],
@@ -93,6 +95,10 @@ _SIGNATURES = {
     "hpcla_cg_update_f64": [_vp, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp],
     "hpcla_cg_residual_f64": [_vp, _f64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp],
     "hpcla_cg_direction_f64": [_f64, _vp, _vp, _f64, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
+    "hpcla_cg_iterations_f64_i32": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp,
+                                    _vp, _vp, _vp, _i32, _vp],
+    "hpcla_cg_iterations_f64_i64": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp,
+                                    _vp, _vp, _vp, _i32, _vp],
     "hpcla_colspace_work_bytes": [_i64],
     "hpcla_compress_columns_i32": [_vp, _i64, _i64, _i64, _vp, _i32, _vp, _vp, _vp, _vp],
     "hpcla_compress_columns_i64": [_vp, _i64, _i64, _i64, _vp, _i32, _vp, _vp, _vp, _vp],

@@ -332,11 +332,11 @@ static void scan_contiguous(hpcla_halo_plan *p, const std::vector<I> &idx)
     }
 }
 
-HPCLA_API int hpcla_halo_plan_create(hpcla_halo_plan_t **plan, hpcla_comm_t *comm, int n_send,
-                                     const int32_t *send_ranks_host,
-                                     const int64_t *send_counts_host, const void *send_idx,
-                                     int idx_is_i64, int n_recv, const int32_t *recv_ranks_host,
-                                     const int64_t *recv_counts_host, int width)
+static int halo_plan_create_impl(hpcla_halo_plan_t **plan, hpcla_comm_t *comm, int n_send,
+                                 const int32_t *send_ranks_host,
+                                 const int64_t *send_counts_host, const void *send_idx,
+                                 int idx_is_i64, int n_recv, const int32_t *recv_ranks_host,
+                                 const int64_t *recv_counts_host, int width, int flags)
 {
     if (!plan || !comm) return set_error(HPCLA_ERR_INVALID, "halo_plan_create: null plan/comm");
     if (n_send < 0 || n_recv < 0 || width < 1)
@@ -351,6 +351,7 @@ HPCLA_API int hpcla_halo_plan_create(hpcla_halo_plan_t **plan, hpcla_comm_t *com
     if (!p) return set_error(HPCLA_ERR_ALLOC, "halo_plan_create: out of memory");
     p->comm = comm;
     p->width = width;
+    p->single_buffer = (flags & HPCLA_HALO_SINGLE_BUFFER) != 0;
     p->idx_is_i64 = idx_is_i64 ? 1 : 0;
     for (int i = 0; i < n_send; ++i) {
         if (send_ranks_host[i] < 0 || send_ranks_host[i] >= comm->nranks || send_counts_host[i] < 0) {
@@ -435,6 +436,27 @@ HPCLA_API int hpcla_halo_plan_create(hpcla_halo_plan_t **plan, hpcla_comm_t *com
 #undef HALO_HIP
     *plan = p;
     return HPCLA_OK;
+}
+
+HPCLA_API int hpcla_halo_plan_create(hpcla_halo_plan_t **plan, hpcla_comm_t *comm, int n_send,
+                                     const int32_t *send_ranks_host,
+                                     const int64_t *send_counts_host, const void *send_idx,
+                                     int idx_is_i64, int n_recv, const int32_t *recv_ranks_host,
+                                     const int64_t *recv_counts_host, int width)
+{
+    return halo_plan_create_impl(plan, comm, n_send, send_ranks_host, send_counts_host, send_idx, idx_is_i64, n_recv,
+                                 recv_ranks_host, recv_counts_host, width, 0);
+}
+
+HPCLA_API int hpcla_halo_plan_create_ex(hpcla_halo_plan_t **plan, hpcla_comm_t *comm, int n_send,
+                                        const int32_t *send_ranks_host,
+                                        const int64_t *send_counts_host, const void *send_idx,
+                                        int idx_is_i64, int n_recv, const int32_t *recv_ranks_host,
+                                        const int64_t *recv_counts_host, int width, int flags)
+{
+    if (flags & ~HPCLA_HALO_SINGLE_BUFFER) return set_error(HPCLA_ERR_INVALID, "halo_plan_create_ex: unknown flags");
+    return halo_plan_create_impl(plan, comm, n_send, send_ranks_host, send_counts_host, send_idx, idx_is_i64, n_recv,
+                                 recv_ranks_host, recv_counts_host, width, flags);
 }
 
 HPCLA_API int hpcla_halo_plan_destroy(hpcla_halo_plan_t *plan)
@@ -856,4 +878,62 @@ HPCLA_API int hpcla_spmv_dist_f64_i64(hpcla_halo_plan_t *plan, const int64_t *ro
     return spmv_dist_impl<int64_t>(spmv_split_i64, spmv_fused_i64, plan, rowptr, colval_split, nzval, x, n_own, y,
                                    nrows, nnz, index_base, interior_blocks, n_interior,
                                    boundary_blocks, n_boundary, stream);
+}
+
+// ---- k fused CG iterations in ONE host call ----------------------------------------------------------
+// The iteration a caller composes from A*p, dot, the broadcasts and norm (the reference has no Krylov
+// solver: src/sparse.jl:2096-2128, src/vectors.jl:798-812, 1203-1226, 758-765), enqueued `iters` times on
+// `stream` without returning to the host language in between: per iteration the launches of
+// hpcla_spmv_dist_dot_* (Ap = A p, pAp), hpcla_cg_residual_f64 (r -= a Ap, rr') and hpcla_cg_direction_f64
+// (x += a p, p = r + (rr'/rr) p) -- the same kernels with the same arguments as the three separate calls,
+// hence the same bits.  rr_hist_dev[j] holds sum r_j^2: [0] on entry, [1..iters] written here.
+template <typename I, typename F, typename G>
+static int cg_iterations_impl(F split_fn, G fused_fn, hpcla_halo_plan_t *plan, hpcla_comm_t *comm, const I *rowptr,
+                              const I *colval, const double *nzval, int64_t nrows, int64_t nnz, int index_base,
+                              const int32_t *interior, int64_t n_interior, const int32_t *boundary,
+                              int64_t n_boundary, double *x, double *r, double *p, double *Ap, double *rr_hist_dev,
+                              double *pAp_dev, void *dot_work, void *reduce_work, int iters, void *stream)
+{
+    if (iters < 0) return set_error(HPCLA_ERR_INVALID, "cg_iterations: negative iteration count");
+    if (!rr_hist_dev || !pAp_dev || !dot_work || !reduce_work)
+        return set_error(HPCLA_ERR_INVALID, "cg_iterations: null scalar / work buffer");
+    if (nrows > 0 && (!x || !r || !p || !Ap)) return set_error(HPCLA_ERR_INVALID, "cg_iterations: null vector");
+    for (int j = 0; j < iters; ++j) {
+        double *rr = rr_hist_dev + j;
+        int rc = spmv_dist_dot_impl<I>(split_fn, fused_fn, plan, comm, rowptr, colval, nzval, p, nrows, Ap, nrows, nnz,
+                                       index_base, interior, n_interior, boundary, n_boundary, pAp_dev, dot_work,
+                                       stream);
+        if (rc) return rc;
+        rc = hpcla_cg_residual_f64(comm, 1.0, rr, pAp_dev, Ap, r, nrows, rr + 1, reduce_work, stream);
+        if (rc) return rc;
+        rc = hpcla_cg_direction_f64(1.0, rr, pAp_dev, 1.0, rr + 1, rr, r, x, p, nrows, stream);
+        if (rc) return rc;
+    }
+    return HPCLA_OK;
+}
+
+HPCLA_API int hpcla_cg_iterations_f64_i32(hpcla_halo_plan_t *plan, hpcla_comm_t *comm, const int32_t *rowptr,
+                                          const int32_t *colval_split, const double *nzval, int64_t nrows,
+                                          int64_t nnz, int index_base, const int32_t *interior_blocks,
+                                          int64_t n_interior, const int32_t *boundary_blocks, int64_t n_boundary,
+                                          double *x, double *r, double *p, double *Ap, double *rr_hist_dev,
+                                          double *pAp_dev, void *dot_work, void *reduce_work, int iters,
+                                          void *stream)
+{
+    return cg_iterations_impl<int32_t>(spmv_split_i32, spmv_fused_i32, plan, comm, rowptr, colval_split, nzval, nrows,
+                                       nnz, index_base, interior_blocks, n_interior, boundary_blocks, n_boundary, x, r,
+                                       p, Ap, rr_hist_dev, pAp_dev, dot_work, reduce_work, iters, stream);
+}
+
+HPCLA_API int hpcla_cg_iterations_f64_i64(hpcla_halo_plan_t *plan, hpcla_comm_t *comm, const int64_t *rowptr,
+                                          const int64_t *colval_split, const double *nzval, int64_t nrows,
+                                          int64_t nnz, int index_base, const int32_t *interior_blocks,
+                                          int64_t n_interior, const int32_t *boundary_blocks, int64_t n_boundary,
+                                          double *x, double *r, double *p, double *Ap, double *rr_hist_dev,
+                                          double *pAp_dev, void *dot_work, void *reduce_work, int iters,
+                                          void *stream)
+{
+    return cg_iterations_impl<int64_t>(spmv_split_i64, spmv_fused_i64, plan, comm, rowptr, colval_split, nzval, nrows,
+                                       nnz, index_base, interior_blocks, n_interior, boundary_blocks, n_boundary, x, r,
+                                       p, Ap, rr_hist_dev, pAp_dev, dot_work, reduce_work, iters, stream);
 }

@@ -50,7 +50,7 @@ uint64_t host_identity();
 int window_alloc(void **p, size_t bytes, bool uncached);
 int window_open(const WindowDesc &d, int peer_rank, int my_rank, void *my_base, PeerMap *out);
 void window_close(PeerMap *m);
-int64_t spin_timeout_ticks();                  // HPCLA_PUSH_TIMEOUT_S (default 20 s) in wall_clock64 ticks
+int64_t spin_timeout_ticks();                  // HPCLA_PUSH_TIMEOUT_S (default 300 s) in wall_clock64 ticks
 
 }  // namespace hpcla
 
@@ -91,6 +91,7 @@ struct hpcla_halo_plan {
     void *win = nullptr;                       // this rank's window (ghost lives inside it) or null
     size_t win_bytes = 0;
     int nbuf = 1;                              // ghost buffers in the window
+    bool single_buffer = false;                // HPCLA_HALO_SINGLE_BUFFER: never double-buffer (begin/end consumers)
     uint64_t *flags = nullptr, *acks = nullptr;      // local control lines (stride WIN_LINE_U64)
     uint32_t *status = nullptr;                // local: nonzero after a spin timed out
     std::vector<hpcla::PeerMap> peer_maps;     // mapped windows of my neighbours (one per distinct rank)

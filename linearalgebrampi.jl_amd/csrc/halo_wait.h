@@ -65,9 +65,13 @@ struct HaloWait {
 // system-scope loads (no fence per poll), then ONE system-scope acquire drops this CU's stale lines;
 // the other waves read the ghosts only after the barrier (MI355X visibility rules: the acquire is per
 // CU, the barrier holds the other waves until it has completed).
-// Returns the INDEX of the ghost buffer of the exchange waited for (epoch % nbuf), as a wave-uniform value
-// (readfirstlane: the caller's pointer arithmetic then stays in scalar registers).  `reader` = this workgroup's
-// index among the exchange's epoch readers.
+// Returns the INDEX of the ghost buffer of the exchange waited for (epoch % nbuf) in the low bits, as a
+// wave-uniform value (readfirstlane: the caller's pointer arithmetic then stays in scalar registers), and
+// HALO_WAIT_TIMED_OUT in bit 31 when the spin gave up: the caller must then POISON what it would have computed
+// from the ghosts (NaN), so that an expired wait can never pass as a result -- the reference's MPI exchange
+// would block instead (src/vectors.jl:446).  `reader` = this workgroup's index among the exchange's epoch readers.
+constexpr uint32_t HALO_WAIT_TIMED_OUT = 0x80000000u;
+
 __device__ __forceinline__ uint32_t halo_wait_block(const HaloWait &w, uint32_t reader)
 {
     __shared__ uint32_t s_buf;
@@ -88,12 +92,14 @@ __device__ __forceinline__ uint32_t halo_wait_block(const HaloWait &w, uint32_t 
         }
         __atomic_thread_fence(__ATOMIC_ACQUIRE);           // system scope
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        s_buf = (uint32_t)(epoch % (uint64_t)w.nbuf);
+        s_buf = (uint32_t)(epoch % (uint64_t)w.nbuf) | (ok ? 0u : HALO_WAIT_TIMED_OUT);
         epoch_release(w.er, epoch, reader);                // the number is not needed any more (the DATA is:
     }                                                      // the producers learn that from the next step's acks)
     __syncthreads();
     return __builtin_amdgcn_readfirstlane(s_buf);
 }
+
+__device__ __forceinline__ double halo_poison() { return __builtin_nan(""); }
 
 // ---- producer side -----------------------------------------------------------------------------
 // One send neighbour of a plan, as the push code sees it (built at attach time, window.hip).
@@ -156,9 +162,21 @@ __device__ __forceinline__ void halo_push_block(const PushArgs &a, int b)
         return;
     }
     const PushTarget T = a.targets[t];
-    if (threadIdx.x == 0 && epoch > (uint64_t)T.nbuf)
-        spin_until_ge(T.ack, epoch - (uint64_t)T.nbuf, (int64_t)wall_clock64(), a.timeout_ticks, a.status);
+    // the consumer must have released the buffer this epoch overwrites.  If that wait EXPIRES the chunk is NOT
+    // stored and the epoch is NOT published: the consumer may still be reading the buffer, and its own wait for
+    // this epoch then expires too and poisons its result (halo_wait_block) -- a timeout can corrupt nothing.
+    __shared__ uint32_t s_ack_ok;
+    if (threadIdx.x == 0)
+        s_ack_ok = (epoch > (uint64_t)T.nbuf)
+                       ? (spin_until_ge(T.ack, epoch - (uint64_t)T.nbuf, (int64_t)wall_clock64(), a.timeout_ticks, a.status) ? 1u : 0u)
+                       : 1u;
     __syncthreads();
+    if (!s_ack_ok) {                                   // workgroup-uniform
+        // (the arrival counter is NOT bumped: no later chunk of this or any later epoch can then be "the last
+        //  one", so this neighbour never sees a flag from this plan again -- the plan is dead, status says so)
+        if (threadIdx.x == 0) epoch_release(a.er, epoch, (uint32_t)b);
+        return;
+    }
     double *dst = T.ghost + (int64_t)(epoch % (uint64_t)T.nbuf) * T.buf_stride;
     const I *idx = reinterpret_cast<const I *>(a.idx);
     const int w = a.w;

@@ -125,10 +125,20 @@ __global__ __launch_bounds__(RPB) __attribute__((amdgpu_num_sgpr(80), amdgpu_wav
     // boundary workgroup of a fused distributed launch (workgroup-uniform branch): the ghosts may be read once
     // every neighbour has published this step; the buffer of the step's epoch is computed here, uniformly, so
     // the loop below is the same code as in the plain kernel
-    if (WAIT && wait_ghosts)       // reader index: the plan's push workgroups come first (window.hip), then the boundary blocks
-        x_ghost = hw.ghost0 + (int64_t)halo_wait_block(hw, hw.first_wait_reader + (uint32_t)(blockIdx.x - push.n_blocks - bs.n_first)) * hw.buf_stride;
+    uint32_t waited = 0;
+    if (WAIT && wait_ghosts) {     // reader index: the plan's push workgroups come first (window.hip), then the boundary blocks
+        waited = halo_wait_block(hw, hw.first_wait_reader + (uint32_t)(blockIdx.x - push.n_blocks - bs.n_first));
+        x_ghost = hw.ghost0 + (int64_t)(waited & ~HALO_WAIT_TIMED_OUT) * hw.buf_stride;
+    }
     const int64_t r0 = blk * RPB;
     const int nr = (int)((nrows - r0) < RPB ? (nrows - r0) : RPB);
+    if (WAIT && (waited & HALO_WAIT_TIMED_OUT)) {
+        // the neighbours' values never arrived (wait expired): this block's rows are POISONED, never computed from
+        // stale ghosts (workgroup-uniform branch, taken before the row loop: no register held across it)
+        if ((int)threadIdx.x < nr) y[r0 + threadIdx.x] = halo_poison();
+        if (dot_partial && threadIdx.x == 0) dot_partial[blk] = halo_poison();
+        return;
+    }
 
     const int64_t p0 = (int64_t)rowptr[r0] - base;
     const int64_t p1 = (int64_t)rowptr[r0 + nr] - base;
@@ -240,10 +250,20 @@ __global__ __launch_bounds__(RPB) __attribute__((amdgpu_num_sgpr(80), amdgpu_wav
     // boundary workgroup of a fused distributed launch (workgroup-uniform branch): the ghosts may be read once
     // every neighbour has published this step; the buffer of the step's epoch is computed here, uniformly, so
     // the loop below is the same code as in the plain kernel
-    if (WAIT && wait_ghosts)       // reader index: the plan's push workgroups come first (window.hip), then the boundary blocks
-        x_ghost = hw.ghost0 + (int64_t)halo_wait_block(hw, hw.first_wait_reader + (uint32_t)(blockIdx.x - push.n_blocks - bs.n_first)) * hw.buf_stride;
+    uint32_t waited = 0;
+    if (WAIT && wait_ghosts) {     // reader index: the plan's push workgroups come first (window.hip), then the boundary blocks
+        waited = halo_wait_block(hw, hw.first_wait_reader + (uint32_t)(blockIdx.x - push.n_blocks - bs.n_first));
+        x_ghost = hw.ghost0 + (int64_t)(waited & ~HALO_WAIT_TIMED_OUT) * hw.buf_stride;
+    }
     const int64_t r0 = blk * RPB;
     const int nr = (int)((nrows - r0) < RPB ? (nrows - r0) : RPB);
+    if (WAIT && (waited & HALO_WAIT_TIMED_OUT)) {
+        // the neighbours' values never arrived (wait expired): this block's rows are POISONED, never computed from
+        // stale ghosts (workgroup-uniform branch, taken before the row loop: no register held across it)
+        if ((int)threadIdx.x < nr) y[r0 + threadIdx.x] = halo_poison();
+        if (dot_partial && threadIdx.x == 0) dot_partial[blk] = halo_poison();
+        return;
+    }
 
     const int64_t p0 = (int64_t)rowptr[r0] - base;
     const int64_t p1 = (int64_t)rowptr[r0 + nr] - base;

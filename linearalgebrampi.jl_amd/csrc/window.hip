@@ -22,8 +22,12 @@
 //     overwrite values a slow neighbour is still reading, for symmetric and asymmetric patterns alike.
 //
 // The step epochs live in device memory (halo_wait.h), so distributed steps are HIP-graph capturable.
-// Every spin is bounded (HPCLA_PUSH_TIMEOUT_S, default 20 s): on expiry the kernel sets the plan's
-// status word and carries on, so a grid always drains; hpcla_halo_status reports it.
+// Every spin is bounded (HPCLA_PUSH_TIMEOUT_S, default 300 s -- long enough to WAIT for a slow neighbour the
+// way a blocking MPI receive would): on expiry the kernel sets the plan's sticky status word, POISONS what the
+// expired wait would have fed (boundary rows / dot partials / all-reduce results become NaN, a push whose ack
+// wait expired stores nothing and publishes nothing) and carries on, so a grid always drains and a timeout can
+// neither corrupt a neighbour nor pass as a result; hpcla_halo_status / hpcla_comm_status report it, and the
+// host layers check them wherever a NaN scalar reaches the host.
 #include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
@@ -56,8 +60,12 @@ int64_t spin_timeout_ticks()
 {
     static const int64_t ticks = [] {
         const char *e = getenv("HPCLA_PUSH_TIMEOUT_S");
-        double s = e ? atof(e) : 20.0;
-        if (!(s > 0.0)) s = 20.0;
+        // default 300 s: a slow neighbour (host I/O, a plan build on one rank, a debugger) must be WAITED for like a
+        // blocking MPI receive would (src/vectors.jl:446); the bound only exists so that a grid drains when a peer
+        // has died.  Expiry poisons the result (NaN) and sets the sticky status word; tests and bench.py set
+        // shorter bounds.
+        double s = e ? atof(e) : 300.0;
+        if (!(s > 0.0)) s = 300.0;
         return (int64_t)(s * 1.0e8);           // wall_clock64 runs at 100 MHz
     }();
     return ticks;
@@ -181,9 +189,10 @@ int push_plan_alloc(hpcla_halo_plan *p)
     const size_t ctrl = halo_ctrl_bytes(nf, na);
     const size_t buf = halo_buf_bytes((uint64_t)p->n_ghost, (uint32_t)p->width);
     // vectors (the fused SpMV computes the buffer of its epoch in the kernel): two buffers, one step of slack
-    // between neighbours; dense ghost rows (their consumers take the ghost pointer from the host): one buffer,
-    // the ack wait orders producer and consumer strictly
-    p->nbuf = (p->width == 1 && (int64_t)buf <= WIN_DOUBLE_BUFFER_MAX) ? 2 : 1;
+    // between neighbours; dense ghost rows -- of ANY width, a one-column B included (HPCLA_HALO_SINGLE_BUFFER) --
+    // whose consumers take the ghost pointer from the host between halo_begin and halo_end: one buffer, the ack
+    // wait orders producer and consumer strictly
+    p->nbuf = (p->width == 1 && !p->single_buffer && (int64_t)buf <= WIN_DOUBLE_BUFFER_MAX) ? 2 : 1;
     p->win_bytes = ctrl + buf * p->nbuf;
     int rc = window_alloc(&p->win, p->win_bytes, p->width == 1);
     if (rc) return rc;
@@ -221,9 +230,15 @@ __global__ __launch_bounds__(PUSH_THREADS) void halo_push_kernel(PushArgs a)
 
 // standalone consumer (hpcla_halo_end, SpMM boundary blocks): kernels launched after it on the same
 // stream start behind its acquire
-__global__ __launch_bounds__(64) void halo_wait_kernel(HaloWait w)
+// On an expired wait the ghost buffer is filled with NaN (failure path only; the single workgroup takes its
+// time): the kernels behind it then compute NaN from it instead of a plausible result from stale rows.
+__global__ __launch_bounds__(64) void halo_wait_kernel(HaloWait w, int64_t ghost_doubles)
 {
-    halo_wait_block(w, w.first_wait_reader);
+    const uint32_t waited = halo_wait_block(w, w.first_wait_reader);
+    if (waited & HALO_WAIT_TIMED_OUT) {
+        double *g = const_cast<double *>(w.ghost0) + (int64_t)(waited & ~HALO_WAIT_TIMED_OUT) * w.buf_stride;
+        for (int64_t i = threadIdx.x; i < ghost_doubles; i += 64) g[i] = halo_poison();
+    }
 }
 
 // n_wait_readers: waiting workgroups of the exchange (boundary blocks of the fused launch, or 1 for the
@@ -296,7 +311,7 @@ int push_post(hpcla_halo_plan *p, const double *x, int64_t n_wait_readers, void 
 // exchange's epoch readers)
 int push_wait_kernel_launch(hpcla_halo_plan *p, void *stream)
 {
-    halo_wait_kernel<<<1, 64, 0, as_stream(stream)>>>(push_wait_args(p, 1));
+    halo_wait_kernel<<<1, 64, 0, as_stream(stream)>>>(push_wait_args(p, 1), p->n_ghost * (int64_t)p->width);
     HPCLA_CHECK_LAUNCH();
     return HPCLA_OK;
 }
@@ -347,10 +362,14 @@ __global__ __launch_bounds__(64) void window_allreduce_kernel(uint64_t *const *_
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_store(dst, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         const uint64_t *src = my_slots + (parity * (uint64_t)nranks + (uint64_t)j) * WIN_LINE_U64;
-        spin_until_ge(src, epoch, (int64_t)wall_clock64(), timeout, status);
+        const bool arrived = spin_until_ge(src, epoch, (int64_t)wall_clock64(), timeout, status);
+        // acquire between the epoch poll and the payload loads (system scope: the payload came over xGMI); the
+        // loads below are relaxed atomics, which the fence orders behind the poll in the memory model too
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
         for (int c = 0; c < count; ++c)
-            s_val[j][c] = __hip_atomic_load(reinterpret_cast<const double *>(src + 1 + c), __ATOMIC_RELAXED,
-                                            __HIP_MEMORY_SCOPE_SYSTEM);
+            s_val[j][c] = arrived ? __hip_atomic_load(reinterpret_cast<const double *>(src + 1 + c), __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_SYSTEM)
+                                  : __builtin_nan("");     // a partial that never arrived poisons the result
     }
     __syncthreads();
     if (j < count) {

@@ -289,35 +289,27 @@ def clear_spmm_cache() -> None:
     _spmm_halo_cache.clear()
 
 
-def spmm(A, B: HPCMatrix) -> HPCMatrix:
-    """``A * B`` (src/sparse.jl:2391-2413): result has A's row partition and B's backend."""
+def _spmm_plan(A, B: HPCMatrix):
+    """(vector plan, width-k exchange entry) for ``A * B``: the vector plan for (A, B's row partition) provides the
+    neighbour lists, the split colval and the blocks; the width-k halo plan hangs off the same key plus k.
+    Entry = (halo handle | None, interior blocks, boundary blocks, send_idx, colval_split, ghost pointer, n_ghost rows,
+    send rows).  Collective on first use."""
     from .sparse import get_vector_plan
     from .vectors import HPCVector
     torch = _torch()
-    assert_backends_compatible(A.backend, B.backend)
     backend = A.backend
     dev = backend.torch_device
     k = int(B.A.shape[1])
-    # the vector plan for (A, B's row partition) provides neighbour lists, split colval, blocks
     probe = HPCVector(compute_partition_hash(B.row_partition), B.row_partition,
                       B.A[:, 0] if k > 0 else torch.empty(0, dtype=torch.float64, device=dev), backend)
     plan = get_vector_plan(A, probe)
     if int(B.A.shape[0]) != plan.n_own:
         raise ValueError("A*B: B's local rows do not match its row partition")
-    C = torch.empty((A.nrows_local, k), dtype=torch.float64, device=dev)
-    out = HPCMatrix(plan.result_partition, uniform_partition(k, comm_size(backend.comm)), C, backend)
-    if k == 0:                       # (a rank without local rows still takes part in the exchange below)
-        return out
+    nranks = comm_size(backend.comm)
+    if nranks == 1 or k == 0:
+        return plan, None
     s = current_stream_ptr()
     sfx = "i64" if plan.is_i64 else "i32"
-    Bc = B.A.contiguous()
-    nranks = comm_size(backend.comm)
-    if nranks == 1:
-        # every column owned: split indices == offsets into B's local rows
-        _capi.call(f"hpcla_spmm_csr_f64_{sfx}", dptr(A.rowptr_target), dptr(plan.colval_split),
-                   dptr(A.nzval), dptr(Bc), k, _capi.LAYOUT_ROW, dptr(C), k, _capi.LAYOUT_ROW,
-                   A.nrows_local, A.nnz, k, 0, s)
-        return out
     key = (A._ensure_hash(), probe.structural_hash, k)
     _spmm_backends[id(backend)] = backend
     ent = _spmm_halo_cache.get(key)
@@ -332,7 +324,7 @@ def spmm(A, B: HPCMatrix) -> HPCMatrix:
         tdt = torch.int64 if plan.is_i64 else torch.int32
         if not plan.has_halo:
             attach_halo_windows(backend, None)          # collective: the other ranks' plans are attaching
-            ent = _spmm_halo_cache[key] = (None, None, None, None, plan.colval_split)
+            ent = _spmm_halo_cache[key] = (None, None, None, None, plan.colval_split, None, 0, 0, (0, 0))
         else:
             send_indices, recv_counts_l, cmap = whole_slice_lists(h, A.col_indices, B.row_partition, wish, granted)
             n_send, n_recv = len(h.send_rank_ids), len(h.recv_rank_ids)
@@ -353,9 +345,13 @@ def spmm(A, B: HPCMatrix) -> HPCMatrix:
                 colval_split = plan.colval_split
             halo = ctypes.c_void_p()
             torch.cuda.current_stream().synchronize()
-            _capi.check("hpcla_halo_plan_create", _capi.load().hpcla_halo_plan_create(
+            # SINGLE_BUFFER: this plan is driven through halo_begin / halo_end and its consumers take the ghost
+            # pointer from the host while the exchange is still in flight -- a width-1 plan (one-column B) must
+            # not be double-buffered like the fused SpMV's vector plans (round-2 defect: k == 1 read the buffer
+            # of the PREVIOUS exchange)
+            _capi.check("hpcla_halo_plan_create_ex", _capi.load().hpcla_halo_plan_create_ex(
                 ctypes.byref(halo), backend.rccl, n_send, send_ranks, send_counts, dptr(send_idx),
-                1 if plan.is_i64 else 0, n_recv, recv_ranks, recv_counts, k))
+                1 if plan.is_i64 else 0, n_recv, recv_ranks, recv_counts, k, _capi.HALO_SINGLE_BUFFER))
             bp = np.asarray(B.row_partition, dtype=np.int64)
             wprobe = (plan.n_own, k, [(r, np.arange(bp[r + 1] - bp[r]) if wish[r] else A.col_indices[perm] - bp[r])
                                      for r, perm in zip(h.recv_rank_ids, h.recv_perm)])
@@ -369,19 +365,49 @@ def spmm(A, B: HPCMatrix) -> HPCMatrix:
             flags = flags_i != 0
             interior = torch.nonzero(~flags).flatten().to(torch.int32).contiguous()
             boundary = torch.nonzero(flags).flatten().to(torch.int32).contiguous()
-            ent = (halo, interior, boundary, send_idx, colval_split)
+            # the ghost buffer of a single-buffered plan is a constant: fetched once, at plan time
+            ghost, ng = ctypes.c_void_p(), ctypes.c_int64()
+            _capi.call("hpcla_halo_ghost_ptr", halo, ctypes.byref(ghost), ctypes.byref(ng))
+            peers = (sum(1 for c in recv_counts_l if c), sum(1 for i in send_indices if len(i)))
+            ent = (halo, interior, boundary, send_idx, colval_split, ghost, int(ng.value),
+                   int(sum(len(i) for i in send_indices)), peers)
             _spmm_halo_cache[key] = ent
-    if ent[0] is None:
+    return plan, ent
+
+
+def spmm_exchange_bytes(A, B: HPCMatrix):
+    """(bytes received, bytes sent, peers received from, peers sent to) by THIS rank per ``A * B``: the ghost rows of
+    B that cross xGMI (8k bytes per row) -- the communication side of config 5's roofline."""
+    k = int(B.A.shape[1])
+    _, ent = _spmm_plan(A, B)
+    if ent is None or ent[0] is None:
+        return 0, 0, 0, 0
+    return ent[6] * k * 8, ent[7] * k * 8, ent[8][0], ent[8][1]
+
+
+def spmm(A, B: HPCMatrix) -> HPCMatrix:
+    """``A * B`` (src/sparse.jl:2391-2413): result has A's row partition and B's backend."""
+    torch = _torch()
+    assert_backends_compatible(A.backend, B.backend)
+    backend = A.backend
+    dev = backend.torch_device
+    k = int(B.A.shape[1])
+    plan, ent = _spmm_plan(A, B)
+    C = torch.empty((A.nrows_local, k), dtype=torch.float64, device=dev)
+    out = HPCMatrix(plan.result_partition, uniform_partition(k, comm_size(backend.comm)), C, backend)
+    if k == 0:                       # (a rank without local rows still takes part in the exchange below)
+        return out
+    s = current_stream_ptr()
+    sfx = "i64" if plan.is_i64 else "i32"
+    Bc = B.A.contiguous()
+    if ent is None or ent[0] is None:
+        # every column owned: split indices == offsets into B's local rows
         _capi.call(f"hpcla_spmm_csr_f64_{sfx}", dptr(A.rowptr_target), dptr(plan.colval_split),
                    dptr(A.nzval), dptr(Bc), k, _capi.LAYOUT_ROW, dptr(C), k, _capi.LAYOUT_ROW,
                    A.nrows_local, A.nnz, k, 0, s)
         return out
-    halo, interior, boundary, _, colval_split = ent
-    ghost = ctypes.c_void_p()
-    ng = ctypes.c_int64()
+    halo, interior, boundary, _, colval_split, ghost = ent[:6]
     _capi.call("hpcla_halo_begin", halo, dptr(Bc), s)
-    # after begin: with the push transport the ghost window is double-buffered per exchange
-    _capi.call("hpcla_halo_ghost_ptr", halo, ctypes.byref(ghost), ctypes.byref(ng))
     if interior.numel():
         _capi.call(f"hpcla_spmm_split_f64_{sfx}", dptr(A.rowptr_target), dptr(colval_split),
                    dptr(A.nzval), dptr(Bc), k, ghost, k, plan.n_own, dptr(C), k, A.nrows_local,

@@ -267,9 +267,45 @@ def clear_plan_cache() -> None:
     """``clear_plan_cache!`` (src/HPCLinearAlgebra.jl:181-201): plans are freed only here, never
     by a finaliser (a finaliser must not issue device/collective work)."""
     _quiesce([p.backend for p in _vector_plan_cache.values()])
+    dead = [p for p in _vector_plan_cache.values() if p.timed_out()]
     for p in _vector_plan_cache.values():
         p.destroy()
     _vector_plan_cache.clear()
+    if dead:
+        import warnings
+        warnings.warn(f"clear_plan_cache: {len(dead)} plan(s) had a timed-out exchange (their results were NaN)")
+
+
+class ExchangeTimeout(RuntimeError):
+    """A peer-window exchange or all-reduce gave up waiting for a neighbour (HPCLA_PUSH_TIMEOUT_S): every result
+    that depended on it has been poisoned with NaN by the kernels; the plans involved are dead."""
+
+
+def check_exchange_health(backend=None, always: bool = False) -> None:
+    """Raise ExchangeTimeout if the backend's communicator or any cached plan reports an expired spin.
+    Called wherever a NaN scalar reaches the host (dot / norm / CG history read-backs): the device poisons the
+    result of an expired wait, this turns the poison into an error that says what happened -- the reference's
+    MPI exchange would have blocked instead (src/vectors.jl:446).  Each status is a synchronising 4-byte read,
+    so the good path never pays for it."""
+    bad = []
+    if backend is not None and getattr(backend, "rccl", None) and comm_size(backend.comm) > 1:
+        flag = ctypes.c_int(0)
+        _capi.call("hpcla_comm_status", backend.rccl, ctypes.byref(flag))
+        if flag.value:
+            bad.append("window all-reduce")
+    for plan in _vector_plan_cache.values():
+        if plan.timed_out():
+            bad.append("halo plan of a sparse matrix")
+    from . import dense
+    for ent in dense._spmm_halo_cache.values():
+        if ent[0]:
+            flag = ctypes.c_int(0)
+            _capi.call("hpcla_halo_status", ent[0], ctypes.byref(flag))
+            if flag.value:
+                bad.append("SpMM ghost-row plan")
+    if bad:
+        raise ExchangeTimeout("exchange timed out (" + ", ".join(sorted(set(bad))) + "): a neighbour did not publish its "
+                              "values within HPCLA_PUSH_TIMEOUT_S; the affected results are NaN")
 
 
 def _quiesce(backends) -> None:

@@ -235,6 +235,15 @@ def HPCVector_local(v_local, backend: HPCBackend) -> HPCVector:
     return HPCVector(compute_partition_hash(partition), partition, v_local, backend)
 
 
+def _host_scalar(t, backend) -> float:
+    """Read a device scalar; a NaN may be the poison of an expired exchange wait -- ask before returning it."""
+    v = float(t.item())
+    if v != v:
+        from .sparse import check_exchange_health
+        check_exchange_health(backend)
+    return v
+
+
 # ---- reductions -----------------------------------------------------------------------------------
 def _reduce(kind: str, x: HPCVector, y: Optional[HPCVector], out=None):
     """Launch the local reduction + RCCL all-reduce; returns the 1-element device tensor."""
@@ -261,21 +270,21 @@ def vsum(v: HPCVector, out=None):
     work, scal = _Scratch.get(v.v.device)
     r = out if out is not None else scal[:1]
     _capi.call("hpcla_sum_f64", v.backend.rccl, dptr(v.v), v.local_length, dptr(r), dptr(work), current_stream_ptr())
-    return r if out is not None else float(r.item())
+    return r if out is not None else _host_scalar(r, v.backend)
 
 
 def prod(v: HPCVector) -> float:
     """``prod(v)`` (src/vectors.jl:853-858): local product (1 for an empty part), then an all-reduce with ``*``."""
     work, scal = _Scratch.get(v.v.device)
     _capi.call("hpcla_prod_f64", v.backend.rccl, dptr(v.v), v.local_length, dptr(scal[:1]), dptr(work), current_stream_ptr())
-    return float(scal[:1].item())
+    return _host_scalar(scal[:1], v.backend)
 
 
 def _maxval(v: HPCVector, negate: int) -> float:
     work, scal = _Scratch.get(v.v.device)
     _capi.call("hpcla_maxval_f64", v.backend.rccl, dptr(v.v), v.local_length, negate, dptr(scal[:1]), dptr(work),
                current_stream_ptr())
-    return float(scal[:1].item())
+    return _host_scalar(scal[:1], v.backend)
 
 
 def maximum(v: HPCVector) -> float:
@@ -293,7 +302,7 @@ def dot(x: HPCVector, y: HPCVector, out=None):
     (1-element device tensor) is given, leaves the result on the device and returns ``out``."""
     y = x._aligned(y)
     r = _reduce("dot", x, y, out)
-    return r if out is not None else float(r.item())
+    return r if out is not None else _host_scalar(r, x.backend)
 
 
 def norm(v: HPCVector, p: float = 2, out=None):
@@ -303,17 +312,17 @@ def norm(v: HPCVector, p: float = 2, out=None):
     the caller's), for p=1 / Inf the norm itself, for any other p the sum of |x|^p."""
     if p == 2:
         r = _reduce("nrm2sq", v, None, out)
-        return r if out is not None else math.sqrt(float(r.item()))
+        return r if out is not None else math.sqrt(_host_scalar(r, v.backend))
     if p == 1:
         r = _reduce("asum", v, None, out)
-        return r if out is not None else float(r.item())
+        return r if out is not None else _host_scalar(r, v.backend)
     if p == math.inf:
         r = _reduce("amax", v, None, out)
-        return r if out is not None else float(r.item())
+        return r if out is not None else _host_scalar(r, v.backend)
     if not (p > 0):
         raise ValueError("norm: p must be positive")
     work, scal = _Scratch.get(v.v.device)                                        # general p (:774-779)
     r = out if out is not None else scal[:1]
     _capi.call("hpcla_powsum_f64", v.backend.rccl, dptr(v.v), v.local_length, float(p), dptr(r), dptr(work),
                current_stream_ptr())
-    return r if out is not None else float(r.item()) ** (1.0 / p)
+    return r if out is not None else _host_scalar(r, v.backend) ** (1.0 / p)

@@ -166,11 +166,19 @@ def main():
         waited = time.perf_counter() - t0
         st = ctypes.c_int(0)
         capi.call("hpcla_halo_status", plan, ctypes.byref(st))
-        limit = float(os.environ.get("HPCLA_PUSH_TIMEOUT_S", "20"))
+        limit = float(os.environ.get("HPCLA_PUSH_TIMEOUT_S", "300"))
         assert st.value == 1, "the orphan wait did not report a timeout"
         assert 0.5 * limit <= waited <= limit + 5.0, f"orphan wait took {waited:.2f} s (limit {limit} s)"
+        # ... and the expired wait POISONED the ghost buffer of its epoch: whatever is launched behind it computes NaN,
+        # never a plausible result from stale values
+        gp, gn = ctypes.c_void_p(), ctypes.c_int64(0)
+        capi.call("hpcla_halo_ghost_ptr", plan, ctypes.byref(gp), ctypes.byref(gn))
+        ghost = torch.empty(int(gn.value), dtype=torch.float64, device="cuda")
+        capi.call("hpcla_scale_f64", 1.0, gp, ctypes.c_void_p(ghost.data_ptr()), int(gn.value), s)     # copy out through the library
+        torch.cuda.synchronize()
+        assert bool(torch.isnan(ghost).all()), "the expired wait left stale values in the ghost buffer"
         capi.call("hpcla_halo_plan_destroy", plan)
-        print(f"orphan wait gave up after {waited:.2f} s, status flagged")
+        print(f"orphan wait gave up after {waited:.2f} s, status flagged, ghost poisoned")
 
     print("halo self-exchange OK")
 

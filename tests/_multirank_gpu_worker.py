@@ -45,6 +45,9 @@ def main():
         flat = B.comm_allgather(comm, np.ascontiguousarray(v, dtype=np.float64).view(np.int64))
         return flat.view(np.float64)
 
+    if os.environ.get("HPCLA_MR_TIMEOUT_CASE", "") == "1":
+        return timeout_case(torch, dist, hp, orc, rank, nranks)
+
     # HPCLA_MR_TYPES=i32,i64 (default both): the test file gives the larger rank counts one index type each --
     # ranks that share a GPU time-slice it, so the suite's wall time grows with ranks x cases
     types = [t for t in os.environ.get("HPCLA_MR_TYPES", "i32,i64").split(",") if t]
@@ -171,6 +174,13 @@ def main():
                 for fused in (True, False):
                     xc, hist = hp.cg_fixed_iterations(A, b, 8, fused=fused)
                     assert np.allclose(hist, hist_ref, rtol=1e-12, atol=0), (tag, fused, hist, hist_ref)
+                    if fused:
+                        # all iterations enqueued by ONE library call (hpcla_cg_iterations_*, the default) vs one
+                        # call per kernel from Python: same launches, same arguments, same bits
+                        xp_, hist_p = hp.cg_fixed_iterations(A, b, 8, fused=True, native_loop=False)
+                        assert hist_p == hist, (tag, "python-loop CG differs from the native loop", hist_p, hist)
+                        assert np.array_equal(xp_.local_values(), xc.local_values())
+                        xc, hist = hp.cg_fixed_iterations(A, b, 8, fused=True)      # (xp_ shares no storage with xc)
                     # the same iterations replayed from a captured HIP graph: the push-mode step keeps its epoch
                     # in device memory, so a distributed step is capturable; bit-identical to the eager loop
                     xg2, hist_g = hp.cg_fixed_iterations(A, b, 8, fused=fused, graph=True)
@@ -187,18 +197,39 @@ def main():
                 pAp_ref = orc.dot([xg], [y_all])
                 assert abs(out.item() - pAp_ref) <= 1e-12 * float(np.abs(xg) @ np.abs(y_all)), (out.item(), pAp_ref)
 
-            # distributed SpMM: k dense columns, row-major on the device
-            for k in (16, 3):
+            # distributed SpMM: k dense columns, row-major on the device.  k = 1: a width-1 exchange plan driven
+            # through halo_begin / halo_end -- it must be SINGLE-buffered (round-2 defect: the ghost pointer was
+            # taken before the exchange completed and named the PREVIOUS exchange's buffer); two DIFFERENT B in a
+            # row, without a host sync in between, so that a stale buffer cannot pass
+            for k in (16, 3, 1):
                 Bg = orc.fill_uniform(0, ng * k, 4711).reshape(ng, k)
                 Bl = torch.from_numpy(np.ascontiguousarray(Bg[lo:hi])).cuda()
                 Bm = hp.HPCMatrix_local(Bl, backend)
+                Bg2 = orc.fill_uniform(0, ng * k, 1234).reshape(ng, k) - 0.5
+                Bm2 = hp.HPCMatrix_local(torch.from_numpy(np.ascontiguousarray(Bg2[lo:hi])).cuda(), backend)
                 C = A @ Bm
+                C2 = A @ Bm2                                     # cached plan, second exchange, different values
+                C3 = A @ Bm
                 torch.cuda.synchronize()
                 Cw = orc.spmm(rows.rowptr.astype(Ti), cv.astype(Ti), rows.vals, np.ascontiguousarray(Bg[ci]))
+                Cw2 = orc.spmm(rows.rowptr.astype(Ti), cv.astype(Ti), rows.vals, np.ascontiguousarray(Bg2[ci]))
                 assert np.array_equal(C.A.cpu().numpy(), Cw), f"{tag} {name}: A*B (k={k}) differs"
-                C2 = A @ Bm                                      # cached plan, second exchange
-                torch.cuda.synchronize()
-                assert np.array_equal(C2.A.cpu().numpy(), Cw), f"{tag} {name}: second A*B (k={k}) differs"
+                assert np.array_equal(C2.A.cpu().numpy(), Cw2), f"{tag} {name}: second A*B (k={k}, other B) differs"
+                assert np.array_equal(C3.A.cpu().numpy(), Cw), f"{tag} {name}: third A*B (k={k}) differs"
+                if os.environ.get("HPCLA_SPMM_ORDER_TEST", "") == "1":
+                    # opt-in panel order (exchange overlapped chunk by chunk): a different summation ORDER, so
+                    # BASELINE's 1e-12 relative and the componentwise |A||B| bound of SURVEY 8d instead of bits
+                    os.environ["HPCLA_SPMM_ORDER"] = "panel"
+                    try:
+                        Cp = (A @ Bm2).A.cpu().numpy()
+                        Cp1 = (A @ Bm).A.cpu().numpy()
+                    finally:
+                        os.environ.pop("HPCLA_SPMM_ORDER", None)
+                    for got_p, want_p, Bref in ((Cp, Cw2, Bg2), (Cp1, Cw, Bg)):
+                        bound = orc.spmm(rows.rowptr.astype(Ti), cv.astype(Ti), np.abs(rows.vals), np.ascontiguousarray(np.abs(Bref[ci])))
+                        assert np.all(np.abs(got_p - want_p) <= 1e-12 * bound), f"{tag} {name}: panel-order A*B (k={k}) outside the |A||B| bound"
+                        nrm = np.linalg.norm(want_p)
+                        assert np.linalg.norm(got_p - want_p) <= 1e-12 * max(nrm, 1e-300), f"{tag} {name}: panel-order A*B (k={k}) norm error"
         # several cached plans in flight at once: products of DIFFERENT matrices interleaved without a host sync
         # (every plan has its own windows, epochs and acks; their pushes and waits must not disturb each other)
         for _ in range(4):
@@ -218,6 +249,55 @@ def main():
         print(f"{tag} OK", flush=True)
     dist.barrier()
     dist.destroy_process_group()
+
+
+def timeout_case(torch, dist, hp, orc, rank, nranks):
+    """An exchange whose neighbour never shows up (HPCLA_PUSH_TIMEOUT_S = 2): rank 0 takes one step more than the
+    other ranks.  Its boundary workgroups give up after the bound and the step must be IMPOSSIBLE TO MISS: the rows
+    that needed ghost values are NaN (never computed from stale ghosts), interior rows are right, the plan's status
+    is set, and a scalar that reaches the host raises ExchangeTimeout.  The grid drains (the process exits)."""
+    Ti = np.int32
+    backend = hp.backend_rocm_mpi(np.float64, Ti)
+    nx, ny = 512, 6 * nranks + 3
+    n = nx * ny
+    rp = orc.uniform_partition(n, nranks)
+    lo, hi = int(rp[rank]), int(rp[rank + 1])
+    rows = orc.poisson2d_rows(nx, ny, lo, hi)
+    A = hp.HPCSparseMatrix_local(rows.rowptr, rows.colidx, rows.vals, n, backend)
+    xg = orc.fill_uniform(0, n, orc.SEED_X)
+    x = hp.HPCVector.from_global(xg, backend, partition=rp)
+    ci, cv = orc.compress_columns(rows)
+    want = orc.spmv(rows.rowptr.astype(Ti), cv.astype(Ti), rows.vals, xg[ci])
+    y = A @ x                                        # a good step on every rank
+    torch.cuda.synchronize()
+    assert np.array_equal(y.local_values(), want)
+    plan = hp.get_vector_plan(A, x)
+    assert plan.push, "timeout case needs the push transport"
+    dist.barrier()
+    if rank == 0:
+        y.v.zero_()
+        hp.mul_(y, A, x)                             # nobody else takes this step
+        torch.cuda.synchronize()                     # returns after ~HPCLA_PUSH_TIMEOUT_S: the grid drained
+        got = y.local_values()
+        bad = np.isnan(got)
+        assert bad.any(), "a timed-out wait left no NaN in y"
+        assert np.array_equal(got[~bad], want[~bad]), "rows that needed no ghost must still be right"
+        ghost_rows = np.flatnonzero(np.diff(rows.rowptr) > 0)
+        needs_ghost = np.array([np.any((rows.colidx[rows.rowptr[r]:rows.rowptr[r + 1]] < lo) |
+                                       (rows.colidx[rows.rowptr[r]:rows.rowptr[r + 1]] >= hi)) for r in ghost_rows])
+        assert bad[ghost_rows[needs_ghost]].all(), "a row that needs ghost values was computed from stale ghosts"
+        assert plan.timed_out()
+        try:
+            hp.dot(y, y)
+        except hp.ExchangeTimeout as exc:
+            print(f"[rank 0] raised as it must: {exc}", flush=True)
+        else:
+            raise AssertionError("dot of a poisoned vector returned without raising ExchangeTimeout")
+    dist.barrier()
+    print(f"[rank {rank}/{nranks}] timeout case OK", flush=True)
+    # the plan is dead: no collective teardown of its windows (a dead plan's peers may not show up either)
+    dist.destroy_process_group()
+    os._exit(0)
 
 
 if __name__ == "__main__":

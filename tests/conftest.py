@@ -9,6 +9,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# the library's own default spin bound is 300 s (a slow neighbour is waited for like a blocking MPI receive); a test
+# run must never sit that long behind a defect
+os.environ.setdefault("HPCLA_PUSH_TIMEOUT_S", "30")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -53,10 +53,9 @@ def test_guarded_breakdown_watchdog_prints_the_result_and_exits():
             f"sys.path.insert(0, {ROOT!r})\n"
             "import bench\n"
             "res = {'metric': 'm', 'value': 1.0}\n"
-            "bench._guarded_breakdown(lambda: time.sleep(30), res, True, 1)\n"
+            "bench._guarded_breakdown(lambda: time.sleep(30), res, True, 1, 0.3)\n"
             "print('not reached')\n")
-    env = dict(os.environ, HPCLA_BENCH_BREAKDOWN_TIMEOUT_S="0.3")
-    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60, env=env)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
     assert out.returncode == 0, out.stderr[-500:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == 1 and "not reached" not in out.stdout
@@ -66,6 +65,73 @@ def test_guarded_breakdown_watchdog_prints_the_result_and_exits():
     code2 = ("import sys\n"
              f"sys.path.insert(0, {ROOT!r})\n"
              "import bench\n"
-             "print(bench._guarded_breakdown(lambda: {'modes': {}}, {'value': 2.0}, True, 1))\n")
+             "print(bench._guarded_breakdown(lambda: {'modes': {}}, {'value': 2.0}, True, 1, 30.0))\n")
     out2 = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, timeout=60)
     assert out2.returncode == 0 and out2.stdout.strip() == "{'modes': {}}", (out2.stdout, out2.stderr[-300:])
+
+
+# ---- the run's time budget (benchmarks/budget.py): every guard derives from ONE outer limit ------------------
+class _Clock:
+    def __init__(self, t=1000.0):
+        self.t = t
+
+    def __call__(self):
+        return self.t
+
+
+def _budget(outer=600.0, **kw):
+    import io
+    from benchmarks.budget import Budget
+    clk = _Clock()
+    return Budget(outer_s=outer, t0=clk.t, clock=clk, out=io.StringIO(), **kw), clk
+
+
+def test_budget_guards_sum_to_less_than_the_outer_limit():
+    """Round 2's guards (RCCL init 180 s + comparison 240 s, launcher 1500 s) could outlast the driver's 600 s.
+    Now: RCCL init <= 60 s, comparison <= 90 s, launcher = outer - 30 s, for any outer limit."""
+    for outer in (120.0, 300.0, 600.0, 1200.0):
+        b, _ = _budget(outer)
+        assert b.rccl_init_timeout() <= 60.0
+        assert b.comparison_timeout() <= 90.0
+        assert b.launcher_timeout() == max(outer - 30.0, 30.0) < outer
+        assert b.rccl_init_timeout() + b.comparison_timeout() + b.spin_timeout() < outer - 30.0 or outer <= 120.0
+    env = {}
+    b, _ = _budget(600.0)
+    b.export_guards(env)
+    assert float(env["HPCLA_RCCL_INIT_TIMEOUT_S"]) <= 60 and float(env["HPCLA_PUSH_TIMEOUT_S"]) <= 20
+    assert float(env["HPCLA_BENCH_T0"]) == b.t0
+    env2 = {"HPCLA_RCCL_INIT_TIMEOUT_S": "7"}                   # an explicit setting wins
+    b.export_guards(env2)
+    assert env2["HPCLA_RCCL_INIT_TIMEOUT_S"] == "7"
+
+
+def test_budget_skips_optional_stages_when_time_is_short():
+    from benchmarks.budget import ESTIMATE_S, RESERVE_S
+    b, clk = _budget(600.0)
+    assert b.allows("strong_scaling") and b.allows("poisson3d_cg") and not b.skipped
+    clk.t += 600.0 - RESERVE_S - ESTIMATE_S["strong_scaling_n1"] + 1.0      # one second short of the estimate
+    assert not b.allows("strong_scaling_n1")
+    assert b.allows("packed")                                               # a cheaper stage still fits
+    clk.t += 100.0
+    assert not b.allows("comparison") and b.comparison_timeout() == 0.0
+    assert b.skipped == ["strong_scaling_n1", "comparison"]
+    assert "SKIP strong_scaling_n1" in b.out.getvalue()
+
+
+def test_budget_origin_travels_from_the_launching_parent(monkeypatch):
+    """`python bench.py --gpus N` spawns its ranks: their clocks start at the PARENT's start (HPCLA_BENCH_T0), so
+    the spawn, the imports and the rendezvous count against the same limit."""
+    from benchmarks.budget import Budget
+    clk = _Clock(5000.0)
+    monkeypatch.setenv("HPCLA_BENCH_T0", "4900.0")
+    monkeypatch.setenv("HPCLA_BENCH_OUTER_LIMIT_S", "200")
+    b = Budget(clock=clk)
+    assert b.outer == 200.0 and abs(b.elapsed() - 100.0) < 1e-9
+    assert abs(b.remaining() - 70.0) < 1e-9 and b.launcher_timeout() == 170.0
+
+
+def test_bench_main_derives_the_launcher_limit_from_the_outer_limit():
+    """The self-launching parent must never outlive the driver's limit (round 2: 1500 s inside 600 s)."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert '"1500"' not in src and "budget.launcher_timeout()" in src
+    assert "HPCLA_BENCH_BREAKDOWN_TIMEOUT_S\", \"240\"" not in src

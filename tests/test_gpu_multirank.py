@@ -42,6 +42,18 @@ def test_push_transport_ranks_exchange(nranks):
     assert _spawn(nranks, env) == 0
 
 
+def test_expired_exchange_wait_poisons_the_result_and_raises():
+    """a spin timeout used to set a status word nobody read and compute from stale ghosts.  Now the rows
+    that needed the missing values are NaN, a push whose ack wait expired stores nothing, and the host raises."""
+    assert _spawn(2, {"HPCLA_PUSH_TIMEOUT_S": "2", "HPCLA_MR_TIMEOUT_CASE": "1"}, timeout=300) == 0
+
+
+def test_spmm_panel_order_within_tolerance():
+    """HPCLA_SPMM_ORDER=panel (exchange overlapped chunk by chunk, config 5 at N > 1): same sums in a different
+    ORDER -- 1e-12 relative and the componentwise |A||B| bound against the oracle, 2 ranks, both index types."""
+    assert _spawn(2, {"HPCLA_PUSH_TIMEOUT_S": "30", "HPCLA_SPMM_ORDER_TEST": "1", "HPCLA_MR_TYPES": "i32,i64"}) == 0
+
+
 @pytest.mark.parametrize("mode", ["serial", "overlap"])
 def test_rccl_transport_two_gpus(mode):
     if _device_count() < 2:

@@ -707,6 +707,52 @@ def test_cg_graph_replay_is_bit_identical_to_eager(hp, orc, gpu_backend_i32, fus
     np.testing.assert_array_equal(x1.local_values(), x2.local_values())
 
 
+@pytest.mark.parametrize("which", ["i32", "i64"])
+def test_cg_native_loop_same_bits_as_one_call_per_kernel(hp, orc, gpu_backend_i32, gpu_backend_i64, which):
+    """hpcla_cg_iterations_f64_* enqueues k iterations in ONE host call (no Python / Julia in the loop): per
+    iteration the launches of hpcla_spmv_dist_dot, hpcla_cg_residual and hpcla_cg_direction with the same
+    arguments -- so iterate and residual history equal the three-calls-per-iteration loop bit for bit; a reused
+    workspace and a solve continued in two pieces (7 + 6 iterations) change nothing either."""
+    backend = gpu_backend_i32 if which == "i32" else gpu_backend_i64
+    N = 18
+    rows = orc.poisson3d_rows(N, N, N, 0, N ** 3)
+    A = hp.HPCSparseMatrix_local(rows.rowptr, rows.colidx, rows.vals, N ** 3, backend)
+    b = hp.HPCVector.from_global(orc.fill_uniform(0, N ** 3, orc.SEED_RHS), backend)
+    x_py, h_py = hp.cg_fixed_iterations(A, b, 13, native_loop=False)
+    x_py = x_py.local_values()
+    ws = hp.CGWorkspace(b, 20)
+    for _ in range(2):                                   # second pass: the workspace is dirty from the first
+        x_nat, h_nat = hp.cg_fixed_iterations(A, b, 13, workspace=ws)
+        assert x_nat is ws.x and h_nat == h_py
+        np.testing.assert_array_equal(x_nat.local_values(), x_py)
+    plan, fused = hp.cg_setup(A, b, ws)
+    assert fused
+    hp.cg_iterate(A, ws, plan, fused, 7)
+    hp.cg_iterate(A, ws, plan, fused, 6)
+    assert ws.done == 13
+    assert ws.hist[:14].sqrt().cpu().tolist() == h_py
+    np.testing.assert_array_equal(ws.x.local_values(), x_py)
+    with pytest.raises(ValueError):
+        hp.cg_iterate(A, ws, plan, fused, 8)             # history array too short: refused, nothing enqueued
+    # the oracle's restatement, at the tolerance the recurrence allows
+    _, h_ref = orc.cg(rows.rowptr.astype(np.int32), rows.colidx.astype(np.int32), rows.vals,
+                      orc.fill_uniform(0, N ** 3, orc.SEED_RHS), 13)
+    assert np.allclose(h_nat, h_ref, rtol=CG_RTOL, atol=0)
+
+
+def test_cg_iterations_entry_rejects_bad_arguments(hp, gpu_backend_i32):
+    import torch
+    z = torch.zeros(8, dtype=torch.float64, device="cuda")
+    with pytest.raises(hp._capi.HPCLAError) as ei:
+        hp._capi.call("hpcla_cg_iterations_f64_i32", None, None, None, None, None, 4, 0, 0, None, 0, None, 0,
+                      z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), None, None, None, None, 3, None)
+    assert ei.value.status == -1 and "null" in str(ei.value)
+    with pytest.raises(hp._capi.HPCLAError):
+        hp._capi.call("hpcla_cg_iterations_f64_i32", None, None, None, None, None, 4, 0, 0, None, 0, None, 0,
+                      z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(),
+                      z.data_ptr(), -1, None)
+
+
 def test_transpose_times_vector(hp, orc, gpu_backend_i32):
     """transpose(A) * x (test/test_new_operations.jl:73-76; src/sparse.jl:2375-2379): materialised,
     cached bidirectionally, result bit-identical to the row-sequential product with the explicit A^T."""
