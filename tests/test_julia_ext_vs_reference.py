@@ -1,0 +1,280 @@
+"""Static cross-check of integration/HPCLinearAlgebraROCmExt.jl against the REFERENCE's Julia sources.
+
+The extension cannot be executed here (no Julia in the image); tests/test_julia_binding_signatures.py checks its
+`@ccall`s against the C header.  This test checks the OTHER side of the file -- everything it takes from the parent
+package: every name in its `using HPCLinearAlgebra: ...` list, every `HPCLinearAlgebra.<name>` it extends or calls
+(with the number of positional arguments of the methods it adds), and every field it reads from the parent's structs
+(`plan.<field>` of VectorPlan / VectorRepartitionPlan / AdditionPlan, `A.<field>` of HPCSparseMatrix, `x.<field>` of
+HPCVector, `M.<field>` of HPCMatrix, `backend.<field>`, `comm.<field>`) must exist in /root/reference/src/*.jl.
+
+The reference tree exists only in the build container (never on the GPU box): the test skips when it is absent.
+Nothing is copied from it -- it is read as text, names and arities are extracted with regular expressions.
+"""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+EXT = os.path.join(ROOT, "integration", "HPCLinearAlgebraROCmExt.jl")
+
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "src")), reason="reference sources not present")
+
+# names the PARENT PATCH of INTEGRATION.md adds (they cannot exist in the unpatched reference): checked against
+# INTEGRATION.md instead
+PARENT_PATCH_NAMES = {"DeviceROCm", "backend_rocm_serial", "backend_rocm_mpi"}
+
+
+def _strip_comments_and_strings(text):
+    text = re.sub(r'"""(?:.|\n)*?"""', lambda m: '""' + "\n" * m.group(0).count("\n"), text)   # docstrings (line numbers kept)
+    text = re.sub(r'"(?:\\.|[^"\\\n])*"', '""', text)      # string literals
+    return "\n".join(line.split("#", 1)[0] for line in text.splitlines())
+
+
+def _ref_text():
+    out = []
+    for fn in sorted(os.listdir(os.path.join(REF, "src"))):
+        if fn.endswith(".jl"):
+            out.append(open(os.path.join(REF, "src", fn)).read())
+    return _strip_comments_and_strings("\n".join(out))
+
+
+def _match_paren(text, i):
+    """index just behind the parenthesis that closes the one at text[i]"""
+    depth = 0
+    for j in range(i, len(text)):
+        if text[j] in "([{":
+            depth += 1
+        elif text[j] in ")]}":
+            depth -= 1
+            if depth == 0:
+                return j + 1
+    raise AssertionError("unbalanced parentheses")
+
+
+def _split_top(s):
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        if ch in ",;" and depth == 0:
+            out.append((cur, ch))
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append((cur, ""))
+    return out
+
+
+def _arity(argtext):
+    """(minimum, maximum) number of POSITIONAL arguments of a Julia signature's argument text (max None = varargs)."""
+    lo = hi = 0
+    kw = False
+    for a, sep in _split_top(argtext):
+        a = a.strip()
+        if not a:
+            if sep == ";":
+                kw = True
+            continue
+        if not kw:
+            if a.endswith("..."):
+                hi = None
+            else:
+                if hi is not None:
+                    hi += 1
+                if "=" not in re.sub(r"\{[^{}]*\}", "", a).replace("==", ""):
+                    lo += 1
+        if sep == ";":
+            kw = True
+    return lo, hi
+
+
+def reference_structs(text):
+    """struct name -> list of field names"""
+    out = {}
+    for m in re.finditer(r"^\s*(?:mutable\s+)?struct\s+(\w+)[^\n]*\bend\s*$", text, flags=re.M):
+        out[m.group(1)] = []                              # one-line definitions: `struct CommSerial <: AbstractComm end`
+    for m in re.finditer(r"^\s*(?:mutable\s+)?struct\s+(\w+)(?:(?!\bend\s*$)[^\n])*\n(.*?)^end\b", text, flags=re.S | re.M):
+        fields = []
+        depth = 0
+        for line in m.group(2).splitlines():
+            s = line.strip()
+            if re.match(r"(function\b|for\b|if\b|while\b|let\b|begin\b)", s):
+                depth += 1
+            if depth == 0:
+                f = re.match(r"(\w+)\s*(::|$)", s)
+                if f and f.group(1) not in ("end", "new"):
+                    fields.append(f.group(1))
+            if s == "end" or s.startswith("end "):
+                depth = max(depth - 1, 0)
+        out[m.group(1)] = fields
+    return out
+
+
+def reference_functions(text):
+    """function name -> list of (min, max) positional arities over all its methods ([] for bare `function f end`)"""
+    out = {}
+    for m in re.finditer(r"^\s*function\s+(?:\w+\.)*([\w!]+)\s*(\(|end\b|\{)", text, flags=re.M):
+        name = m.group(1)
+        out.setdefault(name, [])
+        if m.group(2) == "(":
+            i = m.end() - 1
+            out[name].append(_arity(text[i + 1:_match_paren(text, i) - 1]))
+        elif m.group(2) == "{":
+            i = text.index("(", m.end())
+            out[name].append(_arity(text[i + 1:_match_paren(text, i) - 1]))
+    for m in re.finditer(r"^(?:\w+\.)*([\w!]+)(?:\{[^\n]*?\})?\(", text, flags=re.M):          # one-line definitions
+        i = m.end() - 1
+        j = _match_paren(text, i)
+        if re.match(r"\s*(?:where\s+[^=\n]+?)?\s*=(?!=)", text[j:j + 200]):
+            out.setdefault(m.group(1), []).append(_arity(text[i + 1:j - 1]))
+    return out
+
+
+def reference_names(text):
+    names = set(reference_structs(text)) | set(reference_functions(text))
+    names |= set(re.findall(r"^\s*abstract\s+type\s+(\w+)", text, flags=re.M))
+    names |= set(re.findall(r"^\s*const\s+(\w+)", text, flags=re.M))
+    return names
+
+
+def _ext_text():
+    return _strip_comments_and_strings(open(EXT).read())
+
+
+def test_reference_parser_sees_the_known_landmarks():
+    """The regex parser is only trusted if it finds what SURVEY.md section 8 cites by line."""
+    text = _ref_text()
+    structs = reference_structs(text)
+    assert {"send_rank_ids", "send_indices", "recv_rank_ids", "recv_perm", "local_src_indices", "local_dst_indices",
+            "gathered", "gathered_cpu", "result_partition_hash", "result_partition"} <= set(structs["VectorPlan"])
+    assert {"row_partition", "col_partition", "col_indices", "rowptr", "colval", "nzval", "nrows_local",
+            "ncols_compressed", "rowptr_target", "colval_target", "backend", "cached_transpose"} <= set(structs["HPCSparseMatrix"])
+    assert structs["HPCVector"][:4] == ["structural_hash", "partition", "v", "backend"]
+    funcs = reference_functions(text)
+    assert (2, 2) in funcs["execute_plan!"] and (2, 2) in funcs["_convert_array"] and (2, 2) in funcs["get_vector_plan"]
+    assert "backend_cuda_mpi" in funcs                       # the stub pattern the parent patch copies
+
+
+def test_imported_names_exist_in_the_reference():
+    ext = _ext_text()
+    m = re.search(r"using\s+HPCLinearAlgebra\s*:\s*((?:[\w!]+\s*,\s*)*[\w!]+)", ext)
+    assert m, "no `using HPCLinearAlgebra: ...` list"
+    imported = [n.strip() for n in m.group(1).split(",")]
+    assert len(imported) >= 12
+    names = reference_names(_ref_text())
+    missing = [n for n in imported if n not in names and n not in PARENT_PATCH_NAMES]
+    assert not missing, f"imported from HPCLinearAlgebra but not defined in {REF}/src: {missing}"
+    integ = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for n in PARENT_PATCH_NAMES & set(imported):
+        assert n in integ, f"{n} must be added by the parent patch shown in INTEGRATION.md"
+
+
+def test_qualified_names_exist_and_extended_methods_have_a_reference_arity():
+    ext = _ext_text()
+    text = _ref_text()
+    names = reference_names(text)
+    funcs = reference_functions(text)
+    problems = []
+    for m in re.finditer(r"HPCLinearAlgebra\.([\w!]+)", ext):
+        n = m.group(1)
+        if n not in names and n not in PARENT_PATCH_NAMES:
+            problems.append(f"line {ext.count(chr(10), 0, m.start()) + 1}: HPCLinearAlgebra.{n} is not defined in the reference")
+    # method extensions: `function HPCLinearAlgebra.f(args)` and `HPCLinearAlgebra.f(args) = ...`
+    extended = []
+    for m in re.finditer(r"^(?:function\s+)?HPCLinearAlgebra\.([\w!]+)\(", ext, flags=re.M):
+        i = m.end() - 1
+        j = _match_paren(ext, i)
+        is_def = m.group(0).startswith("function") or re.match(r"\s*(?:where\s+[^=\n]+?)?\s*=(?!=)", ext[j:j + 200])
+        if is_def:
+            extended.append((m.group(1), _arity(ext[i + 1:j - 1]), ext.count("\n", 0, m.start()) + 1))
+    assert len(extended) >= 12, extended
+    for name, (lo, hi), line in extended:
+        if name in PARENT_PATCH_NAMES:
+            continue                                          # the stubs the parent patch declares (`function f end`)
+        ref = list(funcs.get(name, []))
+        if not ref and name in funcs:
+            # a bare stub in the parent (`function _array_to_device end`): the contract is the parent's CALL sites
+            for c in re.finditer(r"(?<![\w.!])%s\(" % re.escape(name), text):
+                if text[max(c.start() - 9, 0):c.start()].strip().endswith("function"):
+                    continue
+                k = c.end() - 1
+                n_args = len([a for a, _ in _split_top(text[k + 1:_match_paren(text, k) - 1]) if a.strip()])
+                ref.append((n_args, n_args))
+            if not ref:
+                continue                                      # declared for extensions, never called by the parent: any arity
+        if not ref:
+            problems.append(f"line {line}: {name} has neither a method nor a stub in the reference")
+            continue
+        ok = any((rhi is None or lo <= rhi) and (hi is None or hi >= rlo) for rlo, rhi in ref)
+        if not ok:
+            problems.append(f"line {line}: {name} extended with {lo}..{hi} positional arguments, reference methods take {sorted(set(ref), key=str)}")
+    assert not problems, "\n".join(problems)
+
+
+# variable -> struct, from the type annotations of each definition's signature (plus the two idioms
+# `plan = get_vector_plan(...)` and `d = _device_plan(...)`)
+_TYPE_OF_ANNOTATION = [
+    (r"HPCSparseMatrix\b", "HPCSparseMatrix"), (r"HPCVector\b", "HPCVector"), (r"HPCMatrix\b", "HPCMatrix"),
+    (r"(?<![A-Za-z])VectorRepartitionPlan\b", "VectorRepartitionPlan"), (r"(?<![A-Za-z])AdditionPlan\b", "AdditionPlan"),
+    (r"(?<![A-Za-z])VectorPlan\b", "VectorPlan"),             # (not ROCVectorPlan: that struct is the extension's own)
+    (r"HPCBackend\b|ROCBackend\b", "HPCBackend"), (r"CommMPI\b", "CommMPI"),
+]
+
+
+def _chunks(ext):
+    """(signature text, body text, first line) of every top-level definition of the extension"""
+    starts = [m.start() for m in re.finditer(r"^(?:function\s|[\w.:!*]+(?:\{[^\n]*?\})?\([^\n]*\)\s*(?:where[^\n=]*)?=(?!=))", ext, flags=re.M)]
+    starts.append(len(ext))
+    for a, b in zip(starts, starts[1:]):
+        chunk = ext[a:b]
+        i = chunk.index("(")
+        j = _match_paren(chunk, i)
+        yield chunk[i + 1:j - 1], chunk[j:], ext.count("\n", 0, a) + 1
+
+
+def test_every_field_read_from_a_parent_struct_exists_there():
+    ext = _ext_text()
+    structs = reference_structs(_ref_text())
+    for need in ("VectorPlan", "VectorRepartitionPlan", "AdditionPlan", "HPCSparseMatrix", "HPCVector", "HPCMatrix",
+                 "HPCBackend", "CommMPI"):
+        assert need in structs and structs[need], f"struct {need} not found in the reference"
+    problems, checked = [], 0
+    for sig, body, line in _chunks(ext):
+        var_type = {}
+        for a, _sep in _split_top(sig):
+            m = re.match(r"\s*(\w+)\s*::\s*(.+)", a.strip(), flags=re.S)
+            if not m:
+                continue
+            for pat, st in _TYPE_OF_ANNOTATION:
+                if re.search(pat, m.group(2)):
+                    var_type[m.group(1)] = st
+                    break
+        if re.search(r"\bplan\s*=\s*get_vector_plan\(", body) or ("plan" in [a.strip() for a, _ in _split_top(sig)]
+                                                                  and re.search(r"plan\.(send_rank_ids|recv_perm)", body)):
+            var_type.setdefault("plan", "VectorPlan")
+        for var, st in var_type.items():
+            for m in re.finditer(r"(?<![\w.])%s((?:\.\w+)+)" % re.escape(var), body):
+                chain = m.group(1).strip(".").split(".")
+                cur = st
+                for f in chain:
+                    if cur is None:
+                        break
+                    checked += 1
+                    if f not in structs[cur]:
+                        problems.append(f"definition at line {line}: {var}.{'.'.join(chain)} -- struct {cur} of the reference has no field `{f}` "
+                                        f"(fields: {structs[cur]})")
+                        break
+                    cur = {("HPCSparseMatrix", "backend"): "HPCBackend", ("HPCVector", "backend"): "HPCBackend",
+                           ("HPCMatrix", "backend"): "HPCBackend"}.get((cur, f))
+                    if cur == "HPCBackend" and chain[chain.index(f) + 1:chain.index(f) + 2] == ["comm"] and chain[-1] == "comm" and len(chain) > chain.index(f) + 2:
+                        # A.backend.comm.comm: the MPI communicator inside CommMPI (guarded by `isa CommMPI` in the file)
+                        if "comm" not in structs["CommMPI"]:
+                            problems.append(f"line {line}: CommMPI has no field comm")
+                        cur = None
+    assert checked >= 60, f"only {checked} field reads were checked: the parser lost track of the file"
+    assert not problems, "\n".join(problems)
