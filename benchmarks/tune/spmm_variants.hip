@@ -211,14 +211,218 @@ __global__ __launch_bounds__(TPB) void k_spmm(const int *__restrict__ rowptr, co
     if (MODE == 5) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         t4 = now();
-        if (tid == 0) {
-            atomicAdd(&stamps[0], (unsigned long long)(t1 - t0));      // rowptr round trip
-            atomicAdd(&stamps[1], (unsigned long long)(t2 - t1));      // A entries: load + stage + barrier
-            atomicAdd(&stamps[2], (unsigned long long)(t3 - t2));      // B gathers + flops
-            atomicAdd(&stamps[3], (unsigned long long)(t4 - t3));      // C through LDS + stores drained
-            atomicAdd(&stamps[4], 1ULL);
+        if (tid == 0) {                                          // per-workgroup slots (atomics on 5 words serialise)
+            unsigned long long *o = stamps + 16 + (size_t)blockIdx.x * 4;
+            o[0] = t1 - t0;                                      // rowptr round trip
+            o[1] = t2 - t1;                                      // A entries: load + stage + barrier
+            o[2] = t3 - t2;                                      // B gathers + flops
+            o[3] = t4 - t3;                                      // C through LDS + stores drained
         }
     }
+}
+
+// ---- MODE 9 / 10: TWO 64-row half-tiles per workgroup (128 rows, still 256 threads): one rowptr round trip and one
+// A round trip per 128 rows -- twice the bytes in flight per wave slot in the latency phases; the two halves are
+// gathered one after the other (no extra registers).  MODE 10 adds MODE 7's rowptr touch for the block ahead.
+constexpr int RPB2 = 128, CHUNK2 = 1024;
+
+template <bool PREFETCH>
+__global__ __launch_bounds__(TPB) void k_spmm_two_halves(const int *__restrict__ rowptr, const int *__restrict__ colval,
+                                                         const double *__restrict__ nzval, const double *__restrict__ B,
+                                                         double *__restrict__ C, int64_t nrows, unsigned long long *stamps,
+                                                         int param)
+{
+    __shared__ Entry s_ent[CHUNK2];                               // 16 KiB; the C tile (128 x 16 doubles) aliases it
+    const int tid = threadIdx.x;
+    const int g = tid / VG, l = tid % VG;
+    const int64_t r0 = (int64_t)blockIdx.x * RPB2;
+    const int nr = (int)((nrows - r0) < RPB2 ? (nrows - r0) : RPB2);
+    int pf_sink = 0;
+    if (PREFETCH) {
+        const int64_t ahead = r0 + (int64_t)RPB2 * param;
+        if (ahead + RPB2 <= nrows && tid < 4) pf_sink = rowptr[ahead + 32 * tid + 16];
+    }
+    const int64_t p0 = rowptr[r0];
+    const int64_t p1 = rowptr[r0 + nr];
+    const int64_t total = p1 - p0;
+    int64_t lo[2] = {0, 0}, hi[2] = {0, 0};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int r = g + h * 64;
+        if (r < nr) {
+            lo[h] = (int64_t)rowptr[r0 + r] - p0;
+            hi[h] = (int64_t)rowptr[r0 + r + 1] - p0;
+        }
+    }
+    const int c = 2 * l;
+    const int64_t lane_bytes = (int64_t)c * 8;
+    double acc[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+    for (int64_t ch = 0; ch < total; ch += CHUNK2) {
+        const int n = (int)((total - ch) < CHUNK2 ? (total - ch) : CHUNK2);
+        __syncthreads();
+        for (int i = tid; i < n; i += TPB) {
+            const int64_t col = __builtin_nontemporal_load(colval + p0 + ch + i);
+            Entry e;
+            e.val = __builtin_nontemporal_load(nzval + p0 + ch + i);
+            e.row = B + col * KT;
+            s_ent[i] = e;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int j = (int)((lo[h] > ch ? lo[h] : ch) - ch);
+            const int e = (int)((hi[h] < ch + n ? hi[h] : ch + n) - ch);
+            for (; j + VU <= e; j += VU) {
+                Entry en[VU];
+                vdouble2 b0[VU], b1[VU];
+#pragma unroll
+                for (int u = 0; u < VU; ++u) en[u] = s_ent[j + u];
+#pragma unroll
+                for (int u = 0; u < VU; ++u) {
+                    const char *src = reinterpret_cast<const char *>(en[u].row) + lane_bytes;
+                    b0[u] = *(gvec2_ptr)(src);
+                    b1[u] = *(gvec2_ptr)(src + 64);
+                }
+#pragma unroll
+                for (int u = 0; u < VU; ++u) {
+                    acc[h][0] += en[u].val * b0[u].x;
+                    acc[h][1] += en[u].val * b0[u].y;
+                    acc[h][2] += en[u].val * b1[u].x;
+                    acc[h][3] += en[u].val * b1[u].y;
+                }
+            }
+            for (; j < e; ++j) {
+                const Entry en = s_ent[j];
+                const char *src = reinterpret_cast<const char *>(en.row) + lane_bytes;
+                const vdouble2 b0 = *(gvec2_ptr)(src);
+                const vdouble2 b1 = *(gvec2_ptr)(src + 64);
+                acc[h][0] += en.val * b0.x;
+                acc[h][1] += en.val * b0.y;
+                acc[h][2] += en.val * b1.x;
+                acc[h][3] += en.val * b1.y;
+            }
+        }
+    }
+    __syncthreads();
+    double *s_c = reinterpret_cast<double *>(s_ent);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        vdouble2 o0, o1;
+        o0.x = acc[h][0]; o0.y = acc[h][1]; o1.x = acc[h][2]; o1.y = acc[h][3];
+        *reinterpret_cast<vdouble2 *>(s_c + (g + h * 64) * KT + c) = o0;
+        *reinterpret_cast<vdouble2 *>(s_c + (g + h * 64) * KT + c + 8) = o1;
+    }
+    __syncthreads();
+    vdouble2 *dst = reinterpret_cast<vdouble2 *>(C + r0 * KT);
+    const vdouble2 *srcl = reinterpret_cast<const vdouble2 *>(s_c);
+#pragma unroll
+    for (int u = 0; u < (RPB2 * KT / 2) / TPB; ++u) {
+        const int i = tid + u * TPB;
+        if (i < nr * (KT / 2)) dst[i] = srcl[i];
+    }
+    if (PREFETCH && pf_sink == 0x7fffff01 && total == -7) stamps[7] = 1;
+}
+
+// ---- MODE 11 / 12: WAVE-PRIVATE tiles: every wavefront owns 16 rows and its own slice of LDS -- its rowptr values,
+// its A entries, its records, its C tile; no workgroup barrier anywhere, so the four waves of a workgroup (and the
+// 32 of a CU) drift apart and their latency phases interleave freely.  MODE 12 adds the rowptr touch.
+constexpr int RPW = 16, WCHUNK = 128;                             // 16 rows per wave; 128 records (2 KiB) per wave pass
+
+template <bool PREFETCH>
+__global__ __launch_bounds__(TPB) void k_spmm_wave_tiles(const int *__restrict__ rowptr, const int *__restrict__ colval,
+                                                         const double *__restrict__ nzval, const double *__restrict__ B,
+                                                         double *__restrict__ C, int64_t nrows, unsigned long long *stamps,
+                                                         int param)
+{
+    __shared__ Entry s_all[(TPB / 64) * WCHUNK];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    Entry *s_ent = s_all + w * WCHUNK;                            // this wave's slice: nobody else touches it
+    const int g = lane / VG, l = lane % VG;                       // g = row of the wave's tile (0..15)
+    const int64_t r0 = ((int64_t)blockIdx.x * (TPB / 64) + w) * RPW;
+    if (r0 >= nrows) return;
+    const int nr = (int)((nrows - r0) < RPW ? (nrows - r0) : RPW);
+    int pf_sink = 0;
+    if (PREFETCH) {
+        const int64_t ahead = r0 + (int64_t)RPW * 4 * param;
+        if (ahead + 64 <= nrows && w == 0 && lane < 2) pf_sink = rowptr[ahead + 32 * lane + 16];
+    }
+    const int64_t p0 = rowptr[r0];
+    const int64_t p1 = rowptr[r0 + nr];
+    const int64_t total = p1 - p0;
+    int64_t lo = 0, hi = 0;
+    if (g < nr) {
+        lo = (int64_t)rowptr[r0 + g] - p0;
+        hi = (int64_t)rowptr[r0 + g + 1] - p0;
+    }
+    const int c = 2 * l;
+    const int64_t lane_bytes = (int64_t)c * 8;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int64_t ch = 0; ch < total; ch += WCHUNK) {
+        const int n = (int)((total - ch) < WCHUNK ? (total - ch) : WCHUNK);
+        // (the previous pass's record reads of this wave are complete: its FMAs consumed them)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < n; i += 64) {
+            const int64_t col = __builtin_nontemporal_load(colval + p0 + ch + i);
+            Entry e;
+            e.val = __builtin_nontemporal_load(nzval + p0 + ch + i);
+            e.row = B + col * KT;
+            s_ent[i] = e;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // LDS writes of this wave before its reads below
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        int j = (int)((lo > ch ? lo : ch) - ch);
+        const int e = (int)((hi < ch + n ? hi : ch + n) - ch);
+        for (; j + VU <= e; j += VU) {
+            Entry en[VU];
+            vdouble2 b0[VU], b1[VU];
+#pragma unroll
+            for (int u = 0; u < VU; ++u) en[u] = s_ent[j + u];
+#pragma unroll
+            for (int u = 0; u < VU; ++u) {
+                const char *src = reinterpret_cast<const char *>(en[u].row) + lane_bytes;
+                b0[u] = *(gvec2_ptr)(src);
+                b1[u] = *(gvec2_ptr)(src + 64);
+            }
+#pragma unroll
+            for (int u = 0; u < VU; ++u) {
+                acc[0] += en[u].val * b0[u].x;
+                acc[1] += en[u].val * b0[u].y;
+                acc[2] += en[u].val * b1[u].x;
+                acc[3] += en[u].val * b1[u].y;
+            }
+        }
+        for (; j < e; ++j) {
+            const Entry en = s_ent[j];
+            const char *src = reinterpret_cast<const char *>(en.row) + lane_bytes;
+            const vdouble2 b0 = *(gvec2_ptr)(src);
+            const vdouble2 b1 = *(gvec2_ptr)(src + 64);
+            acc[0] += en.val * b0.x;
+            acc[1] += en.val * b0.y;
+            acc[2] += en.val * b1.x;
+            acc[3] += en.val * b1.y;
+        }
+    }
+    // the wave's 16 x 16 results leave through its LDS slice as whole 128-byte lines (2 KiB contiguous in C)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    double *s_c = reinterpret_cast<double *>(s_ent);
+    vdouble2 o0, o1;
+    o0.x = acc[0]; o0.y = acc[1]; o1.x = acc[2]; o1.y = acc[3];
+    *reinterpret_cast<vdouble2 *>(s_c + g * KT + c) = o0;
+    *reinterpret_cast<vdouble2 *>(s_c + g * KT + c + 8) = o1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    vdouble2 *dst = reinterpret_cast<vdouble2 *>(C + r0 * KT);
+    const vdouble2 *srcl = reinterpret_cast<const vdouble2 *>(s_c);
+#pragma unroll
+    for (int u = 0; u < (RPW * KT / 2) / 64; ++u) {
+        const int i = lane + u * 64;
+        if (i < nr * (KT / 2)) dst[i] = srcl[i];
+    }
+    if (PREFETCH && pf_sink == 0x7fffff01 && total == -7) stamps[7] = 1;
 }
 
 extern "C" int hpcla_tune_spmm(int mode, const void *rowptr, const void *colval, const void *nzval, const void *B,
@@ -241,6 +445,21 @@ extern "C" int hpcla_tune_spmm(int mode, const void *rowptr, const void *colval,
     case 6: LAUNCH(6); break;
     case 7: LAUNCH(7); break;
     case 8: LAUNCH(8); break;
+    case 9: case 10: {
+        const uint32_t g2 = (uint32_t)((nrows + RPB2 - 1) / RPB2);
+        if (mode == 9) k_spmm_two_halves<false><<<g2, TPB, 0, s>>>((const int *)rowptr, (const int *)colval, (const double *)nzval,
+                           (const double *)B, (double *)C, nrows, (unsigned long long *)stamps, param);
+        else k_spmm_two_halves<true><<<g2, TPB, 0, s>>>((const int *)rowptr, (const int *)colval, (const double *)nzval,
+                           (const double *)B, (double *)C, nrows, (unsigned long long *)stamps, param);
+        break;
+    }
+    case 11: case 12: {
+        if (mode == 11) k_spmm_wave_tiles<false><<<grid, TPB, 0, s>>>((const int *)rowptr, (const int *)colval, (const double *)nzval,
+                           (const double *)B, (double *)C, nrows, (unsigned long long *)stamps, param);
+        else k_spmm_wave_tiles<true><<<grid, TPB, 0, s>>>((const int *)rowptr, (const int *)colval, (const double *)nzval,
+                           (const double *)B, (double *)C, nrows, (unsigned long long *)stamps, param);
+        break;
+    }
     default: return -2;
     }
 #undef LAUNCH

@@ -36,7 +36,7 @@ def main():
     ap.add_argument("--workload", default="poisson2d", choices=["poisson2d", "sprand"])
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--bmult", type=int, default=8)
-    ap.add_argument("--variants", default="100,0,1,2,3,4,6,7:1024,7:2048,8:1024,8:2048,5")
+    ap.add_argument("--variants", default="100,0,7:1024,9,10:512,11,12:1024,1,4,5")
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--build-only", action="store_true")
@@ -90,7 +90,7 @@ def main():
         n_brows = int(Bl.shape[0])
     C = torch.empty_like(C_ref)
     small = torch.rand(1024 * k, dtype=torch.float64, device=dev)
-    stamps = torch.zeros(16, dtype=torch.int64, device=dev)
+    stamps = torch.zeros(16 + 4 * ((n + 63) // 64), dtype=torch.int64, device=dev)      # [16 + 4*b ..]: block b's phase stamps
     b_alg = wl.spmm_algorithmic_bytes(nnz, n, A.ncols_compressed, k, 4)
 
     def parse(v):
@@ -135,14 +135,17 @@ def main():
         res[name] = dict(median_ms=med, min_ms=mn, gbs=b_alg / med / 1e6, exact=exact[v])
         ex = "-" if v[0] in ABLATIONS and v[0] != 5 else str(exact[v])
         print(f"{name:>10} {med:>10.4f} {mn:>10.4f} {b_alg / med / 1e6:>10.1f} {b_alg / med / 1e6 / 8000:>9.3f} {ex:>9}  {note}")
-    st = stamps.cpu().numpy()
-    if st[4] > 0:
+    if any(v[0] == 5 for v in variants):
+        launch((5, 0))
+        torch.cuda.synchronize()
+        st = stamps[16:].view(-1, 4).double().cpu().numpy()
         tick_us = 0.01                                  # wall_clock64: 100 MHz
         names = ["rowptr round trip", "A entries: load + stage + barrier", "B gathers + flops", "C via LDS + stores drained"]
-        tot = sum(st[:4]) / st[4] * tick_us
-        print(f"# MODE 5 stamps, average per workgroup over {int(st[4])} workgroups (us): " +
-              "; ".join(f"{nm} {st[i] / st[4] * tick_us:.2f}" for i, nm in enumerate(names)) + f"; lifetime {tot:.2f}")
-        res["stamps_us"] = {nm: float(st[i] / st[4] * tick_us) for i, nm in enumerate(names)}
+        mean = st.mean(axis=0) * tick_us
+        med = np.median(st, axis=0) * tick_us
+        print(f"# MODE 5 stamps, mean (median) per workgroup over {len(st)} workgroups (us): " +
+              "; ".join(f"{nm} {mean[i]:.2f} ({med[i]:.2f})" for i, nm in enumerate(names)) + f"; lifetime {mean.sum():.2f}")
+        res["stamps_us"] = {nm: float(mean[i]) for i, nm in enumerate(names)}
     print(json.dumps(res))
 
 

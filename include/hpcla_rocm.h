@@ -194,6 +194,20 @@ int hpcla_spmm_split_f64_i64(const int64_t *rowptr, const int64_t *colval_split,
                              int64_t ldc, int64_t nrows, int64_t nnz, int k, int index_base,
                              const int32_t *block_list, int64_t n_blocks, void *stream);
 /* layout conversion for column-major callers (Julia Matrix): dst(row-major, ld=k) <- src */
+/* One column PANEL of a product in panel order (opt-in order of the distributed SpMM; the reference's column loop
+ * src/sparse.jl:2391-2413 runs one exchange + SpMV per column instead).  (rowptr, colval_split, nzval) hold the
+ * entries of A whose columns lie in the panel, in stored order; columns < n_own index B_own, the others B_ghost
+ * (n_own = 0: every column is a ghost position).  accumulate = 1: every C(r, c) continues from its current value,
+ * entry by entry -- a product taken panel by panel is the reference's sum in a different ORDER (1e-12 relative,
+ * not bit-identical).  Row-major B / C (ldb, ldc = row strides). */
+int hpcla_spmm_panel_f64_i32(const int32_t *rowptr, const int32_t *colval_split, const double *nzval,
+                             const double *B_own, int64_t ldb_own, const double *B_ghost, int64_t ldb_ghost,
+                             int64_t n_own, double *C, int64_t ldc, int64_t nrows, int64_t nnz, int k,
+                             int index_base, int accumulate, void *stream);
+int hpcla_spmm_panel_f64_i64(const int64_t *rowptr, const int64_t *colval_split, const double *nzval,
+                             const double *B_own, int64_t ldb_own, const double *B_ghost, int64_t ldb_ghost,
+                             int64_t n_own, double *C, int64_t ldc, int64_t nrows, int64_t nnz, int k,
+                             int index_base, int accumulate, void *stream);
 int hpcla_transpose_f64(const double *src, int64_t ld_src, int src_layout, double *dst,
                         int64_t ld_dst, int dst_layout, int64_t rows, int64_t cols, void *stream);
 
@@ -317,6 +331,10 @@ int hpcla_halo_plan_create_ex(hpcla_halo_plan_t **plan, hpcla_comm_t *comm, int 
                               const void *send_idx, int idx_is_i64, int n_recv,
                               const int32_t *recv_ranks_host, const int64_t *recv_counts_host,
                               int width, int flags);
+/* Chain `plan` behind `leader`: both exchange on the LEADER's side stream, so exchanges begun one after the other
+ * (hpcla_halo_begin(leader), hpcla_halo_begin(plan), ...) also RUN one after the other -- the chunk-sets of a
+ * panel-ordered SpMM arrive in order instead of all at once.  Destroy the chained plans before their leader. */
+int hpcla_halo_plan_chain(hpcla_halo_plan_t *plan, hpcla_halo_plan_t *leader);
 int hpcla_halo_plan_destroy(hpcla_halo_plan_t *plan);
 /* Push transport for this plan.  When the communicator's window is attached, create() places the ghost
  * segment (double-buffered up to 64 MiB) inside a peer-mappable window.  export: this rank's descriptor

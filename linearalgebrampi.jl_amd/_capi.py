@@ -58,6 +58,8 @@ _SIGNATURES = {
     "hpcla_spmm_csr_f64_i64": [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _i64, _i32, _i64, _i64, _i32, _i32, _vp],
     "hpcla_spmm_split_f64_i32": [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _i64, _vp],
     "hpcla_spmm_split_f64_i64": [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _i64, _vp],
+    "hpcla_spmm_panel_f64_i32": [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _vp],
+    "hpcla_spmm_panel_f64_i64": [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _vp],
     "hpcla_transpose_f64": [_vp, _i64, _i32, _vp, _i64, _i32, _i64, _i64, _vp],
     "hpcla_gather_f64_i32": [_vp, _vp, _vp, _vp, _i64, _i32, _vp],
     "hpcla_gather_f64_i64": [_vp, _vp, _vp, _vp, _i64, _i32, _vp],
@@ -83,6 +85,7 @@ _SIGNATURES = {
     "hpcla_exchange_ranges_f64": [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp],
     "hpcla_halo_plan_create": [_vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32],
     "hpcla_halo_plan_create_ex": [_vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32],
+    "hpcla_halo_plan_chain": [_vp, _vp],
     "hpcla_halo_plan_destroy": [_vp],
     "hpcla_halo_ghost_ptr": [_vp, _vp, _vp],
     "hpcla_halo_begin": [_vp, _vp, _vp],

@@ -313,7 +313,7 @@ static void halo_free(hpcla_halo_plan *p)
     if (p->ghost) (void)hipFree(p->ghost);
     if (p->ev_ready) (void)hipEventDestroy(p->ev_ready);
     if (p->ev_done) (void)hipEventDestroy(p->ev_done);
-    if (p->side) (void)hipStreamDestroy(p->side);
+    if (p->side && p->owns_side) (void)hipStreamDestroy(p->side);
     delete p;
 }
 
@@ -457,6 +457,20 @@ HPCLA_API int hpcla_halo_plan_create_ex(hpcla_halo_plan_t **plan, hpcla_comm_t *
     if (flags & ~HPCLA_HALO_SINGLE_BUFFER) return set_error(HPCLA_ERR_INVALID, "halo_plan_create_ex: unknown flags");
     return halo_plan_create_impl(plan, comm, n_send, send_ranks_host, send_counts_host, send_idx, idx_is_i64, n_recv,
                                  recv_ranks_host, recv_counts_host, width, flags);
+}
+
+HPCLA_API int hpcla_halo_plan_chain(hpcla_halo_plan_t *plan, hpcla_halo_plan_t *leader)
+{
+    if (!plan || !leader || plan == leader) return set_error(HPCLA_ERR_INVALID, "halo_plan_chain: bad plans");
+    if (!leader->side) return set_error(HPCLA_ERR_INVALID, "halo_plan_chain: the leader has no exchange stream");
+    if (plan->side == leader->side) return HPCLA_OK;
+    if (plan->side) {
+        HPCLA_CHECK_HIP(hipStreamSynchronize(plan->side));
+        if (plan->owns_side) HPCLA_CHECK_HIP(hipStreamDestroy(plan->side));
+    }
+    plan->side = leader->side;
+    plan->owns_side = false;
+    return HPCLA_OK;
 }
 
 HPCLA_API int hpcla_halo_plan_destroy(hpcla_halo_plan_t *plan)

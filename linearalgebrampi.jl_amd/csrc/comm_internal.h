@@ -81,6 +81,7 @@ struct hpcla_halo_plan {
     double *send_buf = nullptr;                // device, n_send_total * width (RCCL transport only)
     double *ghost = nullptr;                   // device, n_ghost * width (buffer 0)
     hipStream_t side = nullptr;
+    bool owns_side = true;                     // false: the stream belongs to the plan this one is chained to
     hipEvent_t ev_ready = nullptr, ev_done = nullptr;
     // contiguity of the caller's (ascending) interior block list, probed once per list
     const int32_t *probed_list = nullptr;

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(TPB_MM) void spmm_rowblock_kernel(
     const double *__restrict__ B_own, int64_t b_rs, int64_t b_cs,
     const double *__restrict__ B_ghost, int64_t bg_rs, int64_t n_own, double *__restrict__ C,
     int64_t c_rs, int64_t c_cs, int64_t nrows, int k, int base,
-    const int32_t *__restrict__ block_list, uint32_t nblocks)
+    const int32_t *__restrict__ block_list, uint32_t nblocks, int accumulate)
 {
     __shared__ double s_val[CHUNK_MM];
     __shared__ int64_t s_col[CHUNK_MM];   // element offset of the B row (col * row stride), 64-bit
@@ -72,7 +72,12 @@ __global__ __launch_bounds__(TPB_MM) void spmm_rowblock_kernel(
         const int64_t c_off = (int64_t)c * b_cs;
         double acc[SLOTS];
 #pragma unroll
-        for (int s = 0; s < SLOTS; ++s) acc[s] = 0.0;
+        for (int s = 0; s < SLOTS; ++s) {
+            acc[s] = 0.0;
+            // panel order (hpcla_spmm_panel_*): the sums continue from what earlier panels left in C
+            const int r = g + s * NGROUPS;
+            if (accumulate && r < nr && col_ok) acc[s] = C[(r0 + r) * c_rs + (int64_t)c * c_cs];
+        }
 
         for (int64_t ch = 0; ch < total; ch += CHUNK_MM) {
             const int n = (int)((total - ch) < CHUNK_MM ? (total - ch) : CHUNK_MM);
@@ -199,7 +204,7 @@ __global__ __launch_bounds__(TPB_MM) void spmm_rowblock_vec_kernel(
     const I *__restrict__ rowptr, const I *__restrict__ colval, const double *__restrict__ nzval,
     const double *__restrict__ B_own, int64_t b_rs, const double *__restrict__ B_ghost, int64_t bg_rs,
     int64_t n_own, double *__restrict__ C, int64_t c_rs, int64_t nrows, int k, int base,
-    const int32_t *__restrict__ block_list, uint32_t nblocks)
+    const int32_t *__restrict__ block_list, uint32_t nblocks, int accumulate)
 {
     __shared__ SpmmEntry s_ent[CHUNK_V];
 
@@ -230,6 +235,13 @@ __global__ __launch_bounds__(TPB_MM) void spmm_rowblock_vec_kernel(
         double acc[VCPL];
 #pragma unroll
         for (int q = 0; q < VCPL; ++q) acc[q] = 0.0;
+        if (accumulate && g < nr && col_ok) {
+            // panel order (hpcla_spmm_panel_*): this lane's four sums continue from what earlier panels left in C
+            const double *cur = C + (r0 + g) * c_rs + c;
+            const vdouble2 c0 = *reinterpret_cast<const vdouble2 *>(cur);
+            const vdouble2 c1 = *reinterpret_cast<const vdouble2 *>(cur + SECOND / 8);
+            acc[0] = c0.x; acc[1] = c0.y; acc[2] = c1.x; acc[3] = c1.y;
+        }
 
         for (int64_t ch = 0; ch < total; ch += CHUNK_V) {
             const int n = (int)((total - ch) < CHUNK_V ? (total - ch) : CHUNK_V);
@@ -344,7 +356,7 @@ static int spmm_launch(const I *rowptr, const I *colval, const double *nzval, co
                        int64_t b_rs, int64_t b_cs, const double *B_ghost, int64_t bg_rs,
                        int64_t n_own, bool split, double *C, int64_t c_rs, int64_t c_cs,
                        int64_t nrows, int64_t nnz, int k, int index_base,
-                       const int32_t *block_list, int64_t n_blocks, void *stream)
+                       const int32_t *block_list, int64_t n_blocks, void *stream, int accumulate = 0)
 {
     if (nrows < 0 || nnz < 0 || k < 0) return set_error(HPCLA_ERR_INVALID, "spmm: negative size");
     if (index_base != 0 && index_base != 1)
@@ -384,7 +396,7 @@ static int spmm_launch(const I *rowptr, const I *colval, const double *nzval, co
 #define HPCLA_SPMM_VEC(SP, VUU, CH, H64, CST)                                                           \
     spmm_rowblock_vec_kernel<I, SP, VUU, CH, H64, CST><<<grid, block, 0, s>>>(                           \
         rowptr, colval, nzval, B_own, b_rs, SP ? B_ghost : nullptr, SP ? bg_rs : 0, SP ? n_own : 0, C, c_rs, \
-        nrows, k, index_base, block_list, (uint32_t)launch_blocks)
+        nrows, k, index_base, block_list, (uint32_t)launch_blocks, accumulate)
         // lane->column mapping: 64 contiguous bytes per row per load when k % 16 == 0 (HPCLA_SPMM_HALF64=0: off)
         static const int h64_env = [] {
             const char *e = getenv("HPCLA_SPMM_HALF64");
@@ -412,11 +424,11 @@ static int spmm_launch(const I *rowptr, const I *colval, const double *nzval, co
     } else if (split)
         spmm_rowblock_kernel<I, true><<<grid, block, 0, s>>>(
             rowptr, colval, nzval, B_own, b_rs, b_cs, B_ghost, bg_rs, n_own, C, c_rs, c_cs, nrows,
-            k, index_base, block_list, (uint32_t)launch_blocks);
+            k, index_base, block_list, (uint32_t)launch_blocks, accumulate);
     else
         spmm_rowblock_kernel<I, false><<<grid, block, 0, s>>>(
             rowptr, colval, nzval, B_own, b_rs, b_cs, nullptr, 0, 0, C, c_rs, c_cs, nrows, k,
-            index_base, block_list, (uint32_t)launch_blocks);
+            index_base, block_list, (uint32_t)launch_blocks, accumulate);
     HPCLA_CHECK_LAUNCH();
     return HPCLA_OK;
 }
@@ -475,6 +487,29 @@ HPCLA_API int hpcla_spmm_split_f64_i64(const int64_t *rowptr, const int64_t *col
     return spmm_launch<int64_t>(rowptr, colval_split, nzval, B_own, ldb_own, 1, B_ghost, ldb_ghost,
                                 n_own, true, C, ldc, 1, nrows, nnz, k, index_base, block_list,
                                 n_blocks, stream);
+}
+
+// One PANEL of a product in panel order (the opt-in order of the distributed SpMM): a CSR
+// matrix that holds the entries of A whose columns lie in one column panel; accumulate = 1 continues every
+// C(r, c) from its current value, entry by entry in stored order -- so a product taken panel by panel is the
+// reference's sum (src/sparse.jl:2391-2413) in a different ORDER (own columns, then chunk by chunk), never a sum of
+// separately rounded partial sums.
+HPCLA_API int hpcla_spmm_panel_f64_i32(const int32_t *rowptr, const int32_t *colval_split, const double *nzval,
+                                       const double *B_own, int64_t ldb_own, const double *B_ghost,
+                                       int64_t ldb_ghost, int64_t n_own, double *C, int64_t ldc, int64_t nrows,
+                                       int64_t nnz, int k, int index_base, int accumulate, void *stream)
+{
+    return spmm_launch<int32_t>(rowptr, colval_split, nzval, B_own, ldb_own, 1, B_ghost, ldb_ghost, n_own, true, C,
+                                ldc, 1, nrows, nnz, k, index_base, nullptr, 0, stream, accumulate ? 1 : 0);
+}
+
+HPCLA_API int hpcla_spmm_panel_f64_i64(const int64_t *rowptr, const int64_t *colval_split, const double *nzval,
+                                       const double *B_own, int64_t ldb_own, const double *B_ghost,
+                                       int64_t ldb_ghost, int64_t n_own, double *C, int64_t ldc, int64_t nrows,
+                                       int64_t nnz, int k, int index_base, int accumulate, void *stream)
+{
+    return spmm_launch<int64_t>(rowptr, colval_split, nzval, B_own, ldb_own, 1, B_ghost, ldb_ghost, n_own, true, C,
+                                ldc, 1, nrows, nnz, k, index_base, nullptr, 0, stream, accumulate ? 1 : 0);
 }
 
 HPCLA_API int hpcla_transpose_f64(const double *src, int64_t ld_src, int src_layout, double *dst,

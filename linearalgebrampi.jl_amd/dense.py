@@ -15,6 +15,7 @@ neighbour (the reference: k exchanges, k kernel launches, 17 Allgathers, A strea
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Dict, Optional
 
 import numpy as np
@@ -276,6 +277,7 @@ _spmm_halo_cache: Dict[tuple, object] = {}
 
 
 _spmm_backends: Dict[int, HPCBackend] = {}
+_spmm_panel_cache: Dict[tuple, "SpmmPanelPlan"] = {}
 
 
 def clear_spmm_cache() -> None:
@@ -283,6 +285,11 @@ def clear_spmm_cache() -> None:
     from .sparse import _quiesce
     _quiesce(list(_spmm_backends.values()))
     _spmm_backends.clear()
+    for pp in _spmm_panel_cache.values():
+        for h in reversed(pp.halos):                  # chained plans before their leader (hpcla_halo_plan_chain)
+            if h:
+                _capi.call("hpcla_halo_plan_destroy", h)
+    _spmm_panel_cache.clear()
     for h in _spmm_halo_cache.values():
         if h[0]:
             _capi.call("hpcla_halo_plan_destroy", h[0])
@@ -324,7 +331,7 @@ def _spmm_plan(A, B: HPCMatrix):
         tdt = torch.int64 if plan.is_i64 else torch.int32
         if not plan.has_halo:
             attach_halo_windows(backend, None)          # collective: the other ranks' plans are attaching
-            ent = _spmm_halo_cache[key] = (None, None, None, None, plan.colval_split, None, 0, 0, (0, 0))
+            ent = _spmm_halo_cache[key] = (None, None, None, None, plan.colval_split, None, 0, 0, (0, 0), None)
         else:
             send_indices, recv_counts_l, cmap = whole_slice_lists(h, A.col_indices, B.row_partition, wish, granted)
             n_send, n_recv = len(h.send_rank_ids), len(h.recv_rank_ids)
@@ -370,9 +377,165 @@ def _spmm_plan(A, B: HPCMatrix):
             _capi.call("hpcla_halo_ghost_ptr", halo, ctypes.byref(ghost), ctypes.byref(ng))
             peers = (sum(1 for c in recv_counts_l if c), sum(1 for i in send_indices if len(i)))
             ent = (halo, interior, boundary, send_idx, colval_split, ghost, int(ng.value),
-                   int(sum(len(i) for i in send_indices)), peers)
+                   int(sum(len(i) for i in send_indices)), peers,
+                   {"send_indices": send_indices, "recv_counts": list(recv_counts_l), "wish": wish})
             _spmm_halo_cache[key] = ent
     return plan, ent
+
+
+def spmm_order() -> str:
+    """``HPCLA_SPMM_ORDER``: "sequential" (default: the reference's bits) or "panel" (exchange overlapped chunk by
+    chunk; the same sums in a different order)."""
+    o = os.environ.get("HPCLA_SPMM_ORDER", "sequential").strip().lower()
+    if o not in ("sequential", "panel"):
+        raise ValueError("HPCLA_SPMM_ORDER must be 'sequential' or 'panel'")
+    return o
+
+
+class SpmmPanelPlan:
+    """Opt-in PANEL order of the distributed ``A * B`` (``HPCLA_SPMM_ORDER=panel``; default stays sequential).
+
+    Why: with uniformly random columns (BASELINE config 5) no 64-row block of A is interior, so the sequential
+    form is exchange + kernel (~1.8 GB per GPU ~ 1.7 ms at link rate, plus ~1.4 ms of kernel), not
+    the larger of the two.  Here every sender's slice travels in ``n_chunks`` chunk-sets, one after the other on
+    ONE exchange stream (chained halo plans), and the consumer multiplies panel by panel as the chunk-sets land:
+    first the own columns (overlapping chunk-set 0), then the panel of chunk-set c as soon as it has arrived,
+    each panel CONTINUING the sums in C (``hpcla_spmm_panel_*``, accumulate).  Every C(r, c) is therefore the
+    reference's sum (src/sparse.jl:2391-2413) with its terms taken own-columns-first, then chunk by chunk --
+    one running sum, never separately rounded partials; it differs from the sequential result by reassociation
+    only (tests: <= 1e-12 relative and within 1e-12 * (|A||B|) componentwise, BASELINE's tolerance).
+
+    Plan time: the split-column CSR is cut into 1 + n_chunks panels (torch index ops -- setup plumbing); the
+    values are a snapshot taken through the panel permutations and refreshed when ``A.nzval`` has changed
+    (torch's version counter), like the packed copy."""
+
+    def __init__(self, A, plan, ent, k: int, B_row_partition, n_chunks: int):
+        torch = _torch()
+        backend = A.backend
+        dev = backend.torch_device
+        self.k, self.n_chunks = k, n_chunks
+        self.is_i64 = plan.is_i64
+        self.halos, self.ghosts, self._keep, self.panels, self.vals = [], [], [], [], []
+        if ent is None or ent[0] is None:
+            # a rank without neighbours: nothing to cut, but the other ranks' chunk-set plans attach COLLECTIVELY
+            for _ in range(n_chunks):
+                attach_halo_windows(backend, None)
+            return
+        Ti = np.int64 if plan.is_i64 else np.int32
+        tdt = torch.int64 if plan.is_i64 else torch.int32
+        h = plan.host
+        info = ent[9]
+        send_indices, recv_counts = info["send_indices"], info["recv_counts"]
+        colval_split = ent[4]
+        n_own = plan.n_own
+        cut = lambda n, c: (n * c) // n_chunks                      # both ends of a link cut its list the same way
+        # ghost position (in the sequential plan's ghost order) -> (chunk, position in that chunk-set's ghost)
+        n_ghost = int(sum(recv_counts))
+        chunk_of = np.empty(n_ghost, dtype=np.int8)
+        newpos = np.empty(n_ghost, dtype=np.int64)
+        chunk_fill = [0] * n_chunks
+        off = 0
+        for cnt in recv_counts:
+            for c in range(n_chunks):
+                lo, hi = cut(cnt, c), cut(cnt, c + 1)
+                chunk_of[off + lo:off + hi] = c
+                newpos[off + lo:off + hi] = chunk_fill[c] + np.arange(hi - lo, dtype=np.int64)
+                chunk_fill[c] += hi - lo
+            off += cnt
+        # one chained halo plan per chunk-set
+        n_send, n_recv = len(h.send_rank_ids), len(h.recv_rank_ids)
+        send_ranks = (ctypes.c_int32 * max(n_send, 1))(*h.send_rank_ids)
+        recv_ranks = (ctypes.c_int32 * max(n_recv, 1))(*h.recv_rank_ids)
+        bp = np.asarray(B_row_partition, dtype=np.int64)
+        wish = info["wish"]
+        torch.cuda.current_stream().synchronize()
+        for c in range(n_chunks):
+            s_lists = [np.asarray(i[cut(len(i), c):cut(len(i), c + 1)], dtype=np.int64) for i in send_indices]
+            r_counts = [cut(cnt, c + 1) - cut(cnt, c) for cnt in recv_counts]
+            send_counts = (ctypes.c_int64 * max(n_send, 1))(*[len(i) for i in s_lists])
+            recv_cnt_c = (ctypes.c_int64 * max(n_recv, 1))(*r_counts)
+            send_idx = torch.from_numpy(np.concatenate(s_lists).astype(Ti)).to(dev) if n_send else None
+            halo = ctypes.c_void_p()
+            _capi.check("hpcla_halo_plan_create_ex", _capi.load().hpcla_halo_plan_create_ex(
+                ctypes.byref(halo), backend.rccl, n_send, send_ranks, send_counts, dptr(send_idx),
+                1 if plan.is_i64 else 0, n_recv, recv_ranks, recv_cnt_c, k, _capi.HALO_SINGLE_BUFFER))
+            # the rows this chunk-set must deliver, for the plan's connection test (owner-local row numbers)
+            seg = []
+            for r, perm, cnt in zip(h.recv_rank_ids, h.recv_perm, recv_counts):
+                rows_all = (np.arange(bp[r + 1] - bp[r]) if wish[r] else A.col_indices[perm] - bp[r])
+                seg.append((r, rows_all[cut(cnt, c):cut(cnt, c + 1)]))
+            attach_halo_windows(backend, halo, (n_own, k, seg))      # collective, like the sequential plan's
+            if self.halos:
+                _capi.call("hpcla_halo_plan_chain", halo, self.halos[0])
+            g, ng = ctypes.c_void_p(), ctypes.c_int64()
+            _capi.call("hpcla_halo_ghost_ptr", halo, ctypes.byref(g), ctypes.byref(ng))
+            self.halos.append(halo)
+            self.ghosts.append(g)
+            self._keep.append(send_idx)
+        # the panels of A: panel 0 = own columns, panel 1 + c = ghost columns that arrive with chunk-set c
+        cs = colval_split.to(torch.int64)
+        is_ghost = cs >= n_own
+        gpos = torch.clamp(cs - n_own, min=0)
+        chunk_dev = torch.from_numpy(chunk_of.astype(np.int64)).to(dev)
+        newpos_dev = torch.from_numpy(newpos).to(dev)
+        panel_id = torch.where(is_ghost, 1 + chunk_dev[gpos] if n_ghost else torch.zeros_like(cs), torch.zeros_like(cs))
+        newcol = torch.where(is_ghost, newpos_dev[gpos] if n_ghost else cs, cs)
+        counts = (A.rowptr_target[1:] - A.rowptr_target[:-1]).to(torch.int64)
+        rowid = torch.repeat_interleave(torch.arange(A.nrows_local, device=dev, dtype=torch.int64), counts)
+        self.panels = []                                             # (rowptr, colval, perm, nnz)
+        for q in range(1 + n_chunks):
+            perm = torch.nonzero(panel_id == q).flatten()            # ascending: stored order survives inside a row
+            rp = torch.zeros(A.nrows_local + 1, dtype=torch.int64, device=dev)
+            if perm.numel():
+                torch.cumsum(torch.bincount(rowid[perm], minlength=A.nrows_local), 0, out=rp[1:])
+            self.panels.append((rp.to(tdt).contiguous(), newcol[perm].to(tdt).contiguous(), perm.to(tdt).contiguous(),
+                                int(perm.numel())))
+        del cs, is_ghost, gpos, panel_id, newcol, rowid, counts
+        self.vals = [torch.empty(pn[3], dtype=torch.float64, device=dev) for pn in self.panels]
+        self._vals_version = None
+        self.n_own = n_own
+
+    def refresh_values(self, A) -> None:
+        ver = (A.nzval.data_ptr(), A.nzval._version)
+        if ver == self._vals_version:
+            return
+        sfx = "i64" if self.is_i64 else "i32"
+        s = current_stream_ptr()
+        for (rp, cv, perm, n), v in zip(self.panels, self.vals):
+            if n:
+                _capi.call(f"hpcla_gather_f64_{sfx}", dptr(A.nzval), dptr(perm), None, dptr(v), n, 0, s)
+        self._vals_version = ver
+
+    def multiply(self, A, Bc, C, plan_colval=None) -> None:
+        sfx = "i64" if self.is_i64 else "i32"
+        s = current_stream_ptr()
+        k = self.k
+        if not self.halos:                                           # no neighbours: every column is owned
+            _capi.call(f"hpcla_spmm_csr_f64_{sfx}", dptr(A.rowptr_target), dptr(plan_colval), dptr(A.nzval), dptr(Bc), k,
+                       _capi.LAYOUT_ROW, dptr(C), k, _capi.LAYOUT_ROW, A.nrows_local, A.nnz, k, 0, s)
+            return
+        self.refresh_values(A)
+        for halo in self.halos:                                      # chunk-sets leave in order on one exchange stream
+            _capi.call("hpcla_halo_begin", halo, dptr(Bc), s)
+        rp, cv, _, n = self.panels[0]                                # own columns: overlaps chunk-set 0
+        _capi.call(f"hpcla_spmm_panel_f64_{sfx}", dptr(rp), dptr(cv), dptr(self.vals[0]), dptr(Bc), k, None, k,
+                   self.n_own, dptr(C), k, A.nrows_local, n, k, 0, 0, s)
+        for c, halo in enumerate(self.halos):
+            _capi.call("hpcla_halo_end", halo, s)
+            rp, cv, _, n = self.panels[1 + c]
+            # every column of this panel is a position in chunk-set c's ghost buffer (n_own = 0)
+            _capi.call(f"hpcla_spmm_panel_f64_{sfx}", dptr(rp), dptr(cv), dptr(self.vals[1 + c]), dptr(Bc), k,
+                       self.ghosts[c], k, 0, dptr(C), k, A.nrows_local, n, k, 0, 1, s)
+
+
+def _spmm_panel_plan(A, B, plan, ent) -> SpmmPanelPlan:
+    k = int(B.A.shape[1])
+    n_chunks = max(1, int(os.environ.get("HPCLA_SPMM_PANELS", "4")))
+    key = (A._ensure_hash(), compute_partition_hash(B.row_partition), k, n_chunks)
+    pp = _spmm_panel_cache.get(key)
+    if pp is None:
+        pp = _spmm_panel_cache[key] = SpmmPanelPlan(A, plan, ent, k, B.row_partition, n_chunks)
+    return pp
 
 
 def spmm_exchange_bytes(A, B: HPCMatrix):
@@ -400,6 +563,11 @@ def spmm(A, B: HPCMatrix) -> HPCMatrix:
     s = current_stream_ptr()
     sfx = "i64" if plan.is_i64 else "i32"
     Bc = B.A.contiguous()
+    if ent is not None and spmm_order() == "panel":
+        # COLLECTIVE choice: every rank must run the same order (the chunk-set plans are separate exchanges, and a
+        # rank without neighbours still takes part in their collective attach)
+        _spmm_panel_plan(A, B, plan, ent).multiply(A, Bc, C, plan.colval_split)
+        return out
     if ent is None or ent[0] is None:
         # every column owned: split indices == offsets into B's local rows
         _capi.call(f"hpcla_spmm_csr_f64_{sfx}", dptr(A.rowptr_target), dptr(plan.colval_split),

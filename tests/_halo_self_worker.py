@@ -170,13 +170,18 @@ def main():
         assert st.value == 1, "the orphan wait did not report a timeout"
         assert 0.5 * limit <= waited <= limit + 5.0, f"orphan wait took {waited:.2f} s (limit {limit} s)"
         # ... and the expired wait POISONED the ghost buffer of its epoch: whatever is launched behind it computes NaN,
-        # never a plausible result from stale values
+        # never a plausible result from stale values.  (This plan is a double-buffered vector plan; the orphan wait
+        # was for epoch 1, i.e. buffer 1 = 64 doubles behind buffer 0 -- 64 * 8 B is already a multiple of the
+        # window's 256-byte buffer alignment.  No push ever ran, so the step counter still says 0 and
+        # hpcla_halo_ghost_ptr names buffer 0.)
         gp, gn = ctypes.c_void_p(), ctypes.c_int64(0)
         capi.call("hpcla_halo_ghost_ptr", plan, ctypes.byref(gp), ctypes.byref(gn))
-        ghost = torch.empty(int(gn.value), dtype=torch.float64, device="cuda")
-        capi.call("hpcla_scale_f64", 1.0, gp, ctypes.c_void_p(ghost.data_ptr()), int(gn.value), s)     # copy out through the library
+        assert gn.value == 64
+        both = torch.zeros(128, dtype=torch.float64, device="cuda")
+        capi.call("hpcla_scale_f64", 1.0, gp, ctypes.c_void_p(both.data_ptr()), 128, s)     # copy out through the library
         torch.cuda.synchronize()
-        assert bool(torch.isnan(ghost).all()), "the expired wait left stale values in the ghost buffer"
+        assert bool(torch.isnan(both[64:]).all()), "the expired wait left stale values in the ghost buffer of its epoch"
+        assert not bool(torch.isnan(both[:64]).any()), "the other buffer was touched"
         capi.call("hpcla_halo_plan_destroy", plan)
         print(f"orphan wait gave up after {waited:.2f} s, status flagged, ghost poisoned")
 
