@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
-"""Turn the rocprofv3 outputs of `run_gpu_checks.sh TAG prof pmc_rd pmc_wr` (under gpurun_out/) into the
-tracked evidence under profiles/: kernel stats + trace CSV, the two PMC CSVs and
-profiles/traffic_latest.json (HBM bytes per launch of the dominant kernel, corrected as
-/opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE counts 128-byte requests as
-64 bytes -> doubled; WRITE_SIZE is exact; both are reported in KiB).
+"""Turn the rocprofv3 outputs of `benchmarks/run_r03_pmc.sh TAG` (under gpurun_out/) into the tracked evidence under
+profiles/: kernel stats + trace CSV of the headline command, the PMC CSVs, and profiles/traffic_latest.json -- HBM bytes
+per launch of the headline kernel and, under "workloads", per launch / per CG iteration of every sub-record of the bench
+line -- corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE counts 128-byte requests
+as 64 bytes -> doubled; WRITE_SIZE is exact; both are reported in KiB; separate --pmc passes.
 
-usage: python benchmarks/collect_profiles.py TAG [ROUND]      (ROUND defaults to r02)
+usage: python benchmarks/collect_profiles.py TAG [ROUND]      (ROUND defaults to r03)
 """
+import collections
 import csv
 import glob
 import json
@@ -17,6 +18,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNEL = "spmv_rowblock_quad_kernel<int, false, false>"     # <index type, SPLIT, WAIT>: the single-GPU headline kernel
 B_ALG = 1_341_980_676          # config 2, Int32
+CORRECTION = "gfx950: FETCH_SIZE counts 128-B requests at 64 B -> doubled (MI355X_MICROARCH.md, HBM); WRITE_SIZE exact"
 
 
 def find(tag, step, suffix):
@@ -26,23 +28,75 @@ def find(tag, step, suffix):
     return hits[-1]
 
 
-def counter_mean(path, name):
-    vals = []
+def per_kernel(path, counter):
+    """kernel name -> list of counter values (one per launch)"""
+    acc = collections.defaultdict(list)
     with open(path, newline="") as f:
         for row in csv.DictReader(f):
-            if KERNEL in row["Kernel_Name"] and row["Counter_Name"] == name:
-                vals.append(float(row["Counter_Value"]))
+            if row["Counter_Name"] == counter:
+                acc[row["Kernel_Name"]].append(float(row["Counter_Value"]))
+    return acc
+
+
+def counter_mean(path, name, kernel=KERNEL, skip=0):
+    vals = [v for k, vs in per_kernel(path, name).items() if kernel in k for v in vs][skip:]
     if not vals:
-        raise SystemExit(f"{name}: no rows for {KERNEL} in {path}")
+        raise SystemExit(f"{name}: no rows for {kernel} in {path}")
     return sum(vals) / len(vals), len(vals)
+
+
+def hbm(fetch_kb, write_kb):
+    return int(round(2 * fetch_kb * 1024 + write_kb * 1024))
+
+
+def workload_single_kernel(tag, step, kernel, rnd, prof, label, alg, cmd, skip=1):
+    rd = find(tag, f"pmc_{step}_FETCH_SIZE", "counter_collection.csv")
+    wr = find(tag, f"pmc_{step}_WRITE_SIZE", "counter_collection.csv")
+    shutil.copy(rd, os.path.join(prof, f"{rnd}_pmc_{step}_FETCH_SIZE.csv"))
+    shutil.copy(wr, os.path.join(prof, f"{rnd}_pmc_{step}_WRITE_SIZE.csv"))
+    f, nf = counter_mean(rd, "FETCH_SIZE", kernel, skip)
+    w, nw = counter_mean(wr, "WRITE_SIZE", kernel, skip)
+    b = hbm(f, w)
+    return {"what": label, "kernel": kernel, "hbm_bytes": b, "FETCH_SIZE_KB_mean": round(f, 1), "WRITE_SIZE_KB_mean": round(w, 1),
+            "algorithmic_bytes": alg, "ratio_to_algorithmic": round(b / alg, 4) if alg else None, "correction": CORRECTION,
+            "source": f"profiles/{rnd}_pmc_{step}_FETCH_SIZE.csv + profiles/{rnd}_pmc_{step}_WRITE_SIZE.csv (separate rocprofv3 --pmc "
+                      f"passes over `{cmd}`; {nf} / {nw} launches)"}
+
+
+def workload_cg(tag, rnd, prof, alg_textbook, alg_moved):
+    """HBM bytes per CG ITERATION: every kernel of the iteration (SpMV + p.Ap epilogue, its partial reduction, the
+    residual update with its two reduction stages, the direction update), per-launch means x launches per iteration."""
+    rd = find(tag, "pmc_cg_FETCH_SIZE", "counter_collection.csv")
+    wr = find(tag, "pmc_cg_WRITE_SIZE", "counter_collection.csv")
+    shutil.copy(rd, os.path.join(prof, f"{rnd}_pmc_cg_FETCH_SIZE.csv"))
+    shutil.copy(wr, os.path.join(prof, f"{rnd}_pmc_cg_WRITE_SIZE.csv"))
+    names = ("spmv_rowblock_quad_kernel", "cg_direction_kernel", "cg_residual_kernel", "reduce_stage1", "reduce_stage2")
+    fk, wk = per_kernel(rd, "FETCH_SIZE"), per_kernel(wr, "WRITE_SIZE")
+    n_iter_f = sum(len(v) for k, v in fk.items() if "spmv_rowblock_quad_kernel" in k)
+    n_iter_w = sum(len(v) for k, v in wk.items() if "spmv_rowblock_quad_kernel" in k)
+    ftot = sum(sum(v) for k, v in fk.items() if any(n in k for n in names))
+    wtot = sum(sum(v) for k, v in wk.items() if any(n in k for n in names))
+    per = {}
+    for n in names:
+        f = [x for k, v in fk.items() if n in k for x in v]
+        w = [x for k, v in wk.items() if n in k for x in v]
+        per[n] = {"launches_per_iteration": round(len(f) / max(n_iter_f, 1), 2),
+                  "hbm_bytes_per_launch": hbm(sum(f) / max(len(f), 1), sum(w) / max(len(w), 1))}
+    b = hbm(ftot / n_iter_f, wtot / n_iter_w)
+    return {"what": "CG iteration, 3-D 7-pt 512x512x64 slab (config 4's per-GPU share), fused form",
+            "hbm_bytes": b, "per_kernel": per, "algorithmic_bytes_textbook": alg_textbook, "moved_bytes_fused_form": alg_moved,
+            "ratio_to_textbook": round(b / alg_textbook, 4), "ratio_to_moved": round(b / alg_moved, 4), "correction": CORRECTION,
+            "source": f"profiles/{rnd}_pmc_cg_FETCH_SIZE.csv + profiles/{rnd}_pmc_cg_WRITE_SIZE.csv (separate rocprofv3 --pmc passes over "
+                      f"`python3 bench.py --workload poisson3d_cg --steps 10 --warmup 5`; {n_iter_f} / {n_iter_w} iterations, all of "
+                      "them counted: setup launches of the same kernels included)"}
 
 
 def main():
     tag = sys.argv[1]
-    rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
+    rnd = sys.argv[2] if len(sys.argv) > 2 else "r03"
     prof = os.path.join(ROOT, "profiles")
     shutil.copy(find(tag, "prof", "kernel_stats.csv"), os.path.join(prof, f"{rnd}_bench_kernel_stats.csv"))
-    # the trace is large: keep the SpMV launches only
+    # the trace is large: keep the library's launches only
     src = find(tag, "prof", "kernel_trace.csv")
     with open(src, newline="") as f, open(os.path.join(prof, f"{rnd}_bench_kernel_trace.csv"), "w", newline="") as g:
         r = csv.reader(f)
@@ -53,24 +107,40 @@ def main():
         for row in r:
             if "hpcla::" in row[kcol]:
                 w.writerow(row)
-    rd = find(tag, "pmc_rd", "counter_collection.csv")
-    wr = find(tag, "pmc_wr", "counter_collection.csv")
+    rd = find(tag, "pmc_head_FETCH_SIZE", "counter_collection.csv")
+    wr = find(tag, "pmc_head_WRITE_SIZE", "counter_collection.csv")
     shutil.copy(rd, os.path.join(prof, f"{rnd}_bench_pmc_FETCH_SIZE.csv"))
     shutil.copy(wr, os.path.join(prof, f"{rnd}_bench_pmc_WRITE_SIZE.csv"))
     fetch_kb, nf = counter_mean(rd, "FETCH_SIZE")
     write_kb, nw = counter_mean(wr, "WRITE_SIZE")
-    hbm = int(round(2 * fetch_kb * 1024 + write_kb * 1024))
     out = {
         "kernel": "hpcla::" + KERNEL,
         "source": f"profiles/{rnd}_bench_pmc_FETCH_SIZE.csv + profiles/{rnd}_bench_pmc_WRITE_SIZE.csv (separate rocprofv3 "
                   f"--pmc passes over `python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-strong --no-extras --no-packed`; {nf} / {nw} launches)",
         "FETCH_SIZE_KB_mean": round(fetch_kb, 1), "WRITE_SIZE_KB_mean": round(write_kb, 1),
-        "correction": "gfx950: FETCH_SIZE counts 128-B requests at 64 B -> doubled (MI355X_MICROARCH.md, HBM); WRITE_SIZE exact",
-        "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": B_ALG,
-        "ratio_to_algorithmic": round(hbm / B_ALG, 4),
+        "correction": CORRECTION,
+        "hbm_bytes_per_launch": hbm(fetch_kb, write_kb), "algorithmic_bytes_per_launch": B_ALG,
+        "ratio_to_algorithmic": round(hbm(fetch_kb, write_kb) / B_ALG, 4),
         "calibration_note": "k_copy (known 1 207 762 944 B read with 16-B loads) read FETCH_SIZE 612 339 KB in the r01 "
                             "calibration pass (profiles/r01_calib_pmc_*.csv) -> factor 1.926 rather than 2",
     }
+    wl = {}
+    wl["poisson2d_spmv_int64"] = workload_single_kernel(
+        tag, "i64", "spmv_rowblock_quad_kernel<long, false, false>", rnd, prof, "headline matrix, Int64 indices", 1_744_568_328,
+        "python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-strong --no-extras --no-packed --index i64")
+    n3, nnz3 = 16_777_216, 116_785_152
+    b_spmv3 = 12 * nnz3 + 4 * (n3 + 1) + 8 * n3 + 8 * n3
+    wl["poisson3d_cg_iteration"] = workload_cg(tag, rnd, prof, b_spmv3 + 96 * n3, b_spmv3 + 64 * n3)
+    wl["poisson2d_spmm"] = workload_single_kernel(
+        tag, "spmm2d", "spmm_rowblock_vec_kernel", rnd, prof, "5-point matrix 4096x2048 rows x 16 columns", 2_684_207_108,
+        "python3 bench.py --workload poisson2d_spmm --steps 5 --warmup 5")
+    wl["sprand_spmm_b2e24"] = workload_single_kernel(
+        tag, "sprand8", "spmm_rowblock_vec_kernel", rnd, prof, "sprand 2 097 152 rows x 29.8, B = 2^24 rows x 16 (config 5's gather set)", 3_122_571_200,
+        "HPCLA_SPMM_COLS_MULT=8 python3 bench.py --workload sprand_spmm --steps 5 --warmup 5")
+    wl["sprand_spmm_mall_sized"] = workload_single_kernel(
+        tag, "sprand1", "spmm_rowblock_vec_kernel", rnd, prof, "sprand 2 097 152 rows x 29.8, B = 2 097 152 rows x 16 (Infinity-Cache-sized)", 1_295_259_584,
+        "HPCLA_SPMM_COLS_MULT=1 python3 bench.py --workload sprand_spmm --steps 5 --warmup 5")
+    out["workloads"] = wl
     with open(os.path.join(prof, "traffic_latest.json"), "w") as f:
         json.dump(out, f, indent=1)
     with open(os.path.join(prof, f"{rnd}_bench_kernel_stats.csv")) as f:

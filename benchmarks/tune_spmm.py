@@ -36,7 +36,7 @@ def main():
     ap.add_argument("--workload", default="poisson2d", choices=["poisson2d", "sprand"])
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--bmult", type=int, default=8)
-    ap.add_argument("--variants", default="100,0,7:1024,9,10:512,11,12:1024,1,4,5")
+    ap.add_argument("--variants", default="100,0,17,19,20:2,20:4,20:8,20:16,9")
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--build-only", action="store_true")
@@ -90,7 +90,7 @@ def main():
         n_brows = int(Bl.shape[0])
     C = torch.empty_like(C_ref)
     small = torch.rand(1024 * k, dtype=torch.float64, device=dev)
-    stamps = torch.zeros(16 + 4 * ((n + 63) // 64), dtype=torch.int64, device=dev)      # [16 + 4*b ..]: block b's phase stamps
+    stamps = torch.zeros(16 + 4 * ((n + 63) // 64) + ((n + 63) // 64 + 2) // 2 + 8, dtype=torch.int64, device=dev)   # ... then MODE 16's block starts      # [16 + 4*b ..]: block b's phase stamps
     b_alg = wl.spmm_algorithmic_bytes(nnz, n, A.ncols_compressed, k, 4)
 
     def parse(v):
@@ -138,7 +138,7 @@ def main():
     if any(v[0] == 5 for v in variants):
         launch((5, 0))
         torch.cuda.synchronize()
-        st = stamps[16:].view(-1, 4).double().cpu().numpy()
+        st = stamps[16:16 + 4 * ((n + 63) // 64)].view(-1, 4).double().cpu().numpy()
         tick_us = 0.01                                  # wall_clock64: 100 MHz
         names = ["rowptr round trip", "A entries: load + stage + barrier", "B gathers + flops", "C via LDS + stores drained"]
         mean = st.mean(axis=0) * tick_us

@@ -268,28 +268,86 @@ function LinearAlgebra.dot(x::HPCVector{T,B}, y::HPCVector{T,B}) where {T<:Float
     work, out = _scratch()
     _check(@ccall(LIB.hpcla_dot_f64(_rccl(x.backend.comm)::Ptr{Cvoid}, _ptr(x.v)::Ptr{Cvoid}, _ptr(y.v)::Ptr{Cvoid},
            length(x.v)::Int64, _ptr(out)::Ptr{Cvoid}, _ptr(work)::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_dot_f64")
-    return Array(out)[1]
+    return _host_scalar(out, x.backend)
 end
 function LinearAlgebra.norm(v::HPCVector{T,B}, p::Real=2) where {T<:Float64,B<:ROCBackend}
     work, out = _scratch(); c = _rccl(v.backend.comm); n = length(v.v)
     if p == 2
         _check(@ccall(LIB.hpcla_nrm2sq_f64(c::Ptr{Cvoid}, _ptr(v.v)::Ptr{Cvoid}, n::Int64, _ptr(out)::Ptr{Cvoid},
                _ptr(work)::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_nrm2sq_f64")
-        return sqrt(Array(out)[1])
+        return sqrt(_host_scalar(out, v.backend))
     elseif p == 1
         _check(@ccall(LIB.hpcla_asum_f64(c::Ptr{Cvoid}, _ptr(v.v)::Ptr{Cvoid}, n::Int64, _ptr(out)::Ptr{Cvoid},
                _ptr(work)::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_asum_f64")
-        return Array(out)[1]
+        return _host_scalar(out, v.backend)
     elseif p == Inf
         _check(@ccall(LIB.hpcla_amax_f64(c::Ptr{Cvoid}, _ptr(v.v)::Ptr{Cvoid}, n::Int64, _ptr(out)::Ptr{Cvoid},
                _ptr(work)::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_amax_f64")
-        return Array(out)[1]
+        return _host_scalar(out, v.backend)
     else
         p > 0 || return invoke(LinearAlgebra.norm, Tuple{HPCVector,Real}, v, p)     # generic path of the parent
         _check(@ccall(LIB.hpcla_powsum_f64(c::Ptr{Cvoid}, _ptr(v.v)::Ptr{Cvoid}, n::Int64, Float64(p)::Cdouble,
                _ptr(out)::Ptr{Cvoid}, _ptr(work)::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_powsum_f64")
-        return Array(out)[1]^(1 / p)
+        return _host_scalar(out, v.backend)^(1 / p)
     end
+end
+
+# A NaN that reaches the host may be the POISON of an expired exchange wait (the kernels never compute from stale
+# ghosts: rows / partials / all-reduce results that depended on a neighbour that did not show up within
+# HPCLA_PUSH_TIMEOUT_S become NaN, and the plan's sticky status word is set).  The reference's MPI exchange would
+# block instead (src/vectors.jl:446); here the failure is turned into an error wherever a scalar is read back.
+function _check_exchange_health(backend)
+    flag = Ref{Cint}(0)
+    c = _rccl(backend.comm)
+    if c != C_NULL
+        _check(@ccall(LIB.hpcla_comm_status(c::Ptr{Cvoid}, flag::Ptr{Cint})::Cint), "hpcla_comm_status")
+        flag[] == 0 || error("HPCLinearAlgebraROCmExt: a window all-reduce timed out (a rank did not arrive within HPCLA_PUSH_TIMEOUT_S)")
+    end
+    for d in values(_rocm_plans)
+        d isa ROCVectorPlan && d.halo != C_NULL || continue
+        _check(@ccall(LIB.hpcla_halo_status(d.halo::Ptr{Cvoid}, flag::Ptr{Cint})::Cint), "hpcla_halo_status")
+        flag[] == 0 || error("HPCLinearAlgebraROCmExt: a halo exchange timed out; the affected results are NaN")
+    end
+    return nothing
+end
+_host_scalar(out, backend) = (v = Array(out)[1]; isnan(v) && _check_exchange_health(backend); v)
+
+# ---- k fused CG iterations in ONE library call (the reference has no Krylov solver, SURVEY 3.4: a caller composes
+# the iteration from A*p src/sparse.jl:2096-2128, dot src/vectors.jl:798-812, the broadcasts :1203-1226 and norm
+# :758-765; this is that composition with neither Julia nor Python inside the loop).  x0 = 0, r0 = p0 = b;
+# returns (x, [norm(r_0), ..., norm(r_iters)]).
+function rocm_cg_iterations(A::HPCSparseMatrix{T,Ti,B}, b::HPCVector{T,B}, iters::Integer) where {T<:Float64,Ti,B<:ROCBackend}
+    assert_backends_compatible(A.backend, b.backend)
+    plan = get_vector_plan(A, b)
+    d = _device_plan(A, b, plan)
+    d.n_own == A.nrows_local || error("rocm_cg_iterations: b must be partitioned like the rows of A")
+    n = A.nrows_local
+    x = AMDGPU.zeros(T, n); r = copy(b.v); p = copy(b.v); Ap = similar(b.v)
+    hist = AMDGPU.zeros(T, iters + 1); pAp = AMDGPU.zeros(T, 1)
+    work, _ = _scratch()
+    dot_work = AMDGPU.zeros(UInt8, @ccall LIB.hpcla_spmv_dot_work_bytes(n::Int64)::Int64)
+    c = _rccl(A.backend.comm)
+    _check(@ccall(LIB.hpcla_nrm2sq_f64(c::Ptr{Cvoid}, _ptr(r)::Ptr{Cvoid}, n::Int64, _ptr(hist)::Ptr{Cvoid},
+           _ptr(work)::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_nrm2sq_f64")          # hist[1] = sum r0^2
+    rp0 = _rowptr0(A); nnz = length(A.nzval)
+    if Ti === Int32
+        _check(@ccall(LIB.hpcla_cg_iterations_f64_i32(d.halo::Ptr{Cvoid}, c::Ptr{Cvoid}, _ptr(rp0)::Ptr{Cvoid},
+               _ptr(d.colval_split)::Ptr{Cvoid}, _ptr(A.nzval)::Ptr{Cvoid}, n::Int64, nnz::Int64, 0::Cint,
+               _ptr(d.interior)::Ptr{Cvoid}, length(d.interior)::Int64, _ptr(d.boundary)::Ptr{Cvoid},
+               length(d.boundary)::Int64, _ptr(x)::Ptr{Cvoid}, _ptr(r)::Ptr{Cvoid}, _ptr(p)::Ptr{Cvoid}, _ptr(Ap)::Ptr{Cvoid},
+               _ptr(hist)::Ptr{Cvoid}, _ptr(pAp)::Ptr{Cvoid}, _ptr(dot_work)::Ptr{Cvoid}, _ptr(work)::Ptr{Cvoid},
+               Cint(iters)::Cint, _stream()::Ptr{Cvoid})::Cint), "hpcla_cg_iterations_f64_i32")
+    else
+        _check(@ccall(LIB.hpcla_cg_iterations_f64_i64(d.halo::Ptr{Cvoid}, c::Ptr{Cvoid}, _ptr(rp0)::Ptr{Cvoid},
+               _ptr(d.colval_split)::Ptr{Cvoid}, _ptr(A.nzval)::Ptr{Cvoid}, n::Int64, nnz::Int64, 0::Cint,
+               _ptr(d.interior)::Ptr{Cvoid}, length(d.interior)::Int64, _ptr(d.boundary)::Ptr{Cvoid},
+               length(d.boundary)::Int64, _ptr(x)::Ptr{Cvoid}, _ptr(r)::Ptr{Cvoid}, _ptr(p)::Ptr{Cvoid}, _ptr(Ap)::Ptr{Cvoid},
+               _ptr(hist)::Ptr{Cvoid}, _ptr(pAp)::Ptr{Cvoid}, _ptr(dot_work)::Ptr{Cvoid}, _ptr(work)::Ptr{Cvoid},
+               Cint(iters)::Cint, _stream()::Ptr{Cvoid})::Cint), "hpcla_cg_iterations_f64_i64")
+    end
+    h = sqrt.(Array(hist))
+    any(isnan, h) && _check_exchange_health(A.backend)
+    return HPCVector{T,B}(b.structural_hash, b.partition, x, A.backend), h
 end
 
 # sum / prod / maximum / minimum (src/vectors.jl:815-858): same two-stage device reduction + scalar all-reduce
@@ -305,7 +363,7 @@ function _reduce_scalar(sym::Symbol, v::HPCVector, negate::Int=0)
         _check(@ccall(LIB.hpcla_maxval_f64(c::Ptr{Cvoid}, _ptr(v.v)::Ptr{Cvoid}, n::Int64, negate::Cint, _ptr(out)::Ptr{Cvoid},
                _ptr(work)::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_maxval_f64")
     end
-    return Array(out)[1]
+    return _host_scalar(out, v.backend)
 end
 Base.sum(v::HPCVector{T,B}) where {T<:Float64,B<:ROCBackend} = _reduce_scalar(:sum, v)
 Base.prod(v::HPCVector{T,B}) where {T<:Float64,B<:ROCBackend} = _reduce_scalar(:prod, v)

@@ -601,13 +601,17 @@ __global__ void probe_fill_kernel(double *x, int64_t n, double base, double shif
         x[i] = base + (double)i + shift;
 }
 
+// EVERY workgroup checks EVERY sampled element (the grid is a few workgroups per XCD): after round one each XCD's L2
+// (and the L1 of every CU that ran a workgroup) holds the sampled lines of the ghost buffer, so round two -- which
+// rewrites a single-buffered (cacheable, fine-grained) dense ghost window with DIFFERENT values -- reads them WARM on
+// every XCD.  A line a peer's xGMI store failed to invalidate here shows up as a wrong value, the plan fails its
+// connection test on the real topology and stays on RCCL.  (Vector ghost windows are uncached and double-buffered.)
 __global__ void probe_check_kernel(const double *ghost, const int64_t *slots, const int64_t *rows,
                                    const int32_t *owners, int64_t n_check, int w, double shift,
                                    unsigned long long *bad)      // bad[0] = count, bad[1] = first wrong element
 {
     const int64_t total = n_check * w;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
-         e += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t e = threadIdx.x; e < total; e += blockDim.x) {
         const int64_t t = e / w;
         const int j = (int)(e % w);
         const double want = (double)owners[t] * 1099511627776.0 + (double)(rows[t] * w + j) + shift;
@@ -618,6 +622,8 @@ __global__ void probe_check_kernel(const double *ghost, const int64_t *slots, co
         }
     }
 }
+
+constexpr int PROBE_CHECK_BLOCKS = 64;          // 8 per XCD (workgroups are dealt round-robin over the XCDs)
 
 HPCLA_API int hpcla_halo_plan_probe(hpcla_halo_plan_t *plan, int64_t n_local_rows, const int64_t *check_slots_host,
                                     const int64_t *check_rows_host, int64_t n_check, void *stream, int *ok)
@@ -674,10 +680,8 @@ HPCLA_API int hpcla_halo_plan_probe(hpcla_halo_plan_t *plan, int64_t n_local_row
         double *ghost = nullptr;
         if (rc == HPCLA_OK) rc = hpcla_halo_ghost_ptr(plan, &ghost, nullptr);
         if (rc != HPCLA_OK) break;
-        if (n_check) {
-            g = (n_check * w + 255) / 256;
-            probe_check_kernel<<<(uint32_t)(g > 4096 ? 4096 : g), 256, 0, s>>>(ghost, d_slots, d_rows, d_own, n_check, w, shift, d_bad);
-        }
+        if (n_check)
+            probe_check_kernel<<<PROBE_CHECK_BLOCKS, 256, 0, s>>>(ghost, d_slots, d_rows, d_own, n_check, w, shift, d_bad);
         unsigned long long bad[2] = {0, 0};
         e = hipMemcpyAsync(bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
@@ -693,7 +697,7 @@ HPCLA_API int hpcla_halo_plan_probe(hpcla_halo_plan_t *plan, int64_t n_local_row
         if (bad[0]) {
             good = false;
             snprintf(why, sizeof(why), "halo_plan_probe: round %d: %llu of %lld checked ghost values wrong, first at ghost element %llu",
-                     round, bad[0], (long long)(n_check * w), bad[1]);
+                     round, (bad[0] + PROBE_CHECK_BLOCKS - 1) / PROBE_CHECK_BLOCKS, (long long)(n_check * w), bad[1]);
             break;
         }
     }
@@ -761,18 +765,23 @@ static int spmv_dist_impl(F split_fn, G fused_fn, hpcla_halo_plan_t *plan, const
         }
         PushArgs pa;
         int rcp;
-        if ((plan->idx_is_i64 != 0) == (sizeof(I) == 8)) {
+        const bool own_push_kernel = (plan->idx_is_i64 != 0) != (sizeof(I) == 8);
+        if (!own_push_kernel) {
             rcp = push_begin(plan, x, n_boundary, &pa);    // the push rides in the leading workgroups of the launch
         } else {                                           // send lists typed unlike the matrix: push kernel of its own
-            rcp = push_post(plan, x, n_boundary, stream);
+            rcp = push_post(plan, x, n_boundary, stream);  // (commits the step's epoch readers: see below)
             memset(&pa, 0, sizeof(pa));
         }
         if (rcp) return rcp;
         const bool contig = n_interior > 0 && plan->probed_contig;
         // (the ghost argument is buffer 0; a boundary workgroup computes the buffer of its epoch after its wait)
-        return fused_fn(rowptr, colval, nzval, x, plan->ghost, n_own, y, nrows, nnz, index_base,
-                        contig ? nullptr : interior, contig ? plan->probed_first : 0, n_interior, boundary,
-                        n_boundary, push_wait_args(plan, n_boundary), pa, stream, dot_partial);
+        const int rcf = fused_fn(rowptr, colval, nzval, x, plan->ghost, n_own, y, nrows, nnz, index_base,
+                                 contig ? nullptr : interior, contig ? plan->probed_first : 0, n_interior, boundary,
+                                 n_boundary, push_wait_args(plan, n_boundary), pa, stream, dot_partial);
+        // a refused launch behind an ALREADY POSTED push would strand the exchange's waiting readers (the step counter
+        // never advances, every later exchange of the plan reuses the epoch): release them without computing
+        if (rcf && own_push_kernel) (void)push_abandon_waiters(plan, n_boundary, stream);
+        return rcf;
     }
     if (mode == HALO_SERIAL) {
         int rc0 = halo_post(plan, x, stream, false, true);

@@ -132,6 +132,8 @@ bool halo_want_window();                       // false when HPCLA_HALO_MODE nam
 int push_begin(hpcla_halo_plan *plan, const double *x, int64_t n_wait_readers, PushArgs *out);   // launch args
 int push_post(hpcla_halo_plan *plan, const double *x, int64_t n_wait_readers, void *stream);     // own kernel
 int push_wait_kernel_launch(hpcla_halo_plan *plan, void *stream);          // standalone wait (halo_end)
+// after push_post(plan, x, n, ...) whose n consuming workgroups cannot be launched: release them (keeps the epochs in step)
+int push_abandon_waiters(hpcla_halo_plan *plan, int64_t n_wait_readers, void *stream);
 double *push_ghost_ptr(const hpcla_halo_plan *plan);                       // host view (may synchronise)
 HaloWait push_wait_args(const hpcla_halo_plan *plan, int64_t n_wait_readers);
 void push_free(hpcla_halo_plan *plan);

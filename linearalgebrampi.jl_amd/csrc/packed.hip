@@ -381,11 +381,19 @@ HPCLA_API int hpcla_spmv_dist_packed_f64_i32(hpcla_halo_plan_t *plan, hpcla_comm
         if (halo_mode_of(plan) == HALO_PUSH) {
             // push transport: the push kernel, the packed interior blocks, then the boundary blocks through the
             // CSR kernel's waiting form (they poll the flags themselves and find the ghost buffer of the epoch)
+            // everything that can be refused is checked BEFORE the exchange is posted: push_post commits this step's
+            // epoch readers (push workgroups + n_boundary waiting workgroups)
+            if ((n_interior > 0 && !interior_blocks) || (n_boundary > 0 && !boundary_blocks))
+                return set_error(HPCLA_ERR_INVALID, "spmv_dist_packed: null block list");
+            if (n_interior < 0 || n_boundary < 0 || n_interior + n_boundary > all_blocks)
+                return set_error(HPCLA_ERR_INVALID, "spmv_dist_packed: block counts out of range");
+            if (!rowptr || !y || (nnz > 0 && (!colval_split || !nzval || !x)))
+                return set_error(HPCLA_ERR_INVALID, "spmv_dist_packed: null array");
             rc = push_post(plan, x, n_boundary, stream);
             if (rc) return rc;
             if (n_interior > 0) {
                 rc = hpcla_spmv_packed_f64_i32(p, rowptr, x, y, index_base, interior_blocks, n_interior, partial, stream);
-                if (rc) return rc;
+                if (rc) { (void)push_abandon_waiters(plan, n_boundary, stream); return rc; }   // the posted readers still release
             }
             if (n_boundary > 0) {
                 PushArgs nopush;
@@ -393,7 +401,7 @@ HPCLA_API int hpcla_spmv_dist_packed_f64_i32(hpcla_halo_plan_t *plan, hpcla_comm
                 rc = spmv_fused_i32(rowptr, colval_split, nzval, x, plan->ghost, n_own, y, nrows, nnz, index_base,
                                     nullptr, 0, 0, boundary_blocks, n_boundary, push_wait_args(plan, n_boundary),
                                     nopush, stream, partial);
-                if (rc) return rc;
+                if (rc) { (void)push_abandon_waiters(plan, n_boundary, stream); return rc; }
             }
             if (dot_out_dev) {
                 rc = reduce_partials_sum(partial, all_blocks, scratch, dot_out_dev, stream);

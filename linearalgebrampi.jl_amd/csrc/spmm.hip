@@ -208,6 +208,12 @@ __global__ __launch_bounds__(TPB_MM) void spmm_rowblock_vec_kernel(
 {
     __shared__ SpmmEntry s_ent[CHUNK_V];
 
+    if (CSTAGE) {
+        // the device-native shape (k = 16, B / ghost / C rows of exactly 16 doubles: checked by the launcher): strides
+        // and the column-tile loop fold to constants (measured against a k = 16-only copy of this kernel in the tuning
+        // harness, benchmarks/tune/spmm_variants.hip MODE 0: the generic form ran 3 % behind it)
+        k = KT; b_rs = KT; bg_rs = KT; c_rs = KT;
+    }
     const int tid = threadIdx.x;
     const int g = tid / VG, l = tid % VG;   // g = row of the block (0..63)
     const uint32_t b = blockIdx.x;
@@ -408,7 +414,7 @@ static int spmm_launch(const I *rowptr, const I *colval, const double *nzval, co
             const char *e = getenv("HPCLA_SPMM_CSTAGE");
             return e ? atoi(e) : 1;
         }();
-        const bool cstage = cst_env != 0 && k == KT && c_rs == KT;
+        const bool cstage = cst_env != 0 && k == KT && c_rs == KT && b_rs == KT && (!split || bg_rs == KT);
 #define HPCLA_SPMM_VEC2(SP)                                                                             \
     do {                                                                                                \
         if (h64 && cstage) {                                                                            \

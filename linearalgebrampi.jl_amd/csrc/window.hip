@@ -316,6 +316,23 @@ int push_wait_kernel_launch(hpcla_halo_plan *p, void *stream)
     return HPCLA_OK;
 }
 
+// Stand-in for waiting workgroups that will never be launched (an error between push_post and the consuming launch):
+// the exchange's epoch readers were counted when it was posted, so the missing ones are released here -- each waits
+// for the flags like the real consumer would and releases the step counter -- and the plan stays in lockstep with its
+// neighbours instead of hanging every later exchange.
+__global__ __launch_bounds__(64) void halo_release_kernel(HaloWait w)
+{
+    (void)halo_wait_block(w, w.first_wait_reader + blockIdx.x);
+}
+
+int push_abandon_waiters(hpcla_halo_plan *p, int64_t n_wait_readers, void *stream)
+{
+    if (n_wait_readers <= 0) return HPCLA_OK;
+    halo_release_kernel<<<(uint32_t)n_wait_readers, 64, 0, as_stream(stream)>>>(push_wait_args(p, n_wait_readers));
+    HPCLA_CHECK_LAUNCH();
+    return HPCLA_OK;
+}
+
 void push_free(hpcla_halo_plan *p)
 {
     for (auto &m : p->peer_maps) window_close(&m);

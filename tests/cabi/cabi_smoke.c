@@ -2,7 +2,8 @@
  * only (plain C + the HIP runtime for memory), the way the Julia extension's @ccall stubs do:
  * generate the 2-D Poisson rows on the device, build the compressed column space on the device,
  * run y = A*x through the plain CSR entry point AND the distributed entry point (serial communicator,
- * no neighbours), a dot product and a fused CG update, and compare with a scalar CPU loop.
+ * no neighbours), a dot product, a fused CG update and 12 CG iterations enqueued by ONE call, and compare with
+ * scalar CPU loops.
  * Build/run: tests/test_cabi_from_c.py (gcc + libamdhip64 for hipMalloc/hipMemcpy only). */
 #include <hip/hip_runtime_api.h>
 #include <math.h>
@@ -158,6 +159,56 @@ int main(int argc, char **argv)
     double rr_ref = 0.0;
     for (int64_t r = 0; r < n; ++r) { const double rn = h_y[r] - 0.5 * h_y[r]; rr_ref += rn * rn; }
     if (fabs(h_s[1] - rr_ref) > 1e-12 * rr_ref) { fprintf(stderr, "cg_update rr %g vs %g\n", h_s[1], rr_ref); return 1; }
+
+    /* (5) 12 CG iterations enqueued by ONE call (hpcla_cg_iterations_f64_i32: no host language in the loop), b = x,
+     * against the textbook recurrence on the host: row-sequential SpMV like the reference loop; the dot products are
+     * tree sums on the device, so the residual history is compared at 1e-12 relative (BASELINE's tolerance) */
+    {
+        const int iters = 12;
+        double *cx, *cr, *cp, *cAp, *hist, *pAp;
+        void *dot_work;
+        HIPCHECK(hipMalloc((void **)&cx, n * 8)); HIPCHECK(hipMalloc((void **)&cr, n * 8));
+        HIPCHECK(hipMalloc((void **)&cp, n * 8)); HIPCHECK(hipMalloc((void **)&cAp, n * 8));
+        HIPCHECK(hipMalloc((void **)&hist, (iters + 1) * 8)); HIPCHECK(hipMalloc((void **)&pAp, 8));
+        HIPCHECK(hipMalloc(&dot_work, hpcla_spmv_dot_work_bytes(n)));
+        HIPCHECK(hipMemset(cx, 0, n * 8));
+        HIPCHECK(hipMemcpy(cr, x, n * 8, hipMemcpyDeviceToDevice));
+        HIPCHECK(hipMemcpy(cp, x, n * 8, hipMemcpyDeviceToDevice));
+        HIPCHECK(hipMemset(hist, 0, (iters + 1) * 8));
+        CHECK(hpcla_nrm2sq_f64(comm, cr, n, hist, rwork, NULL));                       /* hist[0] = sum r0^2 */
+        CHECK(hpcla_cg_iterations_f64_i32(NULL, comm, rowptr, colval, vals, n, nnz, 0, NULL, 0, NULL, 0, cx, cr, cp, cAp,
+                                          hist, pAp, dot_work, rwork, iters, NULL));
+        double *h_hist = (double *)malloc((iters + 1) * 8), *h_cx = (double *)malloc(n * 8);
+        HIPCHECK(hipMemcpy(h_hist, hist, (iters + 1) * 8, hipMemcpyDeviceToHost));
+        HIPCHECK(hipMemcpy(h_cx, cx, n * 8, hipMemcpyDeviceToHost));
+        double *rx = (double *)calloc(n, 8), *rr_ = (double *)malloc(n * 8), *rp = (double *)malloc(n * 8), *rAp = (double *)malloc(n * 8);
+        double rr = 0.0;
+        for (int64_t i = 0; i < n; ++i) { rr_[i] = rp[i] = h_x[i]; rr += h_x[i] * h_x[i]; }
+        if (fabs(h_hist[0] - rr) > 1e-12 * rr) { fprintf(stderr, "cg: r0.r0 %g vs %g\n", h_hist[0], rr); return 1; }
+        for (int it = 0; it < iters; ++it) {
+            double pap = 0.0;
+            for (int64_t r = 0; r < n; ++r) {
+                double acc = 0.0;
+                for (int64_t j = h_rp[r]; j < h_rp[r + 1]; ++j) acc += h_val[j] * rp[h_col[j]];
+                rAp[r] = acc; pap += rp[r] * acc;
+            }
+            const double a = rr / pap;
+            double rr_new = 0.0;
+            for (int64_t i = 0; i < n; ++i) { rr_[i] -= a * rAp[i]; rr_new += rr_[i] * rr_[i]; }
+            const double bta = rr_new / rr;
+            for (int64_t i = 0; i < n; ++i) { rx[i] += a * rp[i]; rp[i] = rr_[i] + bta * rp[i]; }
+            rr = rr_new;
+            if (fabs(h_hist[it + 1] - rr) > 1e-12 * rr) {
+                fprintf(stderr, "cg: iteration %d: sum r^2 %.17g (device) vs %.17g (host)\n", it + 1, h_hist[it + 1], rr);
+                return 1;
+            }
+        }
+        double xmax = 0.0, dmax = 0.0;
+        for (int64_t i = 0; i < n; ++i) { xmax = fmax(xmax, fabs(rx[i])); dmax = fmax(dmax, fabs(rx[i] - h_cx[i])); }
+        if (dmax > 1e-12 * xmax) { fprintf(stderr, "cg: x differs by %g of max |x| %g\n", dmax, xmax); return 1; }
+        printf("C-ABI CG: %d iterations in one call, residual history within 1e-12 of the host recurrence, |dx|/|x| = %.1e\n",
+               iters, dmax / xmax);
+    }
 
     /* error convention: negative status + message, never abort */
     if (hpcla_spmv_csr_f64_i32(NULL, NULL, NULL, NULL, NULL, 5, 5, 0, NULL) != HPCLA_ERR_INVALID ||
