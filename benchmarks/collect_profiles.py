@@ -22,7 +22,8 @@ CORRECTION = "gfx950: FETCH_SIZE counts 128-B requests at 64 B -> doubled (MI355
 
 
 def find(tag, step, suffix):
-    hits = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"{tag}_{step}", "**", f"*{suffix}"), recursive=True))
+    hits = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"{tag}_{step}", "**", f"*{suffix}"), recursive=True),
+                  key=os.path.getmtime)                    # the NEWEST: a reused tag may have left older files behind
     if not hits:
         raise SystemExit(f"no *{suffix} under gpurun_out/{tag}_{step}")
     return hits[-1]
