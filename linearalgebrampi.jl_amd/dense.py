@@ -428,20 +428,10 @@ class SpmmPanelPlan:
         send_indices, recv_counts = info["send_indices"], info["recv_counts"]
         colval_split = ent[4]
         n_own = plan.n_own
+        from .sparse import panel_chunk_lists
         cut = lambda n, c: (n * c) // n_chunks                      # both ends of a link cut its list the same way
-        # ghost position (in the sequential plan's ghost order) -> (chunk, position in that chunk-set's ghost)
-        n_ghost = int(sum(recv_counts))
-        chunk_of = np.empty(n_ghost, dtype=np.int8)
-        newpos = np.empty(n_ghost, dtype=np.int64)
-        chunk_fill = [0] * n_chunks
-        off = 0
-        for cnt in recv_counts:
-            for c in range(n_chunks):
-                lo, hi = cut(cnt, c), cut(cnt, c + 1)
-                chunk_of[off + lo:off + hi] = c
-                newpos[off + lo:off + hi] = chunk_fill[c] + np.arange(hi - lo, dtype=np.int64)
-                chunk_fill[c] += hi - lo
-            off += cnt
+        send_chunks, recv_chunk_counts, chunk_of, newpos = panel_chunk_lists(send_indices, recv_counts, n_chunks)
+        n_ghost = len(chunk_of)
         # one chained halo plan per chunk-set
         n_send, n_recv = len(h.send_rank_ids), len(h.recv_rank_ids)
         send_ranks = (ctypes.c_int32 * max(n_send, 1))(*h.send_rank_ids)
@@ -450,8 +440,7 @@ class SpmmPanelPlan:
         wish = info["wish"]
         torch.cuda.current_stream().synchronize()
         for c in range(n_chunks):
-            s_lists = [np.asarray(i[cut(len(i), c):cut(len(i), c + 1)], dtype=np.int64) for i in send_indices]
-            r_counts = [cut(cnt, c + 1) - cut(cnt, c) for cnt in recv_counts]
+            s_lists, r_counts = send_chunks[c], recv_chunk_counts[c]
             send_counts = (ctypes.c_int64 * max(n_send, 1))(*[len(i) for i in s_lists])
             recv_cnt_c = (ctypes.c_int64 * max(n_recv, 1))(*r_counts)
             send_idx = torch.from_numpy(np.concatenate(s_lists).astype(Ti)).to(dev) if n_send else None

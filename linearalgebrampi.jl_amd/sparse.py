@@ -151,6 +151,36 @@ def whole_slice_lists(plan: HostVectorPlan, col_indices: np.ndarray, x_partition
     return send_indices, recv_counts, m
 
 
+def panel_chunk_lists(send_indices, recv_counts, n_chunks: int):
+    """Cut an exchange into ``n_chunks`` chunk-sets for the panel-ordered SpMM (dense.SpmmPanelPlan): every link's list is
+    cut at ``floor(c * len / n_chunks)`` on BOTH ends (sender: its index list; receiver: the count it expects), so the
+    two ends agree without exchanging anything.  Returns
+
+    * ``send_chunks[c][j]``  -- the part of ``send_indices[j]`` that travels in chunk-set c (order kept),
+    * ``recv_chunk_counts[c][i]`` -- entries neighbour i delivers in chunk-set c,
+    * ``chunk_of[p]``, ``newpos[p]`` -- for ghost position p of the UNCUT exchange (segments back to back in neighbour
+      order): the chunk-set that carries it and its position in that chunk-set's ghost buffer (again the neighbours'
+      parts back to back in neighbour order)."""
+    cut = lambda n, c: (int(n) * c) // n_chunks
+    send_chunks = [[np.asarray(i[cut(len(i), c):cut(len(i), c + 1)], dtype=np.int64) for i in send_indices]
+                   for c in range(n_chunks)]
+    recv_chunk_counts = [[cut(cnt, c + 1) - cut(cnt, c) for cnt in recv_counts] for c in range(n_chunks)]
+    n_ghost = int(sum(int(c) for c in recv_counts))
+    chunk_of = np.empty(n_ghost, dtype=np.int64)
+    newpos = np.empty(n_ghost, dtype=np.int64)
+    fill = [0] * n_chunks
+    off = 0
+    for cnt in recv_counts:
+        cnt = int(cnt)
+        for c in range(n_chunks):
+            lo, hi = cut(cnt, c), cut(cnt, c + 1)
+            chunk_of[off + lo:off + hi] = c
+            newpos[off + lo:off + hi] = fill[c] + np.arange(hi - lo, dtype=np.int64)
+            fill[c] += hi - lo
+        off += cnt
+    return send_chunks, recv_chunk_counts, chunk_of, newpos
+
+
 # =====================================================================================================
 # device plan
 # =====================================================================================================

@@ -252,6 +252,65 @@ def test_whole_slice_lists_reproduce_the_gathered_rows(hp, orc, nranks):
         np.testing.assert_array_equal(ext[cmap], Bg[cis[r]])
 
 
+@pytest.mark.parametrize("nranks,n_chunks", [(2, 4), (3, 3), (4, 5), (4, 1)])
+def test_panel_chunk_lists_agree_on_both_ends_and_reproduce_the_exchange(hp, orc, nranks, n_chunks):
+    """Panel-ordered SpMM (HPCLA_SPMM_ORDER=panel): every link's list is cut into chunk-sets on both ends by the same
+    formula.  All ranks simulated: per chunk-set the sender's piece has the length the receiver expects, the emulated
+    chunk-set exchanges put every ghost row exactly where (chunk_of, newpos) say, the mapping is a bijection onto the
+    chunk-sets' ghost buffers, and chunk-sets of a link follow each other in list order (arrival order = column order
+    inside a neighbour's segment)."""
+    from hpcla_amd.sparse import panel_chunk_lists, whole_slice_lists, whole_slice_wishes
+    rng = np.random.default_rng(7 * nranks + n_chunks)
+    n = 97 * nranks + 5
+    xp = orc.uniform_partition(n, nranks)
+    cis = []
+    for r in range(nranks):
+        sel = []
+        for o in range(nranks):
+            frac = 1.0 if o == r else (0.95 if o == (r + 1) % nranks else 0.07)    # whole-slice and requested-rows links
+            cols = np.arange(xp[o], xp[o + 1])
+            sel.append(cols[rng.random(len(cols)) < frac])
+        cis.append(np.sort(np.concatenate(sel)).astype(np.int64))
+    oplans = orc.vector_plans(cis, xp)
+    plans = [hp.HostVectorPlan(p.send_rank_ids, p.send_indices, p.recv_rank_ids, p.recv_perm, p.local_src_indices,
+                               p.local_dst_indices, p.n_gathered, int(xp[r + 1] - xp[r])) for r, p in enumerate(oplans)]
+    wishes = [whole_slice_wishes(p, xp, nranks) for p in plans]
+    granted = [np.array([wishes[q][r] for q in range(nranks)]) for r in range(nranks)]
+    lists = [whole_slice_lists(plans[r], cis[r], xp, wishes[r], granted[r]) for r in range(nranks)]
+    cut = [panel_chunk_lists(lists[r][0], lists[r][1], n_chunks) for r in range(nranks)]
+    Bg = rng.random((n, 2))
+    for r in range(nranks):
+        send_idx_r, recv_counts, cmap = lists[r]
+        _, recv_chunk_counts, chunk_of, newpos = cut[r]
+        n_ghost = int(sum(recv_counts))
+        # what the UNCUT exchange delivers, in ghost order
+        whole = np.concatenate([Bg[xp[src]:xp[src + 1]][lists[src][0][plans[src].send_rank_ids.index(r)]]
+                                for src in plans[r].recv_rank_ids]) if n_ghost else np.empty((0, 2))
+        # emulate the chunk-set exchanges
+        bufs = []
+        for c in range(n_chunks):
+            parts = []
+            for i, src in enumerate(plans[r].recv_rank_ids):
+                piece = cut[src][0][c][plans[src].send_rank_ids.index(r)]
+                assert len(piece) == recv_chunk_counts[c][i], "the two ends of a link disagree on a chunk's size"
+                parts.append(Bg[xp[src]:xp[src + 1]][piece])
+            bufs.append(np.concatenate(parts) if parts else np.empty((0, 2)))
+        assert sum(len(b) for b in bufs) == n_ghost
+        seen = [np.zeros(len(b), dtype=bool) for b in bufs]
+        for p in range(n_ghost):
+            c, q = int(chunk_of[p]), int(newpos[p])
+            np.testing.assert_array_equal(bufs[c][q], whole[p])
+            assert not seen[c][q]
+            seen[c][q] = True
+        assert all(s.all() for s in seen)
+        # chunks of one neighbour's segment are contiguous pieces in order
+        off = 0
+        for cnt in recv_counts:
+            seg = chunk_of[off:off + cnt]
+            assert np.all(np.diff(seg) >= 0)
+            off += cnt
+
+
 def test_rccl_init_guard_reports_failure_and_deadline(hp, monkeypatch):
     """backends._init_rccl_guarded: ncclCommInitRank runs on a helper thread with a deadline; a failing or a
     hanging initialisation becomes a REASON (all-gathered by the caller, who then continues on the peer
