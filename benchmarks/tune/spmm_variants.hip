@@ -32,6 +32,8 @@
 //          that hold a second entry pay two dependent memory round trips)
 // MODE 18  everything: MODE 16 (last entry first, touches, block starts) + MODE 17
 // MODE 19  MODE 17 + block starts from the compact array (no touches)
+// MODE 21  MODE 0 with NON-TEMPORAL stores of C (the result is never re-read: keep its lines out of L2 / Infinity Cache)
+// MODE 22  MODE 0 with the A entries requested as plain (cacheable) loads instead of non-temporal ones
 // MODE 20  LOADER WAVE: a workgroup of FIVE waves owns `param` consecutive 64-row tiles; wave 4 does nothing but the
 //          front end -- tile boundaries, per-row rowptr values and the A entries of tile t+1 (requested one tile ahead,
 //          staged as records into the other half of a double-buffered LDS area) -- while waves 0-3 gather / multiply /
@@ -139,9 +141,9 @@ __global__ __launch_bounds__(TPB) void k_spmm(const int *__restrict__ rowptr, co
             }
         } else
         for (int i = tid; i < n; i += TPB) {
-            const int64_t col = __builtin_nontemporal_load(colval + p0 + ch + i);
+            const int64_t col = MODE == 22 ? colval[p0 + ch + i] : __builtin_nontemporal_load(colval + p0 + ch + i);
             Entry e;
-            e.val = __builtin_nontemporal_load(nzval + p0 + ch + i);
+            e.val = MODE == 22 ? nzval[p0 + ch + i] : __builtin_nontemporal_load(nzval + p0 + ch + i);
             e.row = B + col * KT;
             if (MODE == 15 || MODE == 16) touch_sink += *reinterpret_cast<const int *>(e.row);   // the line starts its trip now
             s_ent[i] = e;
@@ -269,6 +271,7 @@ __global__ __launch_bounds__(TPB) void k_spmm(const int *__restrict__ rowptr, co
         const int i = tid + u * TPB;
         if (i < nr * (KT / 2)) {
             if (MODE == 4) { if (srcl[i].x == 1.2345e301) dst[i] = srcl[i]; }
+            else if (MODE == 21) __builtin_nontemporal_store(srcl[i], dst + i);
             else dst[i] = srcl[i];
         }
     }
@@ -657,6 +660,8 @@ extern "C" int hpcla_tune_spmm(int mode, const void *rowptr, const void *colval,
     case 14: LAUNCH(14); break;
     case 15: LAUNCH(15); break;
     case 17: LAUNCH(17); break;
+    case 21: LAUNCH(21); break;
+    case 22: LAUNCH(22); break;
     case 19: {
         int *bp = reinterpret_cast<int *>(reinterpret_cast<unsigned long long *>(stamps) + 16 + 4 * (size_t)grid);
         k_bptr<<<(grid + 1 + 255) / 256, 256, 0, s>>>((const int *)rowptr, bp, nrows, (int)grid);

@@ -311,7 +311,9 @@ __global__ __launch_bounds__(TPB_MM) void spmm_rowblock_vec_kernel(
 #pragma unroll
             for (int u = 0; u < (RPB_MM * KT / 2) / TPB_MM; ++u) {
                 const int i = tid + u * TPB_MM;
-                if (i < nr * (KT / 2)) dst[i] = src[i];
+                // non-temporal: C is never re-read by this kernel; measured -1.4 % (stencil) / -1.2 % (config 5's
+                // pattern) against plain stores, benchmarks/tune_spmm.py MODE 21 (profiles/r03_spmm_ablations_and_candidates.txt)
+                if (i < nr * (KT / 2)) __builtin_nontemporal_store(src[i], dst + i);
             }
         } else
         if (g < nr && col_ok) {

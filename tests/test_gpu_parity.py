@@ -497,6 +497,55 @@ def test_spmm_bit_exact_raw_abi(hp, orc, gpu_backend_i32, k, layout):
     np.testing.assert_array_equal(C, want)
 
 
+@pytest.mark.parametrize("k", [16, 12, 3, 1])
+@pytest.mark.parametrize("Ti", [np.int32, np.int64])
+def test_spmm_panel_accumulate_is_one_running_sum(hp, orc, gpu_backend_i32, k, Ti):
+    """hpcla_spmm_panel_* with accumulate = 1 CONTINUES every C(r, c) from its current value, entry by entry.  A product
+    taken panel by panel (own columns, then two ghost panels) is therefore the reference's sum in a different ORDER, not a
+    sum of separately rounded partials: it must equal, BIT FOR BIT, a CPU loop that adds each row's terms in panel order --
+    and the sequential product only to 1e-12 (asserted with the componentwise |A||B| bound of SURVEY 8d)."""
+    import torch
+    n, m = 1500, 1300
+    rows = orc.sprand_rows(m, 0.012, 0, n)
+    ci, cv = orc.compress_columns(rows)
+    nc = len(ci)
+    B = orc.fill_uniform(0, nc * k, 21).reshape(nc, k) - 0.5
+    rp = rows.rowptr.astype(np.int64)
+    # three column panels: "own" columns [0, c1), ghost panel A [c1, c2), ghost panel B [c2, nc); each ghost panel's
+    # columns are positions in ITS buffer
+    c1, c2 = nc // 3, (2 * nc) // 3
+    pid = np.where(cv < c1, 0, np.where(cv < c2, 1, 2))
+    rowid = np.repeat(np.arange(n), np.diff(rp))
+    want_order = np.zeros((n, k))
+    panels = []
+    for q, base in ((0, 0), (1, c1), (2, c2)):
+        sel = np.flatnonzero(pid == q)
+        prp = np.concatenate([[0], np.cumsum(np.bincount(rowid[sel], minlength=n))])
+        panels.append((prp.astype(Ti), (cv[sel] - base).astype(Ti), rows.vals[sel]))
+        for r in range(n):                                   # the CPU loop in panel order: one running sum per entry of C
+            for j in range(prp[r], prp[r + 1]):
+                want_order[r] += rows.vals[sel][j] * B[cv[sel][j]]
+    sfx = "i32" if Ti == np.int32 else "i64"
+    s = torch.cuda.current_stream().cuda_stream
+    dB_own, dB_g1, dB_g2 = _t(B[:c1].ravel()), _t(B[c1:c2].ravel()), _t(B[c2:].ravel())
+    dC = torch.full((n * k,), float("nan"), dtype=torch.float64, device="cuda")
+    keep = []
+    for q, (prp, pcv, pval) in enumerate(panels):
+        d = (_t(prp), _t(pcv), _t(pval))
+        keep.append(d)
+        n_own = c1 if q == 0 else 0                          # ghost panels: every column is a ghost position
+        ghost = None if q == 0 else (dB_g1 if q == 1 else dB_g2).data_ptr()
+        hp._capi.call(f"hpcla_spmm_panel_f64_{sfx}", d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), dB_own.data_ptr(), k,
+                      ghost, k, n_own, dC.data_ptr(), k, n, len(pval), k, 0, 0 if q == 0 else 1, s)
+    torch.cuda.synchronize()
+    C = dC.cpu().numpy().reshape(n, k)
+    np.testing.assert_array_equal(C, want_order)             # one running sum in panel order: exact
+    seq = orc.spmm(rows.rowptr.astype(np.int32), cv.astype(np.int32), rows.vals, B)
+    bound = orc.spmm(rows.rowptr.astype(np.int32), cv.astype(np.int32), np.abs(rows.vals), np.abs(B))
+    assert np.all(np.abs(C - seq) <= 1e-12 * bound)
+    assert np.linalg.norm(C - seq) <= 1e-12 * np.linalg.norm(seq)
+
+
 def test_transpose_layout_conversion(hp, gpu_backend_i32):
     import torch
     for rows, cols in ((1, 1), (33, 16), (1000, 16), (65, 70)):
