@@ -39,6 +39,9 @@
 //          staged as records into the other half of a double-buffered LDS area) -- while waves 0-3 gather / multiply /
 //          store tile t.  The front end of a tile (two dependent memory round trips, 46 % of a workgroup's lifetime by
 //          the MODE 5 stamps) then occupies ONE wave slot instead of four, and never the compute waves.
+// MODE 23:W  WIDE ROUNDS: up to W (= 5, 6, 8) entries of a row are requested in ONE masked round (the shipped kernel takes
+//          them two at a time: a 5-entry stencil row is three dependent gather rounds); more bytes in flight per wave at the
+//          price of registers (fewer, fatter waves).  Entry order of the sums unchanged (same bits).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -636,6 +639,83 @@ __global__ __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     }
 }
 
+// ---- MODE 23: wide masked gather rounds ----------------------------------------------------------------------------------
+template <int W, int WAVES_PER_EU>
+__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(WAVES_PER_EU, 8))) void k_spmm_wide(
+    const int *__restrict__ rowptr, const int *__restrict__ colval, const double *__restrict__ nzval,
+    const double *__restrict__ B, double *__restrict__ C, int64_t nrows)
+{
+    __shared__ Entry s_ent[CHUNK_V];
+    const int tid = threadIdx.x;
+    const int g = tid / VG, l = tid % VG;
+    const int64_t r0 = (int64_t)blockIdx.x * RPB;
+    const int nr = (int)((nrows - r0) < RPB ? (nrows - r0) : RPB);
+    const int64_t p0 = rowptr[r0];
+    const int64_t p1 = rowptr[r0 + nr];
+    const int64_t total = p1 - p0;
+    int64_t lo = 0, hi = 0;
+    if (g < nr) {
+        lo = (int64_t)rowptr[r0 + g] - p0;
+        hi = (int64_t)rowptr[r0 + g + 1] - p0;
+    }
+    const int c = 2 * l;
+    const int64_t lane_bytes = (int64_t)c * 8;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int64_t ch = 0; ch < total; ch += CHUNK_V) {
+        const int n = (int)((total - ch) < CHUNK_V ? (total - ch) : CHUNK_V);
+        __syncthreads();
+        for (int i = tid; i < n; i += TPB) {
+            const int64_t col = __builtin_nontemporal_load(colval + p0 + ch + i);
+            Entry e;
+            e.val = __builtin_nontemporal_load(nzval + p0 + ch + i);
+            e.row = B + col * KT;
+            s_ent[i] = e;
+        }
+        __syncthreads();
+        int j = (int)((lo > ch ? lo : ch) - ch);
+        const int e = (int)((hi < ch + n ? hi : ch + n) - ch);
+        for (; j < e; j += W) {
+            Entry en[W];
+            vdouble2 b0[W], b1[W];
+#pragma unroll
+            for (int u = 0; u < W; ++u) en[u] = s_ent[j + u < e ? j + u : j];          // clamped: always a valid record
+#pragma unroll
+            for (int u = 0; u < W; ++u) {
+                const char *src = reinterpret_cast<const char *>(en[u].row) + lane_bytes;
+                if (j + u < e) {
+                    b0[u] = *(gvec2_ptr)(src);
+                    b1[u] = *(gvec2_ptr)(src + 64);
+                } else {
+                    b0[u] = b1[u] = (vdouble2)(0.0);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < W; ++u) {
+                if (j + u < e) {
+                    acc[0] += en[u].val * b0[u].x;
+                    acc[1] += en[u].val * b0[u].y;
+                    acc[2] += en[u].val * b1[u].x;
+                    acc[3] += en[u].val * b1[u].y;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    double *s_c = reinterpret_cast<double *>(s_ent);
+    vdouble2 o0, o1;
+    o0.x = acc[0]; o0.y = acc[1]; o1.x = acc[2]; o1.y = acc[3];
+    *reinterpret_cast<vdouble2 *>(s_c + g * KT + c) = o0;
+    *reinterpret_cast<vdouble2 *>(s_c + g * KT + c + 8) = o1;
+    __syncthreads();
+    vdouble2 *dst = reinterpret_cast<vdouble2 *>(C + r0 * KT);
+    const vdouble2 *srcl = reinterpret_cast<const vdouble2 *>(s_c);
+#pragma unroll
+    for (int u = 0; u < (RPB * KT / 2) / TPB; ++u) {
+        const int i = tid + u * TPB;
+        if (i < nr * (KT / 2)) __builtin_nontemporal_store(srcl[i], dst + i);
+    }
+}
+
 extern "C" int hpcla_tune_spmm(int mode, const void *rowptr, const void *colval, const void *nzval, const void *B,
                                void *C, int64_t nrows, int64_t n_brows, const void *small_tab, void *stamps,
                                int param, void *stream)
@@ -659,6 +739,17 @@ extern "C" int hpcla_tune_spmm(int mode, const void *rowptr, const void *colval,
     case 13: LAUNCH(13); break;
     case 14: LAUNCH(14); break;
     case 15: LAUNCH(15); break;
+    case 23: {
+        const int *rp = (const int *)rowptr, *cv = (const int *)colval;
+        const double *nz = (const double *)nzval, *Bp = (const double *)B;
+        double *Cp = (double *)C;
+        if (param == 3) k_spmm_wide<3, 6><<<grid, TPB, 0, s>>>(rp, cv, nz, Bp, Cp, nrows);
+        else if (param == 5) k_spmm_wide<5, 4><<<grid, TPB, 0, s>>>(rp, cv, nz, Bp, Cp, nrows);
+        else if (param == 6) k_spmm_wide<6, 4><<<grid, TPB, 0, s>>>(rp, cv, nz, Bp, Cp, nrows);
+        else if (param == 8) k_spmm_wide<8, 3><<<grid, TPB, 0, s>>>(rp, cv, nz, Bp, Cp, nrows);
+        else return -2;
+        break;
+    }
     case 17: LAUNCH(17); break;
     case 21: LAUNCH(21); break;
     case 22: LAUNCH(22); break;
