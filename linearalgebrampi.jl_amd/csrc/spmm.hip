@@ -21,10 +21,7 @@
 namespace hpcla {
 
 constexpr int TPB_MM = 256;
-constexpr int GROUP = 16;                   // lanes per row
-constexpr int NGROUPS = TPB_MM / GROUP;     // 16 rows in flight per pass
-constexpr int SLOTS = 4;                    // rows per lane-group
-constexpr int RPB_MM = NGROUPS * SLOTS;     // 64 rows per block
+constexpr int RPB_MM = 64;                  // rows per workgroup (the granularity of the callers' block lists)
 constexpr int CHUNK_MM = 2048;              // entries staged per pass: 2048 * 12 B = 24 KiB
 constexpr int KT = 16;                      // columns per tile (one per lane of a group)
 
@@ -34,7 +31,10 @@ constexpr int KT = 16;                      // columns per tile (one per lane of
 // interleaved form measured 1.255 -> 1.041 ms on the 5-point matrix x 16 columns and 1.707 -> 1.616 ms
 // on config 5's random pattern, profiles/r01_spmm_variants.log.)  Per row the entries are still
 // accumulated one after the other in stored order: same bits.
-template <typename I, bool SPLIT>
+// GRP = lanes per row = columns per tile (16, 8 or 4: the smallest that holds k, so that a narrow B does not leave most
+// lanes of a group idle -- k = 3 on 16 lanes per row ran at 0.12 of peak, profiles/r03_spmm_rate_vs_k_before.log);
+// a group owns SL = GRP / 4 rows, a workgroup 64 rows whatever GRP is (the block lists' granularity).
+template <typename I, bool SPLIT, int GRP>
 __global__ __launch_bounds__(TPB_MM) void spmm_rowblock_kernel(
     const I *__restrict__ rowptr, const I *__restrict__ colval, const double *__restrict__ nzval,
     const double *__restrict__ B_own, int64_t b_rs, int64_t b_cs,
@@ -46,7 +46,9 @@ __global__ __launch_bounds__(TPB_MM) void spmm_rowblock_kernel(
     __shared__ int64_t s_col[CHUNK_MM];   // element offset of the B row (col * row stride), 64-bit
 
     const int tid = threadIdx.x;
-    const int g = tid / GROUP, l = tid % GROUP;
+    constexpr int NGR = TPB_MM / GRP, SL = RPB_MM / NGR;        // groups per workgroup, rows per group
+    static_assert(NGR * SL == RPB_MM && SL >= 1, "64 rows per workgroup");
+    const int g = tid / GRP, l = tid % GRP;
     const uint32_t b = blockIdx.x;
     const int64_t blk = block_list ? (int64_t)block_list[b] : (int64_t)b;
     const int64_t r0 = blk * RPB_MM;
@@ -55,10 +57,10 @@ __global__ __launch_bounds__(TPB_MM) void spmm_rowblock_kernel(
     const int64_t p1 = (int64_t)rowptr[r0 + nr] - base;
     const int64_t total = p1 - p0;
 
-    int64_t lo[SLOTS], hi[SLOTS];
+    int64_t lo[SL], hi[SL];
 #pragma unroll
-    for (int s = 0; s < SLOTS; ++s) {
-        const int r = g + s * NGROUPS;
+    for (int s = 0; s < SL; ++s) {
+        const int r = g + s * NGR;
         lo[s] = hi[s] = 0;
         if (r < nr) {
             lo[s] = (int64_t)rowptr[r0 + r] - base - p0;
@@ -66,16 +68,16 @@ __global__ __launch_bounds__(TPB_MM) void spmm_rowblock_kernel(
         }
     }
 
-    for (int kt = 0; kt < k; kt += KT) {
+    for (int kt = 0; kt < k; kt += GRP) {
         const int c = kt + l;
         const bool col_ok = c < k;
         const int64_t c_off = (int64_t)c * b_cs;
-        double acc[SLOTS];
+        double acc[SL];
 #pragma unroll
-        for (int s = 0; s < SLOTS; ++s) {
+        for (int s = 0; s < SL; ++s) {
             acc[s] = 0.0;
             // panel order (hpcla_spmm_panel_*): the sums continue from what earlier panels left in C
-            const int r = g + s * NGROUPS;
+            const int r = g + s * NGR;
             if (accumulate && r < nr && col_ok) acc[s] = C[(r0 + r) * c_rs + (int64_t)c * c_cs];
         }
 
@@ -92,10 +94,10 @@ __global__ __launch_bounds__(TPB_MM) void spmm_rowblock_kernel(
             }
             __syncthreads();
             if (!col_ok) continue;
-            int a[SLOTS], len[SLOTS];
+            int a[SL], len[SL];
             int maxlen = 0;
 #pragma unroll
-            for (int s = 0; s < SLOTS; ++s) {
+            for (int s = 0; s < SL; ++s) {
                 const int64_t a64 = lo[s] > ch ? lo[s] : ch;
                 const int64_t e64 = hi[s] < ch + n ? hi[s] : ch + n;
                 a[s] = (int)(a64 - ch);
@@ -103,13 +105,13 @@ __global__ __launch_bounds__(TPB_MM) void spmm_rowblock_kernel(
                 maxlen = len[s] > maxlen ? len[s] : maxlen;
             }
             for (int i = 0; i < maxlen; i += 2) {
-                double v[SLOTS][2], bv[SLOTS][2];
-                int64_t off[SLOTS][2];
-                bool ok[SLOTS][2];
+                double v[SL][2], bv[SL][2];
+                int64_t off[SL][2];
+                bool ok[SL][2];
                 // LDS reads first (all unconditional, index clamped to a valid entry), then the B
                 // loads back to back, then the sums in stored order
 #pragma unroll
-                for (int s = 0; s < SLOTS; ++s) {
+                for (int s = 0; s < SL; ++s) {
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
                         ok[s][u] = i + u < len[s];
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(TPB_MM) void spmm_rowblock_kernel(
                     }
                 }
 #pragma unroll
-                for (int s = 0; s < SLOTS; ++s) {
+                for (int s = 0; s < SL; ++s) {
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
                         bv[s][u] = 0.0;
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(TPB_MM) void spmm_rowblock_kernel(
                     }
                 }
 #pragma unroll
-                for (int s = 0; s < SLOTS; ++s) {
+                for (int s = 0; s < SL; ++s) {
 #pragma unroll
                     for (int u = 0; u < 2; ++u)
                         if (ok[s][u]) acc[s] += v[s][u] * bv[s][u];
@@ -141,8 +143,8 @@ __global__ __launch_bounds__(TPB_MM) void spmm_rowblock_kernel(
         }
         // (col_ok is uniform per lane for the whole kt pass: no barrier is skipped by a subset)
 #pragma unroll
-        for (int s = 0; s < SLOTS; ++s) {
-            const int r = g + s * NGROUPS;
+        for (int s = 0; s < SL; ++s) {
+            const int r = g + s * NGR;
             if (r < nr && col_ok) C[(r0 + r) * c_rs + (int64_t)c * c_cs] = acc[s];
         }
     }
@@ -199,23 +201,31 @@ struct __attribute__((aligned(16))) SpmmEntry {
 
 typedef const vdouble2 __attribute__((address_space(1))) *gvec2_ptr;   // global address space: global_load, not flat_load
 
-template <typename I, bool SPLIT, int VU, int CHUNK_V, bool HALF64, bool CSTAGE>
-__global__ __launch_bounds__(TPB_MM) void spmm_rowblock_vec_kernel(
+// LPR = lanes per row (4, or 2 for k <= 8: a narrow B on four lanes per row leaves half or three quarters of every
+// wave idle through the gather loop -- k = 4 ran at 0.38, k = 8 at 0.50 of peak, profiles/r03_spmm_rate_vs_k_before.log);
+// the workgroup is 64 * LPR threads and still owns 64 rows, a column tile is 4 * LPR columns.
+// CSTAGE: the block's results leave through LDS as whole lines whenever its C rows form ONE contiguous region
+// (c_rs == k <= tile width); K16 additionally folds the strides of the device-native shape to constants.
+template <typename I, bool SPLIT, int CHUNK_V, bool HALF64, bool CSTAGE, bool K16, int LPR>
+__global__ __launch_bounds__(64 * LPR) void spmm_rowblock_vec_kernel(
     const I *__restrict__ rowptr, const I *__restrict__ colval, const double *__restrict__ nzval,
     const double *__restrict__ B_own, int64_t b_rs, const double *__restrict__ B_ghost, int64_t bg_rs,
     int64_t n_own, double *__restrict__ C, int64_t c_rs, int64_t nrows, int k, int base,
     const int32_t *__restrict__ block_list, uint32_t nblocks, int accumulate)
 {
+    constexpr int TPB = 64 * LPR, KTILE = VCPL * LPR, VU = 2;
+    static_assert(!HALF64 || LPR == 4, "the 64-contiguous-bytes lane mapping needs four lanes per row");
+    static_assert(!K16 || (CSTAGE && HALF64), "K16 is the device-native shape");
     __shared__ SpmmEntry s_ent[CHUNK_V];
 
-    if (CSTAGE) {
+    if (K16) {
         // the device-native shape (k = 16, B / ghost / C rows of exactly 16 doubles: checked by the launcher): strides
         // and the column-tile loop fold to constants (measured against a k = 16-only copy of this kernel in the tuning
         // harness, benchmarks/tune/spmm_variants.hip MODE 0: the generic form ran 3 % behind it)
         k = KT; b_rs = KT; bg_rs = KT; c_rs = KT;
     }
     const int tid = threadIdx.x;
-    const int g = tid / VG, l = tid % VG;   // g = row of the block (0..63)
+    const int g = tid / LPR, l = tid % LPR;   // g = row of the block (0..63)
     const uint32_t b = blockIdx.x;
     const int64_t blk = block_list ? (int64_t)block_list[b] : (int64_t)b;
     const int64_t r0 = blk * RPB_MM;
@@ -229,7 +239,7 @@ __global__ __launch_bounds__(TPB_MM) void spmm_rowblock_vec_kernel(
         hi = (int64_t)rowptr[r0 + g + 1] - base - p0;
     }
 
-    for (int kt = 0; kt < k; kt += KT) {
+    for (int kt = 0; kt < k; kt += KTILE) {
         // lane -> columns.  Default: four adjacent columns (32 contiguous bytes of the B row, two 16-byte loads).
         // HALF64 (full 16-column tiles only): columns {2l, 2l+1} and {8+2l, 8+2l+1}, i.e. the four lanes of a row
         // read 64 CONTIGUOUS bytes per load instruction (one half line each) instead of every other 16 bytes
@@ -252,7 +262,7 @@ __global__ __launch_bounds__(TPB_MM) void spmm_rowblock_vec_kernel(
         for (int64_t ch = 0; ch < total; ch += CHUNK_V) {
             const int n = (int)((total - ch) < CHUNK_V ? (total - ch) : CHUNK_V);
             __syncthreads();   // previous pass finished reading LDS
-            for (int i = tid; i < n; i += TPB_MM) {
+            for (int i = tid; i < n; i += TPB) {
                 const int64_t col = (int64_t)__builtin_nontemporal_load(colval + p0 + ch + i) - base;
                 SpmmEntry e;
                 e.val = __builtin_nontemporal_load(nzval + p0 + ch + i);
@@ -295,26 +305,26 @@ __global__ __launch_bounds__(TPB_MM) void spmm_rowblock_vec_kernel(
             }
         }
         if (CSTAGE) {
-            // C through LDS (k == 16, C rows contiguous): the block's 64 x 16 results form ONE contiguous 8 KiB
-            // region of C; written from the accumulators, a store instruction covers 16 half lines, written from
-            // LDS in linear order it covers 8 whole lines
+            // C through LDS (k <= one column tile, C rows contiguous: c_rs == k): the block's 64 x k results form ONE
+            // contiguous region of C (8 KiB at k = 16); written from the accumulators, a store instruction covers 16
+            // half lines, written from LDS in linear order it covers 8 whole lines
             __syncthreads();                               // every lane has finished reading the records
             double *s_c = reinterpret_cast<double *>(s_ent);
             static_assert(sizeof(SpmmEntry) * CHUNK_V >= sizeof(double) * RPB_MM * KT, "C tile fits the record area");
-            vdouble2 o0, o1;
-            o0.x = acc[0]; o0.y = acc[1]; o1.x = acc[2]; o1.y = acc[3];
-            *reinterpret_cast<vdouble2 *>(s_c + g * KT + c) = o0;
-            *reinterpret_cast<vdouble2 *>(s_c + g * KT + c + SECOND / 8) = o1;
+            if (col_ok) {
+                vdouble2 o0, o1;
+                o0.x = acc[0]; o0.y = acc[1]; o1.x = acc[2]; o1.y = acc[3];
+                *reinterpret_cast<vdouble2 *>(s_c + g * k + c) = o0;
+                *reinterpret_cast<vdouble2 *>(s_c + g * k + c + SECOND / 8) = o1;
+            }
             __syncthreads();
             vdouble2 *dst = reinterpret_cast<vdouble2 *>(C + r0 * c_rs);
             const vdouble2 *src = reinterpret_cast<const vdouble2 *>(s_c);
-#pragma unroll
-            for (int u = 0; u < (RPB_MM * KT / 2) / TPB_MM; ++u) {
-                const int i = tid + u * TPB_MM;
+            const int count = nr * (k / 2);
+            for (int i = tid; i < count; i += TPB)
                 // non-temporal: C is never re-read by this kernel; measured -1.4 % (stencil) / -1.2 % (config 5's
                 // pattern) against plain stores, benchmarks/tune_spmm.py MODE 21 (profiles/r03_spmm_ablations_and_candidates.txt)
-                if (i < nr * (KT / 2)) __builtin_nontemporal_store(src[i], dst + i);
-            }
+                __builtin_nontemporal_store(src[i], dst + i);
         } else
         if (g < nr && col_ok) {
             double *dst = C + (r0 + g) * c_rs + c;
@@ -359,6 +369,23 @@ static inline void layout_strides(int layout, int64_t ld, int64_t *rs, int64_t *
     else { *rs = 1; *cs = ld; }
 }
 
+// spmv.hip
+int spmv_split_i32(const int32_t *, const int32_t *, const double *, const double *, const double *, int64_t, double *,
+                   int64_t, int64_t, int, const int32_t *, int64_t, void *, double *, int64_t);
+int spmv_split_i64(const int64_t *, const int64_t *, const double *, const double *, const double *, int64_t, double *,
+                   int64_t, int64_t, int, const int32_t *, int64_t, void *, double *, int64_t);
+constexpr int64_t nrows_b_unused = 0;     // n_own of an unsplit product: no column is a ghost (x_ghost == NULL)
+static inline int spmv_split_any(const int32_t *rp, const int32_t *cv, const double *nz, const double *x, const double *xg,
+                                 int64_t n_own, double *y, int64_t nrows, int64_t nnz, int base, void *stream)
+{
+    return spmv_split_i32(rp, cv, nz, x, xg, n_own, y, nrows, nnz, base, nullptr, 0, stream, nullptr, -1);
+}
+static inline int spmv_split_any(const int64_t *rp, const int64_t *cv, const double *nz, const double *x, const double *xg,
+                                 int64_t n_own, double *y, int64_t nrows, int64_t nnz, int base, void *stream)
+{
+    return spmv_split_i64(rp, cv, nz, x, xg, n_own, y, nrows, nnz, base, nullptr, 0, stream, nullptr, -1);
+}
+
 template <typename I>
 static int spmm_launch(const I *rowptr, const I *colval, const double *nzval, const double *B_own,
                        int64_t b_rs, int64_t b_cs, const double *B_ghost, int64_t bg_rs,
@@ -382,6 +409,13 @@ static int spmm_launch(const I *rowptr, const I *colval, const double *nzval, co
     }
     if (launch_blocks == 0) return HPCLA_OK;
     if (launch_blocks > 0x7fffffffLL) return set_error(HPCLA_ERR_INVALID, "spmm: too many blocks");
+    if (k == 1 && !block_list && !accumulate && b_rs == 1 && c_rs == 1 && (!split || !B_ghost || bg_rs == 1)) {
+        // one dense column with unit stride IS a vector: the SpMV kernel computes the same row sums in the same
+        // order (the reference's A * B is a column loop over A * x, src/sparse.jl:2391-2413) -- 0.88 ms through the
+        // 16-lanes-per-row SpMM form against the SpMV's rate on the 5-point matrix (profiles/r03_spmm_rate_vs_k_*.log)
+        return spmv_split_any(rowptr, colval, nzval, B_own, split ? B_ghost : nullptr, split ? n_own : nrows_b_unused, C,
+                              nrows, nnz, index_base, stream);
+    }
     hipStream_t s = as_stream(stream);
     dim3 grid((uint32_t)launch_blocks), block(TPB_MM);
     // device-native layout: row-major B / C, k % 4 == 0, everything 16-byte aligned, 32-bit column space
@@ -390,53 +424,60 @@ static int spmm_launch(const I *rowptr, const I *colval, const double *nzval, co
                         ((reinterpret_cast<uintptr_t>(B_own) | reinterpret_cast<uintptr_t>(C) |
                           (split ? reinterpret_cast<uintptr_t>(B_ghost) : 0)) & 15) == 0;
     if (vec_ok) {
-        // tuning knobs: entries per inner step (HPCLA_SPMM_VU = 2 | 4) and records per LDS pass
-        // (HPCLA_SPMM_CHUNK = 512 | 1536; default by density: short rows fit the small pass)
-        static const int vu = [] {
-            const char *e = getenv("HPCLA_SPMM_VU");
-            return (e && atoi(e) == 4) ? 4 : 2;
-        }();
+        // records per LDS pass (HPCLA_SPMM_CHUNK = 512 | 1536; default by density: short rows fit the small pass)
         static const int chunk_env = [] {
             const char *e = getenv("HPCLA_SPMM_CHUNK");
             return e ? atoi(e) : 0;
         }();
         const bool small = chunk_env ? chunk_env == 512 : nnz <= 8 * nrows;
-#define HPCLA_SPMM_VEC(SP, VUU, CH, H64, CST)                                                           \
-    spmm_rowblock_vec_kernel<I, SP, VUU, CH, H64, CST><<<grid, block, 0, s>>>(                           \
-        rowptr, colval, nzval, B_own, b_rs, SP ? B_ghost : nullptr, SP ? bg_rs : 0, SP ? n_own : 0, C, c_rs, \
-        nrows, k, index_base, block_list, (uint32_t)launch_blocks, accumulate)
         // lane->column mapping: 64 contiguous bytes per row per load when k % 16 == 0 (HPCLA_SPMM_HALF64=0: off)
         static const int h64_env = [] {
             const char *e = getenv("HPCLA_SPMM_HALF64");
             return e ? atoi(e) : 1;
         }();
-        const bool h64 = h64_env != 0 && (k % 16) == 0;
         // C through LDS when the block's C rows are one contiguous region (HPCLA_SPMM_CSTAGE=0: off)
         static const int cst_env = [] {
             const char *e = getenv("HPCLA_SPMM_CSTAGE");
             return e ? atoi(e) : 1;
         }();
-        const bool cstage = cst_env != 0 && k == KT && c_rs == KT && b_rs == KT && (!split || bg_rs == KT);
-#define HPCLA_SPMM_VEC2(SP)                                                                             \
+        // two lanes per row for a narrow B (HPCLA_SPMM_LPR=4: always four)
+        static const int lpr_env = [] {
+            const char *e = getenv("HPCLA_SPMM_LPR");
+            return e ? atoi(e) : 0;
+        }();
+        const int lpr = (k <= 8 && lpr_env != 4) ? 2 : 4;
+        const bool h64 = lpr == 4 && h64_env != 0 && (k % 16) == 0;
+        const bool cstage = cst_env != 0 && k <= 4 * lpr && c_rs == k;
+        const bool k16 = h64 && cstage && k == KT && b_rs == KT && (!split || bg_rs == KT);
+#define HPCLA_SPMM_VEC(SP, CH, H64, CST, K16F, LPRV)                                                     \
+    spmm_rowblock_vec_kernel<I, SP, CH, H64, CST, K16F, LPRV><<<grid, dim3(64 * LPRV), 0, s>>>(           \
+        rowptr, colval, nzval, B_own, b_rs, SP ? B_ghost : nullptr, SP ? bg_rs : 0, SP ? n_own : 0, C, c_rs, \
+        nrows, k, index_base, block_list, (uint32_t)launch_blocks, accumulate)
+#define HPCLA_SPMM_VEC1(SP, CH)                                                                          \
     do {                                                                                                \
-        if (h64 && cstage) {                                                                            \
-            if (small) HPCLA_SPMM_VEC(SP, 2, 512, true, true); else HPCLA_SPMM_VEC(SP, 2, 1536, true, true); \
-        } else if (h64) {                                                                               \
-            if (small) HPCLA_SPMM_VEC(SP, 2, 512, true, false); else HPCLA_SPMM_VEC(SP, 2, 1536, true, false); \
-        } else if (small) { if (vu == 4) HPCLA_SPMM_VEC(SP, 4, 512, false, false); else HPCLA_SPMM_VEC(SP, 2, 512, false, false); } \
-        else { if (vu == 4) HPCLA_SPMM_VEC(SP, 4, 1536, false, false); else HPCLA_SPMM_VEC(SP, 2, 1536, false, false); } \
+        if (lpr == 2) { if (cstage) HPCLA_SPMM_VEC(SP, CH, false, true, false, 2); else HPCLA_SPMM_VEC(SP, CH, false, false, false, 2); } \
+        else if (k16) HPCLA_SPMM_VEC(SP, CH, true, true, true, 4);                                      \
+        else if (h64 && cstage) HPCLA_SPMM_VEC(SP, CH, true, true, false, 4);                           \
+        else if (h64) HPCLA_SPMM_VEC(SP, CH, true, false, false, 4);                                    \
+        else if (cstage) HPCLA_SPMM_VEC(SP, CH, false, true, false, 4);                                 \
+        else HPCLA_SPMM_VEC(SP, CH, false, false, false, 4);                                            \
     } while (0)
+#define HPCLA_SPMM_VEC2(SP)                                                                             \
+    do { if (small) HPCLA_SPMM_VEC1(SP, 512); else HPCLA_SPMM_VEC1(SP, 1536); } while (0)
         if (split) HPCLA_SPMM_VEC2(true); else HPCLA_SPMM_VEC2(false);
 #undef HPCLA_SPMM_VEC2
+#undef HPCLA_SPMM_VEC1
 #undef HPCLA_SPMM_VEC
-    } else if (split)
-        spmm_rowblock_kernel<I, true><<<grid, block, 0, s>>>(
-            rowptr, colval, nzval, B_own, b_rs, b_cs, B_ghost, bg_rs, n_own, C, c_rs, c_cs, nrows,
-            k, index_base, block_list, (uint32_t)launch_blocks, accumulate);
-    else
-        spmm_rowblock_kernel<I, false><<<grid, block, 0, s>>>(
-            rowptr, colval, nzval, B_own, b_rs, b_cs, nullptr, 0, 0, C, c_rs, c_cs, nrows, k,
-            index_base, block_list, (uint32_t)launch_blocks, accumulate);
+    } else {
+        // generic strides / any k: lanes per row = the smallest of 4, 8, 16 that holds k (wider B: 16-column tiles)
+#define HPCLA_SPMM_GEN(SP, GRP)                                                                                  \
+    spmm_rowblock_kernel<I, SP, GRP><<<grid, block, 0, s>>>(                                                    \
+        rowptr, colval, nzval, B_own, b_rs, b_cs, SP ? B_ghost : nullptr, SP ? bg_rs : 0, SP ? n_own : 0, C, c_rs, \
+        c_cs, nrows, k, index_base, block_list, (uint32_t)launch_blocks, accumulate)
+        if (split) { if (k <= 4) HPCLA_SPMM_GEN(true, 4); else if (k <= 8) HPCLA_SPMM_GEN(true, 8); else HPCLA_SPMM_GEN(true, 16); }
+        else { if (k <= 4) HPCLA_SPMM_GEN(false, 4); else if (k <= 8) HPCLA_SPMM_GEN(false, 8); else HPCLA_SPMM_GEN(false, 16); }
+#undef HPCLA_SPMM_GEN
+    }
     HPCLA_CHECK_LAUNCH();
     return HPCLA_OK;
 }
