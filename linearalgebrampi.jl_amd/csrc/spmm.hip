@@ -239,6 +239,19 @@ __global__ __launch_bounds__(64 * LPR) void spmm_rowblock_vec_kernel(
         hi = (int64_t)rowptr[r0 + g + 1] - base - p0;
     }
 
+    // A block whose entries fit ONE pass is staged once for ALL column tiles (k > one tile: the records are read-only
+    // across tiles); longer blocks re-stage per tile and pass (the running sums of a tile live in registers).
+    const bool single = total <= CHUNK_V;
+    if (single) {
+        for (int i = tid; i < (int)total; i += TPB) {
+            const int64_t col = (int64_t)__builtin_nontemporal_load(colval + p0 + i) - base;
+            SpmmEntry e;
+            e.val = __builtin_nontemporal_load(nzval + p0 + i);
+            e.row = (SPLIT && col >= n_own) ? B_ghost + (col - n_own) * bg_rs : B_own + col * b_rs;
+            s_ent[i] = e;
+        }
+        __syncthreads();
+    }
     for (int kt = 0; kt < k; kt += KTILE) {
         // lane -> columns.  Default: four adjacent columns (32 contiguous bytes of the B row, two 16-byte loads).
         // HALF64 (full 16-column tiles only): columns {2l, 2l+1} and {8+2l, 8+2l+1}, i.e. the four lanes of a row
@@ -261,15 +274,17 @@ __global__ __launch_bounds__(64 * LPR) void spmm_rowblock_vec_kernel(
 
         for (int64_t ch = 0; ch < total; ch += CHUNK_V) {
             const int n = (int)((total - ch) < CHUNK_V ? (total - ch) : CHUNK_V);
-            __syncthreads();   // previous pass finished reading LDS
-            for (int i = tid; i < n; i += TPB) {
-                const int64_t col = (int64_t)__builtin_nontemporal_load(colval + p0 + ch + i) - base;
-                SpmmEntry e;
-                e.val = __builtin_nontemporal_load(nzval + p0 + ch + i);
-                e.row = (SPLIT && col >= n_own) ? B_ghost + (col - n_own) * bg_rs : B_own + col * b_rs;
-                s_ent[i] = e;
+            if (!single) {
+                __syncthreads();   // previous pass finished reading LDS
+                for (int i = tid; i < n; i += TPB) {
+                    const int64_t col = (int64_t)__builtin_nontemporal_load(colval + p0 + ch + i) - base;
+                    SpmmEntry e;
+                    e.val = __builtin_nontemporal_load(nzval + p0 + ch + i);
+                    e.row = (SPLIT && col >= n_own) ? B_ghost + (col - n_own) * bg_rs : B_own + col * b_rs;
+                    s_ent[i] = e;
+                }
+                __syncthreads();
             }
-            __syncthreads();
             if (!col_ok) continue;
             int j = (int)((lo > ch ? lo : ch) - ch);
             const int e = (int)((hi < ch + n ? hi : ch + n) - ch);
