@@ -19,7 +19,7 @@ def main():
     s = torch.cuda.current_stream().cuda_stream
     print(f"# 5-point matrix {nx}x{ny}: rows={n} nnz={A.nnz}")
     print(f"{'k':>4} {'ms':>9} {'GFLOP/s':>10} {'GB/s alg':>10} {'frac':>7}")
-    for k in [int(a) for a in (sys.argv[1:] or "1 2 3 4 6 8 12 16 24 32".split())]:
+    for k in [int(a) for a in (sys.argv[1:] or "1 2 3 4 6 8 10 12 14 16 24 32".split())]:
         Bl = torch.empty((n, k), dtype=torch.float64, device="cuda")
         hp._capi.call("hpcla_fill_uniform_f64", Bl.data_ptr(), 0, n * k, wl.SEED_X, s)
         B = hp.HPCMatrix_local(Bl, backend)

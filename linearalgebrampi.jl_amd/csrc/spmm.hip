@@ -206,7 +206,9 @@ typedef const vdouble2 __attribute__((address_space(1))) *gvec2_ptr;   // global
 // the workgroup is 64 * LPR threads and still owns 64 rows, a column tile is 4 * LPR columns.
 // CSTAGE: the block's results leave through LDS as whole lines whenever its C rows form ONE contiguous region
 // (c_rs == k <= tile width); K16 additionally folds the strides of the device-native shape to constants.
-template <typename I, bool SPLIT, int CHUNK_V, bool HALF64, bool CSTAGE, bool K16, int LPR>
+// TAIL2: k is even but not a multiple of 4 (k = 2, 6, 10, 14 ...): the lane that holds the last column pair loads, adds
+// and stores only its first 16 bytes -- the reference's own SpMM test has k = 6 (test/test_new_operations.jl:43-59).
+template <typename I, bool SPLIT, int CHUNK_V, bool HALF64, bool CSTAGE, bool K16, int LPR, bool TAIL2>
 __global__ __launch_bounds__(64 * LPR) void spmm_rowblock_vec_kernel(
     const I *__restrict__ rowptr, const I *__restrict__ colval, const double *__restrict__ nzval,
     const double *__restrict__ B_own, int64_t b_rs, const double *__restrict__ B_ghost, int64_t bg_rs,
@@ -216,6 +218,7 @@ __global__ __launch_bounds__(64 * LPR) void spmm_rowblock_vec_kernel(
     constexpr int TPB = 64 * LPR, KTILE = VCPL * LPR, VU = 2;
     static_assert(!HALF64 || LPR == 4, "the 64-contiguous-bytes lane mapping needs four lanes per row");
     static_assert(!K16 || (CSTAGE && HALF64), "K16 is the device-native shape");
+    static_assert(!TAIL2 || !HALF64, "the 64-contiguous-bytes mapping needs whole 16-column tiles");
     __shared__ SpmmEntry s_ent[CHUNK_V];
 
     if (K16) {
@@ -259,6 +262,7 @@ __global__ __launch_bounds__(64 * LPR) void spmm_rowblock_vec_kernel(
         // of the whole line.
         const int c = HALF64 ? kt + 2 * l : kt + VCPL * l;
         const bool col_ok = c < k;
+        const bool two = !TAIL2 || c + 2 < k;                              // this lane owns a second column pair
         constexpr int SECOND = HALF64 ? 64 : 16;                           // byte offset of the lane's second load
         const int64_t lane_bytes = (int64_t)c * (int64_t)sizeof(double);   // this lane's slice of every B row
         double acc[VCPL];
@@ -268,7 +272,8 @@ __global__ __launch_bounds__(64 * LPR) void spmm_rowblock_vec_kernel(
             // panel order (hpcla_spmm_panel_*): this lane's four sums continue from what earlier panels left in C
             const double *cur = C + (r0 + g) * c_rs + c;
             const vdouble2 c0 = *reinterpret_cast<const vdouble2 *>(cur);
-            const vdouble2 c1 = *reinterpret_cast<const vdouble2 *>(cur + SECOND / 8);
+            vdouble2 c1 = (vdouble2)(0.0);
+            if (two) c1 = *reinterpret_cast<const vdouble2 *>(cur + SECOND / 8);
             acc[0] = c0.x; acc[1] = c0.y; acc[2] = c1.x; acc[3] = c1.y;
         }
 
@@ -298,7 +303,8 @@ __global__ __launch_bounds__(64 * LPR) void spmm_rowblock_vec_kernel(
                 for (int u = 0; u < VU; ++u) {
                     const char *src = reinterpret_cast<const char *>(en[u].row) + lane_bytes;
                     b0[u] = *(gvec2_ptr)(src);
-                    b1[u] = *(gvec2_ptr)(src + SECOND);
+                    b1[u] = (vdouble2)(0.0);
+                    if (two) b1[u] = *(gvec2_ptr)(src + SECOND);       // (never reads past the end of the last B row)
                 }
 #pragma unroll
                 for (int u = 0; u < VU; ++u) {
@@ -312,7 +318,8 @@ __global__ __launch_bounds__(64 * LPR) void spmm_rowblock_vec_kernel(
                 const SpmmEntry en = s_ent[j];
                 const char *src = reinterpret_cast<const char *>(en.row) + lane_bytes;
                 const vdouble2 b0 = *(gvec2_ptr)(src);
-                const vdouble2 b1 = *(gvec2_ptr)(src + SECOND);
+                vdouble2 b1 = (vdouble2)(0.0);
+                if (two) b1 = *(gvec2_ptr)(src + SECOND);
                 acc[0] += en.val * b0.x;
                 acc[1] += en.val * b0.y;
                 acc[2] += en.val * b1.x;
@@ -330,7 +337,7 @@ __global__ __launch_bounds__(64 * LPR) void spmm_rowblock_vec_kernel(
                 vdouble2 o0, o1;
                 o0.x = acc[0]; o0.y = acc[1]; o1.x = acc[2]; o1.y = acc[3];
                 *reinterpret_cast<vdouble2 *>(s_c + g * k + c) = o0;
-                *reinterpret_cast<vdouble2 *>(s_c + g * k + c + SECOND / 8) = o1;
+                if (two) *reinterpret_cast<vdouble2 *>(s_c + g * k + c + SECOND / 8) = o1;
             }
             __syncthreads();
             vdouble2 *dst = reinterpret_cast<vdouble2 *>(C + r0 * c_rs);
@@ -346,7 +353,7 @@ __global__ __launch_bounds__(64 * LPR) void spmm_rowblock_vec_kernel(
             vdouble2 o0, o1;
             o0.x = acc[0]; o0.y = acc[1]; o1.x = acc[2]; o1.y = acc[3];
             *reinterpret_cast<vdouble2 *>(dst) = o0;
-            *reinterpret_cast<vdouble2 *>(dst + SECOND / 8) = o1;
+            if (two) *reinterpret_cast<vdouble2 *>(dst + SECOND / 8) = o1;
         }
     }
 }
@@ -433,8 +440,8 @@ static int spmm_launch(const I *rowptr, const I *colval, const double *nzval, co
     }
     hipStream_t s = as_stream(stream);
     dim3 grid((uint32_t)launch_blocks), block(TPB_MM);
-    // device-native layout: row-major B / C, k % 4 == 0, everything 16-byte aligned, 32-bit column space
-    const bool vec_ok = b_cs == 1 && c_cs == 1 && (k % 4) == 0 && (b_rs % 2) == 0 && (c_rs % 2) == 0 &&
+    // device-native layout: row-major B / C, k even (16-byte column pairs), everything 16-byte aligned
+    const bool vec_ok = b_cs == 1 && c_cs == 1 && (k % 2) == 0 && (b_rs % 2) == 0 && (c_rs % 2) == 0 &&
                         (!split || (bg_rs % 2) == 0) &&
                         ((reinterpret_cast<uintptr_t>(B_own) | reinterpret_cast<uintptr_t>(C) |
                           (split ? reinterpret_cast<uintptr_t>(B_ghost) : 0)) & 15) == 0;
@@ -464,8 +471,14 @@ static int spmm_launch(const I *rowptr, const I *colval, const double *nzval, co
         const bool h64 = lpr == 4 && h64_env != 0 && (k % 16) == 0;
         const bool cstage = cst_env != 0 && k <= 4 * lpr && c_rs == k;
         const bool k16 = h64 && cstage && k == KT && b_rs == KT && (!split || bg_rs == KT);
+        const bool tail2 = (k % 4) != 0;                 // even k: the last column pair of a row is half a lane's share
 #define HPCLA_SPMM_VEC(SP, CH, H64, CST, K16F, LPRV)                                                     \
-    spmm_rowblock_vec_kernel<I, SP, CH, H64, CST, K16F, LPRV><<<grid, dim3(64 * LPRV), 0, s>>>(           \
+    do {                                                                                                \
+        if (!H64 && tail2) HPCLA_SPMM_VECT(SP, CH, H64, CST, K16F, LPRV, (!H64));                       \
+        else HPCLA_SPMM_VECT(SP, CH, H64, CST, K16F, LPRV, false);                                      \
+    } while (0)
+#define HPCLA_SPMM_VECT(SP, CH, H64, CST, K16F, LPRV, T2)                                                \
+    spmm_rowblock_vec_kernel<I, SP, CH, H64, CST, K16F, LPRV, (T2)><<<grid, dim3(64 * LPRV), 0, s>>>(     \
         rowptr, colval, nzval, B_own, b_rs, SP ? B_ghost : nullptr, SP ? bg_rs : 0, SP ? n_own : 0, C, c_rs, \
         nrows, k, index_base, block_list, (uint32_t)launch_blocks, accumulate)
 #define HPCLA_SPMM_VEC1(SP, CH)                                                                          \
@@ -483,6 +496,7 @@ static int spmm_launch(const I *rowptr, const I *colval, const double *nzval, co
 #undef HPCLA_SPMM_VEC2
 #undef HPCLA_SPMM_VEC1
 #undef HPCLA_SPMM_VEC
+#undef HPCLA_SPMM_VECT
     } else {
         // generic strides / any k: lanes per row = the smallest of 4, 8, 16 that holds k (wider B: 16-column tiles)
 #define HPCLA_SPMM_GEN(SP, GRP)                                                                                  \

@@ -48,10 +48,15 @@ def test_expired_exchange_wait_poisons_the_result_and_raises():
     assert _spawn(2, {"HPCLA_PUSH_TIMEOUT_S": "2", "HPCLA_MR_TIMEOUT_CASE": "1"}, timeout=300) == 0
 
 
-def test_spmm_panel_order_within_tolerance():
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_spmm_panel_order_within_tolerance(nranks):
     """HPCLA_SPMM_ORDER=panel (exchange overlapped chunk by chunk, config 5 at N > 1): same sums in a different
-    ORDER -- 1e-12 relative and the componentwise |A||B| bound against the oracle, 2 ranks, both index types."""
-    assert _spawn(2, {"HPCLA_PUSH_TIMEOUT_S": "30", "HPCLA_SPMM_ORDER_TEST": "1", "HPCLA_MR_TYPES": "i32,i64"}) == 0
+    ORDER -- 1e-12 relative and the componentwise |A||B| bound against the oracle; 2 ranks with both index types, 3 ranks
+    (every rank has two neighbours per chunk-set plan, three chunk-sets) with Int64."""
+    env = {"HPCLA_PUSH_TIMEOUT_S": "30", "HPCLA_SPMM_ORDER_TEST": "1", "HPCLA_MR_TYPES": "i32,i64" if nranks == 2 else "i64"}
+    if nranks == 3:
+        env["HPCLA_SPMM_PANELS"] = "3"
+    assert _spawn(nranks, env) == 0
 
 
 @pytest.mark.parametrize("mode", ["serial", "overlap"])

@@ -472,7 +472,7 @@ def test_to_backend_round_trip(hp, orc, gpu_backend_i32):
     hp.clear_plan_cache()
 
 
-@pytest.mark.parametrize("k", [1, 2, 3, 4, 6, 8, 12, 16, 17, 24, 40])
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 6, 8, 10, 12, 14, 16, 17, 18, 24, 40])
 @pytest.mark.parametrize("layout", ["row", "col"])
 def test_spmm_bit_exact_raw_abi(hp, orc, gpu_backend_i32, k, layout):
     import torch
@@ -497,7 +497,7 @@ def test_spmm_bit_exact_raw_abi(hp, orc, gpu_backend_i32, k, layout):
     np.testing.assert_array_equal(C, want)
 
 
-@pytest.mark.parametrize("k", [16, 12, 3, 1])
+@pytest.mark.parametrize("k", [16, 12, 6, 3, 1])
 @pytest.mark.parametrize("Ti", [np.int32, np.int64])
 def test_spmm_panel_accumulate_is_one_running_sum(hp, orc, gpu_backend_i32, k, Ti):
     """hpcla_spmm_panel_* with accumulate = 1 CONTINUES every C(r, c) from its current value, entry by entry.  A product
@@ -623,7 +623,7 @@ def test_spmv_unaligned_pointers_take_fallback_kernel(hp, orc, gpu_backend_i32, 
 
 
 @pytest.mark.parametrize("Ti", [np.int32, np.int64])
-@pytest.mark.parametrize("nranks,k", [(2, 16), (3, 5), (2, 8), (3, 4), (2, 12), (2, 1)])
+@pytest.mark.parametrize("nranks,k", [(2, 16), (3, 5), (2, 8), (3, 4), (2, 12), (2, 1), (2, 6), (3, 2), (2, 10)])
 def test_split_spmm_per_rank_matches_reference_pipeline(hp, orc, gpu_backend_i32, nranks, k, Ti):
     """hpcla_spmm_split_f64_{i32,i64} (Int64 is the reference's default Ti, src/backends.jl:348) (own rows of B + ghost rows, interior/boundary block lists at SpMM
     granularity) == the reference's column loop over gathered B, for every simulated rank."""
