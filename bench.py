@@ -773,9 +773,14 @@ def _run(args, budget):
                 ("poisson2d_spmm", "poisson2d_spmm", 20, 0)]
         if world == 1:
             todo.append(("sprand_spmm_mall_sized", "sprand_spmm", 10, 1))
+        else:
+            # config 5 once more in the opt-in PANEL order (exchange overlapped chunk by chunk), so that
+            # one N > 1 run carries both orders of the same step and their xGMI rooflines side by side
+            todo.append(("sprand_spmm_panel_order", "sprand_spmm", 10, max(1, 8 // world)))
         for name, workload, wsteps, mult in todo:
             a2 = copy.copy(args)
             a2.workload, a2.steps, a2.warmup, a2.size, a2.cols_mult = workload, wsteps, 5, 0, mult
+            a2.spmm_order = "panel" if name == "sprand_spmm_panel_order" else None
             if not job.agree(budget.allows(name)):
                 extras[name] = dict(SKIPPED)
                 continue

@@ -26,6 +26,7 @@ ESTIMATE_S = {
     "poisson2d_spmm": 20.0,
     "sprand_spmm": 35.0,
     "sprand_spmm_mall_sized": 25.0,
+    "sprand_spmm_panel_order": 45.0,  # N > 1 only: four more chunk-set plans to attach
     "packed": 15.0,
     "cpu_baseline": 30.0,
     "comparison": 45.0,               # minimum worth starting; its watchdog gets what is left, <= 90 s

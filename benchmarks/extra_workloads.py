@@ -300,6 +300,10 @@ def run_record(args, backend, rank, world, job):
                       torch.cuda.current_stream().cuda_stream)
         B = hp.HPCMatrix_local(Bl, backend)
         setup_s = time.perf_counter() - t0
+        order = getattr(args, "spmm_order", None)
+        saved_order = os.environ.get("HPCLA_SPMM_ORDER")
+        if order:
+            os.environ["HPCLA_SPMM_ORDER"] = order          # every rank runs this record: the choice is collective
         regime = ("B = %d rows x 16 = %.2f GB: config 5's gather set, far beyond the 256 MiB Infinity Cache" % (ncols, ncols * 128 / 1e9)
                   if ncols * 128 > (1 << 29) else
                   "B = %d rows x 16 = %.0f MB: Infinity-Cache-sized B (MALL-assisted gathers), NOT config 5's regime" % (ncols, ncols * 128 / 1e6))
@@ -308,6 +312,12 @@ def run_record(args, backend, rank, world, job):
                             f"sprand-like {rows_loc} rows per GPU x {ncols} cols, nnz/GPU={A.nnz}, k={k}, C = A*B; {regime}",
                             traffic_key=("sprand_spmm_b2e24" if (rows_loc, ncols) == (2_097_152, 16_777_216) else
                                          "sprand_spmm_mall_sized" if (rows_loc, ncols) == (2_097_152, 2_097_152) else None))
+        if order:
+            out["config"]["workload"] += f"; HPCLA_SPMM_ORDER={order}"
+            if saved_order is None:
+                os.environ.pop("HPCLA_SPMM_ORDER", None)
+            else:
+                os.environ["HPCLA_SPMM_ORDER"] = saved_order
     job.barrier()
     hp.clear_spmm_cache()
     hp.clear_plan_cache()
