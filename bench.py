@@ -777,6 +777,9 @@ def _run(args, budget):
             # config 5 once more in the opt-in PANEL order (exchange overlapped chunk by chunk), so that
             # one N > 1 run carries both orders of the same step and their xGMI rooflines side by side
             todo.append(("sprand_spmm_panel_order", "sprand_spmm", 10, max(1, 8 // world)))
+        only = [t for t in os.environ.get("HPCLA_BENCH_EXTRAS", "").split(",") if t]       # diagnostics: a subset, in this order
+        if only:
+            todo = [t for nm in only for t in todo if t[0] == nm]
         for name, workload, wsteps, mult in todo:
             a2 = copy.copy(args)
             a2.workload, a2.steps, a2.warmup, a2.size, a2.cols_mult = workload, wsteps, 5, 0, mult

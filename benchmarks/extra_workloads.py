@@ -9,6 +9,7 @@
 """
 import json
 import os
+import sys
 import time
 
 import numpy as np
@@ -32,6 +33,16 @@ def stored_traffic(key, applicable=True):
                               "the builder's rocprofv3 passes of this workload -- " + rec.get("source", path))
 
 
+_T0 = time.perf_counter()
+
+
+def _stamp(msg):
+    """HPCLA_BENCH_VERBOSE=1: per-rank progress lines on stderr (where does a record's wall time go)."""
+    if os.environ.get("HPCLA_BENCH_VERBOSE", "") == "1":
+        sys.stderr.write(f"[extra +{time.perf_counter() - _T0:7.2f}s rank {os.environ.get('RANK', '0')}] {msg}\n")
+        sys.stderr.flush()
+
+
 def _sync_barrier(job, closing=False):
     job.barrier(device_only=closing)      # closing bracket of a timed region: device rendezvous only (bench.py Job)
 
@@ -42,7 +53,11 @@ XGMI_LINKS = 7
 
 def _measure_spmm(args, job, hp, wl, A, B, k, world, dev, setup_s, metric, workload, traffic_key=None):
     import torch
+    _stamp("spmm: operands ready")
     C = A @ B
+    if os.environ.get("HPCLA_BENCH_VERBOSE", "") == "1":
+        torch.cuda.synchronize()
+        _stamp("spmm: first product (plan built)")
     for _ in range(max(args.warmup, 5)):
         C = A @ B
     steps = min(args.steps, 50)
@@ -256,6 +271,7 @@ def run_record(args, backend, rank, world, job):
         t0 = time.perf_counter()
         gen = torch.Generator(device=dev)
         gen.manual_seed(0xA11CE + rank)
+        _stamp("sprand: start")
         counts = torch.poisson(torch.full((rows_loc,), mean_nnz, dtype=torch.float64, device=dev), generator=gen).to(torch.int64)
         rowptr = torch.zeros(rows_loc + 1, dtype=torch.int64, device=dev)
         torch.cumsum(counts, 0, out=rowptr[1:])
@@ -266,6 +282,7 @@ def run_record(args, backend, rank, world, job):
         cols = key - rowid * ncols
         del key, rowid, counts
         vals = torch.rand(nnz, generator=gen, device=dev, dtype=torch.float64)
+        _stamp("sprand: entries generated")
         A = hp.HPCSparseMatrix_local_device(rowptr, cols, vals, ncols, backend, col_window=(0, ncols - 1))
         del cols
         if os.environ.get("HPCLA_SPRAND_SPMV", "") == "1":
@@ -318,8 +335,10 @@ def run_record(args, backend, rank, world, job):
                 os.environ.pop("HPCLA_SPMM_ORDER", None)
             else:
                 os.environ["HPCLA_SPMM_ORDER"] = saved_order
+    _stamp("record measured")
     job.barrier()
     hp.clear_spmm_cache()
     hp.clear_plan_cache()
     torch.cuda.empty_cache()
+    _stamp("plans destroyed, cache emptied")
     return out

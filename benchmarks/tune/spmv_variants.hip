@@ -87,7 +87,18 @@ __global__ __launch_bounds__(TPB) void k_narrow(const int *__restrict__ rowptr,
 }
 
 // ---- wide kernel: 16-byte loads (4 entries per lane per load), aligned to 4 entries ----------------
-template <int TPB, int RPT, int U, bool NT, bool XCD>
+// XCD: 0 natural order, 1 one contiguous slice per XCD, G >= 2: groups of G consecutive row blocks per XCD, groups
+// dealt round-robin (the hardware deals workgroups to XCDs round-robin by blockIdx: blocks b and b +- 2 -- the
+// +-512-row neighbours of config 4's grid -- then share an L2, and the launch still walks ONE moving window)
+__device__ __forceinline__ uint32_t xcd_group_index(uint32_t b, uint32_t n, uint32_t G)
+{
+    const uint32_t span = NUM_XCD * G;
+    if (b >= n - n % span) return b;                      // ragged tail: natural order
+    const uint32_t xcd = b % NUM_XCD, q = b / NUM_XCD;
+    return ((q / G) * NUM_XCD + xcd) * G + q % G;
+}
+
+template <int TPB, int RPT, int U, bool NT, int XCD>
 __global__ __launch_bounds__(TPB) void k_wide(const int *__restrict__ rowptr,
                                               const int *__restrict__ colval,
                                               const double *__restrict__ nzval,
@@ -98,7 +109,7 @@ __global__ __launch_bounds__(TPB) void k_wide(const int *__restrict__ rowptr,
     constexpr int CHUNK = TPB * 4 * U;
     __shared__ double s_prod[CHUNK];
     const int tid = threadIdx.x;
-    const uint32_t b = XCD ? xcd_slice_index(blockIdx.x, nblocks) : blockIdx.x;
+    const uint32_t b = XCD == 0 ? blockIdx.x : XCD == 1 ? xcd_slice_index(blockIdx.x, nblocks) : xcd_group_index(blockIdx.x, nblocks, XCD);
     const int64_t r0 = (int64_t)b * R;
     const int nr = (int)((nrows - r0) < R ? (nrows - r0) : R);
     const int64_t p0 = rowptr[r0], p1 = rowptr[r0 + nr];
@@ -890,6 +901,7 @@ extern "C" __attribute__((visibility("default"))) int hpcla_tune_spmv(
         case 17: NARROW(256, 1, 8, false, false, 0) break; // narrow, no NT, no XCD
         case 18: WIDE(256, 1, 1, false, false) break;      // wide, 1024 chunk (8 KiB LDS)
         case 19: WIDE(256, 2, 3, false, false) break;      // wide, 512 rows, no NT, no XCD
+        case 21: WIDE(256, 1, 2, true, 0) break;       // wide, NT stream loads, natural order (3-D: does x survive in L2 beside a streaming-hinted A?)
 #define PIPE(TPB, RPT, U, NT, PERCU)                                                              \
     {                                                                                             \
         int64_t nb = (nrows + TPB * RPT - 1) / (TPB * RPT);                                       \
@@ -947,6 +959,14 @@ extern "C" __attribute__((visibility("default"))) int hpcla_tune_spmv(
         case 84: k_packed2<256, 4><<<(uint32_t)((nrows + 1023) / 1024), 256, 0, s>>>(rowptr, dcol1024, code, dict, ndict, x, y, nrows, nnz); break;
         case 85: k_packed2<512, 2><<<(uint32_t)((nrows + 1023) / 1024), 512, 0, s>>>(rowptr, dcol1024, code, dict, ndict, x, y, nrows, nnz); break;
         case 86: k_packed2<1024, 1><<<(uint32_t)((nrows + 1023) / 1024), 1024, 0, s>>>(rowptr, dcol1024, code, dict, ndict, x, y, nrows, nnz); break;
+        case 22: WIDE(256, 1, 2, false, 4) break;          // natural kernel, XCD groups of 4 / 8 / 16 / 32 / 64 / 128 blocks
+        case 23: WIDE(256, 1, 2, false, 8) break;
+        case 24: WIDE(256, 1, 2, false, 16) break;
+        case 25: WIDE(256, 1, 2, false, 32) break;
+        case 26: WIDE(256, 1, 2, false, 64) break;
+        case 27: WIDE(256, 1, 2, false, 128) break;
+        case 28: WIDE(256, 1, 2, true, 16) break;          // groups + NT stream loads
+        case 29: WIDE(256, 1, 2, true, 64) break;
         case 20:
             k_copy<<<256 * 16, 256, 0, s>>>((const v4i *)colval, (const v2d *)nzval, (const v4i *)rowptr,
                                             (double2 *)y, (const double2 *)x, nnz, nrows);

@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""Times whole-library variants (benchmarks/tune/libhpcla_exp<N>.so = the production library with spmv.hip rebuilt under
+-DHPCLA_EXP=N, see build_spmv_lib_variants.sh) against the shipped library, interleaved in ONE process, on config 2's
+matrix (4096^2, 5-point) and config 4's per-GPU slab (512 x 512 x 64, 7-point): plain SpMV entry and the fused
+SpMV + x.y entry CG uses.  Every variant's y must be bit-identical to the shipped library's."""
+import argparse
+import ctypes
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--variants", default="0,1,2,4,5,7")
+    ap.add_argument("--rounds", type=int, default=9)
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--dims", default="2,3")
+    args = ap.parse_args()
+    import torch
+    import hpcla_amd as hp
+    from hpcla_amd import workloads as wl
+    from benchmarks.extra_workloads import device_stencil
+    backend = hp.backend_rocm_serial(np.float64, np.int32)
+    s = torch.cuda.current_stream().cuda_stream
+    names = ["prod"] + [f"exp{v}" for v in args.variants.split(",") if v]
+    libs = {"prod": hp._capi.load()}
+    for nm in names[1:]:
+        lib = ctypes.CDLL(os.path.join(ROOT, "benchmarks", "tune", f"libhpcla_{nm}.so"), mode=ctypes.RTLD_LOCAL)
+        for fn in ("hpcla_spmv_csr_f64_i32", "hpcla_spmv_dist_dot_f64_i32", "hpcla_spmv_split_f64_i32"):
+            getattr(lib, fn).argtypes = getattr(libs["prod"], fn).argtypes
+            getattr(lib, fn).restype = ctypes.c_int
+        libs[nm] = lib
+    out = {}
+    for dim in [int(d) for d in args.dims.split(",")]:
+        dims = (4096, 4096) if dim == 2 else (512, 512, 64)
+        n = int(np.prod(dims))
+        A = device_stencil(hp, torch, backend, dims, 0, n)
+        x = hp.HPCVector.zeros(A.row_partition, backend)
+        hp._capi.call("hpcla_fill_uniform_f64", x.v.data_ptr(), 0, n, wl.SEED_X, s)
+        plan = hp.get_vector_plan(A, x)
+        cv = plan.colval_split
+        nnz = A.nnz
+        y_ref = torch.empty(n, dtype=torch.float64, device="cuda")
+        y = torch.empty_like(y_ref)
+        dot_out = torch.zeros(1, dtype=torch.float64, device="cuda")
+        dot_work = torch.empty(libs["prod"].hpcla_spmv_dot_work_bytes(n) // 8 + 1, dtype=torch.float64, device="cuda")
+        b_alg = wl.spmv_algorithmic_bytes(nnz, n, n, 4)
+
+        ghost = torch.zeros(16, dtype=torch.float64, device="cuda")
+
+        def launch(nm, fused, yy):
+            lib = libs[nm]
+            if fused == "split":             # the split-column kernel (ghost select per entry), every column owned
+                return lib.hpcla_spmv_split_f64_i32(A.rowptr_target.data_ptr(), cv.data_ptr(), A.nzval.data_ptr(), x.v.data_ptr(),
+                                                    ghost.data_ptr(), n, yy.data_ptr(), n, nnz, 0, None, 0, s)
+            if fused:
+                return lib.hpcla_spmv_dist_dot_f64_i32(None, None, A.rowptr_target.data_ptr(), cv.data_ptr(), A.nzval.data_ptr(),
+                                                       x.v.data_ptr(), n, yy.data_ptr(), n, nnz, 0, None, 0, None, 0,
+                                                       dot_out.data_ptr(), dot_work.data_ptr(), s)
+            return lib.hpcla_spmv_csr_f64_i32(A.rowptr_target.data_ptr(), cv.data_ptr(), A.nzval.data_ptr(), x.v.data_ptr(),
+                                              yy.data_ptr(), n, nnz, 0, s)
+        print(f"# poisson{dim}d {dims} n={n} nnz={nnz} B_alg={b_alg}")
+        print(f"{'variant':>8} {'entry':>6} {'median_ms':>10} {'min_ms':>10} {'frac_8TB':>9} exact")
+        for fused in (False, True, "split"):
+            assert launch("prod", fused, y_ref) == 0
+            torch.cuda.synchronize()
+            dref = float(dot_out.item())
+            exact, times = {}, {nm: [] for nm in names}
+            for nm in names:
+                y.fill_(float("nan"))
+                rc = launch(nm, fused, y)
+                assert rc == 0, (nm, rc)
+                torch.cuda.synchronize()
+                exact[nm] = bool(torch.equal(y, y_ref)) and (fused is not True or float(dot_out.item()) == dref)
+            for _ in range(args.rounds):
+                for nm in names:
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    for _ in range(args.reps):
+                        launch(nm, fused, y)
+                    b.record()
+                    torch.cuda.synchronize()
+                    times[nm].append(a.elapsed_time(b) / args.reps)
+            for nm in names:
+                med, mn = float(np.median(times[nm])), float(np.min(times[nm]))
+                ename = "split" if fused == "split" else "dot" if fused else "plain"
+                out[f"{dim}d/{ename}/{nm}"] = dict(median_ms=med, min_ms=mn, exact=exact[nm])
+                print(f"{nm:>8} {ename:>6} {med:>10.4f} {mn:>10.4f} {b_alg / med / 1e6 / 8000:>9.3f} {exact[nm]}")
+        del A, x, plan, y, y_ref
+        hp.clear_plan_cache()
+        torch.cuda.empty_cache()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

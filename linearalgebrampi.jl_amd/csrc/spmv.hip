@@ -31,6 +31,10 @@
 #include "common.h"
 #include "halo_wait.h"
 
+// occupancy hint of the quad kernel: the split-column instantiations need the register cap spelled out to stay at 8
+// waves per SIMD; the plain ones reach <= 64 VGPRs on their own and schedule better without it (measured, both ways)
+#define HPCLA_SPMV_ATTRS __attribute__((amdgpu_waves_per_eu(SPLIT ? 8 : 4, 8)))
+
 namespace hpcla {
 
 constexpr int RPB = 256;      // rows per block == threads per block
@@ -101,9 +105,70 @@ __device__ __forceinline__ void block_dot_epilogue(double *s_scratch, double *__
     if (threadIdx.x == 0) dot_partial[blk] = ((s_scratch[0] + s_scratch[1]) + s_scratch[2]) + s_scratch[3];
 }
 
+// One pass of a WAVE over NQ aligned quads per lane, all of them inside the arrays: STRAIGHT-LINE code, no lane
+// predicate anywhere.  Order: the column quads leave first; as they land the x gathers leave; then the value loads
+// (needed last; a scheduling barrier keeps them behind the gathers), so the dependent chain columns -> x is two round
+// trips and the registers hold either columns + addresses or gathered x + values, never all of them (<= 64 VGPRs, 8
+// workgroups per CU).  Lanes whose quad starts at or beyond n re-read the pass's last quad (lines their neighbours
+// read anyway) and park their unused products in their own slots of s_prod, which the row sums never read.
+// Rounds 1-2 shipped one general pass with a per-entry tail path for the last quad of the matrix inside per-lane
+// branches: the tail loads target the same registers as the full-quad loads, so the compiler put vmcnt(0) between
+// them -- every pass's second quad waited for the first quad's round trip, and its gathers for the first quad's
+// gathers (profiles/r03_spmv_straight_line_pass.log: -2.1 % / -3.0 % plain 2-D / 3-D, -4.5 % with the x.y epilogue).
+template <typename I, bool SPLIT, int NQ>
+__device__ __forceinline__ void quad_pass_whole(const I *__restrict__ colval, const double *__restrict__ nzval,
+                                                const double *__restrict__ x_own, const double *x_ghost, int64_t n_own,
+                                                int base, int n, int tid, double *s_prod)
+{
+    const int last = (n - 1) & ~3;
+    int e[NQ];
+    vec<I, 4> col[NQ];
+    vec<double, 2> va[NQ], vb[NQ];
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+        const int e0 = (u * RPB + tid) * 4;
+        e[u] = e0 < last ? e0 : last;
+    }
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) col[u] = *reinterpret_cast<const vec<I, 4> *>(colval + e[u]);
+    const double *xp[NQ][4];
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {            // columns are >= base: the subtraction stays in the index type
+        xp[u][0] = gather_ptr<SPLIT>(x_own, x_ghost, n_own, (int64_t)(I)(col[u].x - (I)base));
+        xp[u][1] = gather_ptr<SPLIT>(x_own, x_ghost, n_own, (int64_t)(I)(col[u].y - (I)base));
+        xp[u][2] = gather_ptr<SPLIT>(x_own, x_ghost, n_own, (int64_t)(I)(col[u].z - (I)base));
+        xp[u][3] = gather_ptr<SPLIT>(x_own, x_ghost, n_own, (int64_t)(I)(col[u].w - (I)base));
+    }
+    double xv[NQ][4];
+#pragma unroll
+    for (int u = 0; u < NQ; ++u)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xv[u][k] = *xp[u][k];
+    __builtin_amdgcn_sched_barrier(0);
+    // the values leave AFTER the gathers: they are needed last, and the chain col -> x stays two round trips long
+    // while the registers hold either columns + addresses or gathered x + values, never all of them
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+        va[u] = *reinterpret_cast<const vec<double, 2> *>(nzval + e[u]);
+        vb[u] = *reinterpret_cast<const vec<double, 2> *>(nzval + e[u] + 2);
+    }
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+        const int e0 = (u * RPB + tid) * 4;
+        vec<double, 2> pa2, pb2;
+        pa2.x = va[u].x * xv[u][0];
+        pa2.y = va[u].y * xv[u][1];
+        pb2.x = vb[u].x * xv[u][2];
+        pb2.y = vb[u].y * xv[u][3];
+        // unconditional: a conditional store would let the compiler sink this quad's loads behind the branch
+        *reinterpret_cast<vec<double, 2> *>(&s_prod[e0]) = pa2;
+        *reinterpret_cast<vec<double, 2> *>(&s_prod[e0 + 2]) = pb2;
+    }
+}
+
 // ---- primary kernel: aligned quads (needs colval 4*sizeof(I)- and nzval 32-byte aligned) -----------
 template <typename I, bool SPLIT, bool WAIT>
-__global__ __launch_bounds__(RPB) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8))) void spmv_rowblock_quad_kernel(
+__global__ __launch_bounds__(RPB) HPCLA_SPMV_ATTRS void spmv_rowblock_quad_kernel(
     const I *__restrict__ rowptr, const I *__restrict__ colval, const double *__restrict__ nzval,
     const double *__restrict__ x_own, const double *x_ghost, int64_t n_own,
     double *__restrict__ y, int64_t nrows, int64_t nnz, int base,
@@ -146,10 +211,10 @@ __global__ __launch_bounds__(RPB) __attribute__((amdgpu_num_sgpr(80), amdgpu_wav
     const int64_t total = p1 - pa;
 
     // this thread's row, relative to pa
-    int lo = 0, hi = 0;
-    if (tid < nr) {
-        lo = (int)((int64_t)rowptr[r0 + tid] - base - pa);
-        hi = (int)((int64_t)rowptr[r0 + tid + 1] - base - pa);
+    I rlo = 0, rhi = 0;                      // raw values: the subtraction (first use) sits in the reduce phase, so the
+    if (tid < nr) {                          // round trip of this load runs under the A stream instead of before it
+        rlo = rowptr[r0 + tid];
+        rhi = rowptr[r0 + tid + 1];
     }
 
     // fused x.y epilogue: fetch x at this lane's row NOW, so the load rides along with the stream instead of
@@ -161,65 +226,27 @@ __global__ __launch_bounds__(RPB) __attribute__((amdgpu_num_sgpr(80), amdgpu_wav
     for (int64_t c = 0; c < total; c += CHUNK) {
         const int n = (int)((total - c) < CHUNK ? (total - c) : CHUNK);
 
-        // stream phase: QUADS aligned quads per lane, all loads issued before the first use
-        vec<I, 4> col[QUADS];
-        vec<double, 2> va[QUADS], vb[QUADS];
-#pragma unroll
-        for (int u = 0; u < QUADS; ++u) {
-            const int e0 = (u * RPB + tid) * 4;
-            const int64_t g = pa + c + e0;
-            col[u] = (vec<I, 4>)(base);            // entries past nnz (<= 3 in the last quad): column 0, value 0
-            va[u] = (vec<double, 2>)(0.0);
-            vb[u] = (vec<double, 2>)(0.0);
-            if (e0 < n) {
-                if (g + 3 < nnz) {
-                    col[u] = *reinterpret_cast<const vec<I, 4> *>(colval + g);
-                    va[u] = *reinterpret_cast<const vec<double, 2> *>(nzval + g);
-                    vb[u] = *reinterpret_cast<const vec<double, 2> *>(nzval + g + 2);
-                } else {
-                    if (g + 0 < nnz) { col[u].x = colval[g + 0]; va[u].x = nzval[g + 0]; }
-                    if (g + 1 < nnz) { col[u].y = colval[g + 1]; va[u].y = nzval[g + 1]; }
-                    if (g + 2 < nnz) { col[u].z = colval[g + 2]; vb[u].x = nzval[g + 2]; }
-                }
-            }
-        }
-        // gather phase: all x loads of the pass issued back to back (addresses first, then loads, then
-        // the multiplies -- written as separate loops so hipcc clusters the loads instead of waiting
-        // for each gather before issuing the next)
-        const double *xp[QUADS][4];
-#pragma unroll
-        for (int u = 0; u < QUADS; ++u) {
-            xp[u][0] = gather_ptr<SPLIT>(x_own, x_ghost, n_own, (int64_t)col[u].x - base);
-            xp[u][1] = gather_ptr<SPLIT>(x_own, x_ghost, n_own, (int64_t)col[u].y - base);
-            xp[u][2] = gather_ptr<SPLIT>(x_own, x_ghost, n_own, (int64_t)col[u].z - base);
-            xp[u][3] = gather_ptr<SPLIT>(x_own, x_ghost, n_own, (int64_t)col[u].w - base);
-        }
-        double xv[QUADS][4];
-#pragma unroll
-        for (int u = 0; u < QUADS; ++u) {
-            const int e0 = (u * RPB + tid) * 4;
-            if (e0 < n) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) xv[u][k] = *xp[u][k];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < QUADS; ++u) {
-            const int e0 = (u * RPB + tid) * 4;
-            if (e0 < n) {
-                vec<double, 2> pa2, pb2;
-                pa2.x = va[u].x * xv[u][0];
-                pa2.y = va[u].y * xv[u][1];
-                pb2.x = vb[u].x * xv[u][2];
-                pb2.y = vb[u].y * xv[u][3];
-                *reinterpret_cast<vec<double, 2> *>(&s_prod[e0]) = pa2;
-                *reinterpret_cast<vec<double, 2> *>(&s_prod[e0 + 2]) = pb2;
+        // Every quad of this pass lies inside the arrays (workgroup-uniform; true for all passes but the very last
+        // of the matrix): each WAVE runs one straight-line pass over the quads it has (wave-uniform choice).
+        if (pa + c + ((n + 3) & ~3) <= nnz) {
+            const int wave_e0 = (__builtin_amdgcn_readfirstlane(tid) & ~63) * 4;
+            if (QUADS == 2 && wave_e0 + RPB * 4 < n)
+                quad_pass_whole<I, SPLIT, 2>(colval + pa + c, nzval + pa + c, x_own, x_ghost, n_own, base, n, tid, s_prod);
+            else if (wave_e0 < n)
+                quad_pass_whole<I, SPLIT, 1>(colval + pa + c, nzval + pa + c, x_own, x_ghost, n_own, base, n, tid, s_prod);
+        } else {
+            // the one pass of the launch whose last quad reaches past the end of the arrays: entry by entry
+            for (int e = tid; e < n; e += RPB) {
+                const int64_t g = pa + c + e;
+                s_prod[e] = g < nnz ? nzval[g] * gather_x<SPLIT>(x_own, x_ghost, n_own, (int64_t)(I)(colval[g] - (I)base)) : 0.0;
             }
         }
         __syncthreads();
 
         // reduce phase: sequential, stored order (== reference order)
         {
+            const int lo = tid < nr ? (int)((int64_t)rlo - base - pa) : 0;
+            const int hi = tid < nr ? (int)((int64_t)rhi - base - pa) : 0;
             const int a = lo > c ? lo : (int)c;
             const int e = hi < c + n ? hi : (int)(c + n);
             for (int j = a; j < e; ++j) acc += s_prod[j - c];
