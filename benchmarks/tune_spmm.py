@@ -100,8 +100,21 @@ def main():
         return int(v), 0
     variants = [parse(v) for v in args.variants.split(",")]
 
+    explibs = {}
+
+    def explib(n):            # 200 + N: the production library with spmm.hip rebuilt under -DHPCLA_EXP=N (build_spmv_lib_variants.sh)
+        if n not in explibs:
+            lib = ctypes.CDLL(os.path.join(ROOT, "benchmarks", "tune", f"libhpcla_spmm_exp{n}.so"), mode=ctypes.RTLD_LOCAL)
+            lib.hpcla_spmm_csr_f64_i32.argtypes = hp._capi.load().hpcla_spmm_csr_f64_i32.argtypes
+            lib.hpcla_spmm_csr_f64_i32.restype = ctypes.c_int
+            explibs[n] = lib
+        return explibs[n]
+
     def launch(v):
         mode, param = v
+        if mode >= 200:
+            return explib(mode - 200).hpcla_spmm_csr_f64_i32(A.rowptr_target.data_ptr(), cv.data_ptr(), A.nzval.data_ptr(), Bl.data_ptr(), k,
+                                                             0, C.data_ptr(), k, 0, n, nnz, k, 0, s)
         if mode == 100:
             return hp._capi.load().hpcla_spmm_csr_f64_i32(A.rowptr_target.data_ptr(), cv.data_ptr(), A.nzval.data_ptr(), Bl.data_ptr(), k,
                                                          0, C.data_ptr(), k, 0, n, nnz, k, 0, s)
@@ -131,7 +144,7 @@ def main():
     for v in variants:
         med, mn = float(np.median(times[v])), float(np.min(times[v]))
         name = f"{v[0]}" + (f":{v[1]}" if v[1] else "")
-        note = ABLATIONS.get(v[0], "production library" if v[0] == 100 else "")
+        note = ABLATIONS.get(v[0], "production library" if v[0] == 100 else f"library with spmm.hip under -DHPCLA_EXP={v[0] - 200}" if v[0] >= 200 else "")
         res[name] = dict(median_ms=med, min_ms=mn, gbs=b_alg / med / 1e6, exact=exact[v])
         ex = "-" if v[0] in ABLATIONS and v[0] != 5 else str(exact[v])
         print(f"{name:>10} {med:>10.4f} {mn:>10.4f} {b_alg / med / 1e6:>10.1f} {b_alg / med / 1e6 / 8000:>9.3f} {ex:>9}  {note}")

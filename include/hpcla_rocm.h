@@ -95,6 +95,29 @@ int hpcla_spmv_split_f64_i64(const int64_t *rowptr, const int64_t *colval_split,
 int hpcla_spmv_rows_per_block(void);
 int hpcla_spmm_rows_per_block(void);
 
+/* Optional plan-time performance hint (no reference counterpart: the reference launches one work-item per row in
+ * index order, src/sparse.jl:2055-2066, 2081-2082): SpMV launches over the matrix whose `rowptr` device pointer is
+ * given walk their contiguous runs of row blocks in an XCD-grouped order -- groups of `group` consecutive row blocks
+ * per XCD, groups dealt round-robin -- so that row blocks whose columns overlap share one of the 8 L2s (config 4's
+ * 512 x 512 planes: neighbours two blocks apart; -2 to -5 % per SpMV on every stencil matrix measured).  `group` = 0 or 1 removes the hint (natural order);
+ * otherwise a power of two <= 1024.  Results are bit-identical in every order (each row is still one sequential sum);
+ * launches restricted to a block LIST keep the list's order.  Keyed by the pointer: remove the hint before the
+ * array is freed (a stale entry can only cost performance).  Thread-safe. */
+int hpcla_spmv_block_order_hint(const void *rowptr, int group);
+
+/* Plan-time choice of that order BY MEASUREMENT (run once per structure, next to the VectorPlan build of
+ * src/sparse.jl:1875-1984, never inside a timed or captured region: it synchronises): times the split-column SpMV of
+ * this matrix -- the arguments of hpcla_spmv_split_f64_*, results discarded into `y_scratch` (nrows doubles) -- under the
+ * natural order and groups of 8 / 32 / 64 row blocks, interleaved over four rounds of four launches each, keeps the
+ * fastest registered for `rowptr` (the natural order unless a grouped one is >= 1 % faster) and returns it in
+ * *chosen_group (1 = natural).  Matrices below 4096 row blocks keep the natural order unmeasured. */
+int hpcla_spmv_tune_block_order_f64_i32(const int32_t *rowptr, const int32_t *colval_split, const double *nzval,
+                                        const double *x_own, const double *x_ghost, int64_t n_own, double *y_scratch,
+                                        int64_t nrows, int64_t nnz, int index_base, void *stream, int *chosen_group);
+int hpcla_spmv_tune_block_order_f64_i64(const int64_t *rowptr, const int64_t *colval_split, const double *nzval,
+                                        const double *x_own, const double *x_ghost, int64_t n_own, double *y_scratch,
+                                        int64_t nrows, int64_t nnz, int index_base, void *stream, int *chosen_group);
+
 /* Plan-time helpers (run once per (A, x.partition), cached with the VectorPlan like
  * _vector_plan_cache, src/HPCLinearAlgebra.jl:133).
  * remap: out[j] = map[in[j] - index_base]   (compressed column -> split column; out is 0-based)

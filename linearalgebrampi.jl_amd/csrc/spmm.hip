@@ -236,10 +236,13 @@ __global__ __launch_bounds__(64 * LPR) void spmm_rowblock_vec_kernel(
     const int64_t p0 = (int64_t)rowptr[r0] - base;
     const int64_t p1 = (int64_t)rowptr[r0 + nr] - base;
     const int64_t total = p1 - p0;
-    int64_t lo = 0, hi = 0;
+    // this lane's row bounds stay RAW until their first use behind the staging barrier: subtracting here would put a
+    // full memory round trip (1.3 us of a workgroup's 7.4, profiles/r03_spmm_ablations_and_candidates.txt) in front of the
+    // staging loads instead of under them (stencil 0.5220 -> 0.5150 ms, profiles/r03_spmm_late_row_bounds.log)
+    I rlo = 0, rhi = 0;
     if (g < nr) {
-        lo = (int64_t)rowptr[r0 + g] - base - p0;
-        hi = (int64_t)rowptr[r0 + g + 1] - base - p0;
+        rlo = rowptr[r0 + g];
+        rhi = rowptr[r0 + g + 1];
     }
 
     // A block whose entries fit ONE pass is staged once for ALL column tiles (k > one tile: the records are read-only
@@ -291,6 +294,8 @@ __global__ __launch_bounds__(64 * LPR) void spmm_rowblock_vec_kernel(
                 __syncthreads();
             }
             if (!col_ok) continue;
+            const int64_t lo = g < nr ? (int64_t)rlo - base - p0 : 0;
+            const int64_t hi = g < nr ? (int64_t)rhi - base - p0 : 0;
             int j = (int)((lo > ch ? lo : ch) - ch);
             const int e = (int)((hi < ch + n ? hi : ch + n) - ch);
             // VU entries per step: 2*VU independent 16-byte loads in flight per lane

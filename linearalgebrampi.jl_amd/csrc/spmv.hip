@@ -26,7 +26,12 @@
 // 8 XCDs through the 256 MiB Infinity Cache); a software-pipelined persistent variant and a
 // branch-free variant (idle lanes re-reading quad 0) both lose to plain high occupancy
 // (8 workgroups per CU) with whole waves skipping the quads past the end of a row block.
+#include <stdlib.h>
 #include <string.h>
+
+#include <atomic>
+#include <mutex>
+#include <unordered_map>
 
 #include "common.h"
 #include "halo_wait.h"
@@ -76,7 +81,26 @@ struct BlockSel {
     const int32_t *first_list;   // WAIT only: interior blocks; null: first_base + b
     int64_t first_base;
     int64_t n_first;
+    int64_t n_run;               // length of the contiguous run the group order applies to (plain: the launch; WAIT: n_first)
+    int32_t group_log2;          // > 0: XCD-grouped order of the contiguous run, groups of 2^group_log2 row blocks
 };
+
+// XCD-grouped order of a contiguous run of n row blocks.  The hardware deals workgroups to the 8 XCDs round-robin by
+// workgroup id, so in the natural order block b runs on XCD b % 8 and the x lines two blocks shared are fetched into
+// two L2s unless their distance is a multiple of 8 (a 4096-wide 2-D grid: +-16 blocks -- fine; config 4's 512 x 512
+// planes: +-2 blocks -- every x line came into ~4 L2s, 1.26 x the algorithmic reads).  Here every XCD takes GROUPS of
+// G consecutive blocks, groups dealt round-robin: neighbours at distance << G share an L2, distances that are
+// multiples of 8 G still do, and the launch still walks ONE moving window through the matrix (the property that made
+// the natural order beat one slice per XCD in round 1).  A bijection on [0, n): the ragged tail keeps its order.
+// Chosen per matrix at plan time (hpcla_spmv_block_order_hint); profiles/r03_spmv_xcd_group_order.log.
+constexpr int NUM_XCD_LOG2 = 3;
+__device__ __forceinline__ int64_t xcd_group_index(int64_t b, int64_t n, int group_log2)
+{
+    const int64_t span = (int64_t)1 << (NUM_XCD_LOG2 + group_log2);
+    if (b >= n - (n & (span - 1))) return b;
+    const int64_t xcd = b & ((1 << NUM_XCD_LOG2) - 1), q = b >> NUM_XCD_LOG2;
+    return ((((q >> group_log2) << NUM_XCD_LOG2) + xcd) << group_log2) + (q & (((int64_t)1 << group_log2) - 1));
+}
 
 template <bool WAIT>
 __device__ __forceinline__ int64_t select_block(const BlockSel &bs, bool &wait, int lead)
@@ -84,11 +108,15 @@ __device__ __forceinline__ int64_t select_block(const BlockSel &bs, bool &wait, 
     const int64_t b = (int64_t)blockIdx.x - lead;     // `lead` push workgroups come first in a fused launch
     wait = false;
     if (WAIT) {
-        if (b < bs.n_first) return bs.first_list ? (int64_t)bs.first_list[b] : bs.first_base + b;
+        if (b < bs.n_first) {
+            if (bs.first_list) return (int64_t)bs.first_list[b];
+            return bs.first_base + (bs.group_log2 > 0 ? xcd_group_index(b, bs.n_run, bs.group_log2) : b);
+        }
         wait = true;
         return bs.list ? (int64_t)bs.list[b - bs.n_first] : bs.base + (b - bs.n_first);
     }
-    return bs.list ? (int64_t)bs.list[b] : bs.base + b;
+    if (bs.list) return (int64_t)bs.list[b];
+    return bs.base + (bs.group_log2 > 0 ? xcd_group_index(b, bs.n_run, bs.group_log2) : b);
 }
 
 // Fused x.y epilogue (CG's p.Ap): every workgroup leaves the
@@ -383,6 +411,26 @@ static inline uint32_t stream_grid(int64_t n, int threads)
     return (uint32_t)g;
 }
 
+// ---- per-matrix block order (a performance hint, never a correctness matter: every order is a bijection) ----------
+static std::mutex g_order_mu;
+static std::unordered_map<const void *, int> g_order;          // rowptr device pointer -> log2(group)
+static std::atomic<int> g_order_count{0};
+
+static int block_order_of(const void *rowptr)
+{
+    static const int forced = [] {                              // HPCLA_SPMV_XCD_GROUP=G: every launch (experiments)
+        const char *e = getenv("HPCLA_SPMV_XCD_GROUP");
+        int g = e ? atoi(e) : 0, l = 0;
+        while (g > 1) { g >>= 1; ++l; }
+        return l > 10 ? 10 : l;
+    }();
+    if (forced) return forced;
+    if (g_order_count.load(std::memory_order_relaxed) == 0) return 0;
+    std::lock_guard<std::mutex> lock(g_order_mu);
+    auto it = g_order.find(rowptr);
+    return it == g_order.end() ? 0 : it->second;
+}
+
 template <typename I>
 static int spmv_launch(const I *rowptr, const I *colval, const double *nzval, const double *x_own,
                        const double *x_ghost, int64_t n_own, bool split, double *y, int64_t nrows,
@@ -419,7 +467,7 @@ static int spmv_launch(const I *rowptr, const I *colval, const double *nzval, co
     // quad kernel: a 4-entry quad must never straddle a page -> colval 4*sizeof(I)-, nzval 32-byte aligned
     const bool aligned = (reinterpret_cast<uintptr_t>(colval) % (4 * sizeof(I)) == 0) &&
                          (reinterpret_cast<uintptr_t>(nzval) % 32 == 0);
-    const BlockSel bs{block_list, block_base, nullptr, 0, 0};
+    const BlockSel bs{block_list, block_base, nullptr, 0, 0, launch_blocks, block_list ? 0 : block_order_of(rowptr)};
     HaloWait nowait;
     memset(&nowait, 0, sizeof(nowait));
     PushArgs nopush;
@@ -474,7 +522,8 @@ static int spmv_launch_fused(const I *rowptr, const I *colval, const double *nzv
     hipStream_t s = as_stream(stream);
     const bool aligned = (reinterpret_cast<uintptr_t>(colval) % (4 * sizeof(I)) == 0) &&
                          (reinterpret_cast<uintptr_t>(nzval) % 32 == 0);
-    const BlockSel bs{boundary_list, 0, interior_list, interior_base, n_interior};
+    const BlockSel bs{boundary_list, 0, interior_list, interior_base, n_interior, n_interior,
+                      interior_list ? 0 : block_order_of(rowptr)};
     if (aligned)
         spmv_rowblock_quad_kernel<I, true, true><<<grid, block, 0, s>>>(
             rowptr, colval, nzval, x_own, x_ghost, n_own, y, nrows, nnz, index_base, bs, dot_partial, hw, pa);
@@ -529,6 +578,98 @@ int spmv_split_i64(const int64_t *rowptr, const int64_t *colval, const double *n
 using namespace hpcla;
 
 HPCLA_API int hpcla_spmv_rows_per_block(void) { return RPB; }
+
+static void set_block_order(const void *rowptr, int group_log2)
+{
+    std::lock_guard<std::mutex> lock(g_order_mu);
+    if (group_log2 <= 0) g_order.erase(rowptr);
+    else g_order[rowptr] = group_log2;
+    g_order_count.store((int)g_order.size(), std::memory_order_relaxed);
+}
+
+// Plan-time choice of the block order BY MEASUREMENT: the same launch the plan will make, timed under the natural order
+// and groups of 8 / 32 / 64 row blocks, interleaved over a few rounds; the fastest stays registered for `rowptr`.  The
+// natural order is kept unless a grouped one is >= 1 % faster.  (A model of which x lines two XCDs share predicts
+// config 4's planes and the 256^3 cube, but not that 4096- and 8192-wide 2-D grids gain 3 % from groups of 32 / 64
+// although their neighbours already share an XCD in the natural order, nor that a 1000-wide grid loses 1 % with
+// groups of 64 -- profiles/r03_spmv_xcd_group_order.log -- so the choice is measured, like an FFT plan's.)
+template <typename I>
+static int tune_block_order(const I *rowptr, const I *colval_split, const double *nzval, const double *x_own,
+                            const double *x_ghost, int64_t n_own, double *y_scratch, int64_t nrows, int64_t nnz,
+                            int index_base, void *stream, int *chosen_group)
+{
+    if (chosen_group) *chosen_group = 1;
+    if (nrows < 0 || nnz < 0 || !rowptr) return set_error(HPCLA_ERR_INVALID, "spmv_tune_block_order: bad arguments");
+    set_block_order(rowptr, 0);
+    const int64_t n_blocks = (nrows + RPB - 1) / RPB;
+    if (n_blocks < 4096 || nnz == 0) return HPCLA_OK;      // small matrices live in the caches whatever the order
+    if (!y_scratch) return set_error(HPCLA_ERR_INVALID, "spmv_tune_block_order: null scratch vector");
+    constexpr int NC = 4, ROUNDS = 4, REPS = 4;            // round 0 warms up (clocks, TLBs) and is not counted
+    const int cand[NC] = {0, 3, 5, 6};
+    float ms[NC][ROUNDS];
+    hipEvent_t e0, e1;
+    HPCLA_CHECK_HIP(hipEventCreate(&e0));
+    HPCLA_CHECK_HIP(hipEventCreate(&e1));
+    hipStream_t s = as_stream(stream);
+    int rc = HPCLA_OK;
+    for (int r = 0; r < ROUNDS && rc == HPCLA_OK; ++r)
+        for (int c = 0; c < NC && rc == HPCLA_OK; ++c) {
+            set_block_order(rowptr, cand[c]);
+            if (hipEventRecord(e0, s) != hipSuccess) { rc = set_error(HPCLA_ERR_HIP, "spmv_tune_block_order: event"); break; }
+            for (int i = 0; i < REPS && rc == HPCLA_OK; ++i)
+                rc = spmv_launch<I>(rowptr, colval_split, nzval, x_own, x_ghost, n_own, true, y_scratch, nrows, nnz,
+                                    index_base, nullptr, 0, stream);
+            if (rc != HPCLA_OK) break;
+            if (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+                hipEventElapsedTime(&ms[c][r], e0, e1) != hipSuccess)
+                rc = set_error(HPCLA_ERR_HIP, "spmv_tune_block_order: timing");
+        }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    set_block_order(rowptr, 0);
+    if (rc != HPCLA_OK) return rc;
+    float best_t[NC];
+    for (int c = 0; c < NC; ++c) {                         // median of the three counted rounds
+        float a = ms[c][1], b = ms[c][2], d = ms[c][3];
+        best_t[c] = a > b ? (b > d ? b : (a > d ? d : a)) : (a > d ? a : (b > d ? d : b));
+    }
+    int best = 0;
+    for (int c = 1; c < NC; ++c)
+        if (best_t[c] < best_t[best]) best = c;
+    if (best != 0 && best_t[best] > 0.99f * best_t[0]) best = 0;
+    set_block_order(rowptr, cand[best]);
+    if (chosen_group) *chosen_group = 1 << cand[best];
+    return HPCLA_OK;
+}
+
+HPCLA_API int hpcla_spmv_tune_block_order_f64_i32(const int32_t *rowptr, const int32_t *colval_split, const double *nzval,
+                                                  const double *x_own, const double *x_ghost, int64_t n_own,
+                                                  double *y_scratch, int64_t nrows, int64_t nnz, int index_base,
+                                                  void *stream, int *chosen_group)
+{
+    return tune_block_order<int32_t>(rowptr, colval_split, nzval, x_own, x_ghost, n_own, y_scratch, nrows, nnz, index_base,
+                                     stream, chosen_group);
+}
+
+HPCLA_API int hpcla_spmv_tune_block_order_f64_i64(const int64_t *rowptr, const int64_t *colval_split, const double *nzval,
+                                                  const double *x_own, const double *x_ghost, int64_t n_own,
+                                                  double *y_scratch, int64_t nrows, int64_t nnz, int index_base,
+                                                  void *stream, int *chosen_group)
+{
+    return tune_block_order<int64_t>(rowptr, colval_split, nzval, x_own, x_ghost, n_own, y_scratch, nrows, nnz, index_base,
+                                     stream, chosen_group);
+}
+
+HPCLA_API int hpcla_spmv_block_order_hint(const void *rowptr, int group)
+{
+    if (!rowptr) return set_error(HPCLA_ERR_INVALID, "spmv_block_order_hint: null rowptr");
+    if (group < 0 || group > 1024 || (group & (group - 1)) != 0)
+        return set_error(HPCLA_ERR_INVALID, "spmv_block_order_hint: group must be 0 or a power of two <= 1024");
+    int l = 0;
+    for (int g = group; g > 1; g >>= 1) ++l;
+    set_block_order(rowptr, l);
+    return HPCLA_OK;
+}
 
 HPCLA_API int hpcla_spmv_csr_f64_i32(const int32_t *rowptr, const int32_t *colval,
                                      const double *nzval, const double *x, double *y,

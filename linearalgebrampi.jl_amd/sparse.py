@@ -256,6 +256,23 @@ class VectorPlan:
             self.n_interior = int(self.interior.numel())
             self.n_boundary = int(self.boundary.numel())
         self._keep = (cmap_dev, send_idx)
+        # block order of the SpMV launches over this structure: measured once, here (hpcla_spmv_tune_block_order_*, a few
+        # dozen launches into a scratch vector); HPCLA_BLOCK_ORDER=natural skips it, =<G> forces groups of G row blocks
+        self.block_group = 1
+        want = _os.environ.get("HPCLA_BLOCK_ORDER", "auto")
+        if want.isdigit():
+            self.block_group = max(1, int(want))
+        elif want != "natural" and A.nrows_local > 0 and A.nnz > 0:
+            scratch = torch.empty(A.nrows_local, dtype=torch.float64, device=dev)
+            ghost, _ng = self.ghost_tensor_ptr()
+            chosen = ctypes.c_int(1)
+            _capi.call(f"hpcla_spmv_tune_block_order_f64_{sfx}", dptr(A.rowptr_target), dptr(self.colval_split), dptr(A.nzval),
+                       dptr(x.v), ghost, self.n_own, dptr(scratch), A.nrows_local, A.nnz, 0, s, ctypes.byref(chosen))
+            self.block_group = int(chosen.value)
+            A._block_order_hint = self.block_group       # the tuner left it registered for this matrix
+            if self.block_group > 1:
+                import weakref
+                A._block_order_finalizer = weakref.finalize(A, _unhint_block_order, A.rowptr_target.data_ptr())
 
     def ghost_tensor_ptr(self) -> Tuple[ctypes.c_void_p, int]:
         g = ctypes.c_void_p()
@@ -290,7 +307,28 @@ def get_vector_plan(A: "HPCSparseMatrix", x: HPCVector) -> VectorPlan:
         plan = VectorPlan(A, x)
         plan.key = key
         _vector_plan_cache[key] = plan
+    if getattr(A, "_block_order_hint", 1) != plan.block_group:
+        _hint_block_order(A, plan.block_group)
     return plan
+
+
+def _unhint_block_order(ptr: int) -> None:
+    try:
+        _capi.load().hpcla_spmv_block_order_hint(ctypes.c_void_p(ptr), 0)
+    except Exception:                          # interpreter shutdown
+        pass
+
+
+def _hint_block_order(A, group: int) -> None:
+    """Tell the library the block order of SpMV launches over THIS matrix (keyed by its rowptr device pointer, which
+    several matrices of one structure do not share); the hint goes when the matrix does (a host-side table entry:
+    no device work in the finaliser)."""
+    import weakref
+    ptr = A.rowptr_target.data_ptr()
+    _capi.call("hpcla_spmv_block_order_hint", ptr, int(group))
+    A._block_order_hint = group
+    if group > 1 and not getattr(A, "_block_order_finalizer", None):
+        A._block_order_finalizer = weakref.finalize(A, _unhint_block_order, ptr)
 
 
 def clear_plan_cache() -> None:

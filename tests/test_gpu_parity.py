@@ -125,6 +125,76 @@ def test_spmv_long_rows_chunk_loop(hp, orc, gpu_backend_i32):
     assert got[1] == 0.0 and got[298] == 0.0
 
 
+@pytest.mark.parametrize("Ti", [np.int32, np.int64])
+def test_spmv_block_order_hint_is_a_bijection_with_the_same_bits(hp, orc, gpu_backend_i32, Ti):
+    """hpcla_spmv_block_order_hint: XCD-grouped order of the row blocks.  Every group size must visit every row block
+    exactly once -- y bit-identical to the natural order, incl. a ragged tail (block count not a multiple of 8 G),
+    groups larger than the launch, and the fused x.y entry; a bad group is rejected; group 0 removes the hint."""
+    import torch
+    n = 256 * 1237 + 77                       # 1238 row blocks: ragged for every G
+    rows = orc.poisson2d_rows(n // 50 + 1, 50, 0, n)
+    x = orc.fill_uniform(0, (n // 50 + 1) * 50, orc.SEED_X)
+    want = orc.spmv(rows.rowptr.astype(Ti), rows.colidx.astype(Ti), rows.vals, x)
+    sfx = "i32" if Ti == np.int32 else "i64"
+    rp, cv, nz, xd = _t(rows.rowptr.astype(Ti)), _t(rows.colidx.astype(Ti)), _t(rows.vals), _t(x)
+    s = torch.cuda.current_stream().cuda_stream
+    lib = hp._capi.load()
+    work = torch.empty(lib.hpcla_spmv_dot_work_bytes(n) // 8 + 1, dtype=torch.float64, device="cuda")
+    dots = []
+    try:
+        for G in (0, 2, 4, 64, 1024, 1):
+            hp._capi.call("hpcla_spmv_block_order_hint", rp.data_ptr(), G)
+            y = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+            hp._capi.call(f"hpcla_spmv_csr_f64_{sfx}", rp.data_ptr(), cv.data_ptr(), nz.data_ptr(), xd.data_ptr(), y.data_ptr(),
+                          n, len(rows.vals), 0, s)
+            np.testing.assert_array_equal(y.cpu().numpy(), want, err_msg=f"group {G}")
+            y.fill_(float("nan"))
+            d = torch.zeros(1, dtype=torch.float64, device="cuda")
+            hp._capi.call(f"hpcla_spmv_dist_dot_f64_{sfx}", None, None, rp.data_ptr(), cv.data_ptr(), nz.data_ptr(), xd.data_ptr(),
+                          n, y.data_ptr(), n, len(rows.vals), 0, None, 0, None, 0, d.data_ptr(), work.data_ptr(), s)
+            np.testing.assert_array_equal(y.cpu().numpy(), want, err_msg=f"fused entry, group {G}")
+            dots.append(float(d.item()))
+        assert len(set(dots)) == 1               # the partials are indexed by ROW BLOCK, not by workgroup: same sum
+        for bad in (3, -2, 2048):
+            assert lib.hpcla_spmv_block_order_hint(ctypes.c_void_p(rp.data_ptr()), bad) != 0
+        assert lib.hpcla_spmv_block_order_hint(None, 4) != 0
+    finally:
+        lib.hpcla_spmv_block_order_hint(ctypes.c_void_p(rp.data_ptr()), 0)
+
+
+def test_plan_measures_block_order_once_per_structure(hp, orc, gpu_backend_i32):
+    """hpcla_spmv_tune_block_order_* at plan time: the choice is one of the measured candidates, it is registered for
+    the matrix, products are bit-identical under it and under the natural order, small matrices are not measured, and
+    the hint dies with the matrix (host table only)."""
+    import gc
+    import torch
+    from benchmarks.extra_workloads import device_stencil
+    backend = gpu_backend_i32
+    s = torch.cuda.current_stream().cuda_stream
+    A3 = device_stencil(hp, torch, backend, (512, 512, 8), 0, 512 * 512 * 8)          # 8192 row blocks: measured
+    x3 = hp.HPCVector.zeros(A3.row_partition, backend)
+    hp._capi.call("hpcla_fill_uniform_f64", x3.v.data_ptr(), 0, A3.nrows_local, orc.SEED_X, s)
+    plan3 = hp.get_vector_plan(A3, x3)
+    assert plan3.block_group in (1, 8, 32, 64) and A3._block_order_hint == plan3.block_group
+    y_plan = (A3 @ x3).v.clone()
+    for G in (0, 64):
+        hp._capi.call("hpcla_spmv_block_order_hint", A3.rowptr_target.data_ptr(), G)
+        np.testing.assert_array_equal((A3 @ x3).v.cpu().numpy(), y_plan.cpu().numpy())
+    # a second matrix of the same structure shares the plan and gets the same order registered for ITS arrays
+    B3 = device_stencil(hp, torch, backend, (512, 512, 8), 0, 512 * 512 * 8)
+    assert hp.get_vector_plan(B3, x3) is plan3 and B3._block_order_hint == plan3.block_group
+    # the raw entry: small matrix -> natural, unmeasured; bad arguments -> error
+    A2 = device_stencil(hp, torch, backend, (256, 256), 0, 256 * 256)
+    x2 = hp.HPCVector.zeros(A2.row_partition, backend)
+    assert hp.get_vector_plan(A2, x2).block_group == 1
+    lib = hp._capi.load()
+    chosen = ctypes.c_int(-1)
+    assert lib.hpcla_spmv_tune_block_order_f64_i32(None, None, None, None, None, 0, None, 10, 10, 0, None, ctypes.byref(chosen)) != 0
+    del A3, B3, plan3
+    gc.collect()
+    hp.clear_plan_cache()
+
+
 def test_spmv_empty_and_zero_nnz(hp, gpu_backend_i32):
     got = _raw_spmv(hp, np.zeros(5, dtype=np.int64), np.empty(0, dtype=np.int64), np.empty(0), np.ones(3), np.int32)
     np.testing.assert_array_equal(got, np.zeros(4))

@@ -340,3 +340,21 @@ def test_rccl_init_guard_reports_failure_and_deadline(hp, monkeypatch):
     t0 = time.perf_counter()
     why = backends._init_rccl_guarded(FakeLib(0, delay=5.0), h, None, 2, 0, 0, 0)
     assert "did not return" in why and time.perf_counter() - t0 < 3.0
+
+
+def test_xcd_group_order_is_a_bijection():
+    """Restatement of csrc/spmv.hip xcd_group_index (the GPU suite checks the kernel's own through bit-equal results)."""
+    def index(b, n, l):
+        span = 1 << (3 + l)
+        if b >= n - (n & (span - 1)):
+            return b
+        xcd, q = b & 7, b >> 3
+        return ((((q >> l) << 3) + xcd) << l) + (q & ((1 << l) - 1))
+    for n in (1, 7, 8, 64, 1238, 4096, 65536 + 13):
+        for l in (1, 2, 6, 10):
+            img = sorted(index(b, n, l) for b in range(n))
+            assert img == list(range(n)), (n, l)
+    # blocks of one group land on one XCD: workgroup ids b with equal b % 8 and q // G
+    G, l = 64, 6
+    got = [index(b, 8 * G * 4, l) for b in range(0, 8 * G, 8)]          # XCD 0's first G workgroups
+    assert got == list(range(G))
