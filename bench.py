@@ -700,7 +700,8 @@ def _run(args, budget):
                      "kernel": kernel, "algorithmic_bytes_per_launch": b_alg_loc,
                      "launch_ms_timed_region": round(timed_region_launch_ms, 5),
                      "launch_ms_event_pairs": round(launch_ms, 5), "launch_ms_back_to_back": round(stream_ms, 5),
-                     "launches_before_timed_region": 1 + 2 * reps + args.warmup,
+                     "launches_before_timed_region": 1 + 2 * reps + args.warmup + (64 if run.plan.block_group_measured else 0),
+                     "block_order_group": run.plan.block_group,
                      "launch_ms_min": round(float(per_launch_ms.min()), 5),
                      "launch_ms_median": round(float(np.median(per_launch_ms)), 5)},
         "hbm_gbs_whole_job": round(b_alg_tot / (elapsed / args.steps) / 1e9, 1),

@@ -18,6 +18,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNEL = "spmv_rowblock_quad_kernel<int, false, false>"     # <index type, SPLIT, WAIT>: the single-GPU headline kernel
 B_ALG = 1_341_980_676          # config 2, Int32
+ORDER_NOTE = ("block order fixed for the profiled runs (HPCLA_BLOCK_ORDER=32, 64 for the 3-D slab: what the plans' measurement picks on "
+              "these matrices) so that no launch of the plan-time measurement sits in the per-kernel means")
 CORRECTION = "gfx950: FETCH_SIZE counts 128-B requests at 64 B -> doubled (MI355X_MICROARCH.md, HBM); WRITE_SIZE exact"
 
 
@@ -119,7 +121,7 @@ def main():
         "source": f"profiles/{rnd}_bench_pmc_FETCH_SIZE.csv + profiles/{rnd}_bench_pmc_WRITE_SIZE.csv (separate rocprofv3 "
                   f"--pmc passes over `python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-strong --no-extras --no-packed`; {nf} / {nw} launches)",
         "FETCH_SIZE_KB_mean": round(fetch_kb, 1), "WRITE_SIZE_KB_mean": round(write_kb, 1),
-        "correction": CORRECTION,
+        "correction": CORRECTION, "block_order": ORDER_NOTE,
         "hbm_bytes_per_launch": hbm(fetch_kb, write_kb), "algorithmic_bytes_per_launch": B_ALG,
         "ratio_to_algorithmic": round(hbm(fetch_kb, write_kb) / B_ALG, 4),
         "calibration_note": "k_copy (known 1 207 762 944 B read with 16-B loads) read FETCH_SIZE 612 339 KB in the r01 "

@@ -259,6 +259,7 @@ class VectorPlan:
         # block order of the SpMV launches over this structure: measured once, here (hpcla_spmv_tune_block_order_*, a few
         # dozen launches into a scratch vector); HPCLA_BLOCK_ORDER=natural skips it, =<G> forces groups of G row blocks
         self.block_group = 1
+        self.block_group_measured = False
         want = _os.environ.get("HPCLA_BLOCK_ORDER", "auto")
         if want.isdigit():
             self.block_group = max(1, int(want))
@@ -269,6 +270,7 @@ class VectorPlan:
             _capi.call(f"hpcla_spmv_tune_block_order_f64_{sfx}", dptr(A.rowptr_target), dptr(self.colval_split), dptr(A.nzval),
                        dptr(x.v), ghost, self.n_own, dptr(scratch), A.nrows_local, A.nnz, 0, s, ctypes.byref(chosen))
             self.block_group = int(chosen.value)
+            self.block_group_measured = (A.nrows_local + 255) // 256 >= 4096      # the tuner's own threshold (64 launches)
             A._block_order_hint = self.block_group       # the tuner left it registered for this matrix
             if self.block_group > 1:
                 import weakref
