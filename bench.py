@@ -678,6 +678,12 @@ def _run(args, budget):
             traffic = rec.get("hbm_bytes_per_launch")
             traffic_source = ("NOT measured by this run: PMC counters cannot be read from inside the process; value "
                               "stored by the builder's rocprofv3 passes of this same command -- " + rec.get("source", tj))
+            # the counter depends on the block order the plan's measurement chose for this run (neighbouring XCD groups
+            # share x lines; FETCH_SIZE counts them once per L2 although the Infinity Cache serves the repeats)
+            per_order = rec.get("by_block_order", {}).get(str(run.plan.block_group))
+            if per_order:
+                traffic = per_order["hbm_bytes_per_launch"]
+                traffic_source += f"; the pass under this run's block order (groups of {run.plan.block_group})"
         except Exception:
             traffic = traffic_source = None
 

@@ -127,6 +127,22 @@ def main():
         "calibration_note": "k_copy (known 1 207 762 944 B read with 16-B loads) read FETCH_SIZE 612 339 KB in the r01 "
                             "calibration pass (profiles/r01_calib_pmc_*.csv) -> factor 1.926 rather than 2",
     }
+    # the same command under the other block orders the plan's measurement may choose (the traffic differs: neighbouring
+    # XCD groups share x lines, which FETCH_SIZE counts once per L2 although the Infinity Cache serves the repeats)
+    by_order = {"32": {"hbm_bytes_per_launch": out["hbm_bytes_per_launch"], "ratio_to_algorithmic": out["ratio_to_algorithmic"]}}
+    for key, step in (("1", "headnat"), ("8", "head8"), ("64", "head64")):
+        try:
+            rdo = find(tag, f"pmc_{step}_FETCH_SIZE", "counter_collection.csv")
+            wro = find(tag, f"pmc_{step}_WRITE_SIZE", "counter_collection.csv")
+        except SystemExit:
+            continue
+        shutil.copy(rdo, os.path.join(prof, f"{rnd}_bench_pmc_order{key}_FETCH_SIZE.csv"))
+        shutil.copy(wro, os.path.join(prof, f"{rnd}_bench_pmc_order{key}_WRITE_SIZE.csv"))
+        fo, _ = counter_mean(rdo, "FETCH_SIZE")
+        wo, _ = counter_mean(wro, "WRITE_SIZE")
+        by_order[key] = {"hbm_bytes_per_launch": hbm(fo, wo), "ratio_to_algorithmic": round(hbm(fo, wo) / B_ALG, 4),
+                         "source": f"profiles/{rnd}_bench_pmc_order{key}_FETCH_SIZE.csv + ..._WRITE_SIZE.csv (HPCLA_BLOCK_ORDER={'natural' if key == '1' else key})"}
+    out["by_block_order"] = by_order
     wl = {}
     wl["poisson2d_spmv_int64"] = workload_single_kernel(
         tag, "i64", "spmv_rowblock_quad_kernel<long, false, false>", rnd, prof, "headline matrix, Int64 indices", 1_744_568_328,

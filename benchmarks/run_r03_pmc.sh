@@ -19,6 +19,9 @@ export HPCLA_BLOCK_ORDER=32
 step 300 gpurun_out/${TAG}_prof.log rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_prof -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-strong --no-extras --no-packed
 for c in FETCH_SIZE WRITE_SIZE; do
   step 300 gpurun_out/${TAG}_pmc_head_$c.log rocprofv3 --pmc $c --output-format csv -d gpurun_out/${TAG}_pmc_head_$c -- python3 bench.py $HEAD
+  HPCLA_BLOCK_ORDER=natural step 300 gpurun_out/${TAG}_pmc_headnat_$c.log rocprofv3 --pmc $c --output-format csv -d gpurun_out/${TAG}_pmc_headnat_$c -- python3 bench.py $HEAD
+  HPCLA_BLOCK_ORDER=8 step 300 gpurun_out/${TAG}_pmc_head8_$c.log rocprofv3 --pmc $c --output-format csv -d gpurun_out/${TAG}_pmc_head8_$c -- python3 bench.py $HEAD
+  HPCLA_BLOCK_ORDER=64 step 300 gpurun_out/${TAG}_pmc_head64_$c.log rocprofv3 --pmc $c --output-format csv -d gpurun_out/${TAG}_pmc_head64_$c -- python3 bench.py $HEAD
   step 300 gpurun_out/${TAG}_pmc_i64_$c.log rocprofv3 --pmc $c --output-format csv -d gpurun_out/${TAG}_pmc_i64_$c -- python3 bench.py $HEAD --index i64
   export HPCLA_BLOCK_ORDER=64
   step 300 gpurun_out/${TAG}_pmc_cg_$c.log rocprofv3 --pmc $c --output-format csv -d gpurun_out/${TAG}_pmc_cg_$c -- python3 bench.py --workload poisson3d_cg --steps 10 --warmup 5

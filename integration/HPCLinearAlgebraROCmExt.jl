@@ -209,6 +209,29 @@ function _device_plan(A::HPCSparseMatrix{T,Ti,B}, x::HPCVector{T,B}, plan) where
         A.backend.comm isa CommMPI &&
             _attach_halo_window(_rccl(A.backend.comm), halo[], A.backend.comm.comm, comm_size(A.backend.comm),
                                 (n_own, segments))
+        # Block order of this matrix's SpMV launches, MEASURED once here (hpcla_spmv_tune_block_order_*: 64 launches of
+        # the split-column SpMV into a scratch vector; the library keeps the fastest order registered for the rowptr
+        # array the launches use -- the 0-based copy, _rowptr0).  No reference counterpart: a performance setting only,
+        # every order gives the same bits.
+        if A.nrows_local > 0 && nnz > 0
+            scratch = similar(A.nzval, A.nrows_local)
+            gh = Ref{Ptr{Cvoid}}(C_NULL); ngh = Ref{Int64}(0)
+            halo[] != C_NULL &&
+                _check(@ccall(LIB.hpcla_halo_ghost_ptr(halo[]::Ptr{Cvoid}, gh::Ptr{Ptr{Cvoid}}, ngh::Ptr{Int64})::Cint), "hpcla_halo_ghost_ptr")
+            chosen = Ref{Cint}(1)
+            rp0 = _rowptr0(A)
+            if Ti === Int32
+                _check(@ccall(LIB.hpcla_spmv_tune_block_order_f64_i32(_ptr(rp0)::Ptr{Cvoid}, _ptr(split)::Ptr{Cvoid},
+                       _ptr(A.nzval)::Ptr{Cvoid}, _ptr(x.v)::Ptr{Cvoid}, gh[]::Ptr{Cvoid}, n_own::Int64, _ptr(scratch)::Ptr{Cvoid},
+                       A.nrows_local::Int64, nnz::Int64, 0::Cint, _stream()::Ptr{Cvoid}, chosen::Ptr{Cint})::Cint),
+                       "hpcla_spmv_tune_block_order_f64_i32")
+            else
+                _check(@ccall(LIB.hpcla_spmv_tune_block_order_f64_i64(_ptr(rp0)::Ptr{Cvoid}, _ptr(split)::Ptr{Cvoid},
+                       _ptr(A.nzval)::Ptr{Cvoid}, _ptr(x.v)::Ptr{Cvoid}, gh[]::Ptr{Cvoid}, n_own::Int64, _ptr(scratch)::Ptr{Cvoid},
+                       A.nrows_local::Int64, nnz::Int64, 0::Cint, _stream()::Ptr{Cvoid}, chosen::Ptr{Cint})::Cint),
+                       "hpcla_spmv_tune_block_order_f64_i64")
+            end
+        end
         ROCVectorPlan{Ti}(halo[], split, interior, boundary, n_own, segments)
     end
 end
@@ -513,6 +536,9 @@ function clear_rocm_plan_cache!()
     for d in values(_rocm_plans); d isa ROCVectorPlan && destroy(d.halo); end
     for st in values(_spmm_plans); destroy(st[1]); end
     for st in values(_rocm_exec); destroy(st[1]); end
+    for (k, v) in _rocm_plans       # the 0-based rowptr copies carry the block-order hints: removed before the arrays go
+        k isa Tuple && k[2] === :rowptr0 && @ccall LIB.hpcla_spmv_block_order_hint(_ptr(v)::Ptr{Cvoid}, 0::Cint)::Cint
+    end
     empty!(_rocm_plans); empty!(_spmm_plans); empty!(_rocm_exec); empty!(_merge_lists)
     return nothing
 end
