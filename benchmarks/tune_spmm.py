@@ -115,7 +115,8 @@ def main():
         if mode >= 200:
             return explib(mode - 200).hpcla_spmm_csr_f64_i32(A.rowptr_target.data_ptr(), cv.data_ptr(), A.nzval.data_ptr(), Bl.data_ptr(), k,
                                                              0, C.data_ptr(), k, 0, n, nnz, k, 0, s)
-        if mode == 100:
+        if mode == 100 or mode == 101:     # 101:G = the production library with HPCLA_SPMM_XCD_GROUP=G (experiment switch)
+            os.environ["HPCLA_SPMM_XCD_GROUP"] = str(param if mode == 101 else 0)
             return hp._capi.load().hpcla_spmm_csr_f64_i32(A.rowptr_target.data_ptr(), cv.data_ptr(), A.nzval.data_ptr(), Bl.data_ptr(), k,
                                                          0, C.data_ptr(), k, 0, n, nnz, k, 0, s)
         return tune.hpcla_tune_spmm(mode, A.rowptr_target.data_ptr(), cv.data_ptr(), A.nzval.data_ptr(), Bl.data_ptr(), C.data_ptr(),

@@ -213,7 +213,7 @@ __global__ __launch_bounds__(64 * LPR) void spmm_rowblock_vec_kernel(
     const I *__restrict__ rowptr, const I *__restrict__ colval, const double *__restrict__ nzval,
     const double *__restrict__ B_own, int64_t b_rs, const double *__restrict__ B_ghost, int64_t bg_rs,
     int64_t n_own, double *__restrict__ C, int64_t c_rs, int64_t nrows, int k, int base,
-    const int32_t *__restrict__ block_list, uint32_t nblocks, int accumulate)
+    const int32_t *__restrict__ block_list, uint32_t nblocks, int accumulate, int group_log2)
 {
     constexpr int TPB = 64 * LPR, KTILE = VCPL * LPR, VU = 2;
     static_assert(!HALF64 || LPR == 4, "the 64-contiguous-bytes lane mapping needs four lanes per row");
@@ -230,7 +230,20 @@ __global__ __launch_bounds__(64 * LPR) void spmm_rowblock_vec_kernel(
     const int tid = threadIdx.x;
     const int g = tid / LPR, l = tid % LPR;   // g = row of the block (0..63)
     const uint32_t b = blockIdx.x;
-    const int64_t blk = block_list ? (int64_t)block_list[b] : (int64_t)b;
+    // XCD-grouped order of a contiguous launch (spmv.hip xcd_group_index), an EXPERIMENT switch (HPCLA_SPMM_XCD_GROUP):
+    // on the 5-point matrix every group size from 32 to 1024 blocks loses (B rows of +-64-block neighbours land in other
+    // L2s: +2.5 ... +20 %), 8 is neutral; config 5's random pattern gains 2.6 % at 64-256 (profiles/r03_spmm_xcd_group.log).
+    // Default: the natural order.
+    const int glog = group_log2;
+    int64_t blk = (int64_t)b;
+    if (block_list) blk = (int64_t)block_list[b];
+    else if (glog > 0) {
+        const int64_t span = (int64_t)1 << (3 + glog), nb = (int64_t)nblocks;
+        if (blk < nb - (nb & (span - 1))) {
+            const int64_t xcd = blk & 7, q = blk >> 3;
+            blk = ((((q >> glog) << 3) + xcd) << glog) + (q & (((int64_t)1 << glog) - 1));
+        }
+    }
     const int64_t r0 = blk * RPB_MM;
     const int nr = (int)((nrows - r0) < RPB_MM ? (nrows - r0) : RPB_MM);
     const int64_t p0 = (int64_t)rowptr[r0] - base;
@@ -413,6 +426,14 @@ static inline int spmv_split_any(const int64_t *rp, const int64_t *cv, const dou
     return spmv_split_i64(rp, cv, nz, x, xg, n_own, y, nrows, nnz, base, nullptr, 0, stream, nullptr, -1);
 }
 
+static int spmm_group_log2()
+{
+    const char *e = getenv("HPCLA_SPMM_XCD_GROUP");          // re-read per launch: the tuning harness switches it between launches
+    int g = e ? atoi(e) : 0, l = 0;
+    while (g > 1) { g >>= 1; ++l; }
+    return l > 12 ? 12 : l;
+}
+
 template <typename I>
 static int spmm_launch(const I *rowptr, const I *colval, const double *nzval, const double *B_own,
                        int64_t b_rs, int64_t b_cs, const double *B_ghost, int64_t bg_rs,
@@ -485,7 +506,7 @@ static int spmm_launch(const I *rowptr, const I *colval, const double *nzval, co
 #define HPCLA_SPMM_VECT(SP, CH, H64, CST, K16F, LPRV, T2)                                                \
     spmm_rowblock_vec_kernel<I, SP, CH, H64, CST, K16F, LPRV, (T2)><<<grid, dim3(64 * LPRV), 0, s>>>(     \
         rowptr, colval, nzval, B_own, b_rs, SP ? B_ghost : nullptr, SP ? bg_rs : 0, SP ? n_own : 0, C, c_rs, \
-        nrows, k, index_base, block_list, (uint32_t)launch_blocks, accumulate)
+        nrows, k, index_base, block_list, (uint32_t)launch_blocks, accumulate, spmm_group_log2())
 #define HPCLA_SPMM_VEC1(SP, CH)                                                                          \
     do {                                                                                                \
         if (lpr == 2) { if (cstage) HPCLA_SPMM_VEC(SP, CH, false, true, false, 2); else HPCLA_SPMM_VEC(SP, CH, false, false, false, 2); } \
