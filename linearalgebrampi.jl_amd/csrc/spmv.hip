@@ -20,12 +20,15 @@
 // (+ x once).  Rows longer than CHUNK are handled by the chunk loop (the row's running sum is
 // carried in a register), so there is no row-length limit and no preprocessing.
 //
-// Measured choices (benchmarks/tune_spmv.py, 4096^2 Poisson, profiles/): 16-byte loads beat
-// element-per-lane loads; plain loads beat nontemporal ones; the natural blockIdx order beats an
-// XCD-sliced order (one moving window over the matrix keeps DRAM pages and the x window hot for all
-// 8 XCDs through the 256 MiB Infinity Cache); a software-pipelined persistent variant and a
-// branch-free variant (idle lanes re-reading quad 0) both lose to plain high occupancy
-// (8 workgroups per CU) with whole waves skipping the quads past the end of a row block.
+// Measured choices (benchmarks/tune_spmv.py, tune_spmv_lib.py; profiles/): 16-byte loads beat
+// element-per-lane loads; plain loads beat nontemporal ones (again in round 3: +10 ... +14 %); one
+// moving window over the matrix beats one slice per XCD (DRAM pages and the x window stay hot for all 8
+// XCDs through the 256 MiB Infinity Cache) -- WITHIN that window the row blocks are dealt to the XCDs in
+// groups whose size is measured per matrix at plan time (xcd_group_index, hpcla_spmv_tune_block_order_*);
+// a software-pipelined persistent variant loses to plain high occupancy (8 workgroups per CU) with whole
+// waves skipping the quads past the end of a row block.  Round 3: every pass but the matrix's very last
+// runs as straight-line wave passes (quad_pass_whole): the general pass's per-entry tail path forced a
+// vmcnt(0) between the two quads of every pass (profiles/r03_spmv_straight_line_pass.log).
 #include <stdlib.h>
 #include <string.h>
 
