@@ -683,7 +683,8 @@ def _run(args, budget):
             per_order = rec.get("by_block_order", {}).get(str(run.plan.block_group))
             if per_order:
                 traffic = per_order["hbm_bytes_per_launch"]
-                traffic_source += f"; the pass under this run's block order (groups of {run.plan.block_group})"
+                traffic_source += ("; the pass under this run's block order (" +
+                                   ("natural" if run.plan.block_group <= 1 else f"XCD groups of {run.plan.block_group} row blocks") + ")")
         except Exception:
             traffic = traffic_source = None
 
