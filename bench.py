@@ -576,6 +576,9 @@ def _run(args, budget):
                          "share a device for a functional rehearsal; its timings mean nothing)")
     torch.cuda.set_device(local_rank % ndev)
     budget.stage(f"rank {rank}/{world}: torch imported, device set")
+    if os.environ.get("HPCLA_BENCH_VERBOSE", "") == "1":
+        import faulthandler                      # diagnostics: where is a rank when a stage takes long?
+        faulthandler.dump_traceback_later(float(os.environ.get("HPCLA_BENCH_DUMP_S", "40")), repeat=True, file=sys.stderr)
 
     import hpcla_amd as hp
     from hpcla_amd import workloads as wl

@@ -43,6 +43,14 @@ def _stamp(msg):
         sys.stderr.flush()
 
 
+def _sync_stamp(msg):
+    """Verbose runs: synchronise the device, then stamp (which piece of GPU work does a stall sit in?)."""
+    if os.environ.get("HPCLA_BENCH_VERBOSE", "") == "1":
+        import torch
+        torch.cuda.synchronize()
+        _stamp(msg)
+
+
 def _sync_barrier(job, closing=False):
     job.barrier(device_only=closing)      # closing bracket of a timed region: device rendezvous only (bench.py Job)
 
@@ -271,18 +279,34 @@ def run_record(args, backend, rank, world, job):
         t0 = time.perf_counter()
         gen = torch.Generator(device=dev)
         gen.manual_seed(0xA11CE + rank)
-        _stamp("sprand: start")
+        # Ranks that SHARE a GPU (HPCLA_ALLOW_SHARED_GPU=1 rehearsals) generate one after the other: four processes'
+        # torch.sort calls (rocPRIM onesweep, decoupled look-back) running on one GPU at once made no visible progress for
+        # 40-300 s (all ranks inside the sort's synchronisation, GPU 100 % busy, no memory traffic; gpurun_out/r03_reh5.log).
+        # One process per GPU -- the real layout -- never has two sorts on one device.
+        take_turns = world > 1 and os.environ.get("HPCLA_ALLOW_SHARED_GPU", "") == "1"
+        for turn in range(rank if take_turns else 0):
+            job.barrier()
+        _sync_stamp("sprand: start (device idle)")
         counts = torch.poisson(torch.full((rows_loc,), mean_nnz, dtype=torch.float64, device=dev), generator=gen).to(torch.int64)
+        _sync_stamp("sprand: poisson counts")
         rowptr = torch.zeros(rows_loc + 1, dtype=torch.int64, device=dev)
         torch.cumsum(counts, 0, out=rowptr[1:])
         nnz = int(rowptr[-1].item())
+        _sync_stamp("sprand: cumsum")
         cols = torch.randint(0, ncols, (nnz,), generator=gen, device=dev, dtype=torch.int64)
+        _sync_stamp("sprand: randint")
         rowid = torch.repeat_interleave(torch.arange(rows_loc, device=dev, dtype=torch.int64), counts)
+        _sync_stamp("sprand: repeat_interleave")
         key = torch.sort(rowid * ncols + cols).values
+        _sync_stamp("sprand: sort")
         cols = key - rowid * ncols
         del key, rowid, counts
         vals = torch.rand(nnz, generator=gen, device=dev, dtype=torch.float64)
-        _stamp("sprand: entries generated")
+        if take_turns:
+            torch.cuda.synchronize()
+            for turn in range(rank, world):
+                job.barrier()
+        _sync_stamp("sprand: entries generated")
         A = hp.HPCSparseMatrix_local_device(rowptr, cols, vals, ncols, backend, col_window=(0, ncols - 1))
         del cols
         if os.environ.get("HPCLA_SPRAND_SPMV", "") == "1":
