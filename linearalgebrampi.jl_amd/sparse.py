@@ -263,7 +263,8 @@ class VectorPlan:
         want = _os.environ.get("HPCLA_BLOCK_ORDER", "auto")
         if want.isdigit():
             self.block_group = max(1, int(want))
-        elif want != "natural" and A.nrows_local > 0 and A.nnz > 0:
+        elif want != "natural" and A.nrows_local > 0 and A.nnz > 0 and int(x.v.numel()) >= max(self.n_own, 1):
+            # (x only has to be readable at the plan's own columns: the products are discarded; a width-0 SpMM probe is not)
             scratch = torch.empty(A.nrows_local, dtype=torch.float64, device=dev)
             ghost, _ng = self.ghost_tensor_ptr()
             chosen = ctypes.c_int(1)
