@@ -56,6 +56,10 @@ static int bench(int64_t N)
     HIPCHECK(hipMalloc((void **)&x, n * 8));
     HIPCHECK(hipMalloc((void **)&y, n * 8));
     CHECK(hpcla_fill_uniform_f64(x, 0, n, 0xC0FFEEULL, NULL));
+    /* plan time: the order in which the launches walk the row blocks, measured once for this matrix (y as scratch) */
+    int group = 0;
+    CHECK(hpcla_spmv_tune_block_order_f64_i32(rowptr, colval, vals, x, NULL, n, y, n, nnz, 0, NULL, &group));
+    printf("C-ABI bench: block order chosen by measurement: %s%d\n", group > 1 ? "XCD groups of " : "natural, group = ", group);
     for (int i = 0; i < 20; ++i) CHECK(hpcla_spmv_csr_f64_i32(rowptr, colval, vals, x, y, n, nnz, 0, NULL));
     hipEvent_t e0, e1;
     HIPCHECK(hipEventCreate(&e0)); HIPCHECK(hipEventCreate(&e1));
@@ -211,6 +215,24 @@ int main(int argc, char **argv)
     }
 
     /* error convention: negative status + message, never abort */
+    /* block-order hint: any power of two is a valid order (same y), anything else is refused */
+    {
+        double *yn, *yo;
+        HIPCHECK(hipMalloc((void **)&yn, n * 8));
+        HIPCHECK(hipMalloc((void **)&yo, n * 8));
+        CHECK(hpcla_spmv_csr_f64_i32(rowptr, colval, vals, x, yn, n, nnz, 0, NULL));
+        CHECK(hpcla_spmv_block_order_hint(rowptr, 4));
+        CHECK(hpcla_spmv_csr_f64_i32(rowptr, colval, vals, x, yo, n, nnz, 0, NULL));
+        CHECK(hpcla_spmv_block_order_hint(rowptr, 0));
+        double *hy = (double *)malloc(n * 8), *hyo = (double *)malloc(n * 8);
+        HIPCHECK(hipMemcpy(hy, yn, n * 8, hipMemcpyDeviceToHost));
+        HIPCHECK(hipMemcpy(hyo, yo, n * 8, hipMemcpyDeviceToHost));
+        if (memcmp(hy, hyo, n * 8) != 0) { fprintf(stderr, "grouped block order changed y\n"); return 1; }
+        if (hpcla_spmv_block_order_hint(rowptr, 3) != HPCLA_ERR_INVALID) { fprintf(stderr, "bad group accepted\n"); return 1; }
+        free(hy); free(hyo);
+        HIPCHECK(hipFree(yn)); HIPCHECK(hipFree(yo));
+        printf("block-order hint: same bits under groups of 4\n");
+    }
     if (hpcla_spmv_csr_f64_i32(NULL, NULL, NULL, NULL, NULL, 5, 5, 0, NULL) != HPCLA_ERR_INVALID ||
         strlen(hpcla_last_error()) == 0) { fprintf(stderr, "error convention broken\n"); return 1; }
     CHECK(hpcla_comm_destroy(comm));
