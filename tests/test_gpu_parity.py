@@ -1002,6 +1002,45 @@ def test_spmv_randomised_structures(hp, orc, gpu_backend_i32):
         np.testing.assert_array_equal(got, want, err_msg=f"trial {trial} kind {kind} nrows {nrows} nnz {nnz}")
 
 
+@pytest.mark.parametrize("Ti", [np.int32, np.int64])
+def test_spmv_pass_boundaries_of_the_straight_line_kernel(hp, orc, gpu_backend_i32, Ti):
+    """The quad kernel's wave passes switch on the entry count of a 256-row block: waves with one quad / two quads /
+    none, full 2048-entry passes followed by a short one, and the entry-by-entry pass for the last quad of the MATRIX
+    when nnz is not a multiple of 4.  Block totals straddling every one of those limits, every nnz mod 4, split-column
+    entry included."""
+    import torch
+    rng = np.random.default_rng(77)
+    sfx = "i32" if Ti == np.int32 else "i64"
+    totals = [0, 1, 3, 4, 5, 255, 256, 257, 1020, 1023, 1024, 1025, 1027, 1280, 2044, 2047, 2048, 2049, 2052, 3071, 3072, 4095,
+              4096, 4097, 6143, 6150]
+    for t0 in totals:
+        for t1 in (t0, 7, 0):
+            lens = np.zeros(512, dtype=np.int64)
+            for blk, tot in enumerate((t0, t1)):
+                cuts = np.sort(rng.integers(0, tot + 1, size=255))
+                lens[blk * 256:(blk + 1) * 256] = np.diff(np.concatenate([[0], cuts, [tot]]))
+            rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+            nnz = int(rowptr[-1])
+            ncols = 3000
+            cols = rng.integers(0, ncols, size=nnz)
+            rowid = np.repeat(np.arange(512), lens)
+            cols = cols[np.lexsort((cols, rowid))].astype(np.int64)
+            vals = rng.standard_normal(nnz)
+            x = rng.standard_normal(ncols)
+            want = orc.spmv(rowptr.astype(Ti), cols.astype(Ti), vals, x)
+            got = _raw_spmv(hp, rowptr, cols, vals, x, Ti)
+            np.testing.assert_array_equal(got, want, err_msg=f"block totals {t0}, {t1}")
+            # the split-column kernel: columns >= n_own read the ghost segment
+            n_own = 1700
+            rp, cv, nz = _t(rowptr.astype(Ti)), _t(cols.astype(Ti)), _t(vals)
+            xo, xg = _t(x[:n_own]), _t(x[n_own:])
+            y = torch.full((512,), float("nan"), dtype=torch.float64, device="cuda")
+            hp._capi.call(f"hpcla_spmv_split_f64_{sfx}", rp.data_ptr(), cv.data_ptr() if nnz else None, nz.data_ptr() if nnz else None,
+                          xo.data_ptr(), xg.data_ptr(), n_own, y.data_ptr(), 512, nnz, 0, None, 0,
+                          torch.cuda.current_stream().cuda_stream)
+            np.testing.assert_array_equal(y.cpu().numpy(), want, err_msg=f"split, block totals {t0}, {t1}")
+
+
 def test_spmv_x_partition_differs_from_row_partition(hp, orc, gpu_backend_i32):
     """A*x accepts any partition of x (the plan is keyed on it): simulated ranks
     with a non-uniform x partition, split-column map + ghost segment, bit-exact per rank."""
