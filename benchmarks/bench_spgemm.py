@@ -19,7 +19,10 @@ def main():
     from hpcla_amd import workloads as wl
     from hpcla_amd.matmat import clear_matrix_plan_cache
     b = hp.backend_rocm_serial(np.float64, np.int32)
-    for N in (100, 1000, 2048):
+    for N, lists in [(N, m) for N in (100, 1000, 2048) for m in ("1", "0")]:
+        # lists = "1": repeated products run on the per-entry product lists (hpcla_spgemm_numeric_mapped_f64, built by
+        # the second product); "0": on the expand-sort-combine / hash kernels every time
+        os.environ["HPCLA_SPGEMM_MAP"] = lists
         n = N * N
         rowptr, colidx, vals = wl.poisson2d_rows(N, N, 0, n)
         A = hp.HPCSparseMatrix_local(rowptr, colidx, vals, n, b)
@@ -27,6 +30,10 @@ def main():
         C = A @ A
         torch.cuda.synchronize()
         first = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        C = A @ A
+        torch.cuda.synchronize()
+        second = time.perf_counter() - t0
         ts = []
         for _ in range(30):
             torch.cuda.synchronize()
@@ -40,7 +47,8 @@ def main():
             C = A @ A
         ev1.record()
         torch.cuda.synchronize()
-        print(f"laplacian2d n={n:9d} nnz(A)={A.nnz:10d} nnz(A*A)={C.nnz:11d}  first {first*1e3:9.3f} ms   "
+        print(f"laplacian2d n={n:9d} nnz(A)={A.nnz:10d} nnz(A*A)={C.nnz:11d}  {'product lists' if lists == '1' else 'numeric kernels'}: "
+              f"first {first*1e3:9.3f} ms   second {second*1e3:9.3f} ms   "
               f"repeat median {np.median(ts)*1e3:8.3f} ms (min {np.min(ts)*1e3:.3f})   device/stream {ev0.elapsed_time(ev1)/20:8.3f} ms")
         clear_matrix_plan_cache()
         hp.clear_plan_cache()

@@ -193,6 +193,14 @@ int hpcla_spgemm_numeric_i64(int bin, const int64_t *a_rowptr, const int64_t *a_
 int hpcla_spgemm_compact(const int64_t *c_rowptr, const int64_t *ub_prefix, int64_t nrows,
                          const int64_t *c_col_tmp, const double *c_val_tmp, int64_t *c_col, double *c_val,
                          void *stream);
+/* Repeated product on a cached structure (the reference recomputes `plan.AT * A_csc` with SparseArrays every time,
+ * src/sparse.jl:1011; its MatrixPlan caches the gathering only): result entry e is the sum, in list order, of
+ * g_val[pairs[2t + 1]] * a_val[pairs[2t]] for t in [pair_ptr[e], pair_ptr[e + 1]) -- the first product, then the others
+ * added one by one (ascending k when the lists are built that way: the bits of hpcla_spgemm_numeric_*).  `pair_ptr` has
+ * nnz_c + 1 entries, int32 or int64 (`ptr_is_i64`); `pairs` is 8-byte aligned.  One streaming pass: 8 B per product. */
+int hpcla_spgemm_numeric_mapped_f64(const void *pair_ptr, int ptr_is_i64, const int32_t *pairs,
+                                    const double *a_val, const double *g_val, double *c_val, int64_t nnz_c,
+                                    void *stream);
 
 /* ---- SpMM:  replaces A*B column loop (src/sparse.jl:2391-2413) -------------------------------
  * C[r,c] = sum_j nzval[j] * B[colval[j], c], c in [0,k): one pass over A for all k columns, each

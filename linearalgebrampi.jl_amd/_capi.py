@@ -123,6 +123,7 @@ _SIGNATURES = {
     "hpcla_spgemm_numeric_i32": [_i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp],
     "hpcla_spgemm_numeric_i64": [_i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp],
     "hpcla_spgemm_compact": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp],
+    "hpcla_spgemm_numeric_mapped_f64": [_vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp],
     "hpcla_packed_create_i32": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp, _i64, _vp],
     "hpcla_packed_destroy": [_vp],
     "hpcla_packed_info": [_vp, _vp, _vp],

@@ -286,6 +286,76 @@ __global__ __launch_bounds__(256) void spgemm_compact_kernel(const int64_t *__re
     }
 }
 
+// Repeated products on a KNOWN structure (the MatrixPlan caches it): every result entry e owns the list of its products
+// -- pairs (index into A's values, index into the gathered B values), in ascending k = ascending A entry -- built once at
+// plan level (matmat.py: expand, stable sort by (row, column), run lengths).  The numeric product is then one streaming
+// pass: 8 B per product + 4 or 8 B + 8 B per result entry, the two value gathers mostly from L2; no expansion, no sort
+// network, no ballot ranking.  Each entry is the first product plus the others added one by one in list order: the
+// accumulation of the expand-sort-combine and hash kernels above, so the same bits (tested).
+template <int R>
+__device__ __forceinline__ void mapped_pass(const int2 *__restrict__ src, int n, const double *__restrict__ a_val,
+                                            const double *__restrict__ g_val, double *s_prod, int tid)
+{
+    int2 q[R];
+    double av[R], gv[R];
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+        const int idx = u * 256 + tid;
+        q[u] = src[idx < n ? idx : n - 1];
+    }
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+        av[u] = a_val[q[u].x];
+        gv[u] = g_val[q[u].y];
+    }
+#pragma unroll
+    for (int u = 0; u < R; ++u) s_prod[u * 256 + tid] = gv[u] * av[u];
+}
+
+template <typename P>
+__global__ __launch_bounds__(256) void spgemm_mapped_kernel(const P *__restrict__ pair_ptr, const int2 *__restrict__ pairs,
+                                                            const double *__restrict__ a_val,
+                                                            const double *__restrict__ g_val,
+                                                            double *__restrict__ c_val, int64_t nnz_c)
+{
+    // The SpMV kernel's shape (spmv.hip) with result entries as rows and products as nonzeros: a workgroup owns 256
+    // consecutive result entries, whose products are ONE contiguous range of the pair list; the range is streamed with
+    // coalesced 8-byte loads (up to four pairs per lane per pass, all loads first, then the value gathers), every
+    // product is parked in LDS, then thread t adds up entry t's products in list order.  A lane past the pass's end
+    // re-reads the last pair (one broadcast line) and parks a product nobody reads: straight-line code.
+    constexpr int EPB = 256, MCHUNK = EPB * 4;
+    __shared__ double s_prod[MCHUNK];
+    const int tid = threadIdx.x;
+    const int64_t e0 = (int64_t)blockIdx.x * EPB;
+    const int nr = (int)((nnz_c - e0) < EPB ? (nnz_c - e0) : EPB);
+    const int64_t p0 = (int64_t)pair_ptr[e0], p1 = (int64_t)pair_ptr[e0 + nr];
+    P rlo = 0, rhi = 0;                                // used in the sum phase: the load runs under the stream
+    if (tid < nr) {
+        rlo = pair_ptr[e0 + tid];
+        rhi = pair_ptr[e0 + tid + 1];
+    }
+    const int64_t total = p1 - p0;
+    double acc = 0.0;
+    for (int64_t c = 0; c < total; c += MCHUNK) {
+        const int n = (int)((total - c) < MCHUNK ? (total - c) : MCHUNK);
+        const int2 *src = pairs + p0 + c;
+        // as many rounds of 256 products as the pass holds (workgroup-uniform), each variant straight-line
+        if (n > 3 * EPB) mapped_pass<4>(src, n, a_val, g_val, s_prod, tid);
+        else if (n > 2 * EPB) mapped_pass<3>(src, n, a_val, g_val, s_prod, tid);
+        else if (n > EPB) mapped_pass<2>(src, n, a_val, g_val, s_prod, tid);
+        else mapped_pass<1>(src, n, a_val, g_val, s_prod, tid);
+        __syncthreads();
+        {
+            const int64_t lo = tid < nr ? (int64_t)rlo - p0 : 0, hi = tid < nr ? (int64_t)rhi - p0 : 0;
+            const int64_t a = lo > c ? lo : c;
+            const int64_t e = hi < c + n ? hi : c + n;
+            for (int64_t j = a; j < e; ++j) acc = (j == lo) ? s_prod[j - c] : acc + s_prod[j - c];
+        }
+        __syncthreads();
+    }
+    if (tid < nr) c_val[e0 + tid] = acc;
+}
+
 template <typename I>
 static int numeric_launch(int bin, const I *a_rowptr, const I *a_col, const double *a_val, int base,
                           const int64_t *g_rowptr, const int64_t *g_col, const double *g_val,
@@ -349,6 +419,29 @@ HPCLA_API int64_t hpcla_spgemm_bin_cap(int bin)
     }
 SPGEMM_API(i32, int32_t)
 SPGEMM_API(i64, int64_t)
+
+HPCLA_API int hpcla_spgemm_numeric_mapped_f64(const void *pair_ptr, int ptr_is_i64, const int32_t *pairs,
+                                              const double *a_val, const double *g_val, double *c_val,
+                                              int64_t nnz_c, void *stream)
+{
+    if (nnz_c < 0) return set_error(HPCLA_ERR_INVALID, "spgemm_numeric_mapped: negative size");
+    if (nnz_c == 0) return HPCLA_OK;
+    if (!pair_ptr || !pairs || !a_val || !g_val || !c_val)
+        return set_error(HPCLA_ERR_INVALID, "spgemm_numeric_mapped: null pointer");
+    if (reinterpret_cast<uintptr_t>(pairs) & 7)
+        return set_error(HPCLA_ERR_INVALID, "spgemm_numeric_mapped: the pair list must be 8-byte aligned");
+    const int64_t blocks = (nnz_c + 255) / 256;
+    HPCLA_CHECK_GRID(blocks, "spgemm_numeric_mapped");
+    const int2 *pr = reinterpret_cast<const int2 *>(pairs);
+    if (ptr_is_i64)
+        spgemm_mapped_kernel<int64_t><<<(uint32_t)blocks, 256, 0, as_stream(stream)>>>(
+            static_cast<const int64_t *>(pair_ptr), pr, a_val, g_val, c_val, nnz_c);
+    else
+        spgemm_mapped_kernel<int32_t><<<(uint32_t)blocks, 256, 0, as_stream(stream)>>>(
+            static_cast<const int32_t *>(pair_ptr), pr, a_val, g_val, c_val, nnz_c);
+    HPCLA_CHECK_LAUNCH();
+    return HPCLA_OK;
+}
 
 HPCLA_API int hpcla_spgemm_compact(const int64_t *c_rowptr, const int64_t *ub_prefix, int64_t nrows,
                                    const int64_t *c_col_tmp, const double *c_val_tmp, int64_t *c_col,

@@ -17,6 +17,7 @@ the reference's order (bit-identical).  The result's column space is compressed 
 from __future__ import annotations
 
 import ctypes
+import os
 from dataclasses import dataclass
 from typing import Dict, List
 
@@ -126,6 +127,10 @@ class MatrixPlan:
         self.cache = {}
         self.halo = ctypes.c_void_p()
         self.has_halo = bool(h.send_rank_ids or h.recv_rank_ids)
+        # every stored entry of B is needed, in B's own order, and none from another rank (A*A on one rank, say): the
+        # gathered value array IS B.nzval -- no copy per product
+        self.identity = (not self.has_halo and len(h.local_src) == self.nnz_g and int(h.local_dst_start) == 0 and
+                         bool(np.array_equal(h.local_src, np.arange(self.nnz_g, dtype=h.local_src.dtype))))
         if self.has_halo:
             n_send, n_recv = len(h.send_rank_ids), len(h.recv_rank_ids)
             send_ranks = (ctypes.c_int32 * max(n_send, 1))(*h.send_rank_ids)
@@ -145,6 +150,8 @@ class MatrixPlan:
         torch = _torch()
         h = self.host
         s = current_stream_ptr()
+        if self.identity and int(B.nzval.numel()) == self.nnz_g:
+            return B.nzval
         g_val = torch.empty(self.nnz_g, dtype=torch.float64, device=B.nzval.device)
         if self.has_halo:
             _capi.call("hpcla_halo_begin", self.halo, dptr(B.nzval), s)
@@ -185,6 +192,48 @@ def clear_matrix_plan_cache() -> None:
     for p in _plan_cache.values():
         p.destroy()
     _plan_cache.clear()
+
+
+def build_product_map(A, g_rowptr, g_col, c_rowptr64, c_col, max_products: int):
+    """Per result entry, the list of its products as (index into A.nzval, index into the gathered B values), in
+    ascending A entry (= ascending k, the accumulation order of the numeric kernels): expand every A entry over its B
+    row, STABLE sort by (row, result column), run lengths.  Device tensor ops (plan-time plumbing, once per structure);
+    returns (pair_ptr, pairs int32 [n, 2], ptr_is_i64) or None when the lists would not fit ``max_products`` / int32, or
+    -- a safety net -- when the runs do not reproduce the result structure the numeric kernels produced."""
+    torch = _torch()
+    dev = A.backend.torch_device
+    nrows, nnz_a = A.nrows_local, A.nnz
+    nnz_c = int(c_col.numel())
+    if nnz_a == 0 or nnz_c == 0 or nnz_a > np.iinfo(np.int32).max or int(g_col.numel()) > np.iinfo(np.int32).max:
+        return None
+    a_rp = A.rowptr_target.to(torch.int64)
+    k = A.colval_target().to(torch.int64)
+    starts = g_rowptr[k]
+    lens = g_rowptr[k + 1] - starts
+    total = int(lens.sum().item())
+    if total == 0 or total > max_products:
+        return None
+    ai = torch.repeat_interleave(torch.arange(nnz_a, device=dev, dtype=torch.int64), lens)
+    excl = torch.cumsum(lens, 0) - lens
+    gi = starts[ai] + (torch.arange(total, device=dev, dtype=torch.int64) - excl[ai])
+    a_row = torch.repeat_interleave(torch.arange(nrows, device=dev, dtype=torch.int64), a_rp[1:] - a_rp[:-1])
+    width = int(max(int(g_col.max().item()), int(c_col.max().item())) + 1)
+    key = a_row[ai] * width + g_col[gi]
+    del a_row, excl, starts, lens
+    key, perm = torch.sort(key, stable=True)
+    uniq, counts = torch.unique_consecutive(key, return_counts=True)
+    del key
+    c_row = torch.repeat_interleave(torch.arange(nrows, device=dev, dtype=torch.int64), c_rowptr64[1:] - c_rowptr64[:-1])
+    if int(uniq.numel()) != nnz_c or not bool(torch.equal(uniq, c_row * width + c_col)):
+        return None
+    del uniq, c_row
+    ptr64 = total > np.iinfo(np.int32).max
+    ptr = torch.zeros(nnz_c + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(counts, 0, out=ptr[1:])
+    if not ptr64:
+        ptr = ptr.to(torch.int32)
+    pairs = torch.stack([ai[perm], gi[perm]], dim=1).to(torch.int32).contiguous()
+    return ptr, pairs, ptr64
 
 
 def spgemm_local(A, g_rowptr, g_col, g_val, ncols_global: int, col_partition, cache=None):
@@ -247,7 +296,9 @@ def spgemm_local(A, g_rowptr, g_col, g_val, ncols_global: int, col_partition, ca
                    dptr(sym["c_val_tmp"]), dptr(c_col), dptr(c_val), s)
         C = HPCSparseMatrix_local_device(c_rowptr, c_col, c_val, ncols_global, A.backend,
                                          col_partition=col_partition)
-        sym["result"] = dict(c_rowptr64=c_rowptr, nnz=nnz_c, template=C, scratch_col=c_col)
+        # c_col64: the result's global columns (for the product lists); scratch_col: the same array, where the numeric
+        # kernels rewrite the same columns on a repeated product without the lists
+        sym["result"] = dict(c_rowptr64=c_rowptr, nnz=nnz_c, template=C, scratch_col=c_col, c_col64=c_col)
         sym["c_col_tmp"] = sym["c_val_tmp"] = sym["ub_prefix"] = None      # upper-bound slots: first product only
         return C
     # structure known: only the values are new (same structure arrays, like conj(A), src/sparse.jl:2261-2270)
@@ -256,7 +307,20 @@ def spgemm_local(A, g_rowptr, g_col, g_val, ncols_global: int, col_partition, ca
     # the rows' final offsets are known, so the numeric kernels write the compacted arrays directly
     # (offsets = the result's rowptr): no upper-bound slots, no compaction pass
     c_val = torch.empty(res["nnz"], dtype=torch.float64, device=dev)
-    numeric(res["c_rowptr64"], res["scratch_col"], c_val)
+    # second product on this structure: build the per-entry product lists once (HPCLA_SPGEMM_MAP=0: never; the lists
+    # cost 8 B per product of device memory, HPCLA_SPGEMM_MAP_MAX products at most, default 4e8); from then on the
+    # numeric product is one streaming pass (hpcla_spgemm_numeric_mapped_f64), same bits
+    if "map" not in res:
+        res["map"] = None
+        if os.environ.get("HPCLA_SPGEMM_MAP", "1") != "0" and res["nnz"] > 0:
+            res["map"] = build_product_map(A, g_rowptr, g_col, res["c_rowptr64"], res["c_col64"],
+                                           int(float(os.environ.get("HPCLA_SPGEMM_MAP_MAX", "4e8"))))
+    if res["map"] is not None:
+        ptr, pairs, ptr64 = res["map"]
+        _capi.call("hpcla_spgemm_numeric_mapped_f64", dptr(ptr), 1 if ptr64 else 0, dptr(pairs), dptr(A.nzval), dptr(g_val),
+                   dptr(c_val), res["nnz"], s)
+    else:
+        numeric(res["c_rowptr64"], res["scratch_col"], c_val)
     C = HPCSparseMatrix(T.row_partition, T.col_partition, T.col_indices, T._rowptr, T._colval, c_val,
                         T.rowptr_target, A.backend)
     C._colval_target = T._colval_target

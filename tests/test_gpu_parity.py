@@ -1193,6 +1193,25 @@ def test_spgemm_bit_exact_vs_oracle(hp, orc, gpu_backend_i32, gpu_backend_i64, w
         np.testing.assert_array_equal(rp_2, w_rp)
         np.testing.assert_array_equal(col_2, w_col)
         np.testing.assert_array_equal(val_2, 2.0 * w_val)
+        # that second product built the per-entry product lists (hpcla_spgemm_numeric_mapped_f64); a third and fourth
+        # product, with new values in B and then in both, run on them: still the oracle's bits (scaling by a power
+        # of two is exact in every product and every sum)
+        B4 = hp.HPCSparseMatrix_local(Br.rowptr, Br.colidx, Br.vals * 4.0, Br.ncols_global, b)
+        rp_3, col_3, val_3 = _csr_of(A @ B4)
+        np.testing.assert_array_equal(col_3, w_col)
+        np.testing.assert_array_equal(val_3, 4.0 * w_val)
+        np.testing.assert_array_equal(_csr_of(A2 @ B4)[2], 8.0 * w_val)
+        from hpcla_amd.matmat import get_matrix_plan
+        res = get_matrix_plan(A, B).cache["symbolic"]["result"]
+        assert res.get("map") is not None or res["nnz"] == 0, "the product lists were not built"
+        os.environ["HPCLA_SPGEMM_MAP"] = "0"                       # and without them (the numeric kernels): same bits
+        try:
+            from hpcla_amd.matmat import clear_matrix_plan_cache as _clear
+            _clear()
+            _csr_of(A @ B)
+            np.testing.assert_array_equal(_csr_of(A2 @ B4)[2], 8.0 * w_val)
+        finally:
+            del os.environ["HPCLA_SPGEMM_MAP"]
         Cs = (sp.csr_matrix((Ar.vals, Ar.colidx, Ar.rowptr), shape=(Ar.nrows, Ar.ncols_global)) @
               sp.csr_matrix((Br.vals, Br.colidx, Br.rowptr), shape=(Br.nrows, Br.ncols_global))).tocsr()
         got = sp.csr_matrix((val_c, col_c, rp_c), shape=Cs.shape)
