@@ -155,6 +155,60 @@ __global__ __launch_bounds__(GEMVT_THREADS) void gemv_t_stage1(const double *__r
     }
 }
 
+// The same with 16-byte loads (ncols and lda even, A 16-byte aligned): a lane owns TWO adjacent columns, a wavefront
+// covers up to 128 columns x (128/W) rows per pass -- 8-byte loads run at 0.54-0.70 of the 16-byte rate
+// (MI355X_MICROARCH.md), which is what the scalar form measured (0.53-0.66 of peak against 0.66-0.74 for A*x).
+__global__ __launch_bounds__(GEMVT_THREADS) void gemv_t_stage1_vec2(const double *__restrict__ A, int64_t lda,
+                                                                    int64_t nrows, int64_t ncols,
+                                                                    const double *__restrict__ x, int W,
+                                                                    int64_t rows_per_chunk,
+                                                                    double *__restrict__ partial)
+{
+    typedef double vd2 __attribute__((ext_vector_type(2)));
+    __shared__ vd2 red[GEMVT_THREADS];
+    const int tid = threadIdx.x;
+    const int WL = W / 2;                // lanes per row
+    const int c = tid % WL;              // column PAIR within the tile
+    const int rl = tid / WL;
+    const int rstep = GEMVT_THREADS / WL;
+    const int64_t col = (int64_t)blockIdx.x * W + 2 * c;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
+    const int64_t r1 = min(nrows, r0 + rows_per_chunk);
+    vd2 acc = (vd2)(0.0);
+    if (col < ncols) {
+        int64_t r = r0 + rl;
+        for (; r + 7 * rstep < r1; r += 8 * rstep) {      // 8 independent 16-byte loads in flight
+            vd2 av[8];
+            double xv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) av[u] = *reinterpret_cast<const vd2 *>(A + (r + (int64_t)u * rstep) * lda + col);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xv[u] = x[r + (int64_t)u * rstep];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                acc.x += av[u].x * xv[u];
+                acc.y += av[u].y * xv[u];
+            }
+        }
+        for (; r < r1; r += rstep) {
+            const vd2 a = *reinterpret_cast<const vd2 *>(A + r * lda + col);
+            const double xr = x[r];
+            acc.x += a.x * xr;
+            acc.y += a.y * xr;
+        }
+    }
+    red[tid] = acc;
+    __syncthreads();
+    if (tid < WL && col < ncols) {
+        vd2 s = red[tid];
+        for (int k = 1; k < rstep; ++k) {                 // ascending row phase
+            s.x += red[k * WL + tid].x;
+            s.y += red[k * WL + tid].y;
+        }
+        *reinterpret_cast<vd2 *>(partial + (int64_t)blockIdx.y * ncols + col) = s;
+    }
+}
+
 // stage 2: column sums of partial[nchunks][ncols].  A workgroup owns CT = min(64, W) columns; its
 // 1024/CT row phases each sum every (1024/CT)-th chunk in ascending order (8 loads in flight), then
 // the phases are added in ascending order through LDS -- a fixed tree, so the result is deterministic.
@@ -195,7 +249,10 @@ static int64_t gemv_t_rows_per_chunk(int64_t nrows, int64_t ncols)
     int W = 1;
     while (W < 64 && W < ncols) W <<= 1;
     const int64_t tiles = (ncols + W - 1) / W;
-    int64_t want_chunks = (1024 + tiles - 1) / (tiles > 0 ? tiles : 1);   // ~4 workgroups per CU in stage 1
+    // ~8 workgroups per CU in stage 1; half that for very narrow blocks, whose chunks would shrink to a few dozen KB
+    // (1 000 000 x 16: 0.030 ms with 1024 chunks, 0.034 with 2048)
+    const int64_t target = ncols <= 32 ? 1024 : 2048;
+    int64_t want_chunks = (target + tiles - 1) / (tiles > 0 ? tiles : 1);
     if (want_chunks < 1) want_chunks = 1;
     int64_t rpc = (nrows + want_chunks - 1) / want_chunks;
     if (rpc < 64) rpc = 64;
@@ -232,8 +289,18 @@ HPCLA_API int hpcla_gemv_t_rowmajor_f64(const double *A, int64_t lda, int64_t nr
     const int64_t nchunks = (nrows + rpc - 1) / rpc;
     const int64_t tiles = (ncols + W - 1) / W;
     if (nchunks > 65535 || tiles > 0x7fffffff) return set_error(HPCLA_ERR_UNSUPPORTED, "gemv_t: grid too large");
-    gemv_t_stage1<<<dim3((uint32_t)tiles, (uint32_t)nchunks), GEMVT_THREADS, 0, s>>>(
-        A, lda, nrows, ncols, x, W, rpc, static_cast<double *>(work));
+    const bool vec2 = ncols % 2 == 0 && lda % 2 == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0 &&
+                      (reinterpret_cast<uintptr_t>(work) & 15) == 0;
+    if (vec2) {
+        int W2 = 2;
+        while (W2 < 128 && W2 < ncols) W2 <<= 1;
+        const int64_t tiles2 = (ncols + W2 - 1) / W2;
+        gemv_t_stage1_vec2<<<dim3((uint32_t)tiles2, (uint32_t)nchunks), GEMVT_THREADS, 0, s>>>(
+            A, lda, nrows, ncols, x, W2, rpc, static_cast<double *>(work));
+    } else {
+        gemv_t_stage1<<<dim3((uint32_t)tiles, (uint32_t)nchunks), GEMVT_THREADS, 0, s>>>(
+            A, lda, nrows, ncols, x, W, rpc, static_cast<double *>(work));
+    }
     HPCLA_CHECK_LAUNCH();
     const int CT = W < 64 ? W : 64;
     gemv_t_stage2<<<(uint32_t)((ncols + CT - 1) / CT), GEMVT2_THREADS, 0, s>>>(
