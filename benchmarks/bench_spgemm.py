@@ -21,7 +21,7 @@ def main():
     b = hp.backend_rocm_serial(np.float64, np.int32)
     for N, lists in [(N, m) for N in (100, 1000, 2048) for m in ("1", "0")]:
         # lists = "1": repeated products run on the per-entry product lists (hpcla_spgemm_numeric_mapped_f64, built by
-        # the second product); "0": on the expand-sort-combine / hash kernels every time
+        # the third product); "0": on the expand-sort-combine / hash kernels every time
         os.environ["HPCLA_SPGEMM_MAP"] = lists
         n = N * N
         rowptr, colidx, vals = wl.poisson2d_rows(N, N, 0, n)

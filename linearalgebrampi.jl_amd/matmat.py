@@ -307,15 +307,16 @@ def spgemm_local(A, g_rowptr, g_col, g_val, ncols_global: int, col_partition, ca
     # the rows' final offsets are known, so the numeric kernels write the compacted arrays directly
     # (offsets = the result's rowptr): no upper-bound slots, no compaction pass
     c_val = torch.empty(res["nnz"], dtype=torch.float64, device=dev)
-    # second product on this structure: build the per-entry product lists once (HPCLA_SPGEMM_MAP=0: never; the lists
+    # third product on this structure: build the per-entry product lists once (HPCLA_SPGEMM_MAP=0: never; the lists
     # cost 8 B per product of device memory, HPCLA_SPGEMM_MAP_MAX products at most, default 4e8); from then on the
     # numeric product is one streaming pass (hpcla_spgemm_numeric_mapped_f64), same bits
-    if "map" not in res:
+    res["repeats"] = res.get("repeats", 0) + 1
+    if "map" not in res and res["repeats"] >= 2:        # a structure multiplied a third time will be multiplied again
         res["map"] = None
         if os.environ.get("HPCLA_SPGEMM_MAP", "1") != "0" and res["nnz"] > 0:
             res["map"] = build_product_map(A, g_rowptr, g_col, res["c_rowptr64"], res["c_col64"],
                                            int(float(os.environ.get("HPCLA_SPGEMM_MAP_MAX", "4e8"))))
-    if res["map"] is not None:
+    if res.get("map") is not None:
         ptr, pairs, ptr64 = res["map"]
         _capi.call("hpcla_spgemm_numeric_mapped_f64", dptr(ptr), 1 if ptr64 else 0, dptr(pairs), dptr(A.nzval), dptr(g_val),
                    dptr(c_val), res["nnz"], s)

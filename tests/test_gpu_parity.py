@@ -1193,9 +1193,9 @@ def test_spgemm_bit_exact_vs_oracle(hp, orc, gpu_backend_i32, gpu_backend_i64, w
         np.testing.assert_array_equal(rp_2, w_rp)
         np.testing.assert_array_equal(col_2, w_col)
         np.testing.assert_array_equal(val_2, 2.0 * w_val)
-        # that second product built the per-entry product lists (hpcla_spgemm_numeric_mapped_f64); a third and fourth
-        # product, with new values in B and then in both, run on them: still the oracle's bits (scaling by a power
-        # of two is exact in every product and every sum)
+        # the third product on a structure builds the per-entry product lists (hpcla_spgemm_numeric_mapped_f64) and
+        # runs on them, like every later one: new values in B, then in both -- still the oracle's bits (scaling by a
+        # power of two is exact in every product and every sum)
         B4 = hp.HPCSparseMatrix_local(Br.rowptr, Br.colidx, Br.vals * 4.0, Br.ncols_global, b)
         rp_3, col_3, val_3 = _csr_of(A @ B4)
         np.testing.assert_array_equal(col_3, w_col)
