@@ -268,8 +268,14 @@ class VectorPlan:
             scratch = torch.empty(A.nrows_local, dtype=torch.float64, device=dev)
             ghost, _ng = self.ghost_tensor_ptr()
             chosen = ctypes.c_int(1)
-            _capi.call(f"hpcla_spmv_tune_block_order_f64_{sfx}", dptr(A.rowptr_target), dptr(self.colval_split), dptr(A.nzval),
-                       dptr(x.v), ghost, self.n_own, dptr(scratch), A.nrows_local, A.nnz, 0, s, ctypes.byref(chosen))
+            try:
+                _capi.call(f"hpcla_spmv_tune_block_order_f64_{sfx}", dptr(A.rowptr_target), dptr(self.colval_split),
+                           dptr(A.nzval), dptr(x.v), ghost, self.n_own, dptr(scratch), A.nrows_local, A.nnz, 0, s,
+                           ctypes.byref(chosen))
+            except _capi.HPCLAError as exc:        # an optional performance step must not take A*x down with it
+                import sys
+                sys.stderr.write(f"hpcla: block-order measurement failed ({exc}); natural order\n")
+                chosen = ctypes.c_int(1)
             self.block_group = int(chosen.value)
             self.block_group_measured = (A.nrows_local + 255) // 256 >= 4096      # the tuner's own threshold (64 launches)
             A._block_order_hint = self.block_group       # the tuner left it registered for this matrix
