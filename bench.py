@@ -552,6 +552,7 @@ def int64_record(hp, wl, job, args, N, steps, warmup):
                         "unit": "GB/s", "frac": round(run.b_alg_loc / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                         "traffic": traffic, "traffic_source": traffic_source,
                         "kernel": "hpcla::spmv_rowblock_quad_kernel<long, false, false>",
+                        "block_order_group": run.plan.block_group,
                         "algorithmic_bytes_per_launch": run.b_alg_loc, "launch_ms_timed_region": round(launch_ms, 5)},
            "verified_vs_closed_form": run.verified}
     ok = run.verified

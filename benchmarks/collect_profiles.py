@@ -63,7 +63,7 @@ def workload_single_kernel(tag, step, kernel, rnd, prof, label, alg, cmd, skip=1
     return {"what": label, "kernel": kernel, "hbm_bytes": b, "FETCH_SIZE_KB_mean": round(f, 1), "WRITE_SIZE_KB_mean": round(w, 1),
             "algorithmic_bytes": alg, "ratio_to_algorithmic": round(b / alg, 4) if alg else None, "correction": CORRECTION,
             "source": f"profiles/{rnd}_pmc_{step}_FETCH_SIZE.csv + profiles/{rnd}_pmc_{step}_WRITE_SIZE.csv (separate rocprofv3 --pmc "
-                      f"passes over `{cmd}`; {nf} / {nw} launches)"}
+                      f"passes over `{cmd}`; {nf} / {nw} launches; block order fixed, HPCLA_BLOCK_ORDER=32)"}
 
 
 def workload_cg(tag, rnd, prof, alg_textbook, alg_moved):
@@ -91,7 +91,7 @@ def workload_cg(tag, rnd, prof, alg_textbook, alg_moved):
             "ratio_to_textbook": round(b / alg_textbook, 4), "ratio_to_moved": round(b / alg_moved, 4), "correction": CORRECTION,
             "source": f"profiles/{rnd}_pmc_cg_FETCH_SIZE.csv + profiles/{rnd}_pmc_cg_WRITE_SIZE.csv (separate rocprofv3 --pmc passes over "
                       f"`python3 bench.py --workload poisson3d_cg --steps 10 --warmup 5`; {n_iter_f} / {n_iter_w} iterations, all of "
-                      "them counted: setup launches of the same kernels included)"}
+                      "them counted: setup launches of the same kernels included; block order fixed to XCD groups of 64, HPCLA_BLOCK_ORDER=64)"}
 
 
 def main():

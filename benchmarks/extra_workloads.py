@@ -240,6 +240,7 @@ def run_record(args, backend, rank, world, job):
                          "note": "whole iteration (SpMV, 2 reductions, the x / r / p updates); achieved = bytes / WALL clock per iteration "
                                  "(max over ranks); device_ms_per_iter = HIP events on the launch stream around the same iterations; "
                                  "bytes = the textbook unfused count of SURVEY 8d (SpMV + 96 n), the fused form moves SpMV + 64 n"},
+            "block_order_group": int(getattr(plan, "block_group", 1)),
             "residual_first": hist[0], "residual_last": hist[-1], "setup_s": round(setup_s, 2),
             "exchange_timed_out": bool(job.max(1.0 if hp.get_vector_plan(A, b).timed_out() else 0.0)),
         }
