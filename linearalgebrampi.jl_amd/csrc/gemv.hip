@@ -61,6 +61,14 @@ __global__ __launch_bounds__(256) void gemv_rowmajor_kernel(const double *__rest
 // flight; a contiguous block (lda == ncols == 2L) is then read as one sequential stream.
 constexpr int SKINNY_PASSES = 16;
 
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ double seg_x(const double *__restrict__ x_lo, int64_t n_lo,
                                         const double *__restrict__ x_own, int64_t n_own,
                                         const double *__restrict__ x_hi, int64_t n_hi, int64_t e)
@@ -104,7 +112,15 @@ __global__ __launch_bounds__(256) void gemv_skinny_kernel(const double *__restri
                 if (has1) acc += a[1] * xb;
             }
         }
-        for (int off = L >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        // the L lanes of a row: within 16 lanes by DPP (quad permutes, then the half-row and row mirrors: every lane ends
+        // with the sum of its 4, 8, 16) -- VALU moves instead of the two ds_bpermute per step that made this kernel
+        // LDS-pipe-bound (ten of them per KiB loaded at L = 32); only the steps across 16-lane rows go through the crossbar
+        if (L > 1) acc += dpp_f64<0xB1>(acc);          // quad_perm [1,0,3,2]
+        if (L > 2) acc += dpp_f64<0x4E>(acc);          // quad_perm [2,3,0,1]
+        if (L > 4) acc += dpp_f64<0x141>(acc);         // row_half_mirror
+        if (L > 8) acc += dpp_f64<0x140>(acc);         // row_mirror
+        if (L > 16) acc += __shfl_xor(acc, 16, 64);
+        if (L > 32) acc += __shfl_xor(acc, 32, 64);
         if (sub == 0 && row < nrows) y[row] = acc;
     }
 }
