@@ -214,13 +214,13 @@ def step_breakdown(hp, job, backend, plan, A, x, y):
         return _g[0]
 
     def split(blocks, nb):
-        capi.call(f"hpcla_spmv_split_f64_{sfx}", sp(A.rowptr_target), sp(plan.colval_split), sp(A.nzval), sp(x.v),
+        capi.call(f"hpcla_spmv_split_f64_{sfx}", sp(plan.rowptr_of(A)), sp(plan.colval_split), sp(A.nzval), sp(x.v),
                   ghost()[0], plan.n_own, sp(y.v), A.nrows_local, A.nnz, 0, sp(blocks), nb, cur())
 
     def exchange():
         # the step's own exchange and nothing else: the fused entry point over ZERO rows (same stream, same
         # transport and ordering as the timed loop -- no communication pattern the loop did not use)
-        capi.call(f"hpcla_spmv_dist_f64_{sfx}", plan.halo, sp(A.rowptr_target), sp(plan.colval_split), sp(A.nzval),
+        capi.call(f"hpcla_spmv_dist_f64_{sfx}", plan.halo, sp(plan.rowptr_of(A)), sp(plan.colval_split), sp(A.nzval),
                   sp(x.v), plan.n_own, sp(y.v), 0, 0, 0, None, 0, None, 0, cur())
 
     def timed(fn, reps=50):
@@ -452,7 +452,11 @@ class PoissonRun:
         torch.cuda.synchronize()
         self.setup_s = time.perf_counter() - t0
         self.nnz_loc, self.nrows_loc = A.nnz, A.nrows_local
-        self.b_alg_loc = wl.spmv_algorithmic_bytes(A.nnz, A.nrows_local, A.ncols_compressed, np.dtype(Ti).itemsize)
+        # bytes per index the KERNEL streams: the plan's (an Int64 matrix whose plan was narrowed streams Int32)
+        self.index_bytes = 8 if self.plan.is_i64 else 4
+        self.narrowed = bool(getattr(self.plan, "narrowed", False))
+        self.b_alg_loc = wl.spmv_algorithmic_bytes(A.nnz, A.nrows_local, A.ncols_compressed, self.index_bytes)
+        self.b_alg_matrix_index_type = wl.spmv_algorithmic_bytes(A.nnz, A.nrows_local, A.ncols_compressed, np.dtype(Ti).itemsize)
         hp.mul_(self.y, A, self.x)
         torch.cuda.synchronize()
         ok, self.samp, self.want = closed_form_check(wl, torch, self.y, nx, ny, lo, self.nrows_loc, rank)
@@ -531,10 +535,36 @@ def strong_scaling_record(hp, wl, job, backend, args, world, rank, budget=None):
     return rec, verified
 
 
+def headline_traffic(block_group, applicable=True):
+    """HBM bytes per launch of the headline kernel (config 2's slab, Int32 kernel) from the builder's stored rocprofv3
+    --pmc passes (profiles/traffic_latest.json), under the block order this run's plan chose.  The same per-GPU share
+    at N > 1: one 4096^2 slab per rank is the single-rank pass's workload plus two ghost rows."""
+    tj = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if not applicable or not os.path.exists(tj):
+        return None, "no stored PMC measurement for this shape (profiles/traffic_latest.json)"
+    try:
+        rec = json.load(open(tj))
+        traffic = rec.get("hbm_bytes_per_launch")
+        source = ("NOT measured by this run: PMC counters cannot be read from inside the process; value "
+                  "stored by the builder's rocprofv3 passes of this same command -- " + rec.get("source", tj))
+        # the counter depends on the block order the plan's measurement chose for this run (neighbouring XCD groups
+        # share x lines; FETCH_SIZE counts them once per L2 although the Infinity Cache serves the repeats)
+        per_order = rec.get("by_block_order", {}).get(str(block_group))
+        if per_order:
+            traffic = per_order["hbm_bytes_per_launch"]
+            source += ("; the pass under this run's block order (" +
+                       ("natural" if block_group <= 1 else f"XCD groups of {block_group} row blocks") + ")")
+        return traffic, source
+    except Exception as exc:
+        return None, f"profiles/traffic_latest.json unreadable ({type(exc).__name__})"
+
+
 def int64_record(hp, wl, job, args, N, steps, warmup):
     """The headline matrix with Int64 indices -- the reference's default `Ti = Int` (src/backends.jl:348, 369) -- as a
-    driver-timed sub-record (N = 1): same kernel template, 16 B per stored entry instead of 12; its own algorithmic
-    byte count (1 744 568 328 B at 4096^2), never mixed with the Int32 headline."""
+    driver-timed sub-record (N = 1).  Round 4: the plan NARROWS such a matrix (nnz and the split column space fit
+    Int32: sparse.can_narrow_indices), so the launches take the Int32 kernel and stream 12 B per stored entry; the
+    record says so (`narrowed`, `index_bytes_streamed`) and prices the launch by the bytes it streams, with the Int64
+    count (1 744 568 328 B at 4096^2) beside it.  HPCLA_NARROW_INDICES=0 gives the Int64 kernel back."""
     import copy
     torch = job.torch
     a2 = copy.copy(args)
@@ -544,16 +574,24 @@ def int64_record(hp, wl, job, args, N, steps, warmup):
     el, launch_ms = run.time_steps(steps, warmup)
     ms = el / steps * 1e3
     from benchmarks.extra_workloads import stored_traffic
-    traffic, traffic_source = stored_traffic("poisson2d_spmv_int64", N == 4096)
+    if run.narrowed:
+        traffic, traffic_source = headline_traffic(run.plan.block_group, N == 4096)
+        if traffic_source:
+            traffic_source += "; this Int64 matrix runs the headline's Int32 kernel on a narrowed plan, so the headline's passes apply"
+    else:
+        traffic, traffic_source = stored_traffic("poisson2d_spmv_int64", N == 4096)
     rec = {"workload": f"poisson2d 5-pt {N}x{N}, CSR SpMV y=A*x, index=i64 (reference default Ti=Int)",
+           "narrowed": run.narrowed, "index_bytes_streamed": run.index_bytes,
            "steps": steps, "warmup": warmup, "ms_per_step": round(ms, 5),
            "gflops": round(2.0 * run.nnz_loc / (ms * 1e-3) / 1e9, 2),
            "roofline": {"bound": "hbm", "achieved": round(run.b_alg_loc / (launch_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(run.b_alg_loc / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                         "traffic": traffic, "traffic_source": traffic_source,
-                        "kernel": "hpcla::spmv_rowblock_quad_kernel<long, false, false>",
+                        "kernel": "hpcla::spmv_rowblock_quad_kernel<%s, false, false>" % ("long" if run.plan.is_i64 else "int"),
                         "block_order_group": run.plan.block_group,
-                        "algorithmic_bytes_per_launch": run.b_alg_loc, "launch_ms_timed_region": round(launch_ms, 5)},
+                        "algorithmic_bytes_per_launch": run.b_alg_loc,
+                        "algorithmic_bytes_if_int64_were_streamed": run.b_alg_matrix_index_type,
+                        "launch_ms_timed_region": round(launch_ms, 5)},
            "verified_vs_closed_form": run.verified}
     ok = run.verified
     run.release()
@@ -674,26 +712,15 @@ def _run(args, budget):
     # (device time between the two events / K; the per-launch event pairs are a cross-check)
     achieved = b_alg_loc / (timed_region_launch_ms * 1e-3) / 1e9
 
-    traffic = traffic_source = None
-    tj = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if os.path.exists(tj) and args.index == "i32" and N == 4096 and not strong and world == 1:
-        try:
-            rec = json.load(open(tj))
-            traffic = rec.get("hbm_bytes_per_launch")
-            traffic_source = ("NOT measured by this run: PMC counters cannot be read from inside the process; value "
-                              "stored by the builder's rocprofv3 passes of this same command -- " + rec.get("source", tj))
-            # the counter depends on the block order the plan's measurement chose for this run (neighbouring XCD groups
-            # share x lines; FETCH_SIZE counts them once per L2 although the Infinity Cache serves the repeats)
-            per_order = rec.get("by_block_order", {}).get(str(run.plan.block_group))
-            if per_order:
-                traffic = per_order["hbm_bytes_per_launch"]
-                traffic_source += ("; the pass under this run's block order (" +
-                                   ("natural" if run.plan.block_group <= 1 else f"XCD groups of {run.plan.block_group} row blocks") + ")")
-        except Exception:
-            traffic = traffic_source = None
+    # (an Int64 matrix on a narrowed plan runs the Int32 kernel: the same stored passes apply)
+    traffic, traffic_source = headline_traffic(run.plan.block_group,
+                                               run.index_bytes == 4 and N == 4096 and not strong)
+    if world > 1 and traffic is not None:
+        traffic_source += (f"; N = {world}: the SINGLE-RANK passes of the same per-GPU share (one {N}x{N} slab; the "
+                           "distributed launch adds two ghost rows of x and the push stores, < 0.01 % of the bytes)")
 
     kernel = "hpcla::spmv_rowblock_quad_kernel<%s, %s, %s>" % (
-        "int" if args.index == "i32" else "long", "true" if plan.has_halo else "false",
+        "long" if plan.is_i64 else "int", "true" if plan.has_halo else "false",
         "true" if getattr(plan, "push", False) else "false")
     nx, ny, ny_loc, n_glob = run.nx, run.ny, run.ny_loc, run.n_glob
     result = {
@@ -704,6 +731,7 @@ def _run(args, budget):
         "config": {"workload": f"poisson2d 5-pt, {nx}x{ny_loc} slab per GPU ({nx}x{ny} global), "
                                f"n={n_glob}, nnz={nnz_tot}, index={args.index}, CSR SpMV y=A*x",
                    "global_rows": n_glob, "nnz": nnz_tot, "index_type": args.index,
+                   "index_bytes_streamed": run.index_bytes, "narrowed": run.narrowed,
                    "parallelism": (f"row-slab x{world}, halo: " + ("peer-window push over xGMI" if getattr(plan, "push", False)
                                                                    else "RCCL send/recv")) if world > 1 else "single GPU"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

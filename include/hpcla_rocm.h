@@ -127,6 +127,16 @@ int hpcla_remap_i32(const int32_t *in, const int32_t *map, int32_t *out, int64_t
                     void *stream);
 int hpcla_remap_i64(const int64_t *in, const int64_t *map, int64_t *out, int64_t n, int index_base,
                     void *stream);
+/* Plan-time NARROWING of an Int64 structure.  The reference's default index type is Ti = Int (src/backends.jl:348,
+ * 369: backend_cpu_serial / backend_cpu_mpi default to Int), so a caller who follows the defaults hands over Int64
+ * rowptr / colval although every BASELINE configuration fits Int32 per GPU.  Indices are never results: when
+ * nnz + index_base and n_own + n_ghost + index_base fit Int32, the plan keeps Int32 copies (remap_i64_to_i32: the
+ * split colval straight from the Int64 compressed colval through an Int32 map; narrow_i64_to_i32: rowptr) and every
+ * launch over that plan takes the _i32 kernels -- 12 instead of 16 index+value bytes per stored entry, same bits.
+ * narrow: if `overflow_dev` is not NULL, *overflow_dev |= 1 when a value does not fit (the caller zeroes it). */
+int hpcla_remap_i64_to_i32(const int64_t *in, const int32_t *map, int32_t *out, int64_t n, int index_base,
+                           void *stream);
+int hpcla_narrow_i64_to_i32(const int64_t *in, int32_t *out, int64_t n, uint32_t *overflow_dev, void *stream);
 int hpcla_classify_blocks_i32(const int32_t *rowptr, const int32_t *colval_split, int64_t nrows,
                               int index_base, int64_t n_own, int rows_per_block, int32_t *flags,
                               void *stream);

@@ -55,6 +55,8 @@ _SIGNATURES = {
     "hpcla_spmm_rows_per_block": [],
     "hpcla_remap_i32": [_vp, _vp, _vp, _i64, _i32, _vp],
     "hpcla_remap_i64": [_vp, _vp, _vp, _i64, _i32, _vp],
+    "hpcla_remap_i64_to_i32": [_vp, _vp, _vp, _i64, _i32, _vp],
+    "hpcla_narrow_i64_to_i32": [_vp, _vp, _i64, _vp, _vp],
     "hpcla_classify_blocks_i32": [_vp, _vp, _i64, _i32, _i64, _i32, _vp, _vp],
     "hpcla_classify_blocks_i64": [_vp, _vp, _i64, _i32, _i64, _i32, _vp, _vp],
     "hpcla_spmm_csr_f64_i32": [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _i64, _i32, _i64, _i64, _i32, _i32, _vp],

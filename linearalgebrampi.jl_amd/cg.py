@@ -99,7 +99,7 @@ def cg_iterate(A, ws: CGWorkspace, plan, fused: bool, iters: int, native_loop: b
         sfx = "i64" if plan.is_i64 else "i32"
         work, _ = _Scratch.get(ws.r.v.device)
         _capi.call(f"hpcla_cg_iterations_f64_{sfx}", plan.halo if plan.has_halo else None, A.backend.rccl,
-                   dptr(A.rowptr_target), dptr(plan.colval_split), dptr(A.nzval), A.nrows_local, A.nnz, 0,
+                   dptr(plan.rowptr_of(A)), dptr(plan.colval_split), dptr(A.nzval), A.nrows_local, A.nnz, 0,
                    dptr(plan.interior), plan.n_interior, dptr(plan.boundary), plan.n_boundary,
                    dptr(ws.x.v), dptr(ws.r.v), dptr(ws.p.v), dptr(ws.Ap.v), dptr(hist[first:]), dptr(ws.pAp),
                    dptr(plan._dot_work), dptr(work), int(iters), current_stream_ptr())

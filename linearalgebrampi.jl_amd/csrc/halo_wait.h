@@ -82,6 +82,14 @@ __device__ __forceinline__ uint32_t halo_wait_block(const HaloWait &w, uint32_t 
         for (int i = 0; i < w.n_flags && ok; ++i) {
             const uint64_t *f = w.flags + (int64_t)i * WIN_FLAG_STRIDE_U64;
             while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+                // A DEAD plan drains at once: the status word is sticky, so once any wait of this plan has expired
+                // every later wait (the other boundary workgroups of this launch, the k iterations a CG call has
+                // already enqueued behind it) gives up on its first failed poll instead of spinning out its own full
+                // bound -- k enqueued steps cost one timeout, not k.  Only read on the slow path (a flag not there yet).
+                if (__hip_atomic_load(w.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                    ok = false;
+                    break;
+                }
                 __builtin_amdgcn_s_sleep(2);
                 if ((int64_t)wall_clock64() - t0 > w.timeout_ticks) {
                     __hip_atomic_store(w.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -134,6 +142,9 @@ __device__ __forceinline__ bool spin_until_ge(const uint64_t *word, uint64_t wan
                                               uint32_t *status)
 {
     while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
+        // sticky status already set (an earlier wait of this plan / communicator expired): give up at once, so that
+        // work enqueued behind a dead peer drains in ONE timeout (read on the slow path only)
+        if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
         __builtin_amdgcn_s_sleep(2);
         if ((int64_t)wall_clock64() - t0 > timeout) {
             __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -365,14 +365,30 @@ __global__ __launch_bounds__(RPB) __attribute__((amdgpu_num_sgpr(80), amdgpu_wav
     if (dot_partial) block_dot_epilogue(s_prod, dot_partial, blk, tid < nr ? acc * x_own[r0 + tid] : 0.0);
 }
 
-template <typename I>
-__global__ __launch_bounds__(256) void remap_kernel(const I *__restrict__ in,
-                                                    const I *__restrict__ map, I *__restrict__ out,
+// IN != OUT: plan-time NARROWING of an Int64 matrix (the reference's default Ti = Int, src/backends.jl:348,369) whose
+// nonzero count and split column space fit Int32 -- the kernels then stream 4-byte indices (hpcla_remap_i64_to_i32)
+template <typename IN, typename OUT>
+__global__ __launch_bounds__(256) void remap_kernel(const IN *__restrict__ in,
+                                                    const OUT *__restrict__ map, OUT *__restrict__ out,
                                                     int64_t n, int base)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) out[i] = map[(int64_t)in[i] - base];
+}
+
+__global__ __launch_bounds__(256) void narrow_kernel(const int64_t *__restrict__ in, int32_t *__restrict__ out,
+                                                     int64_t n, unsigned int *__restrict__ overflow)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    bool bad = false;
+    for (; i < n; i += stride) {
+        const int64_t v = in[i];
+        bad |= (v < INT32_MIN || v > INT32_MAX);
+        out[i] = (int32_t)v;
+    }
+    if (overflow && bad) atomicOr(overflow, 1u);
 }
 
 template <typename I>
@@ -710,14 +726,14 @@ HPCLA_API int hpcla_spmv_split_f64_i64(const int64_t *rowptr, const int64_t *col
                           index_base, block_list, n_blocks, stream, nullptr, -1);
 }
 
-template <typename I>
-static int remap_impl(const I *in, const I *map, I *out, int64_t n, int index_base, void *stream)
+template <typename IN, typename OUT>
+static int remap_impl(const IN *in, const OUT *map, OUT *out, int64_t n, int index_base, void *stream)
 {
     if (n < 0) return set_error(HPCLA_ERR_INVALID, "remap: negative size");
+    if (index_base != 0 && index_base != 1) return set_error(HPCLA_ERR_INVALID, "remap: index_base must be 0 or 1");
     if (n == 0) return HPCLA_OK;
     if (!in || !map || !out) return set_error(HPCLA_ERR_INVALID, "remap: null pointer");
-    remap_kernel<I><<<stream_grid(n, 256), 256, 0, as_stream(stream)>>>(in, map, out, n,
-                                                                         index_base);
+    remap_kernel<IN, OUT><<<stream_grid(n, 256), 256, 0, as_stream(stream)>>>(in, map, out, n, index_base);
     HPCLA_CHECK_LAUNCH();
     return HPCLA_OK;
 }
@@ -725,12 +741,29 @@ static int remap_impl(const I *in, const I *map, I *out, int64_t n, int index_ba
 HPCLA_API int hpcla_remap_i32(const int32_t *in, const int32_t *map, int32_t *out, int64_t n,
                               int index_base, void *stream)
 {
-    return remap_impl<int32_t>(in, map, out, n, index_base, stream);
+    return remap_impl<int32_t, int32_t>(in, map, out, n, index_base, stream);
 }
 HPCLA_API int hpcla_remap_i64(const int64_t *in, const int64_t *map, int64_t *out, int64_t n,
                               int index_base, void *stream)
 {
-    return remap_impl<int64_t>(in, map, out, n, index_base, stream);
+    return remap_impl<int64_t, int64_t>(in, map, out, n, index_base, stream);
+}
+
+// ---- plan-time narrowing of Int64 structures (the kernels' index bytes: 16 -> 12 B per stored entry) ----------------
+HPCLA_API int hpcla_remap_i64_to_i32(const int64_t *in, const int32_t *map, int32_t *out, int64_t n,
+                                     int index_base, void *stream)
+{
+    return remap_impl<int64_t, int32_t>(in, map, out, n, index_base, stream);
+}
+
+HPCLA_API int hpcla_narrow_i64_to_i32(const int64_t *in, int32_t *out, int64_t n, uint32_t *overflow_dev, void *stream)
+{
+    if (n < 0) return set_error(HPCLA_ERR_INVALID, "narrow: negative size");
+    if (n == 0) return HPCLA_OK;
+    if (!in || !out) return set_error(HPCLA_ERR_INVALID, "narrow: null pointer");
+    narrow_kernel<<<stream_grid(n, 256), 256, 0, as_stream(stream)>>>(in, out, n, overflow_dev);
+    HPCLA_CHECK_LAUNCH();
+    return HPCLA_OK;
 }
 
 template <typename I>

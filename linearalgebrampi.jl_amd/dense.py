@@ -300,7 +300,9 @@ def _spmm_plan(A, B: HPCMatrix):
     """(vector plan, width-k exchange entry) for ``A * B``: the vector plan for (A, B's row partition) provides the
     neighbour lists, the split colval and the blocks; the width-k halo plan hangs off the same key plus k.
     Entry = (halo handle | None, interior blocks, boundary blocks, send_idx, colval_split, ghost pointer, n_ghost rows,
-    send rows).  Collective on first use."""
+    send rows, peers, lists, entry_is_i64).  ``entry_is_i64``: index type of THIS entry's kernel arrays -- the vector
+    plan's (Int32 for a narrowed Int64 matrix, sparse.can_narrow_indices) unless whole slices made the ghost row space
+    outgrow Int32, in which case the entry falls back to the matrix's own Int64 arrays.  Collective on first use."""
     from .sparse import get_vector_plan
     from .vectors import HPCVector
     torch = _torch()
@@ -316,24 +318,27 @@ def _spmm_plan(A, B: HPCMatrix):
     if nranks == 1 or k == 0:
         return plan, None
     s = current_stream_ptr()
-    sfx = "i64" if plan.is_i64 else "i32"
-    key = (A._ensure_hash(), probe.structural_hash, k)
+    key = (A._ensure_hash(), probe.structural_hash, k, plan.is_i64)
     _spmm_backends[id(backend)] = backend
     ent = _spmm_halo_cache.get(key)
     if ent is None:
         # plan time, collective (every rank, with or without neighbours): who gets whole slices
         from .backends import comm_alltoall_counts
-        from .sparse import whole_slice_lists, whole_slice_wishes
+        from .sparse import can_narrow_indices, split_colval, whole_slice_lists, whole_slice_wishes
         h = plan.host
         wish = whole_slice_wishes(h, B.row_partition, nranks)
         granted = comm_alltoall_counts(backend.comm, wish)
-        Ti = np.int64 if plan.is_i64 else np.int32
-        tdt = torch.int64 if plan.is_i64 else torch.int32
         if not plan.has_halo:
             attach_halo_windows(backend, None)          # collective: the other ranks' plans are attaching
-            ent = _spmm_halo_cache[key] = (None, None, None, None, plan.colval_split, None, 0, 0, (0, 0), None)
+            ent = _spmm_halo_cache[key] = (None, None, None, None, plan.colval_split, None, 0, 0, (0, 0), None, plan.is_i64)
         else:
             send_indices, recv_counts_l, cmap = whole_slice_lists(h, A.col_indices, B.row_partition, wish, granted)
+            # index type of this entry's kernel arrays: the vector plan's, unless whole slices outgrow a narrowed plan
+            ent_i64 = plan.is_i64
+            if plan.narrowed and not can_narrow_indices(A.nnz, A.nrows_local, plan.n_own, sum(recv_counts_l)):
+                ent_i64 = True
+            sfx = "i64" if ent_i64 else "i32"
+            Ti = np.int64 if ent_i64 else np.int32
             n_send, n_recv = len(h.send_rank_ids), len(h.recv_rank_ids)
             send_ranks = (ctypes.c_int32 * max(n_send, 1))(*h.send_rank_ids)
             send_counts = (ctypes.c_int64 * max(n_send, 1))(*[len(i) for i in send_indices])
@@ -343,11 +348,9 @@ def _spmm_plan(A, B: HPCMatrix):
                         if n_send else None)
             if plan.n_own + sum(recv_counts_l) > np.iinfo(Ti).max:
                 raise OverflowError("split column space does not fit the index type")
-            if wish.any():
-                # ghost positions differ from the vector plan's: a split colval copy of its own
-                cmap_dev = torch.from_numpy(cmap.astype(Ti)).to(dev)
-                colval_split = torch.empty(A.nnz, dtype=tdt, device=dev)
-                _capi.call(f"hpcla_remap_{sfx}", dptr(A.colval_target()), dptr(cmap_dev), dptr(colval_split), A.nnz, 0, s)
+            if wish.any() or ent_i64 != plan.is_i64:
+                # ghost positions (or the index type) differ from the vector plan's: a split colval copy of its own
+                colval_split, _ = split_colval(A, cmap, to_i32=not ent_i64)
             else:
                 colval_split = plan.colval_split
             halo = ctypes.c_void_p()
@@ -358,7 +361,7 @@ def _spmm_plan(A, B: HPCMatrix):
             # of the PREVIOUS exchange)
             _capi.check("hpcla_halo_plan_create_ex", _capi.load().hpcla_halo_plan_create_ex(
                 ctypes.byref(halo), backend.rccl, n_send, send_ranks, send_counts, dptr(send_idx),
-                1 if plan.is_i64 else 0, n_recv, recv_ranks, recv_counts, k, _capi.HALO_SINGLE_BUFFER))
+                1 if ent_i64 else 0, n_recv, recv_ranks, recv_counts, k, _capi.HALO_SINGLE_BUFFER))
             bp = np.asarray(B.row_partition, dtype=np.int64)
             wprobe = (plan.n_own, k, [(r, np.arange(bp[r + 1] - bp[r]) if wish[r] else A.col_indices[perm] - bp[r])
                                      for r, perm in zip(h.recv_rank_ids, h.recv_perm)])
@@ -367,7 +370,7 @@ def _spmm_plan(A, B: HPCMatrix):
             rpb = _capi.load().hpcla_spmm_rows_per_block()
             nblk = (A.nrows_local + rpb - 1) // rpb
             flags_i = torch.empty(nblk, dtype=torch.int32, device=dev)
-            _capi.call(f"hpcla_classify_blocks_{sfx}", dptr(A.rowptr_target), dptr(colval_split),
+            _capi.call(f"hpcla_classify_blocks_{sfx}", dptr(_entry_rowptr(A, plan, ent_i64)), dptr(colval_split),
                        A.nrows_local, 0, plan.n_own, rpb, dptr(flags_i), s)
             flags = flags_i != 0
             interior = torch.nonzero(~flags).flatten().to(torch.int32).contiguous()
@@ -378,9 +381,15 @@ def _spmm_plan(A, B: HPCMatrix):
             peers = (sum(1 for c in recv_counts_l if c), sum(1 for i in send_indices if len(i)))
             ent = (halo, interior, boundary, send_idx, colval_split, ghost, int(ng.value),
                    int(sum(len(i) for i in send_indices)), peers,
-                   {"send_indices": send_indices, "recv_counts": list(recv_counts_l), "wish": wish})
+                   {"send_indices": send_indices, "recv_counts": list(recv_counts_l), "wish": wish}, ent_i64)
             _spmm_halo_cache[key] = ent
     return plan, ent
+
+
+def _entry_rowptr(A, plan, ent_i64: bool):
+    """``rowptr`` for the kernels of an SpMM entry: the vector plan's (its Int32 copy when narrowed), or the matrix's
+    own Int64 array when the entry could not stay narrowed."""
+    return plan.rowptr_of(A) if ent_i64 == plan.is_i64 else A.rowptr_target
 
 
 def spmm_order() -> str:
@@ -414,15 +423,15 @@ class SpmmPanelPlan:
         backend = A.backend
         dev = backend.torch_device
         self.k, self.n_chunks = k, n_chunks
-        self.is_i64 = plan.is_i64
+        self.is_i64 = plan.is_i64 if ent is None else bool(ent[10])
         self.halos, self.ghosts, self._keep, self.panels, self.vals = [], [], [], [], []
         if ent is None or ent[0] is None:
             # a rank without neighbours: nothing to cut, but the other ranks' chunk-set plans attach COLLECTIVELY
             for _ in range(n_chunks):
                 attach_halo_windows(backend, None)
             return
-        Ti = np.int64 if plan.is_i64 else np.int32
-        tdt = torch.int64 if plan.is_i64 else torch.int32
+        Ti = np.int64 if self.is_i64 else np.int32
+        tdt = torch.int64 if self.is_i64 else torch.int32
         h = plan.host
         info = ent[9]
         send_indices, recv_counts = info["send_indices"], info["recv_counts"]
@@ -447,7 +456,7 @@ class SpmmPanelPlan:
             halo = ctypes.c_void_p()
             _capi.check("hpcla_halo_plan_create_ex", _capi.load().hpcla_halo_plan_create_ex(
                 ctypes.byref(halo), backend.rccl, n_send, send_ranks, send_counts, dptr(send_idx),
-                1 if plan.is_i64 else 0, n_recv, recv_ranks, recv_cnt_c, k, _capi.HALO_SINGLE_BUFFER))
+                1 if self.is_i64 else 0, n_recv, recv_ranks, recv_cnt_c, k, _capi.HALO_SINGLE_BUFFER))
             # the rows this chunk-set must deliver, for the plan's connection test (owner-local row numbers)
             seg = []
             for r, perm, cnt in zip(h.recv_rank_ids, h.recv_perm, recv_counts):
@@ -495,13 +504,14 @@ class SpmmPanelPlan:
                 _capi.call(f"hpcla_gather_f64_{sfx}", dptr(A.nzval), dptr(perm), None, dptr(v), n, 0, s)
         self._vals_version = ver
 
-    def multiply(self, A, Bc, C, plan_colval=None) -> None:
+    def multiply(self, A, Bc, C, plan=None) -> None:
         sfx = "i64" if self.is_i64 else "i32"
         s = current_stream_ptr()
         k = self.k
         if not self.halos:                                           # no neighbours: every column is owned
-            _capi.call(f"hpcla_spmm_csr_f64_{sfx}", dptr(A.rowptr_target), dptr(plan_colval), dptr(A.nzval), dptr(Bc), k,
-                       _capi.LAYOUT_ROW, dptr(C), k, _capi.LAYOUT_ROW, A.nrows_local, A.nnz, k, 0, s)
+            psfx = "i64" if plan.is_i64 else "i32"
+            _capi.call(f"hpcla_spmm_csr_f64_{psfx}", dptr(plan.rowptr_of(A)), dptr(plan.colval_split), dptr(A.nzval),
+                       dptr(Bc), k, _capi.LAYOUT_ROW, dptr(C), k, _capi.LAYOUT_ROW, A.nrows_local, A.nnz, k, 0, s)
             return
         self.refresh_values(A)
         for halo in self.halos:                                      # chunk-sets leave in order on one exchange stream
@@ -520,7 +530,7 @@ class SpmmPanelPlan:
 def _spmm_panel_plan(A, B, plan, ent) -> SpmmPanelPlan:
     k = int(B.A.shape[1])
     n_chunks = max(1, int(os.environ.get("HPCLA_SPMM_PANELS", "4")))
-    key = (A._ensure_hash(), compute_partition_hash(B.row_partition), k, n_chunks)
+    key = (A._ensure_hash(), compute_partition_hash(B.row_partition), k, n_chunks, plan.is_i64)
     pp = _spmm_panel_cache.get(key)
     if pp is None:
         pp = _spmm_panel_cache[key] = SpmmPanelPlan(A, plan, ent, k, B.row_partition, n_chunks)
@@ -550,28 +560,30 @@ def spmm(A, B: HPCMatrix) -> HPCMatrix:
     if k == 0:                       # (a rank without local rows still takes part in the exchange below)
         return out
     s = current_stream_ptr()
-    sfx = "i64" if plan.is_i64 else "i32"
     Bc = B.A.contiguous()
     if ent is not None and spmm_order() == "panel":
         # COLLECTIVE choice: every rank must run the same order (the chunk-set plans are separate exchanges, and a
         # rank without neighbours still takes part in their collective attach)
-        _spmm_panel_plan(A, B, plan, ent).multiply(A, Bc, C, plan.colval_split)
+        _spmm_panel_plan(A, B, plan, ent).multiply(A, Bc, C, plan)
         return out
     if ent is None or ent[0] is None:
         # every column owned: split indices == offsets into B's local rows
-        _capi.call(f"hpcla_spmm_csr_f64_{sfx}", dptr(A.rowptr_target), dptr(plan.colval_split),
+        sfx = "i64" if plan.is_i64 else "i32"
+        _capi.call(f"hpcla_spmm_csr_f64_{sfx}", dptr(plan.rowptr_of(A)), dptr(plan.colval_split),
                    dptr(A.nzval), dptr(Bc), k, _capi.LAYOUT_ROW, dptr(C), k, _capi.LAYOUT_ROW,
                    A.nrows_local, A.nnz, k, 0, s)
         return out
     halo, interior, boundary, _, colval_split, ghost = ent[:6]
+    sfx = "i64" if ent[10] else "i32"
+    rowptr = _entry_rowptr(A, plan, bool(ent[10]))
     _capi.call("hpcla_halo_begin", halo, dptr(Bc), s)
     if interior.numel():
-        _capi.call(f"hpcla_spmm_split_f64_{sfx}", dptr(A.rowptr_target), dptr(colval_split),
+        _capi.call(f"hpcla_spmm_split_f64_{sfx}", dptr(rowptr), dptr(colval_split),
                    dptr(A.nzval), dptr(Bc), k, ghost, k, plan.n_own, dptr(C), k, A.nrows_local,
                    A.nnz, k, 0, dptr(interior), int(interior.numel()), s)
     _capi.call("hpcla_halo_end", halo, s)
     if boundary.numel():
-        _capi.call(f"hpcla_spmm_split_f64_{sfx}", dptr(A.rowptr_target), dptr(colval_split),
+        _capi.call(f"hpcla_spmm_split_f64_{sfx}", dptr(rowptr), dptr(colval_split),
                    dptr(A.nzval), dptr(Bc), k, ghost, k, plan.n_own, dptr(C), k, A.nrows_local,
                    A.nnz, k, 0, dptr(boundary), int(boundary.numel()), s)
     return out

@@ -184,6 +184,54 @@ def panel_chunk_lists(send_indices, recv_counts, n_chunks: int):
 # =====================================================================================================
 # device plan
 # =====================================================================================================
+INT32_MAX = int(np.iinfo(np.int32).max)
+
+
+def narrowing_enabled() -> bool:
+    """``HPCLA_NARROW_INDICES=0`` keeps Int64 structures on the Int64 kernels (A/B measurements, and the tests that
+    must still reach those kernels through the host layer)."""
+    return _os.environ.get("HPCLA_NARROW_INDICES", "1").strip().lower() not in ("0", "off", "false", "no")
+
+
+def can_narrow_indices(nnz: int, nrows_local: int, n_own: int, n_ghost: int, index_base: int = 0) -> bool:
+    """May the kernels of a plan over an Int64 matrix stream Int32 indices?  Everything an index array of the plan
+    can hold must fit: row pointers reach ``nnz + index_base``, split columns reach ``n_own + n_ghost - 1 +
+    index_base`` (own offsets first, then positions in the ghost segment), send indices stay below ``n_own``.
+    Indices are never results, so narrowing cannot change a bit of y (reference default ``Ti = Int``,
+    src/backends.jl:348,369)."""
+    lim = INT32_MAX - int(index_base)
+    return (int(nnz) <= lim and int(nrows_local) <= lim and int(n_own) + int(n_ghost) <= lim and int(n_own) <= lim)
+
+
+def split_colval(A: "HPCSparseMatrix", cmap: np.ndarray, to_i32: bool):
+    """Device split-column ``colval`` of A through the compressed-column map ``cmap`` (one remap kernel over the stored
+    entries): in A's index type, or -- ``to_i32`` with an Int64 matrix -- narrowed on the fly
+    (``hpcla_remap_i64_to_i32``).  Returns (colval_split, cmap_dev)."""
+    torch = _torch()
+    dev = A.backend.torch_device
+    a64 = A.Ti == np.dtype(np.int64)
+    out64 = a64 and not to_i32
+    cmap_dev = torch.from_numpy(cmap.astype(np.int64 if out64 else np.int32)).to(dev)
+    out = torch.empty(A.nnz, dtype=torch.int64 if out64 else torch.int32, device=dev)
+    fn = "hpcla_remap_i64" if out64 else ("hpcla_remap_i64_to_i32" if a64 else "hpcla_remap_i32")
+    _capi.call(fn, dptr(A.colval_target()), dptr(cmap_dev), dptr(out), A.nnz, 0, current_stream_ptr())
+    return out, cmap_dev
+
+
+def narrowed_rowptr(A: "HPCSparseMatrix"):
+    """Int32 copy of an Int64 ``rowptr_target`` (``hpcla_narrow_i64_to_i32``; the overflow word is checked: a caller
+    may not reach this with nnz >= 2^31)."""
+    torch = _torch()
+    dev = A.backend.torch_device
+    n = int(A.rowptr_target.numel())
+    out = torch.empty(n, dtype=torch.int32, device=dev)
+    ovf = torch.zeros(1, dtype=torch.int32, device=dev)
+    _capi.call("hpcla_narrow_i64_to_i32", dptr(A.rowptr_target), dptr(out), n, dptr(ovf), current_stream_ptr())
+    if int(ovf.item()):
+        raise OverflowError("rowptr does not fit Int32")
+    return out
+
+
 class VectorPlan:
     """Memoized communication + launch plan for ``A*x`` (the cache entry of _vector_plan_cache,
     src/HPCLinearAlgebra.jl:133).  Holds the reference plan's lists (``host``) and their device
@@ -202,9 +250,6 @@ class VectorPlan:
         self.n_own = h.n_own
         self.result_partition = A.row_partition.copy()                       # src/sparse.jl:2103-2106
         self.result_partition_hash = compute_partition_hash(self.result_partition)
-        self.is_i64 = A.Ti == np.dtype(np.int64)
-        sfx = "i64" if self.is_i64 else "i32"
-        tdt = torch.int64 if self.is_i64 else torch.int32
         s = current_stream_ptr()
 
         # split-column colval (device): one remap kernel over the nonzeros
@@ -212,11 +257,19 @@ class VectorPlan:
         n_ghost = h.n_gathered - len(h.local_dst_indices)
         if self.n_own + n_ghost > np.iinfo(A.Ti).max:
             raise OverflowError("split column space does not fit the index type")
-        cmap_dev = torch.from_numpy(cmap.astype(A.Ti)).to(dev)
-        colval_dev = A.colval_target()
-        self.colval_split = torch.empty(A.nnz, dtype=tdt, device=dev)
-        _capi.call(f"hpcla_remap_{sfx}", dptr(colval_dev), dptr(cmap_dev), dptr(self.colval_split),
-                   A.nnz, 0, s)
+        # Index type of the KERNEL arrays of this plan (colval_split, rowptr, send lists).  An Int64 matrix -- the
+        # reference's default Ti = Int, src/backends.jl:348,369 -- whose nonzero count and split column space fit Int32
+        # is NARROWED here, once per structure: every launch over the plan then takes the _i32 kernels (12 instead of
+        # 16 bytes per stored entry; indices are not results, the bits of y cannot change).  The matrix keeps its type.
+        a64 = A.Ti == np.dtype(np.int64)
+        self.narrowed = bool(a64 and narrowing_enabled() and can_narrow_indices(A.nnz, A.nrows_local, self.n_own, n_ghost))
+        self.is_i64 = a64 and not self.narrowed
+        sfx = "i64" if self.is_i64 else "i32"
+        Tk = np.int64 if self.is_i64 else np.int32
+        self.colval_split, cmap_dev = split_colval(A, cmap, to_i32=self.narrowed)
+        # rowptr of the kernels: the matrix's own array, or the plan's Int32 copy (matrices that share this plan share
+        # the structural hash, hence the contents of rowptr)
+        self._rowptr32 = narrowed_rowptr(A) if self.narrowed else None
 
         # halo plan (RCCL)
         self.halo = ctypes.c_void_p()
@@ -227,7 +280,7 @@ class VectorPlan:
         recv_ranks = (ctypes.c_int32 * max(n_recv, 1))(*h.recv_rank_ids)
         recv_counts = (ctypes.c_int64 * max(n_recv, 1))(*[len(p) for p in h.recv_perm])
         if n_send:
-            send_idx = torch.from_numpy(np.concatenate(h.send_indices).astype(A.Ti)).to(dev)
+            send_idx = torch.from_numpy(np.concatenate(h.send_indices).astype(Tk)).to(dev)
         else:
             send_idx = None
         self.has_halo = (n_send + n_recv) > 0
@@ -249,7 +302,7 @@ class VectorPlan:
             rpb = _capi.load().hpcla_spmv_rows_per_block()
             nblk = (A.nrows_local + rpb - 1) // rpb
             flags = torch.empty(nblk, dtype=torch.int32, device=dev)
-            _capi.call(f"hpcla_classify_blocks_{sfx}", dptr(A.rowptr_target), dptr(self.colval_split),
+            _capi.call(f"hpcla_classify_blocks_{sfx}", dptr(self.rowptr_of(A)), dptr(self.colval_split),
                        A.nrows_local, 0, self.n_own, rpb, dptr(flags), s)
             self.interior = torch.nonzero(flags == 0).flatten().to(torch.int32).contiguous()
             self.boundary = torch.nonzero(flags != 0).flatten().to(torch.int32).contiguous()
@@ -269,7 +322,7 @@ class VectorPlan:
             ghost, _ng = self.ghost_tensor_ptr()
             chosen = ctypes.c_int(1)
             try:
-                _capi.call(f"hpcla_spmv_tune_block_order_f64_{sfx}", dptr(A.rowptr_target), dptr(self.colval_split),
+                _capi.call(f"hpcla_spmv_tune_block_order_f64_{sfx}", dptr(self.rowptr_of(A)), dptr(self.colval_split),
                            dptr(A.nzval), dptr(x.v), ghost, self.n_own, dptr(scratch), A.nrows_local, A.nnz, 0, s,
                            ctypes.byref(chosen))
             except _capi.HPCLAError as exc:        # an optional performance step must not take A*x down with it
@@ -278,10 +331,17 @@ class VectorPlan:
                 chosen = ctypes.c_int(1)
             self.block_group = int(chosen.value)
             self.block_group_measured = (A.nrows_local + 255) // 256 >= 4096      # the tuner's own threshold (64 launches)
-            A._block_order_hint = self.block_group       # the tuner left it registered for this matrix
+            # the tuner left it registered for the rowptr array it was given: the matrix's, or this plan's Int32 copy
+            owner = self if self.narrowed else A
+            owner._block_order_hint = A._block_order_hint = self.block_group
             if self.block_group > 1:
                 import weakref
-                A._block_order_finalizer = weakref.finalize(A, _unhint_block_order, A.rowptr_target.data_ptr())
+                owner._block_order_finalizer = weakref.finalize(owner, _unhint_block_order, self.rowptr_of(A).data_ptr())
+
+    def rowptr_of(self, A: "HPCSparseMatrix"):
+        """The ``rowptr`` the kernels of this plan read for matrix A: A's own device array, or -- narrowed plan -- the
+        plan's Int32 copy (equal contents for every matrix that shares the plan: the structural hash covers rowptr)."""
+        return self._rowptr32 if self.narrowed else A.rowptr_target
 
     def ghost_tensor_ptr(self) -> Tuple[ctypes.c_void_p, int]:
         g = ctypes.c_void_p()
@@ -311,13 +371,16 @@ _vector_plan_cache: Dict[tuple, VectorPlan] = {}
 def get_vector_plan(A: "HPCSparseMatrix", x: HPCVector) -> VectorPlan:
     """src/sparse.jl:1992-2001."""
     key = (A._ensure_hash(), x.structural_hash, str(A.T), str(A.Ti), "ROCArray")
+    if A.Ti == np.dtype(np.int64) and not narrowing_enabled():
+        key += ("wide",)                       # HPCLA_NARROW_INDICES=0: a plan of its own, on the Int64 kernels
     plan = _vector_plan_cache.get(key)
     if plan is None:
         plan = VectorPlan(A, x)
         plan.key = key
         _vector_plan_cache[key] = plan
-    if getattr(A, "_block_order_hint", 1) != plan.block_group:
-        _hint_block_order(A, plan.block_group)
+    if getattr(plan if plan.narrowed else A, "_block_order_hint", 1) != plan.block_group:
+        _hint_block_order(A, plan)
+    A._block_order_hint = plan.block_group
     return plan
 
 
@@ -328,16 +391,19 @@ def _unhint_block_order(ptr: int) -> None:
         pass
 
 
-def _hint_block_order(A, group: int) -> None:
-    """Tell the library the block order of SpMV launches over THIS matrix (keyed by its rowptr device pointer, which
-    several matrices of one structure do not share); the hint goes when the matrix does (a host-side table entry:
-    no device work in the finaliser)."""
+def _hint_block_order(A, plan: VectorPlan) -> None:
+    """Tell the library the block order of SpMV launches over THIS matrix under this plan (keyed by the rowptr device
+    pointer the kernels read: the matrix's own array, which several matrices of one structure do not share, or a
+    narrowed plan's Int32 copy, which they do); the hint goes when the owner of that array does (a host-side table
+    entry: no device work in the finaliser)."""
     import weakref
-    ptr = A.rowptr_target.data_ptr()
-    _capi.call("hpcla_spmv_block_order_hint", ptr, int(group))
-    A._block_order_hint = group
-    if group > 1 and not getattr(A, "_block_order_finalizer", None):
-        A._block_order_finalizer = weakref.finalize(A, _unhint_block_order, ptr)
+    group = int(plan.block_group)
+    owner = plan if plan.narrowed else A
+    ptr = plan.rowptr_of(A).data_ptr()
+    _capi.call("hpcla_spmv_block_order_hint", ptr, group)
+    owner._block_order_hint = group
+    if group > 1 and not getattr(owner, "_block_order_finalizer", None):
+        owner._block_order_finalizer = weakref.finalize(owner, _unhint_block_order, ptr)
 
 
 def clear_plan_cache() -> None:
@@ -496,7 +562,7 @@ class HPCSparseMatrix:
             return False
         h = ctypes.c_void_p()
         rc = _capi.load().hpcla_packed_create_i32(
-            ctypes.byref(h), dptr(self.rowptr_target), dptr(plan.colval_split), dptr(self.nzval),
+            ctypes.byref(h), dptr(plan.rowptr_of(self)), dptr(plan.colval_split), dptr(self.nzval),
             self.nrows_local, self.nnz, plan.n_own, 0, dptr(plan.interior) if plan.has_halo else None,
             plan.n_interior if plan.has_halo else 0, current_stream_ptr())
         if rc == -5:        # HPCLA_ERR_UNSUPPORTED: not packable, keep CSR
@@ -642,13 +708,13 @@ def _spmv_into(y: HPCVector, A: HPCSparseMatrix, x: HPCVector, plan: VectorPlan)
     pk = A._packed_for(plan)
     if pk is not None:
         _capi.call("hpcla_spmv_dist_packed_f64_i32", plan.halo if plan.has_halo else None, A.backend.rccl,
-                   pk, dptr(A.rowptr_target), dptr(plan.colval_split), dptr(A.nzval), dptr(x.v),
+                   pk, dptr(plan.rowptr_of(A)), dptr(plan.colval_split), dptr(A.nzval), dptr(x.v),
                    plan.n_own, dptr(y.v), A.nrows_local, A.nnz, 0, dptr(plan.interior), plan.n_interior,
                    dptr(plan.boundary), plan.n_boundary, None, None, current_stream_ptr())
         return
     sfx = "i64" if plan.is_i64 else "i32"
     _capi.call(f"hpcla_spmv_dist_f64_{sfx}", plan.halo if plan.has_halo else None,
-               dptr(A.rowptr_target), dptr(plan.colval_split), dptr(A.nzval), dptr(x.v), plan.n_own,
+               dptr(plan.rowptr_of(A)), dptr(plan.colval_split), dptr(A.nzval), dptr(x.v), plan.n_own,
                dptr(y.v), A.nrows_local, A.nnz, 0, dptr(plan.interior), plan.n_interior,
                dptr(plan.boundary), plan.n_boundary, current_stream_ptr())
 
@@ -683,13 +749,13 @@ def mul_dot_(y: HPCVector, A: HPCSparseMatrix, x: HPCVector, out) -> HPCVector:
     pk = A._packed_for(plan)
     if pk is not None:
         _capi.call("hpcla_spmv_dist_packed_f64_i32", plan.halo if plan.has_halo else None, A.backend.rccl,
-                   pk, dptr(A.rowptr_target), dptr(plan.colval_split), dptr(A.nzval), dptr(x.v),
+                   pk, dptr(plan.rowptr_of(A)), dptr(plan.colval_split), dptr(A.nzval), dptr(x.v),
                    plan.n_own, dptr(y.v), A.nrows_local, A.nnz, 0, dptr(plan.interior), plan.n_interior,
                    dptr(plan.boundary), plan.n_boundary, dptr(out), dptr(work), current_stream_ptr())
         return y
     sfx = "i64" if plan.is_i64 else "i32"
     _capi.call(f"hpcla_spmv_dist_dot_f64_{sfx}", plan.halo if plan.has_halo else None, A.backend.rccl,
-               dptr(A.rowptr_target), dptr(plan.colval_split), dptr(A.nzval), dptr(x.v), plan.n_own,
+               dptr(plan.rowptr_of(A)), dptr(plan.colval_split), dptr(A.nzval), dptr(x.v), plan.n_own,
                dptr(y.v), A.nrows_local, A.nnz, 0, dptr(plan.interior), plan.n_interior,
                dptr(plan.boundary), plan.n_boundary, dptr(out), dptr(work), current_stream_ptr())
     return y

@@ -50,11 +50,16 @@ def main():
 
     # HPCLA_MR_TYPES=i32,i64 (default both): the test file gives the larger rank counts one index type each --
     # ranks that share a GPU time-slice it, so the suite's wall time grows with ranks x cases
+    # "i64": Int64 matrices on NARROWED plans (the default: Int32 kernels); "i64wide": HPCLA_NARROW_INDICES=0, the
+    # Int64 kernels themselves
     types = [t for t in os.environ.get("HPCLA_MR_TYPES", "i32,i64").split(",") if t]
-    for Ti in [np.int32 if t == "i32" else np.int64 for t in types]:
+    for tname in types:
+        assert tname in ("i32", "i64", "i64wide"), tname
+        Ti = np.int32 if tname == "i32" else np.int64
+        os.environ["HPCLA_NARROW_INDICES"] = "0" if tname == "i64wide" else "1"
         backend = hp.backend_rocm_mpi(np.float64, Ti)
         comm = backend.comm
-        tag = f"[rank {rank}/{nranks} {np.dtype(Ti).name} mode={mode} windows={backend.peer_windows}]"
+        tag = f"[rank {rank}/{nranks} {tname} mode={mode} windows={backend.peer_windows}]"
 
         cases = []
         # stencil slab: rows partitioned uniformly, 2 boundary lines per interior rank
@@ -119,6 +124,8 @@ def main():
             got = y.local_values()
             assert np.array_equal(got, want), f"{tag} {name}: A*x differs, max err {np.abs(got - want).max()}"
             plan = hp.get_vector_plan(A, x)
+            assert plan.narrowed == (tname == "i64") and plan.is_i64 == (tname == "i64wide"), (tag, name)
+            assert plan.colval_split.dtype == (torch.int64 if tname == "i64wide" else torch.int32), (tag, name)
             if nranks > 1 and mode in ("(default)", "push") and backend.peer_windows:
                 assert plan.push or not plan.has_halo, f"{tag} {name}: push transport not attached"
             # repeated in-place products (same x): ghost buffers are reused / double-buffered
@@ -287,6 +294,31 @@ def timeout_case(torch, dist, hp, orc, rank, nranks):
                                        (rows.colidx[rows.rowptr[r]:rows.rowptr[r + 1]] >= hi)) for r in ghost_rows])
         assert bad[ghost_rows[needs_ghost]].all(), "a row that needs ghost values was computed from stale ghosts"
         assert plan.timed_out()
+        # a DEAD plan must drain at once.  The status word is sticky and every wait reads it on its first
+        # failed poll, so steps enqueued behind the expiry cost (almost) nothing -- before, each of them spun out the
+        # full bound again (8 steps = 8 timeouts; 100 enqueued CG iterations = 300).
+        import time
+        bound = float(os.environ["HPCLA_PUSH_TIMEOUT_S"])
+        t0 = time.perf_counter()
+        for _ in range(8):
+            hp.mul_(y, A, x)
+        torch.cuda.synchronize()
+        dt_steps = time.perf_counter() - t0
+        assert dt_steps < 0.5 * bound, f"8 steps on a dead plan took {dt_steps:.2f} s (bound {bound} s): not draining at once"
+        assert np.isnan(y.local_values()[ghost_rows[needs_ghost]]).all()
+        # ... and the same for a whole CG call: 6 iterations = 6 halo waits + 12 all-reduces (+ 1 in the setup) enqueued
+        # with no host in the loop.  The communicator's first all-reduce spins out ONE bound (nobody answers), sets the
+        # communicator's sticky word, and everything behind it returns poison at once.
+        ws = hp.CGWorkspace(x, 8)
+        t0 = time.perf_counter()
+        cplan, fused = hp.cg_setup(A, x, ws)
+        hp.cg_iterate(A, ws, cplan, fused, 6)
+        torch.cuda.synchronize()
+        dt_cg = time.perf_counter() - t0
+        assert dt_cg < 1.8 * bound, f"a 6-iteration CG call on a dead plan took {dt_cg:.2f} s (bound {bound} s)"
+        assert np.isnan(ws.hist[1:7].cpu().numpy()).all(), "CG history behind an expired exchange must be NaN"
+        print(f"[rank 0] dead plan drains: 8 steps {dt_steps * 1e3:.1f} ms, 6 CG iterations {dt_cg:.2f} s "
+              f"(bound {bound} s)", flush=True)
         try:
             hp.dot(y, y)
         except hp.ExchangeTimeout as exc:

@@ -34,9 +34,10 @@ def _spawn(nranks, env_extra, timeout=600):
 @pytest.mark.parametrize("nranks", [2, 3, 4])
 def test_push_transport_ranks_exchange(nranks):
     """Default mode (push): halo by direct peer stores, scalar all-reduce through the communicator window.
-    2 ranks run both index types; 3 ranks Int64 (the reference's default Ti), 4 ranks Int32 -- the ranks share the
-    one GPU of the box by time-slicing, so wall time grows with ranks x cases."""
-    env = {"HPCLA_PUSH_TIMEOUT_S": "30", "HPCLA_MR_TYPES": {2: "i32,i64", 3: "i64", 4: "i32"}[nranks]}
+    2 ranks run both index types (Int64 -- the reference's default Ti -- on NARROWED plans, i.e. the Int32 kernels);
+    3 ranks Int64 with narrowing off (the Int64 kernels themselves), 4 ranks Int32 -- the ranks share the one GPU of
+    the box by time-slicing, so wall time grows with ranks x cases."""
+    env = {"HPCLA_PUSH_TIMEOUT_S": "30", "HPCLA_MR_TYPES": {2: "i32,i64", 3: "i64wide", 4: "i32"}[nranks]}
     if nranks == 3:
         # every launch in the XCD-grouped block order (groups of 2 row blocks: the test matrices are far below the
         # size the plan would measure at), so the FUSED kernels' interior runs walk it too -- same bits required
@@ -55,9 +56,9 @@ def test_expired_exchange_wait_poisons_the_result_and_raises():
 @pytest.mark.parametrize("nranks", [2, 3])
 def test_spmm_panel_order_within_tolerance(nranks):
     """HPCLA_SPMM_ORDER=panel (exchange overlapped chunk by chunk, config 5 at N > 1): same sums in a different
-    ORDER -- 1e-12 relative and the componentwise |A||B| bound against the oracle; 2 ranks with both index types, 3 ranks
-    (every rank has two neighbours per chunk-set plan, three chunk-sets) with Int64."""
-    env = {"HPCLA_PUSH_TIMEOUT_S": "30", "HPCLA_SPMM_ORDER_TEST": "1", "HPCLA_MR_TYPES": "i32,i64" if nranks == 2 else "i64"}
+    ORDER -- 1e-12 relative and the componentwise |A||B| bound against the oracle; 2 ranks with both index types (Int64
+    narrowed), 3 ranks (every rank has two neighbours per chunk-set plan, three chunk-sets) on the Int64 kernels."""
+    env = {"HPCLA_PUSH_TIMEOUT_S": "30", "HPCLA_SPMM_ORDER_TEST": "1", "HPCLA_MR_TYPES": "i32,i64" if nranks == 2 else "i64wide"}
     if nranks == 3:
         env["HPCLA_SPMM_PANELS"] = "3"
     assert _spawn(nranks, env) == 0

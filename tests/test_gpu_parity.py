@@ -66,10 +66,12 @@ def test_spmv_golden_raw_abi(hp, orc, golden, gpu_backend_i32, name, Ti, base):
 
 
 @pytest.mark.parametrize("name", ["spmv_tridiagonal", "spmv_nonsquare", "spmv_local_ctor"])
-@pytest.mark.parametrize("which", ["i32", "i64"])
-def test_spmv_golden_host_layer(hp, golden, gpu_backend_i32, gpu_backend_i64, name, which):
-    """Reads like test/test_vector_multiplication.jl:42-118: HPCSparseMatrix(A, backend) * HPCVector."""
+@pytest.mark.parametrize("which", ["i32", "i64", "i64wide"])
+def test_spmv_golden_host_layer(hp, golden, gpu_backend_i32, gpu_backend_i64, name, which, monkeypatch):
+    """Reads like test/test_vector_multiplication.jl:42-118: HPCSparseMatrix(A, backend) * HPCVector.
+    "i64": the reference's default Ti on a NARROWED plan (Int32 kernels); "i64wide": the Int64 kernels."""
     import scipy.sparse as sp
+    monkeypatch.setenv("HPCLA_NARROW_INDICES", "0" if which == "i64wide" else "1")
     backend = gpu_backend_i32 if which == "i32" else gpu_backend_i64
     case = golden[name]
     A = sp.coo_matrix((case["V"], (np.array(case["I"]) - 1, np.array(case["J"]) - 1)),
@@ -735,15 +737,69 @@ def test_split_spmm_per_rank_matches_reference_pipeline(hp, orc, gpu_backend_i32
         np.testing.assert_array_equal(C.cpu().numpy(), want)
 
 
-def test_spmv_int64_moderate_scale(hp, orc, gpu_backend_i64):
+@pytest.mark.parametrize("narrow", [True, False])
+def test_spmv_int64_moderate_scale(hp, orc, gpu_backend_i64, narrow, monkeypatch):
+    """Int64 matrix (the reference's default Ti = Int, src/backends.jl:348,369).  narrow: the plan keeps Int32 copies of
+    rowptr / split colval and launches the Int32 kernels (the matrix keeps its Int64 arrays); HPCLA_NARROW_INDICES=0:
+    the Int64 kernels.  Indices are not results: the same bits either way."""
+    import torch
+    monkeypatch.setenv("HPCLA_NARROW_INDICES", "1" if narrow else "0")
     N = 1500
     rows = orc.poisson2d_rows(N, N, 0, N * N)
     A = hp.HPCSparseMatrix_local(rows.rowptr, rows.colidx, rows.vals, N * N, gpu_backend_i64)
     assert A.rowptr.dtype == np.int64 and A.colval.dtype == np.int64
     xg = orc.fill_uniform(0, N * N, orc.SEED_X)
-    y = (A @ hp.HPCVector.from_global(xg, gpu_backend_i64)).local_values()
+    x = hp.HPCVector.from_global(xg, gpu_backend_i64)
+    y = (A @ x).local_values()
     want = orc.spmv(rows.rowptr, rows.colidx, rows.vals, xg)
     np.testing.assert_array_equal(y, want)
+    plan = hp.get_vector_plan(A, x)
+    assert plan.narrowed == narrow and plan.is_i64 == (not narrow)
+    assert plan.colval_split.dtype == (torch.int32 if narrow else torch.int64)
+    assert plan.rowptr_of(A).dtype == (torch.int32 if narrow else torch.int64)
+    assert A.rowptr_target.dtype == torch.int64 and A.colval_target().dtype == torch.int64      # the matrix keeps its type
+    if narrow:
+        np.testing.assert_array_equal(plan.rowptr_of(A).cpu().numpy(), rows.rowptr)
+    # a second matrix of the same structure shares the plan (and its Int32 rowptr copy), other values
+    A2 = hp.HPCSparseMatrix_local(rows.rowptr, rows.colidx, 2.0 * rows.vals, N * N, gpu_backend_i64)
+    assert hp.get_vector_plan(A2, x) is plan
+    np.testing.assert_array_equal((A2 @ x).local_values(), orc.spmv(rows.rowptr, rows.colidx, 2.0 * rows.vals, xg))
+    # fused p.Ap and SpMM go through the same narrowed arrays
+    out = torch.zeros(1, dtype=torch.float64, device="cuda")
+    yy = x.similar()
+    hp.mul_dot_(yy, A, x, out)
+    np.testing.assert_array_equal(yy.local_values(), want)
+    Bg = np.stack([xg, 0.5 - xg, xg * xg, 1.0 + xg], axis=1)
+    C = A @ hp.HPCMatrix.from_global(Bg, gpu_backend_i64)
+    Cw = orc.spmm(rows.rowptr, rows.colidx, rows.vals, np.ascontiguousarray(Bg))
+    np.testing.assert_array_equal(C.local_values(), Cw)
+
+
+def test_narrowing_entries_raw_abi(hp, gpu_backend_i32):
+    """hpcla_remap_i64_to_i32 / hpcla_narrow_i64_to_i32: values, index_base, and the overflow word."""
+    import ctypes
+    import torch
+    rng = np.random.default_rng(5)
+    n, m = 100003, 777
+    for base in (0, 1):
+        cv = rng.integers(0, m, n).astype(np.int64) + base
+        cmap = (rng.permutation(m).astype(np.int32) + base)
+        d_in, d_map = torch.from_numpy(cv).cuda(), torch.from_numpy(cmap).cuda()
+        d_out = torch.empty(n, dtype=torch.int32, device="cuda")
+        hp._capi.call("hpcla_remap_i64_to_i32", d_in.data_ptr(), d_map.data_ptr(), d_out.data_ptr(), n, base, None)
+        np.testing.assert_array_equal(d_out.cpu().numpy(), cmap[cv - base])
+    src = torch.from_numpy(np.array([0, 5, 2**31 - 1, 17], dtype=np.int64)).cuda()
+    dst = torch.empty(4, dtype=torch.int32, device="cuda")
+    ovf = torch.zeros(1, dtype=torch.int32, device="cuda")
+    hp._capi.call("hpcla_narrow_i64_to_i32", src.data_ptr(), dst.data_ptr(), 4, ovf.data_ptr(), None)
+    assert dst.cpu().tolist() == [0, 5, 2**31 - 1, 17] and int(ovf.item()) == 0
+    src[1] = 2**31
+    hp._capi.call("hpcla_narrow_i64_to_i32", src.data_ptr(), dst.data_ptr(), 4, ovf.data_ptr(), None)
+    assert int(ovf.item()) == 1
+    lib = hp._capi.load()
+    assert lib.hpcla_remap_i64_to_i32(None, None, None, 5, 0, None) != 0
+    assert lib.hpcla_remap_i64_to_i32(src.data_ptr(), dst.data_ptr(), dst.data_ptr(), 4, 2, None) != 0
+    assert lib.hpcla_narrow_i64_to_i32(None, None, -1, None, None) != 0
 
 
 def test_fused_spmv_dot_and_cg_update(hp, orc, gpu_backend_i32):
@@ -826,12 +882,13 @@ def test_cg_graph_replay_is_bit_identical_to_eager(hp, orc, gpu_backend_i32, fus
     np.testing.assert_array_equal(x1.local_values(), x2.local_values())
 
 
-@pytest.mark.parametrize("which", ["i32", "i64"])
-def test_cg_native_loop_same_bits_as_one_call_per_kernel(hp, orc, gpu_backend_i32, gpu_backend_i64, which):
+@pytest.mark.parametrize("which", ["i32", "i64", "i64wide"])
+def test_cg_native_loop_same_bits_as_one_call_per_kernel(hp, orc, gpu_backend_i32, gpu_backend_i64, which, monkeypatch):
     """hpcla_cg_iterations_f64_* enqueues k iterations in ONE host call (no Python / Julia in the loop): per
     iteration the launches of hpcla_spmv_dist_dot, hpcla_cg_residual and hpcla_cg_direction with the same
     arguments -- so iterate and residual history equal the three-calls-per-iteration loop bit for bit; a reused
     workspace and a solve continued in two pieces (7 + 6 iterations) change nothing either."""
+    monkeypatch.setenv("HPCLA_NARROW_INDICES", "0" if which == "i64wide" else "1")
     backend = gpu_backend_i32 if which == "i32" else gpu_backend_i64
     N = 18
     rows = orc.poisson3d_rows(N, N, N, 0, N ** 3)

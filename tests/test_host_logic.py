@@ -358,3 +358,32 @@ def test_xcd_group_order_is_a_bijection():
     G, l = 64, 6
     got = [index(b, 8 * G * 4, l) for b in range(0, 8 * G, 8)]          # XCD 0's first G workgroups
     assert got == list(range(G))
+
+
+def test_narrowing_decision_of_int64_plans(hp, monkeypatch):
+    """sparse.can_narrow_indices: an Int64 matrix's plan streams Int32 indices iff everything an index array of the
+    plan can hold fits -- row pointers (nnz), split columns (own offsets, then positions in the ghost segment) and send
+    indices.  Every BASELINE configuration fits per GPU; a synthetic ghost segment past 2^31 must be REFUSED (and so
+    must nnz >= 2^31), 1-based callers lose one value."""
+    from hpcla_amd.sparse import INT32_MAX, can_narrow_indices, narrowing_enabled
+    assert INT32_MAX == 2**31 - 1
+    # BASELINE shapes per GPU: config 2 (4096^2), config 3 whole (8192^2), config 4 share, config 5 share
+    assert can_narrow_indices(83_869_696, 16_777_216, 16_777_216, 0)
+    assert can_narrow_indices(335_511_552, 67_108_864, 67_108_864, 0)
+    assert can_narrow_indices(117_178_368, 16_777_216, 16_777_216, 2 * 262_144)
+    assert can_narrow_indices(62_500_000, 2_097_152, 2_097_152, 14_680_064)
+    # refusals
+    assert not can_narrow_indices(1000, 10, 10, 2**31)                    # ghost positions past Int32
+    assert not can_narrow_indices(1000, 10, 2**30, 2**30)                 # n_own + n_ghost == 2^31
+    assert can_narrow_indices(1000, 10, 2**30, 2**30 - 1)                 # largest split column = 2^31 - 2
+    assert not can_narrow_indices(2**31, 10, 10, 0)                       # rowptr[end] = nnz does not fit
+    assert can_narrow_indices(2**31 - 1, 10, 10, 0)
+    assert not can_narrow_indices(2**31 - 1, 10, 10, 0, index_base=1)     # Julia's 1-based rowptr[end] = nnz + 1
+    assert not can_narrow_indices(10, 2**31, 10, 0)
+    # the switch
+    monkeypatch.setenv("HPCLA_NARROW_INDICES", "0")
+    assert not narrowing_enabled()
+    monkeypatch.setenv("HPCLA_NARROW_INDICES", "1")
+    assert narrowing_enabled()
+    monkeypatch.delenv("HPCLA_NARROW_INDICES")
+    assert narrowing_enabled()
