@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turn the rocprofv3 outputs of `benchmarks/run_r03_pmc.sh TAG` (under gpurun_out/) into the tracked evidence under
+"""Turn the rocprofv3 outputs of `./run_gpu_checks.sh TAG pmc_all` (under gpurun_out/) into the tracked evidence under
 profiles/: kernel stats + trace CSV of the headline command, the PMC CSVs, and profiles/traffic_latest.json -- HBM bytes
 per launch of the headline kernel and, under "workloads", per launch / per CG iteration of every sub-record of the bench
 line -- corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE counts 128-byte requests

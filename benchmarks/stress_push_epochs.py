@@ -1,7 +1,7 @@
 """One-off stress of the push transport's epoch / ack / double-buffer protocol: thousands of dependent steps
 x <- A x / 8 with a window all-reduce (norm) every step and NO host synchronisation, on N ranks (sharing the GPU if
 there are fewer GPUs), checked at the end against the oracle's recurrence.
-Run:  python -c "import hpcla_launch..."  -- see benchmarks/run_r02v.sh"""
+Run:  python -c "import hpcla_launch..."  -- see benchmarks/EXPERIMENTS.md"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

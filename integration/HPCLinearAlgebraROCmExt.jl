@@ -143,9 +143,17 @@ function _attach_halo_window(h::Ptr{Cvoid}, halo::Ptr{Cvoid}, mpicomm::MPI.Comm,
 end
 
 # ---- device half of the VectorPlan, cached next to the reference plan -----------------------------------
-mutable struct ROCVectorPlan{Ti}
+# Tk = index type of the KERNEL arrays of the plan.  The parent's default is Ti = Int (src/backends.jl:348,369), so a
+# caller who follows the defaults hands over Int64 structure arrays although every realistic per-GPU share fits Int32.
+# Indices are never results: when nnz and the split column space (own offsets, then positions in the ghost segment)
+# fit, the plan keeps Int32 copies (hpcla_remap_i64_to_i32, hpcla_narrow_i64_to_i32) and every launch over it takes
+# the _i32 kernels -- 12 instead of 16 bytes per stored entry, the same bits of y.  A and its arrays keep their type.
+# HPCLA_NARROW_INDICES=0 keeps Int64 structures on the Int64 kernels.
+mutable struct ROCVectorPlan{Tk}
     halo::Ptr{Cvoid}                 # hpcla_halo_plan_t* (C_NULL when there are no neighbours)
-    colval_split::ROCVector{Ti}      # 0-based split columns: < n_own -> x.v, >= n_own -> ghost segment
+    colval_split::ROCVector{Tk}      # 0-based split columns: < n_own -> x.v, >= n_own -> ghost segment
+    rowptr0::ROCVector{Tk}           # 0-based rowptr of the kernels (equal for every matrix that shares the plan: the
+                                     # structural hash covers rowptr); carries the block-order hint
     interior::ROCVector{Int32}
     boundary::ROCVector{Int32}
     n_own::Int
@@ -153,38 +161,64 @@ mutable struct ROCVectorPlan{Ti}
 end
 const _rocm_plans = IdDict{Any,Any}()    # reference plan object -> ROCVectorPlan (freed by clear_rocm_plan_cache!)
 
+# everything an index array of the plan can hold must fit Int32 (0-based arrays: rowptr reaches nnz, split columns
+# n_own + n_ghost - 1, send indices n_own - 1)
+_can_narrow(nnz, nrows, n_own, n_ghost) =
+    get(ENV, "HPCLA_NARROW_INDICES", "1") != "0" && nnz <= typemax(Int32) && nrows <= typemax(Int32) &&
+    n_own + n_ghost <= typemax(Int32)
+_kernel_index_type(::Type{Int32}, nnz, nrows, n_own, n_ghost) = Int32
+_kernel_index_type(::Type{Int64}, nnz, nrows, n_own, n_ghost) = _can_narrow(nnz, nrows, n_own, n_ghost) ? Int32 : Int64
+
 function _device_plan(A::HPCSparseMatrix{T,Ti,B}, x::HPCVector{T,B}, plan) where {T,Ti,B<:ROCBackend}
     get!(_rocm_plans, plan) do
         n_own = length(x.v)
+        nnz = length(A.nzval)
+        n_ghost = sum(length, plan.recv_perm; init=0)
+        Tk = _kernel_index_type(Ti, nnz, A.nrows_local, n_own, n_ghost)
         # compressed column -> split column (0-based): own columns map to their offset in x.v,
         # ghosts to n_own + position in the ghost segment (recv_perm order == ascending global column)
-        cmap = Vector{Ti}(undef, length(A.col_indices))
-        cmap[plan.local_dst_indices] .= plan.local_src_indices .- one(Ti)
+        cmap = Vector{Tk}(undef, length(A.col_indices))
+        cmap[plan.local_dst_indices] .= Tk.(plan.local_src_indices .- one(Ti))
         off = n_own
         for perm in plan.recv_perm
-            cmap[perm] .= Ti.(off .+ (0:length(perm)-1)); off += length(perm)
+            cmap[perm] .= Tk.(off .+ (0:length(perm)-1)); off += length(perm)
         end
         cmap_d = ROCVector(cmap)
-        split = similar(A.colval_target)
-        nnz = length(A.nzval)
+        split = ROCVector{Tk}(undef, nnz)
         if Ti === Int32
             _check(@ccall(LIB.hpcla_remap_i32(_ptr(A.colval_target)::Ptr{Cvoid}, _ptr(cmap_d)::Ptr{Cvoid},
                    _ptr(split)::Ptr{Cvoid}, nnz::Int64, 1::Cint, _stream()::Ptr{Cvoid})::Cint), "hpcla_remap_i32")
-        else
+        elseif Tk === Int64
             _check(@ccall(LIB.hpcla_remap_i64(_ptr(A.colval_target)::Ptr{Cvoid}, _ptr(cmap_d)::Ptr{Cvoid},
                    _ptr(split)::Ptr{Cvoid}, nnz::Int64, 1::Cint, _stream()::Ptr{Cvoid})::Cint), "hpcla_remap_i64")
+        else        # Int64 matrix, narrowed plan: Int64 compressed columns in, Int32 split columns out
+            _check(@ccall(LIB.hpcla_remap_i64_to_i32(_ptr(A.colval_target)::Ptr{Cvoid}, _ptr(cmap_d)::Ptr{Cvoid},
+                   _ptr(split)::Ptr{Cvoid}, nnz::Int64, 1::Cint, _stream()::Ptr{Cvoid})::Cint), "hpcla_remap_i64_to_i32")
+        end
+        # The split-column copy is 0-based while A.rowptr_target keeps the reference's 1-based values; the SpMV entry
+        # points apply ONE index_base to rowptr and colval alike, so the plan keeps a 0-based rowptr copy (in Tk) and
+        # every kernel over the plan is called with index_base = 0.
+        rp0_wide = A.rowptr_target .- one(Ti)
+        rp0 = if Tk === Ti
+            rp0_wide
+        else
+            narrow = ROCVector{Int32}(undef, length(rp0_wide)); ovf = AMDGPU.zeros(UInt32, 1)
+            _check(@ccall(LIB.hpcla_narrow_i64_to_i32(_ptr(rp0_wide)::Ptr{Cvoid}, _ptr(narrow)::Ptr{Cvoid},
+                   length(rp0_wide)::Int64, _ptr(ovf)::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_narrow_i64_to_i32")
+            Array(ovf)[1] == 0 || error("HPCLinearAlgebraROCmExt: rowptr does not fit Int32")
+            narrow
         end
         halo = Ref{Ptr{Cvoid}}(C_NULL)
         segments = [Int.(A.col_indices[perm] .- x.partition[r + 1])       # 0-based row in its owner (rank r, 0-based)
                     for (r, perm) in zip(plan.recv_rank_ids, plan.recv_perm)]
         interior = ROCVector{Int32}(undef, 0); boundary = ROCVector{Int32}(undef, 0)
         if !isempty(plan.send_rank_ids) || !isempty(plan.recv_rank_ids)
-            send_idx = ROCVector(Ti.(reduce(vcat, plan.send_indices; init=Ti[]) .- one(Ti)))   # 0-based
+            send_idx = ROCVector(Tk.(reduce(vcat, plan.send_indices; init=Ti[]) .- one(Ti)))   # 0-based, the kernels' type
             AMDGPU.synchronize()
             _check(@ccall(LIB.hpcla_halo_plan_create(halo::Ptr{Ptr{Cvoid}}, _rccl(A.backend.comm)::Ptr{Cvoid},
                    length(plan.send_rank_ids)::Cint, Int32.(plan.send_rank_ids)::Ptr{Int32},
                    Int64.(length.(plan.send_indices))::Ptr{Int64}, _ptr(send_idx)::Ptr{Cvoid},
-                   (Ti === Int64 ? 1 : 0)::Cint, length(plan.recv_rank_ids)::Cint,
+                   (Tk === Int64 ? 1 : 0)::Cint, length(plan.recv_rank_ids)::Cint,
                    Int32.(plan.recv_rank_ids)::Ptr{Int32}, Int64.(length.(plan.recv_perm))::Ptr{Int64},
                    1::Cint)::Cint), "hpcla_halo_plan_create")
             rpb = @ccall LIB.hpcla_spmv_rows_per_block()::Cint
@@ -192,8 +226,7 @@ function _device_plan(A::HPCSparseMatrix{T,Ti,B}, x::HPCVector{T,B}, plan) where
             # `split` is 0-based (hpcla_remap output) while A.rowptr_target is 1-based: the classifier applies
             # ONE index_base to both arrays, so it gets the 0-based rowptr copy and index_base = 0 -- with
             # base 1 the first ghost column (== n_own) would count as owned and its row block as interior
-            rp0 = _rowptr0(A)
-            if Ti === Int32
+            if Tk === Int32
                 _check(@ccall(LIB.hpcla_classify_blocks_i32(_ptr(rp0)::Ptr{Cvoid}, _ptr(split)::Ptr{Cvoid},
                        A.nrows_local::Int64, 0::Cint, n_own::Int64, rpb::Cint, _ptr(flags)::Ptr{Cvoid},
                        _stream()::Ptr{Cvoid})::Cint), "hpcla_classify_blocks_i32")
@@ -211,7 +244,7 @@ function _device_plan(A::HPCSparseMatrix{T,Ti,B}, x::HPCVector{T,B}, plan) where
                                 (n_own, segments))
         # Block order of this matrix's SpMV launches, MEASURED once here (hpcla_spmv_tune_block_order_*: 64 launches of
         # the split-column SpMV into a scratch vector; the library keeps the fastest order registered for the rowptr
-        # array the launches use -- the 0-based copy, _rowptr0).  No reference counterpart: a performance setting only,
+        # array the launches use -- the plan's 0-based copy).  No reference counterpart: a performance setting only,
         # every order gives the same bits.
         if A.nrows_local > 0 && nnz > 0
             scratch = similar(A.nzval, A.nrows_local)
@@ -219,8 +252,7 @@ function _device_plan(A::HPCSparseMatrix{T,Ti,B}, x::HPCVector{T,B}, plan) where
             halo[] != C_NULL &&
                 _check(@ccall(LIB.hpcla_halo_ghost_ptr(halo[]::Ptr{Cvoid}, gh::Ptr{Ptr{Cvoid}}, ngh::Ptr{Int64})::Cint), "hpcla_halo_ghost_ptr")
             chosen = Ref{Cint}(1)
-            rp0 = _rowptr0(A)
-            if Ti === Int32
+            if Tk === Int32
                 _check(@ccall(LIB.hpcla_spmv_tune_block_order_f64_i32(_ptr(rp0)::Ptr{Cvoid}, _ptr(split)::Ptr{Cvoid},
                        _ptr(A.nzval)::Ptr{Cvoid}, _ptr(x.v)::Ptr{Cvoid}, gh[]::Ptr{Cvoid}, n_own::Int64, _ptr(scratch)::Ptr{Cvoid},
                        A.nrows_local::Int64, nnz::Int64, 0::Cint, _stream()::Ptr{Cvoid}, chosen::Ptr{Cint})::Cint),
@@ -232,21 +264,16 @@ function _device_plan(A::HPCSparseMatrix{T,Ti,B}, x::HPCVector{T,B}, plan) where
                        "hpcla_spmv_tune_block_order_f64_i64")
             end
         end
-        ROCVectorPlan{Ti}(halo[], split, interior, boundary, n_own, segments)
+        ROCVectorPlan{Tk}(halo[], split, rp0, interior, boundary, n_own, segments)
     end
 end
-
-# The split-column copy made by hpcla_remap is 0-based, while A.rowptr_target keeps the reference's
-# 1-based values; the SpMV entry points apply ONE index_base to rowptr and colval alike, so the
-# extension keeps a 0-based rowptr copy next to the plan and calls the split kernels with index_base = 0.
-_rowptr0(A) = get!(() -> A.rowptr_target .- one(eltype(A.rowptr_target)), _rocm_plans, (A, :rowptr0))
 
 function _spmv_dist!(y::ROCVector{T}, A::HPCSparseMatrix{T,Ti,B}, x::HPCVector{T,B}) where {T<:Float64,Ti,B<:ROCBackend}
     plan = get_vector_plan(A, x)                   # reference host plan, memoized (src/sparse.jl:1992-2001)
     d = _device_plan(A, x, plan)
-    rp0 = _rowptr0(A)
+    rp0 = d.rowptr0
     nnz = length(A.nzval)
-    if Ti === Int32
+    if eltype(rp0) === Int32                       # the PLAN's index type: Int32 also for a narrowed Int64 matrix
         _check(@ccall(LIB.hpcla_spmv_dist_f64_i32(d.halo::Ptr{Cvoid}, _ptr(rp0)::Ptr{Cvoid},
                _ptr(d.colval_split)::Ptr{Cvoid}, _ptr(A.nzval)::Ptr{Cvoid}, _ptr(x.v)::Ptr{Cvoid}, d.n_own::Int64,
                _ptr(y)::Ptr{Cvoid}, A.nrows_local::Int64, nnz::Int64, 0::Cint, _ptr(d.interior)::Ptr{Cvoid},
@@ -352,8 +379,8 @@ function rocm_cg_iterations(A::HPCSparseMatrix{T,Ti,B}, b::HPCVector{T,B}, iters
     c = _rccl(A.backend.comm)
     _check(@ccall(LIB.hpcla_nrm2sq_f64(c::Ptr{Cvoid}, _ptr(r)::Ptr{Cvoid}, n::Int64, _ptr(hist)::Ptr{Cvoid},
            _ptr(work)::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_nrm2sq_f64")          # hist[1] = sum r0^2
-    rp0 = _rowptr0(A); nnz = length(A.nzval)
-    if Ti === Int32
+    rp0 = d.rowptr0; nnz = length(A.nzval)
+    if eltype(rp0) === Int32
         _check(@ccall(LIB.hpcla_cg_iterations_f64_i32(d.halo::Ptr{Cvoid}, c::Ptr{Cvoid}, _ptr(rp0)::Ptr{Cvoid},
                _ptr(d.colval_split)::Ptr{Cvoid}, _ptr(A.nzval)::Ptr{Cvoid}, n::Int64, nnz::Int64, 0::Cint,
                _ptr(d.interior)::Ptr{Cvoid}, length(d.interior)::Int64, _ptr(d.boundary)::Ptr{Cvoid},
@@ -402,10 +429,10 @@ const _spmm_plans = IdDict{Any,Any}()     # (reference plan, k) -> (halo handle,
 # (row-major rows travel as contiguous k-doubles).  The Python twin additionally swaps a neighbour's requested
 # rows for its WHOLE slice when more than half of it is needed (config 5; linearalgebrampi.jl_amd/sparse.py
 # whole_slice_lists) -- an optimisation of the lists, not of this binding.
-function _spmm_halo(A::HPCSparseMatrix{T,Ti,B}, plan, d::ROCVectorPlan{Ti}, k::Int) where {T,Ti,B<:ROCBackend}
+function _spmm_halo(A::HPCSparseMatrix{T,Ti,B}, plan, d::ROCVectorPlan{Tk}, k::Int) where {T,Ti,Tk,B<:ROCBackend}
     get!(_spmm_plans, (plan, k)) do
         halo = Ref{Ptr{Cvoid}}(C_NULL)
-        send_idx = ROCVector(Ti.(reduce(vcat, plan.send_indices; init=Ti[]) .- one(Ti)))
+        send_idx = ROCVector(Tk.(reduce(vcat, plan.send_indices; init=Ti[]) .- one(Ti)))
         AMDGPU.synchronize()
         # flags = 1 (HPCLA_HALO_SINGLE_BUFFER): this plan is driven through halo_begin / halo_end and its consumers
         # take the ghost pointer from the host while the exchange is in flight, so a one-column B (width 1) must
@@ -413,7 +440,7 @@ function _spmm_halo(A::HPCSparseMatrix{T,Ti,B}, plan, d::ROCVectorPlan{Ti}, k::I
         _check(@ccall(LIB.hpcla_halo_plan_create_ex(halo::Ptr{Ptr{Cvoid}}, _rccl(A.backend.comm)::Ptr{Cvoid},
                length(plan.send_rank_ids)::Cint, Int32.(plan.send_rank_ids)::Ptr{Int32},
                Int64.(length.(plan.send_indices))::Ptr{Int64}, _ptr(send_idx)::Ptr{Cvoid},
-               (Ti === Int64 ? 1 : 0)::Cint, length(plan.recv_rank_ids)::Cint,
+               (Tk === Int64 ? 1 : 0)::Cint, length(plan.recv_rank_ids)::Cint,
                Int32.(plan.recv_rank_ids)::Ptr{Int32}, Int64.(length.(plan.recv_perm))::Ptr{Int64},
                k::Cint, 1::Cint)::Cint), "hpcla_halo_plan_create_ex")
         A.backend.comm isa CommMPI &&
@@ -421,8 +448,8 @@ function _spmm_halo(A::HPCSparseMatrix{T,Ti,B}, plan, d::ROCVectorPlan{Ti}, k::I
                                 (d.n_own, d.segments))
         rpb = @ccall LIB.hpcla_spmm_rows_per_block()::Cint          # SpMM row blocks are smaller than SpMV's
         flags = AMDGPU.zeros(Int32, cld(A.nrows_local, rpb))
-        rp0 = _rowptr0(A)
-        if Ti === Int32
+        rp0 = d.rowptr0
+        if Tk === Int32
             _check(@ccall(LIB.hpcla_classify_blocks_i32(_ptr(rp0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
                    A.nrows_local::Int64, 0::Cint, d.n_own::Int64, rpb::Cint, _ptr(flags)::Ptr{Cvoid},
                    _stream()::Ptr{Cvoid})::Cint), "hpcla_classify_blocks_i32")
@@ -441,8 +468,8 @@ end
 
 function _spmm_split!(Crow, A::HPCSparseMatrix{T,Ti,B}, d, Brow, ghost::Ptr{Cvoid}, k::Int, blocks) where {T,Ti,B}
     isempty(blocks) && return
-    rp0 = _rowptr0(A); nnz = length(A.nzval)
-    if Ti === Int32
+    rp0 = d.rowptr0; nnz = length(A.nzval)
+    if eltype(rp0) === Int32
         _check(@ccall(LIB.hpcla_spmm_split_f64_i32(_ptr(rp0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
                _ptr(A.nzval)::Ptr{Cvoid}, _ptr(Brow)::Ptr{Cvoid}, k::Int64, ghost::Ptr{Cvoid}, k::Int64, d.n_own::Int64,
                _ptr(Crow)::Ptr{Cvoid}, k::Int64, A.nrows_local::Int64, nnz::Int64, k::Cint, 0::Cint,
@@ -536,8 +563,8 @@ function clear_rocm_plan_cache!()
     for d in values(_rocm_plans); d isa ROCVectorPlan && destroy(d.halo); end
     for st in values(_spmm_plans); destroy(st[1]); end
     for st in values(_rocm_exec); destroy(st[1]); end
-    for (k, v) in _rocm_plans       # the 0-based rowptr copies carry the block-order hints: removed before the arrays go
-        k isa Tuple && k[2] === :rowptr0 && @ccall LIB.hpcla_spmv_block_order_hint(_ptr(v)::Ptr{Cvoid}, 0::Cint)::Cint
+    for d in values(_rocm_plans)    # the plans' rowptr copies carry the block-order hints: removed before the arrays go
+        d isa ROCVectorPlan && @ccall LIB.hpcla_spmv_block_order_hint(_ptr(d.rowptr0)::Ptr{Cvoid}, 0::Cint)::Cint
     end
     empty!(_rocm_plans); empty!(_spmm_plans); empty!(_rocm_exec); empty!(_merge_lists)
     return nothing

@@ -25,7 +25,10 @@ from typing import List
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "_build", "libhpcla_oracle.so")
+# HPCLA_ORACLE_SANITIZE=1: the AddressSanitizer + UBSan build (`make -C oracle asan`); the process must have libasan
+# preloaded (tests/test_sanitizers.py does that for a child pytest)
+_SANITIZE = os.environ.get("HPCLA_ORACLE_SANITIZE", "") == "1"
+_LIB_PATH = os.path.join(_HERE, "_build", "libhpcla_oracle_asan.so" if _SANITIZE else "libhpcla_oracle.so")
 
 SEED_STRUCT = 0xA11CE
 SEED_VALS = 0xB0B
@@ -38,7 +41,7 @@ def build(force: bool = False) -> str:
     if force or not os.path.exists(_LIB_PATH) or (
         os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "hpcla_oracle.c"))
     ):
-        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["asan"] if _SANITIZE else []) + (["-B"] if force else []))
     return _LIB_PATH
 
 

@@ -1,5 +1,9 @@
 #!/bin/bash
-# Helper for gpurun calls.  usage: ./run_gpu_checks.sh TAG [steps...]   steps: pytest bench tune prof
+# THE runner for gpurun calls (round 4: the 60-odd one-off benchmarks/run_r02*.sh / run_r03*.sh launch scripts were folded
+# into the steps below or deleted; benchmarks/EXPERIMENTS.md keeps the table of what each measured, its log under profiles/
+# and the commit that holds the variant).
+# usage: ./run_gpu_checks.sh TAG [steps...]   steps: pytest smoke bench driverbench torchrun2 validate pmc_all cgtrace
+#        rehearse2 rehearse4 tune ... (see the case list)
 # Stops at the first step that is killed by its timeout (never start a GPU step after a hang).
 set -o pipefail
 mkdir -p gpurun_out
@@ -16,6 +20,50 @@ run() {  # run <timeout_s> <logfile> <cmd...>
 for st in $STEPS; do
   case $st in
     pytest) run 900 gpurun_out/${TAG}_pytest.log python -m pytest tests -m gpu -q -x; tail -5 gpurun_out/${TAG}_pytest.log;;
+    smoke)  run 300 gpurun_out/${TAG}_smoke.log python -c "import __graft_entry__ as g; g.smoke()"; tail -1 gpurun_out/${TAG}_smoke.log;;
+    driverbench)   # the bench line at the DRIVER's flags, with a short digest of every record
+      run 560 gpurun_out/${TAG}_bench.log python bench.py --gpus 1 --steps 20 --warmup 5
+      grep "^{" gpurun_out/${TAG}_bench.log | tail -1 > gpurun_out/${TAG}_bench.json
+      python3 benchmarks/digest_bench_line.py gpurun_out/${TAG}_bench.json;;
+    torchrun2)     # the N > 1 line under the driver's launcher, two ranks sharing the one GPU (rehearsal: timings mean nothing)
+      HPCLA_ALLOW_SHARED_GPU=1 run 600 gpurun_out/${TAG}_torchrun2.log python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 5 --warmup 2 ${REHEARSE_ARGS:---no-extras}
+      grep "^{" gpurun_out/${TAG}_torchrun2.log | tail -1 > gpurun_out/${TAG}_torchrun2.json
+      python3 benchmarks/digest_bench_line.py gpurun_out/${TAG}_torchrun2.json;;
+    rehearse2|rehearse4)  # bench.py starting its own ranks on the shared GPU
+      n=${st#rehearse}
+      HPCLA_ALLOW_SHARED_GPU=1 run 900 gpurun_out/${TAG}_reh$n.log python bench.py --gpus $n --steps 5 --warmup 2 ${REHEARSE_ARGS}
+      grep "^{" gpurun_out/${TAG}_reh$n.log | tail -1 > gpurun_out/${TAG}_reh$n.json
+      python3 benchmarks/digest_bench_line.py gpurun_out/${TAG}_reh$n.json;;
+    validate) "$0" "$TAG" pytest smoke driverbench torchrun2;;
+    pmc_all)       # kernel stats + FETCH_SIZE / WRITE_SIZE passes (separate runs) of the headline and of every sub-record;
+                   # then: python benchmarks/collect_profiles.py TAG rNN   (-> profiles/, traffic_latest.json)
+      cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
+      HEADARGS="--steps 10 --warmup 2 --no-cpu-baseline --no-strong --no-extras --no-packed"
+      # the plan's block-order measurement (64 launches of the SAME kernel under four orders) would sit in every per-kernel
+      # mean: the profiled runs take a fixed order instead, so every counted launch is a launch of the step
+      export HPCLA_BLOCK_ORDER=${PMC_ORDER_2D:-32}
+      run 300 gpurun_out/${TAG}_prof.log rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_prof -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-strong --no-extras --no-packed
+      for c in FETCH_SIZE WRITE_SIZE; do
+        run 300 gpurun_out/${TAG}_pmc_head_$c.log rocprofv3 --pmc $c --output-format csv -d gpurun_out/${TAG}_pmc_head_$c -- python3 bench.py $HEADARGS
+        for o in natural 8 64; do
+          HPCLA_BLOCK_ORDER=$o run 300 gpurun_out/${TAG}_pmc_head${o/natural/nat}_$c.log rocprofv3 --pmc $c --output-format csv -d gpurun_out/${TAG}_pmc_head${o/natural/nat}_$c -- python3 bench.py $HEADARGS
+        done
+        HPCLA_NARROW_INDICES=0 run 300 gpurun_out/${TAG}_pmc_i64_$c.log rocprofv3 --pmc $c --output-format csv -d gpurun_out/${TAG}_pmc_i64_$c -- python3 bench.py $HEADARGS --index i64
+        HPCLA_BLOCK_ORDER=${PMC_ORDER_3D:-64} run 300 gpurun_out/${TAG}_pmc_cg_$c.log rocprofv3 --pmc $c --output-format csv -d gpurun_out/${TAG}_pmc_cg_$c -- python3 bench.py --workload poisson3d_cg --steps 10 --warmup 5
+        run 300 gpurun_out/${TAG}_pmc_spmm2d_$c.log rocprofv3 --pmc $c --output-format csv -d gpurun_out/${TAG}_pmc_spmm2d_$c -- python3 bench.py --workload poisson2d_spmm --steps 5 --warmup 5
+        HPCLA_SPMM_COLS_MULT=8 run 300 gpurun_out/${TAG}_pmc_sprand8_$c.log rocprofv3 --pmc $c --output-format csv -d gpurun_out/${TAG}_pmc_sprand8_$c -- python3 bench.py --workload sprand_spmm --steps 5 --warmup 5
+        HPCLA_SPMM_COLS_MULT=1 run 300 gpurun_out/${TAG}_pmc_sprand1_$c.log rocprofv3 --pmc $c --output-format csv -d gpurun_out/${TAG}_pmc_sprand1_$c -- python3 bench.py --workload sprand_spmm --steps 5 --warmup 5
+      done
+      unset HPCLA_BLOCK_ORDER
+      # keep what is merged back small: only the counter CSVs and the stats
+      find gpurun_out/${TAG}_p* -type f ! -name '*counter_collection.csv' ! -name '*kernel_stats.csv' ! -name '*kernel_trace.csv' ! -name '*.log' -delete;;
+    cgtrace)       # kernel timeline of the CG iteration (fixed block order: see pmc_all)
+      cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
+      rm -rf gpurun_out/${TAG}_cgtrace
+      HPCLA_BLOCK_ORDER=${PMC_ORDER_3D:-64} run 300 gpurun_out/${TAG}_cgtrace.log rocprofv3 --kernel-trace --output-format csv -d gpurun_out/${TAG}_cgtrace -- python3 bench.py --workload poisson3d_cg --steps 40 --warmup 8
+      t=$(find gpurun_out/${TAG}_cgtrace -name '*kernel_trace.csv' | head -1)
+      python benchmarks/trace_gaps.py "$t" "CG 512x512x64, eager (${TAG})" > gpurun_out/${TAG}_cg_gaps.txt 2>&1
+      rm -rf gpurun_out/${TAG}_cgtrace; head -20 gpurun_out/${TAG}_cg_gaps.txt;;
     bench)  run 600 gpurun_out/${TAG}_bench.log python bench.py --steps 100 --warmup 10; tail -3 gpurun_out/${TAG}_bench.log;;
     tune)   run 600 gpurun_out/${TAG}_tune.log python benchmarks/tune_spmv.py ${TUNE_ARGS}; tail -25 gpurun_out/${TAG}_tune.log;;
     tune8k) run 900 gpurun_out/${TAG}_tune8k.log python benchmarks/tune_spmv.py --size 8192 --variants 16,100,101,102,20 --rounds 5 --reps 10; tail -8 gpurun_out/${TAG}_tune8k.log;;

@@ -109,6 +109,17 @@ def main():
         cases.append(("sprand_xpart", n3, lambda lo, hi: orc.sprand_rows(n3, 0.002, lo, hi),
                       orc.uniform_partition(n3, nranks), xp3))
 
+        # the pin at the reference's own sizes (tests/golden/pin_large.npz): laplacian_2d_sparse(10^4) and the
+        # generate_sparse(1000)-shaped matrix; x = u01(SEED_X) is the x of every case here, so `got` is also held to
+        # the fixture's exact-rational product below
+        with np.load(os.path.join(ROOT, "tests", "golden", "pin_large.npz"), allow_pickle=False) as z:
+            pin = {k: z[k] for k in z.files}
+        for which in ("lap", "gs"):
+            npin = int(pin[f"{which}_n"])
+            cases.append((f"pin_{which}", npin,
+                          lambda lo, hi, w=which, m=npin: orc.rows_from_coo(pin[f"{w}_I"], pin[f"{w}_J"], pin[f"{w}_V"], m, m, lo, hi),
+                          orc.uniform_partition(npin, nranks), orc.uniform_partition(npin, nranks)))
+
         kept = []                                   # (name, A, x, y, want): for the interleaved-plans check below
         for name, ng, gen, rp, xp in cases:
             lo, hi = int(rp[rank]), int(rp[rank + 1])
@@ -123,6 +134,14 @@ def main():
             torch.cuda.synchronize()
             got = y.local_values()
             assert np.array_equal(got, want), f"{tag} {name}: A*x differs, max err {np.abs(got - want).max()}"
+            if name.startswith("pin_"):             # ... and against the exact-rational product of the fixture
+                which = name[4:]
+                assert np.array_equal(xg, pin[f"{which}_x_u01"])
+                kk = np.diff(rows.rowptr).astype(np.float64)
+                absAx = orc.abs_spmv(rows.rowptr, rows.colidx, rows.vals, xg)
+                err = np.abs(got - pin[f"{which}_y_u01"][lo:hi])
+                u = 2.0 ** -53
+                assert np.all(err <= (kk * u / (1.0 - kk * u) + u) * absAx) and np.all(err <= 1e-12 * absAx), (tag, name)
             plan = hp.get_vector_plan(A, x)
             assert plan.narrowed == (tname == "i64") and plan.is_i64 == (tname == "i64wide"), (tag, name)
             assert plan.colval_split.dtype == (torch.int64 if tname == "i64wide" else torch.int32), (tag, name)

@@ -61,3 +61,14 @@ def gpu_backend_i32(hp):
 def gpu_backend_i64(hp):
     import numpy as np
     return hp.backend_rocm_serial(np.float64, np.int64)
+
+
+@pytest.fixture(scope="session")
+def pin_large():
+    """tests/golden/pin_large.npz (tests/golden/make_golden_large.py): the reference's own LARGER input definitions --
+    laplacian_2d_sparse(10^4), tools/benchmark_vs_petsc.jl:42-49, and a generate_sparse(1000)-shaped matrix,
+    tools/benchmark_single_rank.jl:48-71 -- with exact-rational products rounded once.  Data only; loaded with
+    numpy's non-executing loader."""
+    import numpy as np
+    with np.load(os.path.join(ROOT, "tests", "golden", "pin_large.npz"), allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}

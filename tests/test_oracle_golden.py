@@ -225,3 +225,82 @@ def test_widened_row_fixtures_are_self_consistent(golden):
     dx, W, eye = coo(c["Idx"], c["Jdx"], c["Vdx"], 8), np.diag(c["w"]), np.eye(8)
     assert np.max(np.abs(eye.T @ W @ dx + dx.T @ W @ eye - np.array(c["M_sum"]))) < TOL
     assert np.max(np.abs(dx.T @ W @ dx + eye.T @ W @ eye - np.array(c["H"]))) < TOL
+
+
+# ---------------------------------------------------------------------------------------------------
+# The pin at the sizes the reference itself defines (tests/golden/pin_large.npz, make_golden_large.py):
+# n = 10^4 (laplacian_2d_sparse, tools/benchmark_vs_petsc.jl:42-49) and n = 1000 x ~20 entries per row
+# (generate_sparse-shaped, tools/benchmark_single_rank.jl:48-71).  Expected values: exact rational
+# arithmetic, rounded once -- independent of the oracle.
+# ---------------------------------------------------------------------------------------------------
+U = 2.0 ** -53      # unit roundoff of fp64
+
+
+def _pin_case(pin, which):
+    n = int(pin[f"{which}_n"])
+    return dict(m=n, n=n, I=pin[f"{which}_I"], J=pin[f"{which}_J"], V=pin[f"{which}_V"])
+
+
+def _gamma_bound(orc, rows_all, x):
+    """Componentwise bound of a sequentially summed row: |fl(sum) - sum| <= gamma_k (|A||x|)_i with k = the row's
+    length (Higham, Accuracy and Stability, section 3.1: k products + k - 1 additions); plus half an ulp of the
+    correctly rounded expected value itself."""
+    k = np.diff(rows_all.rowptr).astype(np.float64)
+    absAx = orc.abs_spmv(rows_all.rowptr, rows_all.colidx, rows_all.vals, x)
+    return (k * U / (1.0 - k * U) + U) * absAx, absAx
+
+
+@pytest.mark.parametrize("which", ["lap", "gs"])
+@pytest.mark.parametrize("nranks", [1, 3])
+@pytest.mark.parametrize("Ti", [np.int32, np.int64])
+def test_oracle_pinned_at_reference_sizes(orc, pin_large, which, nranks, Ti):
+    case = _pin_case(pin_large, which)
+    n = case["n"]
+    rows_all = _rows(orc, case)
+    assert rows_all.nnz == len(case["V"])
+    # x = 1..n
+    case["x"] = np.arange(1, n + 1, dtype=np.float64)
+    y = _spmv_via_oracle(orc, case, nranks, Ti)
+    want = pin_large[f"{which}_y_int"]
+    if which == "lap":
+        # integer-valued matrix and vector: every product and partial sum is exact, any order gives these bits
+        np.testing.assert_array_equal(y, want)
+    else:
+        bound, absAx = _gamma_bound(orc, rows_all, case["x"])
+        assert np.all(np.abs(y - want) <= bound)
+        assert np.all(np.abs(y - want) <= 1e-12 * absAx)            # BASELINE's tolerance, componentwise
+    # x = u01(SEED_X, i): the oracle's generator must reproduce the fixture's x bit for bit, first
+    xu = pin_large[f"{which}_x_u01"]
+    np.testing.assert_array_equal(orc.fill_uniform(0, n, orc.SEED_X), xu)
+    case["x"] = xu
+    y = _spmv_via_oracle(orc, case, nranks, Ti)
+    want = pin_large[f"{which}_y_u01"]
+    bound, absAx = _gamma_bound(orc, rows_all, xu)
+    assert np.all(np.abs(y - want) <= bound), float(np.max(np.abs(y - want) / absAx))
+    assert np.all(np.abs(y - want) <= 1e-12 * absAx)
+    assert np.max(np.abs(y - want)) < TOL                           # and the reference's own 1e-10 absolute
+
+
+def test_oracle_generator_equals_reference_laplacian(orc, pin_large):
+    """laplacian_2d_sparse(10^4) (tools/benchmark_vs_petsc.jl:42-49) IS the 100 x 100 five-point matrix of
+    create_2d_laplacian (test/test_factorization.jl:60-102) that the oracle's poisson2d generator restates -- entry for
+    entry, which ties the generator used at BASELINE's sizes to a reference-defined input of n = 10^4."""
+    case = _pin_case(pin_large, "lap")
+    ref = _rows(orc, case)
+    got = orc.poisson2d_rows(100, 100, 0, 10_000)
+    np.testing.assert_array_equal(got.rowptr, ref.rowptr)
+    np.testing.assert_array_equal(got.colidx, ref.colidx)
+    np.testing.assert_array_equal(got.vals, ref.vals)
+
+
+def test_spgemm_oracle_pinned_on_the_published_product(orc, pin_large):
+    """A*A on laplacian_2d_sparse(10^4): the product behind the reference's one published number
+    (tools/benchmark_vs_petsc_results.txt:3-11).  Small integers: exact in every order, so pattern AND values of the
+    oracle's restatement (src/sparse.jl:991-1059) must equal the exact product."""
+    case = _pin_case(pin_large, "lap")
+    A = _rows(orc, case)
+    rp, col, val = orc.spgemm(A.rowptr, A.colidx, A.vals, A.rowptr, A.colidx, A.vals, case["n"])
+    sq = orc.rows_from_coo(pin_large["lap_sq_I"], pin_large["lap_sq_J"], pin_large["lap_sq_V"], case["n"], case["n"])
+    np.testing.assert_array_equal(rp, sq.rowptr)
+    np.testing.assert_array_equal(col, sq.colidx)
+    np.testing.assert_array_equal(val, sq.vals)

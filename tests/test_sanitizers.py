@@ -1,0 +1,52 @@
+"""Sanitizers where they can run: on the CPU (GPU AddressSanitizer / XNACK runs are not available on this pool).
+
+* the oracle's C restatement (`make -C oracle asan`: AddressSanitizer + UndefinedBehaviorSanitizer) under its own
+  golden tests -- `orc_spgemm`, `sprand_row`, the generators and the SpMV / SpMM loops index by hand, and agreement
+  with scipy would not notice a read one element past an array;
+* the C ABI's host-side argument validation, walked from a plain C program (tests/cabi/cabi_args.c) built with the
+  same sanitizers: no GPU is needed because every entry point validates before it touches HIP.
+"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _gcc_file(name):
+    return subprocess.check_output(["gcc", f"-print-file-name={name}"], text=True).strip()
+
+
+def test_oracle_under_address_and_ub_sanitizers():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "asan"])
+    libasan = _gcc_file("libasan.so")
+    assert os.path.isabs(libasan) and os.path.exists(libasan), "gcc has no libasan.so"
+    env = dict(os.environ, LD_PRELOAD=libasan, HPCLA_ORACLE_SANITIZE="1", OMP_NUM_THREADS="2",
+               ASAN_OPTIONS="detect_leaks=0:halt_on_error=1:abort_on_error=0",     # CPython itself leaks by design
+               UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_oracle_golden.py"),
+                          "-x", "-q", "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True,
+                         timeout=900)
+    tail = out.stdout[-3000:] + out.stderr[-3000:]
+    assert out.returncode == 0, tail
+    assert "AddressSanitizer" not in tail and "runtime error" not in tail, tail
+    assert " passed" in out.stdout
+    # the child really ran the instrumented build
+    probe = subprocess.run([sys.executable, "-c", "from oracle import oracle as o; o.lib(); print(o._LIB_PATH)"],
+                           cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert probe.returncode == 0 and probe.stdout.strip().endswith("libhpcla_oracle_asan.so"), probe.stdout + probe.stderr
+
+
+def test_cabi_argument_validation_under_sanitizers():
+    exe = os.path.join(ROOT, "tests", "cabi", "_build", "cabi_args_asan")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    libdir = os.path.join(ROOT, "linearalgebrampi.jl_amd")
+    subprocess.check_call(["gcc", "-std=c11", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined",
+                           "-fno-sanitize-recover=undefined", "-Wall", "-Werror=implicit-function-declaration",
+                           os.path.join(ROOT, "tests", "cabi", "cabi_args.c"), "-I", os.path.join(ROOT, "include"),
+                           "-L", libdir, "-lhpcla_rocm", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0:halt_on_error=1"))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "C-ABI argument validation PASS" in out.stdout
+    assert "AddressSanitizer" not in out.stderr and "runtime error" not in out.stderr, out.stderr[-2000:]
