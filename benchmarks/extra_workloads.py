@@ -17,11 +17,13 @@ import numpy as np
 HBM_PEAK_GBS = 8000.0
 
 
-def stored_traffic(key, applicable=True):
+def stored_traffic(key, applicable=True, world=1, share_note=""):
     """HBM bytes per launch / iteration measured by the builder's separate rocprofv3 --pmc passes of the same
     workload (profiles/traffic_latest.json, written by benchmarks/collect_profiles.py; corrected for gfx950 as
     MI355X_MICROARCH.md prescribes).  PMC counters cannot be read from inside the process, so the value is a
-    stored measurement and labelled as such; (None, reason) when this run's shape differs from the stored one."""
+    stored measurement and labelled as such; (None, reason) when this run's shape differs from the stored one.
+    At N > 1 the value is the SINGLE-RANK pass of the same per-GPU share (the records are weak-scaled: every rank runs
+    the stored workload's kernel on its own share) and the source says so; `share_note` names any difference."""
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic_latest.json")
     try:
         rec = json.load(open(path)).get("workloads", {}).get(key)
@@ -29,8 +31,13 @@ def stored_traffic(key, applicable=True):
         rec = None
     if not applicable or not rec:
         return None, "no stored PMC measurement for this shape (profiles/traffic_latest.json)"
-    return rec["hbm_bytes"], ("NOT measured by this run: PMC counters cannot be read from inside the process; value stored by "
-                              "the builder's rocprofv3 passes of this workload -- " + rec.get("source", path))
+    src = ("NOT measured by this run: PMC counters cannot be read from inside the process; value stored by "
+           "the builder's rocprofv3 passes of this workload -- " + rec.get("source", path))
+    if world > 1:
+        src += f"; N = {world}: the SINGLE-RANK passes of the same per-GPU share (per GPU, like `achieved`)"
+    if share_note:
+        src += "; " + share_note
+    return rec["hbm_bytes"], src
 
 
 _T0 = time.perf_counter()
@@ -59,7 +66,7 @@ XGMI_LINK_GBS = 153.0        # MI355X_MICROARCH.md / SURVEY 5: 7 xGMI links per 
 XGMI_LINKS = 7
 
 
-def _measure_spmm(args, job, hp, wl, A, B, k, world, dev, setup_s, metric, workload, traffic_key=None):
+def _measure_spmm(args, job, hp, wl, A, B, k, world, dev, setup_s, metric, workload, traffic_key=None, share_note=""):
     import torch
     _stamp("spmm: operands ready")
     C = A @ B
@@ -83,7 +90,7 @@ def _measure_spmm(args, job, hp, wl, A, B, k, world, dev, setup_s, metric, workl
     ms = elapsed / steps * 1e3
     b_alg = wl.spmm_algorithmic_bytes(A.nnz, A.nrows_local, A.ncols_compressed, k, 4)
     b_gather = A.nnz * (12 + 8 * k) + 4 * A.nrows_local + 8 * k * A.nrows_local    # every B row read per entry
-    traffic, traffic_source = stored_traffic(traffic_key, traffic_key is not None and world == 1)
+    traffic, traffic_source = stored_traffic(traffic_key, traffic_key is not None, world, share_note)
     out = {
         "metric": metric, "value": round(2.0 * k * A.nnz * world / (ms * 1e-3) / 1e9, 1),
         "unit": "GFLOP/s", "n_gpus": world, "steps": steps, "warmup": max(args.warmup, 5), "ms_per_step": round(ms, 4),
@@ -95,6 +102,7 @@ def _measure_spmm(args, job, hp, wl, A, B, k, world, dev, setup_s, metric, workl
                      "frac": round(b_alg / (device_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                      "traffic": traffic, "traffic_source": traffic_source,
                      "algorithmic_bytes_per_launch": b_alg,
+                     "block_order_group": int(job.max(hp.spmm_block_order_of(A, B))),
                      "gather_bytes_per_launch": b_gather,
                      "gather_gbs": round(b_gather / (device_ms * 1e-3) / 1e9, 1),
                      "note": "achieved = algorithmic bytes / device time per step (HIP events on the launch stream); algorithmic "
@@ -219,7 +227,8 @@ def run_record(args, backend, rank, world, job):
         b_iter = b_spmv + 96 * n_loc        # textbook unfused CG = SpMV + 96 n bytes
         b_moved = b_spmv + (64 if fused_eff else 96) * n_loc
         ms_iter = elapsed / iters_timed * 1e3
-        traffic, traffic_source = stored_traffic("poisson3d_cg_iteration", N == 512 and world == 1 and fused_eff)
+        traffic, traffic_source = stored_traffic("poisson3d_cg_iteration", N == 512 and fused_eff, world,
+                                                 "the distributed step adds two ghost planes (2 x 2 MiB) per iteration" if world > 1 else "")
         out = {
             "metric": "CG ms/iteration, 3-D 7-pt Poisson, fp64", "value": round(ms_iter, 4), "unit": "ms/iter",
             "n_gpus": world, "steps": iters_timed, "warmup": n_warm, "ms_per_step": round(ms_iter, 4),
@@ -352,8 +361,11 @@ def run_record(args, backend, rank, world, job):
         out = _measure_spmm(args, job, hp, wl, A, B, k, world, dev, setup_s,
                             "SpMM GFLOP/s (2*k*nnz/t), sprand ~29.8 nnz/row, k=16, fp64",
                             f"sprand-like {rows_loc} rows per GPU x {ncols} cols, nnz/GPU={A.nnz}, k={k}, C = A*B; {regime}",
-                            traffic_key=("sprand_spmm_b2e24" if (rows_loc, ncols) == (2_097_152, 16_777_216) else
-                                         "sprand_spmm_mall_sized" if (rows_loc, ncols) == (2_097_152, 2_097_152) else None))
+                            traffic_key=("sprand_spmm_b2e24" if rows_loc == 2_097_152 and ncols * 128 > (1 << 29) else
+                                         "sprand_spmm_mall_sized" if (rows_loc, ncols) == (2_097_152, 2_097_152) else None),
+                            share_note=("" if ncols in (16_777_216, 2_097_152) else
+                                        f"the stored pass has B = 16777216 rows (the 8-GPU gather set), this run {ncols}: both far "
+                                        "beyond the Infinity Cache, one 128-byte line per stored entry either way"))
         if order:
             out["config"]["workload"] += f"; HPCLA_SPMM_ORDER={order}"
             if saved_order is None:

@@ -94,6 +94,24 @@ int hpcla_spmv_split_f64_i64(const int64_t *rowptr, const int64_t *colval_split,
                              const int32_t *block_list, int64_t n_blocks, void *stream);
 int hpcla_spmv_rows_per_block(void);
 int hpcla_spmm_rows_per_block(void);
+/* SpMM twins of the two block-order entries below (no reference counterpart: src/sparse.jl:2391-2413 is a column loop
+ * over A*x in index order): the row blocks (hpcla_spmm_rows_per_block() rows each) of every SpMM launch over `rowptr`
+ * -- a contiguous launch, or the POSITIONS of a block list -- are walked in XCD groups of `group` blocks.  Measured per
+ * structure at plan time: the 5-point matrix loses with every group from 32 up, config 5's random pattern gains 2.6 %
+ * at 64-256 (profiles/r03_spmm_xcd_group.log); the tuner times the plan's own launch (results go to the caller's C:
+ * every launch writes the complete product) under natural / 16 / 64 / 256, keeps natural unless a group is >= 1 %
+ * faster, and skips launches below 4096 row blocks, k < 2 and odd k.  B_ghost == NULL: the unsplit kernel. */
+int hpcla_spmm_block_order_hint(const void *rowptr, int group);
+int hpcla_spmm_tune_block_order_f64_i32(const int32_t *rowptr, const int32_t *colval_split, const double *nzval,
+                                        const double *B_own, int64_t ldb_own, const double *B_ghost, int64_t ldb_ghost,
+                                        int64_t n_own, double *C, int64_t ldc, int64_t nrows, int64_t nnz, int k,
+                                        int index_base, const int32_t *block_list, int64_t n_blocks, void *stream,
+                                        int *chosen_group);
+int hpcla_spmm_tune_block_order_f64_i64(const int64_t *rowptr, const int64_t *colval_split, const double *nzval,
+                                        const double *B_own, int64_t ldb_own, const double *B_ghost, int64_t ldb_ghost,
+                                        int64_t n_own, double *C, int64_t ldc, int64_t nrows, int64_t nnz, int k,
+                                        int index_base, const int32_t *block_list, int64_t n_blocks, void *stream,
+                                        int *chosen_group);
 
 /* Optional plan-time performance hint (no reference counterpart: the reference launches one work-item per row in
  * index order, src/sparse.jl:2055-2066, 2081-2082): SpMV launches over the matrix whose `rowptr` device pointer is

@@ -53,6 +53,11 @@ _SIGNATURES = {
     "hpcla_spmv_tune_block_order_f64_i32": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp],
     "hpcla_spmv_tune_block_order_f64_i64": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp],
     "hpcla_spmm_rows_per_block": [],
+    "hpcla_spmm_block_order_hint": [_vp, _i32],
+    "hpcla_spmm_tune_block_order_f64_i32": [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32,
+                                            _vp, _i64, _vp, _vp],
+    "hpcla_spmm_tune_block_order_f64_i64": [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32,
+                                            _vp, _i64, _vp, _vp],
     "hpcla_remap_i32": [_vp, _vp, _vp, _i64, _i32, _vp],
     "hpcla_remap_i64": [_vp, _vp, _vp, _i64, _i32, _vp],
     "hpcla_remap_i64_to_i32": [_vp, _vp, _vp, _i64, _i32, _vp],

@@ -16,6 +16,10 @@
 // the fast one.  Algorithmic bytes: 12 B/nnz + 4 B/row + 8k B/row (C) + 8k B per B row touched.
 #include <stdlib.h>
 
+#include <atomic>
+#include <mutex>
+#include <unordered_map>
+
 #include "common.h"
 
 namespace hpcla {
@@ -234,16 +238,19 @@ __global__ __launch_bounds__(64 * LPR) void spmm_rowblock_vec_kernel(
     // on the 5-point matrix every group size from 32 to 1024 blocks loses (B rows of +-64-block neighbours land in other
     // L2s: +2.5 ... +20 %), 8 is neutral; config 5's random pattern gains 2.6 % at 64-256 (profiles/r03_spmm_xcd_group.log).
     // Default: the natural order.
+    // Round 4: the order is MEASURED per structure at plan time (hpcla_spmm_tune_block_order_*), natural unless a grouped
+    // one is >= 1 % faster, and it applies to the POSITIONS of a block list as well (config 5 at N > 1: every block is a
+    // boundary block and arrives through the list).
     const int glog = group_log2;
     int64_t blk = (int64_t)b;
-    if (block_list) blk = (int64_t)block_list[b];
-    else if (glog > 0) {
+    if (glog > 0) {
         const int64_t span = (int64_t)1 << (3 + glog), nb = (int64_t)nblocks;
         if (blk < nb - (nb & (span - 1))) {
             const int64_t xcd = blk & 7, q = blk >> 3;
             blk = ((((q >> glog) << 3) + xcd) << glog) + (q & (((int64_t)1 << glog) - 1));
         }
     }
+    if (block_list) blk = (int64_t)block_list[blk];
     const int64_t r0 = blk * RPB_MM;
     const int nr = (int)((nrows - r0) < RPB_MM ? (nrows - r0) : RPB_MM);
     const int64_t p0 = (int64_t)rowptr[r0] - base;
@@ -426,12 +433,31 @@ static inline int spmv_split_any(const int64_t *rp, const int64_t *cv, const dou
     return spmv_split_i64(rp, cv, nz, x, xg, n_own, y, nrows, nnz, base, nullptr, 0, stream, nullptr, -1);
 }
 
-static int spmm_group_log2()
+// ---- per-matrix block order of the SpMM launches (a performance hint: every order is a bijection) -------------------
+static std::mutex g_mm_order_mu;
+static std::unordered_map<const void *, int> g_mm_order;       // rowptr device pointer -> log2(group)
+static std::atomic<int> g_mm_order_count{0};
+
+static void set_spmm_block_order(const void *rowptr, int group_log2)
 {
-    const char *e = getenv("HPCLA_SPMM_XCD_GROUP");          // re-read per launch: the tuning harness switches it between launches
-    int g = e ? atoi(e) : 0, l = 0;
-    while (g > 1) { g >>= 1; ++l; }
-    return l > 12 ? 12 : l;
+    std::lock_guard<std::mutex> lock(g_mm_order_mu);
+    if (group_log2 <= 0) g_mm_order.erase(rowptr);
+    else g_mm_order[rowptr] = group_log2;
+    g_mm_order_count.store((int)g_mm_order.size(), std::memory_order_relaxed);
+}
+
+static int spmm_group_log2(const void *rowptr)
+{
+    const char *e = getenv("HPCLA_SPMM_XCD_GROUP");          // experiments: every launch; re-read per launch (the tuning harness switches it between launches)
+    if (e) {
+        int g = atoi(e), l = 0;
+        while (g > 1) { g >>= 1; ++l; }
+        return l > 12 ? 12 : l;
+    }
+    if (g_mm_order_count.load(std::memory_order_relaxed) == 0) return 0;
+    std::lock_guard<std::mutex> lock(g_mm_order_mu);
+    auto it = g_mm_order.find(rowptr);
+    return it == g_mm_order.end() ? 0 : it->second;
 }
 
 template <typename I>
@@ -498,6 +524,7 @@ static int spmm_launch(const I *rowptr, const I *colval, const double *nzval, co
         const bool cstage = cst_env != 0 && k <= 4 * lpr && c_rs == k;
         const bool k16 = h64 && cstage && k == KT && b_rs == KT && (!split || bg_rs == KT);
         const bool tail2 = (k % 4) != 0;                 // even k: the last column pair of a row is half a lane's share
+        const int glog2 = spmm_group_log2(rowptr);
 #define HPCLA_SPMM_VEC(SP, CH, H64, CST, K16F, LPRV)                                                     \
     do {                                                                                                \
         if (!H64 && tail2) HPCLA_SPMM_VECT(SP, CH, H64, CST, K16F, LPRV, (!H64));                       \
@@ -506,7 +533,7 @@ static int spmm_launch(const I *rowptr, const I *colval, const double *nzval, co
 #define HPCLA_SPMM_VECT(SP, CH, H64, CST, K16F, LPRV, T2)                                                \
     spmm_rowblock_vec_kernel<I, SP, CH, H64, CST, K16F, LPRV, (T2)><<<grid, dim3(64 * LPRV), 0, s>>>(     \
         rowptr, colval, nzval, B_own, b_rs, SP ? B_ghost : nullptr, SP ? bg_rs : 0, SP ? n_own : 0, C, c_rs, \
-        nrows, k, index_base, block_list, (uint32_t)launch_blocks, accumulate, spmm_group_log2())
+        nrows, k, index_base, block_list, (uint32_t)launch_blocks, accumulate, glog2)
 #define HPCLA_SPMM_VEC1(SP, CH)                                                                          \
     do {                                                                                                \
         if (lpr == 2) { if (cstage) HPCLA_SPMM_VEC(SP, CH, false, true, false, 2); else HPCLA_SPMM_VEC(SP, CH, false, false, false, 2); } \
@@ -542,6 +569,95 @@ static int spmm_launch(const I *rowptr, const I *colval, const double *nzval, co
 using namespace hpcla;
 
 HPCLA_API int hpcla_spmm_rows_per_block(void) { return RPB_MM; }
+
+HPCLA_API int hpcla_spmm_block_order_hint(const void *rowptr, int group)
+{
+    if (!rowptr) return set_error(HPCLA_ERR_INVALID, "spmm_block_order_hint: null rowptr");
+    if (group < 0 || group > 4096 || (group & (group - 1)) != 0)
+        return set_error(HPCLA_ERR_INVALID, "spmm_block_order_hint: group must be 0 or a power of two <= 4096");
+    int l = 0;
+    for (int g = group; g > 1; g >>= 1) ++l;
+    set_spmm_block_order(rowptr, l);
+    return HPCLA_OK;
+}
+
+// Plan-time choice of the SpMM block order BY MEASUREMENT, the SpMV tuner's twin (spmv.hip tune_block_order): the launch
+// the plan will make -- same arguments, results into the caller's C (every launch writes the complete, correct product) --
+// under the natural order and groups of 16 / 64 / 256 row blocks (of 64 rows), interleaved; natural unless a grouped order
+// is >= 1 % faster.  What was measured by hand (profiles/r03_spmm_xcd_group.log): the 5-point matrix LOSES with every
+// group from 32 up (the B rows of its +-64-block neighbours land in other L2s), config 5's random pattern GAINS 2.6 % at
+// 64-256 -- per structure, hence measured.
+template <typename I>
+static int spmm_tune_block_order(const I *rowptr, const I *colval_split, const double *nzval, const double *B_own,
+                                 int64_t ldb_own, const double *B_ghost, int64_t ldb_ghost, int64_t n_own, double *C,
+                                 int64_t ldc, int64_t nrows, int64_t nnz, int k, int index_base,
+                                 const int32_t *block_list, int64_t n_blocks, void *stream, int *chosen_group)
+{
+    if (chosen_group) *chosen_group = 1;
+    if (nrows < 0 || nnz < 0 || k < 0 || !rowptr) return set_error(HPCLA_ERR_INVALID, "spmm_tune_block_order: bad arguments");
+    set_spmm_block_order(rowptr, 0);
+    const int64_t launch_blocks = block_list ? n_blocks : (nrows + RPB_MM - 1) / RPB_MM;
+    // small launches live in the caches; k = 1 is the SpMV; odd k takes the generic-stride kernel, which keeps the natural order
+    if (launch_blocks < 4096 || nnz == 0 || k < 2 || (k & 1)) return HPCLA_OK;
+    const bool split = B_ghost != nullptr;                   // no ghost segment: the unsplit instantiation, like hpcla_spmm_csr_*
+    if (!C || !B_own) return set_error(HPCLA_ERR_INVALID, "spmm_tune_block_order: null B / C");
+    constexpr int NC = 4, ROUNDS = 4, REPS = 2;              // round 0 warms up and is not counted
+    const int cand[NC] = {0, 4, 6, 8};
+    float ms[NC][ROUNDS];
+    hipEvent_t e0, e1;
+    HPCLA_CHECK_HIP(hipEventCreate(&e0));
+    HPCLA_CHECK_HIP(hipEventCreate(&e1));
+    hipStream_t s = as_stream(stream);
+    int rc = HPCLA_OK;
+    for (int r = 0; r < ROUNDS && rc == HPCLA_OK; ++r)
+        for (int c = 0; c < NC && rc == HPCLA_OK; ++c) {
+            set_spmm_block_order(rowptr, cand[c]);
+            if (hipEventRecord(e0, s) != hipSuccess) { rc = set_error(HPCLA_ERR_HIP, "spmm_tune_block_order: event"); break; }
+            for (int i = 0; i < REPS && rc == HPCLA_OK; ++i)
+                rc = spmm_launch<I>(rowptr, colval_split, nzval, B_own, ldb_own, 1, B_ghost, ldb_ghost, n_own, split, C, ldc,
+                                    1, nrows, nnz, k, index_base, block_list, n_blocks, stream);
+            if (rc != HPCLA_OK) break;
+            if (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+                hipEventElapsedTime(&ms[c][r], e0, e1) != hipSuccess)
+                rc = set_error(HPCLA_ERR_HIP, "spmm_tune_block_order: timing");
+        }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    set_spmm_block_order(rowptr, 0);
+    if (rc != HPCLA_OK) return rc;
+    float med[NC];
+    for (int c = 0; c < NC; ++c) {                           // median of the three counted rounds
+        float a = ms[c][1], b = ms[c][2], d = ms[c][3];
+        med[c] = a > b ? (b > d ? b : (a > d ? d : a)) : (a > d ? a : (b > d ? d : b));
+    }
+    int best = 0;
+    for (int c = 1; c < NC; ++c)
+        if (med[c] < med[best]) best = c;
+    if (best != 0 && med[best] > 0.99f * med[0]) best = 0;
+    set_spmm_block_order(rowptr, cand[best]);
+    if (chosen_group) *chosen_group = 1 << cand[best];
+    return HPCLA_OK;
+}
+
+HPCLA_API int hpcla_spmm_tune_block_order_f64_i32(const int32_t *rowptr, const int32_t *colval_split, const double *nzval,
+                                                  const double *B_own, int64_t ldb_own, const double *B_ghost,
+                                                  int64_t ldb_ghost, int64_t n_own, double *C, int64_t ldc, int64_t nrows,
+                                                  int64_t nnz, int k, int index_base, const int32_t *block_list,
+                                                  int64_t n_blocks, void *stream, int *chosen_group)
+{
+    return spmm_tune_block_order<int32_t>(rowptr, colval_split, nzval, B_own, ldb_own, B_ghost, ldb_ghost, n_own, C, ldc,
+                                          nrows, nnz, k, index_base, block_list, n_blocks, stream, chosen_group);
+}
+
+HPCLA_API int hpcla_spmm_tune_block_order_f64_i64(const int64_t *rowptr, const int64_t *colval_split, const double *nzval,
+                                                  const double *B_own, int64_t ldb_own, const double *B_ghost,
+                                                  int64_t ldb_ghost, int64_t n_own, double *C, int64_t ldc, int64_t nrows,
+                                                  int64_t nnz, int k, int index_base, const int32_t *block_list,
+                                                  int64_t n_blocks, void *stream, int *chosen_group)
+{
+    return spmm_tune_block_order<int64_t>(rowptr, colval_split, nzval, B_own, ldb_own, B_ghost, ldb_ghost, n_own, C, ldc,
+                                          nrows, nnz, k, index_base, block_list, n_blocks, stream, chosen_group);
+}
 
 HPCLA_API int hpcla_spmm_csr_f64_i32(const int32_t *rowptr, const int32_t *colval,
                                      const double *nzval, const double *B, int64_t ldb,

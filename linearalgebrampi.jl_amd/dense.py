@@ -547,6 +547,52 @@ def spmm_exchange_bytes(A, B: HPCMatrix):
     return ent[6] * k * 8, ent[7] * k * 8, ent[8][0], ent[8][1]
 
 
+def _spmm_block_order(A, plan, rowptr, colval_split, is_i64, Bc, ghost, C, k, blocks) -> int:
+    """Block order of the SpMM launches over this structure, MEASURED once per (plan, k) after the first product
+    (``hpcla_spmm_tune_block_order_*``: the plan's own launch -- contiguous, or the larger of its two block lists --
+    under natural / 16 / 64 / 256-block XCD groups; every timed launch rewrites C with the same complete product).
+    ``HPCLA_SPMM_BLOCK_ORDER`` = auto (default) | natural | <G>.  Returns the group (1 = natural).  The hint is keyed
+    by the rowptr array the kernels read (the matrix's, or the narrowed plan's copy)."""
+    cache = plan.__dict__.setdefault("_spmm_order", {})
+    key = (k, rowptr.data_ptr())
+    if key in cache:
+        return cache[key]
+    want = os.environ.get("HPCLA_SPMM_BLOCK_ORDER", "auto").strip().lower()
+    group = 1
+    if want.isdigit():
+        group = max(1, int(want))
+        _capi.call("hpcla_spmm_block_order_hint", rowptr.data_ptr(), group)
+    elif want != "natural":
+        sfx = "i64" if is_i64 else "i32"
+        chosen = ctypes.c_int(1)
+        try:
+            _capi.call(f"hpcla_spmm_tune_block_order_f64_{sfx}", dptr(rowptr), dptr(colval_split), dptr(A.nzval),
+                       dptr(Bc), k, ghost, k, plan.n_own, dptr(C), k, A.nrows_local, A.nnz, k, 0,
+                       dptr(blocks) if blocks is not None else None, int(blocks.numel()) if blocks is not None else 0,
+                       current_stream_ptr(), ctypes.byref(chosen))
+            group = int(chosen.value)
+        except _capi.HPCLAError as exc:            # an optional performance step must not take A*B down with it
+            import sys
+            sys.stderr.write(f"hpcla: SpMM block-order measurement failed ({exc}); natural order\n")
+    cache[key] = group
+    if group > 1:
+        import weakref
+        from .sparse import _unhint_spmm_block_order
+        owner = plan if plan.narrowed else A
+        keep = owner.__dict__.setdefault("_spmm_order_finalizers", {})
+        if rowptr.data_ptr() not in keep:
+            keep[rowptr.data_ptr()] = weakref.finalize(owner, _unhint_spmm_block_order, rowptr.data_ptr())
+    return group
+
+
+def spmm_block_order_of(A, B: HPCMatrix) -> int:
+    """The block-order group the plan measured for ``A * B`` (1 = natural; 0 = not measured yet)."""
+    plan, ent = _spmm_plan(A, B)
+    k = int(B.A.shape[1])
+    rowptr = plan.rowptr_of(A) if (ent is None or ent[0] is None) else _entry_rowptr(A, plan, bool(ent[10]))
+    return plan.__dict__.get("_spmm_order", {}).get((k, rowptr.data_ptr()), 0)
+
+
 def spmm(A, B: HPCMatrix) -> HPCMatrix:
     """``A * B`` (src/sparse.jl:2391-2413): result has A's row partition and B's backend."""
     torch = _torch()
@@ -572,6 +618,7 @@ def spmm(A, B: HPCMatrix) -> HPCMatrix:
         _capi.call(f"hpcla_spmm_csr_f64_{sfx}", dptr(plan.rowptr_of(A)), dptr(plan.colval_split),
                    dptr(A.nzval), dptr(Bc), k, _capi.LAYOUT_ROW, dptr(C), k, _capi.LAYOUT_ROW,
                    A.nrows_local, A.nnz, k, 0, s)
+        _spmm_block_order(A, plan, plan.rowptr_of(A), plan.colval_split, plan.is_i64, Bc, None, C, k, None)
         return out
     halo, interior, boundary, _, colval_split, ghost = ent[:6]
     sfx = "i64" if ent[10] else "i32"
@@ -586,4 +633,7 @@ def spmm(A, B: HPCMatrix) -> HPCMatrix:
         _capi.call(f"hpcla_spmm_split_f64_{sfx}", dptr(rowptr), dptr(colval_split),
                    dptr(A.nzval), dptr(Bc), k, ghost, k, plan.n_own, dptr(C), k, A.nrows_local,
                    A.nnz, k, 0, dptr(boundary), int(boundary.numel()), s)
+    # (local launches only -- no exchange: the ranks need not agree on the order, every order is a bijection)
+    _spmm_block_order(A, plan, rowptr, colval_split, bool(ent[10]), Bc, ghost, C, k,
+                      boundary if boundary.numel() >= interior.numel() else interior)
     return out

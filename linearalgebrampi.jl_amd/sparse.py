@@ -391,6 +391,13 @@ def _unhint_block_order(ptr: int) -> None:
         pass
 
 
+def _unhint_spmm_block_order(ptr: int) -> None:
+    try:
+        _capi.load().hpcla_spmm_block_order_hint(ctypes.c_void_p(ptr), 0)
+    except Exception:                          # interpreter shutdown
+        pass
+
+
 def _hint_block_order(A, plan: VectorPlan) -> None:
     """Tell the library the block order of SpMV launches over THIS matrix under this plan (keyed by the rowptr device
     pointer the kernels read: the matrix's own array, which several matrices of one structure do not share, or a

@@ -57,6 +57,36 @@ for st in $STEPS; do
       unset HPCLA_BLOCK_ORDER
       # keep what is merged back small: only the counter CSVs and the stats
       find gpurun_out/${TAG}_p* -type f ! -name '*counter_collection.csv' ! -name '*kernel_stats.csv' ! -name '*kernel_trace.csv' ! -name '*.log' -delete;;
+    pmc_spmv_study)  # round 4: SQ / TCP / TA / UTCL1 counters of the SpMV kernel in five contexts (2-D, 2-D + dot, 3-D, 3-D + dot,
+                   # inside CG), one pass per small counter set (a pass that asks for more than a block's slots aborts the
+                   # profiler: gpurun_out/r03e_pmc_ta.log); then: python benchmarks/pmc_spmv_table.py TAG profiles/rNN_...txt
+      cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
+      run 300 gpurun_out/${TAG}_pmcs_plain.log python3 benchmarks/pmc_spmv_cases.py --reps ${PMC_REPS:-6} --manifest gpurun_out/${TAG}_pmcs_manifest.json
+      i=0
+      while read -r set; do
+        [ -z "$set" ] && continue
+        i=$((i+1))
+        run 150 gpurun_out/${TAG}_pmcs_$i.log rocprofv3 --pmc $set --output-format csv -d gpurun_out/${TAG}_pmcs_$i -- python3 benchmarks/pmc_spmv_cases.py --reps ${PMC_REPS:-6}
+      done <<'SETS'
+SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS
+SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INST_LEVEL_VMEM
+SQ_LEVEL_WAVES SQ_INST_LEVEL_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAVES SQ_INSTS_SMEM SQ_LDS_UNALIGNED_STALL SQ_INSTS_VMEM_WR
+TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum
+TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum
+TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum
+TCP_TCR_TCP_STALL_CYCLES_sum TCP_GATE_EN1_sum
+TCP_UTCL1_REQUEST_sum TCP_UTCL1_TRANSLATION_MISS_sum
+TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_TRANSLATION_MISS_UNDER_MISS_sum
+TCP_UTCL1_STALL_INFLIGHT_MAX_sum TCP_UTCL1_STALL_MULTI_MISS_sum
+TCP_UTCL1_STALL_UTCL2_REQ_OUT_OF_CREDITS_sum TCP_UTCL1_SERIALIZATION_STALL_sum
+TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum
+TCC_TAG_STALL_sum TCC_EA0_RDREQ_32B_sum
+GRBM_GUI_ACTIVE GRBM_UTCL2_BUSY
+TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum
+TA_DATA_STALLED_BY_TC_CYCLES_sum TA_FLAT_READ_WAVEFRONTS_sum
+SETS
+      find gpurun_out/${TAG}_pmcs_* -type f ! -name '*counter_collection.csv' ! -name '*.log' ! -name '*.json' -delete 2>/dev/null
+      python3 benchmarks/pmc_spmv_table.py ${TAG} gpurun_out/${TAG}_pmcs_table.txt | tail -60;;
     cgtrace)       # kernel timeline of the CG iteration (fixed block order: see pmc_all)
       cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
       rm -rf gpurun_out/${TAG}_cgtrace
