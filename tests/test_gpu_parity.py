@@ -618,6 +618,72 @@ def test_spmm_panel_accumulate_is_one_running_sum(hp, orc, gpu_backend_i32, k, T
     assert np.linalg.norm(C - seq) <= 1e-12 * np.linalg.norm(seq)
 
 
+@pytest.mark.parametrize("Ti", [np.int32, np.int64])
+def test_spmm_block_order_is_a_bijection_with_the_same_bits(hp, orc, gpu_backend_i32, Ti):
+    """hpcla_spmm_block_order_hint / hpcla_spmm_tune_block_order_*: XCD-grouped order of the 64-row blocks of an SpMM
+    launch -- of a contiguous launch AND of the positions of a block list.  Every group size visits every block exactly
+    once (ragged tail included), each C(r, c) is still one sequential sum: the reference's bits (src/sparse.jl:2391-2413)."""
+    import ctypes
+    import torch
+    n, k = 64 * 301 + 17, 16
+    rows = orc.sprand_rows(n, 6.0 / n, 0, n)
+    ci, cv = orc.compress_columns(rows)
+    B = orc.fill_uniform(0, n * k, 11).reshape(n, k)
+    want = orc.spmm(rows.rowptr.astype(np.int32), cv.astype(np.int32), rows.vals, np.ascontiguousarray(B[ci]))
+    sfx = "i32" if Ti == np.int32 else "i64"
+    s = torch.cuda.current_stream().cuda_stream
+    rp, dcv, nz, dB = _t(rows.rowptr.astype(Ti)), _t(cv.astype(Ti)), _t(rows.vals), _t(np.ascontiguousarray(B[ci]).ravel())
+    nblk = (n + 63) // 64
+    perm = np.random.default_rng(2).permutation(nblk).astype(np.int32)          # an arbitrary block list
+    lists = [None, _t(np.arange(nblk, dtype=np.int32)), _t(perm)]
+    lib = hp._capi.load()
+    try:
+        for G in (0, 2, 16, 64, 256, 4096):
+            hp._capi.call("hpcla_spmm_block_order_hint", rp.data_ptr(), G)
+            for lst in lists:
+                C = torch.full((n * k,), float("nan"), dtype=torch.float64, device="cuda")
+                hp._capi.call(f"hpcla_spmm_split_f64_{sfx}", rp.data_ptr(), dcv.data_ptr(), nz.data_ptr(), dB.data_ptr(), k,
+                              None, k, len(ci), C.data_ptr(), k, n, rows.nnz, k, 0,
+                              lst.data_ptr() if lst is not None else None, nblk if lst is not None else 0, s)
+                torch.cuda.synchronize()
+                np.testing.assert_array_equal(C.cpu().numpy().reshape(n, k), want)
+        for bad in (3, -1, 8192):
+            assert lib.hpcla_spmm_block_order_hint(ctypes.c_void_p(rp.data_ptr()), bad) != 0
+        assert lib.hpcla_spmm_block_order_hint(None, 4) != 0
+        # the tuner: below 4096 blocks it keeps the natural order unmeasured; odd k and k = 1 likewise
+        chosen = ctypes.c_int(-1)
+        C = torch.empty(n * k, dtype=torch.float64, device="cuda")
+        hp._capi.call(f"hpcla_spmm_tune_block_order_f64_{sfx}", rp.data_ptr(), dcv.data_ptr(), nz.data_ptr(), dB.data_ptr(), k,
+                      None, k, len(ci), C.data_ptr(), k, n, rows.nnz, k, 0, None, 0, s, ctypes.byref(chosen))
+        assert chosen.value == 1
+    finally:
+        lib.hpcla_spmm_block_order_hint(ctypes.c_void_p(rp.data_ptr()), 0)
+
+
+def test_spmm_plan_measures_block_order(hp, orc, gpu_backend_i32, gpu_backend_i64):
+    """A structure large enough to be measured (>= 4096 blocks of 64 rows): the first product leaves a measured group
+    from {1, 16, 64, 256} on the plan, every later product runs under it, and the bits stay the oracle's -- Int32 and a
+    narrowed Int64 matrix alike."""
+    import torch
+    N = 640                                        # 409 600 rows = 6400 blocks
+    rows = orc.poisson2d_rows(N, N, 0, N * N)
+    k = 4
+    Bg = orc.fill_uniform(0, N * N * k, 5).reshape(N * N, k)
+    want = orc.spmm(rows.rowptr.astype(np.int32), rows.colidx.astype(np.int32), rows.vals, Bg)
+    for backend in (gpu_backend_i32, gpu_backend_i64):
+        A = hp.HPCSparseMatrix_local(rows.rowptr, rows.colidx, rows.vals, N * N, backend)
+        B = hp.HPCMatrix.from_global(Bg, backend)
+        assert hp.spmm_block_order_of(A, B) == 0
+        C1 = (A @ B).local_values()
+        g = hp.spmm_block_order_of(A, B)
+        assert g in (1, 16, 64, 256), g
+        C2 = (A @ B).local_values()
+        np.testing.assert_array_equal(C1, want)
+        np.testing.assert_array_equal(C2, want)
+    hp.clear_spmm_cache()
+    hp.clear_plan_cache()
+
+
 def test_transpose_layout_conversion(hp, gpu_backend_i32):
     import torch
     for rows, cols in ((1, 1), (33, 16), (1000, 16), (65, 70)):
