@@ -392,7 +392,8 @@ int hpcla_halo_plan_create_ex(hpcla_halo_plan_t **plan, hpcla_comm_t *comm, int 
                               int width, int flags);
 /* Chain `plan` behind `leader`: both exchange on the LEADER's side stream, so exchanges begun one after the other
  * (hpcla_halo_begin(leader), hpcla_halo_begin(plan), ...) also RUN one after the other -- the chunk-sets of a
- * panel-ordered SpMM arrive in order instead of all at once.  Destroy the chained plans before their leader. */
+ * panel-ordered SpMM arrive in order instead of all at once.  The stream is shared by reference count and goes with
+ * the LAST plan of the chain, so the plans may be destroyed in any order. */
 int hpcla_halo_plan_chain(hpcla_halo_plan_t *plan, hpcla_halo_plan_t *leader);
 int hpcla_halo_plan_destroy(hpcla_halo_plan_t *plan);
 /* Push transport for this plan.  When the communicator's window is attached, create() places the ghost

@@ -358,6 +358,14 @@ function _check_exchange_health(backend)
         _check(@ccall(LIB.hpcla_halo_status(d.halo::Ptr{Cvoid}, flag::Ptr{Cint})::Cint), "hpcla_halo_status")
         flag[] == 0 || error("HPCLinearAlgebraROCmExt: a halo exchange timed out; the affected results are NaN")
     end
+    # the width-k plans of A * B and the device exchanges of execute_plan! poison their ghost buffers the same way
+    for (what, cache) in (("an SpMM ghost-row exchange", _spmm_plans), ("an execute_plan! exchange", _rocm_exec))
+        for st in values(cache)
+            st[1] == C_NULL && continue
+            _check(@ccall(LIB.hpcla_halo_status(st[1]::Ptr{Cvoid}, flag::Ptr{Cint})::Cint), "hpcla_halo_status")
+            flag[] == 0 || error("HPCLinearAlgebraROCmExt: $what timed out; the affected results are NaN")
+        end
+    end
     return nothing
 end
 _host_scalar(out, backend) = (v = Array(out)[1]; isnan(v) && _check_exchange_health(backend); v)

@@ -313,8 +313,7 @@ static void halo_free(hpcla_halo_plan *p)
     if (p->ghost) (void)hipFree(p->ghost);
     if (p->ev_ready) (void)hipEventDestroy(p->ev_ready);
     if (p->ev_done) (void)hipEventDestroy(p->ev_done);
-    if (p->side && p->owns_side) (void)hipStreamDestroy(p->side);
-    delete p;
+    delete p;                                      // the exchange stream goes with the last plan that shares it (side_owner)
 }
 
 template <typename I>
@@ -429,7 +428,9 @@ static int halo_plan_create_impl(hpcla_halo_plan_t **plan, hpcla_comm_t *comm, i
         // workgroups wherever a CU has room for it (next to the SpMV kernel none has: spmv_dist_impl)
         int prio_least = 0, prio_greatest = 0;
         HALO_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-        HALO_HIP(hipStreamCreateWithPriority(&p->side, hipStreamNonBlocking, prio_greatest));
+        p->side_owner = std::make_shared<hpcla::SideStream>();
+        HALO_HIP(hipStreamCreateWithPriority(&p->side_owner->s, hipStreamNonBlocking, prio_greatest));
+        p->side = p->side_owner->s;
     }
     HALO_HIP(hipEventCreateWithFlags(&p->ev_ready, hipEventDisableTiming));
     HALO_HIP(hipEventCreateWithFlags(&p->ev_done, hipEventDisableTiming));
@@ -464,12 +465,9 @@ HPCLA_API int hpcla_halo_plan_chain(hpcla_halo_plan_t *plan, hpcla_halo_plan_t *
     if (!plan || !leader || plan == leader) return set_error(HPCLA_ERR_INVALID, "halo_plan_chain: bad plans");
     if (!leader->side) return set_error(HPCLA_ERR_INVALID, "halo_plan_chain: the leader has no exchange stream");
     if (plan->side == leader->side) return HPCLA_OK;
-    if (plan->side) {
-        HPCLA_CHECK_HIP(hipStreamSynchronize(plan->side));
-        if (plan->owns_side) HPCLA_CHECK_HIP(hipStreamDestroy(plan->side));
-    }
+    if (plan->side) HPCLA_CHECK_HIP(hipStreamSynchronize(plan->side));
+    plan->side_owner = leader->side_owner;         // drops this plan's own stream (destroyed if nobody else shares it)
     plan->side = leader->side;
-    plan->owns_side = false;
     return HPCLA_OK;
 }
 

@@ -3,6 +3,7 @@
 #pragma once
 #include <rccl/rccl.h>
 
+#include <memory>
 #include <vector>
 
 #include "common.h"
@@ -67,6 +68,13 @@ struct hpcla_comm {
     uint64_t *ar_done_dev = nullptr;           // device: window all-reduces completed (read + bumped by the kernel)
 };
 
+namespace hpcla {
+struct SideStream {
+    hipStream_t s = nullptr;
+    ~SideStream() { if (s) (void)hipStreamDestroy(s); }
+};
+}  // namespace hpcla
+
 struct hpcla_halo_plan {
     hpcla_comm *comm = nullptr;
     int width = 1;
@@ -80,8 +88,11 @@ struct hpcla_halo_plan {
     int idx_is_i64 = 0;
     double *send_buf = nullptr;                // device, n_send_total * width (RCCL transport only)
     double *ghost = nullptr;                   // device, n_ghost * width (buffer 0)
-    hipStream_t side = nullptr;
-    bool owns_side = true;                     // false: the stream belongs to the plan this one is chained to
+    hipStream_t side = nullptr;                // == side_owner->s
+    // The exchange stream is SHARED by the plans of a chain (hpcla_halo_plan_chain) and goes with the LAST of them,
+    // whatever order they are destroyed in (round 3 let a follower borrow the leader's stream without tracking it:
+    // destroying the leader first left the followers with a dangling hipStream_t).
+    std::shared_ptr<hpcla::SideStream> side_owner;
     hipEvent_t ev_ready = nullptr, ev_done = nullptr;
     // contiguity of the caller's (ascending) interior block list, probed once per list
     const int32_t *probed_list = nullptr;

@@ -285,6 +285,18 @@ def clear_spmm_cache() -> None:
     from .sparse import _quiesce
     _quiesce(list(_spmm_backends.values()))
     _spmm_backends.clear()
+
+    def _dead(h) -> bool:
+        if not h:
+            return False
+        flag = ctypes.c_int(0)
+        _capi.call("hpcla_halo_status", h, ctypes.byref(flag))
+        return bool(flag.value)
+    n_dead = sum(1 for ent in _spmm_halo_cache.values() if _dead(ent[0])) + \
+        sum(1 for pp in _spmm_panel_cache.values() if any(_dead(h) for h in pp.halos))
+    if n_dead:
+        import warnings
+        warnings.warn(f"clear_spmm_cache: {n_dead} SpMM exchange plan(s) had a timed-out exchange (their results were NaN)")
     for pp in _spmm_panel_cache.values():
         for h in reversed(pp.halos):                  # chained plans before their leader (hpcla_halo_plan_chain)
             if h:

@@ -195,6 +195,24 @@ def clear_matrix_plan_cache() -> None:
 
 
 def build_product_map(A, g_rowptr, g_col, c_rowptr64, c_col, max_products: int):
+    """``_build_product_map`` behind a safety net: the lists are an OPTIONAL speed-up of repeated products, built
+    automatically by the third product over a structure, and the build needs ~64 B of transient device memory per
+    product (several int64 temporaries of length `total`, the sort's key / permutation and its scratch).  A product that
+    worked twice must not fail on its third call for that: the cap is lowered to what the device has free right now, and
+    an out-of-memory (or any runtime) error during the build returns None -- the numeric kernels stay in use."""
+    torch = _torch()
+    try:
+        free_b, _total_b = torch.cuda.mem_get_info()
+        max_products = min(int(max_products), int(free_b // 64))
+        return _build_product_map(A, g_rowptr, g_col, c_rowptr64, c_col, max_products)
+    except (torch.cuda.OutOfMemoryError, RuntimeError) as exc:
+        import sys
+        sys.stderr.write(f"hpcla: SpGEMM product lists not built ({type(exc).__name__}: {str(exc)[:120]}); numeric kernels stay\n")
+        torch.cuda.empty_cache()
+        return None
+
+
+def _build_product_map(A, g_rowptr, g_col, c_rowptr64, c_col, max_products: int):
     """Per result entry, the list of its products as (index into A.nzval, index into the gathered B values), in
     ascending A entry (= ascending k, the accumulation order of the numeric kernels): expand every A entry over its B
     row, STABLE sort by (row, result column), run lengths.  Device tensor ops (plan-time plumbing, once per structure);
@@ -220,6 +238,8 @@ def build_product_map(A, g_rowptr, g_col, c_rowptr64, c_col, max_products: int):
     width = int(max(int(g_col.max().item()), int(c_col.max().item())) + 1)
     key = a_row[ai] * width + g_col[gi]
     del a_row, excl, starts, lens
+    pairs_unsorted = torch.stack([ai, gi], dim=1).to(torch.int32)       # (the int64 lists go as soon as the pairs exist)
+    del ai, gi
     key, perm = torch.sort(key, stable=True)
     uniq, counts = torch.unique_consecutive(key, return_counts=True)
     del key
@@ -232,7 +252,7 @@ def build_product_map(A, g_rowptr, g_col, c_rowptr64, c_col, max_products: int):
     torch.cumsum(counts, 0, out=ptr[1:])
     if not ptr64:
         ptr = ptr.to(torch.int32)
-    pairs = torch.stack([ai[perm], gi[perm]], dim=1).to(torch.int32).contiguous()
+    pairs = pairs_unsorted[perm].contiguous()
     return ptr, pairs, ptr64
 
 

@@ -313,9 +313,14 @@ class VectorPlan:
         # dozen launches into a scratch vector); HPCLA_BLOCK_ORDER=natural skips it, =<G> forces groups of G row blocks
         self.block_group = 1
         self.block_group_measured = False
-        want = _os.environ.get("HPCLA_BLOCK_ORDER", "auto")
+        want = _os.environ.get("HPCLA_BLOCK_ORDER", "auto").strip().lower()
         if want.isdigit():
-            self.block_group = max(1, int(want))
+            g = int(want)
+            if g > 1024 or (g & (g - 1)) != 0:           # the hint takes 0 / 1 or a power of two <= 1024
+                import sys
+                sys.stderr.write(f"hpcla: HPCLA_BLOCK_ORDER={want} is not a power of two <= 1024; natural order\n")
+                g = 1
+            self.block_group = max(1, g)
         elif want != "natural" and A.nrows_local > 0 and A.nnz > 0 and int(x.v.numel()) >= max(self.n_own, 1):
             # (x only has to be readable at the plan's own columns: the products are discarded; a width-0 SpMM probe is not)
             scratch = torch.empty(A.nrows_local, dtype=torch.float64, device=dev)
@@ -446,13 +451,24 @@ def check_exchange_health(backend=None, always: bool = False) -> None:
     for plan in _vector_plan_cache.values():
         if plan.timed_out():
             bad.append("halo plan of a sparse matrix")
-    from . import dense
+    from . import dense, matmat
+
+    def _status(handle) -> bool:
+        if not handle:
+            return False
+        flag = ctypes.c_int(0)
+        _capi.call("hpcla_halo_status", handle, ctypes.byref(flag))
+        return bool(flag.value)
+
     for ent in dense._spmm_halo_cache.values():
-        if ent[0]:
-            flag = ctypes.c_int(0)
-            _capi.call("hpcla_halo_status", ent[0], ctypes.byref(flag))
-            if flag.value:
-                bad.append("SpMM ghost-row plan")
+        if _status(ent[0]):
+            bad.append("SpMM ghost-row plan")
+    for pp in dense._spmm_panel_cache.values():           # the chained chunk-set plans of the panel-ordered SpMM
+        if any(_status(h) for h in pp.halos):
+            bad.append("SpMM chunk-set plan (panel order)")
+    for mp in matmat._plan_cache.values():                # sparse x sparse: the value exchange of the gathered rows
+        if _status(getattr(mp, "halo", None)):
+            bad.append("MatrixPlan value exchange")
     if bad:
         raise ExchangeTimeout("exchange timed out (" + ", ".join(sorted(set(bad))) + "): a neighbour did not publish its "
                               "values within HPCLA_PUSH_TIMEOUT_S; the affected results are NaN")

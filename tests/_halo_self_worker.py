@@ -71,6 +71,42 @@ def main():
     if push:
         run(np.arange(50, 900), 1, x, bad_probe=True)                      # failed connection test -> RCCL, same values
 
+    # chained plans (the chunk-sets of a panel-ordered SpMM) share ONE exchange stream by reference count: destroying
+    # the LEADER first must leave the follower fully usable (it used to borrow the leader's stream untracked)
+    def make(idx_np, width, xsrc):
+        plan = ctypes.c_void_p()
+        idx = torch.from_numpy(idx_np.astype(np.int32)).cuda()
+        ranks = (ctypes.c_int32 * 1)(0)
+        counts = (ctypes.c_int64 * 1)(len(idx_np))
+        torch.cuda.synchronize()
+        capi.check("create_ex", lib.hpcla_halo_plan_create_ex(ctypes.byref(plan), backend.rccl, 1, ranks, counts, idx.data_ptr(),
+                                                              0, 1, ranks, counts, width, capi.HALO_SINGLE_BUFFER))
+        attach_halo_windows(backend, plan, (xsrc.numel() // width, width, [(0, idx_np)]))
+        return plan, idx
+
+    ia, ib = np.arange(10, 200), np.arange(300, 700)
+    leader, keep_a = make(ia, k, xk)
+    follower, keep_b = make(ib, k, xk)
+    capi.call("hpcla_halo_plan_chain", follower, leader)
+    capi.call("hpcla_halo_begin", leader, xk.data_ptr(), s)
+    capi.call("hpcla_halo_begin", follower, xk.data_ptr(), s)
+    capi.call("hpcla_halo_end", leader, s)
+    capi.call("hpcla_halo_end", follower, s)
+    torch.cuda.synchronize()
+    capi.call("hpcla_halo_plan_destroy", leader)                       # leader FIRST
+    ghost = ctypes.c_void_p(); ng = ctypes.c_int64()
+    for rep in range(3):                                               # the follower still exchanges on the shared stream
+        xs = xk * (rep + 2.0)
+        capi.call("hpcla_halo_begin", follower, xs.data_ptr(), s)
+        capi.call("hpcla_halo_end", follower, s)
+        capi.call("hpcla_halo_ghost_ptr", follower, ctypes.byref(ghost), ctypes.byref(ng))
+        tmp = torch.empty(len(ib) * k, dtype=torch.float64, device="cuda")
+        ident = torch.arange(len(ib) * k, dtype=torch.int64, device="cuda")
+        capi.call("hpcla_gather_f64_i64", ghost, ident.data_ptr(), None, tmp.data_ptr(), ident.numel(), 0, s)
+        torch.cuda.synchronize()
+        assert torch.equal(tmp, xs.view(-1, k)[torch.from_numpy(ib).cuda()].reshape(-1)), "follower after its leader was destroyed"
+    capi.call("hpcla_halo_plan_destroy", follower)
+
     # all-reduce on the one-rank communicator is the identity
     t = torch.tensor([3.25, -1.0], dtype=torch.float64, device="cuda")
     capi.call("hpcla_allreduce_f64", backend.rccl, t.data_ptr(), 2, 0, s)
