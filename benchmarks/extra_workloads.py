@@ -103,6 +103,10 @@ def _measure_spmm(args, job, hp, wl, A, B, k, world, dev, setup_s, metric, workl
                      "traffic": traffic, "traffic_source": traffic_source,
                      "algorithmic_bytes_per_launch": b_alg,
                      "block_order_group": int(job.max(hp.spmm_block_order_of(A, B))),
+                     "run_tiles": (lambda f: None if f is None else
+                                   {"blocks_that_fit": f[0], "blocks": f[1], "used": bool(f[0] >= 0.99 * f[1]),
+                                    "kernel": "hpcla::spmm_rowblock_runs_kernel" if f[0] >= 0.99 * f[1] else "hpcla::spmm_rowblock_vec_kernel"})(
+                                       hp.spmm_runs_fit_of(A, B)),
                      "gather_bytes_per_launch": b_gather,
                      "gather_gbs": round(b_gather / (device_ms * 1e-3) / 1e9, 1),
                      "note": "achieved = algorithmic bytes / device time per step (HIP events on the launch stream); algorithmic "

@@ -716,6 +716,153 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(WAVES_PER_E
     }
 }
 
+
+// ---- MODE 30/31/32: RUN TILES (round 4) ---------------------------------------------------------------
+// Plan time (the driver, once per structure): for every block of R rows the DISTINCT columns its entries touch, as up
+// to four contiguous runs {start, length} (a 64-row block of the 5-point matrix: [r0 - nx, r0 - nx + 64), [r0 - 1,
+// r0 + 65), [r0 + nx, r0 + nx + 64) = 194 rows of B instead of 320 gathered rows); blocks with more runs or rows than
+// fit are marked (len[0] < 0) and take a plain per-entry path.
+// Kernel: the descriptor and the block's row pointers leave together; then the B rows of the runs come STRAIGHT INTO
+// LDS by LDS-DMA (global_load_lds_dwordx4: one wave-instruction = 8 whole 128-byte rows, per-lane source address, no
+// VGPR destination) next to the block's A entries (coalesced); every entry is resolved ONCE to the LDS offset of its B
+// row; then four lanes per row multiply out of LDS in stored order (one sequential sum per C(r, c): the reference's
+// bits), and C leaves through LDS as whole lines with non-temporal stores.  Nothing in the B path depends on A.
+// MODE 30: R = 64 rows / 256 threads; MODE 31: R = 32 rows / 128 threads; MODE 32: MODE 30 with B through registers
+// (global_load_dwordx4 + ds_write_b128) instead of LDS-DMA.
+struct __attribute__((aligned(16))) RunDesc {
+    int start[4];
+    int len[4];          // len[0] < 0: the block does not fit (fallback)
+};
+
+template <int R, bool DMA>
+__global__ __launch_bounds__(R * 4) void k_spmm_runs(const int *__restrict__ rowptr, const int *__restrict__ colval,
+                                                      const double *__restrict__ nzval, const double *__restrict__ B,
+                                                      double *__restrict__ C, int64_t nrows, const RunDesc *__restrict__ runs)
+{
+    constexpr int NT = R * 4, TMAX = 3 * R + 8, EMAX = R * 8;            // tile rows, staged entries per block
+    __shared__ __attribute__((aligned(16))) double s_tile[TMAX * KT];     // B rows of the runs, back to back (then the C tile)
+    __shared__ int s_off[EMAX];                                           // per entry: byte offset of its B row in s_tile
+    __shared__ double s_val[EMAX];
+
+    const int tid = threadIdx.x, g = tid / VG, l = tid % VG;
+    const int64_t r0 = (int64_t)blockIdx.x * R;
+    const int nr = (int)((nrows - r0) < R ? (nrows - r0) : R);
+    const RunDesc d = runs[blockIdx.x];
+    const int p0 = rowptr[r0], p1 = rowptr[r0 + nr];
+    int rlo = 0, rhi = 0;
+    if (g < nr) { rlo = rowptr[r0 + g]; rhi = rowptr[r0 + g + 1]; }
+    const int total = p1 - p0;
+    const int o1 = d.len[0], o2 = o1 + d.len[1], o3 = o2 + d.len[2], T = o3 + d.len[3];     // tile row offsets of the runs
+
+    if (d.len[0] < 0 || total > EMAX) {
+        // fallback: per-entry gathers straight from global memory, four lanes per row (rare: never on the stencil)
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        if (g < nr) {
+            for (int j = rlo; j < rhi; ++j) {
+                const double v = nzval[j];
+                const double *row = B + (int64_t)colval[j] * KT;
+                const vdouble2 b0 = *reinterpret_cast<const vdouble2 *>(row + 2 * l);
+                const vdouble2 b1 = *reinterpret_cast<const vdouble2 *>(row + 8 + 2 * l);
+                acc[0] += v * b0.x; acc[1] += v * b0.y; acc[2] += v * b1.x; acc[3] += v * b1.y;
+            }
+            vdouble2 q0, q1;
+            q0.x = acc[0]; q0.y = acc[1]; q1.x = acc[2]; q1.y = acc[3];
+            *reinterpret_cast<vdouble2 *>(C + (r0 + g) * KT + 2 * l) = q0;
+            *reinterpret_cast<vdouble2 *>(C + (r0 + g) * KT + 8 + 2 * l) = q1;
+        }
+        return;
+    }
+
+    // B rows -> LDS: piece q = 8 tile rows = 1 KiB = one wave-instruction
+    {
+        const int wave = tid >> 6, lane = tid & 63;
+        const int npieces = (T + 7) >> 3;
+        for (int q = wave; q < npieces; q += NT / 64) {
+            int t = q * 8 + (lane >> 3);
+            if (t >= T) t = T - 1;                                      // the ragged last piece re-reads the last row
+            const int brow = t < o1 ? d.start[0] + t : (t < o2 ? d.start[1] + (t - o1) : (t < o3 ? d.start[2] + (t - o2) : d.start[3] + (t - o3)));
+            const double *src = B + (int64_t)brow * KT + (lane & 7) * 2;
+            if (DMA) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(s_tile + q * 8 * KT), 16, 0, 0);
+            } else {
+                const vdouble2 v = *reinterpret_cast<const vdouble2 *>(src);
+                *reinterpret_cast<vdouble2 *>(s_tile + q * 8 * KT + lane * 2) = v;
+            }
+        }
+    }
+    // A entries -> {LDS offset of the B row, value}: both of a thread's entries (EMAX = 2 NT) are requested before
+    // the first is used
+    {
+        static_assert(EMAX == 2 * NT, "two entries per thread");
+        const int i0 = tid, i1 = tid + NT;
+        int c0 = 0, c1 = 0;
+        double v0 = 0.0, v1 = 0.0;
+        if (i0 < total) { c0 = __builtin_nontemporal_load(colval + p0 + i0); v0 = __builtin_nontemporal_load(nzval + p0 + i0); }
+        if (i1 < total) { c1 = __builtin_nontemporal_load(colval + p0 + i1); v1 = __builtin_nontemporal_load(nzval + p0 + i1); }
+        auto tile_row = [&](int c) {
+            if (c >= d.start[3] && d.len[3] > 0) return o3 + (c - d.start[3]);
+            if (c >= d.start[2] && d.len[2] > 0) return o2 + (c - d.start[2]);
+            if (c >= d.start[1] && d.len[1] > 0) return o1 + (c - d.start[1]);
+            return c - d.start[0];
+        };
+        if (i0 < total) { s_off[i0] = tile_row(c0) * (KT * 8); s_val[i0] = v0; }
+        if (i1 < total) { s_off[i1] = tile_row(c1) * (KT * 8); s_val[i1] = v1; }
+    }
+    __syncthreads();                                                    // (drains the LDS-DMA: vmcnt(0) + barrier)
+
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    if (g < nr) {
+        const char *tile = reinterpret_cast<const char *>(s_tile) + l * 16;
+        int j = rlo - p0;
+        const int e = rhi - p0;
+        for (; j + 2 <= e; j += 2) {
+            const int oa = s_off[j], ob = s_off[j + 1];
+            const double va = s_val[j], vb = s_val[j + 1];
+            const vdouble2 a0 = *reinterpret_cast<const vdouble2 *>(tile + oa), a1 = *reinterpret_cast<const vdouble2 *>(tile + oa + 64);
+            const vdouble2 b0 = *reinterpret_cast<const vdouble2 *>(tile + ob), b1 = *reinterpret_cast<const vdouble2 *>(tile + ob + 64);
+            acc[0] += va * a0.x; acc[1] += va * a0.y; acc[2] += va * a1.x; acc[3] += va * a1.y;
+            acc[0] += vb * b0.x; acc[1] += vb * b0.y; acc[2] += vb * b1.x; acc[3] += vb * b1.y;
+        }
+        for (; j < e; ++j) {
+            const int oa = s_off[j];
+            const double va = s_val[j];
+            const vdouble2 a0 = *reinterpret_cast<const vdouble2 *>(tile + oa), a1 = *reinterpret_cast<const vdouble2 *>(tile + oa + 64);
+            acc[0] += va * a0.x; acc[1] += va * a0.y; acc[2] += va * a1.x; acc[3] += va * a1.y;
+        }
+    }
+    __syncthreads();                                                    // everybody has finished reading the tile
+    double *s_c = s_tile;
+    vdouble2 q0, q1;
+    q0.x = acc[0]; q0.y = acc[1]; q1.x = acc[2]; q1.y = acc[3];
+    *reinterpret_cast<vdouble2 *>(s_c + g * KT + 2 * l) = q0;            // HALF64 mapping: columns {2l, 2l+1} and {8+2l, 8+2l+1}
+    *reinterpret_cast<vdouble2 *>(s_c + g * KT + 8 + 2 * l) = q1;
+    __syncthreads();
+    vdouble2 *dst = reinterpret_cast<vdouble2 *>(C + r0 * KT);
+    const vdouble2 *srcl = reinterpret_cast<const vdouble2 *>(s_c);
+#pragma unroll
+    for (int u = 0; u < (R * KT / 2) / NT; ++u) {
+        const int i = tid + u * NT;
+        if (i < nr * (KT / 2)) __builtin_nontemporal_store(srcl[i], dst + i);
+    }
+}
+
+extern "C" int hpcla_tune_spmm_runs(int mode, const void *rowptr, const void *colval, const void *nzval, const void *B,
+                                    void *C, int64_t nrows, const void *runs, void *stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    const int *rp = (const int *)rowptr, *cv = (const int *)colval;
+    const double *nz = (const double *)nzval, *Bp = (const double *)B;
+    double *Cp = (double *)C;
+    const RunDesc *rd = (const RunDesc *)runs;
+    if (mode == 30) k_spmm_runs<64, true><<<(uint32_t)((nrows + 63) / 64), 256, 0, s>>>(rp, cv, nz, Bp, Cp, nrows, rd);
+    else if (mode == 31) k_spmm_runs<32, true><<<(uint32_t)((nrows + 31) / 32), 128, 0, s>>>(rp, cv, nz, Bp, Cp, nrows, rd);
+    else if (mode == 32) k_spmm_runs<64, false><<<(uint32_t)((nrows + 63) / 64), 256, 0, s>>>(rp, cv, nz, Bp, Cp, nrows, rd);
+    else if (mode == 33) k_spmm_runs<32, false><<<(uint32_t)((nrows + 31) / 32), 128, 0, s>>>(rp, cv, nz, Bp, Cp, nrows, rd);
+    else return -2;
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 extern "C" int hpcla_tune_spmm(int mode, const void *rowptr, const void *colval, const void *nzval, const void *B,
                                void *C, int64_t nrows, int64_t n_brows, const void *small_tab, void *stamps,
                                int param, void *stream)

@@ -176,6 +176,169 @@ __global__ __launch_bounds__(TPB) void k_wide(const int *__restrict__ rowptr,
     }
 }
 
+// ---- ROWG (round 4): gathers issued BY ROW, from an LDS-transposed copy of the block's A entries -------------------
+// Why (profiles/r04_spmv_2d_vs_3d_counters.txt): in the product-parking kernels a lane owns a QUAD of consecutive
+// entries, so one gather instruction covers entries 4L + q, L = 0..63 -- ~37 rows x 7 column types of the 7-point
+// matrix, i.e. seven x streams of which five are aligned to the same 4 KiB / 2 MiB power of two (i - 2 MiB, i - 4 KiB,
+// i, i + 4 KiB, i + 2 MiB): ~24 lines per instruction, most of them on the same tag bank of the vector L1
+// (TCP_READ_TAGCONFLICT_STALL_CYCLES 6.2 x the 5-point matrix's per entry, TA_ADDR_STALLED_BY_TC 1.6 x, SQ issue
+// stalls 1.6 x).  Here the block's colval / nzval are streamed coalesced into LDS UNMULTIPLIED (12 B per entry), and
+// thread t then walks ITS OWN row: gather instruction j reads, across the wave, the j-th entry of 64 consecutive rows
+// -- for any banded / stencil matrix ONE x stream, 512 contiguous bytes, 4-5 lines and no conflict; for unstructured
+// rows no worse than before.  The row sum is the same sequential multiply-add chain in stored order: same bits.
+// LDS reads: s_col stride = row length in 4-byte words (5, 7: odd -> conflict-free), s_val in 8-byte words.
+template <int TPB, int CH, int UR, int XCD>
+__global__ __launch_bounds__(TPB) void k_rowg(const int *__restrict__ rowptr, const int *__restrict__ colval,
+                                              const double *__restrict__ nzval, const double *__restrict__ x,
+                                              double *__restrict__ y, int64_t nrows, int64_t nnz, uint32_t nblocks)
+{
+    static_assert(CH % 4 == 0, "whole quads");
+    __shared__ __attribute__((aligned(16))) int s_col[CH];
+    __shared__ __attribute__((aligned(16))) double s_val[CH];
+    const int tid = threadIdx.x;
+    const uint32_t b = XCD == 0 ? blockIdx.x : xcd_group_index(blockIdx.x, nblocks, XCD);
+    const int64_t r0 = (int64_t)b * TPB;
+    const int nr = (int)((nrows - r0) < TPB ? (nrows - r0) : TPB);
+    const int64_t p0 = rowptr[r0], p1 = rowptr[r0 + nr];
+    const int64_t pa = p0 & ~(int64_t)3;
+    const int64_t total = p1 - pa;
+    int rlo = 0, rhi = 0;
+    if (tid < nr) { rlo = rowptr[r0 + tid]; rhi = rowptr[r0 + tid + 1]; }
+    double acc = 0.0;
+    for (int64_t c = 0; c < total; c += CH) {
+        const int n = (int)((total - c) < CH ? (total - c) : CH);
+        // stream the pass's entries into LDS: ALL of a lane's quads are requested before the first is written (lanes past
+        // the end re-read the pass's last quad -- lines their neighbours read anyway -- and write nothing)
+        if (pa + c + ((n + 3) & ~3) <= nnz) {
+            constexpr int NQ = (CH / 4 + TPB - 1) / TPB;
+            const int last = (n - 1) & ~3;
+            v4i cq[NQ];
+            v2d va[NQ], vb[NQ];
+#pragma unroll
+            for (int u = 0; u < NQ; ++u) {
+                const int e0 = (u * TPB + tid) * 4;
+                const int ee = e0 < last ? e0 : last;
+                cq[u] = *reinterpret_cast<const v4i *>(colval + pa + c + ee);
+                va[u] = *reinterpret_cast<const v2d *>(nzval + pa + c + ee);
+                vb[u] = *reinterpret_cast<const v2d *>(nzval + pa + c + ee + 2);
+            }
+#pragma unroll
+            for (int u = 0; u < NQ; ++u) {
+                const int e0 = (u * TPB + tid) * 4;
+                if (e0 < n) {
+                    *reinterpret_cast<v4i *>(&s_col[e0]) = cq[u];
+                    *reinterpret_cast<v2d *>(&s_val[e0]) = va[u];
+                    *reinterpret_cast<v2d *>(&s_val[e0 + 2]) = vb[u];
+                }
+            }
+        } else {                                  // the one pass that reaches past the arrays' end: entry by entry
+            for (int e = tid; e < n; e += TPB) {
+                const int64_t g = pa + c + e;
+                s_col[e] = g < nnz ? colval[g] : 0;
+                s_val[e] = g < nnz ? nzval[g] : 0.0;
+            }
+        }
+        __syncthreads();
+        {
+            const int lo = tid < nr ? (int)(rlo - pa) : 0, hi = tid < nr ? (int)(rhi - pa) : 0;
+            int j = (lo > c ? lo : (int)c) - (int)c;
+            const int e = (hi < c + n ? hi : (int)(c + n)) - (int)c;
+            // UR entries per step, each under its own lane predicate: the step's gathers leave together (a gather none of
+            // the wave's lanes needs is skipped), the sums follow in stored order
+            for (; j < e; j += UR) {
+                int cc[UR];
+                double vv[UR], xx[UR];
+#pragma unroll
+                for (int u = 0; u < UR; ++u) { cc[u] = 0; vv[u] = 0.0; if (j + u < e) { cc[u] = s_col[j + u]; vv[u] = s_val[j + u]; } }
+#pragma unroll
+                for (int u = 0; u < UR; ++u) { xx[u] = 0.0; if (j + u < e) xx[u] = x[cc[u]]; }
+#pragma unroll
+                for (int u = 0; u < UR; ++u) if (j + u < e) acc += vv[u] * xx[u];
+            }
+        }
+        if (c + CH < total) __syncthreads();
+    }
+    if (tid < nr) y[r0 + tid] = acc;
+}
+
+// ---- ROWG, wave-private tiles: every WAVE owns 64 rows and its own slice of LDS; no workgroup barrier at all (LDS
+// operations of one wave complete in order), so a workgroup of WPB waves keeps the 64 * WPB-row block granularity of the
+// callers' block lists while its waves never wait for each other
+template <int WPB, int CHW, int UR, int XCD>
+__global__ __launch_bounds__(64 * WPB) void k_rowg_wave(const int *__restrict__ rowptr, const int *__restrict__ colval,
+                                                        const double *__restrict__ nzval, const double *__restrict__ x,
+                                                        double *__restrict__ y, int64_t nrows, int64_t nnz, uint32_t nblocks)
+{
+    static_assert(CHW % 256 == 0, "whole quads per lane");
+    __shared__ __attribute__((aligned(16))) int s_col_all[WPB * CHW];
+    __shared__ __attribute__((aligned(16))) double s_val_all[WPB * CHW];
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+    int *s_col = s_col_all + wave * CHW;
+    double *s_val = s_val_all + wave * CHW;
+    const uint32_t b = XCD == 0 ? blockIdx.x : xcd_group_index(blockIdx.x, nblocks, XCD);
+    const int64_t r0 = (int64_t)b * (64 * WPB) + wave * 64;
+    if (r0 >= nrows) return;                               // (no barrier anywhere below)
+    const int nr = (int)((nrows - r0) < 64 ? (nrows - r0) : 64);
+    const int64_t p0 = rowptr[r0], p1 = rowptr[r0 + nr];
+    const int64_t pa = p0 & ~(int64_t)3;
+    const int64_t total = p1 - pa;
+    int rlo = 0, rhi = 0;
+    if (lane < nr) { rlo = rowptr[r0 + lane]; rhi = rowptr[r0 + lane + 1]; }
+    double acc = 0.0;
+    for (int64_t c = 0; c < total; c += CHW) {
+        const int n = (int)((total - c) < CHW ? (total - c) : CHW);
+        if (pa + c + ((n + 3) & ~3) <= nnz) {
+            constexpr int NQ = CHW / 256;
+            const int last = (n - 1) & ~3;
+            v4i cq[NQ];
+            v2d va[NQ], vb[NQ];
+#pragma unroll
+            for (int u = 0; u < NQ; ++u) {
+                const int e0 = (u * 64 + lane) * 4;
+                const int ee = e0 < last ? e0 : last;
+                cq[u] = *reinterpret_cast<const v4i *>(colval + pa + c + ee);
+                va[u] = *reinterpret_cast<const v2d *>(nzval + pa + c + ee);
+                vb[u] = *reinterpret_cast<const v2d *>(nzval + pa + c + ee + 2);
+            }
+#pragma unroll
+            for (int u = 0; u < NQ; ++u) {
+                const int e0 = (u * 64 + lane) * 4;
+                if (e0 < n) {
+                    *reinterpret_cast<v4i *>(&s_col[e0]) = cq[u];
+                    *reinterpret_cast<v2d *>(&s_val[e0]) = va[u];
+                    *reinterpret_cast<v2d *>(&s_val[e0 + 2]) = vb[u];
+                }
+            }
+        } else {
+            for (int e = lane; e < n; e += 64) {
+                const int64_t g = pa + c + e;
+                s_col[e] = g < nnz ? colval[g] : 0;
+                s_val[e] = g < nnz ? nzval[g] : 0.0;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // this wave's LDS writes before its LDS reads (in-order per wave)
+        __builtin_amdgcn_wave_barrier();
+        {
+            const int lo = lane < nr ? (int)(rlo - pa) : 0, hi = lane < nr ? (int)(rhi - pa) : 0;
+            int j = (lo > c ? lo : (int)c) - (int)c;
+            const int e = (hi < c + n ? hi : (int)(c + n)) - (int)c;
+            for (; j < e; j += UR) {
+                int cc[UR];
+                double vv[UR], xx[UR];
+#pragma unroll
+                for (int u = 0; u < UR; ++u) { cc[u] = 0; vv[u] = 0.0; if (j + u < e) { cc[u] = s_col[j + u]; vv[u] = s_val[j + u]; } }
+#pragma unroll
+                for (int u = 0; u < UR; ++u) { xx[u] = 0.0; if (j + u < e) xx[u] = x[cc[u]]; }
+#pragma unroll
+                for (int u = 0; u < UR; ++u) if (j + u < e) acc += vv[u] * xx[u];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      // the reads before the next pass's writes
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane < nr) y[r0 + lane] = acc;
+}
+
 // ---- wide kernel + compact per-block pointer array (16 block starts per 64-byte line)
 // ---- wide kernel: 16-byte loads (4 entries per lane per load), aligned to 4 entries ----------------
 template <int TPB, int RPT, int U, bool NT, bool XCD>
@@ -959,6 +1122,42 @@ extern "C" __attribute__((visibility("default"))) int hpcla_tune_spmv(
         case 84: k_packed2<256, 4><<<(uint32_t)((nrows + 1023) / 1024), 256, 0, s>>>(rowptr, dcol1024, code, dict, ndict, x, y, nrows, nnz); break;
         case 85: k_packed2<512, 2><<<(uint32_t)((nrows + 1023) / 1024), 512, 0, s>>>(rowptr, dcol1024, code, dict, ndict, x, y, nrows, nnz); break;
         case 86: k_packed2<1024, 1><<<(uint32_t)((nrows + 1023) / 1024), 1024, 0, s>>>(rowptr, dcol1024, code, dict, ndict, x, y, nrows, nnz); break;
+#define ROWG(TPB, CH, UR, XCD)                                                                    \
+    {                                                                                             \
+        uint32_t nb = (uint32_t)((nrows + TPB - 1) / TPB);                                        \
+        k_rowg<TPB, CH, UR, XCD><<<nb, TPB, 0, s>>>(rowptr, colval, nzval, x, y, nrows, nnz, nb); \
+    }
+        // ROWG: row-wise gathers from LDS-transposed A.  <threads = rows per block, entries per LDS pass, entries per gather step, XCD group>
+        case 90: ROWG(256, 2048, 8, 0) break;              // 24 KiB LDS: 6 workgroups per CU
+        case 91: ROWG(256, 1792, 8, 0) break;              // 21 KiB: 7 per CU; the 7-point block in one pass
+        case 92: ROWG(256, 1344, 8, 0) break;              // 15.75 KiB: 8 per CU; the 7-point block in two passes
+        case 93: ROWG(128, 1024, 8, 0) break;              // 128-row blocks, 12 KiB: 13 workgroups = 26 waves per CU
+        case 94: ROWG(256, 1792, 4, 0) break;              // four entries per gather step
+        case 95: ROWG(256, 1792, 8, 32) break;             // + XCD groups of 32 / 64 row blocks
+        case 96: ROWG(256, 1792, 8, 64) break;
+        case 97: ROWG(128, 1024, 8, 64) break;
+        case 98: ROWG(128, 1024, 8, 128) break;
+        case 99: ROWG(512, 3584, 8, 0) break;              // 512-row blocks, 42 KiB: 3 workgroups = 24 waves per CU
+#define ROWGW(WPB, CHW, UR, XCD)                                                                  \
+    {                                                                                             \
+        uint32_t nb = (uint32_t)((nrows + 64 * WPB - 1) / (64 * WPB));                            \
+        k_rowg_wave<WPB, CHW, UR, XCD><<<nb, 64 * WPB, 0, s>>>(rowptr, colval, nzval, x, y, nrows, nnz, nb); \
+    }
+        case 120: ROWGW(4, 512, 8, 0) break;               // wave-private tiles: 256-row workgroups, 24 KiB, no barrier
+        case 121: ROWGW(2, 512, 8, 0) break;               // 128-row workgroups
+        case 122: ROWGW(4, 512, 8, 32) break;              // 256-row workgroups in XCD groups of 32 / 64
+        case 123: ROWGW(4, 512, 8, 64) break;
+        case 124: ROWGW(1, 512, 8, 0) break;               // one wave per workgroup
+        case 125: ROWGW(4, 256, 8, 0) break;               // 12 KiB per workgroup (a 7-point wave takes two passes)
+        case 126: ROWGW(8, 512, 8, 0) break;               // 512-row workgroups
+        case 110: ROWG(128, 896, 8, 128) break;            // 128 rows x 7 entries exactly: 10.5 KiB, 15 workgroups = 30 waves per CU
+        case 111: ROWG(128, 1024, 8, 256) break;
+        case 112: ROWG(64, 512, 8, 128) break;             // one wave per workgroup (the barrier is free)
+        case 113: ROWG(64, 512, 8, 256) break;
+        case 114: ROWG(128, 1024, 4, 128) break;
+        case 115: ROWG(128, 1024, 8, 32) break;
+        case 116: ROWG(64, 512, 8, 512) break;
+        case 117: ROWG(128, 768, 8, 128) break;            // 9 KiB: 16 workgroups = 32 waves per CU (7-point block in two passes)
         case 22: WIDE(256, 1, 2, false, 4) break;          // natural kernel, XCD groups of 4 / 8 / 16 / 32 / 64 / 128 blocks
         case 23: WIDE(256, 1, 2, false, 8) break;
         case 24: WIDE(256, 1, 2, false, 16) break;

@@ -93,6 +93,41 @@ def main():
     stamps = torch.zeros(16 + 4 * ((n + 63) // 64) + ((n + 63) // 64 + 2) // 2 + 8, dtype=torch.int64, device=dev)   # ... then MODE 16's block starts      # [16 + 4*b ..]: block b's phase stamps
     b_alg = wl.spmm_algorithmic_bytes(nnz, n, A.ncols_compressed, k, 4)
 
+    tune.hpcla_tune_spmm_runs.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
+    run_descs = {}
+
+    def build_runs(R):
+        """Plan-time (once per structure; torch index ops = plumbing): per block of R rows the distinct columns its
+        entries touch as <= 4 contiguous runs {start[4], len[4]}; len[0] = -1 marks a block that does not fit."""
+        if R in run_descs:
+            return run_descs[R]
+        rp = A.rowptr_target.to(torch.int64)
+        counts = rp[1:] - rp[:-1]
+        blk = torch.repeat_interleave(torch.arange(n, device=dev, dtype=torch.int64), counts) // R
+        nb = (n + R - 1) // R
+        key = torch.unique(blk * n_brows + cv.to(torch.int64))                 # sorted
+        kb, kc = key // n_brows, key % n_brows
+        newrun = torch.ones_like(key, dtype=torch.bool)
+        newrun[1:] = (kb[1:] != kb[:-1]) | (kc[1:] != kc[:-1] + 1)
+        first = torch.nonzero(newrun).flatten()
+        run_blk, run_col = kb[first], kc[first]
+        run_len = torch.diff(torch.cat([first, torch.tensor([key.numel()], device=dev)]))
+        first_run = torch.searchsorted(run_blk, torch.arange(nb, device=dev, dtype=torch.int64))
+        within = torch.arange(first.numel(), device=dev, dtype=torch.int64) - first_run[run_blk]
+        nruns = torch.bincount(run_blk, minlength=nb)
+        rows = torch.bincount(run_blk, weights=run_len.double(), minlength=nb).long()
+        desc = torch.zeros((nb, 8), dtype=torch.int32, device=dev)
+        ok = within < 4
+        desc[run_blk[ok], within[ok]] = run_col[ok].int()
+        desc[run_blk[ok], 4 + within[ok]] = run_len[ok].int()
+        bad = (nruns > 4) | (rows > 3 * R + 8)
+        desc[bad, 4] = -1
+        torch.cuda.synchronize()
+        print(f"# run descriptors R={R}: {nb} blocks, {int(bad.sum())} do not fit (fallback), mean tile rows {float(rows.double().mean()):.1f}, "
+              f"max {int(rows.max())}, runs/block max {int(nruns.max())}")
+        run_descs[R] = desc
+        return desc
+
     def parse(v):
         if ":" in v:
             a, b = v.split(":")
@@ -119,6 +154,9 @@ def main():
             os.environ["HPCLA_SPMM_XCD_GROUP"] = str(param if mode == 101 else 0)
             return hp._capi.load().hpcla_spmm_csr_f64_i32(A.rowptr_target.data_ptr(), cv.data_ptr(), A.nzval.data_ptr(), Bl.data_ptr(), k,
                                                          0, C.data_ptr(), k, 0, n, nnz, k, 0, s)
+        if 30 <= mode <= 33:               # RUN TILES: B rows of a block's <= 4 contiguous column runs staged into LDS (plan-time descriptors)
+            return tune.hpcla_tune_spmm_runs(mode, A.rowptr_target.data_ptr(), cv.data_ptr(), A.nzval.data_ptr(), Bl.data_ptr(),
+                                             C.data_ptr(), n, build_runs(64 if mode in (30, 32) else 32).data_ptr(), s)
         return tune.hpcla_tune_spmm(mode, A.rowptr_target.data_ptr(), cv.data_ptr(), A.nzval.data_ptr(), Bl.data_ptr(), C.data_ptr(),
                                     n, n_brows, small.data_ptr(), stamps.data_ptr(), param, s)
     times = {v: [] for v in variants}
@@ -145,7 +183,10 @@ def main():
     for v in variants:
         med, mn = float(np.median(times[v])), float(np.min(times[v]))
         name = f"{v[0]}" + (f":{v[1]}" if v[1] else "")
-        note = ABLATIONS.get(v[0], "production library" if v[0] == 100 else f"library with spmm.hip under -DHPCLA_EXP={v[0] - 200}" if v[0] >= 200 else "")
+        runs_note = {30: "run tiles, 64 rows, LDS-DMA", 31: "run tiles, 32 rows, LDS-DMA", 32: "run tiles, 64 rows, via registers",
+                     33: "run tiles, 32 rows, via registers"}
+        note = (ABLATIONS.get(v[0]) or runs_note.get(v[0]) or ("production library" if v[0] == 100 else
+                f"library with spmm.hip under -DHPCLA_EXP={v[0] - 200}" if v[0] >= 200 else ""))
         res[name] = dict(median_ms=med, min_ms=mn, gbs=b_alg / med / 1e6, exact=exact[v])
         ex = "-" if v[0] in ABLATIONS and v[0] != 5 else str(exact[v])
         print(f"{name:>10} {med:>10.4f} {mn:>10.4f} {b_alg / med / 1e6:>10.1f} {b_alg / med / 1e6 / 8000:>9.3f} {ex:>9}  {note}")

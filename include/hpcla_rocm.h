@@ -252,6 +252,31 @@ int hpcla_spmm_split_f64_i64(const int64_t *rowptr, const int64_t *colval_split,
                              const double *B_ghost, int64_t ldb_ghost, int64_t n_own, double *C,
                              int64_t ldc, int64_t nrows, int64_t nnz, int k, int index_base,
                              const int32_t *block_list, int64_t n_blocks, void *stream);
+/* RUN TILES (round 4; no reference counterpart -- the reference's A * B is a column loop over A * x,
+ * src/sparse.jl:2391-2413): for banded / stencil matrices the 64 rows of an SpMM row block touch a few CONTIGUOUS runs of
+ * B rows (5-point matrix: 194 rows in 3 runs, where its entries name 320).  Plan time, once per structure:
+ * hpcla_spmm_runs_build_* writes one 32-byte descriptor per block of hpcla_spmm_rows_per_block() rows into `desc`
+ * (hpcla_spmm_runs_desc_bytes(nrows) device bytes) -- up to 4 runs {start, length} in the SPLIT column space, cut at the
+ * own / ghost boundary; blocks with more runs, more than 200 distinct B rows or more than 512 entries are marked as
+ * not fitting -- and returns the number of fitting blocks in *n_fit_host (synchronises the stream).  Per product:
+ * hpcla_spmm_runs_k16_f64_* = hpcla_spmm_split_f64_* for k = 16 with ldb_own = ldb_ghost = ldc = 16 (row-major, 16-byte
+ * aligned): the runs' B rows are staged into LDS by LDS-DMA next to the block's A entries and multiplied out of LDS in
+ * stored order -- bit-identical results, 0.466 ms against 0.517 ms on the 5-point matrix x 16 (0.72 of the HBM peak).
+ * Blocks marked as not fitting take a slow per-entry path: use these entries when (nearly) all blocks fit, else the
+ * gather kernel.  B_ghost == NULL: every column is owned.  `block_list` as in hpcla_spmm_split_f64_*. */
+int64_t hpcla_spmm_runs_desc_bytes(int64_t nrows);
+int hpcla_spmm_runs_build_i32(const int32_t *rowptr, const int32_t *colval_split, int64_t nrows, int64_t nnz,
+                              int index_base, int64_t n_own, void *desc, int64_t *n_fit_host, void *stream);
+int hpcla_spmm_runs_build_i64(const int64_t *rowptr, const int64_t *colval_split, int64_t nrows, int64_t nnz,
+                              int index_base, int64_t n_own, void *desc, int64_t *n_fit_host, void *stream);
+int hpcla_spmm_runs_k16_f64_i32(const int32_t *rowptr, const int32_t *colval_split, const double *nzval,
+                                const double *B_own, const double *B_ghost, int64_t n_own, double *C, int64_t nrows,
+                                int64_t nnz, int index_base, const void *desc, const int32_t *block_list,
+                                int64_t n_blocks, void *stream);
+int hpcla_spmm_runs_k16_f64_i64(const int64_t *rowptr, const int64_t *colval_split, const double *nzval,
+                                const double *B_own, const double *B_ghost, int64_t n_own, double *C, int64_t nrows,
+                                int64_t nnz, int index_base, const void *desc, const int32_t *block_list,
+                                int64_t n_blocks, void *stream);
 /* layout conversion for column-major callers (Julia Matrix): dst(row-major, ld=k) <- src */
 /* One column PANEL of a product in panel order (opt-in order of the distributed SpMM; the reference's column loop
  * src/sparse.jl:2391-2413 runs one exchange + SpMV per column instead).  (rowptr, colval_split, nzval) hold the

@@ -29,7 +29,7 @@ from .sparse import (HPCSparseMatrix, HPCSparseMatrix_from_global, HPCSparseMatr
                      ExchangeTimeout, check_exchange_health,
                      clear_plan_cache, execute_plan, get_vector_plan, mul_, mul_dot_, split_column_map)
 from .dense import (HPCMatrix, HPCMatrix_local, TransposedHPCMatrix, clear_dense_plan_cache, clear_spmm_cache,
-                    dense_matvec, dense_matvec_t, spmm, spmm_block_order_of, spmm_exchange_bytes)
+                    dense_matvec, dense_matvec_t, spmm, spmm_block_order_of, spmm_exchange_bytes, spmm_runs_fit_of)
 from .matmat import clear_matrix_plan_cache, get_matrix_plan, spgemm
 from .cg import CGGraphPair, CGWorkspace, cg_fixed_iterations, cg_iterate, cg_setup
 from .convert import to_backend

@@ -53,6 +53,11 @@ _SIGNATURES = {
     "hpcla_spmv_tune_block_order_f64_i32": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp],
     "hpcla_spmv_tune_block_order_f64_i64": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp],
     "hpcla_spmm_rows_per_block": [],
+    "hpcla_spmm_runs_desc_bytes": [_i64],
+    "hpcla_spmm_runs_build_i32": [_vp, _vp, _i64, _i64, _i32, _i64, _vp, _vp, _vp],
+    "hpcla_spmm_runs_build_i64": [_vp, _vp, _i64, _i64, _i32, _i64, _vp, _vp, _vp],
+    "hpcla_spmm_runs_k16_f64_i32": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _i64, _vp],
+    "hpcla_spmm_runs_k16_f64_i64": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _i64, _vp],
     "hpcla_spmm_block_order_hint": [_vp, _i32],
     "hpcla_spmm_tune_block_order_f64_i32": [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32,
                                             _vp, _i64, _vp, _vp],
@@ -164,6 +169,7 @@ _RESTYPES = {
     "hpcla_poisson3d_nnz": _i64,
     "hpcla_spgemm_bin_cap": _i64,
     "hpcla_gemv_t_work_bytes": _i64,
+    "hpcla_spmm_runs_desc_bytes": _i64,
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

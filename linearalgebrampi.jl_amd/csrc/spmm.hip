@@ -383,6 +383,243 @@ __global__ __launch_bounds__(64 * LPR) void spmm_rowblock_vec_kernel(
     }
 }
 
+// ---- RUN TILES (round 4): B rows of a block's contiguous column runs staged into LDS by LDS-DMA ----------------------
+// For a banded / stencil matrix the 64 rows of a workgroup touch only a few CONTIGUOUS runs of B rows (the 5-point matrix
+// on an nx-wide grid: [r0 - nx, r0 - nx + 64), [r0 - 1, r0 + 65), [r0 + nx, r0 + nx + 64) = 194 rows) although its
+// entries name 320 of them; the gather form fetches every entry's row through the vector-memory pipe separately
+// (5.24 M gather wave-instructions of 1 KiB: profiles/r03_spmm_ablations_and_candidates.txt -- the gather path adds
+// almost its full pipe time).  Here the runs are found ONCE per structure (spmm_runs_build_kernel: sort the block's
+// columns, cut where they stop being consecutive, and at the own / ghost boundary), and per product:
+//   * the descriptor and the block's row pointers leave together (nothing of the B path depends on A);
+//   * the runs' B rows come straight into LDS by LDS-DMA (global_load_lds_dwordx4: one wave-instruction = 8 whole
+//     128-byte rows, per-lane SOURCE address, no VGPR destination) next to the block's A entries (coalesced);
+//   * every entry is resolved once to the LDS offset of its B row; four lanes per row then multiply out of LDS in
+//     stored order -- one sequential sum per C(r, c), the reference's bits (src/sparse.jl:2391-2413);
+//   * C leaves through LDS (the tile's space) as whole lines with non-temporal stores.
+// Harness (benchmarks/tune_spmm.py MODE 30, profiles/r04_spmm_run_tiles.log): 0.4662 ms against 0.5167 for the gather
+// form on the 5-point matrix x 16 = 0.72 of peak; through registers instead of LDS-DMA 0.7165; 32-row blocks 0.4930.
+// Shape: k = 16, row-major B / ghost / C of exactly 16 doubles per row, <= RUNS_MAX runs and <= RUNS_TILE_ROWS distinct B
+// rows and <= RUNS_EMAX entries per 64-row block; a block that does not fit takes a plain per-entry path (the host layer
+// uses this kernel only when >= 99 % of the blocks fit).
+constexpr int RUNS_MAX = 4, RUNS_TILE_ROWS = 200, RUNS_EMAX = 512;
+
+struct __attribute__((aligned(16))) SpmmRunDesc {
+    int32_t start[RUNS_MAX];     // first split column of run i (0-based)
+    int32_t len[RUNS_MAX];       // rows in run i (0: unused); len[0] < 0: the block does not fit
+};
+
+template <typename I, bool SPLIT>
+__global__ __launch_bounds__(TPB_MM) void spmm_rowblock_runs_kernel(
+    const I *__restrict__ rowptr, const I *__restrict__ colval, const double *__restrict__ nzval,
+    const double *__restrict__ B_own, const double *__restrict__ B_ghost, int64_t n_own, double *__restrict__ C,
+    int64_t nrows, int base, const SpmmRunDesc *__restrict__ runs, const int32_t *__restrict__ block_list,
+    uint32_t nblocks, int group_log2)
+{
+    __shared__ __attribute__((aligned(16))) double s_tile[RUNS_TILE_ROWS * KT];   // the runs' B rows back to back; then the C tile
+    __shared__ int32_t s_off[RUNS_EMAX];                                          // per entry: byte offset of its B row in s_tile
+    __shared__ double s_val[RUNS_EMAX];
+
+    const int tid = threadIdx.x, g = tid / VG, l = tid % VG;
+    int64_t blk = (int64_t)blockIdx.x;
+    if (group_log2 > 0) {                                  // XCD-grouped order of the launch's positions (as in the gather kernel)
+        const int64_t span = (int64_t)1 << (3 + group_log2), nb = (int64_t)nblocks;
+        if (blk < nb - (nb & (span - 1))) {
+            const int64_t xcd = blk & 7, q = blk >> 3;
+            blk = ((((q >> group_log2) << 3) + xcd) << group_log2) + (q & (((int64_t)1 << group_log2) - 1));
+        }
+    }
+    if (block_list) blk = (int64_t)block_list[blk];
+    const int64_t r0 = blk * RPB_MM;
+    const int nr = (int)((nrows - r0) < RPB_MM ? (nrows - r0) : RPB_MM);
+    const SpmmRunDesc d = runs[blk];
+    const int64_t p0 = (int64_t)rowptr[r0] - base, p1 = (int64_t)rowptr[r0 + nr] - base;
+    I rlo = 0, rhi = 0;                                    // raw: first used behind the staging barrier
+    if (g < nr) { rlo = rowptr[r0 + g]; rhi = rowptr[r0 + g + 1]; }
+    const int total = (int)(p1 - p0);
+    const int o1 = d.len[0], o2 = o1 + d.len[1], o3 = o2 + d.len[2], T = o3 + d.len[3];      // tile row offsets of the runs
+
+    if (d.len[0] < 0) {
+        // the block does not fit the tile (workgroup-uniform; rare by the host layer's choice): per-entry gathers straight
+        // from global memory, four lanes per row, same order of the sums
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        if (g < nr) {
+            for (int64_t j = (int64_t)rlo - base; j < (int64_t)rhi - base; ++j) {
+                const double v = nzval[j];
+                const int64_t c = (int64_t)colval[j] - base;
+                const double *row = (SPLIT && c >= n_own) ? B_ghost + (c - n_own) * KT : B_own + c * KT;
+                const vdouble2 b0 = *reinterpret_cast<const vdouble2 *>(row + 2 * l);
+                const vdouble2 b1 = *reinterpret_cast<const vdouble2 *>(row + 8 + 2 * l);
+                acc[0] += v * b0.x; acc[1] += v * b0.y; acc[2] += v * b1.x; acc[3] += v * b1.y;
+            }
+            vdouble2 q0, q1;
+            q0.x = acc[0]; q0.y = acc[1]; q1.x = acc[2]; q1.y = acc[3];
+            *reinterpret_cast<vdouble2 *>(C + (r0 + g) * KT + 2 * l) = q0;
+            *reinterpret_cast<vdouble2 *>(C + (r0 + g) * KT + 8 + 2 * l) = q1;
+        }
+        return;
+    }
+
+    // B rows -> LDS: piece q = 8 tile rows = 1 KiB = one wave-instruction (lanes 8 r .. 8 r + 7 carry row r of the piece)
+    {
+        const int wave = tid >> 6, lane = tid & 63;
+        const int npieces = (T + 7) >> 3;
+        for (int q = wave; q < npieces; q += TPB_MM / 64) {
+            int t = q * 8 + (lane >> 3);
+            if (t >= T) t = T - 1;                          // the ragged last piece re-reads the last row (inside the tile's capacity)
+            const int64_t sc = t < o1 ? (int64_t)d.start[0] + t
+                                      : (t < o2 ? (int64_t)d.start[1] + (t - o1) : (t < o3 ? (int64_t)d.start[2] + (t - o2) : (int64_t)d.start[3] + (t - o3)));
+            const double *src = ((SPLIT && sc >= n_own) ? B_ghost + (sc - n_own) * KT : B_own + sc * KT) + (lane & 7) * 2;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(s_tile + q * 8 * KT), 16, 0, 0);
+        }
+    }
+    // A entries -> {LDS offset of the B row, value}: both of a thread's entries are requested before the first is used
+    {
+        static_assert(RUNS_EMAX == 2 * TPB_MM, "two entries per thread");
+        const int i0 = tid, i1 = tid + TPB_MM;
+        int64_t c0 = 0, c1 = 0;
+        double v0 = 0.0, v1 = 0.0;
+        if (i0 < total) { c0 = (int64_t)__builtin_nontemporal_load(colval + p0 + i0) - base; v0 = __builtin_nontemporal_load(nzval + p0 + i0); }
+        if (i1 < total) { c1 = (int64_t)__builtin_nontemporal_load(colval + p0 + i1) - base; v1 = __builtin_nontemporal_load(nzval + p0 + i1); }
+        auto tile_row = [&](int64_t c) -> int {
+            if (d.len[3] > 0 && c >= d.start[3]) return o3 + (int)(c - d.start[3]);
+            if (d.len[2] > 0 && c >= d.start[2]) return o2 + (int)(c - d.start[2]);
+            if (d.len[1] > 0 && c >= d.start[1]) return o1 + (int)(c - d.start[1]);
+            return (int)(c - d.start[0]);
+        };
+        if (i0 < total) { s_off[i0] = tile_row(c0) * (KT * 8); s_val[i0] = v0; }
+        if (i1 < total) { s_off[i1] = tile_row(c1) * (KT * 8); s_val[i1] = v1; }
+    }
+    __syncthreads();                                        // (drains the LDS-DMA too: vmcnt(0), then the barrier)
+
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    if (g < nr) {
+        const char *tile = reinterpret_cast<const char *>(s_tile) + l * 16;
+        int j = (int)((int64_t)rlo - base - p0);
+        const int e = (int)((int64_t)rhi - base - p0);
+        for (; j + 2 <= e; j += 2) {
+            const int oa = s_off[j], ob = s_off[j + 1];
+            const double va = s_val[j], vb = s_val[j + 1];
+            const vdouble2 a0 = *reinterpret_cast<const vdouble2 *>(tile + oa), a1 = *reinterpret_cast<const vdouble2 *>(tile + oa + 64);
+            const vdouble2 b0 = *reinterpret_cast<const vdouble2 *>(tile + ob), b1 = *reinterpret_cast<const vdouble2 *>(tile + ob + 64);
+            acc[0] += va * a0.x; acc[1] += va * a0.y; acc[2] += va * a1.x; acc[3] += va * a1.y;
+            acc[0] += vb * b0.x; acc[1] += vb * b0.y; acc[2] += vb * b1.x; acc[3] += vb * b1.y;
+        }
+        for (; j < e; ++j) {
+            const int oa = s_off[j];
+            const double va = s_val[j];
+            const vdouble2 a0 = *reinterpret_cast<const vdouble2 *>(tile + oa), a1 = *reinterpret_cast<const vdouble2 *>(tile + oa + 64);
+            acc[0] += va * a0.x; acc[1] += va * a0.y; acc[2] += va * a1.x; acc[3] += va * a1.y;
+        }
+    }
+    __syncthreads();                                        // everybody has finished reading the tile
+    double *s_c = s_tile;
+    vdouble2 q0, q1;
+    q0.x = acc[0]; q0.y = acc[1]; q1.x = acc[2]; q1.y = acc[3];
+    *reinterpret_cast<vdouble2 *>(s_c + g * KT + 2 * l) = q0;         // columns {2l, 2l+1} and {8+2l, 8+2l+1} (the HALF64 mapping)
+    *reinterpret_cast<vdouble2 *>(s_c + g * KT + 8 + 2 * l) = q1;
+    __syncthreads();
+    vdouble2 *dst = reinterpret_cast<vdouble2 *>(C + r0 * KT);
+    const vdouble2 *srcl = reinterpret_cast<const vdouble2 *>(s_c);
+#pragma unroll
+    for (int u = 0; u < (RPB_MM * KT / 2) / TPB_MM; ++u) {
+        const int i = tid + u * TPB_MM;
+        if (i < nr * (KT / 2)) __builtin_nontemporal_store(srcl[i], dst + i);
+    }
+}
+
+// Plan time, once per structure: the run descriptor of every 64-row block.  One workgroup per block: the block's (split)
+// columns are sorted in LDS (bitonic, <= RUNS_EMAX keys), an element starts a run where it is neither equal to nor the
+// successor of its predecessor, or where it crosses the own / ghost boundary; runs are ranked by wave ballots.
+template <typename I>
+__global__ __launch_bounds__(TPB_MM) void spmm_runs_build_kernel(const I *__restrict__ rowptr, const I *__restrict__ colval,
+                                                                 int64_t nrows, int base, int64_t n_own,
+                                                                 SpmmRunDesc *__restrict__ runs,
+                                                                 unsigned long long *__restrict__ n_fit)
+{
+    __shared__ int64_t s_key[RUNS_EMAX];
+    __shared__ unsigned long long s_mask[RUNS_EMAX / 64];
+    __shared__ int s_start_idx[RUNS_MAX + 1];
+    const int tid = threadIdx.x;
+    const int64_t blk = blockIdx.x, r0 = blk * RPB_MM;
+    const int nr = (int)((nrows - r0) < RPB_MM ? (nrows - r0) : RPB_MM);
+    const int64_t p0 = (int64_t)rowptr[r0] - base, p1 = (int64_t)rowptr[r0 + nr] - base;
+    const int64_t total = p1 - p0;
+    SpmmRunDesc d;
+    for (int i = 0; i < RUNS_MAX; ++i) { d.start[i] = 0; d.len[i] = 0; }
+    if (total > RUNS_EMAX) {                               // workgroup-uniform
+        if (tid == 0) { d.len[0] = -1; runs[blk] = d; }
+        return;
+    }
+    constexpr int64_t BIG = (int64_t)1 << 62;
+    for (int i = tid; i < RUNS_EMAX; i += TPB_MM) s_key[i] = i < total ? (int64_t)colval[p0 + i] - base : BIG;
+    __syncthreads();
+    for (int k = 2; k <= RUNS_EMAX; k <<= 1)                // bitonic sort, ascending
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < RUNS_EMAX; i += TPB_MM) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const int64_t a = s_key[i], b = s_key[ixj];
+                    const bool up = (i & k) == 0;
+                    if (up ? a > b : a < b) { s_key[i] = b; s_key[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    // run starts (element e = tid + h * TPB_MM; wave w of half h owns mask word h * 4 + w)
+    bool st[2];
+    int n_starts = 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int e = tid + h * TPB_MM;
+        bool is = false;
+        if (e < total) {
+            const int64_t c = s_key[e];
+            if (e == 0) is = true;
+            else {
+                const int64_t pc = s_key[e - 1];
+                is = (c > pc + 1) || (pc < n_own && c >= n_own);
+            }
+        }
+        st[h] = is;
+        const unsigned long long m = __ballot(is);
+        if ((tid & 63) == 0) s_mask[h * (TPB_MM / 64) + (tid >> 6)] = m;
+        n_starts += __syncthreads_count(is);
+    }
+    if (tid <= RUNS_MAX) s_start_idx[tid] = (int)total;
+    __syncthreads();
+    if (n_starts > RUNS_MAX || total == 0) {               // workgroup-uniform (an empty block "fits": nothing to stage)
+        if (tid == 0) {
+            if (total != 0) d.len[0] = -1;
+            else atomicAdd(n_fit, 1ULL);
+            runs[blk] = d;
+        }
+        return;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+        if (st[h]) {
+            const int word = h * (TPB_MM / 64) + (tid >> 6);
+            int rank = __popcll(s_mask[word] & ((1ULL << (tid & 63)) - 1ULL));
+            for (int w = 0; w < word; ++w) rank += __popcll(s_mask[w]);
+            s_start_idx[rank] = tid + h * TPB_MM;
+        }
+    __syncthreads();
+    if (tid == 0) {
+        int rows = 0;
+        for (int r = 0; r < n_starts; ++r) {
+            const int64_t s0 = s_key[s_start_idx[r]], s1 = s_key[s_start_idx[r + 1] - 1];
+            d.start[r] = (int32_t)s0;
+            d.len[r] = (int32_t)(s1 - s0 + 1);
+            rows += d.len[r];
+            if (s1 > 0x7fffffffLL) rows = RUNS_TILE_ROWS + 1;          // descriptors hold Int32 columns
+        }
+        if (rows > RUNS_TILE_ROWS) { d.len[0] = -1; }
+        else atomicAdd(n_fit, 1ULL);
+        runs[blk] = d;
+    }
+}
+
 // tiled transpose / layout conversion: dst(i,c) = src(i,c), arbitrary (row,col) strides
 __global__ __launch_bounds__(256) void relayout_kernel(const double *__restrict__ src,
                                                        int64_t s_rs, int64_t s_cs,
@@ -707,6 +944,105 @@ HPCLA_API int hpcla_spmm_split_f64_i64(const int64_t *rowptr, const int64_t *col
     return spmm_launch<int64_t>(rowptr, colval_split, nzval, B_own, ldb_own, 1, B_ghost, ldb_ghost,
                                 n_own, true, C, ldc, 1, nrows, nnz, k, index_base, block_list,
                                 n_blocks, stream);
+}
+
+// ---- RUN TILES: plan-time descriptors + the k = 16 kernel (see spmm_rowblock_runs_kernel) ----------------------------
+HPCLA_API int64_t hpcla_spmm_runs_desc_bytes(int64_t nrows)
+{
+    return nrows < 0 ? 0 : (int64_t)sizeof(SpmmRunDesc) * ((nrows + RPB_MM - 1) / RPB_MM);
+}
+
+template <typename I>
+static int spmm_runs_build(const I *rowptr, const I *colval_split, int64_t nrows, int64_t nnz, int index_base, int64_t n_own,
+                           void *desc, int64_t *n_fit_host, void *stream)
+{
+    if (n_fit_host) *n_fit_host = 0;
+    if (nrows < 0 || nnz < 0) return set_error(HPCLA_ERR_INVALID, "spmm_runs_build: negative size");
+    if (index_base != 0 && index_base != 1) return set_error(HPCLA_ERR_INVALID, "spmm_runs_build: index_base must be 0 or 1");
+    if (nrows == 0) return HPCLA_OK;
+    if (!rowptr || !desc || (nnz > 0 && !colval_split)) return set_error(HPCLA_ERR_INVALID, "spmm_runs_build: null pointer");
+    if (n_own > 0x7fffffffLL) return set_error(HPCLA_ERR_UNSUPPORTED, "spmm_runs_build: split columns beyond Int32");
+    const int64_t nb = (nrows + RPB_MM - 1) / RPB_MM;
+    HPCLA_CHECK_GRID(nb, "spmm_runs_build");
+    unsigned long long *d_fit = nullptr;
+    HPCLA_CHECK_HIP(hipMalloc((void **)&d_fit, sizeof(unsigned long long)));
+    hipStream_t s = as_stream(stream);
+    hipError_t e = hipMemsetAsync(d_fit, 0, sizeof(unsigned long long), s);
+    if (e == hipSuccess) {
+        spmm_runs_build_kernel<I><<<(uint32_t)nb, TPB_MM, 0, s>>>(rowptr, colval_split, nrows, index_base, n_own,
+                                                                  reinterpret_cast<SpmmRunDesc *>(desc), d_fit);
+        e = hipGetLastError();
+    }
+    unsigned long long fit = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&fit, d_fit, sizeof(fit), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d_fit);
+    if (e != hipSuccess) return set_error(HPCLA_ERR_HIP, "spmm_runs_build: %s", hipGetErrorString(e));
+    if (n_fit_host) *n_fit_host = (int64_t)fit;
+    return HPCLA_OK;
+}
+
+HPCLA_API int hpcla_spmm_runs_build_i32(const int32_t *rowptr, const int32_t *colval_split, int64_t nrows, int64_t nnz,
+                                        int index_base, int64_t n_own, void *desc, int64_t *n_fit_host, void *stream)
+{
+    return spmm_runs_build<int32_t>(rowptr, colval_split, nrows, nnz, index_base, n_own, desc, n_fit_host, stream);
+}
+
+HPCLA_API int hpcla_spmm_runs_build_i64(const int64_t *rowptr, const int64_t *colval_split, int64_t nrows, int64_t nnz,
+                                        int index_base, int64_t n_own, void *desc, int64_t *n_fit_host, void *stream)
+{
+    return spmm_runs_build<int64_t>(rowptr, colval_split, nrows, nnz, index_base, n_own, desc, n_fit_host, stream);
+}
+
+template <typename I>
+static int spmm_runs_launch(const I *rowptr, const I *colval_split, const double *nzval, const double *B_own,
+                            const double *B_ghost, int64_t n_own, double *C, int64_t nrows, int64_t nnz, int index_base,
+                            const void *desc, const int32_t *block_list, int64_t n_blocks, void *stream)
+{
+    if (nrows < 0 || nnz < 0) return set_error(HPCLA_ERR_INVALID, "spmm_runs: negative size");
+    if (index_base != 0 && index_base != 1) return set_error(HPCLA_ERR_INVALID, "spmm_runs: index_base must be 0 or 1");
+    if (nrows == 0) return HPCLA_OK;
+    if (!rowptr || !C || !desc) return set_error(HPCLA_ERR_INVALID, "spmm_runs: null rowptr / C / descriptors");
+    if (nnz > 0 && (!colval_split || !nzval || !B_own)) return set_error(HPCLA_ERR_INVALID, "spmm_runs: null colval / nzval / B with nnz > 0");
+    if (((reinterpret_cast<uintptr_t>(B_own) | reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(B_ghost)) & 15) != 0)
+        return set_error(HPCLA_ERR_INVALID, "spmm_runs: B / ghost / C must be 16-byte aligned");
+    const int64_t all_blocks = (nrows + RPB_MM - 1) / RPB_MM;
+    int64_t launch_blocks = all_blocks;
+    if (block_list) {
+        if (n_blocks < 0 || n_blocks > all_blocks) return set_error(HPCLA_ERR_INVALID, "spmm_runs: n_blocks out of range");
+        launch_blocks = n_blocks;
+    }
+    if (launch_blocks == 0) return HPCLA_OK;
+    HPCLA_CHECK_GRID(launch_blocks, "spmm_runs");
+    hipStream_t s = as_stream(stream);
+    const SpmmRunDesc *rd = reinterpret_cast<const SpmmRunDesc *>(desc);
+    const int glog2 = spmm_group_log2(rowptr);
+    if (B_ghost)
+        spmm_rowblock_runs_kernel<I, true><<<(uint32_t)launch_blocks, TPB_MM, 0, s>>>(
+            rowptr, colval_split, nzval, B_own, B_ghost, n_own, C, nrows, index_base, rd, block_list, (uint32_t)launch_blocks, glog2);
+    else
+        spmm_rowblock_runs_kernel<I, false><<<(uint32_t)launch_blocks, TPB_MM, 0, s>>>(
+            rowptr, colval_split, nzval, B_own, nullptr, 0, C, nrows, index_base, rd, block_list, (uint32_t)launch_blocks, glog2);
+    HPCLA_CHECK_LAUNCH();
+    return HPCLA_OK;
+}
+
+HPCLA_API int hpcla_spmm_runs_k16_f64_i32(const int32_t *rowptr, const int32_t *colval_split, const double *nzval,
+                                          const double *B_own, const double *B_ghost, int64_t n_own, double *C,
+                                          int64_t nrows, int64_t nnz, int index_base, const void *desc,
+                                          const int32_t *block_list, int64_t n_blocks, void *stream)
+{
+    return spmm_runs_launch<int32_t>(rowptr, colval_split, nzval, B_own, B_ghost, n_own, C, nrows, nnz, index_base, desc,
+                                     block_list, n_blocks, stream);
+}
+
+HPCLA_API int hpcla_spmm_runs_k16_f64_i64(const int64_t *rowptr, const int64_t *colval_split, const double *nzval,
+                                          const double *B_own, const double *B_ghost, int64_t n_own, double *C,
+                                          int64_t nrows, int64_t nnz, int index_base, const void *desc,
+                                          const int32_t *block_list, int64_t n_blocks, void *stream)
+{
+    return spmm_runs_launch<int64_t>(rowptr, colval_split, nzval, B_own, B_ghost, n_own, C, nrows, nnz, index_base, desc,
+                                     block_list, n_blocks, stream);
 }
 
 // One PANEL of a product in panel order (the opt-in order of the distributed SpMM): a CSR

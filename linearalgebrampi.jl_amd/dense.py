@@ -597,6 +597,47 @@ def _spmm_block_order(A, plan, rowptr, colval_split, is_i64, Bc, ghost, C, k, bl
     return group
 
 
+RUNS_MIN_FIT = 0.99            # use the run-tile kernel when at least this share of the 64-row blocks fits its tile
+
+
+def _spmm_runs(A, plan, rowptr, colval_split, is_i64):
+    """Run descriptors of the SpMM row blocks for this (structure, split column space), built ONCE (plan time,
+    ``hpcla_spmm_runs_build_*``: sorts every 64-row block's columns on the device and cuts them into <= 4 contiguous
+    runs), or None when the run-tile kernel should not be used: fewer than RUNS_MIN_FIT of the blocks fit (unstructured
+    columns: config 5), or ``HPCLA_SPMM_RUNS=0``.  Cached on the vector plan, keyed by the colval array it describes."""
+    cache = plan.__dict__.setdefault("_spmm_runs", {})
+    key = (colval_split.data_ptr(), rowptr.data_ptr())
+    if key in cache:
+        return cache[key]
+    desc = None
+    if os.environ.get("HPCLA_SPMM_RUNS", "1").strip().lower() not in ("0", "off", "false", "no") and A.nrows_local > 0 and A.nnz > 0:
+        torch = _torch()
+        nb = (A.nrows_local + 63) // 64
+        buf = torch.empty(_capi.load().hpcla_spmm_runs_desc_bytes(A.nrows_local), dtype=torch.uint8, device=A.backend.torch_device)
+        n_fit = ctypes.c_int64(0)
+        sfx = "i64" if is_i64 else "i32"
+        try:
+            _capi.call(f"hpcla_spmm_runs_build_{sfx}", dptr(rowptr), dptr(colval_split), A.nrows_local, A.nnz, 0, plan.n_own,
+                       dptr(buf), ctypes.byref(n_fit), current_stream_ptr())
+            if n_fit.value >= RUNS_MIN_FIT * nb:
+                desc = buf
+        except _capi.HPCLAError as exc:            # an optional performance step must not take A*B down with it
+            import sys
+            sys.stderr.write(f"hpcla: SpMM run descriptors not built ({exc}); gather kernel stays\n")
+        cache[(key, "fit")] = (int(n_fit.value), nb)
+    cache[key] = desc
+    return desc
+
+
+def spmm_runs_fit_of(A, B: HPCMatrix):
+    """(blocks that fit the run tile, blocks) of the plan for ``A * B``, or None before the first k = 16 product."""
+    plan, ent = _spmm_plan(A, B)
+    for k_, v in plan.__dict__.get("_spmm_runs", {}).items():
+        if isinstance(k_, tuple) and len(k_) == 2 and k_[1] == "fit":
+            return v
+    return None
+
+
 def spmm_block_order_of(A, B: HPCMatrix) -> int:
     """The block-order group the plan measured for ``A * B`` (1 = natural; 0 = not measured yet)."""
     plan, ent = _spmm_plan(A, B)
@@ -627,6 +668,12 @@ def spmm(A, B: HPCMatrix) -> HPCMatrix:
     if ent is None or ent[0] is None:
         # every column owned: split indices == offsets into B's local rows
         sfx = "i64" if plan.is_i64 else "i32"
+        runs = _spmm_runs(A, plan, plan.rowptr_of(A), plan.colval_split, plan.is_i64) if k == 16 else None
+        if runs is not None:
+            # banded / stencil structure: the blocks' B rows are staged as contiguous runs (csrc/spmm.hip, RUN TILES)
+            _capi.call(f"hpcla_spmm_runs_k16_f64_{sfx}", dptr(plan.rowptr_of(A)), dptr(plan.colval_split), dptr(A.nzval),
+                       dptr(Bc), None, plan.n_own, dptr(C), A.nrows_local, A.nnz, 0, dptr(runs), None, 0, s)
+            return out
         _capi.call(f"hpcla_spmm_csr_f64_{sfx}", dptr(plan.rowptr_of(A)), dptr(plan.colval_split),
                    dptr(A.nzval), dptr(Bc), k, _capi.LAYOUT_ROW, dptr(C), k, _capi.LAYOUT_ROW,
                    A.nrows_local, A.nnz, k, 0, s)
@@ -635,16 +682,24 @@ def spmm(A, B: HPCMatrix) -> HPCMatrix:
     halo, interior, boundary, _, colval_split, ghost = ent[:6]
     sfx = "i64" if ent[10] else "i32"
     rowptr = _entry_rowptr(A, plan, bool(ent[10]))
+    runs = _spmm_runs(A, plan, rowptr, colval_split, bool(ent[10])) if (k == 16 and ghost) else None
+
+    def blocks_launch(blocks):
+        if runs is not None:
+            _capi.call(f"hpcla_spmm_runs_k16_f64_{sfx}", dptr(rowptr), dptr(colval_split), dptr(A.nzval), dptr(Bc), ghost,
+                       plan.n_own, dptr(C), A.nrows_local, A.nnz, 0, dptr(runs), dptr(blocks), int(blocks.numel()), s)
+        else:
+            _capi.call(f"hpcla_spmm_split_f64_{sfx}", dptr(rowptr), dptr(colval_split),
+                       dptr(A.nzval), dptr(Bc), k, ghost, k, plan.n_own, dptr(C), k, A.nrows_local,
+                       A.nnz, k, 0, dptr(blocks), int(blocks.numel()), s)
     _capi.call("hpcla_halo_begin", halo, dptr(Bc), s)
     if interior.numel():
-        _capi.call(f"hpcla_spmm_split_f64_{sfx}", dptr(rowptr), dptr(colval_split),
-                   dptr(A.nzval), dptr(Bc), k, ghost, k, plan.n_own, dptr(C), k, A.nrows_local,
-                   A.nnz, k, 0, dptr(interior), int(interior.numel()), s)
+        blocks_launch(interior)
     _capi.call("hpcla_halo_end", halo, s)
     if boundary.numel():
-        _capi.call(f"hpcla_spmm_split_f64_{sfx}", dptr(rowptr), dptr(colval_split),
-                   dptr(A.nzval), dptr(Bc), k, ghost, k, plan.n_own, dptr(C), k, A.nrows_local,
-                   A.nnz, k, 0, dptr(boundary), int(boundary.numel()), s)
+        blocks_launch(boundary)
+    if runs is not None:
+        return out
     # (local launches only -- no exchange: the ranks need not agree on the order, every order is a bijection)
     _spmm_block_order(A, plan, rowptr, colval_split, bool(ent[10]), Bc, ghost, C, k,
                       boundary if boundary.numel() >= interior.numel() else interior)

@@ -135,3 +135,23 @@ def test_bench_main_derives_the_launcher_limit_from_the_outer_limit():
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert '"1500"' not in src and "budget.launcher_timeout()" in src
     assert "HPCLA_BENCH_BREAKDOWN_TIMEOUT_S\", \"240\"" not in src
+
+
+def test_n_gt_1_records_carry_roofline_traffic_from_the_single_rank_passes():
+    """no `"traffic": null` in an N > 1 line.  PMC counters cannot be read from inside the process,
+    so every record takes the builder's stored single-rank rocprofv3 passes of the same per-GPU share and SAYS so."""
+    import bench
+    from benchmarks.extra_workloads import stored_traffic
+    for world in (1, 2, 8):
+        t, src = bench.headline_traffic(32, True)
+        assert t and t > 1.3e9 and "NOT measured by this run" in src
+    t1, s1 = bench.headline_traffic(1, True)               # the natural order has a pass of its own
+    t32, s32 = bench.headline_traffic(32, True)
+    assert t1 != t32 and "natural" in s1 and "groups of 32" in s32
+    assert bench.headline_traffic(32, False) [0] is None
+    for key in ("poisson3d_cg_iteration", "poisson2d_spmm", "sprand_spmm_b2e24"):
+        t1, s1 = stored_traffic(key, True, 1)
+        t8, s8 = stored_traffic(key, True, 8, "note about the share")
+        assert t1 == t8 and t1 > 1e9
+        assert "SINGLE-RANK" in s8 and "N = 8" in s8 and "note about the share" in s8 and "SINGLE-RANK" not in s1
+    assert stored_traffic("no such workload", True, 8)[0] is None

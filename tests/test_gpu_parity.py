@@ -1608,3 +1608,119 @@ def test_host_collectives_on_mixed_gloo_nccl_group():
 def test_graft_entry_smoke():
     import __graft_entry__ as g
     g.smoke()
+
+
+@pytest.mark.parametrize("Ti", [np.int32, np.int64])
+def test_spmm_run_tiles_raw_abi(hp, orc, gpu_backend_i32, Ti):
+    """hpcla_spmm_runs_build_* / hpcla_spmm_runs_k16_f64_* (RUN TILES): descriptors = the distinct columns of every
+    64-row block as <= 4 contiguous runs, cut at the own / ghost boundary; blocks with more runs, > 200 rows or > 512
+    entries are marked; the product is bit-identical to the oracle's column loop (src/sparse.jl:2391-2413) for fitting
+    and for marked blocks alike, with and without a ghost segment, through block lists and in both index bases."""
+    import ctypes
+    import torch
+    k = 16
+    s = torch.cuda.current_stream().cuda_stream
+    sfx = "i32" if Ti == np.int32 else "i64"
+    lib = hp._capi.load()
+
+    def run_case(rows, n_own, base, expect_fit=None, lists=True):
+        n = rows.nrows
+        ci, cv = orc.compress_columns(rows)
+        ncomp = len(ci)
+        Bg = orc.fill_uniform(0, ncomp * k, 21).reshape(ncomp, k)
+        want = orc.spmm(rows.rowptr.astype(np.int32), cv.astype(np.int32), rows.vals, Bg)
+        rp, dcv, nz = _t((rows.rowptr + base).astype(Ti)), _t((cv + base).astype(Ti)), _t(rows.vals)
+        dB_own = _t(Bg[:n_own].ravel()) if n_own else torch.zeros(16, dtype=torch.float64, device="cuda")
+        dB_gh = _t(Bg[n_own:].ravel()) if n_own < ncomp else None
+        desc = torch.empty(lib.hpcla_spmm_runs_desc_bytes(n), dtype=torch.uint8, device="cuda")
+        n_fit = ctypes.c_int64(-1)
+        hp._capi.call(f"hpcla_spmm_runs_build_{sfx}", rp.data_ptr(), dcv.data_ptr(), n, rows.nnz, base, n_own, desc.data_ptr(),
+                      ctypes.byref(n_fit), s)
+        nblk = (n + 63) // 64
+        d = desc.cpu().numpy().view(np.int32).reshape(nblk, 8)
+        # the descriptors against a host restatement
+        fit_ref = 0
+        for b in range(nblk):
+            lo, hi = rows.rowptr[b * 64], rows.rowptr[min((b + 1) * 64, n)]
+            cols = np.unique(cv[lo:hi])
+            if len(cols) == 0:
+                assert (d[b] == 0).all()
+                fit_ref += 1
+                continue
+            brk = np.flatnonzero((np.diff(cols) != 1) | ((cols[:-1] < n_own) & (cols[1:] >= n_own))) + 1
+            starts = np.concatenate([[0], brk])
+            lens = np.diff(np.concatenate([starts, [len(cols)]]))
+            ok = len(starts) <= 4 and len(cols) <= 200 and hi - lo <= 512
+            assert (d[b, 4] >= 0) == ok, (b, d[b], len(starts), len(cols), hi - lo)
+            if ok:
+                fit_ref += 1
+                np.testing.assert_array_equal(d[b, :len(starts)], cols[starts])
+                np.testing.assert_array_equal(d[b, 4:4 + len(starts)], lens)
+                assert (d[b, 4 + len(starts):] == 0).all()
+        assert n_fit.value == fit_ref
+        if expect_fit is not None:
+            assert (fit_ref == nblk) == expect_fit, (fit_ref, nblk)
+        perm = np.random.default_rng(4).permutation(nblk).astype(np.int32)
+        for lst in ([None, _t(perm)] if lists else [None]):
+            C = torch.full((n * k,), float("nan"), dtype=torch.float64, device="cuda")
+            hp._capi.call(f"hpcla_spmm_runs_k16_f64_{sfx}", rp.data_ptr(), dcv.data_ptr(), nz.data_ptr(), dB_own.data_ptr(),
+                          dB_gh.data_ptr() if dB_gh is not None else None, n_own, C.data_ptr(), n, rows.nnz, base, desc.data_ptr(),
+                          lst.data_ptr() if lst is not None else None, nblk if lst is not None else 0, s)
+            torch.cuda.synchronize()
+            np.testing.assert_array_equal(C.cpu().numpy().reshape(n, k), want)
+
+    # 5-point matrix, every column owned: 3 runs of 64 / 66 / 64 rows per block; ragged last block
+    nx, ny = 200, 37
+    rows = orc.poisson2d_rows(nx, ny, 0, nx * ny)
+    run_case(rows, nx * ny, 0, expect_fit=True)
+    run_case(rows, nx * ny, 1, expect_fit=True, lists=False)
+    # a rank's slab of it: ghost lines above and below; the own / ghost cut falls INSIDE a run of consecutive columns
+    lo, hi = 5 * nx + 13, 21 * nx + 150
+    slab = orc.poisson2d_rows(nx, ny, lo, hi)
+    ci, _ = orc.compress_columns(slab)
+    run_case(slab, int(np.searchsorted(ci, hi) - 0), 0)          # "own" = the compressed columns below hi (a split inside the space)
+    # 7-point matrix: 5 runs per block -> every block marked, still the right product (slow path)
+    r3 = orc.poisson3d_rows(24, 24, 6, 0, 24 * 24 * 6)
+    run_case(r3, 24 * 24 * 6, 0, expect_fit=False, lists=False)
+    # unstructured rows and a block with > 512 entries
+    run_case(orc.sprand_rows(3000, 0.004, 0, 700), 2000, 0, lists=False)
+    rng = np.random.default_rng(3)
+    lens = np.full(130, 3, dtype=np.int64); lens[70] = 600
+    rpx = np.concatenate([[0], np.cumsum(lens)])
+    colsx = np.concatenate([np.sort(rng.choice(5000, size=l, replace=False)) for l in lens])
+    run_case(orc.LocalRows(rpx, colsx.astype(np.int64), rng.standard_normal(int(rpx[-1])), 5000), 4000, 0, lists=False)
+    assert lib.hpcla_spmm_runs_build_i32(None, None, 5, 5, 0, 5, None, None, None) != 0
+    assert lib.hpcla_spmm_runs_k16_f64_i32(None, None, None, None, None, 0, None, 5, 5, 0, None, None, 0, None) != 0
+
+
+def test_spmm_host_layer_takes_run_tiles_on_stencils_only(hp, orc, gpu_backend_i32, gpu_backend_i64, monkeypatch):
+    """A * B with k = 16: the plan builds run descriptors once; a stencil matrix takes the run-tile kernel (every block
+    fits), an unstructured one keeps the gather kernel; HPCLA_SPMM_RUNS=0 switches it off -- the same bits every way."""
+    N, k = 300, 16
+    rows = orc.poisson2d_rows(N, N, 0, N * N)
+    Bg = orc.fill_uniform(0, N * N * k, 5).reshape(N * N, k)
+    want = orc.spmm(rows.rowptr.astype(np.int32), rows.colidx.astype(np.int32), rows.vals, Bg)
+    for backend in (gpu_backend_i32, gpu_backend_i64):
+        A = hp.HPCSparseMatrix_local(rows.rowptr, rows.colidx, rows.vals, N * N, backend)
+        B = hp.HPCMatrix.from_global(Bg, backend)
+        assert hp.spmm_runs_fit_of(A, B) is None
+        np.testing.assert_array_equal((A @ B).local_values(), want)
+        fit, nb = hp.spmm_runs_fit_of(A, B)
+        assert fit == nb == (N * N + 63) // 64
+        np.testing.assert_array_equal((A @ B).local_values(), want)
+    hp.clear_spmm_cache(); hp.clear_plan_cache()
+    monkeypatch.setenv("HPCLA_SPMM_RUNS", "0")
+    A = hp.HPCSparseMatrix_local(rows.rowptr, rows.colidx, rows.vals, N * N, gpu_backend_i32)
+    B = hp.HPCMatrix.from_global(Bg, gpu_backend_i32)
+    np.testing.assert_array_equal((A @ B).local_values(), want)
+    assert hp.spmm_runs_fit_of(A, B) is None
+    monkeypatch.delenv("HPCLA_SPMM_RUNS")
+    n = 20000
+    r2 = orc.sprand_rows(n, 0.001, 0, n)
+    A2 = hp.HPCSparseMatrix_local(r2.rowptr, r2.colidx, r2.vals, n, gpu_backend_i32)
+    B2g = orc.fill_uniform(0, n * k, 6).reshape(n, k)
+    C2 = (A2 @ hp.HPCMatrix.from_global(B2g, gpu_backend_i32)).local_values()
+    fit, nb = hp.spmm_runs_fit_of(A2, hp.HPCMatrix.from_global(B2g, gpu_backend_i32))
+    assert fit < 0.5 * nb
+    np.testing.assert_array_equal(C2, orc.spmm(r2.rowptr.astype(np.int32), r2.colidx.astype(np.int32), r2.vals, B2g))
+    hp.clear_spmm_cache(); hp.clear_plan_cache()
