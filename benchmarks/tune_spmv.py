@@ -88,6 +88,16 @@ def main():
     dot_work = torch.empty(hp._capi.load().hpcla_spmv_dot_work_bytes(n) // 8 + 1, dtype=torch.float64, device="cuda")
 
     def launch(v):
+        if v in (100, 101, 102, 103, 104):
+            hp._capi.load().hpcla_set_spmv_kernel(0)           # the shipped default: row gather (round 4)
+        if v in (105, 106):                                    # the shipped library with the product-parking QUAD kernel of rounds 1-3
+            hp._capi.load().hpcla_set_spmv_kernel(1)
+            if v == 105:
+                return hp._capi.load().hpcla_spmv_csr_f64_i32(A.rowptr_target.data_ptr(), cv.data_ptr(), A.nzval.data_ptr(),
+                                                             x.v.data_ptr(), y.data_ptr(), n, nnz, 0, s)
+            return hp._capi.load().hpcla_spmv_dist_dot_f64_i32(None, None, A.rowptr_target.data_ptr(), plan.colval_split.data_ptr(),
+                                                              A.nzval.data_ptr(), x.v.data_ptr(), n, yvec.v.data_ptr(), n, nnz, 0,
+                                                              None, 0, None, 0, dot_out.data_ptr(), dot_work.data_ptr(), s)
         if v == 100:     # production library, plain kernel
             return hp._capi.load().hpcla_spmv_csr_f64_i32(A.rowptr_target.data_ptr(), cv.data_ptr(), A.nzval.data_ptr(),
                                                          x.v.data_ptr(), y.data_ptr(), n, nnz, 0, s)
@@ -115,7 +125,7 @@ def main():
         rc = launch(v)
         assert rc == 0, (v, rc)
         torch.cuda.synchronize()
-        exact[v] = bool(torch.equal(yvec.v if v in (102, 103, 104) else y, y_ref))
+        exact[v] = bool(torch.equal(yvec.v if v in (102, 103, 104, 106) else y, y_ref))
     for rnd in range(args.rounds):
         for v in variants:
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

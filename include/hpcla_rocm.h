@@ -93,6 +93,13 @@ int hpcla_spmv_split_f64_i64(const int64_t *rowptr, const int64_t *colval_split,
                              int64_t n_own, double *y, int64_t nrows, int64_t nnz, int index_base,
                              const int32_t *block_list, int64_t n_blocks, void *stream);
 int hpcla_spmv_rows_per_block(void);
+/* Which CSR SpMV kernel the aligned launches take (every entry point above and below; no reference counterpart -- the
+ * reference has one work-item per row, src/sparse.jl:2055-2066): 0 = "row gather" (round 4, the default: the block's A
+ * entries are streamed into wave-private LDS unmultiplied and every lane walks its own row, so one gather instruction
+ * reads ONE x stream for banded matrices -- the fix for the L1 tag-conflict stalls of the 7-point matrix,
+ * profiles/r04_spmv_2d_vs_3d_counters.txt), 1 = "quad" (rounds 1-3: a lane owns four consecutive entries, products
+ * parked in LDS).  Bit-identical results.  Also HPCLA_SPMV_KERNEL=rowgather|quad in the environment. */
+int hpcla_set_spmv_kernel(int kind);
 int hpcla_spmm_rows_per_block(void);
 /* SpMM twins of the two block-order entries below (no reference counterpart: src/sparse.jl:2391-2413 is a column loop
  * over A*x in index order): the row blocks (hpcla_spmm_rows_per_block() rows each) of every SpMM launch over `rowptr`

@@ -473,22 +473,26 @@ __global__ __launch_bounds__(TPB_MM) void spmm_rowblock_runs_kernel(
                                              (__attribute__((address_space(3))) void *)(s_tile + q * 8 * KT), 16, 0, 0);
         }
     }
-    // A entries -> {LDS offset of the B row, value}: both of a thread's entries are requested before the first is used
-    {
+    // A entries -> {LDS offset of the B row, value}: both of a thread's entries are requested UNCONDITIONALLY (index
+    // clamped to the block's last entry), so the four loads leave back to back -- a predicated load is a branch, and with an
+    // LDS-DMA in flight the compiler waits vmcnt(0) at the first use behind it: one full round trip per entry otherwise
+    if (total > 0) {                                        // workgroup-uniform
         static_assert(RUNS_EMAX == 2 * TPB_MM, "two entries per thread");
         const int i0 = tid, i1 = tid + TPB_MM;
-        int64_t c0 = 0, c1 = 0;
-        double v0 = 0.0, v1 = 0.0;
-        if (i0 < total) { c0 = (int64_t)__builtin_nontemporal_load(colval + p0 + i0) - base; v0 = __builtin_nontemporal_load(nzval + p0 + i0); }
-        if (i1 < total) { c1 = (int64_t)__builtin_nontemporal_load(colval + p0 + i1) - base; v1 = __builtin_nontemporal_load(nzval + p0 + i1); }
+        const int j0 = i0 < total ? i0 : total - 1, j1 = i1 < total ? i1 : total - 1;
+        const I cr0 = __builtin_nontemporal_load(colval + p0 + j0);
+        const double v0 = __builtin_nontemporal_load(nzval + p0 + j0);
+        const I cr1 = __builtin_nontemporal_load(colval + p0 + j1);
+        const double v1 = __builtin_nontemporal_load(nzval + p0 + j1);
         auto tile_row = [&](int64_t c) -> int {
             if (d.len[3] > 0 && c >= d.start[3]) return o3 + (int)(c - d.start[3]);
             if (d.len[2] > 0 && c >= d.start[2]) return o2 + (int)(c - d.start[2]);
             if (d.len[1] > 0 && c >= d.start[1]) return o1 + (int)(c - d.start[1]);
             return (int)(c - d.start[0]);
         };
-        if (i0 < total) { s_off[i0] = tile_row(c0) * (KT * 8); s_val[i0] = v0; }
-        if (i1 < total) { s_off[i1] = tile_row(c1) * (KT * 8); s_val[i1] = v1; }
+        const int t0 = tile_row((int64_t)cr0 - base), t1 = tile_row((int64_t)cr1 - base);
+        if (i0 < total) { s_off[i0] = t0 * (KT * 8); s_val[i0] = v0; }
+        if (i1 < total) { s_off[i1] = t1 * (KT * 8); s_val[i1] = v1; }
     }
     __syncthreads();                                        // (drains the LDS-DMA too: vmcnt(0), then the barrier)
 

@@ -288,6 +288,143 @@ __global__ __launch_bounds__(RPB) HPCLA_SPMV_ATTRS void spmv_rowblock_quad_kerne
     if (dot_partial) block_dot_epilogue(s_prod, dot_partial, blk, tid < nr ? acc * x_row : 0.0);
 }
 
+// ---- round 4: gathers issued BY ROW ("row gather"), from a wave-private LDS copy of the A entries -------------------
+// Counters of the product-parking kernel above on the 7-point matrix against the 5-point one
+// (profiles/r04_spmv_2d_vs_3d_counters.txt): per stored entry 6.2 x the L1 tag-conflict stall cycles
+// (TCP_READ_TAGCONFLICT_STALL_CYCLES: 21 % of the launch per TCP against 3.5 %), 1.6 x the cycles the address unit waits for
+// the cache, 1.6 x the issue stalls -- while LDS conflicts, TLB misses, L2 misses and HBM requests per entry are equal
+// or lower.  Cause: a lane owns a QUAD of consecutive stored entries, so one gather instruction covers entries 4 L + q,
+// L = 0..63: ~37 rows x all 7 column types = seven x streams in ONE instruction, five of them aligned to the same power
+// of two (i - 2 MiB, i - 4 KiB, i, i + 4 KiB, i + 2 MiB) -- ~24 lines per instruction, most on one tag bank.
+// Here the A entries are streamed into LDS UNMULTIPLIED (coalesced 16-byte loads as before; 12 B per entry) and lane t
+// then walks ITS OWN row: gather instruction j of a wave reads the j-th entry of 64 consecutive rows -- for any banded /
+// stencil matrix ONE x stream, 512 contiguous bytes, 4-5 lines; for unstructured rows no worse than before.  The row sum
+// is the same multiply-add chain in stored order: the reference's bits (src/sparse.jl:2055-2066).
+// WAVE-PRIVATE: every wave owns 64 of the block's 256 rows and its own slice of LDS; LDS operations of one wave complete
+// in order, so the kernel has no workgroup barrier at all (the dot epilogue and the halo wait keep theirs) -- and the
+// 256-row block of the callers' block lists, of the p.Ap partials and of the packed copy stays what it was.
+// Harness (benchmarks/tune/spmv_variants.hip k_rowg / k_rowg_wave, profiles/r04_spmv_rowg.log): 7-point slab -4.3 ... -4.8 %,
+// 4096^2 -1.5 %, 8192^2 -2.2 % against the kernel above under its measured block order.
+constexpr int RG_CHW = 464;                         // entries per wave and pass: 64 rows x 7 + the <= 3 entries in front of the aligned start, rounded up (5.4 KiB of LDS per wave: 7 workgroups per CU)
+constexpr int RG_NQ = (RG_CHW / 4 + 63) / 64;       // quads per lane per pass
+constexpr int RG_UR = 8;                            // entries per gather step
+
+template <typename I, bool SPLIT, bool WAIT>
+__global__ __launch_bounds__(RPB) void spmv_rowgather_kernel(
+    const I *__restrict__ rowptr, const I *__restrict__ colval, const double *__restrict__ nzval,
+    const double *__restrict__ x_own, const double *x_ghost, int64_t n_own,
+    double *__restrict__ y, int64_t nrows, int64_t nnz, int base,
+    BlockSel bs, double *__restrict__ dot_partial, HaloWait hw, PushArgs push)
+{
+    __shared__ __attribute__((aligned(16))) I s_col_all[(RPB / 64) * RG_CHW];
+    __shared__ __attribute__((aligned(16))) double s_val_all[(RPB / 64) * RG_CHW];
+    __shared__ double s_red[RPB / 64];
+
+    if (WAIT && (int)blockIdx.x < push.n_blocks) {
+        halo_push_block<I, RPB>(push, (int)blockIdx.x);
+        return;
+    }
+    const int tid = threadIdx.x;
+    bool wait_ghosts;
+    const int64_t blk = select_block<WAIT>(bs, wait_ghosts, WAIT ? push.n_blocks : 0);
+    uint32_t waited = 0;
+    if (WAIT && wait_ghosts) {     // reader index: the plan's push workgroups come first (window.hip), then the boundary blocks
+        waited = halo_wait_block(hw, hw.first_wait_reader + (uint32_t)(blockIdx.x - push.n_blocks - bs.n_first));
+        x_ghost = hw.ghost0 + (int64_t)(waited & ~HALO_WAIT_TIMED_OUT) * hw.buf_stride;
+    }
+    const int64_t r0 = blk * RPB;
+    const int nr = (int)((nrows - r0) < RPB ? (nrows - r0) : RPB);
+    if (WAIT && (waited & HALO_WAIT_TIMED_OUT)) {
+        // the neighbours' values never arrived (wait expired): this block's rows are POISONED, never computed from stale ghosts
+        if ((int)threadIdx.x < nr) y[r0 + threadIdx.x] = halo_poison();
+        if (dot_partial && threadIdx.x == 0) dot_partial[blk] = halo_poison();
+        return;
+    }
+
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    I *s_col = s_col_all + wave * RG_CHW;
+    double *s_val = s_val_all + wave * RG_CHW;
+    const int64_t rw = r0 + wave * 64;                                   // this wave's rows
+    const int nrw = nr - wave * 64 < 0 ? 0 : (nr - wave * 64 > 64 ? 64 : nr - wave * 64);
+    double acc = 0.0, x_row = 0.0;
+    if (nrw > 0) {                                                       // wave-uniform
+        const int64_t p0 = (int64_t)rowptr[rw] - base;
+        const int64_t p1 = (int64_t)rowptr[rw + nrw] - base;
+        const int64_t pa = p0 & ~(int64_t)3;                             // quad-aligned start (<= 3 entries of the rows before)
+        const int64_t total = p1 - pa;
+        // this lane's row bounds, raw and UNCONDITIONAL (lanes past the wave's last row read that row's pair: a predicated
+        // load is a branch whose merge copies the loaded register, i.e. waits for it on the spot); first used behind the A stream
+        const int ll = lane < nrw ? lane : nrw - 1;
+        I rlo = rowptr[rw + ll], rhi = rowptr[rw + ll + 1];
+        if (dot_partial) x_row = x_own[rw + ll];                         // the epilogue's x rides along with the stream
+        for (int64_t c = 0; c < total; c += RG_CHW) {
+            const int n = (int)((total - c) < RG_CHW ? (total - c) : RG_CHW);
+            if (pa + c + ((n + 3) & ~3) <= nnz) {
+                // every quad of the pass lies inside the arrays: ALL of a lane's quads are requested before the first is
+                // written (lanes past the end re-read the pass's last quad -- lines their neighbours read anyway -- and
+                // write nothing)
+                const int last = (n - 1) & ~3;
+                vec<I, 4> cq[RG_NQ];
+                vec<double, 2> va[RG_NQ], vb[RG_NQ];
+#pragma unroll
+                for (int u = 0; u < RG_NQ; ++u) {
+                    const int e0 = (u * 64 + lane) * 4;
+                    const int ee = e0 < last ? e0 : last;
+                    cq[u] = *reinterpret_cast<const vec<I, 4> *>(colval + pa + c + ee);
+                    va[u] = *reinterpret_cast<const vec<double, 2> *>(nzval + pa + c + ee);
+                    vb[u] = *reinterpret_cast<const vec<double, 2> *>(nzval + pa + c + ee + 2);
+                }
+#pragma unroll
+                for (int u = 0; u < RG_NQ; ++u) {
+                    const int e0 = (u * 64 + lane) * 4;
+                    if (e0 < n) {
+                        *reinterpret_cast<vec<I, 4> *>(&s_col[e0]) = cq[u];
+                        *reinterpret_cast<vec<double, 2> *>(&s_val[e0]) = va[u];
+                        *reinterpret_cast<vec<double, 2> *>(&s_val[e0 + 2]) = vb[u];
+                    }
+                }
+            } else {
+                // the one pass of the launch that reaches past the end of the arrays: entry by entry
+                for (int e = lane; e < n; e += 64) {
+                    const int64_t g = pa + c + e;
+                    s_col[e] = g < nnz ? colval[g] : (I)base;
+                    s_val[e] = g < nnz ? nzval[g] : 0.0;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // this wave's LDS writes, then its LDS reads (in order per wave)
+            __builtin_amdgcn_wave_barrier();
+            // the lane's row bounds are first USED here, behind the A stream: the empty asm makes them loop-variant, or the
+            // compiler hoists the (loop-invariant) subtraction in front of the loop and with it a full memory round trip
+            asm volatile("" : "+v"(rlo), "+v"(rhi));
+            {
+                const int lo = lane < nrw ? (int)((int64_t)rlo - base - pa - c) : 0;
+                const int hi = lane < nrw ? (int)((int64_t)rhi - base - pa - c) : 0;
+                int j = lo > 0 ? lo : 0;
+                const int e = hi < n ? hi : n;
+                // RG_UR entries per step, each under its own lane predicate: the step's gathers leave together (a gather
+                // none of the wave's lanes needs is skipped), the sums follow in stored order
+                for (; j < e; j += RG_UR) {
+                    int64_t cc[RG_UR];
+                    double vv[RG_UR], xx[RG_UR];
+#pragma unroll
+                    for (int u = 0; u < RG_UR; ++u) {
+                        cc[u] = 0; vv[u] = 0.0;
+                        if (j + u < e) { cc[u] = (int64_t)(I)(s_col[j + u] - (I)base); vv[u] = s_val[j + u]; }
+                    }
+#pragma unroll
+                    for (int u = 0; u < RG_UR; ++u) { xx[u] = 0.0; if (j + u < e) xx[u] = gather_x<SPLIT>(x_own, x_ghost, n_own, cc[u]); }
+#pragma unroll
+                    for (int u = 0; u < RG_UR; ++u) if (j + u < e) acc += vv[u] * xx[u];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       // ... and the reads before the next pass's writes
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (lane < nrw) y[rw + lane] = acc;
+    }
+    if (dot_partial) block_dot_epilogue(s_red, dot_partial, blk, lane < nrw ? acc * x_row : 0.0);
+}
+
 // ---- fallback kernel: element-per-lane loads, no alignment requirement --------------------------------
 template <typename I, bool SPLIT, bool WAIT>
 __global__ __launch_bounds__(RPB) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8))) void spmv_rowblock_kernel(
@@ -450,6 +587,20 @@ static int block_order_of(const void *rowptr)
     return it == g_order.end() ? 0 : it->second;
 }
 
+// HPCLA_SPMV_KERNEL = rowgather (default, round 4) | quad (the product-parking kernel of rounds 1-3), or
+// hpcla_set_spmv_kernel() at run time (A/B measurements inside one process): same bits either way
+static std::atomic<int> g_spmv_kernel{-1};          // -1: not decided yet, 0: row gather, 1: quad
+static bool use_rowgather()
+{
+    int k = g_spmv_kernel.load(std::memory_order_relaxed);
+    if (k < 0) {
+        const char *e = getenv("HPCLA_SPMV_KERNEL");
+        k = (e && (e[0] == 'q' || e[0] == 'Q')) ? 1 : 0;
+        g_spmv_kernel.store(k, std::memory_order_relaxed);
+    }
+    return k == 0;
+}
+
 template <typename I>
 static int spmv_launch(const I *rowptr, const I *colval, const double *nzval, const double *x_own,
                        const double *x_ghost, int64_t n_own, bool split, double *y, int64_t nrows,
@@ -491,7 +642,14 @@ static int spmv_launch(const I *rowptr, const I *colval, const double *nzval, co
     memset(&nowait, 0, sizeof(nowait));
     PushArgs nopush;
     memset(&nopush, 0, sizeof(nopush));
-    if (aligned) {
+    if (aligned && use_rowgather()) {
+        if (split)
+            spmv_rowgather_kernel<I, true, false><<<grid, block, 0, s>>>(
+                rowptr, colval, nzval, x_own, x_ghost, n_own, y, nrows, nnz, index_base, bs, dot_partial, nowait, nopush);
+        else
+            spmv_rowgather_kernel<I, false, false><<<grid, block, 0, s>>>(
+                rowptr, colval, nzval, x_own, nullptr, 0, y, nrows, nnz, index_base, bs, dot_partial, nowait, nopush);
+    } else if (aligned) {
         if (split)
             spmv_rowblock_quad_kernel<I, true, false><<<grid, block, 0, s>>>(
                 rowptr, colval, nzval, x_own, x_ghost, n_own, y, nrows, nnz, index_base, bs, dot_partial, nowait, nopush);
@@ -543,7 +701,10 @@ static int spmv_launch_fused(const I *rowptr, const I *colval, const double *nzv
                          (reinterpret_cast<uintptr_t>(nzval) % 32 == 0);
     const BlockSel bs{boundary_list, 0, interior_list, interior_base, n_interior, n_interior,
                       interior_list ? 0 : block_order_of(rowptr)};
-    if (aligned)
+    if (aligned && use_rowgather())
+        spmv_rowgather_kernel<I, true, true><<<grid, block, 0, s>>>(
+            rowptr, colval, nzval, x_own, x_ghost, n_own, y, nrows, nnz, index_base, bs, dot_partial, hw, pa);
+    else if (aligned)
         spmv_rowblock_quad_kernel<I, true, true><<<grid, block, 0, s>>>(
             rowptr, colval, nzval, x_own, x_ghost, n_own, y, nrows, nnz, index_base, bs, dot_partial, hw, pa);
     else
@@ -597,6 +758,13 @@ int spmv_split_i64(const int64_t *rowptr, const int64_t *colval, const double *n
 using namespace hpcla;
 
 HPCLA_API int hpcla_spmv_rows_per_block(void) { return RPB; }
+
+HPCLA_API int hpcla_set_spmv_kernel(int kind)
+{
+    if (kind != 0 && kind != 1) return set_error(HPCLA_ERR_INVALID, "set_spmv_kernel: 0 = row gather, 1 = quad");
+    g_spmv_kernel.store(kind, std::memory_order_relaxed);
+    return HPCLA_OK;
+}
 
 static void set_block_order(const void *rowptr, int group_log2)
 {

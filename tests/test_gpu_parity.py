@@ -1724,3 +1724,62 @@ def test_spmm_host_layer_takes_run_tiles_on_stencils_only(hp, orc, gpu_backend_i
     assert fit < 0.5 * nb
     np.testing.assert_array_equal(C2, orc.spmm(r2.rowptr.astype(np.int32), r2.colidx.astype(np.int32), r2.vals, B2g))
     hp.clear_spmm_cache(); hp.clear_plan_cache()
+
+
+@pytest.mark.parametrize("Ti", [np.int32, np.int64])
+def test_both_spmv_kernels_give_the_reference_bits(hp, orc, gpu_backend_i32, Ti):
+    """hpcla_set_spmv_kernel: 0 = row gather (round 4 default: wave-private LDS copy of the A entries, every lane walks
+    its own row), 1 = quad (rounds 1-3: products parked in LDS).  Both are the reference's row-sequential sum
+    (src/sparse.jl:2055-2066): same bits on stencils, unstructured rows, rows longer than a wave's LDS pass, empty rows,
+    ragged last blocks, the split column space and the fused x.y epilogue."""
+    import torch
+    lib = hp._capi.load()
+    sfx = "i32" if Ti == np.int32 else "i64"
+    s = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(9)
+    cases = [orc.poisson3d_rows(40, 40, 7, 0, 40 * 40 * 7), orc.poisson2d_rows(300, 41, 0, 300 * 41),
+             orc.sprand_rows(5000, 0.004, 0, 5000)]
+    lens = rng.integers(0, 12, 700)
+    lens[[5, 300, 699]] = [1500, 449, 3000]                  # longer than one wave pass (448), across several
+    lens[10:20] = 0
+    rp = np.concatenate([[0], np.cumsum(lens)])
+    cols = np.concatenate([np.sort(rng.choice(4000, size=l, replace=False)) for l in lens if l])
+    cases.append(orc.LocalRows(rp, cols.astype(np.int64), rng.standard_normal(int(rp[-1])), 4000))
+    try:
+        for rows in cases:
+            ci, cv = orc.compress_columns(rows)
+            n, ncomp = rows.nrows, len(ci)
+            xg = orc.fill_uniform(0, ncomp, 77) - 0.5
+            want = orc.spmv(rows.rowptr.astype(np.int32), cv.astype(np.int32), rows.vals, xg)
+            n_own = ncomp // 2 + 3                               # split column space: own part, then "ghosts"
+            d_rp, d_cv, d_nz = _t(rows.rowptr.astype(Ti)), _t(cv.astype(Ti)), _t(rows.vals)
+            d_x, d_xo, d_xg = _t(xg), _t(xg[:n_own]), _t(xg[n_own:])
+            got = {}
+            for kind in (0, 1):
+                hp._capi.call("hpcla_set_spmv_kernel", kind)
+                y = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+                hp._capi.call(f"hpcla_spmv_csr_f64_{sfx}", d_rp.data_ptr(), d_cv.data_ptr(), d_nz.data_ptr(), d_x.data_ptr(),
+                              y.data_ptr(), n, rows.nnz, 0, s)
+                y2 = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+                hp._capi.call(f"hpcla_spmv_split_f64_{sfx}", d_rp.data_ptr(), d_cv.data_ptr(), d_nz.data_ptr(), d_xo.data_ptr(),
+                              d_xg.data_ptr(), n_own, y2.data_ptr(), n, rows.nnz, 0, None, 0, s)
+                torch.cuda.synchronize()
+                np.testing.assert_array_equal(y.cpu().numpy(), want)
+                np.testing.assert_array_equal(y2.cpu().numpy(), want)
+                if ncomp == n:                                   # square: the fused x.y epilogue (x partitioned like the rows)
+                    out = torch.zeros(1, dtype=torch.float64, device="cuda")
+                    work = torch.empty(lib.hpcla_spmv_dot_work_bytes(n) // 8 + 1, dtype=torch.float64, device="cuda")
+                    y3 = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+                    hp._capi.call(f"hpcla_spmv_dist_dot_f64_{sfx}", None, None, d_rp.data_ptr(), d_cv.data_ptr(), d_nz.data_ptr(),
+                                  d_x.data_ptr(), n, y3.data_ptr(), n, rows.nnz, 0, None, 0, None, 0, out.data_ptr(),
+                                  work.data_ptr(), s)
+                    torch.cuda.synchronize()
+                    np.testing.assert_array_equal(y3.cpu().numpy(), want)
+                    got[kind] = float(out.item())
+                    ref = float(np.dot(xg, want))
+                    assert abs(got[kind] - ref) <= 1e-12 * float(np.abs(xg) @ np.abs(want))
+            if got:
+                assert got[0] == got[1]                          # same per-row products, same reduction tree
+        assert lib.hpcla_set_spmv_kernel(2) != 0
+    finally:
+        lib.hpcla_set_spmv_kernel(0)
