@@ -5,7 +5,7 @@ per launch of the headline kernel and, under "workloads", per launch / per CG it
 line -- corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE counts 128-byte requests
 as 64 bytes -> doubled; WRITE_SIZE is exact; both are reported in KiB; separate --pmc passes.
 
-usage: python benchmarks/collect_profiles.py TAG [ROUND]      (ROUND defaults to r03)
+usage: python benchmarks/collect_profiles.py TAG [ROUND]      (ROUND defaults to r04)
 """
 import collections
 import csv
@@ -16,7 +16,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL = "spmv_rowblock_quad_kernel<int, false, false>"     # <index type, SPLIT, WAIT>: the single-GPU headline kernel
+KERNEL = "spmv_rowgather_kernel<int, false, false>"     # <index type, SPLIT, WAIT>: the single-GPU headline kernel (round 4: row gather)
 B_ALG = 1_341_980_676          # config 2, Int32
 ORDER_NOTE = ("block order fixed for the profiled runs (HPCLA_BLOCK_ORDER=32, 64 for the 3-D slab: what the plans' measurement picks on "
               "these matrices) so that no launch of the plan-time measurement sits in the per-kernel means")
@@ -73,10 +73,10 @@ def workload_cg(tag, rnd, prof, alg_textbook, alg_moved):
     wr = find(tag, "pmc_cg_WRITE_SIZE", "counter_collection.csv")
     shutil.copy(rd, os.path.join(prof, f"{rnd}_pmc_cg_FETCH_SIZE.csv"))
     shutil.copy(wr, os.path.join(prof, f"{rnd}_pmc_cg_WRITE_SIZE.csv"))
-    names = ("spmv_rowblock_quad_kernel", "cg_direction_kernel", "cg_residual_kernel", "reduce_stage1", "reduce_stage2")
+    names = ("spmv_rowgather_kernel", "cg_direction_kernel", "cg_residual_kernel", "reduce_stage1", "reduce_stage2")
     fk, wk = per_kernel(rd, "FETCH_SIZE"), per_kernel(wr, "WRITE_SIZE")
-    n_iter_f = sum(len(v) for k, v in fk.items() if "spmv_rowblock_quad_kernel" in k)
-    n_iter_w = sum(len(v) for k, v in wk.items() if "spmv_rowblock_quad_kernel" in k)
+    n_iter_f = sum(len(v) for k, v in fk.items() if "spmv_rowgather_kernel" in k)
+    n_iter_w = sum(len(v) for k, v in wk.items() if "spmv_rowgather_kernel" in k)
     ftot = sum(sum(v) for k, v in fk.items() if any(n in k for n in names))
     wtot = sum(sum(v) for k, v in wk.items() if any(n in k for n in names))
     per = {}
@@ -96,7 +96,7 @@ def workload_cg(tag, rnd, prof, alg_textbook, alg_moved):
 
 def main():
     tag = sys.argv[1]
-    rnd = sys.argv[2] if len(sys.argv) > 2 else "r03"
+    rnd = sys.argv[2] if len(sys.argv) > 2 else "r04"
     prof = os.path.join(ROOT, "profiles")
     shutil.copy(find(tag, "prof", "kernel_stats.csv"), os.path.join(prof, f"{rnd}_bench_kernel_stats.csv"))
     # the trace is large: keep the library's launches only
@@ -145,13 +145,13 @@ def main():
     out["by_block_order"] = by_order
     wl = {}
     wl["poisson2d_spmv_int64"] = workload_single_kernel(
-        tag, "i64", "spmv_rowblock_quad_kernel<long, false, false>", rnd, prof, "headline matrix, Int64 indices", 1_744_568_328,
-        "python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-strong --no-extras --no-packed --index i64")
+        tag, "i64", "spmv_rowgather_kernel<long, false, false>", rnd, prof, "headline matrix, Int64 indices STREAMED (HPCLA_NARROW_INDICES=0)", 1_744_568_328,
+        "HPCLA_NARROW_INDICES=0 python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-strong --no-extras --no-packed --index i64")
     n3, nnz3 = 16_777_216, 116_785_152
     b_spmv3 = 12 * nnz3 + 4 * (n3 + 1) + 8 * n3 + 8 * n3
     wl["poisson3d_cg_iteration"] = workload_cg(tag, rnd, prof, b_spmv3 + 96 * n3, b_spmv3 + 64 * n3)
     wl["poisson2d_spmm"] = workload_single_kernel(
-        tag, "spmm2d", "spmm_rowblock_vec_kernel", rnd, prof, "5-point matrix 4096x2048 rows x 16 columns", 2_684_207_108,
+        tag, "spmm2d", "spmm_rowblock_runs_kernel", rnd, prof, "5-point matrix 4096x2048 rows x 16 columns (run-tile kernel)", 2_684_207_108,
         "python3 bench.py --workload poisson2d_spmm --steps 5 --warmup 5")
     wl["sprand_spmm_b2e24"] = workload_single_kernel(
         tag, "sprand8", "spmm_rowblock_vec_kernel", rnd, prof, "sprand 2 097 152 rows x 29.8, B = 2^24 rows x 16 (config 5's gather set)", 3_122_571_200,

@@ -66,6 +66,34 @@ XGMI_LINK_GBS = 153.0        # MI355X_MICROARCH.md / SURVEY 5: 7 xGMI links per 
 XGMI_LINKS = 7
 
 
+SETTLE_MS = float(os.environ.get("HPCLA_BENCH_SETTLE_MS", "40"))
+
+
+def warm_up(job, step, w_min):
+    """Untimed warm-up of a sub-record: at least `w_min` steps AND at least SETTLE_MS of them (HPCLA_BENCH_SETTLE_MS, default
+    40 ms).  SURVEY 8d lists "clocks" among the purposes of the warm-up: the first ~10 ms after load begins run at clocks
+    that are still ramping (profiles/r02_warmup_transient.log: 2-4 % on the SpMV; profiles/r04_spmm_warmup_ramp.log: the
+    LDS-heavy run-tile SpMM 0.500 ms after 5 warm-up products, 0.474 after 100, while the latency-bound gather kernel reads
+    0.525 either way) -- five launches of a 0.5 ms kernel end inside that ramp.  Returns the number of steps run (reported
+    as the record's `warmup`); every rank runs the same count (decided by rank 0's clock through job.max)."""
+    import torch
+    n = 0
+    for _ in range(w_min):
+        step()
+        n += 1
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    step()
+    torch.cuda.synchronize()
+    one = max(time.perf_counter() - t0, 1e-6)
+    n += 1
+    more = int(job.max(max(0.0, SETTLE_MS * 1e-3 / one - n)))
+    for _ in range(min(more, 2000)):
+        step()
+    torch.cuda.synchronize()
+    return n + min(more, 2000)
+
+
 def _measure_spmm(args, job, hp, wl, A, B, k, world, dev, setup_s, metric, workload, traffic_key=None, share_note=""):
     import torch
     _stamp("spmm: operands ready")
@@ -73,8 +101,11 @@ def _measure_spmm(args, job, hp, wl, A, B, k, world, dev, setup_s, metric, workl
     if os.environ.get("HPCLA_BENCH_VERBOSE", "") == "1":
         torch.cuda.synchronize()
         _stamp("spmm: first product (plan built)")
-    for _ in range(max(args.warmup, 5)):
-        C = A @ B
+    keep = [C]
+
+    def one_product():
+        keep[0] = A @ B
+    n_warm = warm_up(job, one_product, max(args.warmup, 5))
     steps = min(args.steps, 50)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     _sync_barrier(job)
@@ -93,7 +124,7 @@ def _measure_spmm(args, job, hp, wl, A, B, k, world, dev, setup_s, metric, workl
     traffic, traffic_source = stored_traffic(traffic_key, traffic_key is not None, world, share_note)
     out = {
         "metric": metric, "value": round(2.0 * k * A.nnz * world / (ms * 1e-3) / 1e9, 1),
-        "unit": "GFLOP/s", "n_gpus": world, "steps": steps, "warmup": max(args.warmup, 5), "ms_per_step": round(ms, 4),
+        "unit": "GFLOP/s", "n_gpus": world, "steps": steps, "warmup": n_warm, "ms_per_step": round(ms, 4),
         "device_ms_per_step": round(device_ms, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": workload,
@@ -200,7 +231,17 @@ def run_record(args, backend, rank, world, job):
             gp = hp.CGGraphPair(A, ws, plan, fused_eff)
             gp.replay(max(n_warm // 2, 3))
         else:
-            hp.cg_iterate(A, ws, plan, fused_eff, n_warm, native_loop=native)
+            # at least n_warm iterations and at least SETTLE_MS of them (clocks: see warm_up), restarting the solve whenever
+            # the workspace's history is used up
+            done = [0]
+
+            def warm_iterations():
+                if ws.done + 5 > ws.max_iters:
+                    hp.cg_setup(A, b, ws, fused)
+                hp.cg_iterate(A, ws, plan, fused_eff, 5, native_loop=native)
+                done[0] += 5
+            warm_up(job, warm_iterations, (n_warm + 4) // 5)
+            n_warm = done[0]
         torch.cuda.synchronize()
         plan, fused_eff = hp.cg_setup(A, b, ws, fused)          # restart from x0 = 0
         if graph:

@@ -42,6 +42,7 @@ for st in $STEPS; do
       # the plan's block-order measurement (64 launches of the SAME kernel under four orders) would sit in every per-kernel
       # mean: the profiled runs take a fixed order instead, so every counted launch is a launch of the step
       export HPCLA_BLOCK_ORDER=${PMC_ORDER_2D:-32}
+      export HPCLA_SPMM_BLOCK_ORDER=natural HPCLA_BENCH_SETTLE_MS=0     # likewise: no SpMM order measurement, no settle-time warm-up under the profiler
       run 300 gpurun_out/${TAG}_prof.log rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_prof -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-strong --no-extras --no-packed
       for c in FETCH_SIZE WRITE_SIZE; do
         run 300 gpurun_out/${TAG}_pmc_head_$c.log rocprofv3 --pmc $c --output-format csv -d gpurun_out/${TAG}_pmc_head_$c -- python3 bench.py $HEADARGS
@@ -54,7 +55,7 @@ for st in $STEPS; do
         HPCLA_SPMM_COLS_MULT=8 run 300 gpurun_out/${TAG}_pmc_sprand8_$c.log rocprofv3 --pmc $c --output-format csv -d gpurun_out/${TAG}_pmc_sprand8_$c -- python3 bench.py --workload sprand_spmm --steps 5 --warmup 5
         HPCLA_SPMM_COLS_MULT=1 run 300 gpurun_out/${TAG}_pmc_sprand1_$c.log rocprofv3 --pmc $c --output-format csv -d gpurun_out/${TAG}_pmc_sprand1_$c -- python3 bench.py --workload sprand_spmm --steps 5 --warmup 5
       done
-      unset HPCLA_BLOCK_ORDER
+      unset HPCLA_BLOCK_ORDER HPCLA_SPMM_BLOCK_ORDER HPCLA_BENCH_SETTLE_MS
       # keep what is merged back small: only the counter CSVs and the stats
       find gpurun_out/${TAG}_p* -type f ! -name '*counter_collection.csv' ! -name '*kernel_stats.csv' ! -name '*kernel_trace.csv' ! -name '*.log' -delete;;
     pmc_spmv_study)  # round 4: SQ / TCP / TA / UTCL1 counters of the SpMV kernel in five contexts (2-D, 2-D + dot, 3-D, 3-D + dot,
