@@ -21,6 +21,8 @@ RESERVE_S = 30.0              # kept back for teardown, process exit and the dri
 ESTIMATE_S = {
     "strong_scaling": 40.0,           # the fixed 8192^2 problem over all ranks
     "strong_scaling_n1": 35.0,        # the same problem on rank 0 alone (gives speedup_vs_n1)
+    "strong_scaling_4096": 15.0,      # the 4096^2 headline matrix strong-scaled (the other reading of ">= 6x at 8 GPUs")
+    "strong_scaling_4096_n1": 12.0,   # ... and on rank 0 alone
     "int64": 20.0,
     "poisson3d_cg": 30.0,
     "poisson2d_spmm": 20.0,

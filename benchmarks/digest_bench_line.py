@@ -24,7 +24,7 @@ def main(path):
     ss = r.get("strong_scaling")
     if isinstance(ss, dict):
         print("  strong_scaling", {k: ss.get(k) for k in ("ms_per_step", "gflops", "speedup_vs_n1", "n1_ms_per_step_rank0_alone", "skipped", "error") if k in ss})
-    for k in ("strong_scaling_4096", "strong_scaling_speedup_vs_n1", "halo_mode", "peer_windows", "budget"):
+    for k in ("strong_scaling_4096", "strong_scaling_speedup_vs_n1", "strong_scaling_4096_speedup_vs_n1", "halo_mode", "peer_windows", "budget"):
         if k in r:
             print(" ", k, r[k])
     cb = r.get("cpu_baseline")

@@ -100,6 +100,7 @@ int hpcla_spmv_rows_per_block(void);
  * profiles/r04_spmv_2d_vs_3d_counters.txt), 1 = "quad" (rounds 1-3: a lane owns four consecutive entries, products
  * parked in LDS).  Bit-identical results.  Also HPCLA_SPMV_KERNEL=rowgather|quad in the environment. */
 int hpcla_set_spmv_kernel(int kind);
+int hpcla_get_spmv_kernel(void);      /* 0 / 1: the kernel the next aligned launch takes */
 int hpcla_spmm_rows_per_block(void);
 /* SpMM twins of the two block-order entries below (no reference counterpart: src/sparse.jl:2391-2413 is a column loop
  * over A*x in index order): the row blocks (hpcla_spmm_rows_per_block() rows each) of every SpMM launch over `rowptr`

@@ -759,6 +759,8 @@ using namespace hpcla;
 
 HPCLA_API int hpcla_spmv_rows_per_block(void) { return RPB; }
 
+HPCLA_API int hpcla_get_spmv_kernel(void) { return use_rowgather() ? 0 : 1; }
+
 HPCLA_API int hpcla_set_spmv_kernel(int kind)
 {
     if (kind != 0 && kind != 1) return set_error(HPCLA_ERR_INVALID, "set_spmv_kernel: 0 = row gather, 1 = quad");
