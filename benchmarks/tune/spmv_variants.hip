@@ -264,7 +264,7 @@ __global__ __launch_bounds__(TPB) void k_rowg(const int *__restrict__ rowptr, co
 // ---- ROWG, wave-private tiles: every WAVE owns 64 rows and its own slice of LDS; no workgroup barrier at all (LDS
 // operations of one wave complete in order), so a workgroup of WPB waves keeps the 64 * WPB-row block granularity of the
 // callers' block lists while its waves never wait for each other
-template <int WPB, int CHW, int UR, int XCD>
+template <int WPB, int CHW, int UR, int XCD, bool DMA = false, bool NTA = false>
 __global__ __launch_bounds__(64 * WPB) void k_rowg_wave(const int *__restrict__ rowptr, const int *__restrict__ colval,
                                                         const double *__restrict__ nzval, const double *__restrict__ x,
                                                         double *__restrict__ y, int64_t nrows, int64_t nnz, uint32_t nblocks)
@@ -287,7 +287,20 @@ __global__ __launch_bounds__(64 * WPB) void k_rowg_wave(const int *__restrict__ 
     double acc = 0.0;
     for (int64_t c = 0; c < total; c += CHW) {
         const int n = (int)((total - c) < CHW ? (total - c) : CHW);
-        if (pa + c + ((n + 3) & ~3) <= nnz) {
+        if (DMA && pa + c + CHW <= nnz) {
+            // LDS-DMA: the pass's colval / nzval pieces go straight into LDS, 1 KiB per wave-instruction (lane L carries
+            // 16 bytes at L * 16 of the piece), no VGPR destination and no ds_write; pieces past the pass's end copy the
+            // next wave's entries (inside the arrays: checked above), which nobody reads
+#pragma unroll
+            for (int i = 0; i < CHW / 256; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(colval + pa + c + i * 256 + lane * 4),
+                                                 (__attribute__((address_space(3))) void *)(s_col + i * 256), 16, 0, 0);
+#pragma unroll
+            for (int i = 0; i < CHW / 128; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(nzval + pa + c + i * 128 + lane * 2),
+                                                 (__attribute__((address_space(3))) void *)(s_val + i * 128), 16, 0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (pa + c + ((n + 3) & ~3) <= nnz) {
             constexpr int NQ = CHW / 256;
             const int last = (n - 1) & ~3;
             v4i cq[NQ];
@@ -296,9 +309,9 @@ __global__ __launch_bounds__(64 * WPB) void k_rowg_wave(const int *__restrict__ 
             for (int u = 0; u < NQ; ++u) {
                 const int e0 = (u * 64 + lane) * 4;
                 const int ee = e0 < last ? e0 : last;
-                cq[u] = *reinterpret_cast<const v4i *>(colval + pa + c + ee);
-                va[u] = *reinterpret_cast<const v2d *>(nzval + pa + c + ee);
-                vb[u] = *reinterpret_cast<const v2d *>(nzval + pa + c + ee + 2);
+                cq[u] = ld<v4i, NTA>(reinterpret_cast<const v4i *>(colval + pa + c + ee));
+                va[u] = ld<v2d, NTA>(reinterpret_cast<const v2d *>(nzval + pa + c + ee));
+                vb[u] = ld<v2d, NTA>(reinterpret_cast<const v2d *>(nzval + pa + c + ee + 2));
             }
 #pragma unroll
             for (int u = 0; u < NQ; ++u) {
@@ -1150,6 +1163,19 @@ extern "C" __attribute__((visibility("default"))) int hpcla_tune_spmv(
         case 124: ROWGW(1, 512, 8, 0) break;               // one wave per workgroup
         case 125: ROWGW(4, 256, 8, 0) break;               // 12 KiB per workgroup (a 7-point wave takes two passes)
         case 126: ROWGW(8, 512, 8, 0) break;               // 512-row workgroups
+#define ROWGWX(WPB, CHW, UR, XCD, DMA, NTA)                                                       \
+    {                                                                                             \
+        uint32_t nb = (uint32_t)((nrows + 64 * WPB - 1) / (64 * WPB));                            \
+        k_rowg_wave<WPB, CHW, UR, XCD, DMA, NTA><<<nb, 64 * WPB, 0, s>>>(rowptr, colval, nzval, x, y, nrows, nnz, nb); \
+    }
+        case 130: ROWGWX(4, 512, 8, 64, true, false) break;    // A entries by LDS-DMA (no VGPR round trip, no ds_write), groups of 64
+        case 131: ROWGWX(4, 512, 8, 32, true, false) break;
+        case 132: ROWGWX(4, 512, 8, 0, true, false) break;
+        case 133: ROWGWX(2, 512, 8, 128, true, false) break;   // ... in 128-row workgroups
+        case 134: ROWGWX(4, 512, 8, 64, false, true) break;    // A entries with non-temporal loads
+        case 135: ROWGWX(4, 512, 8, 32, false, true) break;
+        case 136: ROWGWX(4, 512, 4, 64, false, false) break;   // four entries per gather step
+        case 137: ROWGWX(4, 512, 4, 32, false, false) break;
         case 110: ROWG(128, 896, 8, 128) break;            // 128 rows x 7 entries exactly: 10.5 KiB, 15 workgroups = 30 waves per CU
         case 111: ROWG(128, 1024, 8, 256) break;
         case 112: ROWG(64, 512, 8, 128) break;             // one wave per workgroup (the barrier is free)

@@ -42,6 +42,10 @@ def test_push_transport_ranks_exchange(nranks):
         # every launch in the XCD-grouped block order (groups of 2 row blocks: the test matrices are far below the
         # size the plan would measure at), so the FUSED kernels' interior runs walk it too -- same bits required
         env["HPCLA_SPMV_XCD_GROUP"] = "2"
+    if nranks == 4:
+        # the product-parking QUAD kernel of rounds 1-3 is still shipped (hpcla_set_spmv_kernel(1)): its fused distributed
+        # form (push workgroups, waiting boundary blocks, p.Ap epilogue) keeps a real-rank run of its own
+        env["HPCLA_SPMV_KERNEL"] = "quad"
     env.pop("HPCLA_HALO_MODE", None)
     os.environ.pop("HPCLA_HALO_MODE", None)
     assert _spawn(nranks, env) == 0
