@@ -93,7 +93,9 @@ def main():
         hp.clear_plan_cache()
         torch.cuda.empty_cache()
     if args.manifest:
-        json.dump({"cases": manifest, "event_ms": times, "order2d": args.order2d, "order3d": args.order3d}, open(args.manifest, "w"))
+        json.dump({"cases": manifest, "event_ms": times, "order2d": args.order2d, "order3d": args.order3d,
+                   "kernel": "spmv_rowgather_kernel" if hp._capi.load().hpcla_get_spmv_kernel() == 0 else "spmv_rowblock_quad_kernel"},
+                  open(args.manifest, "w"))
     print(json.dumps({"event_ms_per_launch": {k: round(v, 5) for k, v in times.items()}}))
 
 

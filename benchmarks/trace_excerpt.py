@@ -10,7 +10,7 @@ def main():
     rows = list(csv.DictReader(open(sys.argv[1], newline="")))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     name = lambda r: r["Kernel_Name"]
-    fused = [i for i, r in enumerate(rows) if "spmv_rowblock_quad_kernel<int, true, true>" in name(r)]
+    fused = [i for i, r in enumerate(rows) if ("spmv_rowgather_kernel<int, true, true>" in name(r) or "spmv_rowblock_quad_kernel<int, true, true>" in name(r))]
     rccl = [i for i, r in enumerate(rows) if "rcclGenericKernel" in name(r) or "ncclDevKernel" in name(r)]
     out = []
 
@@ -34,7 +34,7 @@ def main():
     # full steps only (the harness also times the exchange alone): an exchange kernel that runs NEXT TO row blocks
     def beside_rows(i):
         a, b = int(rows[i]["Start_Timestamp"]), int(rows[i]["End_Timestamp"])
-        return any("spmv_rowblock" in name(r) and int(r["Start_Timestamp"]) < b and int(r["End_Timestamp"]) > a
+        return any("spmv_row" in name(r) and int(r["Start_Timestamp"]) < b and int(r["End_Timestamp"]) > a
                    for r in rows[max(i - 4, 0):i + 5])
     overlap = [i for i in overlap if beside_rows(i)]
     if overlap:

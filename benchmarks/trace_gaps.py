@@ -21,7 +21,7 @@ def main():
             or "copy" in r["Kernel_Name"].lower()]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     # the steady part: the last 60 % of the SpMV launches
-    spmv = [i for i, r in enumerate(rows) if "spmv_rowblock" in r["Kernel_Name"]]
+    spmv = [i for i, r in enumerate(rows) if "spmv_row" in r["Kernel_Name"]]
     if len(spmv) < 10:
         raise SystemExit("too few SpMV launches in the trace")
     first = spmv[int(len(spmv) * 0.4)]
@@ -34,7 +34,7 @@ def main():
         pair_gap[(short(a["Kernel_Name"]), short(b["Kernel_Name"]))].append(gap)
     for r in seg:
         kern[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-    iters = sum(1 for r in seg if "spmv_rowblock" in r["Kernel_Name"])
+    iters = sum(1 for r in seg if "spmv_row" in r["Kernel_Name"])
     span = (int(seg[-1]["End_Timestamp"]) - int(seg[0]["Start_Timestamp"])) / 1e3
     ktot = sum(sum(v) for v in kern.values())
     print(f"# {label}: {iters} iterations, {span / iters:.1f} us per iteration on the device timeline; "
