@@ -264,7 +264,7 @@ __global__ __launch_bounds__(TPB) void k_rowg(const int *__restrict__ rowptr, co
 // ---- ROWG, wave-private tiles: every WAVE owns 64 rows and its own slice of LDS; no workgroup barrier at all (LDS
 // operations of one wave complete in order), so a workgroup of WPB waves keeps the 64 * WPB-row block granularity of the
 // callers' block lists while its waves never wait for each other
-template <int WPB, int CHW, int UR, int XCD, bool DMA = false, bool NTA = false>
+template <int WPB, int CHW, int UR, int XCD, bool DMA = false, bool NTA = false, bool NTY = false>
 __global__ __launch_bounds__(64 * WPB) void k_rowg_wave(const int *__restrict__ rowptr, const int *__restrict__ colval,
                                                         const double *__restrict__ nzval, const double *__restrict__ x,
                                                         double *__restrict__ y, int64_t nrows, int64_t nnz, uint32_t nblocks)
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(64 * WPB) void k_rowg_wave(const int *__restrict__ 
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      // the reads before the next pass's writes
         __builtin_amdgcn_wave_barrier();
     }
-    if (lane < nr) y[r0 + lane] = acc;
+    if (lane < nr) { if (NTY) __builtin_nontemporal_store(acc, y + r0 + lane); else y[r0 + lane] = acc; }
 }
 
 // ---- wide kernel + compact per-block pointer array (16 block starts per 64-byte line)
@@ -1174,6 +1174,8 @@ extern "C" __attribute__((visibility("default"))) int hpcla_tune_spmv(
         case 133: ROWGWX(2, 512, 8, 128, true, false) break;   // ... in 128-row workgroups
         case 134: ROWGWX(4, 512, 8, 64, false, true) break;    // A entries with non-temporal loads
         case 135: ROWGWX(4, 512, 8, 32, false, true) break;
+        case 138: k_rowg_wave<4, 512, 8, 64, false, false, true><<<(uint32_t)((nrows + 255) / 256), 256, 0, s>>>(rowptr, colval, nzval, x, y, nrows, nnz, (uint32_t)((nrows + 255) / 256)); break;   // y stored non-temporally
+        case 139: k_rowg_wave<4, 512, 8, 32, false, false, true><<<(uint32_t)((nrows + 255) / 256), 256, 0, s>>>(rowptr, colval, nzval, x, y, nrows, nnz, (uint32_t)((nrows + 255) / 256)); break;
         case 136: ROWGWX(4, 512, 4, 64, false, false) break;   // four entries per gather step
         case 137: ROWGWX(4, 512, 4, 32, false, false) break;
         case 110: ROWG(128, 896, 8, 128) break;            // 128 rows x 7 entries exactly: 10.5 KiB, 15 workgroups = 30 waves per CU

@@ -86,6 +86,7 @@ struct BlockSel {
     int64_t n_first;
     int64_t n_run;               // length of the contiguous run the group order applies to (plain: the launch; WAIT: n_first)
     int32_t group_log2;          // > 0: XCD-grouped order of the contiguous run, groups of 2^group_log2 row blocks
+    int32_t nt_y;                // != 0: y is stored non-temporally (row-gather kernel; see spmv_nt_y below)
 };
 
 // XCD-grouped order of a contiguous run of n row blocks.  The hardware deals workgroups to the 8 XCDs round-robin by
@@ -420,7 +421,10 @@ __global__ __launch_bounds__(RPB) void spmv_rowgather_kernel(
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       // ... and the reads before the next pass's writes
             __builtin_amdgcn_wave_barrier();
         }
-        if (lane < nrw) y[rw + lane] = acc;
+        if (lane < nrw) {
+            if (bs.nt_y) __builtin_nontemporal_store(acc, y + rw + lane);
+            else y[rw + lane] = acc;
+        }
     }
     if (dot_partial) block_dot_epilogue(s_red, dot_partial, blk, lane < nrw ? acc * x_row : 0.0);
 }
@@ -601,6 +605,21 @@ static bool use_rowgather()
     return k == 0;
 }
 
+// Store policy of y (row-gather kernel): NON-TEMPORAL by default (HPCLA_SPMV_NT_Y=0: plain stores).  y is written once per
+// launch and read by nothing inside it, so its lines only displace x and A lines from L2 / Infinity Cache; measured with
+// alternating processes on one box (profiles/r04_spmv_nontemporal_y.log): headline 0.2309 / 0.2276 -> 0.2153 / 0.2156 ms
+// (0.73-0.74 -> 0.78 of peak), and the CG iteration -- whose NEXT kernel reads y -- 0.4840 / 0.4881 -> 0.4799 / 0.4801: the
+// 134 MB vector does not survive the iteration's other traffic in the Infinity Cache anyway.  (Non-temporal LOADS of the A
+// stream are the opposite: +10 % in the harness, profiles/r04_spmv_rowgather_library.log.)
+static int spmv_nt_y(bool /*with_dot*/)
+{
+    static const int on = [] {
+        const char *e = getenv("HPCLA_SPMV_NT_Y");
+        return e ? (atoi(e) ? 1 : 0) : 1;
+    }();
+    return on;
+}
+
 template <typename I>
 static int spmv_launch(const I *rowptr, const I *colval, const double *nzval, const double *x_own,
                        const double *x_ghost, int64_t n_own, bool split, double *y, int64_t nrows,
@@ -637,7 +656,8 @@ static int spmv_launch(const I *rowptr, const I *colval, const double *nzval, co
     // quad kernel: a 4-entry quad must never straddle a page -> colval 4*sizeof(I)-, nzval 32-byte aligned
     const bool aligned = (reinterpret_cast<uintptr_t>(colval) % (4 * sizeof(I)) == 0) &&
                          (reinterpret_cast<uintptr_t>(nzval) % 32 == 0);
-    const BlockSel bs{block_list, block_base, nullptr, 0, 0, launch_blocks, block_list ? 0 : block_order_of(rowptr)};
+    const BlockSel bs{block_list, block_base, nullptr, 0, 0, launch_blocks, block_list ? 0 : block_order_of(rowptr),
+                      spmv_nt_y(dot_partial != nullptr)};
     HaloWait nowait;
     memset(&nowait, 0, sizeof(nowait));
     PushArgs nopush;
@@ -700,7 +720,7 @@ static int spmv_launch_fused(const I *rowptr, const I *colval, const double *nzv
     const bool aligned = (reinterpret_cast<uintptr_t>(colval) % (4 * sizeof(I)) == 0) &&
                          (reinterpret_cast<uintptr_t>(nzval) % 32 == 0);
     const BlockSel bs{boundary_list, 0, interior_list, interior_base, n_interior, n_interior,
-                      interior_list ? 0 : block_order_of(rowptr)};
+                      interior_list ? 0 : block_order_of(rowptr), spmv_nt_y(dot_partial != nullptr)};
     if (aligned && use_rowgather())
         spmv_rowgather_kernel<I, true, true><<<grid, block, 0, s>>>(
             rowptr, colval, nzval, x_own, x_ghost, n_own, y, nrows, nnz, index_base, bs, dot_partial, hw, pa);

@@ -6,6 +6,8 @@
 // two-stage and deterministic: fixed grid, per-block partial -> one block sums the partials in
 // index order; the scalar stays on the device so a CG iteration never synchronises the host.
 // Bytes per element: dot 16 (8 for x.x), nrm2sq/asum/amax 8, axpy/xpay 24, scale 16, axpby 24.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace hpcla {
@@ -199,6 +201,31 @@ __device__ __forceinline__ double dev_scalar(double alpha, const double *num, co
 // their operands are those of cg_update_kernel + update_kernel<1>: same bits.
 //   residual:  a = alpha * *num / *den ;  r -= a*Ap ;  partial[block] = sum r_new^2
 //   direction: a as above, b = beta * *bnum / *bden ;  x += a*p ;  p = r + b*p
+typedef double v2d_nt __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 nt_load2(const double2 *p)
+{
+    const v2d_nt t = __builtin_nontemporal_load(reinterpret_cast<const v2d_nt *>(p));
+    double2 r;
+    r.x = t.x; r.y = t.y;
+    return r;
+}
+__device__ __forceinline__ void nt_store2(double2 v, double2 *p)
+{
+    v2d_nt t;
+    t.x = v.x; t.y = v.y;
+    __builtin_nontemporal_store(t, reinterpret_cast<v2d_nt *>(p));
+}
+
+// Cache policy of the CG update kernels (round 4; HPCLA_CG_NT bit mask, default 7 = all three): a vector that is not touched again
+// before ~2-3 GB of other traffic has passed is loaded / stored NON-TEMPORALLY, so that L2 and the 256 MiB Infinity Cache
+// keep the vectors the next kernels re-read (p: gathered by the SpMV; r, Ap: read by the next update).
+//   bit 0 (1): x in the direction update (load + store) -- measured -4.4 % per CG iteration
+//   bit 1 (2): r load in the direction update (next use: the residual update behind the next SpMV)
+//   bit 2 (4): Ap load in the residual update (its last use)
+// Config 4's slab, ms per iteration, two alternating rounds of processes on one box (profiles/r04_cg_nontemporal_x.log):
+// mask 0: 0.5250 / 0.5233, 1: 0.4997 / 0.5041, 3: 0.4951 / 0.4957, 5: 0.5022 / 0.5006, 7: 0.4903 / 0.4899 (-6.5 %).
+// Same operations on the same operands: same bits.
+template <bool NTQ>
 __global__ __launch_bounds__(RT) void cg_residual_kernel(double alpha, const double *__restrict__ num,
                                                          const double *__restrict__ den,
                                                          const double *__restrict__ Ap, double *__restrict__ r,
@@ -212,7 +239,7 @@ __global__ __launch_bounds__(RT) void cg_residual_kernel(double alpha, const dou
     int64_t i = (int64_t)blockIdx.x * RT + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * RT;
     for (; i < n2; i += stride) {
-        const double2 qv = q2[i];
+        const double2 qv = NTQ ? nt_load2(q2 + i) : q2[i];
         double2 rv = r2[i];
         rv.x = rv.x - a * qv.x;
         rv.y = rv.y - a * qv.y;
@@ -230,6 +257,7 @@ __global__ __launch_bounds__(RT) void cg_residual_kernel(double alpha, const dou
     if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
 
+template <bool NTX, bool NTR>
 __global__ __launch_bounds__(256) void cg_direction_kernel(double alpha, const double *__restrict__ num,
                                                            const double *__restrict__ den, double beta,
                                                            const double *__restrict__ bnum,
@@ -246,13 +274,14 @@ __global__ __launch_bounds__(256) void cg_direction_kernel(double alpha, const d
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * 256;
     for (; i < n2; i += stride) {
-        const double2 rv = r2[i];
-        double2 xv = x2[i], pv = p2[i];
+        const double2 rv = NTR ? nt_load2(r2 + i) : r2[i];
+        const double2 pv0 = p2[i];
+        double2 xv = NTX ? nt_load2(x2 + i) : x2[i], pv = pv0;
         xv.x = xv.x + a * pv.x;
         xv.y = xv.y + a * pv.y;
         pv.x = rv.x + b * pv.x;
         pv.y = rv.y + b * pv.y;
-        x2[i] = xv;
+        if (NTX) nt_store2(xv, x2 + i); else x2[i] = xv;
         p2[i] = pv;
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -448,6 +477,15 @@ HPCLA_API int hpcla_cg_update_f64(hpcla_comm_t *comm, double alpha_host, const d
     return HPCLA_OK;
 }
 
+static int cg_nt_mask()
+{
+    static const int m = [] {
+        const char *e = getenv("HPCLA_CG_NT");
+        return e ? atoi(e) : 7;
+    }();
+    return m;
+}
+
 HPCLA_API int hpcla_cg_residual_f64(hpcla_comm_t *comm, double alpha_host, const double *num_dev,
                                     const double *den_dev, const double *Ap, double *r, int64_t n,
                                     double *rr_out_dev, void *work, void *stream)
@@ -459,7 +497,10 @@ HPCLA_API int hpcla_cg_residual_f64(hpcla_comm_t *comm, double alpha_host, const
         return set_error(HPCLA_ERR_INVALID, "cg_residual: vectors must be 16-byte aligned");
     double *partial = reinterpret_cast<double *>(work);
     const int g = reduce_grid(n);
-    cg_residual_kernel<<<g, RT, 0, as_stream(stream)>>>(alpha_host, num_dev, den_dev, Ap, r, n, partial);
+    if (cg_nt_mask() & 4)
+        cg_residual_kernel<true><<<g, RT, 0, as_stream(stream)>>>(alpha_host, num_dev, den_dev, Ap, r, n, partial);
+    else
+        cg_residual_kernel<false><<<g, RT, 0, as_stream(stream)>>>(alpha_host, num_dev, den_dev, Ap, r, n, partial);
     HPCLA_CHECK_LAUNCH();
     reduce_stage2<RED_SUM><<<1, RT, 0, as_stream(stream)>>>(partial, g, rr_out_dev);
     HPCLA_CHECK_LAUNCH();
@@ -476,8 +517,15 @@ HPCLA_API int hpcla_cg_direction_f64(double alpha_host, const double *a_num_dev,
     if (!r || !x || !p) return set_error(HPCLA_ERR_INVALID, "cg_direction: null vector");
     if ((reinterpret_cast<uintptr_t>(r) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(p)) & 15)
         return set_error(HPCLA_ERR_INVALID, "cg_direction: vectors must be 16-byte aligned");
-    cg_direction_kernel<<<ew_grid(n / 2), 256, 0, as_stream(stream)>>>(alpha_host, a_num_dev, a_den_dev, beta_host,
-                                                                        b_num_dev, b_den_dev, r, x, p, n);
+    const int m = cg_nt_mask();
+#define HPCLA_CG_DIR(NX, NR)                                                                                           \
+    cg_direction_kernel<NX, NR><<<ew_grid(n / 2), 256, 0, as_stream(stream)>>>(alpha_host, a_num_dev, a_den_dev, beta_host, \
+                                                                               b_num_dev, b_den_dev, r, x, p, n)
+    if ((m & 1) && (m & 2)) HPCLA_CG_DIR(true, true);
+    else if (m & 1) HPCLA_CG_DIR(true, false);
+    else if (m & 2) HPCLA_CG_DIR(false, true);
+    else HPCLA_CG_DIR(false, false);
+#undef HPCLA_CG_DIR
     HPCLA_CHECK_LAUNCH();
     return HPCLA_OK;
 }
