@@ -174,7 +174,7 @@ __global__ __launch_bounds__(P_RPB) void spmv_packed_kernel(
         }
         __syncthreads();
     }
-    if (tid < nr) y[r0 + tid] = acc;
+    if (tid < nr) __builtin_nontemporal_store(acc, y + r0 + tid);      // like the row-gather kernel's y (spmv.hip spmv_nt_y)
     if (dot_partial) {
         double v = tid < nr ? acc * x[r0 + tid] : 0.0;
 #pragma unroll
