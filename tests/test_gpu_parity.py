@@ -1783,3 +1783,48 @@ def test_both_spmv_kernels_give_the_reference_bits(hp, orc, gpu_backend_i32, Ti)
         assert lib.hpcla_set_spmv_kernel(2) != 0
     finally:
         lib.hpcla_set_spmv_kernel(0)
+
+
+@pytest.mark.parametrize("Ti", [np.int32, np.int64])
+def test_spmv_rowgather_wave_pass_boundaries(hp, orc, gpu_backend_i32, Ti):
+    """The row-gather kernel's unit is a WAVE: 64 rows whose entry range -- from the quad-aligned entry at or before its
+    first entry -- is streamed into LDS in passes of 464 entries.  Wave totals around every pass limit (one pass, one pass
+    exactly, one entry over, two and three passes), every alignment of the wave's first entry (0..3 entries in front of
+    it in its quad), empty waves, rows that span passes, a ragged last block, and the entry-by-entry pass at the end of the
+    matrix for every nnz mod 4; the quad kernel on the same inputs."""
+    import torch
+    rng = np.random.default_rng(2024)
+    ncols = 5000
+    lib = hp._capi.load()
+    totals = [0, 1, 3, 4, 63, 64, 459, 460, 461, 462, 463, 464, 465, 468, 927, 928, 929, 1391, 1392, 1393, 2000]
+    try:
+        for shift in range(4):
+            lens = []
+            lens += [shift] + [0] * 63                           # a first wave that shifts everybody's alignment
+            for tot in totals:
+                if tot == 0:
+                    w = np.zeros(64, dtype=np.int64)
+                elif tot < 64:
+                    w = np.zeros(64, dtype=np.int64)
+                    w[rng.choice(64, size=tot, replace=False)] = 1
+                else:
+                    cuts = np.sort(rng.integers(0, tot + 1, size=63))
+                    w = np.diff(np.concatenate([[0], cuts, [tot]]))
+                lens += list(w)
+            lens += [5] * 37                                     # ragged tail: the last block has 37 rows
+            lens = np.array(lens, dtype=np.int64)
+            n = len(lens)
+            rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+            nnz = int(rowptr[-1])
+            rowid = np.repeat(np.arange(n), lens)
+            cols = rng.integers(0, ncols, size=nnz)
+            cols = cols[np.lexsort((cols, rowid))].astype(np.int64)
+            vals = rng.standard_normal(nnz)
+            x = rng.standard_normal(ncols)
+            want = orc.spmv(rowptr.astype(Ti), cols.astype(Ti), vals, x)
+            for kind in (0, 1):
+                hp._capi.call("hpcla_set_spmv_kernel", kind)
+                got = _raw_spmv(hp, rowptr, cols, vals, x, Ti)
+                np.testing.assert_array_equal(got, want, err_msg=f"kernel {kind}, shift {shift}, nnz mod 4 = {nnz % 4}")
+    finally:
+        lib.hpcla_set_spmv_kernel(0)
