@@ -34,7 +34,7 @@ for st in $STEPS; do
       HPCLA_ALLOW_SHARED_GPU=1 run 900 gpurun_out/${TAG}_reh$n.log python bench.py --gpus $n --steps 5 --warmup 2 ${REHEARSE_ARGS}
       grep "^{" gpurun_out/${TAG}_reh$n.log | tail -1 > gpurun_out/${TAG}_reh$n.json
       python3 benchmarks/digest_bench_line.py gpurun_out/${TAG}_reh$n.json;;
-    validate) "$0" "$TAG" pytest smoke driverbench torchrun2;;
+    validate) bash "$0" "$TAG" pytest smoke driverbench torchrun2;;
     pmc_all)       # kernel stats + FETCH_SIZE / WRITE_SIZE passes (separate runs) of the headline and of every sub-record;
                    # then: python benchmarks/collect_profiles.py TAG rNN   (-> profiles/, traffic_latest.json)
       cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
