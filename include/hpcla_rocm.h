@@ -639,6 +639,62 @@ int hpcla_merge_combine_f64_i64(double *out, const double *a, const int64_t *ia,
  * generator, v[i] = u01(seed, start+i). */
 int hpcla_fill_uniform_f64(double *v, int64_t start, int64_t count, uint64_t seed, void *stream);
 
+/* ==== Float32 element type on the hot path (csrc/f32.hip) ======================================================
+ * The reference is generic in T; its GPU test configurations are CUDA x {Float32, Float64} and Metal x Float32
+ * (test/test_utils.jl:62-80), all through the same _spmv_kernel! (src/sparse.jl:2055-2066: acc = zero(T),
+ * acc += nzval[j] * x[colval[j]] in T), the same column loop for A * HPCMatrix (:2391-2413) and the same local
+ * dot / nrm2 + scalar all-reduce (src/vectors.jl:758-812).  Float64 is the graded type; these entries give the same
+ * path to a Float32 backend: row sums in float, stored order, separate multiply and add (the reference's bits).
+ *
+ * spmv_csr / spmv_split / spmm_csr / spmm_split: arguments as for the _f64 entries of the same name, with float values,
+ * operands and results.  GHOSTS ARE DOUBLES: the halo transports move 8-byte words, so a Float32 exchange widens what it
+ * sends (float -> double is exact) and the split kernels narrow the ghost values they gather (exact again); x_ghost_wide
+ * / B_ghost_wide are the plan's ordinary ghost segment (hpcla_halo_ghost_ptr).  spmm_split is row-major like its _f64
+ * twin; spmm_csr takes either layout for B and C (Julia's column-major Matrix goes in untouched). */
+int hpcla_spmv_csr_f32_i32(const int32_t *rowptr, const int32_t *colval, const float *nzval, const float *x, float *y,
+                           int64_t nrows, int64_t nnz, int index_base, void *stream);
+int hpcla_spmv_csr_f32_i64(const int64_t *rowptr, const int64_t *colval, const float *nzval, const float *x, float *y,
+                           int64_t nrows, int64_t nnz, int index_base, void *stream);
+int hpcla_spmv_split_f32_i32(const int32_t *rowptr, const int32_t *colval_split, const float *nzval, const float *x_own,
+                             const double *x_ghost_wide, int64_t n_own, float *y, int64_t nrows, int64_t nnz,
+                             int index_base, const int32_t *block_list, int64_t n_blocks, void *stream);
+int hpcla_spmv_split_f32_i64(const int64_t *rowptr, const int64_t *colval_split, const float *nzval, const float *x_own,
+                             const double *x_ghost_wide, int64_t n_own, float *y, int64_t nrows, int64_t nnz,
+                             int index_base, const int32_t *block_list, int64_t n_blocks, void *stream);
+int hpcla_spmm_csr_f32_i32(const int32_t *rowptr, const int32_t *colval, const float *nzval, const float *B, int64_t ldb,
+                           int b_layout, float *C, int64_t ldc, int c_layout, int64_t nrows, int64_t nnz, int k,
+                           int index_base, void *stream);
+int hpcla_spmm_csr_f32_i64(const int64_t *rowptr, const int64_t *colval, const float *nzval, const float *B, int64_t ldb,
+                           int b_layout, float *C, int64_t ldc, int c_layout, int64_t nrows, int64_t nnz, int k,
+                           int index_base, void *stream);
+int hpcla_spmm_split_f32_i32(const int32_t *rowptr, const int32_t *colval_split, const float *nzval, const float *B_own,
+                             int64_t ldb_own, const double *B_ghost_wide, int64_t ldb_ghost, int64_t n_own, float *C,
+                             int64_t ldc, int64_t nrows, int64_t nnz, int k, int index_base, const int32_t *block_list,
+                             int64_t n_blocks, void *stream);
+int hpcla_spmm_split_f32_i64(const int64_t *rowptr, const int64_t *colval_split, const float *nzval, const float *B_own,
+                             int64_t ldb_own, const double *B_ghost_wide, int64_t ldb_ghost, int64_t n_own, float *C,
+                             int64_t ldc, int64_t nrows, int64_t nnz, int k, int index_base, const int32_t *block_list,
+                             int64_t n_blocks, void *stream);
+/* hpcla_halo_begin for a Float32 operand (execute_plan!, src/vectors.jl:394-463): widens x at the plan's send positions
+ * into `stage` (doubles, laid out like x: at least (largest send index + 1) * width entries; the caller's, reused from
+ * call to call) on `stream`, then posts the ordinary exchange from `stage`.  hpcla_halo_end / hpcla_halo_status /
+ * hpcla_halo_ghost_ptr as usual: every transport is the Float64 one. */
+int hpcla_halo_begin_f32(hpcla_halo_plan_t *plan, const float *x, double *stage, void *stream);
+/* dot / norm pieces (src/vectors.jl:758-812): products and squares are formed and summed in DOUBLE (exact products, two
+ * deterministic stages, scalar all-reduce in double); out_dev is a device double, the caller rounds to Float32 once.
+ * work: hpcla_reduce_work_bytes().  16-byte aligned operands. */
+int hpcla_dot_f32(hpcla_comm_t *comm, const float *x, const float *y, int64_t n, double *out_dev, void *work, void *stream);
+int hpcla_nrm2sq_f32(hpcla_comm_t *comm, const float *x, int64_t n, double *out_dev, void *work, void *stream);
+int hpcla_asum_f32(hpcla_comm_t *comm, const float *x, int64_t n, double *out_dev, void *work, void *stream);
+int hpcla_amax_f32(hpcla_comm_t *comm, const float *x, int64_t n, double *out_dev, void *work, void *stream);
+int hpcla_sum_f32(hpcla_comm_t *comm, const float *x, int64_t n, double *out_dev, void *work, void *stream);
+int hpcla_maxval_f32(hpcla_comm_t *comm, const float *x, int64_t n, int negate, double *out_dev, void *work, void *stream);
+/* z = a*x + b*y, y = a*x, y = x / a in float (src/vectors.jl:868-903, 944-964), separate multiply and add; 16-byte
+ * aligned operands. */
+int hpcla_axpby_f32(float a, const float *x, float b, const float *y, float *z, int64_t n, void *stream);
+int hpcla_scale_f32(float a, const float *x, float *y, int64_t n, void *stream);
+int hpcla_divide_f32(const float *x, float a, float *y, int64_t n, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -35,6 +35,7 @@ _i32 = ctypes.c_int
 _i64 = ctypes.c_int64
 _u64 = ctypes.c_uint64
 _f64 = ctypes.c_double
+_f32 = ctypes.c_float
 _vp = ctypes.c_void_p
 
 # name -> argtypes ; every function returns int status unless listed in _RESTYPES
@@ -161,6 +162,25 @@ _SIGNATURES = {
     "hpcla_merge_combine_f64_i32": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp],
     "hpcla_merge_combine_f64_i64": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp],
     "hpcla_fill_uniform_f64": [_vp, _i64, _i64, _u64, _vp],
+    # Float32 element type (csrc/f32.hip)
+    "hpcla_spmv_csr_f32_i32": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp],
+    "hpcla_spmv_csr_f32_i64": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp],
+    "hpcla_spmv_split_f32_i32": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _i64, _vp],
+    "hpcla_spmv_split_f32_i64": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _i64, _vp],
+    "hpcla_spmm_csr_f32_i32": [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _i64, _i32, _i64, _i64, _i32, _i32, _vp],
+    "hpcla_spmm_csr_f32_i64": [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _i64, _i32, _i64, _i64, _i32, _i32, _vp],
+    "hpcla_spmm_split_f32_i32": [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _i64, _vp],
+    "hpcla_spmm_split_f32_i64": [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _i64, _vp],
+    "hpcla_halo_begin_f32": [_vp, _vp, _vp, _vp],
+    "hpcla_dot_f32": [_vp, _vp, _vp, _i64, _vp, _vp, _vp],
+    "hpcla_nrm2sq_f32": [_vp, _vp, _i64, _vp, _vp, _vp],
+    "hpcla_asum_f32": [_vp, _vp, _i64, _vp, _vp, _vp],
+    "hpcla_amax_f32": [_vp, _vp, _i64, _vp, _vp, _vp],
+    "hpcla_sum_f32": [_vp, _vp, _i64, _vp, _vp, _vp],
+    "hpcla_maxval_f32": [_vp, _vp, _i64, _i32, _vp, _vp, _vp],
+    "hpcla_axpby_f32": [_f32, _vp, _f32, _vp, _vp, _i64, _vp],
+    "hpcla_scale_f32": [_f32, _vp, _vp, _i64, _vp],
+    "hpcla_divide_f32": [_vp, _f32, _vp, _i64, _vp],
 }
 _RESTYPES = {
     "hpcla_last_error": ctypes.c_char_p,

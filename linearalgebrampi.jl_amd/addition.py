@@ -80,6 +80,8 @@ def _get_addition_plan(A, B) -> AdditionPlan:
 
 def sparse_add(A, B, subtract: bool = False):
     """``A + B`` (src/sparse.jl:1405-1445) / ``A - B`` (:1454-1494)."""
+    from .vectors import f64_only
+    f64_only(A.backend, "A + B / A - B for sparse operands")
     from .sparse import HPCSparseMatrix
     torch = _torch()
     assert_backends_compatible(A.backend, B.backend)
@@ -115,6 +117,8 @@ def add_scaled_identity(A, lam: float, subtract: bool = False):
     here the identity is an ordinary HPCSparseMatrix on A's row partition (unit diagonal, cached per
     structure), scaled on the device and merged by the same one-pass AdditionPlan as ``A + B`` -- diagonal
     entries missing from A are added structurally, exactly as in the reference's IdentityAdditionPlan."""
+    from .vectors import f64_only
+    f64_only(A.backend, "A + lambda*I")
     from .backends import comm_rank
     from .sparse import HPCSparseMatrix_local
     m, n = A.shape

@@ -73,6 +73,8 @@ class CGWorkspace:
 def cg_setup(A, b: HPCVector, ws: CGWorkspace, fused: bool = True):
     """x0 = 0, r0 = p0 = b, hist[0] = sum r0^2; builds / looks up the plan.  Returns the state ``cg_iterate``
     continues from.  Not an iteration: benchmarks keep it outside the timed region."""
+    from .vectors import f64_only
+    f64_only(A.backend, "the CG building blocks")
     plan = get_vector_plan(A, ws.p)
     fused = bool(fused and plan.result_partition_hash == ws.p.structural_hash)
     ws.x.v.zero_()
@@ -122,6 +124,8 @@ def cg_fixed_iterations(A, b: HPCVector, iters: int, record_history: bool = True
     whole distributed iterations are capturable.  Same kernels, same arguments, hence the same bits as the
     eager loop.  It pays off where an iteration is shorter than the host time to issue its launches (small
     systems); DESIGN.md section 6 has the measurement for large ones, where eager stays the default."""
+    from .vectors import f64_only
+    f64_only(A.backend, "the CG building blocks")
     torch = _torch()
     ws = workspace if workspace is not None and workspace.fits(b, iters) else CGWorkspace(b, iters)
     plan, fused = cg_setup(A, b, ws, fused)

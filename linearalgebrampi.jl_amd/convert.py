@@ -41,6 +41,8 @@ def _to_target_device(idx, backend: HPCBackend):
 def to_backend(obj, backend: HPCBackend):
     if not isinstance(backend.device, (DeviceCPU, DeviceROCm)):
         raise TypeError(f"to_backend: unknown device {backend.device!r}")
+    if getattr(obj, "backend", None) is not None and obj.backend.T != backend.T:
+        raise TypeError(f"to_backend: element type {obj.backend.T} -> {backend.T} (to_backend moves arrays, it does not convert them)")
     if isinstance(obj, HPCVector):                                   # :337-340
         return HPCVector(obj.structural_hash, obj.partition, _convert_array(obj.v, backend), backend)
     if isinstance(obj, HPCMatrix):                                   # :347-350

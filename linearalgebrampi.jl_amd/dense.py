@@ -70,10 +70,11 @@ class HPCMatrix:
     def _scaled(self, a: float, divide: bool) -> "HPCMatrix":
         src = self.A if self.A.is_contiguous() else self.A.contiguous()
         out = _torch().empty_like(src)
+        from .vectors import sfx_of
         if divide:
-            _capi.call("hpcla_divide_f64", dptr(src), a, dptr(out), src.numel(), current_stream_ptr())
+            _capi.call(f"hpcla_divide_{sfx_of(self.backend)}", dptr(src), a, dptr(out), src.numel(), current_stream_ptr())
         else:
-            _capi.call("hpcla_scale_f64", a, dptr(src), dptr(out), src.numel(), current_stream_ptr())
+            _capi.call(f"hpcla_scale_{sfx_of(self.backend)}", a, dptr(src), dptr(out), src.numel(), current_stream_ptr())
         return HPCMatrix(self.row_partition, self.col_partition, out, self.backend)
 
     def norm(self, p: float = 2) -> float:
@@ -110,7 +111,7 @@ class HPCMatrix:
         dev = _host_device(comm)
         sizes = np.diff(self.row_partition)
         nmax, k = int(sizes.max()), loc.shape[1]
-        pad = torch.zeros((nmax, k), dtype=torch.float64, device=dev)
+        pad = torch.zeros((nmax, k), dtype=self.A.dtype, device=dev)
         pad[:loc.shape[0]] = torch.from_numpy(loc).to(dev)
         outs = [torch.empty_like(pad) for _ in range(comm_size(comm))]
         _dist().all_gather(outs, pad, group=comm.group)
@@ -120,7 +121,7 @@ class HPCMatrix:
     def from_global(cls, M, backend: HPCBackend, row_partition=None, col_partition=None):
         """``HPCMatrix(M, backend; row_partition, col_partition)`` (src/dense.jl:185-201)."""
         torch = _torch()
-        M = np.asarray(M, dtype=np.float64)
+        M = np.asarray(M, dtype=backend.T)
         nranks, rank = comm_size(backend.comm), comm_rank(backend.comm)
         if row_partition is None:
             row_partition = uniform_partition(M.shape[0], nranks)
@@ -135,8 +136,9 @@ def HPCMatrix_local(A_local, backend: HPCBackend, col_partition=None) -> HPCMatr
     """src/dense.jl:125-156: row partition inferred by Allgather of ``[nrows, ncols]``."""
     torch = _torch()
     if isinstance(A_local, np.ndarray):
-        A_local = torch.from_numpy(np.ascontiguousarray(A_local, dtype=np.float64))
-    A_local = A_local.to(device=backend.torch_device, dtype=torch.float64).contiguous()
+        A_local = torch.from_numpy(np.ascontiguousarray(A_local, dtype=backend.T))
+    from .vectors import torch_dtype_of
+    A_local = A_local.to(device=backend.torch_device, dtype=torch_dtype_of(backend)).contiguous()
     nranks = comm_size(backend.comm)
     info = comm_allgather(backend.comm, np.array(list(A_local.shape), dtype=np.int64)).reshape(nranks, 2)
     if not np.all(info[:, 1] == info[0, 1]):                       # src/dense.jl:139-143
@@ -192,7 +194,8 @@ def _dense_vector_plan(A: HPCMatrix, x):
 
 def dense_matvec(A: HPCMatrix, x, y=None):
     """``A * x`` / ``mul!(y, A, x)`` for a dense row-partitioned A (src/dense.jl:614-658)."""
-    from .vectors import HPCVector
+    from .vectors import HPCVector, f64_only
+    f64_only(A.backend, "dense A*x")
     torch = _torch()
     assert_backends_compatible(A.backend, x.backend)
     backend = A.backend
@@ -250,6 +253,8 @@ def dense_matvec_t(A: HPCMatrix, x):
     slice.  Here: x is aligned to ``A.row_partition`` device to device (repartition.py; a no-op when
     it already is), ``hpcla_gemv_t_rowmajor_f64`` forms the partial column sums, RCCL all-reduces them
     in place, and the own slice of ``A.col_partition`` is the result."""
+    from .vectors import f64_only
+    f64_only(A.backend, "transpose(A)*x for dense A")
     from .repartition import repartition_vector
     from .vectors import HPCVector
     torch = _torch()
@@ -330,7 +335,7 @@ def _spmm_plan(A, B: HPCMatrix):
     if nranks == 1 or k == 0:
         return plan, None
     s = current_stream_ptr()
-    key = (A._ensure_hash(), probe.structural_hash, k, plan.is_i64)
+    key = (A._ensure_hash(), probe.structural_hash, k, plan.is_i64, str(A.T))
     _spmm_backends[id(backend)] = backend
     ent = _spmm_halo_cache.get(key)
     if ent is None:
@@ -378,8 +383,10 @@ def _spmm_plan(A, B: HPCMatrix):
             wprobe = (plan.n_own, k, [(r, np.arange(bp[r + 1] - bp[r]) if wish[r] else A.col_indices[perm] - bp[r])
                                      for r, perm in zip(h.recv_rank_ids, h.recv_perm)])
             attach_halo_windows(backend, halo, wprobe)  # collective: push transport when all ranks share a node
-            # SpMM row blocks are smaller than SpMV row blocks: classify at SpMM granularity
-            rpb = _capi.load().hpcla_spmm_rows_per_block()
+            # SpMM row blocks are smaller than SpMV row blocks: classify at SpMM granularity (the Float32 product, csrc/f32.hip,
+            # runs on the SpMV's 256-row blocks)
+            rpb = (_capi.load().hpcla_spmv_rows_per_block() if A.T == np.dtype(np.float32)
+                   else _capi.load().hpcla_spmm_rows_per_block())
             nblk = (A.nrows_local + rpb - 1) // rpb
             flags_i = torch.empty(nblk, dtype=torch.int32, device=dev)
             _capi.call(f"hpcla_classify_blocks_{sfx}", dptr(_entry_rowptr(A, plan, ent_i64)), dptr(colval_split),
@@ -646,6 +653,29 @@ def spmm_block_order_of(A, B: HPCMatrix) -> int:
     return plan.__dict__.get("_spmm_order", {}).get((k, rowptr.data_ptr()), 0)
 
 
+def _spmm_f32(A, plan, ent, Bc, C, k: int, s) -> None:
+    """The Float32 product (csrc/f32.hip): the same exchange entry and block lists as the Float64 one; the exchange widens
+    the B rows it sends into a staging block, the boundary blocks narrow the ghost rows they gather."""
+    if ent is None or ent[0] is None:
+        sfx = "i64" if plan.is_i64 else "i32"
+        _capi.call(f"hpcla_spmm_split_f32_{sfx}", dptr(plan.rowptr_of(A)), dptr(plan.colval_split), dptr(A.nzval), dptr(Bc), k,
+                   None, k, plan.n_own, dptr(C), k, A.nrows_local, A.nnz, k, 0, None, 0, s)
+        return
+    halo, interior, boundary, _, colval_split, ghost = ent[:6]
+    sfx = "i64" if ent[10] else "i32"
+    rowptr = _entry_rowptr(A, plan, bool(ent[10]))
+
+    def blocks_launch(blocks, g):
+        _capi.call(f"hpcla_spmm_split_f32_{sfx}", dptr(rowptr), dptr(colval_split), dptr(A.nzval), dptr(Bc), k, g, k,
+                   plan.n_own, dptr(C), k, A.nrows_local, A.nnz, k, 0, dptr(blocks), int(blocks.numel()), s)
+    _capi.call("hpcla_halo_begin_f32", halo, dptr(Bc), dptr(plan.stage_f32(plan.n_own * k)), s)
+    if interior.numel():
+        blocks_launch(interior, None)
+    _capi.call("hpcla_halo_end", halo, s)
+    if boundary.numel():
+        blocks_launch(boundary, ghost)
+
+
 def spmm(A, B: HPCMatrix) -> HPCMatrix:
     """``A * B`` (src/sparse.jl:2391-2413): result has A's row partition and B's backend."""
     torch = _torch()
@@ -654,12 +684,15 @@ def spmm(A, B: HPCMatrix) -> HPCMatrix:
     dev = backend.torch_device
     k = int(B.A.shape[1])
     plan, ent = _spmm_plan(A, B)
-    C = torch.empty((A.nrows_local, k), dtype=torch.float64, device=dev)
+    C = torch.empty((A.nrows_local, k), dtype=B.A.dtype, device=dev)
     out = HPCMatrix(plan.result_partition, uniform_partition(k, comm_size(backend.comm)), C, backend)
     if k == 0:                       # (a rank without local rows still takes part in the exchange below)
         return out
     s = current_stream_ptr()
     Bc = B.A.contiguous()
+    if A.T == np.dtype(np.float32):
+        _spmm_f32(A, plan, ent, Bc, C, k, s)
+        return out
     if ent is not None and spmm_order() == "panel":
         # COLLECTIVE choice: every rank must run the same order (the chunk-set plans are separate exchanges, and a
         # rank without neighbours still takes part in their collective attach)

@@ -351,6 +351,8 @@ def spgemm_local(A, g_rowptr, g_col, g_val, ncols_global: int, col_partition, ca
 
 def spgemm(A, B):
     """``A * B`` for two HPCSparseMatrix (src/sparse.jl:991-1059)."""
+    from .vectors import f64_only
+    f64_only(A.backend, "sparse * sparse")
     assert_backends_compatible(A.backend, B.backend)
     if A.shape[1] != B.shape[0]:
         raise ValueError(f"dimension mismatch: {A.shape} * {B.shape}")

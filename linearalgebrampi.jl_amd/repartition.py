@@ -118,6 +118,8 @@ def get_vector_repartition_plan(x: HPCVector, p: np.ndarray) -> RangePlan:
 
 
 def repartition_vector(x: HPCVector, p) -> HPCVector:
+    from .vectors import f64_only
+    f64_only(x.backend, "repartition")
     nranks = comm_size(x.backend.comm)
     p = check_partition(p, len(x), nranks)
     if np.array_equal(x.partition, p):                               # fast path, src/vectors.jl:713-716
@@ -131,6 +133,8 @@ def repartition_vector(x: HPCVector, p) -> HPCVector:
 
 # ---- dense rows (src/dense.jl:1551-1810) --------------------------------------------------------------
 def repartition_dense(A, p):
+    from .vectors import f64_only
+    f64_only(A.backend, "repartition")
     from .dense import HPCMatrix
     nranks = comm_size(A.backend.comm)
     p = check_partition(p, int(A.row_partition[-1]), nranks)
@@ -227,6 +231,8 @@ def get_sparse_repartition_plan(A, p: np.ndarray) -> SparseRepartitionPlan:
 
 
 def repartition_sparse(A, p):
+    from .vectors import f64_only
+    f64_only(A.backend, "repartition")
     nranks = comm_size(A.backend.comm)
     p = check_partition(p, int(A.row_partition[-1]), nranks)
     if np.array_equal(A.row_partition, p):                           # src/sparse.jl:4591-4594

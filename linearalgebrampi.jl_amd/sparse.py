@@ -284,11 +284,16 @@ class VectorPlan:
         else:
             send_idx = None
         self.has_halo = (n_send + n_recv) > 0
+        # Float32 plans (csrc/f32.hip) drive the exchange through begin / end with the ghost pointer taken from the host in
+        # between: one ghost buffer, so that the pointer is a constant of the plan
+        self.is_f32 = A.T == np.dtype(np.float32)
+        self._stage32 = None
         if self.has_halo:
             torch.cuda.current_stream().synchronize()
-            _capi.check("hpcla_halo_plan_create", _capi.load().hpcla_halo_plan_create(
+            _capi.check("hpcla_halo_plan_create_ex", _capi.load().hpcla_halo_plan_create_ex(
                 ctypes.byref(self.halo), backend.rccl, n_send, send_ranks, send_counts,
-                dptr(send_idx), 1 if self.is_i64 else 0, n_recv, recv_ranks, recv_counts, 1))
+                dptr(send_idx), 1 if self.is_i64 else 0, n_recv, recv_ranks, recv_counts, 1,
+                _capi.HALO_SINGLE_BUFFER if self.is_f32 else 0))
         # collective (ranks without neighbours take part with an empty descriptor): map the neighbours'
         # ghost windows -> push transport for this plan (csrc/window.hip)
         xp = np.asarray(x.partition, dtype=np.int64)
@@ -321,7 +326,8 @@ class VectorPlan:
                 sys.stderr.write(f"hpcla: HPCLA_BLOCK_ORDER={want} is not a power of two <= 1024; natural order\n")
                 g = 1
             self.block_group = max(1, g)
-        elif want != "natural" and A.nrows_local > 0 and A.nnz > 0 and int(x.v.numel()) >= max(self.n_own, 1):
+        elif (want != "natural" and not self.is_f32 and A.nrows_local > 0 and A.nnz > 0
+              and int(x.v.numel()) >= max(self.n_own, 1)):
             # (x only has to be readable at the plan's own columns: the products are discarded; a width-0 SpMM probe is not)
             scratch = torch.empty(A.nrows_local, dtype=torch.float64, device=dev)
             ghost, _ng = self.ghost_tensor_ptr()
@@ -347,6 +353,12 @@ class VectorPlan:
         """The ``rowptr`` the kernels of this plan read for matrix A: A's own device array, or -- narrowed plan -- the
         plan's Int32 copy (equal contents for every matrix that shares the plan: the structural hash covers rowptr)."""
         return self._rowptr32 if self.narrowed else A.rowptr_target
+
+    def stage_f32(self, n: int):
+        """Staging vector of a Float32 exchange (hpcla_halo_begin_f32): n doubles, written at the send positions only."""
+        if self._stage32 is None or int(self._stage32.numel()) < n:
+            self._stage32 = _torch().empty(max(n, 1), dtype=_torch().float64, device=self.backend.torch_device)
+        return self._stage32
 
     def ghost_tensor_ptr(self) -> Tuple[ctypes.c_void_p, int]:
         g = ctypes.c_void_p()
@@ -500,6 +512,8 @@ def execute_plan(plan: VectorPlan, x: HPCVector):
     h = plan.host
     dev = x.v.device
     s = current_stream_ptr()
+    from .vectors import f64_only
+    f64_only(x.backend, "execute_plan (the materialised `gathered`; A*x itself reads x.v and the ghosts in place)")
     gathered = torch.empty(h.n_gathered, dtype=torch.float64, device=dev)
     if plan.has_halo:
         _capi.call("hpcla_halo_begin", plan.halo, dptr(x.v), s)
@@ -660,7 +674,7 @@ class HPCSparseMatrix:
         if isinstance(other, HPCVector):
             plan = get_vector_plan(self, other)
             y = HPCVector(plan.result_partition_hash, plan.result_partition,
-                          _torch().empty(self.nrows_local, dtype=_torch().float64,
+                          _torch().empty(self.nrows_local, dtype=other.v.dtype,
                                          device=self.backend.torch_device), self.backend)
             _spmv_into(y, self, other, plan)
             return y
@@ -697,7 +711,8 @@ class HPCSparseMatrix:
 
     def _scaled(self, a: float) -> "HPCSparseMatrix":
         out = _torch().empty_like(self.nzval)
-        _capi.call("hpcla_scale_f64", a, dptr(self.nzval), dptr(out), self.nnz, current_stream_ptr())
+        from .vectors import sfx_of
+        _capi.call(f"hpcla_scale_{sfx_of(self.backend)}", a, dptr(self.nzval), dptr(out), self.nnz, current_stream_ptr())
         return self._with_values(out)
 
     def copy(self) -> "HPCSparseMatrix":                             # src/sparse.jl:2458
@@ -728,6 +743,9 @@ def _spmv_into(y: HPCVector, A: HPCSparseMatrix, x: HPCVector, plan: VectorPlan)
         raise ValueError("mul!: y has the wrong local length")
     if x.local_length != plan.n_own:
         raise ValueError("A*x: x does not match the plan's partition")
+    if plan.is_f32:
+        _spmv_into_f32(y, A, x, plan)
+        return
     pk = A._packed_for(plan)
     if pk is not None:
         _capi.call("hpcla_spmv_dist_packed_f64_i32", plan.halo if plan.has_halo else None, A.backend.rccl,
@@ -740,6 +758,27 @@ def _spmv_into(y: HPCVector, A: HPCSparseMatrix, x: HPCVector, plan: VectorPlan)
                dptr(plan.rowptr_of(A)), dptr(plan.colval_split), dptr(A.nzval), dptr(x.v), plan.n_own,
                dptr(y.v), A.nrows_local, A.nnz, 0, dptr(plan.interior), plan.n_interior,
                dptr(plan.boundary), plan.n_boundary, current_stream_ptr())
+
+
+def _spmv_into_f32(y: HPCVector, A: HPCSparseMatrix, x: HPCVector, plan: VectorPlan) -> None:
+    """The Float32 form of the distributed product (csrc/f32.hip): the exchange widens what it sends into a staging vector
+    and runs on the plan's side stream while the interior row blocks multiply; the boundary blocks follow the exchange and
+    narrow the ghost values they gather.  Same transports, same block lists as the Float64 product."""
+    s = current_stream_ptr()
+    fn = f"hpcla_spmv_split_f32_{'i64' if plan.is_i64 else 'i32'}"
+    rp, cv = dptr(plan.rowptr_of(A)), dptr(plan.colval_split)
+    if not plan.has_halo:
+        _capi.call(fn, rp, cv, dptr(A.nzval), dptr(x.v), None, plan.n_own, dptr(y.v), A.nrows_local, A.nnz, 0, None, 0, s)
+        return
+    _capi.call("hpcla_halo_begin_f32", plan.halo, dptr(x.v), dptr(plan.stage_f32(plan.n_own)), s)
+    if plan.n_interior:
+        _capi.call(fn, rp, cv, dptr(A.nzval), dptr(x.v), None, plan.n_own, dptr(y.v), A.nrows_local, A.nnz, 0,
+                   dptr(plan.interior), plan.n_interior, s)
+    _capi.call("hpcla_halo_end", plan.halo, s)
+    if plan.n_boundary:
+        ghost, _n = plan.ghost_tensor_ptr()           # single-buffered plan: a constant, no device synchronisation
+        _capi.call(fn, rp, cv, dptr(A.nzval), dptr(x.v), ghost, plan.n_own, dptr(y.v), A.nrows_local, A.nnz, 0,
+                   dptr(plan.boundary), plan.n_boundary, s)
 
 
 def mul_(y: HPCVector, A: HPCSparseMatrix, x: HPCVector) -> HPCVector:
@@ -761,6 +800,8 @@ def mul_dot_(y: HPCVector, A: HPCSparseMatrix, x: HPCVector, out) -> HPCVector:
     the scalar stays in the 1-element device tensor ``out``.  Requires x partitioned like A's rows."""
     assert_backends_compatible(A.backend, x.backend)
     assert_backends_compatible(A.backend, y.backend)
+    from .vectors import f64_only
+    f64_only(A.backend, "mul_dot_ (the fused p.Ap epilogue)")
     plan = get_vector_plan(A, x)
     if y.structural_hash != plan.result_partition_hash or x.structural_hash != plan.result_partition_hash:
         raise ValueError("mul_dot_: x and y must have A's row partition")
@@ -812,7 +853,7 @@ def HPCSparseMatrix_local(rowptr, colidx_global, vals, ncols_global: int, backen
     Ti = backend.Ti.type
     rowptr = np.asarray(rowptr, dtype=np.int64)
     colidx_global = np.asarray(colidx_global, dtype=np.int64)
-    vals = np.ascontiguousarray(vals, dtype=np.float64)
+    vals = np.ascontiguousarray(vals, dtype=backend.T)
     nrows = len(rowptr) - 1
     if rowptr[0] != 0 or rowptr[-1] != len(colidx_global) or len(vals) != len(colidx_global):
         raise ValueError("HPCSparseMatrix_local: inconsistent CSR arrays")

@@ -157,6 +157,8 @@ class TransposedHPCSparseMatrix:
 
     def materialize(self):
         """``HPCSparseMatrix(transpose(A))`` (src/sparse.jl:1846-1862), cached bidirectionally."""
+        from .vectors import f64_only
+        f64_only(self.parent.backend, "transpose(A) (materialised)")
         A = self.parent
         if getattr(A, "cached_transpose", None) is not None:
             return A.cached_transpose

@@ -1,8 +1,9 @@
 """HPCVector on DeviceROCm (reference: src/vectors.jl).
 
 ``HPCVector{T,B}`` (src/vectors.jl:21-30): ``structural_hash`` (hash of the partition),
-``partition`` (host), ``v`` (local slice, here a device buffer held as a torch.float64 CUDA tensor
--- torch is only the allocator/stream provider), ``backend``.
+``partition`` (host), ``v`` (local slice, here a device buffer held as a torch CUDA tensor of the backend's element
+type -- float64, or float32 for the reference's Float32 configurations (test/test_utils.jl:62-80), csrc/f32.hip -- torch
+is only the allocator/stream provider), ``backend``.
 
 Every arithmetic method launches kernels of libhpcla_rocm through the C ABI on torch's current
 stream; nothing here computes on the CPU.
@@ -42,6 +43,29 @@ def dptr(t) -> ctypes.c_void_p:
     return ctypes.c_void_p(t.data_ptr())
 
 
+def sfx_of(backend: HPCBackend) -> str:
+    """Suffix of the C entry points for the backend's element type (``_f64`` kernels, or csrc/f32.hip's ``_f32``)."""
+    return "f32" if backend.T == np.dtype(np.float32) else "f64"
+
+
+def torch_dtype_of(backend: HPCBackend):
+    torch = _torch()
+    return torch.float32 if backend.T == np.dtype(np.float32) else torch.float64
+
+
+def f64_only(backend: HPCBackend, what: str) -> None:
+    """The Float32 element type covers the reference's hot path (A*x, mul!, A*HPCMatrix, dot, norm, u+v, a*v); the
+    widened rows and the fused CG pieces are Float64 entries."""
+    if backend.T != np.dtype(np.float64):
+        raise TypeError(f"{what}: offered for Float64 backends only (Float32 covers A*x, mul!, A*B with dense B, dot, norm, "
+                        "sum, maximum / minimum, u+v, u-v, a*v, v/a)")
+
+
+def _round_to(backend: HPCBackend, v: float) -> float:
+    """A reduction's double result, rounded once to the backend's element type (dot / norm return T in the reference)."""
+    return float(np.float32(v)) if backend.T == np.dtype(np.float32) else v
+
+
 class _Scratch:
     """Per-device reduction workspace + result scalar (allocated once; the launch functions never
     allocate, cdna_hip_programming.md Guideline 9)."""
@@ -72,7 +96,7 @@ class HPCVector:
     @classmethod
     def from_global(cls, v_global, backend: HPCBackend, partition: Optional[np.ndarray] = None):
         torch = _torch()
-        v_global = np.asarray(v_global, dtype=np.float64)
+        v_global = np.asarray(v_global, dtype=backend.T)
         nranks, rank = comm_size(backend.comm), comm_rank(backend.comm)
         if partition is None:
             partition = uniform_partition(len(v_global), nranks)
@@ -86,7 +110,7 @@ class HPCVector:
         rank = comm_rank(backend.comm)
         n = int(partition[rank + 1] - partition[rank])
         return cls(compute_partition_hash(partition), partition,
-                   torch.zeros(n, dtype=torch.float64, device=backend.torch_device), backend)
+                   torch.zeros(n, dtype=torch_dtype_of(backend), device=backend.torch_device), backend)
 
     def similar(self):
         torch = _torch()
@@ -121,7 +145,7 @@ class HPCVector:
         dev = _host_device(comm)
         sizes = np.diff(self.partition)
         nmax = int(sizes.max()) if len(sizes) else 0
-        pad = torch.zeros(nmax, dtype=torch.float64, device=dev)
+        pad = torch.zeros(nmax, dtype=torch_dtype_of(self.backend), device=dev)
         pad[:len(loc)] = torch.from_numpy(loc).to(dev)
         outs = [torch.empty_like(pad) for _ in range(comm_size(comm))]
         dist.all_gather(outs, pad, group=comm.group)
@@ -151,7 +175,7 @@ class HPCVector:
     def _axpby(self, a: float, other: "HPCVector", b: float) -> "HPCVector":
         other = self._aligned(other)
         out = self.similar()
-        _capi.call("hpcla_axpby_f64", float(a), dptr(self.v), float(b), dptr(other.v), dptr(out.v),
+        _capi.call(f"hpcla_axpby_{sfx_of(self.backend)}", float(a), dptr(self.v), float(b), dptr(other.v), dptr(out.v),
                    self.local_length, current_stream_ptr())
         return out
 
@@ -168,7 +192,7 @@ class HPCVector:
         if isinstance(a, HPCVector):
             return NotImplemented
         out = self.similar()
-        _capi.call("hpcla_scale_f64", float(a), dptr(self.v), dptr(out.v), self.local_length,
+        _capi.call(f"hpcla_scale_{sfx_of(self.backend)}", float(a), dptr(self.v), dptr(out.v), self.local_length,
                    current_stream_ptr())
         return out
 
@@ -176,7 +200,7 @@ class HPCVector:
 
     def __truediv__(self, a):
         out = self.similar()
-        _capi.call("hpcla_divide_f64", dptr(self.v), float(a), dptr(out.v), self.local_length,
+        _capi.call(f"hpcla_divide_{sfx_of(self.backend)}", dptr(self.v), float(a), dptr(out.v), self.local_length,
                    current_stream_ptr())
         return out
 
@@ -184,6 +208,7 @@ class HPCVector:
     def axpy_(self, a: float, x: "HPCVector", num=None, den=None) -> "HPCVector":
         """self .= self .+ (a*num/den) .* x ; num/den optional device scalars (1-element tensors)."""
         self._same_partition(x)
+        f64_only(self.backend, "axpy_")
         _capi.call("hpcla_axpy_f64", float(a), dptr(num), dptr(den), dptr(x.v), dptr(self.v),
                    self.local_length, current_stream_ptr())
         return self
@@ -191,6 +216,7 @@ class HPCVector:
     def xpay_(self, x: "HPCVector", a: float, num=None, den=None) -> "HPCVector":
         """self .= x .+ (a*num/den) .* self."""
         self._same_partition(x)
+        f64_only(self.backend, "xpay_")
         _capi.call("hpcla_xpay_f64", dptr(x.v), float(a), dptr(num), dptr(den), dptr(self.v),
                    self.local_length, current_stream_ptr())
         return self
@@ -201,6 +227,7 @@ def cg_update_(x: HPCVector, r: HPCVector, p: HPCVector, Ap: HPCVector, a: float
     ``s = a*num/den`` read from device scalars -- one pass (48 B/elt) instead of two broadcasts and a
     norm (56 B/elt, src/vectors.jl:1203-1226, 758-765)."""
     x._same_partition(r), x._same_partition(p), x._same_partition(Ap)
+    f64_only(x.backend, "cg_update_")
     work, _ = _Scratch.get(x.v.device)
     _capi.call("hpcla_cg_update_f64", x.backend.rccl, float(a), dptr(num), dptr(den), dptr(p.v), dptr(Ap.v),
                dptr(x.v), dptr(r.v), x.local_length, dptr(rr_out), dptr(work), current_stream_ptr())
@@ -210,6 +237,7 @@ def cg_update_(x: HPCVector, r: HPCVector, p: HPCVector, Ap: HPCVector, a: float
 def cg_residual_(r: HPCVector, Ap: HPCVector, a: float, num, den, rr_out):
     """``r .-= s .* Ap ; rr_out = sum(r.^2)``, ``s = a*num/den`` from device scalars (24 B/elt)."""
     r._same_partition(Ap)
+    f64_only(r.backend, "cg_residual_")
     work, _ = _Scratch.get(r.v.device)
     _capi.call("hpcla_cg_residual_f64", r.backend.rccl, float(a), dptr(num), dptr(den), dptr(Ap.v), dptr(r.v),
                r.local_length, dptr(rr_out), dptr(work), current_stream_ptr())
@@ -220,6 +248,7 @@ def cg_direction_(x: HPCVector, p: HPCVector, r: HPCVector, a: float, a_num, a_d
     """``x .+= s .* p ; p .= r .+ t .* p`` with ``s = a*a_num/a_den``, ``t = b*b_num/b_den`` (40 B/elt): the
     deferred x update of a CG iteration rides on the direction update, which reads the same p."""
     x._same_partition(p), x._same_partition(r)
+    f64_only(x.backend, "cg_direction_")
     _capi.call("hpcla_cg_direction_f64", float(a), dptr(a_num), dptr(a_den), float(b), dptr(b_num), dptr(b_den),
                dptr(r.v), dptr(x.v), dptr(p.v), x.local_length, current_stream_ptr())
 
@@ -228,8 +257,8 @@ def HPCVector_local(v_local, backend: HPCBackend) -> HPCVector:
     """src/vectors.jl:76-94: partition inferred by an Allgather of the local sizes."""
     torch = _torch()
     if isinstance(v_local, np.ndarray):
-        v_local = torch.from_numpy(np.ascontiguousarray(v_local, dtype=np.float64))
-    v_local = v_local.to(device=backend.torch_device, dtype=torch.float64).contiguous()
+        v_local = torch.from_numpy(np.ascontiguousarray(v_local, dtype=backend.T))
+    v_local = v_local.to(device=backend.torch_device, dtype=torch_dtype_of(backend)).contiguous()
     sizes = comm_allgather(backend.comm, np.array([v_local.numel()], dtype=np.int64))
     partition = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
     return HPCVector(compute_partition_hash(partition), partition, v_local, backend)
@@ -252,14 +281,15 @@ def _reduce(kind: str, x: HPCVector, y: Optional[HPCVector], out=None):
         out = scal[:1]
     comm = x.backend.rccl
     s = current_stream_ptr()
+    t = sfx_of(x.backend)                  # Float32 operands: the scalar is still formed and all-reduced in double (f32.hip)
     if kind == "dot":
-        _capi.call("hpcla_dot_f64", comm, dptr(x.v), dptr(y.v), x.local_length, dptr(out), dptr(work), s)
+        _capi.call(f"hpcla_dot_{t}", comm, dptr(x.v), dptr(y.v), x.local_length, dptr(out), dptr(work), s)
     elif kind == "nrm2sq":
-        _capi.call("hpcla_nrm2sq_f64", comm, dptr(x.v), x.local_length, dptr(out), dptr(work), s)
+        _capi.call(f"hpcla_nrm2sq_{t}", comm, dptr(x.v), x.local_length, dptr(out), dptr(work), s)
     elif kind == "asum":
-        _capi.call("hpcla_asum_f64", comm, dptr(x.v), x.local_length, dptr(out), dptr(work), s)
+        _capi.call(f"hpcla_asum_{t}", comm, dptr(x.v), x.local_length, dptr(out), dptr(work), s)
     elif kind == "amax":
-        _capi.call("hpcla_amax_f64", comm, dptr(x.v), x.local_length, dptr(out), dptr(work), s)
+        _capi.call(f"hpcla_amax_{t}", comm, dptr(x.v), x.local_length, dptr(out), dptr(work), s)
     else:  # pragma: no cover
         raise ValueError(kind)
     return out
@@ -269,12 +299,14 @@ def vsum(v: HPCVector, out=None):
     """``sum(v)`` (src/vectors.jl:838-845)."""
     work, scal = _Scratch.get(v.v.device)
     r = out if out is not None else scal[:1]
-    _capi.call("hpcla_sum_f64", v.backend.rccl, dptr(v.v), v.local_length, dptr(r), dptr(work), current_stream_ptr())
-    return r if out is not None else _host_scalar(r, v.backend)
+    _capi.call(f"hpcla_sum_{sfx_of(v.backend)}", v.backend.rccl, dptr(v.v), v.local_length, dptr(r), dptr(work),
+               current_stream_ptr())
+    return r if out is not None else _round_to(v.backend, _host_scalar(r, v.backend))
 
 
 def prod(v: HPCVector) -> float:
     """``prod(v)`` (src/vectors.jl:853-858): local product (1 for an empty part), then an all-reduce with ``*``."""
+    f64_only(v.backend, "prod")
     work, scal = _Scratch.get(v.v.device)
     _capi.call("hpcla_prod_f64", v.backend.rccl, dptr(v.v), v.local_length, dptr(scal[:1]), dptr(work), current_stream_ptr())
     return _host_scalar(scal[:1], v.backend)
@@ -282,7 +314,7 @@ def prod(v: HPCVector) -> float:
 
 def _maxval(v: HPCVector, negate: int) -> float:
     work, scal = _Scratch.get(v.v.device)
-    _capi.call("hpcla_maxval_f64", v.backend.rccl, dptr(v.v), v.local_length, negate, dptr(scal[:1]), dptr(work),
+    _capi.call(f"hpcla_maxval_{sfx_of(v.backend)}", v.backend.rccl, dptr(v.v), v.local_length, negate, dptr(scal[:1]), dptr(work),
                current_stream_ptr())
     return _host_scalar(scal[:1], v.backend)
 
@@ -302,7 +334,7 @@ def dot(x: HPCVector, y: HPCVector, out=None):
     (1-element device tensor) is given, leaves the result on the device and returns ``out``."""
     y = x._aligned(y)
     r = _reduce("dot", x, y, out)
-    return r if out is not None else _host_scalar(r, x.backend)
+    return r if out is not None else _round_to(x.backend, _host_scalar(r, x.backend))
 
 
 def norm(v: HPCVector, p: float = 2, out=None):
@@ -312,15 +344,16 @@ def norm(v: HPCVector, p: float = 2, out=None):
     the caller's), for p=1 / Inf the norm itself, for any other p the sum of |x|^p."""
     if p == 2:
         r = _reduce("nrm2sq", v, None, out)
-        return r if out is not None else math.sqrt(_host_scalar(r, v.backend))
+        return r if out is not None else _round_to(v.backend, math.sqrt(_host_scalar(r, v.backend)))
     if p == 1:
         r = _reduce("asum", v, None, out)
-        return r if out is not None else _host_scalar(r, v.backend)
+        return r if out is not None else _round_to(v.backend, _host_scalar(r, v.backend))
     if p == math.inf:
         r = _reduce("amax", v, None, out)
         return r if out is not None else _host_scalar(r, v.backend)
     if not (p > 0):
         raise ValueError("norm: p must be positive")
+    f64_only(v.backend, "norm(v, p) for p other than 1, 2, Inf")
     work, scal = _Scratch.get(v.v.device)                                        # general p (:774-779)
     r = out if out is not None else scal[:1]
     _capi.call("hpcla_powsum_f64", v.backend.rccl, dptr(v.v), v.local_length, float(p), dptr(r), dptr(work),

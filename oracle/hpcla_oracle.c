@@ -194,22 +194,26 @@ ORC_API int64_t orc_sprand_rows(int64_t ncols, double p, uint64_t seed_struct, u
  * KernelAbstractions' CPU backend over Julia threads (src/sparse.jl:2077-2080); here OpenMP
  * static over rows.  nthreads<=0 -> OpenMP default.
  * ---------------------------------------------------------------------------------------- */
-#define ORC_SPMV(NAME, ITYPE)                                                                     \
-    ORC_API void NAME(const ITYPE *rowptr, const ITYPE *colval, const double *nzval,              \
-                      const double *x, double *y, int64_t nrows, int base, int nthreads)          \
+#define ORC_SPMV(NAME, ITYPE, VTYPE)                                                              \
+    ORC_API void NAME(const ITYPE *rowptr, const ITYPE *colval, const VTYPE *nzval,               \
+                      const VTYPE *x, VTYPE *y, int64_t nrows, int base, int nthreads)            \
     {                                                                                             \
         _Pragma("omp parallel for schedule(static) if (nthreads != 1)") for (int64_t row = 0;     \
                                                                              row < nrows; ++row)  \
         {                                                                                         \
-            double acc = 0.0;                                                                     \
+            VTYPE acc = 0;                                                                        \
             for (int64_t j = (int64_t)rowptr[row] - base; j < (int64_t)rowptr[row + 1] - base;    \
                  ++j)                                                                             \
                 acc += nzval[j] * x[(int64_t)colval[j] - base];                                   \
             y[row] = acc;                                                                         \
         }                                                                                         \
     }
-ORC_SPMV(orc_spmv_i32, int32_t)
-ORC_SPMV(orc_spmv_i64, int64_t)
+ORC_SPMV(orc_spmv_i32, int32_t, double)
+ORC_SPMV(orc_spmv_i64, int64_t, double)
+/* the same loop with T = Float32 (`acc = zero(T)`, src/sparse.jl:2059; the reference's GPU configurations run it with
+ * Float32 and Float64, test/test_utils.jl:62-80): float accumulator, float product, separately rounded */
+ORC_SPMV(orc_spmv_f32_i32, int32_t, float)
+ORC_SPMV(orc_spmv_f32_i64, int64_t, float)
 
 ORC_API void orc_set_threads(int n)
 {
@@ -249,16 +253,16 @@ ORC_API void orc_abs_spmv_i32(const int32_t *rowptr, const int32_t *colval, cons
  * strides so both the reference's column-major Matrix (src/dense.jl:63) and a row-major device
  * layout are checkable: element (i,c) at ptr[i*rs + c*cs].
  * ---------------------------------------------------------------------------------------- */
-#define ORC_SPMM(NAME, ITYPE)                                                                     \
-    ORC_API void NAME(const ITYPE *rowptr, const ITYPE *colval, const double *nzval,              \
-                      const double *B, int64_t b_rs, int64_t b_cs, double *C, int64_t c_rs,       \
+#define ORC_SPMM(NAME, ITYPE, VTYPE)                                                              \
+    ORC_API void NAME(const ITYPE *rowptr, const ITYPE *colval, const VTYPE *nzval,               \
+                      const VTYPE *B, int64_t b_rs, int64_t b_cs, VTYPE *C, int64_t c_rs,         \
                       int64_t c_cs, int64_t nrows, int k, int base)                               \
     {                                                                                             \
         for (int c = 0; c < k; ++c) {                                                             \
             _Pragma("omp parallel for schedule(static)") for (int64_t row = 0; row < nrows;       \
                                                               ++row)                              \
             {                                                                                     \
-                double acc = 0.0;                                                                 \
+                VTYPE acc = 0;                                                                    \
                 for (int64_t j = (int64_t)rowptr[row] - base;                                     \
                      j < (int64_t)rowptr[row + 1] - base; ++j)                                    \
                     acc += nzval[j] * B[((int64_t)colval[j] - base) * b_rs + (int64_t)c * b_cs];  \
@@ -266,8 +270,10 @@ ORC_API void orc_abs_spmv_i32(const int32_t *rowptr, const int32_t *colval, cons
             }                                                                                     \
         }                                                                                         \
     }
-ORC_SPMM(orc_spmm_i32, int32_t)
-ORC_SPMM(orc_spmm_i64, int64_t)
+ORC_SPMM(orc_spmm_i32, int32_t, double)
+ORC_SPMM(orc_spmm_i64, int64_t, double)
+ORC_SPMM(orc_spmm_f32_i32, int32_t, float)
+ORC_SPMM(orc_spmm_f32_i64, int64_t, float)
 
 /* ------------------------------------------------------------------------------------------
  * dot (src/vectors.jl:798-812): local dot(x.v, y.v) then comm_allreduce(+).

@@ -63,10 +63,10 @@ def lib() -> ctypes.CDLL:
         L.orc_poisson3d_rows.restype = i64
         L.orc_sprand_rows.argtypes = [i64, f64, u64, u64, i64, i64, vp, vp, vp]
         L.orc_sprand_rows.restype = i64
-        for nm in ("orc_spmv_i32", "orc_spmv_i64"):
+        for nm in ("orc_spmv_i32", "orc_spmv_i64", "orc_spmv_f32_i32", "orc_spmv_f32_i64"):
             getattr(L, nm).argtypes = [vp, vp, vp, vp, vp, i64, i32, i32]
         L.orc_abs_spmv_i32.argtypes = [vp, vp, vp, vp, vp, i64, i32]
-        for nm in ("orc_spmm_i32", "orc_spmm_i64"):
+        for nm in ("orc_spmm_i32", "orc_spmm_i64", "orc_spmm_f32_i32", "orc_spmm_f32_i64"):
             getattr(L, nm).argtypes = [vp, vp, vp, vp, i64, i64, vp, i64, i64, i64, i32, i32]
         L.orc_dot_local.argtypes = [vp, vp, i64]
         L.orc_dot_local.restype = f64
@@ -265,11 +265,12 @@ def spmv(rowptr: np.ndarray, colval: np.ndarray, nzval: np.ndarray, x: np.ndarra
          base: int = 0, nthreads: int = 0) -> np.ndarray:
     """_spmv_kernel! (src/sparse.jl:2055-2066)."""
     nrows = len(rowptr) - 1
-    y = np.empty(nrows, dtype=np.float64)
     assert rowptr.dtype == colval.dtype and rowptr.dtype in (np.int32, np.int64)
-    assert nzval.dtype == np.float64 and x.dtype == np.float64
+    assert nzval.dtype == x.dtype and nzval.dtype in (np.float64, np.float32)      # T of the loop: acc = zero(T)
+    y = np.empty(nrows, dtype=nzval.dtype)
     rowptr, colval, nzval, x = map(np.ascontiguousarray, (rowptr, colval, nzval, x))
-    fn = lib().orc_spmv_i32 if rowptr.dtype == np.int32 else lib().orc_spmv_i64
+    sfx = ("f32_" if nzval.dtype == np.float32 else "") + ("i32" if rowptr.dtype == np.int32 else "i64")
+    fn = getattr(lib(), "orc_spmv_" + sfx)
     fn(_p(rowptr), _p(colval), _p(nzval), _p(x), _p(y), nrows, base, nthreads)
     return y
 
@@ -290,9 +291,11 @@ def spmm(rowptr, colval, nzval, B: np.ndarray, base: int = 0) -> np.ndarray:
     nrows = len(rowptr) - 1
     k = B.shape[1]
     order = "F" if B.flags.f_contiguous and not B.flags.c_contiguous else "C"
-    C = np.empty((nrows, k), dtype=np.float64, order=order)
+    assert nzval.dtype == B.dtype and B.dtype in (np.float64, np.float32)
+    C = np.empty((nrows, k), dtype=B.dtype, order=order)
     rowptr, colval, nzval = map(np.ascontiguousarray, (rowptr, colval, nzval))
-    fn = lib().orc_spmm_i32 if rowptr.dtype == np.int32 else lib().orc_spmm_i64
+    sfx = ("f32_" if B.dtype == np.float32 else "") + ("i32" if rowptr.dtype == np.int32 else "i64")
+    fn = getattr(lib(), "orc_spmm_" + sfx)
     es = B.itemsize
     fn(_p(rowptr), _p(colval), _p(nzval), _p(B), B.strides[0] // es, B.strides[1] // es,
        _p(C), C.strides[0] // es, C.strides[1] // es, nrows, k, base)

@@ -1,7 +1,7 @@
 """The Julia extension (integration/HPCLinearAlgebraROCmExt.jl) cannot be executed here (no Julia in the
 image), so its `@ccall`s are checked statically against the C ABI: every `@ccall LIB.name(arg::T, ...)::R`
 must name a function declared in include/hpcla_rocm.h with the same arity, and every argument's Julia
-type must be the C type of that parameter (pointer / int / int64_t / uint64_t / double); likewise the
+type must be the C type of that parameter (pointer / int / int64_t / uint64_t / double / float); likewise the
 return type.  The ctypes table of linearalgebrampi.jl_amd/_capi.py is checked against the header the same
 way, so the three descriptions of the boundary cannot drift apart unnoticed."""
 import os
@@ -26,6 +26,8 @@ def _c_class(decl):
         return "i64"
     if re.search(r"\bdouble\b", d):
         return "f64"
+    if re.search(r"\bfloat\b", d):
+        return "f32"
     if re.search(r"\bint\b", d):
         return "i32"
     raise AssertionError(f"unclassified C parameter: {d!r}")
@@ -41,7 +43,7 @@ def header_prototypes():
     return protos
 
 
-_JULIA = {"Cint": "i32", "Int32": "i32", "Int64": "i64", "UInt64": "u64", "Cdouble": "f64", "Float64": "f64",
+_JULIA = {"Cint": "i32", "Int32": "i32", "Int64": "i64", "UInt64": "u64", "Cdouble": "f64", "Float64": "f64", "Cfloat": "f32", "Float32": "f32",
           "Cstring": "cstr"}
 
 
@@ -126,7 +128,7 @@ def test_ctypes_table_matches_the_header():
     import hpcla_amd as hp
     protos = header_prototypes()
     cls = {ctypes.c_void_p: "ptr", ctypes.c_int: "i32", ctypes.c_int64: "i64", ctypes.c_uint64: "u64",
-           ctypes.c_double: "f64"}
+           ctypes.c_double: "f64", ctypes.c_float: "f32"}
     problems = []
     for name, argtypes in hp._capi._SIGNATURES.items():
         want = protos[name][1]
