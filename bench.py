@@ -623,6 +623,70 @@ def int64_record(hp, wl, job, args, N, steps, warmup):
     return rec, ok
 
 
+def float32_record(hp, wl, job, args, N, steps, warmup):
+    """The headline matrix with Float32 values -- the reference's other GPU configuration (CUDA x {Float32, Float64},
+    test/test_utils.jl:62-80) -- through the host layer's Float32 backend (csrc/f32.hip), as a driver-timed sub-record
+    (N = 1).  Algorithmic bytes are SURVEY 8d's formula with sizeof(T) = 4: 8 B per stored entry, 4 + 4 B per row, 4 B per
+    column.  Verified like the headline, bit for bit, against the closed form evaluated in Float32."""
+    torch = job.torch
+    b32 = hp.backend_rocm_serial(np.float32, np.int32, device_index=torch.cuda.current_device())
+    nx = ny = N
+    n = nx * ny
+    s0 = torch.cuda.current_stream().cuda_stream
+    nnz = hp._capi.load().hpcla_poisson2d_nnz(nx, ny, 0, n)
+    rp_d = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    ci_d = torch.empty(nnz, dtype=torch.int64, device="cuda")
+    va_d = torch.empty(nnz, dtype=torch.float64, device="cuda")
+    hp._capi.call("hpcla_gen_poisson2d", nx, ny, 0, n, rp_d.data_ptr(), ci_d.data_ptr(), va_d.data_ptr(), s0)
+    A = hp.HPCSparseMatrix_local_device(rp_d, ci_d, va_d, n, b32, col_window=(0, n - 1))
+    del rp_d, ci_d, va_d
+    x64 = torch.empty(n, dtype=torch.float64, device="cuda")
+    hp._capi.call("hpcla_fill_uniform_f64", x64.data_ptr(), 0, n, wl.SEED_X, s0)
+    x = hp.HPCVector.zeros(A.row_partition, b32)
+    x.v.copy_(x64)                                   # rounded to Float32 once, like an upload of Float32 data
+    del x64
+    y = hp.HPCVector.zeros(A.row_partition, b32)
+    step = lambda: hp.mul_(y, A, x)
+    step()
+    torch.cuda.synchronize()
+    # closed form in Float32: same order and rounding as the kernel (ascending column, multiply then add, all in float)
+    samp = np.unique(np.concatenate([np.arange(0, 3 * nx), np.arange(n - 3 * nx, n), np.random.default_rng(0).integers(0, n, 4096)]))
+    gi, gj = samp % nx, samp // nx
+    xs = lambda idx: wl.u01(wl.SEED_X, idx).astype(np.float32)
+    want = np.zeros(len(samp), dtype=np.float32)
+    for col, ok, coef in ((samp - nx, gj > 0, -1.0), (samp - 1, gi > 0, -1.0), (samp, np.ones_like(samp, bool), 4.0),
+                          (samp + 1, gi < nx - 1, -1.0), (samp + nx, gj < ny - 1, -1.0)):
+        term = np.float32(coef) * xs(np.where(ok, col, 0))
+        want = np.where(ok, want + term, want).astype(np.float32)
+    verified = bool(np.array_equal(y.v[torch.from_numpy(samp).cuda()].cpu().numpy(), want))
+    from benchmarks.extra_workloads import warm_up
+    w_run = warm_up(job, step, warmup)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(steps):
+        step()
+    ev1.record()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    launch_ms = ev0.elapsed_time(ev1) / steps
+    b_alg = nnz * 8 + (n + 1) * 4 + 4 * n + 4 * A.ncols_compressed
+    rec = {"workload": f"poisson2d 5-pt {N}x{N}, CSR SpMV y=A*x, Float32 values, index=i32",
+           "steps": steps, "warmup": w_run, "ms_per_step": round(ms, 5), "gflops": round(2.0 * nnz / (ms * 1e-3) / 1e9, 2),
+           "dtype": "f32",
+           "roofline": {"bound": "hbm", "achieved": round(b_alg / (launch_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(b_alg / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                        "traffic_source": "no PMC pass was taken of the Float32 kernel (secondary element type; Float64 is the graded one)",
+                        "kernel": "hpcla::rowgather_f32_kernel<int, false, 1>", "algorithmic_bytes_per_launch": b_alg,
+                        "launch_ms_timed_region": round(launch_ms, 5)},
+           "verified_vs_closed_form": verified}
+    A = x = y = None
+    hp.clear_plan_cache()
+    torch.cuda.empty_cache()
+    return rec, verified
+
+
 def _run(args, budget):
     import torch
     import torch.distributed as dist
@@ -865,6 +929,15 @@ def _run(args, budget):
             else:
                 extras["int64"] = dict(SKIPPED)
             stage("int64 sub-record done")
+            if budget.allows("float32"):
+                try:
+                    extras["float32"], ok = float32_record(hp, wl, job, args, N, min(args.steps, 50), min(args.warmup, 10))
+                    verified = verified and ok
+                except Exception as exc:
+                    extras["float32"] = {"error": f"{type(exc).__name__}: {exc}"}
+            else:
+                extras["float32"] = dict(SKIPPED)
+            stage("float32 sub-record done")
         todo = [("poisson3d_cg", "poisson3d_cg", 100, 0), ("sprand_spmm", "sprand_spmm", 10, max(1, 8 // world)),
                 ("poisson2d_spmm", "poisson2d_spmm", 20, 0)]
         if world == 1:

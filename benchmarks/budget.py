@@ -24,6 +24,7 @@ ESTIMATE_S = {
     "strong_scaling_4096": 15.0,      # the 4096^2 headline matrix strong-scaled (the other reading of ">= 6x at 8 GPUs")
     "strong_scaling_4096_n1": 12.0,   # ... and on rank 0 alone
     "int64": 20.0,
+    "float32": 15.0,                  # the headline matrix on a Float32 backend (csrc/f32.hip)
     "poisson3d_cg": 30.0,
     "poisson2d_spmm": 20.0,
     "sprand_spmm": 35.0,

@@ -215,12 +215,14 @@ function _device_plan(A::HPCSparseMatrix{T,Ti,B}, x::HPCVector{T,B}, plan) where
         if !isempty(plan.send_rank_ids) || !isempty(plan.recv_rank_ids)
             send_idx = ROCVector(Tk.(reduce(vcat, plan.send_indices; init=Ti[]) .- one(Ti)))   # 0-based, the kernels' type
             AMDGPU.synchronize()
-            _check(@ccall(LIB.hpcla_halo_plan_create(halo::Ptr{Ptr{Cvoid}}, _rccl(A.backend.comm)::Ptr{Cvoid},
+            # Float32 plans (csrc/f32.hip) are driven through hpcla_halo_begin_f32 / hpcla_halo_end with the ghost pointer
+            # taken from the host in between: one ghost buffer (flags = HPCLA_HALO_SINGLE_BUFFER), a constant of the plan
+            _check(@ccall(LIB.hpcla_halo_plan_create_ex(halo::Ptr{Ptr{Cvoid}}, _rccl(A.backend.comm)::Ptr{Cvoid},
                    length(plan.send_rank_ids)::Cint, Int32.(plan.send_rank_ids)::Ptr{Int32},
                    Int64.(length.(plan.send_indices))::Ptr{Int64}, _ptr(send_idx)::Ptr{Cvoid},
                    (Tk === Int64 ? 1 : 0)::Cint, length(plan.recv_rank_ids)::Cint,
                    Int32.(plan.recv_rank_ids)::Ptr{Int32}, Int64.(length.(plan.recv_perm))::Ptr{Int64},
-                   1::Cint)::Cint), "hpcla_halo_plan_create")
+                   1::Cint, (T === Float32 ? 1 : 0)::Cint)::Cint), "hpcla_halo_plan_create_ex")
             rpb = @ccall LIB.hpcla_spmv_rows_per_block()::Cint
             flags = AMDGPU.zeros(Int32, cld(A.nrows_local, rpb))
             # `split` is 0-based (hpcla_remap output) while A.rowptr_target is 1-based: the classifier applies
@@ -246,7 +248,7 @@ function _device_plan(A::HPCSparseMatrix{T,Ti,B}, x::HPCVector{T,B}, plan) where
         # the split-column SpMV into a scratch vector; the library keeps the fastest order registered for the rowptr
         # array the launches use -- the plan's 0-based copy).  No reference counterpart: a performance setting only,
         # every order gives the same bits.
-        if A.nrows_local > 0 && nnz > 0
+        if T === Float64 && A.nrows_local > 0 && nnz > 0
             scratch = similar(A.nzval, A.nrows_local)
             gh = Ref{Ptr{Cvoid}}(C_NULL); ngh = Ref{Int64}(0)
             halo[] != C_NULL &&
@@ -550,6 +552,139 @@ function Base.:*(A::HPCSparseMatrix{T,Ti,B}, M::HPCMatrix{T,B}) where {T<:Float6
     return HPCLinearAlgebra.HPCMatrix_local(C, A.backend)
 end
 
+# ==== Float32 backends (csrc/f32.hip) ====================================================================================
+# The parent is generic in T and its GPU test configurations run Float32 as well as Float64 (test/test_utils.jl:62-80).
+# The methods above are Float64's; these give a Float32 backend the same path instead of the parent's host-staged one:
+# A*x, mul!, A*B with a dense B, dot, norm (p = 1, 2, Inf), sum, maximum, minimum.  Row sums run in Float32 in stored order
+# (the bits of _spmv_kernel!, src/sparse.jl:2055-2066, with T = Float32); reductions are formed and all-reduced in double
+# and rounded to Float32 once.  Ghost values travel widened to Float64 (exact both ways), so every halo transport is the
+# Float64 one.  Everything else (CG pieces, transposes, sparse products and sums, repartition) keeps the parent's generic
+# methods for Float32.
+const _stage32 = IdDict{Any,Any}()      # device plan -> staging vector of its Float32 exchanges (ROCVector{Float64})
+_stage(d, n::Int) = (st = get(_stage32, d, nothing); (st === nothing || length(st) < n) ? (_stage32[d] = AMDGPU.zeros(Float64, max(n, 1))) : st)
+
+# y (nrows_local values at `yp`) = A * (x: n_own values at `xp`); both may point into a column of a Matrix
+function _spmv_f32!(yp::Ptr{Cvoid}, A::HPCSparseMatrix{Float32,Ti,B}, xp::Ptr{Cvoid}, d::ROCVectorPlan{Tk}) where {Ti,Tk,B<:ROCBackend}
+    rp0 = d.rowptr0; nnz = length(A.nzval); nb_all = Int64(0)
+    function launch(ghost::Ptr{Cvoid}, blocks, nblocks::Int64)
+        if Tk === Int32
+            _check(@ccall(LIB.hpcla_spmv_split_f32_i32(_ptr(rp0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
+                   _ptr(A.nzval)::Ptr{Cvoid}, xp::Ptr{Cvoid}, ghost::Ptr{Cvoid}, d.n_own::Int64, yp::Ptr{Cvoid},
+                   A.nrows_local::Int64, nnz::Int64, 0::Cint, blocks::Ptr{Cvoid}, nblocks::Int64,
+                   _stream()::Ptr{Cvoid})::Cint), "hpcla_spmv_split_f32_i32")
+        else
+            _check(@ccall(LIB.hpcla_spmv_split_f32_i64(_ptr(rp0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
+                   _ptr(A.nzval)::Ptr{Cvoid}, xp::Ptr{Cvoid}, ghost::Ptr{Cvoid}, d.n_own::Int64, yp::Ptr{Cvoid},
+                   A.nrows_local::Int64, nnz::Int64, 0::Cint, blocks::Ptr{Cvoid}, nblocks::Int64,
+                   _stream()::Ptr{Cvoid})::Cint), "hpcla_spmv_split_f32_i64")
+        end
+    end
+    if d.halo == C_NULL
+        launch(C_NULL, C_NULL, nb_all)                           # no neighbours: every row block, no ghost segment
+        return
+    end
+    _check(@ccall(LIB.hpcla_halo_begin_f32(d.halo::Ptr{Cvoid}, xp::Ptr{Cvoid}, _ptr(_stage(d, d.n_own))::Ptr{Cvoid},
+           _stream()::Ptr{Cvoid})::Cint), "hpcla_halo_begin_f32")
+    isempty(d.interior) || launch(C_NULL, _ptr(d.interior), Int64(length(d.interior)))     # overlaps the exchange
+    _check(@ccall(LIB.hpcla_halo_end(d.halo::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_halo_end")
+    if !isempty(d.boundary)
+        gh = Ref{Ptr{Cvoid}}(C_NULL); ngh = Ref{Int64}(0)       # single-buffered plan: a constant, no device synchronisation
+        _check(@ccall(LIB.hpcla_halo_ghost_ptr(d.halo::Ptr{Cvoid}, gh::Ptr{Ptr{Cvoid}}, ngh::Ptr{Int64})::Cint), "hpcla_halo_ghost_ptr")
+        launch(gh[], _ptr(d.boundary), Int64(length(d.boundary)))
+    end
+    return
+end
+
+function _spmv_dist!(y::ROCVector{Float32}, A::HPCSparseMatrix{Float32,Ti,B}, x::HPCVector{Float32,B}) where {Ti,B<:ROCBackend}
+    plan = get_vector_plan(A, x)
+    _spmv_f32!(_ptr(y), A, _ptr(x.v), _device_plan(A, x, plan))
+    return plan
+end
+
+function Base.:*(A::HPCSparseMatrix{Float32,Ti,B}, x::HPCVector{Float32,B}) where {Ti,B<:ROCBackend}
+    assert_backends_compatible(A.backend, x.backend)
+    y_local = similar(A.nzval, A.nrows_local)
+    plan = _spmv_dist!(y_local, A, x)
+    if plan.result_partition_hash === nothing
+        plan.result_partition_hash = compute_partition_hash(A.row_partition)
+        plan.result_partition = copy(A.row_partition)
+    end
+    return HPCVector{Float32,B}(plan.result_partition_hash, plan.result_partition, y_local, A.backend)
+end
+
+function LinearAlgebra.mul!(y::HPCVector{Float32,B}, A::HPCSparseMatrix{Float32,Ti,B}, x::HPCVector{Float32,B}) where {Ti,B<:ROCBackend}
+    _spmv_dist!(y.v, A, x)
+    return y
+end
+
+# A * B, B::HPCMatrix (src/sparse.jl:2391-2413).  Without neighbours: ONE pass over A for all k columns, on Julia's
+# column-major arrays as they are (hpcla_spmm_csr_f32_*, HPCLA_LAYOUT_COL).  With neighbours: the reference's own column
+# loop, each column one distributed Float32 SpMV straight out of / into the column-major blocks (a column is contiguous).
+function Base.:*(A::HPCSparseMatrix{Float32,Ti,B}, M::HPCMatrix{Float32,B}) where {Ti,B<:ROCBackend}
+    assert_backends_compatible(A.backend, M.backend)
+    nloc, k = size(M.A)
+    probe = HPCVector{Float32,B}(compute_partition_hash(M.row_partition), M.row_partition, similar(A.nzval, nloc), A.backend)   # plan key only
+    plan = get_vector_plan(A, probe)
+    d = _device_plan(A, probe, plan)
+    C = AMDGPU.zeros(Float32, A.nrows_local, k)
+    nnz = length(A.nzval)
+    if d.halo == C_NULL
+        if eltype(d.rowptr0) === Int32
+            _check(@ccall(LIB.hpcla_spmm_csr_f32_i32(_ptr(d.rowptr0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
+                   _ptr(A.nzval)::Ptr{Cvoid}, _ptr(M.A)::Ptr{Cvoid}, max(nloc, 1)::Int64, 1::Cint, _ptr(C)::Ptr{Cvoid},
+                   max(A.nrows_local, 1)::Int64, 1::Cint, A.nrows_local::Int64, nnz::Int64, k::Cint, 0::Cint,
+                   _stream()::Ptr{Cvoid})::Cint), "hpcla_spmm_csr_f32_i32")
+        else
+            _check(@ccall(LIB.hpcla_spmm_csr_f32_i64(_ptr(d.rowptr0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
+                   _ptr(A.nzval)::Ptr{Cvoid}, _ptr(M.A)::Ptr{Cvoid}, max(nloc, 1)::Int64, 1::Cint, _ptr(C)::Ptr{Cvoid},
+                   max(A.nrows_local, 1)::Int64, 1::Cint, A.nrows_local::Int64, nnz::Int64, k::Cint, 0::Cint,
+                   _stream()::Ptr{Cvoid})::Cint), "hpcla_spmm_csr_f32_i64")
+        end
+    else
+        for c in 0:k-1
+            _spmv_f32!(_ptr(C) + c * A.nrows_local * sizeof(Float32), A, _ptr(M.A) + c * nloc * sizeof(Float32), d)
+        end
+    end
+    return HPCLinearAlgebra.HPCMatrix_local(C, A.backend)
+end
+
+function _reduce_f32(sym::Symbol, x::HPCVector{Float32}, y=nothing, negate::Int=0)
+    work, out = _scratch(); c = _rccl(x.backend.comm); n = length(x.v)
+    if sym === :dot
+        _check(@ccall(LIB.hpcla_dot_f32(c::Ptr{Cvoid}, _ptr(x.v)::Ptr{Cvoid}, _ptr(y.v)::Ptr{Cvoid}, n::Int64,
+               _ptr(out)::Ptr{Cvoid}, _ptr(work)::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_dot_f32")
+    elseif sym === :nrm2sq
+        _check(@ccall(LIB.hpcla_nrm2sq_f32(c::Ptr{Cvoid}, _ptr(x.v)::Ptr{Cvoid}, n::Int64, _ptr(out)::Ptr{Cvoid},
+               _ptr(work)::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_nrm2sq_f32")
+    elseif sym === :asum
+        _check(@ccall(LIB.hpcla_asum_f32(c::Ptr{Cvoid}, _ptr(x.v)::Ptr{Cvoid}, n::Int64, _ptr(out)::Ptr{Cvoid},
+               _ptr(work)::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_asum_f32")
+    elseif sym === :amax
+        _check(@ccall(LIB.hpcla_amax_f32(c::Ptr{Cvoid}, _ptr(x.v)::Ptr{Cvoid}, n::Int64, _ptr(out)::Ptr{Cvoid},
+               _ptr(work)::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_amax_f32")
+    elseif sym === :sum
+        _check(@ccall(LIB.hpcla_sum_f32(c::Ptr{Cvoid}, _ptr(x.v)::Ptr{Cvoid}, n::Int64, _ptr(out)::Ptr{Cvoid},
+               _ptr(work)::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_sum_f32")
+    else
+        _check(@ccall(LIB.hpcla_maxval_f32(c::Ptr{Cvoid}, _ptr(x.v)::Ptr{Cvoid}, n::Int64, negate::Cint, _ptr(out)::Ptr{Cvoid},
+               _ptr(work)::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_maxval_f32")
+    end
+    return _host_scalar(out, x.backend)              # a double; the callers round to Float32 once
+end
+function LinearAlgebra.dot(x::HPCVector{Float32,B}, y::HPCVector{Float32,B}) where {B<:ROCBackend}
+    x.structural_hash == y.structural_hash || (y = HPCLinearAlgebra.repartition(y, x.partition))
+    return Float32(_reduce_f32(:dot, x, y))
+end
+function LinearAlgebra.norm(v::HPCVector{Float32,B}, p::Real=2) where {B<:ROCBackend}
+    p == 2 && return Float32(sqrt(_reduce_f32(:nrm2sq, v)))
+    p == 1 && return Float32(_reduce_f32(:asum, v))
+    p == Inf && return Float32(_reduce_f32(:amax, v))
+    return invoke(LinearAlgebra.norm, Tuple{HPCVector,Real}, v, p)        # generic path of the parent
+end
+Base.sum(v::HPCVector{Float32,B}) where {B<:ROCBackend} = Float32(_reduce_f32(:sum, v))
+Base.maximum(v::HPCVector{Float32,B}) where {B<:ROCBackend} = Float32(_reduce_f32(:max, v, nothing, 0))
+Base.minimum(v::HPCVector{Float32,B}) where {B<:ROCBackend} = Float32(-_reduce_f32(:max, v, nothing, 1))
+
 # ---- execute_plan!(::VectorPlan, x) on the device  (replaces src/vectors.jl:394-463 for every OTHER caller of
 # the plan: vector operands with different partitions :870-876, dense A*x, ...; A*x above never needs `gathered`)
 # gathered[local_dst] = x[local_src] and gathered[recv_perm[i]] = what neighbour i sent, GPU to GPU; the CPU
@@ -608,7 +743,7 @@ function clear_rocm_plan_cache!()
     for d in values(_rocm_plans)    # the plans' rowptr copies carry the block-order hints: removed before the arrays go
         d isa ROCVectorPlan && @ccall LIB.hpcla_spmv_block_order_hint(_ptr(d.rowptr0)::Ptr{Cvoid}, 0::Cint)::Cint
     end
-    empty!(_rocm_plans); empty!(_spmm_plans); empty!(_rocm_exec); empty!(_merge_lists); empty!(_spmm_runs_cache)
+    empty!(_rocm_plans); empty!(_spmm_plans); empty!(_rocm_exec); empty!(_merge_lists); empty!(_spmm_runs_cache); empty!(_stage32)
     return nothing
 end
 

@@ -47,6 +47,21 @@ struct F32Operand {               // element (row j, column c) of a dense operan
     int64_t n_own;
 };
 
+// four consecutive columns of one row of a ROW-major operand (16-byte aligned: the callers check)
+template <bool SPLIT>
+__device__ __forceinline__ fvec<float, 4> f32_gather4(const F32Operand &b, int64_t col, int64_t coff)
+{
+    if (SPLIT && col >= b.n_own) {
+        const double *p = b.ghost + (col - b.n_own) * b.ghost_rs + coff;
+        const fvec<double, 2> lo = *reinterpret_cast<const fvec<double, 2> *>(p);
+        const fvec<double, 2> hi = *reinterpret_cast<const fvec<double, 2> *>(p + 2);
+        fvec<float, 4> r;
+        r.x = (float)lo.x; r.y = (float)lo.y; r.z = (float)hi.x; r.w = (float)hi.y;
+        return r;
+    }
+    return *reinterpret_cast<const fvec<float, 4> *>(b.own + col * b.own_rs + coff);
+}
+
 template <bool SPLIT>
 __device__ __forceinline__ float f32_gather(const F32Operand &b, int64_t col, int64_t coff_own, int64_t coff_ghost)
 {
@@ -181,21 +196,23 @@ __global__ __launch_bounds__(F_RPB) void rowgather_f32_kernel(
 // its own 32-byte piece of a different line (measured: 0.12 of peak on the 5-point matrix x 16, 1.55 ms against 0.39 ms
 // column-major).  The wave still owns 64 rows and stages their entries in LDS once; it walks them 64 / KL rows at a time,
 // the KL lanes of a row reading the row's (column, value) pairs from LDS as broadcasts.  Each (row, column) sum is one lane's
-// sequential sum in stored order: the reference's bits.
-template <typename I, bool SPLIT, int KL>
+// sequential sum in stored order: the reference's bits.  V = 4 (k a multiple of 4, 16-byte aligned operands): a lane owns four
+// consecutive columns and moves them as one 16-byte word -- k = 16 is 4 lanes per row, 16 rows per gather instruction, a
+// quarter of the steps (5-point matrix x 16: 0.60 -> see profiles/r04_float32.log).
+template <typename I, bool SPLIT, int KL, int V>
 __global__ __launch_bounds__(F_RPB) void rowmajor_f32_kernel(
     const I *__restrict__ rowptr, const I *__restrict__ colval, const float *__restrict__ nzval, F32Operand b,
     float *__restrict__ C, int64_t ldc, int64_t nrows, int64_t nnz, int base, int k,
     const int32_t *__restrict__ block_list, int vec_ok)
 {
-    constexpr int UR = 4, RPS = 64 / KL;                                 // rows per step of a wave
+    constexpr int UR = V == 4 ? 8 : 4, RPS = 64 / KL;                    // rows per step of a wave
     __shared__ __attribute__((aligned(16))) I s_col_all[(F_RPB / 64) * F_CHW];
     __shared__ __attribute__((aligned(16))) float s_val_all[(F_RPB / 64) * F_CHW];
 
     const int tid = threadIdx.x;
     const int64_t blk = block_list ? (int64_t)block_list[blockIdx.x] : (int64_t)blockIdx.x;
-    const int c0 = (int)blockIdx.y * KL;
-    const int kc = k - c0 < KL ? k - c0 : KL;
+    const int c0 = (int)blockIdx.y * KL * V;
+    const int kc = k - c0 < KL * V ? k - c0 : KL * V;
     const int64_t r0 = blk * F_RPB;
     const int nr = (int)((nrows - r0) < F_RPB ? (nrows - r0) : F_RPB);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -204,7 +221,7 @@ __global__ __launch_bounds__(F_RPB) void rowmajor_f32_kernel(
     const int64_t rw = r0 + wave * 64;
     const int nrw = nr - wave * 64 < 0 ? 0 : (nr - wave * 64 > 64 ? 64 : nr - wave * 64);
     if (nrw <= 0) return;
-    const int q = lane % KL, sub = lane / KL;
+    const int q = (lane % KL) * V, sub = lane / KL;                     // q: this lane's first column within the group
     const int64_t p0 = (int64_t)rowptr[rw] - base;
     const int64_t p1 = (int64_t)rowptr[rw + nrw] - base;
     const int64_t pa = vec_ok ? (p0 & ~(int64_t)3) : p0;
@@ -214,7 +231,10 @@ __global__ __launch_bounds__(F_RPB) void rowmajor_f32_kernel(
     if (total == 0) {                                                    // a wave of empty rows: no pass would write them
         for (int g = 0; g < KL; ++g) {
             const int row = g * RPS + sub;
-            if (row < nrw && q < kc) C[(rw + row) * ldc + c0 + q] = 0.0f;
+            if (row < nrw && q < kc) {
+#pragma unroll
+                for (int t = 0; t < V; ++t) C[(rw + row) * ldc + c0 + q + t] = 0.0f;
+            }
         }
         return;
     }
@@ -258,11 +278,20 @@ __global__ __launch_bounds__(F_RPB) void rowmajor_f32_kernel(
             // only waves with more than one pass -- more than 464 entries in 64 rows -- pay for it
             float *cp = C + (rw + row) * ldc + c0 + q;
             const bool has = j < e;                                       // the row has entries in this pass
-            float acc = 0.0f;
-            if (has && c > 0 && lo64 < 0) acc = *cp;
+            float acc[V];
+#pragma unroll
+            for (int t = 0; t < V; ++t) acc[t] = 0.0f;
+            if (has && c > 0 && lo64 < 0) {
+                if (V == 4) {
+                    const fvec<float, 4> cv = *reinterpret_cast<const fvec<float, 4> *>(cp);
+                    acc[0] = cv.x; acc[1 % V] = cv.y; acc[2 % V] = cv.z; acc[3 % V] = cv.w;
+                } else {
+                    acc[0] = *cp;
+                }
+            }
             for (; j < e; j += UR) {
                 int64_t cc[UR];
-                float vv[UR], xx[UR];
+                float vv[UR], xx[UR][V];
 #pragma unroll
                 for (int u = 0; u < UR; ++u) {
                     cc[u] = 0; vv[u] = 0.0f;
@@ -270,15 +299,35 @@ __global__ __launch_bounds__(F_RPB) void rowmajor_f32_kernel(
                 }
 #pragma unroll
                 for (int u = 0; u < UR; ++u) {
-                    xx[u] = 0.0f;
-                    if (j + u < e) xx[u] = f32_gather<SPLIT>(b, cc[u], c0 + q, c0 + q);
+#pragma unroll
+                    for (int t = 0; t < V; ++t) xx[u][t] = 0.0f;
+                    if (j + u < e) {
+                        if (V == 4) {
+                            const fvec<float, 4> g4 = f32_gather4<SPLIT>(b, cc[u], c0 + q);
+                            xx[u][0] = g4.x; xx[u][1 % V] = g4.y; xx[u][2 % V] = g4.z; xx[u][3 % V] = g4.w;
+                        } else {
+                            xx[u][0] = f32_gather<SPLIT>(b, cc[u], c0 + q, c0 + q);
+                        }
+                    }
                 }
 #pragma unroll
-                for (int u = 0; u < UR; ++u) if (j + u < e) acc += vv[u] * xx[u];
+                for (int u = 0; u < UR; ++u)
+                    if (j + u < e) {
+#pragma unroll
+                        for (int t = 0; t < V; ++t) acc[t] += vv[u] * xx[u][t];
+                    }
             }
             // the first pass gives every row its initial value (0 for rows that start later or are empty), later passes
             // write the rows they touch: a row's last touching pass leaves its final sum
-            if (live && (c == 0 || has)) *cp = acc;
+            if (live && (c == 0 || has)) {
+                if (V == 4) {
+                    fvec<float, 4> cv;
+                    cv.x = acc[0]; cv.y = acc[1 % V]; cv.z = acc[2 % V]; cv.w = acc[3 % V];
+                    *reinterpret_cast<fvec<float, 4> *>(cp) = cv;
+                } else {
+                    *cp = acc[0];
+                }
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -316,26 +365,42 @@ static int f32_launch(const I *rowptr, const I *colval, const float *nzval, cons
             rowgather_f32_kernel<I, false, 1><<<grid, block, 0, s>>>(rowptr, colval, nzval, b, C, 1, 0, nrows, nnz, index_base, 1,
                                                                     block_list, vec_ok, c_rs == 1);
     } else if (b.own_cs == 1 && c_cs == 1 && (!split || b.ghost_cs == 1)) {
-        // row-major operands: KL lanes per row, KL = the power of two >= k (at most 64 columns per workgroup)
-        const int kl = k <= 4 ? 4 : (k <= 8 ? 8 : (k <= 16 ? 16 : (k <= 32 ? 32 : 64)));
-        const int groups = (k + kl - 1) / kl;
+        // row-major operands.  k a multiple of 4 and everything 16-byte aligned: a lane owns 4 columns (V = 4), KL = the power
+        // of two >= k / 4 lanes per row (at most 64 columns per workgroup); else one column per lane, KL = the power of two >= k
+        const bool v4 = k % 4 == 0 && b.own_rs % 4 == 0 && c_rs % 4 == 0 && reinterpret_cast<uintptr_t>(b.own) % 16 == 0 &&
+                        reinterpret_cast<uintptr_t>(C) % 16 == 0 &&
+                        (!split || (b.ghost_rs % 2 == 0 && reinterpret_cast<uintptr_t>(b.ghost) % 16 == 0));
+        const int kq = v4 ? k / 4 : k;
+        const int kl = v4 ? (kq <= 1 ? 1 : (kq <= 2 ? 2 : (kq <= 4 ? 4 : (kq <= 8 ? 8 : 16))))
+                          : (kq <= 4 ? 4 : (kq <= 8 ? 8 : (kq <= 16 ? 16 : (kq <= 32 ? 32 : 64))));
+        const int groups = (kq + kl - 1) / kl;
         if (groups > 65535) return set_error(HPCLA_ERR_UNSUPPORTED, "%s: more than %d columns", who, 65535 * 64);
         dim3 grid((uint32_t)launch_blocks, (uint32_t)groups), block(F_RPB);
-#define HPCLA_F32_ROWMAJOR(KL)                                                                                              \
+#define HPCLA_F32_ROWMAJOR(KL, V)                                                                                           \
     do {                                                                                                                    \
         if (split)                                                                                                          \
-            rowmajor_f32_kernel<I, true, KL><<<grid, block, 0, s>>>(rowptr, colval, nzval, b, C, c_rs, nrows, nnz, index_base, k, \
-                                                                   block_list, vec_ok);                                     \
+            rowmajor_f32_kernel<I, true, KL, V><<<grid, block, 0, s>>>(rowptr, colval, nzval, b, C, c_rs, nrows, nnz, index_base, \
+                                                                      k, block_list, vec_ok);                               \
         else                                                                                                                \
-            rowmajor_f32_kernel<I, false, KL><<<grid, block, 0, s>>>(rowptr, colval, nzval, b, C, c_rs, nrows, nnz, index_base, \
-                                                                    k, block_list, vec_ok);                                 \
+            rowmajor_f32_kernel<I, false, KL, V><<<grid, block, 0, s>>>(rowptr, colval, nzval, b, C, c_rs, nrows, nnz,      \
+                                                                       index_base, k, block_list, vec_ok);                  \
     } while (0)
-        switch (kl) {
-        case 4: HPCLA_F32_ROWMAJOR(4); break;
-        case 8: HPCLA_F32_ROWMAJOR(8); break;
-        case 16: HPCLA_F32_ROWMAJOR(16); break;
-        case 32: HPCLA_F32_ROWMAJOR(32); break;
-        default: HPCLA_F32_ROWMAJOR(64); break;
+        if (v4) {
+            switch (kl) {
+            case 1: HPCLA_F32_ROWMAJOR(1, 4); break;
+            case 2: HPCLA_F32_ROWMAJOR(2, 4); break;
+            case 4: HPCLA_F32_ROWMAJOR(4, 4); break;
+            case 8: HPCLA_F32_ROWMAJOR(8, 4); break;
+            default: HPCLA_F32_ROWMAJOR(16, 4); break;
+            }
+        } else {
+            switch (kl) {
+            case 4: HPCLA_F32_ROWMAJOR(4, 1); break;
+            case 8: HPCLA_F32_ROWMAJOR(8, 1); break;
+            case 16: HPCLA_F32_ROWMAJOR(16, 1); break;
+            case 32: HPCLA_F32_ROWMAJOR(32, 1); break;
+            default: HPCLA_F32_ROWMAJOR(64, 1); break;
+            }
         }
 #undef HPCLA_F32_ROWMAJOR
     } else if (k <= 8) {

@@ -913,7 +913,8 @@ def HPCSparseMatrix_local_device(rowptr_dev, colidx_global_dev, vals_dev, ncols_
                dptr(colidx_global_dev), nnz, lo, window, dptr(colval_dev), 0, dptr(col_indices_dev),
                ctypes.byref(ncomp), dptr(work), current_stream_ptr())
     col_indices = col_indices_dev[:ncomp.value].cpu().numpy()
-    A = HPCSparseMatrix(row_partition, col_partition, col_indices, None, None, vals_dev,
+    from .vectors import torch_dtype_of
+    A = HPCSparseMatrix(row_partition, col_partition, col_indices, None, None, vals_dev.to(torch_dtype_of(backend)),
                         rowptr_dev.to(tdt), backend)
     A._colval_target = colval_dev
     A._col_indices_dev = col_indices_dev[:ncomp.value]

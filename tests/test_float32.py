@@ -254,20 +254,29 @@ def test_spmm_f32_long_and_empty_rows(hp, orc, layout, k):
 
 
 @pytest.mark.gpu
-def test_spmm_split_f32_with_widened_ghost_rows(hp, orc):
+@pytest.mark.parametrize("k,ldb,ldg,ldc", [(16, 16, 16, 16), (16, 20, 18, 24), (16, 17, 16, 16), (12, 12, 12, 12), (6, 6, 7, 6)])
+def test_spmm_split_f32_with_widened_ghost_rows(hp, orc, k, ldb, ldg, ldc):
+    """Row-major operands with their own leading dimensions: multiples of 4 (2 for the double ghosts) take the kernel's
+    four-columns-per-lane form, anything else the one-column-per-lane form; padding columns stay untouched."""
     import torch
-    n, n_own, k = 2000, 1300, 16
+    n, n_own = 2000, 1300
     rows = orc.sprand_rows(n, 0.005, 0, n)
     rng = np.random.default_rng(11)
     B = rng.random((n, k)).astype(F32)
     want = orc.spmm(rows.rowptr.astype(np.int32), rows.colidx.astype(np.int32), rows.vals.astype(F32), B)
     rp, cv, nz = _t(rows.rowptr.astype(np.int32)), _t(rows.colidx.astype(np.int32)), _t(rows.vals.astype(F32))
-    B_own, B_ghost = _t(B[:n_own]), _t(B[n_own:].astype(np.float64))
-    C = torch.full((n, k), float("nan"), dtype=torch.float32, device="cuda")
-    hp._capi.call("hpcla_spmm_split_f32_i32", rp.data_ptr(), cv.data_ptr(), nz.data_ptr(), B_own.data_ptr(), k,
-                  B_ghost.data_ptr(), k, n_own, C.data_ptr(), k, n, len(rows.vals), k, 0, 0, 0, _stream())
+    Bo = np.full((n_own, ldb), np.nan, F32)
+    Bo[:, :k] = B[:n_own]
+    Bg = np.full((n - n_own, ldg), np.nan, np.float64)
+    Bg[:, :k] = B[n_own:]
+    B_own, B_ghost = _t(Bo), _t(Bg)
+    C = torch.full((n, ldc), float("nan"), dtype=torch.float32, device="cuda")
+    hp._capi.call("hpcla_spmm_split_f32_i32", rp.data_ptr(), cv.data_ptr(), nz.data_ptr(), B_own.data_ptr(), ldb,
+                  B_ghost.data_ptr(), ldg, n_own, C.data_ptr(), ldc, n, len(rows.vals), k, 0, 0, 0, _stream())
     torch.cuda.synchronize()
-    np.testing.assert_array_equal(C.cpu().numpy(), want)
+    got = C.cpu().numpy()
+    np.testing.assert_array_equal(got[:, :k], want)
+    assert np.all(np.isnan(got[:, k:]))
 
 
 @pytest.mark.gpu
