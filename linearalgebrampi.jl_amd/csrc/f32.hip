@@ -198,7 +198,8 @@ __global__ __launch_bounds__(F_RPB) void rowgather_f32_kernel(
 // the KL lanes of a row reading the row's (column, value) pairs from LDS as broadcasts.  Each (row, column) sum is one lane's
 // sequential sum in stored order: the reference's bits.  V = 4 (k a multiple of 4, 16-byte aligned operands): a lane owns four
 // consecutive columns and moves them as one 16-byte word -- k = 16 is 4 lanes per row, 16 rows per gather instruction, a
-// quarter of the steps (5-point matrix x 16: 0.60 -> see profiles/r04_float32.log).
+// quarter of the steps (5-point matrix x 16: 0.595 ms with one column per lane, 0.285 ms = 0.63 of peak with four,
+// profiles/r04_float32.log).
 template <typename I, bool SPLIT, int KL, int V>
 __global__ __launch_bounds__(F_RPB) void rowmajor_f32_kernel(
     const I *__restrict__ rowptr, const I *__restrict__ colval, const float *__restrict__ nzval, F32Operand b,
