@@ -233,6 +233,39 @@ int main(int argc, char **argv)
         HIPCHECK(hipFree(yn)); HIPCHECK(hipFree(yo));
         printf("block-order hint: same bits under groups of 4\n");
     }
+    /* Float32 element type (csrc/f32.hip): the same matrix with float values, against the same loop in float */
+    {
+        float *h_vf = (float *)malloc(nnz * 4), *h_xf = (float *)malloc(n * 4), *h_yf = (float *)malloc(n * 4);
+        for (int64_t j = 0; j < nnz; ++j) h_vf[j] = (float)h_val[j];
+        for (int64_t r = 0; r < n; ++r) h_xf[r] = (float)h_x[r];
+        float *vf, *xf, *yf;
+        double *dscal;
+        HIPCHECK(hipMalloc((void **)&vf, nnz * 4));
+        HIPCHECK(hipMalloc((void **)&xf, n * 4));
+        HIPCHECK(hipMalloc((void **)&yf, n * 4));
+        HIPCHECK(hipMalloc((void **)&dscal, 8));
+        HIPCHECK(hipMemcpy(vf, h_vf, nnz * 4, hipMemcpyHostToDevice));
+        HIPCHECK(hipMemcpy(xf, h_xf, n * 4, hipMemcpyHostToDevice));
+        CHECK(hpcla_spmv_csr_f32_i32(rowptr, colval, vf, xf, yf, n, nnz, 0, NULL));
+        CHECK(hpcla_dot_f32(comm, xf, yf, n, dscal, rwork, NULL));
+        HIPCHECK(hipDeviceSynchronize());
+        HIPCHECK(hipMemcpy(h_yf, yf, n * 4, hipMemcpyDeviceToHost));
+        int64_t badf = 0;
+        double dotf_ref = 0.0, dotf = 0.0;
+        for (int64_t r = 0; r < n; ++r) {
+            volatile float acc = 0.0f;                     /* volatile: no contraction, no wider intermediate */
+            for (int64_t j = h_rp[r]; j < h_rp[r + 1]; ++j) { volatile float prod = h_vf[j] * h_xf[h_col[j]]; acc = acc + prod; }
+            float a = acc;
+            if (memcmp(&a, &h_yf[r], 4) != 0) ++badf;
+            dotf_ref += (double)h_xf[r] * (double)a;
+        }
+        HIPCHECK(hipMemcpy(&dotf, dscal, 8, hipMemcpyDeviceToHost));
+        if (badf) { fprintf(stderr, "Float32 SpMV mismatch in %lld rows\n", (long long)badf); return 1; }
+        if (fabs(dotf - dotf_ref) > 1e-12 * fabs(dotf_ref) + 1e-9) { fprintf(stderr, "dot_f32 %g vs %g\n", dotf, dotf_ref); return 1; }
+        free(h_vf); free(h_xf); free(h_yf);
+        HIPCHECK(hipFree(vf)); HIPCHECK(hipFree(xf)); HIPCHECK(hipFree(yf)); HIPCHECK(hipFree(dscal));
+        printf("Float32: SpMV bit-identical to the scalar float loop, dot formed in double\n");
+    }
     if (hpcla_spmv_csr_f64_i32(NULL, NULL, NULL, NULL, NULL, 5, 5, 0, NULL) != HPCLA_ERR_INVALID ||
         strlen(hpcla_last_error()) == 0) { fprintf(stderr, "error convention broken\n"); return 1; }
     CHECK(hpcla_comm_destroy(comm));
