@@ -22,6 +22,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--nx", type=int, default=4096)
     ap.add_argument("--reps", type=int, default=200)
+    ap.add_argument("--only", default="", help="spmv2d | spmv3d | spmm: run one case (profiler passes)")
+    ap.add_argument("--settle-ms", type=float, default=250.0, help="warm-up time before each timed loop (0 under a profiler)")
+    ap.add_argument("--no-f64", action="store_true", help="skip the Float64 twins")
     args = ap.parse_args()
     import torch
     import hpcla_amd as hp
@@ -48,7 +51,9 @@ def main():
         return n, nnz, rp.int(), cv.int(), nz
 
     def timed(fn, reps):
-        t_end = time.time() + 0.25                     # settled clocks (the launch itself decides how many warm-ups that is)
+        for _ in range(3):
+            fn()
+        t_end = time.time() + args.settle_ms * 1e-3    # settled clocks (the launch itself decides how many warm-ups that is)
         while time.time() < t_end:
             for _ in range(20):
                 fn()
@@ -65,22 +70,30 @@ def main():
         print(f"{tag:44s} {ms:8.4f} ms  {nbytes / ms / 1e6:8.1f} GB/s  {nbytes / ms / 1e6 / 8000:6.3f} of 8 TB/s  "
               f"{flops / ms / 1e6:8.1f} GFLOP/s", flush=True)
 
-    cases = [("poisson2d %d^2" % args.nx, gen2d(args.nx, args.nx)), ("poisson3d 512x512x64", gen3d(512, 512, 64))]
+    cases = []
+    if args.only in ("", "spmv2d"):
+        cases.append(("poisson2d %d^2" % args.nx, gen2d(args.nx, args.nx)))
+    if args.only in ("", "spmv3d"):
+        cases.append(("poisson3d 512x512x64", gen3d(512, 512, 64)))
     for name, (n, nnz, rp, cv, nz64) in cases:
         nz32 = nz64.float()
         x64 = torch.rand(n, dtype=torch.float64, device=dev)
         x32 = x64.float()
         y64 = torch.empty(n, dtype=torch.float64, device=dev)
         y32 = torch.empty(n, dtype=torch.float32, device=dev)
-        ms = timed(lambda: hp._capi.call("hpcla_spmv_csr_f64_i32", rp.data_ptr(), cv.data_ptr(), nz64.data_ptr(), x64.data_ptr(),
-                                         y64.data_ptr(), n, nnz, 0, s), args.reps)
-        report(f"spmv f64 {name}", ms, nnz * 12 + (n + 1) * 4 + 16 * n, 2 * nnz)
+        hp._capi.call("hpcla_spmv_csr_f64_i32", rp.data_ptr(), cv.data_ptr(), nz64.data_ptr(), x64.data_ptr(), y64.data_ptr(), n, nnz, 0, s)
+        if not args.no_f64:
+            ms = timed(lambda: hp._capi.call("hpcla_spmv_csr_f64_i32", rp.data_ptr(), cv.data_ptr(), nz64.data_ptr(), x64.data_ptr(),
+                                             y64.data_ptr(), n, nnz, 0, s), args.reps)
+            report(f"spmv f64 {name}", ms, nnz * 12 + (n + 1) * 4 + 16 * n, 2 * nnz)
         ms = timed(lambda: hp._capi.call("hpcla_spmv_csr_f32_i32", rp.data_ptr(), cv.data_ptr(), nz32.data_ptr(), x32.data_ptr(),
                                          y32.data_ptr(), n, nnz, 0, s), args.reps)
         report(f"spmv f32 {name}", ms, nnz * 8 + (n + 1) * 4 + 8 * n, 2 * nnz)
         assert torch.allclose(y32.double(), y64, rtol=0, atol=1e-4 * 16)
         del x64, x32, y64, y32, nz32
 
+    if args.only not in ("", "spmm"):
+        return
     # SpMM: 5-point matrix x 16 columns (other_configs.poisson2d_spmm's share: nx x nx/2 rows)
     k = 16
     n, nnz, rp, cv, nz64 = gen2d(args.nx, args.nx // 2)
@@ -90,9 +103,12 @@ def main():
     C64 = torch.empty(n, k, dtype=torch.float64, device=dev)
     C32 = torch.empty(n, k, dtype=torch.float32, device=dev)
     row = hp._capi.LAYOUT_ROW
-    ms = timed(lambda: hp._capi.call("hpcla_spmm_csr_f64_i32", rp.data_ptr(), cv.data_ptr(), nz64.data_ptr(), B64.data_ptr(), k,
-                                     row, C64.data_ptr(), k, row, n, nnz, k, 0, s), max(args.reps // 4, 10))
-    report(f"spmm f64 k=16 row-major {args.nx}x{args.nx // 2}", ms, nnz * 12 + (n + 1) * 4 + 16 * k * n, 2 * k * nnz)
+    hp._capi.call("hpcla_spmm_csr_f64_i32", rp.data_ptr(), cv.data_ptr(), nz64.data_ptr(), B64.data_ptr(), k, row, C64.data_ptr(), k, row,
+                  n, nnz, k, 0, s)
+    if not args.no_f64:
+        ms = timed(lambda: hp._capi.call("hpcla_spmm_csr_f64_i32", rp.data_ptr(), cv.data_ptr(), nz64.data_ptr(), B64.data_ptr(), k,
+                                         row, C64.data_ptr(), k, row, n, nnz, k, 0, s), max(args.reps // 4, 10))
+        report(f"spmm f64 k=16 row-major {args.nx}x{args.nx // 2}", ms, nnz * 12 + (n + 1) * 4 + 16 * k * n, 2 * k * nnz)
     ms = timed(lambda: hp._capi.call("hpcla_spmm_csr_f32_i32", rp.data_ptr(), cv.data_ptr(), nz32.data_ptr(), B32.data_ptr(), k,
                                      row, C32.data_ptr(), k, row, n, nnz, k, 0, s), max(args.reps // 4, 10))
     report(f"spmm f32 k=16 row-major {args.nx}x{args.nx // 2}", ms, nnz * 8 + (n + 1) * 4 + 8 * k * n, 2 * k * nnz)

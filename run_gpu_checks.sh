@@ -58,6 +58,14 @@ for st in $STEPS; do
       unset HPCLA_BLOCK_ORDER HPCLA_SPMM_BLOCK_ORDER HPCLA_BENCH_SETTLE_MS
       # keep what is merged back small: only the counter CSVs and the stats
       find gpurun_out/${TAG}_p* -type f ! -name '*counter_collection.csv' ! -name '*kernel_stats.csv' ! -name '*kernel_trace.csv' ! -name '*.log' -delete;;
+    pmc_f32)       # HBM traffic of the Float32 kernels (csrc/f32.hip): separate FETCH_SIZE / WRITE_SIZE passes over the raw-ABI
+                   # microbenchmark; then: python benchmarks/pmc_f32_table.py TAG rNN
+      cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
+      for c in FETCH_SIZE WRITE_SIZE; do
+        run 300 gpurun_out/${TAG}_pmc_f32spmv_$c.log rocprofv3 --pmc $c --output-format csv -d gpurun_out/${TAG}_pmc_f32spmv_$c -- python3 benchmarks/bench_f32.py --only spmv2d --no-f64 --settle-ms 0 --reps 20
+        run 300 gpurun_out/${TAG}_pmc_f32spmm_$c.log rocprofv3 --pmc $c --output-format csv -d gpurun_out/${TAG}_pmc_f32spmm_$c -- python3 benchmarks/bench_f32.py --only spmm --no-f64 --settle-ms 0 --reps 40
+      done
+      find gpurun_out/${TAG}_pmc_f32* -type f ! -name '*counter_collection.csv' ! -name '*.log' -delete;;
     pmc_spmv_study)  # round 4: SQ / TCP / TA / UTCL1 counters of the SpMV kernel in five contexts (2-D, 2-D + dot, 3-D, 3-D + dot,
                    # inside CG), one pass per small counter set (a pass that asks for more than a block's slots aborts the
                    # profiler: gpurun_out/r03e_pmc_ta.log); then: python benchmarks/pmc_spmv_table.py TAG profiles/rNN_...txt
