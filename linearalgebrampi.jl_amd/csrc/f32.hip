@@ -69,6 +69,45 @@ __device__ __forceinline__ float f32_gather(const F32Operand &b, int64_t col, in
     return b.own[col * b.own_rs + coff_own];
 }
 
+// One pass of a WAVE: entries [at, at + n) of colval / nzval into the wave's own slice of LDS (n <= F_CHW).  Aligned arrays:
+// 16-byte loads, all of a lane's quads requested before the first LDS write (lanes past the end re-read the pass's last quad
+// -- lines their neighbours read anyway -- and write nothing); unaligned arrays, or the one pass of the launch that reaches
+// past their end: entry by entry.  LDS operations of one wave complete in order, so a wave-level fence is all the consumer
+// needs.
+template <typename I>
+__device__ __forceinline__ void stage_pass_f32(const I *__restrict__ colval, const float *__restrict__ nzval, I *s_col,
+                                               float *s_val, int64_t at, int n, int64_t nnz, int base, int lane, int vec_ok)
+{
+    if (vec_ok && at + ((n + 3) & ~3) <= nnz) {
+        const int last = (n - 1) & ~3;
+        fvec<I, 4> cq[F_NQ];
+        fvec<float, 4> vq[F_NQ];
+#pragma unroll
+        for (int u = 0; u < F_NQ; ++u) {
+            const int e0 = (u * 64 + lane) * 4;
+            const int ee = e0 < last ? e0 : last;
+            cq[u] = *reinterpret_cast<const fvec<I, 4> *>(colval + at + ee);
+            vq[u] = *reinterpret_cast<const fvec<float, 4> *>(nzval + at + ee);
+        }
+#pragma unroll
+        for (int u = 0; u < F_NQ; ++u) {
+            const int e0 = (u * 64 + lane) * 4;
+            if (e0 < n) {
+                *reinterpret_cast<fvec<I, 4> *>(&s_col[e0]) = cq[u];
+                *reinterpret_cast<fvec<float, 4> *>(&s_val[e0]) = vq[u];
+            }
+        }
+    } else {
+        for (int e = lane; e < n; e += 64) {
+            const int64_t g = at + e;
+            s_col[e] = g < nnz ? colval[g] : (I)base;
+            s_val[e] = g < nnz ? nzval[g] : 0.0f;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");               // this wave's LDS writes, then its LDS reads
+    __builtin_amdgcn_wave_barrier();
+}
+
 // KC = 1: y = A*x (strides of the operand ignored: unit).  KC > 1: up to KC columns [c0, c0 + kc) of C = A*B.
 template <typename I, bool SPLIT, int KC>
 __global__ __launch_bounds__(F_RPB) void rowgather_f32_kernel(
@@ -103,36 +142,7 @@ __global__ __launch_bounds__(F_RPB) void rowgather_f32_kernel(
     I rlo = rowptr[rw + ll], rhi = rowptr[rw + ll + 1];                  // unconditional; first used behind the A stream
     for (int64_t c = 0; c < total; c += F_CHW) {
         const int n = (int)((total - c) < F_CHW ? (total - c) : F_CHW);
-        if (vec_ok && pa + c + ((n + 3) & ~3) <= nnz) {
-            // every quad of the pass lies inside the arrays: all of a lane's quads are requested before the first LDS write
-            const int last = (n - 1) & ~3;
-            fvec<I, 4> cq[F_NQ];
-            fvec<float, 4> vq[F_NQ];
-#pragma unroll
-            for (int u = 0; u < F_NQ; ++u) {
-                const int e0 = (u * 64 + lane) * 4;
-                const int ee = e0 < last ? e0 : last;
-                cq[u] = *reinterpret_cast<const fvec<I, 4> *>(colval + pa + c + ee);
-                vq[u] = *reinterpret_cast<const fvec<float, 4> *>(nzval + pa + c + ee);
-            }
-#pragma unroll
-            for (int u = 0; u < F_NQ; ++u) {
-                const int e0 = (u * 64 + lane) * 4;
-                if (e0 < n) {
-                    *reinterpret_cast<fvec<I, 4> *>(&s_col[e0]) = cq[u];
-                    *reinterpret_cast<fvec<float, 4> *>(&s_val[e0]) = vq[u];
-                }
-            }
-        } else {
-            // unaligned arrays, or the one pass of the launch that reaches past their end: entry by entry
-            for (int e = lane; e < n; e += 64) {
-                const int64_t g = pa + c + e;
-                s_col[e] = g < nnz ? colval[g] : (I)base;
-                s_val[e] = g < nnz ? nzval[g] : 0.0f;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");           // this wave's LDS writes, then its LDS reads
-        __builtin_amdgcn_wave_barrier();
+        stage_pass_f32<I>(colval, nzval, s_col, s_val, pa + c, n, nnz, base, lane, vec_ok);
         asm volatile("" : "+v"(rlo), "+v"(rhi));                         // keeps the row bounds' first use behind the stream
         {
             const int lo = lane < nrw ? (int)((int64_t)rlo - base - pa - c) : 0;
@@ -241,34 +251,7 @@ __global__ __launch_bounds__(F_RPB) void rowmajor_f32_kernel(
     }
     for (int64_t c = 0; c < total; c += F_CHW) {
         const int n = (int)((total - c) < F_CHW ? (total - c) : F_CHW);
-        if (vec_ok && pa + c + ((n + 3) & ~3) <= nnz) {
-            const int last = (n - 1) & ~3;
-            fvec<I, 4> cq[F_NQ];
-            fvec<float, 4> vq[F_NQ];
-#pragma unroll
-            for (int u = 0; u < F_NQ; ++u) {
-                const int e0 = (u * 64 + lane) * 4;
-                const int ee = e0 < last ? e0 : last;
-                cq[u] = *reinterpret_cast<const fvec<I, 4> *>(colval + pa + c + ee);
-                vq[u] = *reinterpret_cast<const fvec<float, 4> *>(nzval + pa + c + ee);
-            }
-#pragma unroll
-            for (int u = 0; u < F_NQ; ++u) {
-                const int e0 = (u * 64 + lane) * 4;
-                if (e0 < n) {
-                    *reinterpret_cast<fvec<I, 4> *>(&s_col[e0]) = cq[u];
-                    *reinterpret_cast<fvec<float, 4> *>(&s_val[e0]) = vq[u];
-                }
-            }
-        } else {
-            for (int e = lane; e < n; e += 64) {
-                const int64_t g = pa + c + e;
-                s_col[e] = g < nnz ? colval[g] : (I)base;
-                s_val[e] = g < nnz ? nzval[g] : 0.0f;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        stage_pass_f32<I>(colval, nzval, s_col, s_val, pa + c, n, nnz, base, lane, vec_ok);
         for (int g = 0; g < KL; ++g) {                                   // step g: rows g * RPS + sub
             const int row = g * RPS + sub;                               // < 64
             const int64_t lo64 = __shfl(rlo_own, row, 64) - c, hi64 = __shfl(rhi_own, row, 64) - c;

@@ -54,6 +54,28 @@ int main(void)
     EXPECT_ERR(hpcla_spmv_split_f64_i32(i32buf, i32buf, f64buf, f64buf, NULL, 4, f64buf, 4, 4, 0, i32buf, -1, NULL));
     EXPECT_ERR(hpcla_spmv_split_f64_i64(i64buf, i64buf, f64buf, f64buf, NULL, 4, f64buf, 4, 4, 0, i32buf, 99, NULL));
 
+    /* the Float32 element type (csrc/f32.hip): the same checks in front of the same kind of launch */
+    {
+        float f32buf[8] = {0};
+        EXPECT_ERR(hpcla_spmv_csr_f32_i32(NULL, NULL, NULL, NULL, NULL, -1, 0, 0, NULL));
+        EXPECT_ERR(hpcla_spmv_csr_f32_i64(i64buf, i64buf, f32buf, f32buf, f32buf, 4, 4, 3, NULL));
+        EXPECT_ERR(hpcla_spmv_csr_f32_i32(i32buf, NULL, f32buf, f32buf, f32buf, 4, 4, 0, NULL));
+        EXPECT_OK(hpcla_spmv_csr_f32_i32(NULL, NULL, NULL, NULL, NULL, 0, 0, 0, NULL));
+        EXPECT_ERR(hpcla_spmv_split_f32_i32(i32buf, i32buf, f32buf, f32buf, NULL, -4, f32buf, 4, 4, 0, NULL, 0, NULL));
+        EXPECT_ERR(hpcla_spmv_split_f32_i64(i64buf, i64buf, f32buf, f32buf, f64buf, 4, f32buf, 4, 4, 0, i32buf, 99, NULL));
+        EXPECT_ERR(hpcla_spmm_csr_f32_i32(i32buf, i32buf, f32buf, f32buf, 4, 9, f32buf, 4, 0, 4, 4, 4, 0, NULL));
+        EXPECT_ERR(hpcla_spmm_csr_f32_i32(i32buf, i32buf, f32buf, f32buf, 2, 0, f32buf, 4, 0, 4, 4, 4, 0, NULL));
+        EXPECT_ERR(hpcla_spmm_split_f32_i64(i64buf, i64buf, f32buf, f32buf, 2, NULL, 4, 4, f32buf, 4, 4, 4, 4, 0, NULL, 0, NULL));
+        EXPECT_OK(hpcla_spmm_csr_f32_i64(NULL, NULL, NULL, NULL, 1, 0, NULL, 1, 0, 4, 0, 0, 0, NULL));
+        EXPECT_ERR(hpcla_halo_begin_f32(NULL, f32buf, f64buf, NULL));
+        EXPECT_ERR(hpcla_dot_f32(NULL, NULL, f32buf, 4, f64buf, f64buf, NULL));
+        EXPECT_ERR(hpcla_nrm2sq_f32(NULL, f32buf, -1, f64buf, f64buf, NULL));
+        EXPECT_ERR(hpcla_asum_f32(NULL, f32buf, 4, NULL, f64buf, NULL));
+        EXPECT_ERR(hpcla_axpby_f32(1.0f, NULL, 1.0f, f32buf, f32buf, 4, NULL));
+        EXPECT_ERR(hpcla_scale_f32(1.0f, f32buf, f32buf, -1, NULL));
+        EXPECT_OK(hpcla_divide_f32(NULL, 2.0f, NULL, 0, NULL));
+    }
+
     /* block order: pointer and group */
     EXPECT_ERR(hpcla_spmv_block_order_hint(NULL, 4));
     EXPECT_ERR(hpcla_spmv_block_order_hint(i32buf, 3));

@@ -421,3 +421,25 @@ def test_float32_backend_across_ranks(nranks):
     rc = spawn_ranks([os.path.join(ROOT, "tests", "_multirank_f32_worker.py")], nranks,
                      env_extra={"HPCLA_PUSH_TIMEOUT_S": "30"}, timeout=600, forward_rank0_stdout=False)
     assert rc == 0
+
+
+@pytest.mark.gpu
+def test_f32_golden_spmm_dot_norm_at_the_reference_tolerance(hp, golden, f32_backends):
+    """test/test_new_operations.jl:43-82, :139-147 and test/test_vector_multiplication.jl:163-195 as the reference runs them
+    over its CUDA x Float32 configuration: tolerance(Float32) = 1e-4 (test/test_utils.jl:156); exact where Float32 is."""
+    import scipy.sparse as sp
+    backend = f32_backends[np.int32]
+    TOL = 1e-4
+    case = golden["spmm_sym"]
+    A = sp.coo_matrix((case["V"], (np.array(case["I"]) - 1, np.array(case["J"]) - 1)), shape=(case["m"], case["n"])).tocsr()
+    C = hp.HPCSparseMatrix_from_global(A, backend) @ hp.HPCMatrix.from_global(np.array(case["B"]), backend)
+    got = C.A.cpu().numpy().astype(np.float64)
+    assert np.max(np.abs(got - np.array(case["C"]))) < TOL * max(1.0, np.max(np.abs(case["C"])))
+    assert abs(C.norm() - case["C_fro"]) < TOL * case["C_fro"]
+    d = golden["dot"]
+    x, y = hp.HPCVector.from_global(np.array(d["x"]), backend), hp.HPCVector.from_global(np.array(d["y"]), backend)
+    assert abs(hp.dot(x, y) - d["dot_xy"]) < TOL * abs(d["dot_xy"]) and abs(hp.dot(x, x) - d["dot_xx"]) < TOL * d["dot_xx"]
+    nr = golden["norms"]
+    v = hp.HPCVector.from_global(np.array(nr["x"]), backend)
+    assert abs(hp.norm(v) - nr["norm2"]) < TOL * nr["norm2"]
+    assert hp.norm(v, 1) == nr["norm1"] and hp.norm(v, np.inf) == nr["norminf"]      # 55 and 10: exact in Float32

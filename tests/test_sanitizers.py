@@ -25,6 +25,7 @@ def test_oracle_under_address_and_ub_sanitizers():
                ASAN_OPTIONS="detect_leaks=0:halt_on_error=1:abort_on_error=0",     # CPython itself leaks by design
                UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_oracle_golden.py"),
+                          os.path.join(ROOT, "tests", "test_float32.py"), "-m", "not gpu",      # ... and the Float32 loop's pins
                           "-x", "-q", "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True,
                          timeout=900)
     tail = out.stdout[-3000:] + out.stderr[-3000:]
