@@ -30,7 +30,10 @@ def main():
     dist.init_process_group("gloo")
     rank, nranks = dist.get_rank(), dist.get_world_size()
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", rank)) % torch.cuda.device_count())
-    for Ti in (np.int32, np.int64):
+    # HPCLA_MR_TYPES=i32,i64 (default both): the test file gives each rank count one index type (ranks that share a GPU
+    # time-slice it, so wall time grows with ranks x cases)
+    types = [t for t in os.environ.get("HPCLA_MR_TYPES", "i32,i64").split(",") if t]
+    for Ti in [np.int32 if t == "i32" else np.int64 for t in types]:
         backend = hp.backend_rocm_mpi(F32, Ti)
         comm = backend.comm
         tag = f"[f32 rank {rank}/{nranks} {np.dtype(Ti).name} windows={backend.peer_windows}]"

@@ -415,11 +415,13 @@ def test_f32_host_layer_products_reductions_and_refusals(hp, orc, f32_backends):
 @pytest.mark.gpu
 @pytest.mark.parametrize("nranks", [2, 3])
 def test_float32_backend_across_ranks(nranks):
-    """Real processes, real exchanges (peer-window push on a shared GPU): tests/_multirank_f32_worker.py."""
+    """Real processes, real exchanges (peer-window push on a shared GPU): tests/_multirank_f32_worker.py.  2 ranks: Int32
+    indices; 3 ranks: Int64 (the reference's default Ti, narrowed plans)."""
     from hpcla_amd.launch import spawn_ranks
     os.environ.pop("HPCLA_HALO_MODE", None)
     rc = spawn_ranks([os.path.join(ROOT, "tests", "_multirank_f32_worker.py")], nranks,
-                     env_extra={"HPCLA_PUSH_TIMEOUT_S": "30"}, timeout=600, forward_rank0_stdout=False)
+                     env_extra={"HPCLA_PUSH_TIMEOUT_S": "30", "HPCLA_MR_TYPES": "i32" if nranks == 2 else "i64"},
+                     timeout=600, forward_rank0_stdout=False)
     assert rc == 0
 
 
