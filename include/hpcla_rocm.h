@@ -691,6 +691,10 @@ int hpcla_sum_f32(hpcla_comm_t *comm, const float *x, int64_t n, double *out_dev
 int hpcla_maxval_f32(hpcla_comm_t *comm, const float *x, int64_t n, int negate, double *out_dev, void *work, void *stream);
 /* z = a*x + b*y, y = a*x, y = x / a in float (src/vectors.jl:868-903, 944-964), separate multiply and add; 16-byte
  * aligned operands. */
+/* layout conversion of a Float32 block (hpcla_transpose_f64's twin): column-major Julia Matrix <-> the library's row-major
+ * rows, whose ghost rows travel as contiguous k-value pieces in ONE exchange */
+int hpcla_transpose_f32(const float *src, int64_t ld_src, int src_layout, float *dst, int64_t ld_dst, int dst_layout,
+                        int64_t rows, int64_t cols, void *stream);
 int hpcla_axpby_f32(float a, const float *x, float b, const float *y, float *z, int64_t n, void *stream);
 int hpcla_scale_f32(float a, const float *x, float *y, int64_t n, void *stream);
 int hpcla_divide_f32(const float *x, float a, float *y, int64_t n, void *stream);

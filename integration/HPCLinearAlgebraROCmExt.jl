@@ -456,7 +456,8 @@ function _spmm_halo(A::HPCSparseMatrix{T,Ti,B}, plan, d::ROCVectorPlan{Tk}, k::I
         A.backend.comm isa CommMPI &&
             _attach_halo_window(_rccl(A.backend.comm), halo[], A.backend.comm.comm, comm_size(A.backend.comm),
                                 (d.n_own, d.segments))
-        rpb = @ccall LIB.hpcla_spmm_rows_per_block()::Cint          # SpMM row blocks are smaller than SpMV's
+        # SpMM row blocks are smaller than SpMV's; the Float32 product (csrc/f32.hip) runs on the SpMV's 256-row blocks
+        rpb = T === Float32 ? (@ccall LIB.hpcla_spmv_rows_per_block()::Cint) : (@ccall LIB.hpcla_spmm_rows_per_block()::Cint)
         flags = AMDGPU.zeros(Int32, cld(A.nrows_local, rpb))
         rp0 = d.rowptr0
         if Tk === Int32
@@ -617,9 +618,26 @@ function LinearAlgebra.mul!(y::HPCVector{Float32,B}, A::HPCSparseMatrix{Float32,
     return y
 end
 
-# A * B, B::HPCMatrix (src/sparse.jl:2391-2413).  Without neighbours: ONE pass over A for all k columns, on Julia's
-# column-major arrays as they are (hpcla_spmm_csr_f32_*, HPCLA_LAYOUT_COL).  With neighbours: the reference's own column
-# loop, each column one distributed Float32 SpMV straight out of / into the column-major blocks (a column is contiguous).
+# A * B, B::HPCMatrix (src/sparse.jl:2391-2413).  Without neighbours: ONE pass over A for all k columns on Julia's
+# column-major arrays as they are (hpcla_spmm_csr_f32_*, HPCLA_LAYOUT_COL).  With neighbours: like the Float64 product --
+# B converted once to row-major rows (hpcla_transpose_f32), whose ghost rows travel widened in ONE width-k exchange
+# (_spmm_halo's plan, hpcla_halo_begin_f32) that the interior blocks overlap; C converted back.
+function _spmm_split_f32!(Crow, A::HPCSparseMatrix{Float32,Ti,B}, d::ROCVectorPlan{Tk}, Brow, ghost::Ptr{Cvoid}, k::Int, blocks) where {Ti,Tk,B}
+    isempty(blocks) && return
+    nnz = length(A.nzval)
+    if Tk === Int32
+        _check(@ccall(LIB.hpcla_spmm_split_f32_i32(_ptr(d.rowptr0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
+               _ptr(A.nzval)::Ptr{Cvoid}, _ptr(Brow)::Ptr{Cvoid}, k::Int64, ghost::Ptr{Cvoid}, k::Int64, d.n_own::Int64,
+               _ptr(Crow)::Ptr{Cvoid}, k::Int64, A.nrows_local::Int64, nnz::Int64, k::Cint, 0::Cint,
+               _ptr(blocks)::Ptr{Cvoid}, length(blocks)::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_spmm_split_f32_i32")
+    else
+        _check(@ccall(LIB.hpcla_spmm_split_f32_i64(_ptr(d.rowptr0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
+               _ptr(A.nzval)::Ptr{Cvoid}, _ptr(Brow)::Ptr{Cvoid}, k::Int64, ghost::Ptr{Cvoid}, k::Int64, d.n_own::Int64,
+               _ptr(Crow)::Ptr{Cvoid}, k::Int64, A.nrows_local::Int64, nnz::Int64, k::Cint, 0::Cint,
+               _ptr(blocks)::Ptr{Cvoid}, length(blocks)::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_spmm_split_f32_i64")
+    end
+end
+
 function Base.:*(A::HPCSparseMatrix{Float32,Ti,B}, M::HPCMatrix{Float32,B}) where {Ti,B<:ROCBackend}
     assert_backends_compatible(A.backend, M.backend)
     nloc, k = size(M.A)
@@ -641,9 +659,18 @@ function Base.:*(A::HPCSparseMatrix{Float32,Ti,B}, M::HPCMatrix{Float32,B}) wher
                    _stream()::Ptr{Cvoid})::Cint), "hpcla_spmm_csr_f32_i64")
         end
     else
-        for c in 0:k-1
-            _spmv_f32!(_ptr(C) + c * A.nrows_local * sizeof(Float32), A, _ptr(M.A) + c * nloc * sizeof(Float32), d)
-        end
+        Brow = AMDGPU.zeros(Float32, k, nloc)                 # k x nloc column-major == nloc x k row-major
+        _check(@ccall(LIB.hpcla_transpose_f32(_ptr(M.A)::Ptr{Cvoid}, nloc::Int64, 1::Cint, _ptr(Brow)::Ptr{Cvoid}, k::Int64,
+               0::Cint, nloc::Int64, k::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_transpose_f32")
+        Crow = AMDGPU.zeros(Float32, k, A.nrows_local)
+        halo, interior, boundary, _, ghost = _spmm_halo(A, plan, d, k)
+        _check(@ccall(LIB.hpcla_halo_begin_f32(halo::Ptr{Cvoid}, _ptr(Brow)::Ptr{Cvoid}, _ptr(_stage(d, d.n_own * k))::Ptr{Cvoid},
+               _stream()::Ptr{Cvoid})::Cint), "hpcla_halo_begin_f32")
+        _spmm_split_f32!(Crow, A, d, Brow, C_NULL, k, interior)       # rows without ghost columns overlap the exchange
+        _check(@ccall(LIB.hpcla_halo_end(halo::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_halo_end")
+        _spmm_split_f32!(Crow, A, d, Brow, ghost, k, boundary)
+        _check(@ccall(LIB.hpcla_transpose_f32(_ptr(Crow)::Ptr{Cvoid}, k::Int64, 0::Cint, _ptr(C)::Ptr{Cvoid},
+               A.nrows_local::Int64, 1::Cint, A.nrows_local::Int64, k::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_transpose_f32")
     end
     return HPCLinearAlgebra.HPCMatrix_local(C, A.backend)
 end

@@ -172,6 +172,7 @@ _SIGNATURES = {
     "hpcla_spmm_split_f32_i32": [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _i64, _vp],
     "hpcla_spmm_split_f32_i64": [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _i64, _vp],
     "hpcla_halo_begin_f32": [_vp, _vp, _vp, _vp],
+    "hpcla_transpose_f32": [_vp, _i64, _i32, _vp, _i64, _i32, _i64, _i64, _vp],
     "hpcla_dot_f32": [_vp, _vp, _vp, _i64, _vp, _vp, _vp],
     "hpcla_nrm2sq_f32": [_vp, _vp, _i64, _vp, _vp, _vp],
     "hpcla_asum_f32": [_vp, _vp, _i64, _vp, _vp, _vp],

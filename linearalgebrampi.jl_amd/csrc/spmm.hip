@@ -625,12 +625,13 @@ __global__ __launch_bounds__(TPB_MM) void spmm_runs_build_kernel(const I *__rest
 }
 
 // tiled transpose / layout conversion: dst(i,c) = src(i,c), arbitrary (row,col) strides
-__global__ __launch_bounds__(256) void relayout_kernel(const double *__restrict__ src,
+template <typename T>
+__global__ __launch_bounds__(256) void relayout_kernel(const T *__restrict__ src,
                                                        int64_t s_rs, int64_t s_cs,
-                                                       double *__restrict__ dst, int64_t d_rs,
+                                                       T *__restrict__ dst, int64_t d_rs,
                                                        int64_t d_cs, int64_t rows, int64_t cols)
 {
-    __shared__ double tile[32][33];
+    __shared__ T tile[32][33];
     const int64_t tr = (int64_t)blockIdx.x * 32, tc = (int64_t)blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
     // read with the source's fast axis on tx
@@ -1072,18 +1073,36 @@ HPCLA_API int hpcla_spmm_panel_f64_i64(const int64_t *rowptr, const int64_t *col
                                 ldc, 1, nrows, nnz, k, index_base, nullptr, 0, stream, accumulate ? 1 : 0);
 }
 
-HPCLA_API int hpcla_transpose_f64(const double *src, int64_t ld_src, int src_layout, double *dst,
-                                  int64_t ld_dst, int dst_layout, int64_t rows, int64_t cols,
-                                  void *stream)
+template <typename T>
+static int transpose_impl(const T *src, int64_t ld_src, int src_layout, T *dst, int64_t ld_dst, int dst_layout,
+                          int64_t rows, int64_t cols, void *stream)
 {
     if (rows < 0 || cols < 0) return set_error(HPCLA_ERR_INVALID, "transpose: negative size");
     if (rows == 0 || cols == 0) return HPCLA_OK;
     if (!src || !dst) return set_error(HPCLA_ERR_INVALID, "transpose: null pointer");
+    if ((src_layout != HPCLA_LAYOUT_ROW && src_layout != HPCLA_LAYOUT_COL) ||
+        (dst_layout != HPCLA_LAYOUT_ROW && dst_layout != HPCLA_LAYOUT_COL))
+        return set_error(HPCLA_ERR_INVALID, "transpose: layout must be HPCLA_LAYOUT_ROW or HPCLA_LAYOUT_COL");
     int64_t srs, scs, drs, dcs;
     layout_strides(src_layout, ld_src, &srs, &scs);
     layout_strides(dst_layout, ld_dst, &drs, &dcs);
-    dim3 grid((uint32_t)((rows + 31) / 32), (uint32_t)((cols + 31) / 32));
-    relayout_kernel<<<grid, 256, 0, as_stream(stream)>>>(src, srs, scs, dst, drs, dcs, rows, cols);
+    const int64_t gy = (cols + 31) / 32;
+    if (gy > 65535) return set_error(HPCLA_ERR_UNSUPPORTED, "transpose: more than %d columns", 65535 * 32);
+    dim3 grid((uint32_t)((rows + 31) / 32), (uint32_t)gy);
+    relayout_kernel<T><<<grid, 256, 0, as_stream(stream)>>>(src, srs, scs, dst, drs, dcs, rows, cols);
     HPCLA_CHECK_LAUNCH();
     return HPCLA_OK;
+}
+
+HPCLA_API int hpcla_transpose_f64(const double *src, int64_t ld_src, int src_layout, double *dst,
+                                  int64_t ld_dst, int dst_layout, int64_t rows, int64_t cols,
+                                  void *stream)
+{
+    return transpose_impl<double>(src, ld_src, src_layout, dst, ld_dst, dst_layout, rows, cols, stream);
+}
+
+HPCLA_API int hpcla_transpose_f32(const float *src, int64_t ld_src, int src_layout, float *dst, int64_t ld_dst,
+                                  int dst_layout, int64_t rows, int64_t cols, void *stream)
+{
+    return transpose_impl<float>(src, ld_src, src_layout, dst, ld_dst, dst_layout, rows, cols, stream);
 }

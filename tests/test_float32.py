@@ -445,3 +445,28 @@ def test_f32_golden_spmm_dot_norm_at_the_reference_tolerance(hp, golden, f32_bac
     v = hp.HPCVector.from_global(np.array(nr["x"]), backend)
     assert abs(hp.norm(v) - nr["norm2"]) < TOL * nr["norm2"]
     assert hp.norm(v, 1) == nr["norm1"] and hp.norm(v, np.inf) == nr["norminf"]      # 55 and 10: exact in Float32
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,cols", [(1, 1), (33, 16), (1000, 3), (70, 100)])
+def test_transpose_f32_both_directions(hp, rows, cols):
+    """hpcla_transpose_f32: column-major (Julia Matrix) <-> row-major rows, with padded leading dimensions."""
+    import torch
+    rng = np.random.default_rng(rows * 1000 + cols)
+    M = rng.random((rows, cols)).astype(F32)
+    ld_c, ld_r = rows + 3, cols + 2
+    colmaj = np.full((cols, ld_c), np.nan, F32)
+    colmaj[:, :rows] = M.T                                  # element (i, c) at c * ld_c + i
+    src = _t(colmaj)
+    dst = torch.full((rows, ld_r), float("nan"), dtype=torch.float32, device="cuda")
+    hp._capi.call("hpcla_transpose_f32", src.data_ptr(), ld_c, hp._capi.LAYOUT_COL, dst.data_ptr(), ld_r, hp._capi.LAYOUT_ROW,
+                  rows, cols, _stream())
+    got = dst.cpu().numpy()
+    np.testing.assert_array_equal(got[:, :cols], M)
+    assert np.all(np.isnan(got[:, cols:]))
+    back = torch.full((cols, ld_c), float("nan"), dtype=torch.float32, device="cuda")
+    hp._capi.call("hpcla_transpose_f32", dst.data_ptr(), ld_r, hp._capi.LAYOUT_ROW, back.data_ptr(), ld_c, hp._capi.LAYOUT_COL,
+                  rows, cols, _stream())
+    np.testing.assert_array_equal(back.cpu().numpy()[:, :rows], M.T)
+    with pytest.raises(hp._capi.HPCLAError, match="layout"):
+        hp._capi.call("hpcla_transpose_f32", src.data_ptr(), ld_c, 5, dst.data_ptr(), ld_r, 0, rows, cols, _stream())
