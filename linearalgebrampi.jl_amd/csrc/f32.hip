@@ -340,14 +340,14 @@ static int f32_launch(const I *rowptr, const I *colval, const float *nzval, cons
                        (reinterpret_cast<uintptr_t>(nzval) % 16 == 0);
     const bool split = b.ghost != nullptr;
     hipStream_t s = as_stream(stream);
-    if (k == 1 && b.own_rs == 1 && (!split || b.ghost_rs == 1)) {
+    if (k == 1 && b.own_rs == 1 && c_rs == 1 && (!split || b.ghost_rs == 1)) {       // one contiguous column in, one out: A*x
         dim3 grid((uint32_t)launch_blocks), block(F_RPB);
         if (split)
             rowgather_f32_kernel<I, true, 1><<<grid, block, 0, s>>>(rowptr, colval, nzval, b, C, 1, 0, nrows, nnz, index_base, 1,
-                                                                   block_list, vec_ok, c_rs == 1);
+                                                                   block_list, vec_ok, 1);
         else
             rowgather_f32_kernel<I, false, 1><<<grid, block, 0, s>>>(rowptr, colval, nzval, b, C, 1, 0, nrows, nnz, index_base, 1,
-                                                                    block_list, vec_ok, c_rs == 1);
+                                                                    block_list, vec_ok, 1);
     } else if (b.own_cs == 1 && c_cs == 1 && (!split || b.ghost_cs == 1)) {
         // row-major operands.  k a multiple of 4 and everything 16-byte aligned: a lane owns 4 columns (V = 4), KL = the power
         // of two >= k / 4 lanes per row (at most 64 columns per workgroup); else one column per lane, KL = the power of two >= k

@@ -254,7 +254,8 @@ def test_spmm_f32_long_and_empty_rows(hp, orc, layout, k):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("k,ldb,ldg,ldc", [(16, 16, 16, 16), (16, 20, 18, 24), (16, 17, 16, 16), (12, 12, 12, 12), (6, 6, 7, 6)])
+@pytest.mark.parametrize("k,ldb,ldg,ldc", [(16, 16, 16, 16), (16, 20, 18, 24), (16, 17, 16, 16), (12, 12, 12, 12), (6, 6, 7, 6),
+                                          (1, 1, 1, 1), (1, 1, 1, 3), (1, 2, 1, 1), (1, 1, 2, 1)])
 def test_spmm_split_f32_with_widened_ghost_rows(hp, orc, k, ldb, ldg, ldc):
     """Row-major operands with their own leading dimensions: multiples of 4 (2 for the double ghosts) take the kernel's
     four-columns-per-lane form, anything else the one-column-per-lane form; padding columns stay untouched."""
