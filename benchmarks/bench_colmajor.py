@@ -1,0 +1,84 @@
+"""What a column-major caller (Julia's Matrix) pays for A*B today: the Float64 product on row-major rows plus the two
+layout conversions around it, against the entry called with column-major operands directly.
+
+    python benchmarks/bench_colmajor.py [--nx 4096]
+"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--nx", type=int, default=4096)
+    ap.add_argument("--reps", type=int, default=30)
+    ap.add_argument("--ny", type=int, default=0, help="grid lines (default nx / 2); a non-power-of-two count takes the column stride off the powers of two")
+    args = ap.parse_args()
+    import torch
+    import hpcla_amd as hp
+    L = hp._capi.load()
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    nx, ny, k = args.nx, (args.ny or args.nx // 2), 16
+    n = nx * ny
+    nnz = L.hpcla_poisson2d_nnz(nx, ny, 0, n)
+    rp = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    cv = torch.empty(nnz, dtype=torch.int64, device=dev)
+    nz = torch.empty(nnz, dtype=torch.float64, device=dev)
+    hp._capi.call("hpcla_gen_poisson2d", nx, ny, 0, n, rp.data_ptr(), cv.data_ptr(), nz.data_ptr(), s)
+    rp, cv = rp.int(), cv.int()
+    Bc = torch.rand(k, n, dtype=torch.float64, device=dev)          # column-major n x k
+    Cc = torch.empty(k, n, dtype=torch.float64, device=dev)
+    Br = torch.empty(n, k, dtype=torch.float64, device=dev)
+    Cr = torch.empty(n, k, dtype=torch.float64, device=dev)
+    ROW, COL = hp._capi.LAYOUT_ROW, hp._capi.LAYOUT_COL
+
+    def timed(fn, reps):
+        for _ in range(3):
+            fn()
+        t_end = time.time() + 0.25
+        while time.time() < t_end:
+            fn()
+            torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    def to_row():
+        hp._capi.call("hpcla_transpose_f64", Bc.data_ptr(), n, COL, Br.data_ptr(), k, ROW, n, k, s)
+
+    def to_col():
+        hp._capi.call("hpcla_transpose_f64", Cr.data_ptr(), k, ROW, Cc.data_ptr(), n, COL, n, k, s)
+
+    def prod_row():
+        hp._capi.call("hpcla_spmm_csr_f64_i32", rp.data_ptr(), cv.data_ptr(), nz.data_ptr(), Br.data_ptr(), k, ROW, Cr.data_ptr(), k, ROW,
+                      n, nnz, k, 0, s)
+
+    def prod_col():
+        hp._capi.call("hpcla_spmm_csr_f64_i32", rp.data_ptr(), cv.data_ptr(), nz.data_ptr(), Bc.data_ptr(), n, COL, Cc.data_ptr(), n, COL,
+                      n, nnz, k, 0, s)
+
+    alg = nnz * 12 + (n + 1) * 4 + 16 * k * n
+    for name, fn in (("B column-major -> row-major (hpcla_transpose_f64)", to_row), ("product on row-major rows (gather kernel)", prod_row),
+                     ("C row-major -> column-major", to_col),
+                     ("all three (what the Julia extension does today)", lambda: (to_row(), prod_row(), to_col())),
+                     ("product on column-major operands directly", prod_col)):
+        ms = timed(fn, args.reps)
+        print(f"{name:58s} {ms:8.4f} ms   {alg / ms / 1e6 / 8000:6.3f} of 8 TB/s by the product's algorithmic bytes", flush=True)
+    prod_row()
+    to_col()
+    ref = Cc.clone()
+    prod_col()
+    assert torch.equal(ref, Cc)
+
+
+if __name__ == "__main__":
+    main()

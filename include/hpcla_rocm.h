@@ -285,6 +285,27 @@ int hpcla_spmm_runs_k16_f64_i64(const int64_t *rowptr, const int64_t *colval_spl
                                 const double *B_own, const double *B_ghost, int64_t n_own, double *C, int64_t nrows,
                                 int64_t nnz, int index_base, const void *desc, const int32_t *block_list,
                                 int64_t n_blocks, void *stream);
+/* A * B on the CALLER's column-major blocks (Julia's Matrix, src/dense.jl:63), no layout conversion (csrc/colmajor.hip):
+ * lanes = rows, so the 64 rows of a wave read one contiguous run of a column per gather instruction wherever the matrix is
+ * banded; same bits as the row-major kernels.  hpcla_spmm_csr_f64_* takes this path by itself when both layouts are
+ * HPCLA_LAYOUT_COL.  Split form: B_own (n_own rows) and C (nrows rows) column-major with leading dimensions ldb_own / ldc;
+ * B_ghost is the halo plan's ordinary ROW-major ghost segment (ldb_ghost >= k doubles per ghost row) or NULL; block_list
+ * over blocks of hpcla_spmv_rows_per_block() rows.  For unstructured matrices column-major costs a line per (entry, column)
+ * pair: convert to row-major rows there (hpcla_transpose_f64) and use hpcla_spmm_split_f64_*. */
+int hpcla_spmm_split_colmajor_f64_i32(const int32_t *rowptr, const int32_t *colval_split, const double *nzval,
+                                      const double *B_own, int64_t ldb_own, const double *B_ghost, int64_t ldb_ghost,
+                                      int64_t n_own, double *C, int64_t ldc, int64_t nrows, int64_t nnz, int k,
+                                      int index_base, const int32_t *block_list, int64_t n_blocks, void *stream);
+int hpcla_spmm_split_colmajor_f64_i64(const int64_t *rowptr, const int64_t *colval_split, const double *nzval,
+                                      const double *B_own, int64_t ldb_own, const double *B_ghost, int64_t ldb_ghost,
+                                      int64_t n_own, double *C, int64_t ldc, int64_t nrows, int64_t nnz, int k,
+                                      int index_base, const int32_t *block_list, int64_t n_blocks, void *stream);
+/* hpcla_halo_begin for an operand in any layout (element (row i, column c) at x[i * x_rs + c * x_cs]; a column-major
+ * block: x_rs = 1, x_cs = ld): the rows the plan SENDS are staged into `stage` (row-major like the exchange: at least
+ * (largest send index + 1) * width doubles, the caller's, reused from call to call) on `stream`, then the ordinary
+ * exchange is posted from `stage`.  hpcla_halo_end / status / ghost pointer as usual. */
+int hpcla_halo_begin_strided_f64(hpcla_halo_plan_t *plan, const double *x, int64_t x_rs, int64_t x_cs, double *stage,
+                                 void *stream);
 /* layout conversion for column-major callers (Julia Matrix): dst(row-major, ld=k) <- src */
 /* One column PANEL of a product in panel order (opt-in order of the distributed SpMM; the reference's column loop
  * src/sparse.jl:2391-2413 runs one exchange + SpMV per column instead).  (rowptr, colval_split, nzval) hold the
@@ -675,6 +696,18 @@ int hpcla_spmm_split_f32_i64(const int64_t *rowptr, const int64_t *colval_split,
                              int64_t ldb_own, const double *B_ghost_wide, int64_t ldb_ghost, int64_t n_own, float *C,
                              int64_t ldc, int64_t nrows, int64_t nnz, int k, int index_base, const int32_t *block_list,
                              int64_t n_blocks, void *stream);
+/* column-major own block and result (Julia's Matrix), the plan's row-major ghost segment: hpcla_spmm_split_colmajor_f64_*'s
+ * twin for Float32; hpcla_halo_begin_strided_f32 is hpcla_halo_begin_strided_f64's (the staged values are widened) */
+int hpcla_spmm_split_colmajor_f32_i32(const int32_t *rowptr, const int32_t *colval_split, const float *nzval,
+                                      const float *B_own, int64_t ldb_own, const double *B_ghost_wide, int64_t ldb_ghost,
+                                      int64_t n_own, float *C, int64_t ldc, int64_t nrows, int64_t nnz, int k,
+                                      int index_base, const int32_t *block_list, int64_t n_blocks, void *stream);
+int hpcla_spmm_split_colmajor_f32_i64(const int64_t *rowptr, const int64_t *colval_split, const float *nzval,
+                                      const float *B_own, int64_t ldb_own, const double *B_ghost_wide, int64_t ldb_ghost,
+                                      int64_t n_own, float *C, int64_t ldc, int64_t nrows, int64_t nnz, int k,
+                                      int index_base, const int32_t *block_list, int64_t n_blocks, void *stream);
+int hpcla_halo_begin_strided_f32(hpcla_halo_plan_t *plan, const float *x, int64_t x_rs, int64_t x_cs, double *stage,
+                                 void *stream);
 /* hpcla_halo_begin for a Float32 operand (execute_plan!, src/vectors.jl:394-463): widens x at the plan's send positions
  * into `stage` (doubles, laid out like x: at least (largest send index + 1) * width entries; the caller's, reused from
  * call to call) on `stream`, then posts the ordinary exchange from `stage`.  hpcla_halo_end / hpcla_halo_status /

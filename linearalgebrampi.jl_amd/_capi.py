@@ -76,6 +76,9 @@ _SIGNATURES = {
     "hpcla_spmm_csr_f64_i64": [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _i64, _i32, _i64, _i64, _i32, _i32, _vp],
     "hpcla_spmm_split_f64_i32": [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _i64, _vp],
     "hpcla_spmm_split_f64_i64": [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _i64, _vp],
+    "hpcla_spmm_split_colmajor_f64_i32": [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _i64, _vp],
+    "hpcla_spmm_split_colmajor_f64_i64": [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _i64, _vp],
+    "hpcla_halo_begin_strided_f64": [_vp, _vp, _i64, _i64, _vp, _vp],
     "hpcla_spmm_panel_f64_i32": [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _vp],
     "hpcla_spmm_panel_f64_i64": [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _vp],
     "hpcla_transpose_f64": [_vp, _i64, _i32, _vp, _i64, _i32, _i64, _i64, _vp],
@@ -172,6 +175,9 @@ _SIGNATURES = {
     "hpcla_spmm_split_f32_i32": [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _i64, _vp],
     "hpcla_spmm_split_f32_i64": [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _i64, _vp],
     "hpcla_halo_begin_f32": [_vp, _vp, _vp, _vp],
+    "hpcla_halo_begin_strided_f32": [_vp, _vp, _i64, _i64, _vp, _vp],
+    "hpcla_spmm_split_colmajor_f32_i32": [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _i64, _vp],
+    "hpcla_spmm_split_colmajor_f32_i64": [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _i64, _vp],
     "hpcla_transpose_f32": [_vp, _i64, _i32, _vp, _i64, _i32, _i64, _i64, _vp],
     "hpcla_dot_f32": [_vp, _vp, _vp, _i64, _vp, _vp, _vp],
     "hpcla_nrm2sq_f32": [_vp, _vp, _i64, _vp, _vp, _vp],

@@ -7,7 +7,7 @@
 // (src/vectors.jl:758-812).  Float64 is the graded type (spmv.hip, spmm.hip, vecops.hip); this file gives the SAME
 // path to T = Float32 so that a Float32 backend does not fall through to the parent's host-staged path:
 //
-//   * rowgather_f32_kernel: the row-gather design of spmv.hip (a wave streams its 64 rows' entries into its own slice of
+//   * rowgather_kernel<float, ...> (rowgather_t.h): the row-gather design of spmv.hip (a wave streams its 64 rows' entries into its own slice of
 //     LDS with aligned 16-byte loads -- 8 B per entry here -- and every lane then walks ITS row in stored order, separate
 //     multiply and add in float: the reference's bits).  One template serves A*x (KC = 1) and A*B on COLUMN-major
 //     operands (Julia's Matrix: 8 or 16 columns per workgroup, grid.y column groups); rowmajor_f32_kernel is the same
@@ -27,25 +27,13 @@
 
 #include "comm_internal.h"
 #include "common.h"
+#include "rowgather_t.h"
 
 namespace hpcla {
 
 int allreduce_on(hpcla_comm_t *comm, double *buf, int64_t count, int op, void *stream);   // comm.hip
 
-constexpr int F_RPB = 256;        // rows per block == threads per block: the block lists of hpcla_classify_blocks_* apply
-constexpr int F_CHW = 464;        // entries per wave pass: 64 rows x 7 + alignment slack (spmv.hip RG_CHW)
-constexpr int F_NQ = (F_CHW / 4 + 63) / 64;   // quads per lane per pass
-
-template <typename T, int N>
-using fvec = T __attribute__((ext_vector_type(N)));
-
-struct F32Operand {               // element (row j, column c) of a dense operand lives at p[j * rs + c * cs]
-    const float *own;
-    int64_t own_rs, own_cs;
-    const double *ghost;          // widened ghost rows (halo buffer), or null
-    int64_t ghost_rs, ghost_cs;
-    int64_t n_own;
-};
+using F32Operand = DenseOperand<float>;
 
 // four consecutive columns of one row of a ROW-major operand (16-byte aligned: the callers check)
 template <bool SPLIT>
@@ -60,144 +48,6 @@ __device__ __forceinline__ fvec<float, 4> f32_gather4(const F32Operand &b, int64
         return r;
     }
     return *reinterpret_cast<const fvec<float, 4> *>(b.own + col * b.own_rs + coff);
-}
-
-template <bool SPLIT>
-__device__ __forceinline__ float f32_gather(const F32Operand &b, int64_t col, int64_t coff_own, int64_t coff_ghost)
-{
-    if (SPLIT && col >= b.n_own) return (float)b.ghost[(col - b.n_own) * b.ghost_rs + coff_ghost];
-    return b.own[col * b.own_rs + coff_own];
-}
-
-// One pass of a WAVE: entries [at, at + n) of colval / nzval into the wave's own slice of LDS (n <= F_CHW).  Aligned arrays:
-// 16-byte loads, all of a lane's quads requested before the first LDS write (lanes past the end re-read the pass's last quad
-// -- lines their neighbours read anyway -- and write nothing); unaligned arrays, or the one pass of the launch that reaches
-// past their end: entry by entry.  LDS operations of one wave complete in order, so a wave-level fence is all the consumer
-// needs.
-template <typename I>
-__device__ __forceinline__ void stage_pass_f32(const I *__restrict__ colval, const float *__restrict__ nzval, I *s_col,
-                                               float *s_val, int64_t at, int n, int64_t nnz, int base, int lane, int vec_ok)
-{
-    if (vec_ok && at + ((n + 3) & ~3) <= nnz) {
-        const int last = (n - 1) & ~3;
-        fvec<I, 4> cq[F_NQ];
-        fvec<float, 4> vq[F_NQ];
-#pragma unroll
-        for (int u = 0; u < F_NQ; ++u) {
-            const int e0 = (u * 64 + lane) * 4;
-            const int ee = e0 < last ? e0 : last;
-            cq[u] = *reinterpret_cast<const fvec<I, 4> *>(colval + at + ee);
-            vq[u] = *reinterpret_cast<const fvec<float, 4> *>(nzval + at + ee);
-        }
-#pragma unroll
-        for (int u = 0; u < F_NQ; ++u) {
-            const int e0 = (u * 64 + lane) * 4;
-            if (e0 < n) {
-                *reinterpret_cast<fvec<I, 4> *>(&s_col[e0]) = cq[u];
-                *reinterpret_cast<fvec<float, 4> *>(&s_val[e0]) = vq[u];
-            }
-        }
-    } else {
-        for (int e = lane; e < n; e += 64) {
-            const int64_t g = at + e;
-            s_col[e] = g < nnz ? colval[g] : (I)base;
-            s_val[e] = g < nnz ? nzval[g] : 0.0f;
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");               // this wave's LDS writes, then its LDS reads
-    __builtin_amdgcn_wave_barrier();
-}
-
-// KC = 1: y = A*x (strides of the operand ignored: unit).  KC > 1: up to KC columns [c0, c0 + kc) of C = A*B.
-template <typename I, bool SPLIT, int KC>
-__global__ __launch_bounds__(F_RPB) void rowgather_f32_kernel(
-    const I *__restrict__ rowptr, const I *__restrict__ colval, const float *__restrict__ nzval, F32Operand b,
-    float *__restrict__ y, int64_t y_rs, int64_t y_cs, int64_t nrows, int64_t nnz, int base, int k,
-    const int32_t *__restrict__ block_list, int vec_ok, int nt_y)
-{
-    constexpr int UR = KC == 1 ? 8 : (KC <= 8 ? 4 : 2);
-    __shared__ __attribute__((aligned(16))) I s_col_all[(F_RPB / 64) * F_CHW];
-    __shared__ __attribute__((aligned(16))) float s_val_all[(F_RPB / 64) * F_CHW];
-
-    const int tid = threadIdx.x;
-    const int64_t blk = block_list ? (int64_t)block_list[blockIdx.x] : (int64_t)blockIdx.x;
-    const int c0 = KC == 1 ? 0 : (int)blockIdx.y * KC;
-    const int kc = KC == 1 ? 1 : (k - c0 < KC ? k - c0 : KC);
-    const int64_t r0 = blk * F_RPB;
-    const int nr = (int)((nrows - r0) < F_RPB ? (nrows - r0) : F_RPB);
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    I *s_col = s_col_all + wave * F_CHW;
-    float *s_val = s_val_all + wave * F_CHW;
-    const int64_t rw = r0 + wave * 64;
-    const int nrw = nr - wave * 64 < 0 ? 0 : (nr - wave * 64 > 64 ? 64 : nr - wave * 64);
-    if (nrw <= 0) return;                                                // wave-uniform; the kernel has no workgroup barrier
-    float acc[KC];
-#pragma unroll
-    for (int c = 0; c < KC; ++c) acc[c] = 0.0f;
-    const int64_t p0 = (int64_t)rowptr[rw] - base;
-    const int64_t p1 = (int64_t)rowptr[rw + nrw] - base;
-    const int64_t pa = vec_ok ? (p0 & ~(int64_t)3) : p0;                 // quad-aligned start (<= 3 entries of the rows before)
-    const int64_t total = p1 - pa;
-    const int ll = lane < nrw ? lane : nrw - 1;
-    I rlo = rowptr[rw + ll], rhi = rowptr[rw + ll + 1];                  // unconditional; first used behind the A stream
-    for (int64_t c = 0; c < total; c += F_CHW) {
-        const int n = (int)((total - c) < F_CHW ? (total - c) : F_CHW);
-        stage_pass_f32<I>(colval, nzval, s_col, s_val, pa + c, n, nnz, base, lane, vec_ok);
-        asm volatile("" : "+v"(rlo), "+v"(rhi));                         // keeps the row bounds' first use behind the stream
-        {
-            const int lo = lane < nrw ? (int)((int64_t)rlo - base - pa - c) : 0;
-            const int hi = lane < nrw ? (int)((int64_t)rhi - base - pa - c) : 0;
-            int j = lo > 0 ? lo : 0;
-            const int e = hi < n ? hi : n;
-            for (; j < e; j += UR) {
-                int64_t cc[UR];
-                float vv[UR];
-#pragma unroll
-                for (int u = 0; u < UR; ++u) {
-                    cc[u] = 0; vv[u] = 0.0f;
-                    if (j + u < e) { cc[u] = (int64_t)(I)(s_col[j + u] - (I)base); vv[u] = s_val[j + u]; }
-                }
-                if (KC == 1) {
-                    float xx[UR];
-#pragma unroll
-                    for (int u = 0; u < UR; ++u) {
-                        xx[u] = 0.0f;
-                        if (j + u < e) xx[u] = SPLIT && cc[u] >= b.n_own ? (float)b.ghost[cc[u] - b.n_own] : b.own[cc[u]];
-                    }
-#pragma unroll
-                    for (int u = 0; u < UR; ++u) if (j + u < e) acc[0] += vv[u] * xx[u];
-                } else {
-                    float xx[UR][KC];
-#pragma unroll
-                    for (int u = 0; u < UR; ++u)
-#pragma unroll
-                        for (int q = 0; q < KC; ++q) {
-                            xx[u][q] = 0.0f;
-                            if (j + u < e && q < kc)
-                                xx[u][q] = f32_gather<SPLIT>(b, cc[u], (c0 + q) * b.own_cs, (c0 + q) * b.ghost_cs);
-                        }
-#pragma unroll
-                    for (int u = 0; u < UR; ++u)
-                        if (j + u < e) {
-#pragma unroll
-                            for (int q = 0; q < KC; ++q) acc[q] += vv[u] * xx[u][q];
-                        }
-                }
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");           // ... and the reads before the next pass's writes
-        __builtin_amdgcn_wave_barrier();
-    }
-    if (lane < nrw) {
-        if (KC == 1) {
-            if (nt_y) __builtin_nontemporal_store(acc[0], y + rw + lane);
-            else y[rw + lane] = acc[0];
-        } else {
-#pragma unroll
-            for (int q = 0; q < KC; ++q)
-                if (q < kc) y[(rw + lane) * y_rs + (c0 + q) * y_cs] = acc[q];
-        }
-    }
 }
 
 // Row-major operands (the library's device layout of a dense block: element (j, c) at p[j * ld + c], c fastest): KL lanes own
@@ -251,7 +101,7 @@ __global__ __launch_bounds__(F_RPB) void rowmajor_f32_kernel(
     }
     for (int64_t c = 0; c < total; c += F_CHW) {
         const int n = (int)((total - c) < F_CHW ? (total - c) : F_CHW);
-        stage_pass_f32<I>(colval, nzval, s_col, s_val, pa + c, n, nnz, base, lane, vec_ok);
+        stage_pass<float, I>(colval, nzval, s_col, s_val, pa + c, n, nnz, base, lane, vec_ok);
         for (int g = 0; g < KL; ++g) {                                   // step g: rows g * RPS + sub
             const int row = g * RPS + sub;                               // < 64
             const int64_t lo64 = __shfl(rlo_own, row, 64) - c, hi64 = __shfl(rhi_own, row, 64) - c;
@@ -290,7 +140,7 @@ __global__ __launch_bounds__(F_RPB) void rowmajor_f32_kernel(
                             const fvec<float, 4> g4 = f32_gather4<SPLIT>(b, cc[u], c0 + q);
                             xx[u][0] = g4.x; xx[u][1 % V] = g4.y; xx[u][2 % V] = g4.z; xx[u][3 % V] = g4.w;
                         } else {
-                            xx[u][0] = f32_gather<SPLIT>(b, cc[u], c0 + q, c0 + q);
+                            xx[u][0] = operand_gather<float, SPLIT>(b, cc[u], c0 + q, c0 + q);
                         }
                     }
                 }
@@ -336,17 +186,16 @@ static int f32_launch(const I *rowptr, const I *colval, const float *nzval, cons
     }
     if (launch_blocks == 0) return HPCLA_OK;
     HPCLA_CHECK_GRID(launch_blocks, who);
-    const int vec_ok = (reinterpret_cast<uintptr_t>(colval) % (4 * sizeof(I)) == 0) &&
-                       (reinterpret_cast<uintptr_t>(nzval) % 16 == 0);
+    const int vec_ok = stage_vec_ok<float, I>(colval, nzval);
     const bool split = b.ghost != nullptr;
     hipStream_t s = as_stream(stream);
     if (k == 1 && b.own_rs == 1 && c_rs == 1 && (!split || b.ghost_rs == 1)) {       // one contiguous column in, one out: A*x
         dim3 grid((uint32_t)launch_blocks), block(F_RPB);
         if (split)
-            rowgather_f32_kernel<I, true, 1><<<grid, block, 0, s>>>(rowptr, colval, nzval, b, C, 1, 0, nrows, nnz, index_base, 1,
+            rowgather_kernel<float, I, true, 1><<<grid, block, 0, s>>>(rowptr, colval, nzval, b, C, 1, 0, nrows, nnz, index_base, 1,
                                                                    block_list, vec_ok, 1);
         else
-            rowgather_f32_kernel<I, false, 1><<<grid, block, 0, s>>>(rowptr, colval, nzval, b, C, 1, 0, nrows, nnz, index_base, 1,
+            rowgather_kernel<float, I, false, 1><<<grid, block, 0, s>>>(rowptr, colval, nzval, b, C, 1, 0, nrows, nnz, index_base, 1,
                                                                     block_list, vec_ok, 1);
     } else if (b.own_cs == 1 && c_cs == 1 && (!split || b.ghost_cs == 1)) {
         // row-major operands.  k a multiple of 4 and everything 16-byte aligned: a lane owns 4 columns (V = 4), KL = the power
@@ -390,11 +239,11 @@ static int f32_launch(const I *rowptr, const I *colval, const float *nzval, cons
     } else if (k <= 8) {
         dim3 grid((uint32_t)launch_blocks, 1), block(F_RPB);
         if (split)
-            rowgather_f32_kernel<I, true, 8><<<grid, block, 0, s>>>(rowptr, colval, nzval, b, C, c_rs, c_cs, nrows, nnz,
-                                                                   index_base, k, block_list, vec_ok, 0);
+            rowgather_kernel<float, I, true, 8><<<grid, block, 0, s>>>(rowptr, colval, nzval, b, C, c_rs, c_cs, nrows, nnz,
+                                                                   index_base, k, block_list, vec_ok, c_rs == 1);
         else
-            rowgather_f32_kernel<I, false, 8><<<grid, block, 0, s>>>(rowptr, colval, nzval, b, C, c_rs, c_cs, nrows, nnz,
-                                                                    index_base, k, block_list, vec_ok, 0);
+            rowgather_kernel<float, I, false, 8><<<grid, block, 0, s>>>(rowptr, colval, nzval, b, C, c_rs, c_cs, nrows, nnz,
+                                                                    index_base, k, block_list, vec_ok, c_rs == 1);
     } else {
         // lanes = rows (column-major operands: 64 consecutive rows of one column are one contiguous run), 16 columns per
         // workgroup: A is streamed once per 16 columns
@@ -403,11 +252,11 @@ static int f32_launch(const I *rowptr, const I *colval, const float *nzval, cons
         if (groups > 65535) return set_error(HPCLA_ERR_UNSUPPORTED, "%s: more than %d columns", who, 65535 * KC);
         dim3 grid((uint32_t)launch_blocks, (uint32_t)groups), block(F_RPB);
         if (split)
-            rowgather_f32_kernel<I, true, KC><<<grid, block, 0, s>>>(rowptr, colval, nzval, b, C, c_rs, c_cs, nrows, nnz,
-                                                                    index_base, k, block_list, vec_ok, 0);
+            rowgather_kernel<float, I, true, KC><<<grid, block, 0, s>>>(rowptr, colval, nzval, b, C, c_rs, c_cs, nrows, nnz,
+                                                                    index_base, k, block_list, vec_ok, c_rs == 1);
         else
-            rowgather_f32_kernel<I, false, KC><<<grid, block, 0, s>>>(rowptr, colval, nzval, b, C, c_rs, c_cs, nrows, nnz,
-                                                                     index_base, k, block_list, vec_ok, 0);
+            rowgather_kernel<float, I, false, KC><<<grid, block, 0, s>>>(rowptr, colval, nzval, b, C, c_rs, c_cs, nrows, nnz,
+                                                                     index_base, k, block_list, vec_ok, c_rs == 1);
     }
     HPCLA_CHECK_LAUNCH();
     return HPCLA_OK;
@@ -420,17 +269,9 @@ static int layout_strides(int layout, int64_t ld, int64_t *rs, int64_t *cs, cons
     return set_error(HPCLA_ERR_INVALID, "%s: layout must be HPCLA_LAYOUT_ROW or HPCLA_LAYOUT_COL", who);
 }
 
-// ---- halo: widen the values an exchange sends ----------------------------------------------------------------------
-template <typename I>
-__global__ __launch_bounds__(256) void widen_at_kernel(const float *__restrict__ x, const I *__restrict__ idx,
-                                                       double *__restrict__ stage, int64_t n_idx, int w)
-{
-    const int64_t total = n_idx * w;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t at = (int64_t)idx[e / w] * w + (e % w);
-        stage[at] = (double)x[at];
-    }
-}
+// ---- halo: widen the values an exchange sends (colmajor.hip: stage_at_kernel, any operand strides) -----------------------------
+template <typename T>
+int halo_begin_strided(hpcla_halo_plan_t *plan, const T *x, int64_t x_rs, int64_t x_cs, double *stage, void *stream, const char *who);
 
 // ---- reductions ------------------------------------------------------------------------------------------------------
 constexpr int F_RT = 256;
@@ -630,24 +471,35 @@ using namespace hpcla;
 HPCLA_F32_SPMV(i32, int32_t)
 HPCLA_F32_SPMV(i64, int64_t)
 
+// column-major own block and result (Julia's Matrix), row-major ghost segment: hpcla_spmm_split_colmajor_f64_*'s twin
+#define HPCLA_F32_COLMAJOR_SPLIT(SFX, ITYPE)                                                                                \
+    HPCLA_API int hpcla_spmm_split_colmajor_f32_##SFX(const ITYPE *rowptr, const ITYPE *colval_split, const float *nzval,   \
+                                                      const float *B_own, int64_t ldb_own, const double *B_ghost_wide,      \
+                                                      int64_t ldb_ghost, int64_t n_own, float *C, int64_t ldc,              \
+                                                      int64_t nrows, int64_t nnz, int k, int index_base,                    \
+                                                      const int32_t *block_list, int64_t n_blocks, void *stream)            \
+    {                                                                                                                       \
+        if (n_own < 0) return set_error(HPCLA_ERR_INVALID, "spmm_split_colmajor_f32: negative n_own");                      \
+        if (k > 1 && (ldb_own < n_own || ldc < nrows))                                                                      \
+            return set_error(HPCLA_ERR_INVALID, "spmm_split_colmajor_f32: leading dimension smaller than the row count");   \
+        if (B_ghost_wide && ldb_ghost < k) return set_error(HPCLA_ERR_INVALID, "spmm_split_colmajor_f32: ldb_ghost < k");   \
+        const F32Operand b{B_own, 1, ldb_own, B_ghost_wide, ldb_ghost, 1, n_own};                                           \
+        return f32_launch<ITYPE>(rowptr, colval_split, nzval, b, C, 1, ldc, nrows, nnz, k, index_base, block_list,          \
+                                 n_blocks, stream, "spmm_split_colmajor_f32");                                              \
+    }
+HPCLA_F32_COLMAJOR_SPLIT(i32, int32_t)
+HPCLA_F32_COLMAJOR_SPLIT(i64, int64_t)
+
 HPCLA_API int hpcla_halo_begin_f32(hpcla_halo_plan_t *plan, const float *x, double *stage, void *stream)
 {
     if (!plan) return set_error(HPCLA_ERR_INVALID, "halo_begin_f32: null plan");
-    if (plan->send_ranks.empty() && plan->recv_ranks.empty()) return HPCLA_OK;
-    if (plan->n_send_total > 0) {
-        if (!x || !stage) return set_error(HPCLA_ERR_INVALID, "halo_begin_f32: null x / stage");
-        const int64_t total = plan->n_send_total * plan->width;
-        int64_t g = (total + 255) / 256;
-        if (g > 4096) g = 4096;
-        if (plan->idx_is_i64)
-            widen_at_kernel<int64_t><<<(uint32_t)g, 256, 0, as_stream(stream)>>>(x, (const int64_t *)plan->send_idx, stage,
-                                                                               plan->n_send_total, plan->width);
-        else
-            widen_at_kernel<int32_t><<<(uint32_t)g, 256, 0, as_stream(stream)>>>(x, (const int32_t *)plan->send_idx, stage,
-                                                                               plan->n_send_total, plan->width);
-        HPCLA_CHECK_LAUNCH();
-    }
-    return hpcla_halo_begin(plan, stage, stream);
+    return halo_begin_strided<float>(plan, x, plan->width, 1, stage, stream, "halo_begin_f32");          // row-major, ld = width
+}
+
+HPCLA_API int hpcla_halo_begin_strided_f32(hpcla_halo_plan_t *plan, const float *x, int64_t x_rs, int64_t x_cs, double *stage,
+                                           void *stream)
+{
+    return halo_begin_strided<float>(plan, x, x_rs, x_cs, stage, stream, "halo_begin_strided_f32");
 }
 
 HPCLA_API int hpcla_dot_f32(hpcla_comm_t *comm, const float *x, const float *y, int64_t n, double *out_dev, void *work,

@@ -901,12 +901,22 @@ HPCLA_API int hpcla_spmm_tune_block_order_f64_i64(const int64_t *rowptr, const i
                                           nrows, nnz, k, index_base, block_list, n_blocks, stream, chosen_group);
 }
 
+namespace hpcla {
+// colmajor.hip: both operands column-major (Julia's Matrix) -> the lanes = rows kernel, no layout conversion
+int spmm_colmajor_i32(const int32_t *rowptr, const int32_t *colval, const double *nzval, const double *B, int64_t ldb, double *C,
+                      int64_t ldc, int64_t nrows, int64_t nnz, int k, int index_base, void *stream);
+int spmm_colmajor_i64(const int64_t *rowptr, const int64_t *colval, const double *nzval, const double *B, int64_t ldb, double *C,
+                      int64_t ldc, int64_t nrows, int64_t nnz, int k, int index_base, void *stream);
+}  // namespace hpcla
+
 HPCLA_API int hpcla_spmm_csr_f64_i32(const int32_t *rowptr, const int32_t *colval,
                                      const double *nzval, const double *B, int64_t ldb,
                                      int b_layout, double *C, int64_t ldc, int c_layout,
                                      int64_t nrows, int64_t nnz, int k, int index_base,
                                      void *stream)
 {
+    if (b_layout == HPCLA_LAYOUT_COL && c_layout == HPCLA_LAYOUT_COL && k > 1)
+        return spmm_colmajor_i32(rowptr, colval, nzval, B, ldb, C, ldc, nrows, nnz, k, index_base, stream);
     int64_t brs, bcs, crs, ccs;
     layout_strides(b_layout, ldb, &brs, &bcs);
     layout_strides(c_layout, ldc, &crs, &ccs);
@@ -920,6 +930,8 @@ HPCLA_API int hpcla_spmm_csr_f64_i64(const int64_t *rowptr, const int64_t *colva
                                      int64_t nrows, int64_t nnz, int k, int index_base,
                                      void *stream)
 {
+    if (b_layout == HPCLA_LAYOUT_COL && c_layout == HPCLA_LAYOUT_COL && k > 1)
+        return spmm_colmajor_i64(rowptr, colval, nzval, B, ldb, C, ldc, nrows, nnz, k, index_base, stream);
     int64_t brs, bcs, crs, ccs;
     layout_strides(b_layout, ldb, &brs, &bcs);
     layout_strides(c_layout, ldc, &crs, &ccs);

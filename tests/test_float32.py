@@ -471,3 +471,27 @@ def test_transpose_f32_both_directions(hp, rows, cols):
     np.testing.assert_array_equal(back.cpu().numpy()[:, :rows], M.T)
     with pytest.raises(hp._capi.HPCLAError, match="layout"):
         hp._capi.call("hpcla_transpose_f32", src.data_ptr(), ld_c, 5, dst.data_ptr(), ld_r, 0, rows, cols, _stream())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b_lay,c_lay", [("row", "col"), ("col", "row")])
+@pytest.mark.parametrize("k", [1, 5, 16])
+def test_spmm_f32_mixed_layouts(hp, orc, b_lay, c_lay, k):
+    """hpcla_spmm_csr_f32_* takes B and C in different layouts (the strided lanes = rows kernel)."""
+    import torch
+    n = 900
+    rows = orc.sprand_rows(n, 0.02, 0, n)
+    ci, cv = orc.compress_columns(rows)
+    rng = np.random.default_rng(7 * k)
+    B = rng.random((len(ci), k)).astype(F32)
+    want = orc.spmm(rows.rowptr.astype(np.int32), cv.astype(np.int32), rows.vals.astype(F32), B)
+    rp, cvd, nz = _t(rows.rowptr.astype(np.int32)), _t(cv.astype(np.int32)), _t(rows.vals.astype(F32))
+    lay = {"row": hp._capi.LAYOUT_ROW, "col": hp._capi.LAYOUT_COL}
+    Bd = _t(B if b_lay == "row" else np.ascontiguousarray(B.T))
+    C = torch.full((n * k,), float("nan"), dtype=torch.float32, device="cuda")
+    hp._capi.call("hpcla_spmm_csr_f32_i32", rp.data_ptr(), cvd.data_ptr(), nz.data_ptr(), Bd.data_ptr(),
+                  k if b_lay == "row" else len(ci), lay[b_lay], C.data_ptr(), k if c_lay == "row" else n, lay[c_lay],
+                  n, len(rows.vals), k, 0, _stream())
+    torch.cuda.synchronize()
+    got = C.cpu().numpy().reshape((n, k) if c_lay == "row" else (k, n))
+    np.testing.assert_array_equal(got if c_lay == "row" else got.T, want)

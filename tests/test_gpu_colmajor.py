@@ -1,0 +1,137 @@
+"""A * B on the caller's COLUMN-major blocks (csrc/colmajor.hip, rowgather_t.h): Julia's Matrix is column-major
+(src/dense.jl:63), and with lanes = rows the product needs no layout conversion around it.  Bar: the same bits as the
+reference's column loop (src/sparse.jl:2391-2413) = the oracle = the row-major kernels.
+
+hpcla_spmm_csr_f64_* routes here by itself when both layouts are HPCLA_LAYOUT_COL (tests/test_gpu_parity.py's layout cases run
+through it); this file adds what those do not reach: long and empty rows, padded leading dimensions, the split form with the
+halo plan's row-major ghost segment and block lists, both element types, and -- with real ranks -- the exchange posted from a
+column-major block (hpcla_halo_begin_strided_*).
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _t(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda")
+
+
+def _stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+@pytest.mark.parametrize("k", [2, 8, 16, 17, 40])
+@pytest.mark.parametrize("Ti", [np.int32, np.int64])
+def test_spmm_colmajor_f64_long_and_empty_rows(hp, orc, k, Ti):
+    import torch
+    sfx = "i32" if Ti == np.int32 else "i64"
+    rng = np.random.default_rng(k)
+    ncols = 12_000
+    lens = np.zeros(333, dtype=np.int64)
+    lens[[1, 7, 64, 130, 131, 255, 256, 300]] = [5000, 464, 1, 465, 930, 3, 2000, 11]
+    lens[200:250] = 9
+    rowptr = np.concatenate([[0], np.cumsum(lens)])
+    colval = np.concatenate([np.sort(rng.choice(ncols, int(l), replace=False)) for l in lens]).astype(Ti)
+    vals = rng.random(len(colval)) - 0.5
+    B = rng.random((ncols, k)) - 0.5
+    n = len(lens)
+    want = orc.spmm(rowptr.astype(Ti), colval, vals, B)
+    ldb, ldc = ncols + 5, n + 3                              # padded leading dimensions
+    Bc = np.full((k, ldb), np.nan)
+    Bc[:, :ncols] = B.T
+    rp, cv, nz, Bd = _t(rowptr.astype(Ti)), _t(colval), _t(vals), _t(Bc)
+    C = torch.full((k, ldc), float("nan"), dtype=torch.float64, device="cuda")
+    for base in (0, 1):
+        rpb, cvb = _t(rowptr.astype(Ti) + base), _t(colval + base)
+        C.fill_(float("nan"))
+        hp._capi.call(f"hpcla_spmm_csr_f64_{sfx}", rpb.data_ptr(), cvb.data_ptr(), nz.data_ptr(), Bd.data_ptr(), ldb,
+                      hp._capi.LAYOUT_COL, C.data_ptr(), ldc, hp._capi.LAYOUT_COL, n, len(vals), k, base, _stream())
+        got = C.cpu().numpy()
+        np.testing.assert_array_equal(got[:, :n].T, want)
+        assert np.all(np.isnan(got[:, n:]))
+    del rp, cv
+
+
+@pytest.mark.parametrize("dt", ["f64", "f32"])
+@pytest.mark.parametrize("k", [1, 3, 16])
+def test_spmm_split_colmajor_ghost_segment_and_block_lists(hp, orc, dt, k):
+    """Own block and result column-major, ghost rows row-major doubles (the halo plan's segment); a block list restricts the
+    launch to those 256-row blocks and leaves the other rows untouched."""
+    import torch
+    T = np.float64 if dt == "f64" else np.float32
+    tT = torch.float64 if dt == "f64" else torch.float32
+    n, n_own = 3000, 2100
+    rows = orc.sprand_rows(n, 0.004, 0, n)
+    rng = np.random.default_rng(5 + k)
+    B = (rng.random((n, k)) - 0.5).astype(T)
+    vals = rows.vals.astype(T)
+    want = orc.spmm(rows.rowptr.astype(np.int32), rows.colidx.astype(np.int32), vals, B)
+    rp, cv, nz = _t(rows.rowptr.astype(np.int32)), _t(rows.colidx.astype(np.int32)), _t(vals)
+    ldb, ldg, ldc = n_own + 4, k + 2, n + 8
+    Bo = np.full((k, ldb), np.nan, T)
+    Bo[:, :n_own] = B[:n_own].T
+    Bg = np.full((n - n_own, ldg), np.nan)
+    Bg[:, :k] = B[n_own:]
+    B_own, B_ghost = _t(Bo), _t(Bg)
+    rpb = hp._capi.load().hpcla_spmv_rows_per_block()
+    nblk = (n + rpb - 1) // rpb
+    fn = f"hpcla_spmm_split_colmajor_{dt}_i32"
+    C = torch.full((k, ldc), float("nan"), dtype=tT, device="cuda")
+    hp._capi.call(fn, rp.data_ptr(), cv.data_ptr(), nz.data_ptr(), B_own.data_ptr(), ldb, B_ghost.data_ptr(), ldg, n_own,
+                  C.data_ptr(), ldc, n, len(vals), k, 0, 0, 0, _stream())
+    got = C.cpu().numpy()
+    np.testing.assert_array_equal(got[:, :n].T, want)
+    assert np.all(np.isnan(got[:, n:]))
+    some = np.array([b for b in range(nblk) if b % 3 != 1], dtype=np.int32)
+    lst = _t(some)
+    C.fill_(float("nan"))
+    hp._capi.call(fn, rp.data_ptr(), cv.data_ptr(), nz.data_ptr(), B_own.data_ptr(), ldb, B_ghost.data_ptr(), ldg, n_own,
+                  C.data_ptr(), ldc, n, len(vals), k, 0, lst.data_ptr(), len(some), _stream())
+    got = C.cpu().numpy()[:, :n].T
+    for b in range(nblk):
+        sl = slice(b * rpb, min(n, (b + 1) * rpb))
+        if b % 3 != 1:
+            np.testing.assert_array_equal(got[sl], want[sl])
+        else:
+            assert np.all(np.isnan(got[sl]))
+    with pytest.raises(hp._capi.HPCLAError, match="leading dimension"):
+        hp._capi.call(fn, rp.data_ptr(), cv.data_ptr(), nz.data_ptr(), B_own.data_ptr(), n_own - 1, None, k, n_own,
+                      C.data_ptr(), ldc, n, len(vals), 2, 0, 0, 0, _stream())
+
+
+def test_colmajor_stencil_equals_rowmajor_product(hp, orc):
+    """The 5-point matrix x 16: the column-major product equals the row-major (run-tile / gather) product bit for bit."""
+    import torch
+    nx, ny, k = 256, 130, 16
+    n = nx * ny
+    rows = orc.poisson2d_rows(nx, ny, 0, n)
+    ci, cv = orc.compress_columns(rows)
+    B = orc.fill_uniform(0, n * k, 77).reshape(n, k)
+    rp, cvd, nz = _t(rows.rowptr.astype(np.int32)), _t(cv.astype(np.int32)), _t(rows.vals)
+    Br, Bc = _t(B), _t(B.T)
+    Cr = torch.empty((n, k), dtype=torch.float64, device="cuda")
+    Cc = torch.empty((k, n), dtype=torch.float64, device="cuda")
+    ROW, COL = hp._capi.LAYOUT_ROW, hp._capi.LAYOUT_COL
+    hp._capi.call("hpcla_spmm_csr_f64_i32", rp.data_ptr(), cvd.data_ptr(), nz.data_ptr(), Br.data_ptr(), k, ROW, Cr.data_ptr(), k, ROW,
+                  n, len(rows.vals), k, 0, _stream())
+    hp._capi.call("hpcla_spmm_csr_f64_i32", rp.data_ptr(), cvd.data_ptr(), nz.data_ptr(), Bc.data_ptr(), n, COL, Cc.data_ptr(), n, COL,
+                  n, len(rows.vals), k, 0, _stream())
+    assert torch.equal(Cr, Cc.t())
+    np.testing.assert_array_equal(Cr.cpu().numpy(), orc.spmm(rows.rowptr.astype(np.int32), cv.astype(np.int32), rows.vals, B[ci]))
+
+
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_colmajor_product_across_ranks(nranks):
+    """Real processes (peer-window push on a shared GPU): the exchange posted from a column-major block
+    (hpcla_halo_begin_strided_f64 / _f32), interior blocks overlapping it, boundary blocks behind it; tests/_multirank_colmajor_worker.py."""
+    from hpcla_amd.launch import spawn_ranks
+    os.environ.pop("HPCLA_HALO_MODE", None)
+    rc = spawn_ranks([os.path.join(ROOT, "tests", "_multirank_colmajor_worker.py")], nranks,
+                     env_extra={"HPCLA_PUSH_TIMEOUT_S": "30"}, timeout=600, forward_rank0_stdout=False)
+    assert rc == 0
