@@ -145,6 +145,8 @@ def _measure_spmm(args, job, hp, wl, A, B, k, world, dev, setup_s, metric, workl
                              "(gather_bytes = one 128-byte line per stored entry), which is what HBM actually serves"},
         "setup_s": round(setup_s, 2),
     }
+    if world == 1 and "5-pt" in workload and os.environ.get("HPCLA_BENCH_COLMAJOR", "1") != "0":
+        out["column_major_caller"] = _colmajor_cost(hp, A, B, k, b_alg)
     if world > 1:
         # the exchange side of the step ("report against both HBM and xGMI rooflines"):
         # ghost rows of B that cross xGMI per step, against 7 point-to-point links of ~153 GB/s per direction
@@ -166,6 +168,59 @@ def _measure_spmm(args, job, hp, wl, A, B, k, world, dev, setup_s, metric, workl
                     "per peer (point to point), at most 7; frac = achieved ingress / that peak over the WALL time of a step "
                     "(exchange and kernel together); comm_bound / hbm_bound = the step's two lower bounds"}
     return out
+
+
+def _colmajor_cost(hp, A, B, k, b_alg):
+    """What the same product costs a COLUMN-major caller -- Julia's Matrix, the layout of the reference's dense block
+    (src/dense.jl:63) -- through the raw C ABI on the plan's own arrays: (a) the product on the column-major blocks as they are
+    (csrc/colmajor.hip: hpcla_spmm_csr_f64_* with both layouts HPCLA_LAYOUT_COL), which is what the Julia extension calls for
+    banded matrices, against (b) the two layout conversions around the row-major product it used before."""
+    import torch
+    from hpcla_amd.sparse import get_vector_plan
+    from hpcla_amd.vectors import HPCVector, current_stream_ptr, dptr
+    from hpcla_amd.partition import compute_partition_hash
+    capi = hp._capi
+    probe = HPCVector(compute_partition_hash(B.row_partition), B.row_partition, B.A[:, 0], A.backend)
+    plan = get_vector_plan(A, probe)
+    sfx = "i64" if plan.is_i64 else "i32"
+    rp, cv = plan.rowptr_of(A), plan.colval_split
+    n, nb = A.nrows_local, int(B.A.shape[0])
+    Bc = B.A.t().contiguous()                                   # k x nb: the column-major block
+    Cc = torch.empty((k, n), dtype=torch.float64, device=B.A.device)
+    Br, Cr = torch.empty_like(B.A), torch.empty((n, k), dtype=torch.float64, device=B.A.device)
+    ROW, COL = capi.LAYOUT_ROW, capi.LAYOUT_COL
+    s = current_stream_ptr()
+
+    def direct():
+        capi.call(f"hpcla_spmm_csr_f64_{sfx}", dptr(rp), dptr(cv), dptr(A.nzval), dptr(Bc), nb, COL, dptr(Cc), n, COL, n, A.nnz, k, 0, s)
+
+    def converted():
+        capi.call("hpcla_transpose_f64", dptr(Bc), nb, COL, dptr(Br), k, ROW, nb, k, s)
+        capi.call(f"hpcla_spmm_csr_f64_{sfx}", dptr(rp), dptr(cv), dptr(A.nzval), dptr(Br), k, ROW, dptr(Cr), k, ROW, n, A.nnz, k, 0, s)
+        capi.call("hpcla_transpose_f64", dptr(Cr), k, ROW, dptr(Cc), n, COL, n, k, s)
+
+    def timed(fn, reps=20):
+        t_end = time.perf_counter() + SETTLE_MS * 1e-3
+        while time.perf_counter() < t_end:
+            fn()
+            torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+    converted()
+    ref = Cc.clone()
+    direct()
+    same = bool(torch.equal(ref, Cc))
+    ms_d, ms_c = timed(direct), timed(converted)
+    return {"direct_ms": round(ms_d, 4), "direct_frac_of_peak": round(b_alg / (ms_d * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "kernel": "hpcla::rowgather_kernel<double, int, false, 16, 2>",
+            "via_two_layout_conversions_ms": round(ms_c, 4), "same_bits": same,
+            "note": "the product as a column-major caller (Julia's Matrix) gets it: on the blocks as they are (lanes = rows kernel) "
+                    "against transpose + row-major product + transpose; the record's own ms_per_step is the row-major host layer"}
 
 
 def device_stencil(hp, torch, backend, dims, lo, hi):

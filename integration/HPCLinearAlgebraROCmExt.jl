@@ -433,14 +433,16 @@ Base.minimum(v::HPCVector{T,B}) where {T<:Float64,B<:ROCBackend} = -_reduce_scal
 # ---- A * B, B::HPCMatrix  (replaces the column loop of src/sparse.jl:2391-2413) ---------------------------
 # Julia's Matrix is column-major; the kernel's fast layout is row-major (one 128-byte line per B row at
 # k = 16), so B is converted once with hpcla_transpose_f64 and C converted back.
-const _spmm_plans = IdDict{Any,Any}()     # (reference plan, k) -> (halo handle, interior, boundary, send_idx, ghost pointer); freed by clear_rocm_plan_cache!
+const _spmm_plans = IdDict{Any,Any}()     # (reference plan, k, rows per block) -> (halo handle, interior, boundary, send_idx, ghost pointer); freed by clear_rocm_plan_cache!
 
 # width-k halo plan for the ghost ROWS of B: the reference VectorPlan's own lists, `width = k` values per index
 # (row-major rows travel as contiguous k-doubles).  The Python twin additionally swaps a neighbour's requested
 # rows for its WHOLE slice when more than half of it is needed (config 5; linearalgebrampi.jl_amd/sparse.py
 # whole_slice_lists) -- an optimisation of the lists, not of this binding.
-function _spmm_halo(A::HPCSparseMatrix{T,Ti,B}, plan, d::ROCVectorPlan{Tk}, k::Int) where {T,Ti,Tk,B<:ROCBackend}
-    get!(_spmm_plans, (plan, k)) do
+# `rpb`: rows per block of the kernels that will take the interior / boundary lists (the row-major Float64 kernels of
+# spmm.hip: hpcla_spmm_rows_per_block(); the lanes = rows kernels -- column-major blocks, Float32 --: the SpMV's 256).
+function _spmm_halo(A::HPCSparseMatrix{T,Ti,B}, plan, d::ROCVectorPlan{Tk}, k::Int, rpb::Cint) where {T,Ti,Tk,B<:ROCBackend}
+    get!(_spmm_plans, (plan, k, rpb)) do
         halo = Ref{Ptr{Cvoid}}(C_NULL)
         send_idx = ROCVector(Tk.(reduce(vcat, plan.send_indices; init=Ti[]) .- one(Ti)))
         AMDGPU.synchronize()
@@ -456,8 +458,6 @@ function _spmm_halo(A::HPCSparseMatrix{T,Ti,B}, plan, d::ROCVectorPlan{Tk}, k::I
         A.backend.comm isa CommMPI &&
             _attach_halo_window(_rccl(A.backend.comm), halo[], A.backend.comm.comm, comm_size(A.backend.comm),
                                 (d.n_own, d.segments))
-        # SpMM row blocks are smaller than SpMV's; the Float32 product (csrc/f32.hip) runs on the SpMV's 256-row blocks
-        rpb = T === Float32 ? (@ccall LIB.hpcla_spmv_rows_per_block()::Cint) : (@ccall LIB.hpcla_spmm_rows_per_block()::Cint)
         flags = AMDGPU.zeros(Int32, cld(A.nrows_local, rpb))
         rp0 = d.rowptr0
         if Tk === Int32
@@ -481,10 +481,9 @@ end
 # runs of B rows; their descriptors are built once per plan (hpcla_spmm_runs_build_*) and the product then stages the
 # runs' rows into LDS instead of gathering a row per stored entry (5-point matrix x 16: 0.47 ms against 0.52, same bits).
 # Used when (nearly) all blocks fit; unstructured matrices keep the gather kernel.
-const _spmm_runs_cache = IdDict{Any,Any}()     # device plan -> run descriptors (ROCVector{UInt8}) or nothing
-function _spmm_runs(A, d::ROCVectorPlan{Tk}) where {Tk}
+const _spmm_runs_cache = IdDict{Any,Any}()     # device plan -> (run descriptors::ROCVector{UInt8}, banded::Bool)
+function _spmm_runs_info(A, d::ROCVectorPlan{Tk}) where {Tk}
     get!(_spmm_runs_cache, d) do
-        get(ENV, "HPCLA_SPMM_RUNS", "1") == "0" && return nothing
         desc = AMDGPU.zeros(UInt8, @ccall LIB.hpcla_spmm_runs_desc_bytes(A.nrows_local::Int64)::Int64)
         nfit = Ref{Int64}(0); nnz = length(A.nzval)
         if Tk === Int32
@@ -496,8 +495,64 @@ function _spmm_runs(A, d::ROCVectorPlan{Tk}) where {Tk}
                    A.nrows_local::Int64, nnz::Int64, 0::Cint, d.n_own::Int64, _ptr(desc)::Ptr{Cvoid}, nfit::Ptr{Int64},
                    _stream()::Ptr{Cvoid})::Cint), "hpcla_spmm_runs_build_i64")
         end
-        nfit[] >= 0.99 * cld(A.nrows_local, 64) ? desc : nothing
+        (desc, nfit[] >= 0.99 * cld(A.nrows_local, 64))
     end
+end
+_spmm_runs(A, d) = get(ENV, "HPCLA_SPMM_RUNS", "1") == "0" ? nothing : ((desc, fits) = _spmm_runs_info(A, d); fits ? desc : nothing)
+# BANDED structure (every stencil): (nearly) every 64-row block touches a few contiguous runs of columns.  There the
+# lanes = rows kernels read a column-major block -- Julia's Matrix -- in contiguous runs, so A * B runs on the caller's arrays
+# as they are (csrc/colmajor.hip: 0.67 ms on the 5-point matrix x 16 where the two layout conversions around the row-major
+# product cost 1.52 ms); an unstructured matrix touches a line per (entry, column) pair in that layout and keeps the
+# conversions.  HPCLA_SPMM_COLMAJOR=0 switches the direct path off.
+_banded(A, d) = get(ENV, "HPCLA_SPMM_COLMAJOR", "1") != "0" && _spmm_runs_info(A, d)[2]
+
+# A * B on the column-major blocks themselves (T = Float64 or Float32): without neighbours one launch; with neighbours the
+# exchange is posted from the column-major block (hpcla_halo_begin_strided_*: the rows the plan sends are staged row-major,
+# Float32 values widened), interior 256-row blocks overlap it, boundary blocks read the plan's row-major ghost segment.
+function _spmm_colmajor(A::HPCSparseMatrix{T,Ti,B}, M::HPCMatrix{T,B}, plan, d::ROCVectorPlan{Tk}) where {T<:Union{Float32,Float64},Ti,Tk,B<:ROCBackend}
+    nloc, k = size(M.A)
+    C = AMDGPU.zeros(T, A.nrows_local, k)
+    nnz = length(A.nzval); ldb = max(nloc, 1); ldc = max(A.nrows_local, 1)
+    function launch(ghost::Ptr{Cvoid}, blocks::Ptr{Cvoid}, nblocks::Int64)
+        if T === Float64 && Tk === Int32
+            _check(@ccall(LIB.hpcla_spmm_split_colmajor_f64_i32(_ptr(d.rowptr0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
+                   _ptr(A.nzval)::Ptr{Cvoid}, _ptr(M.A)::Ptr{Cvoid}, ldb::Int64, ghost::Ptr{Cvoid}, k::Int64, d.n_own::Int64,
+                   _ptr(C)::Ptr{Cvoid}, ldc::Int64, A.nrows_local::Int64, nnz::Int64, k::Cint, 0::Cint, blocks::Ptr{Cvoid},
+                   nblocks::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_spmm_split_colmajor_f64_i32")
+        elseif T === Float64
+            _check(@ccall(LIB.hpcla_spmm_split_colmajor_f64_i64(_ptr(d.rowptr0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
+                   _ptr(A.nzval)::Ptr{Cvoid}, _ptr(M.A)::Ptr{Cvoid}, ldb::Int64, ghost::Ptr{Cvoid}, k::Int64, d.n_own::Int64,
+                   _ptr(C)::Ptr{Cvoid}, ldc::Int64, A.nrows_local::Int64, nnz::Int64, k::Cint, 0::Cint, blocks::Ptr{Cvoid},
+                   nblocks::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_spmm_split_colmajor_f64_i64")
+        elseif Tk === Int32
+            _check(@ccall(LIB.hpcla_spmm_split_colmajor_f32_i32(_ptr(d.rowptr0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
+                   _ptr(A.nzval)::Ptr{Cvoid}, _ptr(M.A)::Ptr{Cvoid}, ldb::Int64, ghost::Ptr{Cvoid}, k::Int64, d.n_own::Int64,
+                   _ptr(C)::Ptr{Cvoid}, ldc::Int64, A.nrows_local::Int64, nnz::Int64, k::Cint, 0::Cint, blocks::Ptr{Cvoid},
+                   nblocks::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_spmm_split_colmajor_f32_i32")
+        else
+            _check(@ccall(LIB.hpcla_spmm_split_colmajor_f32_i64(_ptr(d.rowptr0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
+                   _ptr(A.nzval)::Ptr{Cvoid}, _ptr(M.A)::Ptr{Cvoid}, ldb::Int64, ghost::Ptr{Cvoid}, k::Int64, d.n_own::Int64,
+                   _ptr(C)::Ptr{Cvoid}, ldc::Int64, A.nrows_local::Int64, nnz::Int64, k::Cint, 0::Cint, blocks::Ptr{Cvoid},
+                   nblocks::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_spmm_split_colmajor_f32_i64")
+        end
+    end
+    if d.halo == C_NULL
+        launch(C_NULL, C_NULL, Int64(0))                         # every row block, every column owned
+    else
+        halo, interior, boundary, _, ghost = _spmm_halo(A, plan, d, k, (@ccall LIB.hpcla_spmv_rows_per_block()::Cint))
+        stage = _stage(d, d.n_own * k)
+        if T === Float64
+            _check(@ccall(LIB.hpcla_halo_begin_strided_f64(halo::Ptr{Cvoid}, _ptr(M.A)::Ptr{Cvoid}, 1::Int64, ldb::Int64,
+                   _ptr(stage)::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_halo_begin_strided_f64")
+        else
+            _check(@ccall(LIB.hpcla_halo_begin_strided_f32(halo::Ptr{Cvoid}, _ptr(M.A)::Ptr{Cvoid}, 1::Int64, ldb::Int64,
+                   _ptr(stage)::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_halo_begin_strided_f32")
+        end
+        isempty(interior) || launch(C_NULL, _ptr(interior), Int64(length(interior)))     # overlaps the exchange
+        _check(@ccall(LIB.hpcla_halo_end(halo::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_halo_end")
+        isempty(boundary) || launch(ghost, _ptr(boundary), Int64(length(boundary)))
+    end
+    return HPCLinearAlgebra.HPCMatrix_local(C, A.backend)
 end
 
 function _spmm_split!(Crow, A::HPCSparseMatrix{T,Ti,B}, d, Brow, ghost::Ptr{Cvoid}, k::Int, blocks) where {T,Ti,B}
@@ -530,6 +585,10 @@ end
 function Base.:*(A::HPCSparseMatrix{T,Ti,B}, M::HPCMatrix{T,B}) where {T<:Float64,Ti,B<:ROCBackend}
     assert_backends_compatible(A.backend, M.backend)
     nloc, k = size(M.A)
+    let probe = HPCVector{T,B}(compute_partition_hash(M.row_partition), M.row_partition, similar(A.nzval, nloc), A.backend),
+        plan = get_vector_plan(A, probe), d = _device_plan(A, probe, plan)
+        k > 1 && _banded(A, d) && return _spmm_colmajor(A, M, plan, d)       # banded structure: no layout conversion
+    end
     Brow = AMDGPU.zeros(T, k, nloc)                 # k x nloc column-major == nloc x k row-major
     _check(@ccall(LIB.hpcla_transpose_f64(_ptr(M.A)::Ptr{Cvoid}, nloc::Int64, 1::Cint, _ptr(Brow)::Ptr{Cvoid}, k::Int64,
            0::Cint, nloc::Int64, k::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_transpose_f64")
@@ -541,7 +600,7 @@ function Base.:*(A::HPCSparseMatrix{T,Ti,B}, M::HPCMatrix{T,B}) where {T<:Float6
     if isempty(plan.send_rank_ids) && isempty(plan.recv_rank_ids)
         _spmm_split!(Crow, A, d, Brow, C_NULL, k, ROCVector(Int32.(0:cld(A.nrows_local, (@ccall LIB.hpcla_spmm_rows_per_block()::Cint))-1)))
     else
-        halo, interior, boundary, _, ghost = _spmm_halo(A, plan, d, k)
+        halo, interior, boundary, _, ghost = _spmm_halo(A, plan, d, k, (@ccall LIB.hpcla_spmm_rows_per_block()::Cint))
         _check(@ccall(LIB.hpcla_halo_begin(halo::Ptr{Cvoid}, _ptr(Brow)::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_halo_begin")
         _spmm_split!(Crow, A, d, Brow, ghost, k, interior)         # rows without ghost columns overlap the exchange
         _check(@ccall(LIB.hpcla_halo_end(halo::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_halo_end")
@@ -561,7 +620,7 @@ end
 # and rounded to Float32 once.  Ghost values travel widened to Float64 (exact both ways), so every halo transport is the
 # Float64 one.  Everything else (CG pieces, transposes, sparse products and sums, repartition) keeps the parent's generic
 # methods for Float32.
-const _stage32 = IdDict{Any,Any}()      # device plan -> staging vector of its Float32 exchanges (ROCVector{Float64})
+const _stage32 = IdDict{Any,Any}()      # device plan -> staging vector (ROCVector{Float64}) of its Float32 / column-major exchanges
 _stage(d, n::Int) = (st = get(_stage32, d, nothing); (st === nothing || length(st) < n) ? (_stage32[d] = AMDGPU.zeros(Float64, max(n, 1))) : st)
 
 # y (nrows_local values at `yp`) = A * (x: n_own values at `xp`); both may point into a column of a Matrix
@@ -618,23 +677,21 @@ function LinearAlgebra.mul!(y::HPCVector{Float32,B}, A::HPCSparseMatrix{Float32,
     return y
 end
 
-# A * B, B::HPCMatrix (src/sparse.jl:2391-2413).  Without neighbours: ONE pass over A for all k columns on Julia's
-# column-major arrays as they are (hpcla_spmm_csr_f32_*, HPCLA_LAYOUT_COL).  With neighbours: like the Float64 product --
-# B converted once to row-major rows (hpcla_transpose_f32), whose ghost rows travel widened in ONE width-k exchange
-# (_spmm_halo's plan, hpcla_halo_begin_f32) that the interior blocks overlap; C converted back.
-function _spmm_split_f32!(Crow, A::HPCSparseMatrix{Float32,Ti,B}, d::ROCVectorPlan{Tk}, Brow, ghost::Ptr{Cvoid}, k::Int, blocks) where {Ti,Tk,B}
-    isempty(blocks) && return
+# A * B, B::HPCMatrix (src/sparse.jl:2391-2413): like the Float64 product -- banded structure: on the column-major blocks as
+# they are (_spmm_colmajor); unstructured: B converted once to row-major rows (hpcla_transpose_f32), whose ghost rows travel
+# widened in ONE width-k exchange that the interior blocks overlap, the row-major Float32 kernels, C converted back.
+function _spmm_split_f32!(Crow, A::HPCSparseMatrix{Float32,Ti,B}, d::ROCVectorPlan{Tk}, Brow, ghost::Ptr{Cvoid}, k::Int, blocks::Ptr{Cvoid}, nblocks::Int64) where {Ti,Tk,B}
     nnz = length(A.nzval)
     if Tk === Int32
         _check(@ccall(LIB.hpcla_spmm_split_f32_i32(_ptr(d.rowptr0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
                _ptr(A.nzval)::Ptr{Cvoid}, _ptr(Brow)::Ptr{Cvoid}, k::Int64, ghost::Ptr{Cvoid}, k::Int64, d.n_own::Int64,
                _ptr(Crow)::Ptr{Cvoid}, k::Int64, A.nrows_local::Int64, nnz::Int64, k::Cint, 0::Cint,
-               _ptr(blocks)::Ptr{Cvoid}, length(blocks)::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_spmm_split_f32_i32")
+               blocks::Ptr{Cvoid}, nblocks::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_spmm_split_f32_i32")
     else
         _check(@ccall(LIB.hpcla_spmm_split_f32_i64(_ptr(d.rowptr0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
                _ptr(A.nzval)::Ptr{Cvoid}, _ptr(Brow)::Ptr{Cvoid}, k::Int64, ghost::Ptr{Cvoid}, k::Int64, d.n_own::Int64,
                _ptr(Crow)::Ptr{Cvoid}, k::Int64, A.nrows_local::Int64, nnz::Int64, k::Cint, 0::Cint,
-               _ptr(blocks)::Ptr{Cvoid}, length(blocks)::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_spmm_split_f32_i64")
+               blocks::Ptr{Cvoid}, nblocks::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_spmm_split_f32_i64")
     end
 end
 
@@ -644,34 +701,24 @@ function Base.:*(A::HPCSparseMatrix{Float32,Ti,B}, M::HPCMatrix{Float32,B}) wher
     probe = HPCVector{Float32,B}(compute_partition_hash(M.row_partition), M.row_partition, similar(A.nzval, nloc), A.backend)   # plan key only
     plan = get_vector_plan(A, probe)
     d = _device_plan(A, probe, plan)
-    C = AMDGPU.zeros(Float32, A.nrows_local, k)
-    nnz = length(A.nzval)
+    _banded(A, d) && return _spmm_colmajor(A, M, plan, d)
+    Brow = AMDGPU.zeros(Float32, k, nloc)                 # k x nloc column-major == nloc x k row-major
+    _check(@ccall(LIB.hpcla_transpose_f32(_ptr(M.A)::Ptr{Cvoid}, nloc::Int64, 1::Cint, _ptr(Brow)::Ptr{Cvoid}, k::Int64,
+           0::Cint, nloc::Int64, k::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_transpose_f32")
+    Crow = AMDGPU.zeros(Float32, k, A.nrows_local)
     if d.halo == C_NULL
-        if eltype(d.rowptr0) === Int32
-            _check(@ccall(LIB.hpcla_spmm_csr_f32_i32(_ptr(d.rowptr0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
-                   _ptr(A.nzval)::Ptr{Cvoid}, _ptr(M.A)::Ptr{Cvoid}, max(nloc, 1)::Int64, 1::Cint, _ptr(C)::Ptr{Cvoid},
-                   max(A.nrows_local, 1)::Int64, 1::Cint, A.nrows_local::Int64, nnz::Int64, k::Cint, 0::Cint,
-                   _stream()::Ptr{Cvoid})::Cint), "hpcla_spmm_csr_f32_i32")
-        else
-            _check(@ccall(LIB.hpcla_spmm_csr_f32_i64(_ptr(d.rowptr0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
-                   _ptr(A.nzval)::Ptr{Cvoid}, _ptr(M.A)::Ptr{Cvoid}, max(nloc, 1)::Int64, 1::Cint, _ptr(C)::Ptr{Cvoid},
-                   max(A.nrows_local, 1)::Int64, 1::Cint, A.nrows_local::Int64, nnz::Int64, k::Cint, 0::Cint,
-                   _stream()::Ptr{Cvoid})::Cint), "hpcla_spmm_csr_f32_i64")
-        end
+        _spmm_split_f32!(Crow, A, d, Brow, C_NULL, k, C_NULL, Int64(0))
     else
-        Brow = AMDGPU.zeros(Float32, k, nloc)                 # k x nloc column-major == nloc x k row-major
-        _check(@ccall(LIB.hpcla_transpose_f32(_ptr(M.A)::Ptr{Cvoid}, nloc::Int64, 1::Cint, _ptr(Brow)::Ptr{Cvoid}, k::Int64,
-               0::Cint, nloc::Int64, k::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_transpose_f32")
-        Crow = AMDGPU.zeros(Float32, k, A.nrows_local)
-        halo, interior, boundary, _, ghost = _spmm_halo(A, plan, d, k)
+        halo, interior, boundary, _, ghost = _spmm_halo(A, plan, d, k, (@ccall LIB.hpcla_spmv_rows_per_block()::Cint))
         _check(@ccall(LIB.hpcla_halo_begin_f32(halo::Ptr{Cvoid}, _ptr(Brow)::Ptr{Cvoid}, _ptr(_stage(d, d.n_own * k))::Ptr{Cvoid},
                _stream()::Ptr{Cvoid})::Cint), "hpcla_halo_begin_f32")
-        _spmm_split_f32!(Crow, A, d, Brow, C_NULL, k, interior)       # rows without ghost columns overlap the exchange
+        isempty(interior) || _spmm_split_f32!(Crow, A, d, Brow, C_NULL, k, _ptr(interior), Int64(length(interior)))   # overlaps the exchange
         _check(@ccall(LIB.hpcla_halo_end(halo::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_halo_end")
-        _spmm_split_f32!(Crow, A, d, Brow, ghost, k, boundary)
-        _check(@ccall(LIB.hpcla_transpose_f32(_ptr(Crow)::Ptr{Cvoid}, k::Int64, 0::Cint, _ptr(C)::Ptr{Cvoid},
-               A.nrows_local::Int64, 1::Cint, A.nrows_local::Int64, k::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_transpose_f32")
+        isempty(boundary) || _spmm_split_f32!(Crow, A, d, Brow, ghost, k, _ptr(boundary), Int64(length(boundary)))
     end
+    C = AMDGPU.zeros(Float32, A.nrows_local, k)
+    _check(@ccall(LIB.hpcla_transpose_f32(_ptr(Crow)::Ptr{Cvoid}, k::Int64, 0::Cint, _ptr(C)::Ptr{Cvoid},
+           A.nrows_local::Int64, 1::Cint, A.nrows_local::Int64, k::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_transpose_f32")
     return HPCLinearAlgebra.HPCMatrix_local(C, A.backend)
 end
 
