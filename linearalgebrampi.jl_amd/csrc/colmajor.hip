@@ -46,7 +46,8 @@ static int colmajor_launch(const I *rowptr, const I *colval, const double *nzval
     const int vec_ok = stage_vec_ok<double, I>(colval, nzval);
     const bool split = b.ghost != nullptr;
     hipStream_t s = as_stream(stream);
-    const int nt = c_rs == 1;                   // contiguous result runs: stored non-temporally (written once, read by nothing)
+    const int nt = c_rs == 1;                   // contiguous result runs: stored non-temporally (written once, read by nothing;
+                                                // measured neutral here, 0.6346 / 0.6352 ms with / without)
 #define HPCLA_COLMAJOR(KC, UR)                                                                                              \
     do {                                                                                                                    \
         const int groups = (k + KC - 1) / KC;                                                                               \
