@@ -511,7 +511,7 @@ _banded(A, d) = get(ENV, "HPCLA_SPMM_COLMAJOR", "1") != "0" && _spmm_runs_info(A
 # Float32 values widened), interior 256-row blocks overlap it, boundary blocks read the plan's row-major ghost segment.
 function _spmm_colmajor(A::HPCSparseMatrix{T,Ti,B}, M::HPCMatrix{T,B}, plan, d::ROCVectorPlan{Tk}) where {T<:Union{Float32,Float64},Ti,Tk,B<:ROCBackend}
     nloc, k = size(M.A)
-    C = AMDGPU.zeros(T, A.nrows_local, k)
+    C = ROCMatrix{T}(undef, A.nrows_local, k)          # every row block is launched: no zero fill
     nnz = length(A.nzval); ldb = max(nloc, 1); ldc = max(A.nrows_local, 1)
     function launch(ghost::Ptr{Cvoid}, blocks::Ptr{Cvoid}, nblocks::Int64)
         if T === Float64 && Tk === Int32
@@ -589,10 +589,10 @@ function Base.:*(A::HPCSparseMatrix{T,Ti,B}, M::HPCMatrix{T,B}) where {T<:Float6
         plan = get_vector_plan(A, probe), d = _device_plan(A, probe, plan)
         k > 1 && _banded(A, d) && return _spmm_colmajor(A, M, plan, d)       # banded structure: no layout conversion
     end
-    Brow = AMDGPU.zeros(T, k, nloc)                 # k x nloc column-major == nloc x k row-major
+    Brow = ROCMatrix{T}(undef, k, nloc)             # k x nloc column-major == nloc x k row-major (written whole: no zero fill)
     _check(@ccall(LIB.hpcla_transpose_f64(_ptr(M.A)::Ptr{Cvoid}, nloc::Int64, 1::Cint, _ptr(Brow)::Ptr{Cvoid}, k::Int64,
            0::Cint, nloc::Int64, k::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_transpose_f64")
-    Crow = AMDGPU.zeros(T, k, A.nrows_local)
+    Crow = ROCMatrix{T}(undef, k, A.nrows_local)
     # the vector plan for (A, B's row partition) provides neighbour lists and the split column space
     probe = HPCVector{T,B}(compute_partition_hash(M.row_partition), M.row_partition, similar(A.nzval, nloc), A.backend)   # plan key only
     plan = get_vector_plan(A, probe)
@@ -606,7 +606,7 @@ function Base.:*(A::HPCSparseMatrix{T,Ti,B}, M::HPCMatrix{T,B}) where {T<:Float6
         _check(@ccall(LIB.hpcla_halo_end(halo::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_halo_end")
         _spmm_split!(Crow, A, d, Brow, ghost, k, boundary)
     end
-    C = AMDGPU.zeros(T, A.nrows_local, k)
+    C = ROCMatrix{T}(undef, A.nrows_local, k)
     _check(@ccall(LIB.hpcla_transpose_f64(_ptr(Crow)::Ptr{Cvoid}, k::Int64, 0::Cint, _ptr(C)::Ptr{Cvoid},
            A.nrows_local::Int64, 1::Cint, A.nrows_local::Int64, k::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_transpose_f64")
     return HPCLinearAlgebra.HPCMatrix_local(C, A.backend)
@@ -702,10 +702,10 @@ function Base.:*(A::HPCSparseMatrix{Float32,Ti,B}, M::HPCMatrix{Float32,B}) wher
     plan = get_vector_plan(A, probe)
     d = _device_plan(A, probe, plan)
     _banded(A, d) && return _spmm_colmajor(A, M, plan, d)
-    Brow = AMDGPU.zeros(Float32, k, nloc)                 # k x nloc column-major == nloc x k row-major
+    Brow = ROCMatrix{Float32}(undef, k, nloc)             # k x nloc column-major == nloc x k row-major
     _check(@ccall(LIB.hpcla_transpose_f32(_ptr(M.A)::Ptr{Cvoid}, nloc::Int64, 1::Cint, _ptr(Brow)::Ptr{Cvoid}, k::Int64,
            0::Cint, nloc::Int64, k::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_transpose_f32")
-    Crow = AMDGPU.zeros(Float32, k, A.nrows_local)
+    Crow = ROCMatrix{Float32}(undef, k, A.nrows_local)
     if d.halo == C_NULL
         _spmm_split_f32!(Crow, A, d, Brow, C_NULL, k, C_NULL, Int64(0))
     else
@@ -716,7 +716,7 @@ function Base.:*(A::HPCSparseMatrix{Float32,Ti,B}, M::HPCMatrix{Float32,B}) wher
         _check(@ccall(LIB.hpcla_halo_end(halo::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_halo_end")
         isempty(boundary) || _spmm_split_f32!(Crow, A, d, Brow, ghost, k, _ptr(boundary), Int64(length(boundary)))
     end
-    C = AMDGPU.zeros(Float32, A.nrows_local, k)
+    C = ROCMatrix{Float32}(undef, A.nrows_local, k)
     _check(@ccall(LIB.hpcla_transpose_f32(_ptr(Crow)::Ptr{Cvoid}, k::Int64, 0::Cint, _ptr(C)::Ptr{Cvoid},
            A.nrows_local::Int64, 1::Cint, A.nrows_local::Int64, k::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_transpose_f32")
     return HPCLinearAlgebra.HPCMatrix_local(C, A.backend)
