@@ -597,6 +597,9 @@ class HPCSparseMatrix:
         if plan.is_i64:
             self.packed_reason = "Int64 indices"
             return False
+        if plan.is_f32:
+            self.packed_reason = "Float32 values (the packed copy is a Float64 kernel)"
+            return False
         h = ctypes.c_void_p()
         rc = _capi.load().hpcla_packed_create_i32(
             ctypes.byref(h), dptr(plan.rowptr_of(self)), dptr(plan.colval_split), dptr(self.nzval),
