@@ -431,8 +431,10 @@ Base.maximum(v::HPCVector{T,B}) where {T<:Float64,B<:ROCBackend} = _reduce_scala
 Base.minimum(v::HPCVector{T,B}) where {T<:Float64,B<:ROCBackend} = -_reduce_scalar(:max, v, 1)      # min x = -max(-x)
 
 # ---- A * B, B::HPCMatrix  (replaces the column loop of src/sparse.jl:2391-2413) ---------------------------
-# Julia's Matrix is column-major; the kernel's fast layout is row-major (one 128-byte line per B row at
-# k = 16), so B is converted once with hpcla_transpose_f64 and C converted back.
+# Julia's Matrix is column-major.  BANDED structures (every stencil) are multiplied on the column-major blocks as they are
+# (_spmm_colmajor below: lanes = rows, a wave reads one contiguous run of a column per gather instruction).  Unstructured
+# matrices would touch a line per (entry, column) pair in that layout; for them the fast layout is row-major (one 128-byte
+# line per B row at k = 16), so B is converted once with hpcla_transpose_f64 and C converted back.
 const _spmm_plans = IdDict{Any,Any}()     # (reference plan, k, rows per block) -> (halo handle, interior, boundary, send_idx, ghost pointer); freed by clear_rocm_plan_cache!
 
 # width-k halo plan for the ghost ROWS of B: the reference VectorPlan's own lists, `width = k` values per index
