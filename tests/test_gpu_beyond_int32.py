@@ -112,3 +112,54 @@ def test_spmv_and_spmm_with_more_than_2_31_entries(hp):
     torch.cuda.synchronize()
     del nz32, x32, y32, colval, rowptr
     torch.cuda.empty_cache()
+
+
+def test_more_than_2_31_rows(hp):
+    """n = 2^31 + 5 rows with one stored entry each: row-block indices times 256, row offsets and vector lengths beyond Int32
+    in the SpMV, the reductions and the updates.  Small integers again: exact, order-independent, compared bit for bit with
+    chunked int64 arithmetic on the device.  ~90 GB."""
+    import torch
+    n = 2 ** 31 + 5
+    free, _total = torch.cuda.mem_get_info()
+    if free < 120 * 2 ** 30:
+        pytest.skip(f"needs ~90 GB of free device memory, {free / 2**30:.0f} GiB available")
+    dev = "cuda"
+    s = torch.cuda.current_stream().cuda_stream
+    ncols = 1_000_003
+    rowptr = torch.arange(0, n + 1, dtype=torch.int64, device=dev)
+    colval = torch.empty(n, dtype=torch.int64, device=dev)
+    nz = torch.empty(n, dtype=torch.float64, device=dev)
+    big = 2 ** 26
+    for r0 in range(0, n, big):
+        r1 = min(n, r0 + big)
+        i = torch.arange(r0, r1, dtype=torch.int64, device=dev)
+        colval[r0:r1] = i % ncols
+        nz[r0:r1] = ((i % 7) - 3).to(torch.float64)
+    xi = (torch.arange(ncols, dtype=torch.int64, device=dev) % 5) - 2
+    x = xi.to(torch.float64)
+    y = torch.full((n,), float("nan"), dtype=torch.float64, device=dev)
+    hp._capi.call("hpcla_spmv_csr_f64_i64", rowptr.data_ptr(), colval.data_ptr(), nz.data_ptr(), x.data_ptr(), y.data_ptr(), n, n, 0, s)
+    del rowptr
+    tot_dot = tot_sq = 0
+    for r0 in range(0, n, big):
+        r1 = min(n, r0 + big)
+        i = torch.arange(r0, r1, dtype=torch.int64, device=dev)
+        want = ((i % 7) - 3) * xi[i % ncols]
+        assert torch.equal(y[r0:r1], want.to(torch.float64)), f"rows [{r0}, {r1}) differ"
+        tot_dot += int((want * ((i % 7) - 3)).sum())
+        tot_sq += int((want * want).sum())
+    # reductions and an update over n > 2^31 elements: dot(y, nz), sum y^2, z = 2y - nz
+    out = torch.zeros(1, dtype=torch.float64, device=dev)
+    work = torch.empty(hp._capi.load().hpcla_reduce_work_bytes() // 8, dtype=torch.float64, device=dev)
+    hp._capi.call("hpcla_dot_f64", None, y.data_ptr(), nz.data_ptr(), n, out.data_ptr(), work.data_ptr(), s)
+    assert float(out.item()) == float(tot_dot)
+    hp._capi.call("hpcla_nrm2sq_f64", None, y.data_ptr(), n, out.data_ptr(), work.data_ptr(), s)
+    assert float(out.item()) == float(tot_sq)
+    del colval
+    z = torch.empty(n, dtype=torch.float64, device=dev)
+    hp._capi.call("hpcla_axpby_f64", 2.0, y.data_ptr(), -1.0, nz.data_ptr(), z.data_ptr(), n, s)
+    for r0 in range(0, n, big):
+        r1 = min(n, r0 + big)
+        assert torch.equal(z[r0:r1], 2.0 * y[r0:r1] - nz[r0:r1])
+    del x, y, z, nz
+    torch.cuda.empty_cache()
