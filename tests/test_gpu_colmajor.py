@@ -135,3 +135,52 @@ def test_colmajor_product_across_ranks(nranks):
     rc = spawn_ranks([os.path.join(ROOT, "tests", "_multirank_colmajor_worker.py")], nranks,
                      env_extra={"HPCLA_PUSH_TIMEOUT_S": "30"}, timeout=600, forward_rank0_stdout=False)
     assert rc == 0
+
+
+@pytest.mark.parametrize("dt", ["f64", "f32"])
+def test_special_values_propagate_like_the_reference_loop(hp, orc, dt):
+    """Inf, NaN, signed zeros and denormals in x / B and in the stored values: the kernels perform the reference loop's
+    operations one by one (acc = 0; acc += a * b, separately rounded), so Inf - Inf, 0 * Inf and the sign of an exact zero come
+    out as on the CPU -- SpMV, row-major and column-major SpMM.  (NaN payloads are not compared: IEEE leaves them open.)"""
+    import torch
+    T = np.float64 if dt == "f64" else np.float32
+    tT = torch.float64 if dt == "f64" else torch.float32
+    n, k = 2000, 4
+    rows = orc.sprand_rows(n, 0.01, 0, n)
+    ci, cv = orc.compress_columns(rows)
+    rng = np.random.default_rng(12)
+    vals = (rows.vals - 0.5).astype(T)
+    vals[rng.integers(0, len(vals), 40)] = 0.0
+    vals[rng.integers(0, len(vals), 40)] = -0.0
+    vals[rng.integers(0, len(vals), 10)] = np.inf
+    vals[rng.integers(0, len(vals), 5)] = np.finfo(T).tiny / 8          # denormal
+    for r, z in ((10, 0.0), (11, -0.0), (700, -0.0)):                     # whole rows of signed zeros: exact zero sums
+        vals[rows.rowptr[r]:rows.rowptr[r + 1]] = z
+    B = (rng.random((len(ci), k)) - 0.5).astype(T)
+    for col, special in enumerate((np.inf, -np.inf, np.nan, -0.0)):
+        B[rng.integers(0, len(ci), 25), col] = special
+    B[rng.integers(0, len(ci), 25), 0] = np.finfo(T).max                # overflow to Inf in a product or a sum
+    rp, cvd, nz = _t(rows.rowptr.astype(np.int32)), _t(cv.astype(np.int32)), _t(vals)
+    with np.errstate(all="ignore"):
+        want = orc.spmm(rows.rowptr.astype(np.int32), cv.astype(np.int32), vals, B)
+
+    def same(got, what):
+        np.testing.assert_array_equal(got, want, err_msg=what)             # NaN == NaN, values and infinities exact
+        assert np.array_equal(np.signbit(got[want == 0]), np.signbit(want[want == 0])), f"{what}: sign of zero"
+    assert np.isnan(want).any() and np.isinf(want).any() and (want == 0).any()
+    # SpMV per column
+    for c in range(k):
+        y = torch.full((n,), 7.0, dtype=tT, device="cuda")
+        hp._capi.call(f"hpcla_spmv_csr_{dt}_i32", rp.data_ptr(), cvd.data_ptr(), nz.data_ptr(), _t(np.ascontiguousarray(B[:, c])).data_ptr(),
+                      y.data_ptr(), n, len(vals), 0, _stream())
+        np.testing.assert_array_equal(y.cpu().numpy(), want[:, c], err_msg=f"SpMV column {c}")
+    ROW, COL = hp._capi.LAYOUT_ROW, hp._capi.LAYOUT_COL
+    Br, Bc = _t(B), _t(np.ascontiguousarray(B.T))
+    Cr = torch.full((n, k), 7.0, dtype=tT, device="cuda")
+    hp._capi.call(f"hpcla_spmm_csr_{dt}_i32", rp.data_ptr(), cvd.data_ptr(), nz.data_ptr(), Br.data_ptr(), k, ROW, Cr.data_ptr(), k, ROW,
+                  n, len(vals), k, 0, _stream())
+    same(Cr.cpu().numpy(), "row-major SpMM")
+    Cc = torch.full((k, n), 7.0, dtype=tT, device="cuda")
+    hp._capi.call(f"hpcla_spmm_csr_{dt}_i32", rp.data_ptr(), cvd.data_ptr(), nz.data_ptr(), Bc.data_ptr(), len(ci), COL, Cc.data_ptr(), n, COL,
+                  n, len(vals), k, 0, _stream())
+    same(Cc.cpu().numpy().T, "column-major SpMM")
