@@ -145,8 +145,10 @@ def _measure_spmm(args, job, hp, wl, A, B, k, world, dev, setup_s, metric, workl
                              "(gather_bytes = one 128-byte line per stored entry), which is what HBM actually serves"},
         "setup_s": round(setup_s, 2),
     }
-    if world == 1 and "5-pt" in workload and os.environ.get("HPCLA_BENCH_COLMAJOR", "1") != "0":
-        out["column_major_caller"] = _colmajor_cost(hp, A, B, k, b_alg)
+    if world == 1 and os.environ.get("HPCLA_BENCH_COLMAJOR", "1") != "0":
+        # banded structure: the direct column-major product AND the conversions; unstructured: the conversions only (the direct
+        # form touches a line per (entry, column) pair there -- the Julia extension never takes it)
+        out["column_major_caller"] = _colmajor_cost(hp, A, B, k, b_alg, direct_too="5-pt" in workload)
     if world > 1:
         # the exchange side of the step ("report against both HBM and xGMI rooflines"):
         # ghost rows of B that cross xGMI per step, against 7 point-to-point links of ~153 GB/s per direction
@@ -170,7 +172,7 @@ def _measure_spmm(args, job, hp, wl, A, B, k, world, dev, setup_s, metric, workl
     return out
 
 
-def _colmajor_cost(hp, A, B, k, b_alg):
+def _colmajor_cost(hp, A, B, k, b_alg, direct_too=True):
     """What the same product costs a COLUMN-major caller -- Julia's Matrix, the layout of the reference's dense block
     (src/dense.jl:63) -- through the raw C ABI on the plan's own arrays: (a) the product on the column-major blocks as they are
     (csrc/colmajor.hip: hpcla_spmm_csr_f64_* with both layouts HPCLA_LAYOUT_COL), which is what the Julia extension calls for
@@ -212,6 +214,13 @@ def _colmajor_cost(hp, A, B, k, b_alg):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps
     converted()
+    if not direct_too:
+        ms_c = timed(converted, 10)
+        return {"via_two_layout_conversions_ms": round(ms_c, 4),
+                "frac_of_peak": round(b_alg / (ms_c * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "note": "the product as a column-major caller (Julia's Matrix) gets it on an UNSTRUCTURED matrix: B converted to "
+                        "row-major rows, the row-major product, C converted back (the direct column-major form would touch a line "
+                        "per (entry, column) pair here); the record's own ms_per_step is the row-major host layer"}
     ref = Cc.clone()
     direct()
     same = bool(torch.equal(ref, Cc))
