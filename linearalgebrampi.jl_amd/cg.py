@@ -23,7 +23,10 @@ iterations and nothing else; ``cg_fixed_iterations`` is the two together plus th
 """
 from __future__ import annotations
 
+import math
 from typing import List, Optional, Tuple
+
+import numpy as np
 
 from . import _capi
 from .sparse import get_vector_plan, mul_, mul_dot_
@@ -124,8 +127,8 @@ def cg_fixed_iterations(A, b: HPCVector, iters: int, record_history: bool = True
     whole distributed iterations are capturable.  Same kernels, same arguments, hence the same bits as the
     eager loop.  It pays off where an iteration is shorter than the host time to issue its launches (small
     systems); DESIGN.md section 6 has the measurement for large ones, where eager stays the default."""
-    from .vectors import f64_only
-    f64_only(A.backend, "the CG building blocks")
+    if A.backend.T == np.dtype(np.float32):
+        return _cg_composed_f32(A, b, iters, record_history)
     torch = _torch()
     ws = workspace if workspace is not None and workspace.fits(b, iters) else CGWorkspace(b, iters)
     plan, fused = cg_setup(A, b, ws, fused)
@@ -138,6 +141,34 @@ def cg_fixed_iterations(A, b: HPCVector, iters: int, record_history: bool = True
         from .sparse import check_exchange_health
         check_exchange_health(b.backend)
     return ws.x, h
+
+
+def _cg_composed_f32(A, b: HPCVector, iters: int, record_history: bool):
+    """The same iteration on a Float32 backend, composed from the Float32 operators the way a caller of the reference composes
+    it (`A*p`, `dot`, the vector updates; there is no reference solver): mul!, dot (formed in double, rounded to
+    Float32), u + a*v.  Not fused, one host read-back per scalar -- the fused entries (hpcla_cg_iterations_*) are Float64's."""
+    from .sparse import mul_
+    from .vectors import dot
+    x = HPCVector.zeros(b.partition, b.backend)
+    r, p = b.copy(), b.copy()
+    Ap = b.similar()
+    rr = dot(r, r)
+    hist = [math.sqrt(rr)]
+    for _ in range(iters):
+        mul_(Ap, A, p)
+        pAp = dot(p, Ap)
+        alpha = float(np.float32(rr) / np.float32(pAp))
+        x = x._axpby(1.0, p, alpha)
+        r = r._axpby(1.0, Ap, -alpha)
+        rr_new = dot(r, r)
+        beta = float(np.float32(rr_new) / np.float32(rr))
+        p = r._axpby(1.0, p, beta)
+        rr = rr_new
+        hist.append(math.sqrt(rr))
+    if hist[-1] != hist[-1]:
+        from .sparse import check_exchange_health
+        check_exchange_health(b.backend)
+    return x, (hist if record_history else [])
 
 
 class CGGraphPair:

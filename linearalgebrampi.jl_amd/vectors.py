@@ -58,7 +58,7 @@ def f64_only(backend: HPCBackend, what: str) -> None:
     widened rows and the fused CG pieces are Float64 entries."""
     if backend.T != np.dtype(np.float64):
         raise TypeError(f"{what}: offered for Float64 backends only (Float32 covers A*x, mul!, A*B with dense B, dot, norm, "
-                        "sum, maximum / minimum, u+v, u-v, a*v, v/a)")
+                        "sum, maximum / minimum, u+v, u-v, a*v, v/a, and CG composed from them)")
 
 
 def _round_to(backend: HPCBackend, v: float) -> float:

@@ -132,8 +132,8 @@ def main():
                 assert np.array_equal(C3.A.cpu().numpy(), Cw), f"{tag} {name}: third A*B (k={k}) differs"
         # the widened rows stay Float64 entries: a clear error, not a wrong answer
         try:
-            hp.cg_fixed_iterations(A, x, 2)
-            raise AssertionError("CG accepted a Float32 backend")
+            hp.transpose(A) @ x
+            raise AssertionError("transpose(A)*x accepted a Float32 backend")
         except TypeError:
             pass
         hp.check_exchange_health(backend, always=True)

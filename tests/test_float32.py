@@ -405,7 +405,7 @@ def test_f32_host_layer_products_reductions_and_refusals(hp, orc, f32_backends):
     # a*A shares the structure and scales in float
     np.testing.assert_array_equal((2.5 * A).nzval.cpu().numpy(), F32(2.5) * rows.vals.astype(F32))
     # the widened rows and the CG pieces stay Float64 entries
-    for call in (lambda: hp.cg_fixed_iterations(A, x, 2), lambda: hp.transpose(A) @ x, lambda: A @ A, lambda: A + A,
+    for call in (lambda: hp.mul_dot_(y, A, x, None), lambda: hp.transpose(A) @ x, lambda: A @ A, lambda: A + A,
                  lambda: hp.norm(x, 3), lambda: hp.prod(x), lambda: x.axpy_(1.0, x)):
         with pytest.raises(TypeError, match="Float64"):
             call()
@@ -495,3 +495,37 @@ def test_spmm_f32_mixed_layouts(hp, orc, b_lay, c_lay, k):
     torch.cuda.synchronize()
     got = C.cpu().numpy().reshape((n, k) if c_lay == "row" else (k, n))
     np.testing.assert_array_equal(got if c_lay == "row" else got.T, want)
+
+
+@pytest.mark.gpu
+def test_cg_on_a_float32_backend_is_the_composed_iteration(hp, orc, f32_backends):
+    """CG on a Float32 backend: composed from the Float32 operators (mul!, dot, u + a*v) like a caller of the reference
+    composes it; against the same recurrence in numpy Float32 (its dot sums in Float32, the kernels' in double: compared at
+    the reference's Float32 tolerance, test/test_utils.jl:156), and it converges on the SPD 5-point matrix."""
+    backend = f32_backends[np.int32]
+    nx, ny = 48, 40
+    n = nx * ny
+    rows = orc.poisson2d_rows(nx, ny, 0, n)
+    A = hp.HPCSparseMatrix_local(rows.rowptr, rows.colidx, rows.vals, n, backend)
+    bg = orc.fill_uniform(0, n, orc.SEED_RHS).astype(F32)
+    b = hp.HPCVector.from_global(bg, backend)
+    iters = 30
+    x, hist = hp.cg_fixed_iterations(A, b, iters)
+    assert x.v.dtype.is_floating_point and x.local_values().dtype == F32 and len(hist) == iters + 1
+    import scipy.sparse as sp
+    M = sp.csr_matrix((rows.vals.astype(F32), rows.colidx, rows.rowptr), shape=(n, n))
+    xr, r, p = np.zeros(n, F32), bg.copy(), bg.copy()
+    rr = F32(r @ r)
+    ref = [float(np.sqrt(rr))]
+    for _ in range(iters):
+        Ap = M @ p
+        alpha = rr / F32(p @ Ap)
+        xr = xr + alpha * p
+        r = r - alpha * Ap
+        rr_new = F32(r @ r)
+        p = r + (rr_new / rr) * p
+        rr = rr_new
+        ref.append(float(np.sqrt(rr)))
+    assert np.allclose(hist, ref, rtol=2e-3, atol=1e-4 * ref[0]), (hist[-3:], ref[-3:])
+    assert hist[-1] < 0.5 * hist[0]
+    assert np.max(np.abs(x.local_values() - xr)) <= 1e-3 * np.max(np.abs(xr))
