@@ -278,3 +278,75 @@ def test_every_field_read_from_a_parent_struct_exists_there():
                         cur = None
     assert checked >= 60, f"only {checked} field reads were checked: the parser lost track of the file"
     assert not problems, "\n".join(problems)
+
+
+def _julia_code_tokens(text):
+    """The extension's text with comments and string literals blanked out (Julia is not available to parse it)."""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        if text.startswith('"""', i):
+            j = text.index('"""', i + 3)
+            out.append(" " * (j + 3 - i) if "\n" not in text[i:j + 3] else "\n" * text[i:j + 3].count("\n"))
+            i = j + 3
+        elif text[i] == '"':
+            j = i + 1
+            while text[j] != '"':
+                j += 2 if text[j] == "\\" else 1
+            out.append('""')
+            i = j + 1
+        elif text[i] == "#":
+            j = text.find("\n", i)
+            j = n if j < 0 else j
+            i = j
+        else:
+            out.append(text[i])
+            i += 1
+    return "".join(out)
+
+
+def _julia_balance_problem(text):
+    """None when every block keyword at statement level is closed by an `end` and (), [], {} nest properly; else what is wrong."""
+    import re
+    stack, blocks, opens = [], [], 0              # open brackets / open blocks as (token, line)
+    pairs = {")": "(", "]": "[", "}": "{"}
+    line = 1
+    for m in re.finditer(r"\n|[()\[\]{}]|(?<![\w.:@!])(?:mutable\s+struct|function|if|for|while|let|do|struct|module|begin|try|quote|macro|end)(?![\w!?(])", text):
+        tok = m.group(0)
+        if tok == "\n":
+            line += 1
+        elif tok in "([{":
+            stack.append((tok, line))
+        elif tok in ")]}":
+            if not stack or stack[-1][0] != pairs[tok]:
+                return f"line {line}: unbalanced {tok!r}"
+            stack.pop()
+        elif any(b[0] == "[" for b in stack):
+            continue                              # comprehension `for` / `if`, indexing `end`
+        elif tok == "end":
+            if not blocks:
+                return f"line {line}: `end` without an open block"
+            blocks.pop()
+        elif stack and tok in ("for", "if"):
+            continue                              # generator / filter inside parentheses: no `end`
+        else:
+            blocks.append((tok, line))
+            opens += 1
+    if stack:
+        return f"unclosed bracket opened at line {stack[-1][1]}"
+    if blocks:
+        return f"unclosed block: `{blocks[-1][0]}` at line {blocks[-1][1]}"
+    return None if opens > 50 else "the scanner saw almost no blocks"
+
+
+def test_extension_blocks_and_brackets_balance():
+    """No Julia here to parse the extension, so at least its block structure is checked: every function / if / for / while /
+    let / do / struct / module / begin / try at statement level opens a block that an `end` closes (keywords inside square
+    brackets -- comprehensions, `a[end]` -- and generator `for` / `if` inside parentheses do not count), and (), [], {} nest
+    properly.  The scanner is itself checked on mutations of the file: a dropped `end`, a stray `end`, a dropped bracket."""
+    text = _julia_code_tokens(open(os.path.join(ROOT, "integration", "HPCLinearAlgebraROCmExt.jl")).read())
+    assert _julia_balance_problem(text) is None, _julia_balance_problem(text)
+    k = text.rindex("\nend\n", 0, text.rindex("\nend"))           # the `end` of the last function
+    assert _julia_balance_problem(text[:k] + text[k + 4:]) is not None
+    assert _julia_balance_problem(text[:k] + "\nend" + text[k:]) is not None
+    j = text.index("(", text.index("function _check"))
+    assert _julia_balance_problem(text[:j] + text[j + 1:]) is not None
