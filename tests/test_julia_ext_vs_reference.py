@@ -350,3 +350,15 @@ def test_extension_blocks_and_brackets_balance():
     assert _julia_balance_problem(text[:k] + "\nend" + text[k:]) is not None
     j = text.index("(", text.index("function _check"))
     assert _julia_balance_problem(text[:j] + text[j + 1:]) is not None
+
+
+def test_every_private_helper_the_extension_calls_is_defined_in_it():
+    """`_name(...)` calls that are not qualified with the parent module must be helpers of the extension file itself."""
+    import re
+    text = _julia_code_tokens(open(os.path.join(ROOT, "integration", "HPCLinearAlgebraROCmExt.jl")).read())
+    defined = set(re.findall(r"\bfunction\s+(?:[\w.]+\.)?(_\w+!?)", text))
+    defined |= set(re.findall(r"^(?:[\w.]+\.)?(_\w+!?)\([^=\n]*\)(?:\s*where\s*\{[^}]*\})?\s*=", text, flags=re.M))
+    defined |= set(re.findall(r"^const\s+(_\w+)", text, flags=re.M))
+    used = set(re.findall(r"(?<![\w.])(_\w+!?)\(", text))
+    assert len(used) > 20
+    assert not (used - defined), f"called but not defined in the extension: {sorted(used - defined)}"
