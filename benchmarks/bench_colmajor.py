@@ -16,6 +16,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--nx", type=int, default=4096)
     ap.add_argument("--reps", type=int, default=30)
+    ap.add_argument("--dim3", default="", help="nx,ny,nz: the 7-point matrix instead of the 5-point one")
     ap.add_argument("--ny", type=int, default=0, help="grid lines (default nx / 2); a non-power-of-two count takes the column stride off the powers of two")
     args = ap.parse_args()
     import torch
@@ -24,12 +25,20 @@ def main():
     dev = torch.device("cuda:0")
     s = torch.cuda.current_stream().cuda_stream
     nx, ny, k = args.nx, (args.ny or args.nx // 2), 16
-    n = nx * ny
-    nnz = L.hpcla_poisson2d_nnz(nx, ny, 0, n)
+    if args.dim3:
+        mx, my, mz = (int(v) for v in args.dim3.split(","))
+        n = mx * my * mz
+        nnz = L.hpcla_poisson3d_nnz(mx, my, mz, 0, n)
+    else:
+        n = nx * ny
+        nnz = L.hpcla_poisson2d_nnz(nx, ny, 0, n)
     rp = torch.empty(n + 1, dtype=torch.int64, device=dev)
     cv = torch.empty(nnz, dtype=torch.int64, device=dev)
     nz = torch.empty(nnz, dtype=torch.float64, device=dev)
-    hp._capi.call("hpcla_gen_poisson2d", nx, ny, 0, n, rp.data_ptr(), cv.data_ptr(), nz.data_ptr(), s)
+    if args.dim3:
+        hp._capi.call("hpcla_gen_poisson3d", mx, my, mz, 0, n, rp.data_ptr(), cv.data_ptr(), nz.data_ptr(), s)
+    else:
+        hp._capi.call("hpcla_gen_poisson2d", nx, ny, 0, n, rp.data_ptr(), cv.data_ptr(), nz.data_ptr(), s)
     rp, cv = rp.int(), cv.int()
     Bc = torch.rand(k, n, dtype=torch.float64, device=dev)          # column-major n x k
     Cc = torch.empty(k, n, dtype=torch.float64, device=dev)

@@ -277,6 +277,15 @@ int hpcla_spmm_runs_build_i32(const int32_t *rowptr, const int32_t *colval_split
                               int index_base, int64_t n_own, void *desc, int64_t *n_fit_host, void *stream);
 int hpcla_spmm_runs_build_i64(const int64_t *rowptr, const int64_t *colval_split, int64_t nrows, int64_t nnz,
                               int index_base, int64_t n_own, void *desc, int64_t *n_fit_host, void *stream);
+/* BANDED test of a structure (plan time, one pass, synchronises the stream): the number of hpcla_spmm_rows_per_block()-row
+ * blocks whose entries (at most 512) touch at most `max_runs` contiguous runs of split columns, in *n_blocks_host.  Every
+ * stencil qualifies (5-point: 3 runs, 7-point: 5); a random pattern has about as many runs as entries.  Column-major callers
+ * use it to choose between the product on their blocks as they are (hpcla_spmm_split_colmajor_*: contiguous pieces per gather
+ * on a banded structure) and the layout conversions around the row-major kernels. */
+int hpcla_spmm_banded_blocks_i32(const int32_t *rowptr, const int32_t *colval_split, int64_t nrows, int64_t nnz,
+                                 int index_base, int64_t n_own, int max_runs, int64_t *n_blocks_host, void *stream);
+int hpcla_spmm_banded_blocks_i64(const int64_t *rowptr, const int64_t *colval_split, int64_t nrows, int64_t nnz,
+                                 int index_base, int64_t n_own, int max_runs, int64_t *n_blocks_host, void *stream);
 int hpcla_spmm_runs_k16_f64_i32(const int32_t *rowptr, const int32_t *colval_split, const double *nzval,
                                 const double *B_own, const double *B_ghost, int64_t n_own, double *C, int64_t nrows,
                                 int64_t nnz, int index_base, const void *desc, const int32_t *block_list,

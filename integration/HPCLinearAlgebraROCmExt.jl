@@ -501,12 +501,29 @@ function _spmm_runs_info(A, d::ROCVectorPlan{Tk}) where {Tk}
     end
 end
 _spmm_runs(A, d) = get(ENV, "HPCLA_SPMM_RUNS", "1") == "0" ? nothing : ((desc, fits) = _spmm_runs_info(A, d); fits ? desc : nothing)
-# BANDED structure (every stencil): (nearly) every 64-row block touches a few contiguous runs of columns.  There the
-# lanes = rows kernels read a column-major block -- Julia's Matrix -- in contiguous runs, so A * B runs on the caller's arrays
-# as they are (csrc/colmajor.hip: 0.67 ms on the 5-point matrix x 16 where the two layout conversions around the row-major
-# product cost 1.52 ms); an unstructured matrix touches a line per (entry, column) pair in that layout and keeps the
-# conversions.  HPCLA_SPMM_COLMAJOR=0 switches the direct path off.
-_banded(A, d) = get(ENV, "HPCLA_SPMM_COLMAJOR", "1") != "0" && _spmm_runs_info(A, d)[2]
+# BANDED structure (every stencil: the 5-point matrix has 3 runs per block, the 7-point one 5): (nearly) every 64-row block
+# touches at most 16 contiguous runs of columns (hpcla_spmm_banded_blocks_*, one pass at plan time).  There the lanes = rows
+# kernels read a column-major block -- Julia's Matrix -- in contiguous pieces, so A * B runs on the caller's arrays as they are
+# (csrc/colmajor.hip: 0.67 ms on the 5-point matrix x 16 where the two layout conversions around the row-major product cost
+# 1.52 ms; 7-point: 0.99 against 1.63); an unstructured matrix touches a line per (entry, column) pair in that layout and
+# keeps the conversions.  HPCLA_SPMM_COLMAJOR=0 switches the direct path off.
+const _banded_cache = IdDict{Any,Bool}()       # device plan -> banded?
+function _banded(A, d::ROCVectorPlan{Tk}) where {Tk}
+    get(ENV, "HPCLA_SPMM_COLMAJOR", "1") == "0" && return false
+    get!(_banded_cache, d) do
+        nb = Ref{Int64}(0); nnz = length(A.nzval)
+        if Tk === Int32
+            _check(@ccall(LIB.hpcla_spmm_banded_blocks_i32(_ptr(d.rowptr0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
+                   A.nrows_local::Int64, nnz::Int64, 0::Cint, d.n_own::Int64, 16::Cint, nb::Ptr{Int64},
+                   _stream()::Ptr{Cvoid})::Cint), "hpcla_spmm_banded_blocks_i32")
+        else
+            _check(@ccall(LIB.hpcla_spmm_banded_blocks_i64(_ptr(d.rowptr0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
+                   A.nrows_local::Int64, nnz::Int64, 0::Cint, d.n_own::Int64, 16::Cint, nb::Ptr{Int64},
+                   _stream()::Ptr{Cvoid})::Cint), "hpcla_spmm_banded_blocks_i64")
+        end
+        nb[] >= 0.99 * cld(A.nrows_local, 64)
+    end
+end
 
 # A * B on the column-major blocks themselves (T = Float64 or Float32): without neighbours one launch; with neighbours the
 # exchange is posted from the column-major block (hpcla_halo_begin_strided_*: the rows the plan sends are staged row-major,
@@ -819,7 +836,7 @@ function clear_rocm_plan_cache!()
     for d in values(_rocm_plans)    # the plans' rowptr copies carry the block-order hints: removed before the arrays go
         d isa ROCVectorPlan && @ccall LIB.hpcla_spmv_block_order_hint(_ptr(d.rowptr0)::Ptr{Cvoid}, 0::Cint)::Cint
     end
-    empty!(_rocm_plans); empty!(_spmm_plans); empty!(_rocm_exec); empty!(_merge_lists); empty!(_spmm_runs_cache); empty!(_stage32)
+    empty!(_rocm_plans); empty!(_spmm_plans); empty!(_rocm_exec); empty!(_merge_lists); empty!(_spmm_runs_cache); empty!(_stage32); empty!(_banded_cache)
     return nothing
 end
 

@@ -59,6 +59,8 @@ _SIGNATURES = {
     "hpcla_spmm_runs_desc_bytes": [_i64],
     "hpcla_spmm_runs_build_i32": [_vp, _vp, _i64, _i64, _i32, _i64, _vp, _vp, _vp],
     "hpcla_spmm_runs_build_i64": [_vp, _vp, _i64, _i64, _i32, _i64, _vp, _vp, _vp],
+    "hpcla_spmm_banded_blocks_i32": [_vp, _vp, _i64, _i64, _i32, _i64, _i32, _vp, _vp],
+    "hpcla_spmm_banded_blocks_i64": [_vp, _vp, _i64, _i64, _i32, _i64, _i32, _vp, _vp],
     "hpcla_spmm_runs_k16_f64_i32": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _i64, _vp],
     "hpcla_spmm_runs_k16_f64_i64": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _i64, _vp],
     "hpcla_spmm_block_order_hint": [_vp, _i32],

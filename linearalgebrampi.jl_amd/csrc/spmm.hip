@@ -539,8 +539,11 @@ template <typename I>
 __global__ __launch_bounds__(TPB_MM) void spmm_runs_build_kernel(const I *__restrict__ rowptr, const I *__restrict__ colval,
                                                                  int64_t nrows, int base, int64_t n_own,
                                                                  SpmmRunDesc *__restrict__ runs,
-                                                                 unsigned long long *__restrict__ n_fit)
+                                                                 unsigned long long *__restrict__ n_fit, int banded_max_runs)
 {
+    // runs == nullptr: COUNT ONLY (hpcla_spmm_banded_blocks_*): n_fit counts the blocks whose <= RUNS_EMAX entries touch at most
+    // `banded_max_runs` contiguous runs of columns -- the structures on which a lanes = rows kernel reads a column-major block
+    // in contiguous pieces (colmajor.hip); no descriptor is written
     __shared__ int64_t s_key[RUNS_EMAX];
     __shared__ unsigned long long s_mask[RUNS_EMAX / 64];
     __shared__ int s_start_idx[RUNS_MAX + 1];
@@ -552,7 +555,7 @@ __global__ __launch_bounds__(TPB_MM) void spmm_runs_build_kernel(const I *__rest
     SpmmRunDesc d;
     for (int i = 0; i < RUNS_MAX; ++i) { d.start[i] = 0; d.len[i] = 0; }
     if (total > RUNS_EMAX) {                               // workgroup-uniform
-        if (tid == 0) { d.len[0] = -1; runs[blk] = d; }
+        if (tid == 0 && runs) { d.len[0] = -1; runs[blk] = d; }
         return;
     }
     constexpr int64_t BIG = (int64_t)1 << 62;
@@ -592,6 +595,10 @@ __global__ __launch_bounds__(TPB_MM) void spmm_runs_build_kernel(const I *__rest
     }
     if (tid <= RUNS_MAX) s_start_idx[tid] = (int)total;
     __syncthreads();
+    if (!runs) {                                           // count only (workgroup-uniform)
+        if (tid == 0 && n_starts <= banded_max_runs) atomicAdd(n_fit, 1ULL);
+        return;
+    }
     if (n_starts > RUNS_MAX || total == 0) {               // workgroup-uniform (an empty block "fits": nothing to stage)
         if (tid == 0) {
             if (total != 0) d.len[0] = -1;
@@ -971,13 +978,14 @@ HPCLA_API int64_t hpcla_spmm_runs_desc_bytes(int64_t nrows)
 
 template <typename I>
 static int spmm_runs_build(const I *rowptr, const I *colval_split, int64_t nrows, int64_t nnz, int index_base, int64_t n_own,
-                           void *desc, int64_t *n_fit_host, void *stream)
+                           void *desc, int64_t *n_fit_host, void *stream, int banded_max_runs = -1)
 {
+    const bool count_only = banded_max_runs >= 0;          // desc == nullptr: hpcla_spmm_banded_blocks_*
     if (n_fit_host) *n_fit_host = 0;
     if (nrows < 0 || nnz < 0) return set_error(HPCLA_ERR_INVALID, "spmm_runs_build: negative size");
     if (index_base != 0 && index_base != 1) return set_error(HPCLA_ERR_INVALID, "spmm_runs_build: index_base must be 0 or 1");
     if (nrows == 0) return HPCLA_OK;
-    if (!rowptr || !desc || (nnz > 0 && !colval_split)) return set_error(HPCLA_ERR_INVALID, "spmm_runs_build: null pointer");
+    if (!rowptr || (!desc && !count_only) || (nnz > 0 && !colval_split)) return set_error(HPCLA_ERR_INVALID, "spmm_runs_build: null pointer");
     if (n_own > 0x7fffffffLL) return set_error(HPCLA_ERR_UNSUPPORTED, "spmm_runs_build: split columns beyond Int32");
     const int64_t nb = (nrows + RPB_MM - 1) / RPB_MM;
     HPCLA_CHECK_GRID(nb, "spmm_runs_build");
@@ -987,7 +995,8 @@ static int spmm_runs_build(const I *rowptr, const I *colval_split, int64_t nrows
     hipError_t e = hipMemsetAsync(d_fit, 0, sizeof(unsigned long long), s);
     if (e == hipSuccess) {
         spmm_runs_build_kernel<I><<<(uint32_t)nb, TPB_MM, 0, s>>>(rowptr, colval_split, nrows, index_base, n_own,
-                                                                  reinterpret_cast<SpmmRunDesc *>(desc), d_fit);
+                                                                  count_only ? nullptr : reinterpret_cast<SpmmRunDesc *>(desc), d_fit,
+                                                                  banded_max_runs);
         e = hipGetLastError();
     }
     unsigned long long fit = 0;
@@ -1009,6 +1018,20 @@ HPCLA_API int hpcla_spmm_runs_build_i64(const int64_t *rowptr, const int64_t *co
                                         int index_base, int64_t n_own, void *desc, int64_t *n_fit_host, void *stream)
 {
     return spmm_runs_build<int64_t>(rowptr, colval_split, nrows, nnz, index_base, n_own, desc, n_fit_host, stream);
+}
+
+// how many 64-row blocks touch at most `max_runs` contiguous runs of (split) columns: the BANDED test of a structure
+HPCLA_API int hpcla_spmm_banded_blocks_i32(const int32_t *rowptr, const int32_t *colval_split, int64_t nrows, int64_t nnz,
+                                           int index_base, int64_t n_own, int max_runs, int64_t *n_blocks_host, void *stream)
+{
+    if (max_runs < 1) return set_error(HPCLA_ERR_INVALID, "spmm_banded_blocks: max_runs must be positive");
+    return spmm_runs_build<int32_t>(rowptr, colval_split, nrows, nnz, index_base, n_own, nullptr, n_blocks_host, stream, max_runs);
+}
+HPCLA_API int hpcla_spmm_banded_blocks_i64(const int64_t *rowptr, const int64_t *colval_split, int64_t nrows, int64_t nnz,
+                                           int index_base, int64_t n_own, int max_runs, int64_t *n_blocks_host, void *stream)
+{
+    if (max_runs < 1) return set_error(HPCLA_ERR_INVALID, "spmm_banded_blocks: max_runs must be positive");
+    return spmm_runs_build<int64_t>(rowptr, colval_split, nrows, nnz, index_base, n_own, nullptr, n_blocks_host, stream, max_runs);
 }
 
 template <typename I>

@@ -184,3 +184,29 @@ def test_special_values_propagate_like_the_reference_loop(hp, orc, dt):
     hp._capi.call(f"hpcla_spmm_csr_{dt}_i32", rp.data_ptr(), cvd.data_ptr(), nz.data_ptr(), Bc.data_ptr(), len(ci), COL, Cc.data_ptr(), n, COL,
                   n, len(vals), k, 0, _stream())
     same(Cc.cpu().numpy().T, "column-major SpMM")
+
+
+def test_banded_block_count(hp, orc):
+    """hpcla_spmm_banded_blocks_*: the structure test a column-major caller applies (stencils: every block; random: none)."""
+    import ctypes
+
+    def count(rows, max_runs, Ti=np.int32):
+        ci, cv = orc.compress_columns(rows)
+        rp, cvd = _t(rows.rowptr.astype(Ti)), _t(cv.astype(Ti))
+        nb = ctypes.c_int64(-1)
+        hp._capi.call("hpcla_spmm_banded_blocks_" + ("i32" if Ti == np.int32 else "i64"), rp.data_ptr(), cvd.data_ptr(), rows.nrows,
+                      rows.nnz, 0, len(ci), max_runs, ctypes.byref(nb), _stream())
+        return int(nb.value), (rows.nrows + 63) // 64
+    p2 = orc.poisson2d_rows(256, 70, 0, 256 * 70)
+    p3 = orc.poisson3d_rows(200, 20, 6, 0, 200 * 20 * 6)        # lines longer than a block: i, i +- nx, i +- nx*ny are 5 separate runs
+    sr = orc.sprand_rows(20000, 0.001, 0, 20000)
+    for Ti in (np.int32, np.int64):
+        assert count(p2, 16, Ti) == ((256 * 70 + 63) // 64,) * 2
+        got, blocks = count(p3, 16, Ti)
+        assert got == blocks
+    got3, blocks3 = count(p3, 4)
+    assert got3 < blocks3                              # 5 runs per interior block: the run-tile limit does not fit, the banded one does
+    got, blocks = count(sr, 16)
+    assert got < 0.05 * blocks
+    with pytest.raises(hp._capi.HPCLAError, match="max_runs"):
+        count(p2, 0)
