@@ -1,0 +1,80 @@
+"""Randomised sweep through the raw C ABI: ragged CSR shapes (empty matrices, empty rows, single rows, rows around the
+464-entry wave pass and the 2048-entry workgroup pass, duplicate-free ascending columns), both index types and bases, every
+kernel family -- Float64 SpMV (row-gather and quad), Float32 SpMV, SpMM in Float64 and Float32 on row-major and column-major
+blocks with ragged k -- each bit for bit against the oracle's loops (src/sparse.jl:2055-2066, 2391-2413).  Fixed seeds: a
+failure names its case.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+
+
+def _t(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda")
+
+
+def _case(seed):
+    rng = np.random.default_rng(seed)
+    nrows = int(rng.choice([0, 1, 2, 63, 64, 65, 255, 256, 257, int(rng.integers(1, 700))]))
+    ncols = int(rng.integers(1, 3000))
+    kind = seed % 4
+    if kind == 0:
+        lens = rng.integers(0, min(ncols, 12) + 1, nrows)
+    elif kind == 1:
+        lens = np.where(rng.random(nrows) < 0.5, 0, rng.integers(0, min(ncols, 40) + 1, nrows))
+    elif kind == 2:
+        lens = rng.integers(0, min(ncols, 9) + 1, nrows)
+        for r in rng.integers(0, max(nrows, 1), min(nrows, 3)):
+            lens[r] = min(ncols, int(rng.choice([463, 464, 465, 929, 2047, 2048, 2049])))
+    else:
+        lens = np.full(nrows, min(ncols, 7))
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    colval = (np.concatenate([np.sort(rng.choice(ncols, int(l), replace=False)) for l in lens]).astype(np.int64)
+              if nrows and lens.sum() else np.empty(0, np.int64))
+    vals = rng.random(len(colval)) - 0.5
+    k = int(rng.choice([1, 2, 3, 4, 7, 8, 12, 16, 17, 20]))
+    B = rng.random((ncols, k)) - 0.5
+    return nrows, ncols, rowptr, colval, vals, k, B
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_shapes_every_kernel_family(hp, orc, seed):
+    import torch
+    nrows, ncols, rowptr, colval, vals, k, B = _case(seed)
+    Ti = np.int32 if seed % 3 else np.int64
+    sfx = "i32" if Ti == np.int32 else "i64"
+    base = seed % 2
+    s = torch.cuda.current_stream().cuda_stream
+    capi = hp._capi
+    rp, cv = _t((rowptr + base).astype(Ti)), _t((colval + base).astype(Ti))
+    nnz = len(vals)
+    ROW, COL = capi.LAYOUT_ROW, capi.LAYOUT_COL
+    before = capi.load().hpcla_get_spmv_kernel()
+    for T, dt, tT in ((np.float64, "f64", torch.float64), (F32, "f32", torch.float32)):
+        v, Bt = vals.astype(T), B.astype(T)
+        nz = _t(v)
+        want = orc.spmm(rowptr.astype(Ti), colval.astype(Ti), v, Bt) if nrows else np.empty((0, k), T)
+        # SpMV on column 0
+        x = _t(np.ascontiguousarray(Bt[:, 0]))
+        kinds = (0, 1) if dt == "f64" else (0,)
+        try:
+            for kind in kinds:
+                capi.call("hpcla_set_spmv_kernel", kind)
+                y = torch.full((max(nrows, 1),), float("nan"), dtype=tT, device="cuda")
+                capi.call(f"hpcla_spmv_csr_{dt}_{sfx}", rp.data_ptr(), cv.data_ptr(), nz.data_ptr(), x.data_ptr(), y.data_ptr(), nrows, nnz,
+                          base, s)
+                np.testing.assert_array_equal(y[:nrows].cpu().numpy(), want[:, 0], err_msg=f"seed {seed} {dt} spmv kernel {kind}")
+        finally:
+            capi.call("hpcla_set_spmv_kernel", before)
+        # SpMM, both layouts
+        for lay, name in ((ROW, "row"), (COL, "col")):
+            Bd = _t(Bt if lay == ROW else np.ascontiguousarray(Bt.T))
+            C = torch.full((max(nrows, 1) * k,), float("nan"), dtype=tT, device="cuda")
+            capi.call(f"hpcla_spmm_csr_{dt}_{sfx}", rp.data_ptr(), cv.data_ptr(), nz.data_ptr(), Bd.data_ptr(), k if lay == ROW else ncols, lay,
+                      C.data_ptr(), k if lay == ROW else max(nrows, 1), lay, nrows, nnz, k, base, s)
+            got = C.cpu().numpy()
+            got = got[:nrows * k].reshape(nrows, k) if lay == ROW else got.reshape(k, max(nrows, 1))[:, :nrows].T
+            np.testing.assert_array_equal(got, want, err_msg=f"seed {seed} {dt} spmm {name}-major k={k}")
