@@ -387,3 +387,29 @@ def test_narrowing_decision_of_int64_plans(hp, monkeypatch):
     assert narrowing_enabled()
     monkeypatch.delenv("HPCLA_NARROW_INDICES")
     assert narrowing_enabled()
+
+
+def test_element_type_of_a_backend_and_what_float32_covers(hp):
+    """HPCBackend carries T like the reference's HPCBackend{T,...}: Float64 (graded) and Float32 (the reference's other GPU
+    configuration); the C entry-point suffix, the rounding of reduction results and the Float64-only guard follow from it."""
+    from hpcla_amd.backends import CommSerial, DeviceCPU, SolverNone
+    from hpcla_amd.vectors import _round_to, f64_only, sfx_of
+    b64 = hp.HPCBackend(np.float64, np.int32, DeviceCPU(), CommSerial(), SolverNone())
+    b32 = hp.HPCBackend(np.float32, np.int64, DeviceCPU(), CommSerial(), SolverNone())
+    assert sfx_of(b64) == "f64" and sfx_of(b32) == "f32" and hp.cpu_version(b32).T == np.dtype(np.float32)
+    v = 0.1 + 2.0 ** -40
+    assert _round_to(b64, v) == v and _round_to(b32, v) == float(np.float32(v)) != v
+    f64_only(b64, "anything")
+    with pytest.raises(TypeError, match="Float64 backends only"):
+        f64_only(b32, "transpose(A) (materialised)")
+    for bad in (np.float16, np.complex128, np.int32):
+        with pytest.raises(TypeError, match="float64 or float32"):
+            hp.HPCBackend(bad, np.int32, DeviceCPU(), CommSerial(), SolverNone())
+    # every _f32 entry of the header is bound, and each has its _f64 twin's argument classes (pointers / sizes) up to the scalar type
+    sig = hp._capi._SIGNATURES
+    for name, args in sig.items():
+        if "_f32" in name and name.replace("_f32", "_f64") in sig:
+            twin = sig[name.replace("_f32", "_f64")]
+            same = [("s" if a in (hp._capi._f32, hp._capi._f64) else a) for a in args] == \
+                   [("s" if a in (hp._capi._f32, hp._capi._f64) else a) for a in twin]
+            assert same, name
