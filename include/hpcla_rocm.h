@@ -717,6 +717,18 @@ int hpcla_spmm_split_colmajor_f32_i64(const int64_t *rowptr, const int64_t *colv
                                       int index_base, const int32_t *block_list, int64_t n_blocks, void *stream);
 int hpcla_halo_begin_strided_f32(hpcla_halo_plan_t *plan, const float *x, int64_t x_rs, int64_t x_cs, double *stage,
                                  void *stream);
+/* Distributed y = A*x for Float32 (Base.:*(A, x), src/sparse.jl:2096-2128) in one call: hpcla_halo_begin_f32, the interior
+ * blocks (they overlap the exchange), hpcla_halo_end, the boundary blocks with the plan's ghost segment.  Arguments as for
+ * hpcla_spmv_dist_f64_* plus `stage` (hpcla_halo_begin_f32).  A plan with attached peer windows must have been created with
+ * HPCLA_HALO_SINGLE_BUFFER.  plan == NULL or no neighbours: a plain product over all row blocks. */
+int hpcla_spmv_dist_f32_i32(hpcla_halo_plan_t *plan, const int32_t *rowptr, const int32_t *colval_split, const float *nzval,
+                            const float *x, int64_t n_own, float *y, int64_t nrows, int64_t nnz, int index_base,
+                            const int32_t *interior_blocks, int64_t n_interior, const int32_t *boundary_blocks,
+                            int64_t n_boundary, double *stage, void *stream);
+int hpcla_spmv_dist_f32_i64(hpcla_halo_plan_t *plan, const int64_t *rowptr, const int64_t *colval_split, const float *nzval,
+                            const float *x, int64_t n_own, float *y, int64_t nrows, int64_t nnz, int index_base,
+                            const int32_t *interior_blocks, int64_t n_interior, const int32_t *boundary_blocks,
+                            int64_t n_boundary, double *stage, void *stream);
 /* hpcla_halo_begin for a Float32 operand (execute_plan!, src/vectors.jl:394-463): widens x at the plan's send positions
  * into `stage` (doubles, laid out like x: at least (largest send index + 1) * width entries; the caller's, reused from
  * call to call) on `stream`, then posts the ordinary exchange from `stage`.  hpcla_halo_end / hpcla_halo_status /

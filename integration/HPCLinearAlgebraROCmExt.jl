@@ -642,34 +642,21 @@ end
 const _stage32 = IdDict{Any,Any}()      # device plan -> staging vector (ROCVector{Float64}) of its Float32 / column-major exchanges
 _stage(d, n::Int) = (st = get(_stage32, d, nothing); (st === nothing || length(st) < n) ? (_stage32[d] = AMDGPU.zeros(Float64, max(n, 1))) : st)
 
-# y (nrows_local values at `yp`) = A * (x: n_own values at `xp`); both may point into a column of a Matrix
+# y (nrows_local values at `yp`) = A * (x: n_own values at `xp`): hpcla_spmv_dist_f32_* -- the exchange (values widened into
+# the plan's staging vector), the interior blocks overlapping it, the boundary blocks behind it, in one call
 function _spmv_f32!(yp::Ptr{Cvoid}, A::HPCSparseMatrix{Float32,Ti,B}, xp::Ptr{Cvoid}, d::ROCVectorPlan{Tk}) where {Ti,Tk,B<:ROCBackend}
-    rp0 = d.rowptr0; nnz = length(A.nzval); nb_all = Int64(0)
-    function launch(ghost::Ptr{Cvoid}, blocks, nblocks::Int64)
-        if Tk === Int32
-            _check(@ccall(LIB.hpcla_spmv_split_f32_i32(_ptr(rp0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
-                   _ptr(A.nzval)::Ptr{Cvoid}, xp::Ptr{Cvoid}, ghost::Ptr{Cvoid}, d.n_own::Int64, yp::Ptr{Cvoid},
-                   A.nrows_local::Int64, nnz::Int64, 0::Cint, blocks::Ptr{Cvoid}, nblocks::Int64,
-                   _stream()::Ptr{Cvoid})::Cint), "hpcla_spmv_split_f32_i32")
-        else
-            _check(@ccall(LIB.hpcla_spmv_split_f32_i64(_ptr(rp0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
-                   _ptr(A.nzval)::Ptr{Cvoid}, xp::Ptr{Cvoid}, ghost::Ptr{Cvoid}, d.n_own::Int64, yp::Ptr{Cvoid},
-                   A.nrows_local::Int64, nnz::Int64, 0::Cint, blocks::Ptr{Cvoid}, nblocks::Int64,
-                   _stream()::Ptr{Cvoid})::Cint), "hpcla_spmv_split_f32_i64")
-        end
-    end
-    if d.halo == C_NULL
-        launch(C_NULL, C_NULL, nb_all)                           # no neighbours: every row block, no ghost segment
-        return
-    end
-    _check(@ccall(LIB.hpcla_halo_begin_f32(d.halo::Ptr{Cvoid}, xp::Ptr{Cvoid}, _ptr(_stage(d, d.n_own))::Ptr{Cvoid},
-           _stream()::Ptr{Cvoid})::Cint), "hpcla_halo_begin_f32")
-    isempty(d.interior) || launch(C_NULL, _ptr(d.interior), Int64(length(d.interior)))     # overlaps the exchange
-    _check(@ccall(LIB.hpcla_halo_end(d.halo::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_halo_end")
-    if !isempty(d.boundary)
-        gh = Ref{Ptr{Cvoid}}(C_NULL); ngh = Ref{Int64}(0)       # single-buffered plan: a constant, no device synchronisation
-        _check(@ccall(LIB.hpcla_halo_ghost_ptr(d.halo::Ptr{Cvoid}, gh::Ptr{Ptr{Cvoid}}, ngh::Ptr{Int64})::Cint), "hpcla_halo_ghost_ptr")
-        launch(gh[], _ptr(d.boundary), Int64(length(d.boundary)))
+    nnz = length(A.nzval)
+    stage = d.halo == C_NULL ? C_NULL : _ptr(_stage(d, d.n_own))
+    if Tk === Int32
+        _check(@ccall(LIB.hpcla_spmv_dist_f32_i32(d.halo::Ptr{Cvoid}, _ptr(d.rowptr0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
+               _ptr(A.nzval)::Ptr{Cvoid}, xp::Ptr{Cvoid}, d.n_own::Int64, yp::Ptr{Cvoid}, A.nrows_local::Int64, nnz::Int64, 0::Cint,
+               _ptr(d.interior)::Ptr{Cvoid}, length(d.interior)::Int64, _ptr(d.boundary)::Ptr{Cvoid}, length(d.boundary)::Int64,
+               stage::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_spmv_dist_f32_i32")
+    else
+        _check(@ccall(LIB.hpcla_spmv_dist_f32_i64(d.halo::Ptr{Cvoid}, _ptr(d.rowptr0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
+               _ptr(A.nzval)::Ptr{Cvoid}, xp::Ptr{Cvoid}, d.n_own::Int64, yp::Ptr{Cvoid}, A.nrows_local::Int64, nnz::Int64, 0::Cint,
+               _ptr(d.interior)::Ptr{Cvoid}, length(d.interior)::Int64, _ptr(d.boundary)::Ptr{Cvoid}, length(d.boundary)::Int64,
+               stage::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_spmv_dist_f32_i64")
     end
     return
 end

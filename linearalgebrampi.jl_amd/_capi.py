@@ -176,6 +176,8 @@ _SIGNATURES = {
     "hpcla_spmm_csr_f32_i64": [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _i64, _i32, _i64, _i64, _i32, _i32, _vp],
     "hpcla_spmm_split_f32_i32": [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _i64, _vp],
     "hpcla_spmm_split_f32_i64": [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _i64, _vp],
+    "hpcla_spmv_dist_f32_i32": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _vp],
+    "hpcla_spmv_dist_f32_i64": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _vp],
     "hpcla_halo_begin_f32": [_vp, _vp, _vp, _vp],
     "hpcla_halo_begin_strided_f32": [_vp, _vp, _i64, _i64, _vp, _vp],
     "hpcla_spmm_split_colmajor_f32_i32": [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _i64, _vp],

@@ -490,6 +490,57 @@ HPCLA_F32_SPMV(i64, int64_t)
 HPCLA_F32_COLMAJOR_SPLIT(i32, int32_t)
 HPCLA_F32_COLMAJOR_SPLIT(i64, int64_t)
 
+// Distributed y = A*x in ONE call (the Float32 twin of hpcla_spmv_dist_f64_*; not a fused launch: begin -> interior blocks
+// -> end -> boundary blocks on the caller's stream, the exchange itself on the plan's side stream / in the peers' windows)
+template <typename I>
+static int spmv_dist_f32(hpcla_halo_plan_t *plan, const I *rowptr, const I *colval_split, const float *nzval, const float *x,
+                         int64_t n_own, float *y, int64_t nrows, int64_t nnz, int index_base, const int32_t *interior,
+                         int64_t n_interior, const int32_t *boundary, int64_t n_boundary, double *stage, void *stream)
+{
+    if (n_own < 0) return set_error(HPCLA_ERR_INVALID, "spmv_dist_f32: negative n_own");
+    F32Operand b{x, 1, 0, nullptr, 1, 0, n_own};
+    if (!plan || (plan->send_ranks.empty() && plan->recv_ranks.empty()))
+        return f32_launch<I>(rowptr, colval_split, nzval, b, y, 1, 0, nrows, nnz, 1, index_base, nullptr, 0, stream, "spmv_dist_f32");
+    if (n_interior < 0 || n_boundary < 0 || (n_interior > 0 && !interior) || (n_boundary > 0 && !boundary))
+        return set_error(HPCLA_ERR_INVALID, "spmv_dist_f32: bad block lists");
+    if (!plan->single_buffer && plan->attached)
+        return set_error(HPCLA_ERR_INVALID, "spmv_dist_f32: the plan must be single-buffered (hpcla_halo_plan_create_ex with "
+                                            "HPCLA_HALO_SINGLE_BUFFER): its ghost pointer is taken while the exchange is in flight");
+    int rc = hpcla_halo_begin_f32(plan, x, stage, stream);
+    if (rc != HPCLA_OK) return rc;
+    if (n_interior > 0)                                            // no ghost column in these blocks: they overlap the exchange
+        rc = f32_launch<I>(rowptr, colval_split, nzval, b, y, 1, 0, nrows, nnz, 1, index_base, interior, n_interior, stream, "spmv_dist_f32");
+    const int rc_end = hpcla_halo_end(plan, stream);              // always: the caller's stream must be joined to the exchange
+    if (rc != HPCLA_OK) return rc;
+    if (rc_end != HPCLA_OK) return rc_end;
+    if (n_boundary > 0) {
+        double *ghost = nullptr;
+        rc = hpcla_halo_ghost_ptr(plan, &ghost, nullptr);
+        if (rc != HPCLA_OK) return rc;
+        b.ghost = ghost;
+        if (!ghost) return set_error(HPCLA_ERR_INVALID, "spmv_dist_f32: boundary blocks without a ghost segment");
+        rc = f32_launch<I>(rowptr, colval_split, nzval, b, y, 1, 0, nrows, nnz, 1, index_base, boundary, n_boundary, stream, "spmv_dist_f32");
+    }
+    return rc;
+}
+
+HPCLA_API int hpcla_spmv_dist_f32_i32(hpcla_halo_plan_t *plan, const int32_t *rowptr, const int32_t *colval_split, const float *nzval,
+                                      const float *x, int64_t n_own, float *y, int64_t nrows, int64_t nnz, int index_base,
+                                      const int32_t *interior_blocks, int64_t n_interior, const int32_t *boundary_blocks,
+                                      int64_t n_boundary, double *stage, void *stream)
+{
+    return spmv_dist_f32<int32_t>(plan, rowptr, colval_split, nzval, x, n_own, y, nrows, nnz, index_base, interior_blocks, n_interior,
+                                  boundary_blocks, n_boundary, stage, stream);
+}
+HPCLA_API int hpcla_spmv_dist_f32_i64(hpcla_halo_plan_t *plan, const int64_t *rowptr, const int64_t *colval_split, const float *nzval,
+                                      const float *x, int64_t n_own, float *y, int64_t nrows, int64_t nnz, int index_base,
+                                      const int32_t *interior_blocks, int64_t n_interior, const int32_t *boundary_blocks,
+                                      int64_t n_boundary, double *stage, void *stream)
+{
+    return spmv_dist_f32<int64_t>(plan, rowptr, colval_split, nzval, x, n_own, y, nrows, nnz, index_base, interior_blocks, n_interior,
+                                  boundary_blocks, n_boundary, stage, stream);
+}
+
 HPCLA_API int hpcla_halo_begin_f32(hpcla_halo_plan_t *plan, const float *x, double *stage, void *stream)
 {
     if (!plan) return set_error(HPCLA_ERR_INVALID, "halo_begin_f32: null plan");

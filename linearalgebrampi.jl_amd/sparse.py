@@ -764,24 +764,15 @@ def _spmv_into(y: HPCVector, A: HPCSparseMatrix, x: HPCVector, plan: VectorPlan)
 
 
 def _spmv_into_f32(y: HPCVector, A: HPCSparseMatrix, x: HPCVector, plan: VectorPlan) -> None:
-    """The Float32 form of the distributed product (csrc/f32.hip): the exchange widens what it sends into a staging vector
-    and runs on the plan's side stream while the interior row blocks multiply; the boundary blocks follow the exchange and
-    narrow the ghost values they gather.  Same transports, same block lists as the Float64 product."""
-    s = current_stream_ptr()
-    fn = f"hpcla_spmv_split_f32_{'i64' if plan.is_i64 else 'i32'}"
-    rp, cv = dptr(plan.rowptr_of(A)), dptr(plan.colval_split)
-    if not plan.has_halo:
-        _capi.call(fn, rp, cv, dptr(A.nzval), dptr(x.v), None, plan.n_own, dptr(y.v), A.nrows_local, A.nnz, 0, None, 0, s)
-        return
-    _capi.call("hpcla_halo_begin_f32", plan.halo, dptr(x.v), dptr(plan.stage_f32(plan.n_own)), s)
-    if plan.n_interior:
-        _capi.call(fn, rp, cv, dptr(A.nzval), dptr(x.v), None, plan.n_own, dptr(y.v), A.nrows_local, A.nnz, 0,
-                   dptr(plan.interior), plan.n_interior, s)
-    _capi.call("hpcla_halo_end", plan.halo, s)
-    if plan.n_boundary:
-        ghost, _n = plan.ghost_tensor_ptr()           # single-buffered plan: a constant, no device synchronisation
-        _capi.call(fn, rp, cv, dptr(A.nzval), dptr(x.v), ghost, plan.n_own, dptr(y.v), A.nrows_local, A.nnz, 0,
-                   dptr(plan.boundary), plan.n_boundary, s)
+    """The Float32 form of the distributed product (csrc/f32.hip, hpcla_spmv_dist_f32_*): the exchange widens what it sends
+    into the plan's staging vector and runs on the plan's side stream / in the peers' windows while the interior row blocks
+    multiply; the boundary blocks follow the exchange and narrow the ghost values they gather.  Same transports, same block
+    lists as the Float64 product; the plan is single-buffered (a constant ghost pointer)."""
+    sfx = "i64" if plan.is_i64 else "i32"
+    _capi.call(f"hpcla_spmv_dist_f32_{sfx}", plan.halo if plan.has_halo else None, dptr(plan.rowptr_of(A)),
+               dptr(plan.colval_split), dptr(A.nzval), dptr(x.v), plan.n_own, dptr(y.v), A.nrows_local, A.nnz, 0,
+               dptr(plan.interior), plan.n_interior, dptr(plan.boundary), plan.n_boundary,
+               dptr(plan.stage_f32(plan.n_own)) if plan.has_halo else None, current_stream_ptr())
 
 
 def mul_(y: HPCVector, A: HPCSparseMatrix, x: HPCVector) -> HPCVector:
