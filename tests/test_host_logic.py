@@ -410,6 +410,9 @@ def test_element_type_of_a_backend_and_what_float32_covers(hp):
     for name, args in sig.items():
         if "_f32" in name and name.replace("_f32", "_f64") in sig:
             twin = sig[name.replace("_f32", "_f64")]
-            same = [("s" if a in (hp._capi._f32, hp._capi._f64) else a) for a in args] == \
-                   [("s" if a in (hp._capi._f32, hp._capi._f64) else a) for a in twin]
-            assert same, name
+            norm = lambda seq: [("s" if a in (hp._capi._f32, hp._capi._f64) else a) for a in seq]
+            mine = norm(args)
+            if name.startswith("hpcla_spmv_dist_f32"):      # + the staging vector of the widened exchange, before the stream
+                assert mine[-2] is hp._capi._vp
+                mine = mine[:-2] + mine[-1:]
+            assert mine == norm(twin), name
