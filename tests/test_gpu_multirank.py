@@ -46,6 +46,9 @@ def test_push_transport_ranks_exchange(nranks):
         # the product-parking QUAD kernel of rounds 1-3 is still shipped (hpcla_set_spmv_kernel(1)): its fused distributed
         # form (push workgroups, waiting boundary blocks, p.Ap epilogue) keeps a real-rank run of its own
         env["HPCLA_SPMV_KERNEL"] = "quad"
+        # four processes time-slice ONE GPU here: the cases that differ in kind (slab with CG, unstructured all-to-all, the
+        # one-directional band, the empty rank); the 3-D slab, the other x partition and the pin cases run with 2 and 3 ranks
+        env["HPCLA_MR_CASES"] = "poisson2d,sprand,upper,tiny"
     env.pop("HPCLA_HALO_MODE", None)
     os.environ.pop("HPCLA_HALO_MODE", None)
     assert _spawn(nranks, env) == 0
@@ -62,7 +65,10 @@ def test_spmm_panel_order_within_tolerance(nranks):
     """HPCLA_SPMM_ORDER=panel (exchange overlapped chunk by chunk, config 5 at N > 1): same sums in a different
     ORDER -- 1e-12 relative and the componentwise |A||B| bound against the oracle; 2 ranks with both index types (Int64
     narrowed), 3 ranks (every rank has two neighbours per chunk-set plan, three chunk-sets) on the Int64 kernels."""
-    env = {"HPCLA_PUSH_TIMEOUT_S": "30", "HPCLA_SPMM_ORDER_TEST": "1", "HPCLA_MR_TYPES": "i32,i64" if nranks == 2 else "i64wide"}
+    env = {"HPCLA_PUSH_TIMEOUT_S": "30", "HPCLA_SPMM_ORDER_TEST": "1", "HPCLA_MR_TYPES": "i32,i64" if nranks == 2 else "i64wide",
+           # this run is about A*B: the products only (A*x, dependent steps, reductions and CG ran in the test above), on the
+           # cases whose exchanges differ in kind
+           "HPCLA_MR_PARTS": "spmm", "HPCLA_MR_CASES": "poisson2d,sprand" if nranks == 2 else "sprand,upper"}
     if nranks == 3:
         env["HPCLA_SPMM_PANELS"] = "3"
     assert _spawn(nranks, env) == 0
