@@ -5,7 +5,7 @@ per launch of the headline kernel and, under "workloads", per launch / per CG it
 line -- corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE counts 128-byte requests
 as 64 bytes -> doubled; WRITE_SIZE is exact; both are reported in KiB; separate --pmc passes.
 
-usage: python benchmarks/collect_profiles.py TAG [ROUND]      (ROUND defaults to r04)
+usage: python benchmarks/collect_profiles.py TAG [ROUND]      (ROUND defaults to r05)
 """
 import collections
 import csv
@@ -96,7 +96,7 @@ def workload_cg(tag, rnd, prof, alg_textbook, alg_moved):
 
 def main():
     tag = sys.argv[1]
-    rnd = sys.argv[2] if len(sys.argv) > 2 else "r04"
+    rnd = sys.argv[2] if len(sys.argv) > 2 else "r05"
     prof = os.path.join(ROOT, "profiles")
     shutil.copy(find(tag, "prof", "kernel_stats.csv"), os.path.join(prof, f"{rnd}_bench_kernel_stats.csv"))
     # the trace is large: keep the library's launches only
@@ -159,6 +159,16 @@ def main():
     wl["sprand_spmm_mall_sized"] = workload_single_kernel(
         tag, "sprand1", "spmm_rowblock_vec_kernel", rnd, prof, "sprand 2 097 152 rows x 29.8, B = 2 097 152 rows x 16 (Infinity-Cache-sized)", 1_295_259_584,
         "HPCLA_SPMM_COLS_MULT=1 python3 bench.py --workload sprand_spmm --steps 5 --warmup 5")
+    # round 5: the unstructured matrix times ONE vector (bench.py's `spmv_same_matrix` records); absent passes leave the keys out
+    for key, step, label, cmd in (
+            ("sprand_spmv_b2e24", "sprandv8", "sprand 2 097 152 rows x 29.8 times a vector of 2^24 entries (x = 134 MB)",
+             "HPCLA_SPRAND_SPMV=1 HPCLA_SPMM_COLS_MULT=8 python3 bench.py --workload sprand_spmm --steps 5 --warmup 5"),
+            ("sprand_spmv_mall_sized", "sprandv1", "sprand 2 097 152 rows x 29.8 times a vector of 2^21 entries (x = 17 MB)",
+             "HPCLA_SPRAND_SPMV=1 HPCLA_SPMM_COLS_MULT=1 python3 bench.py --workload sprand_spmm --steps 5 --warmup 5")):
+        try:
+            wl[key] = workload_single_kernel(tag, step, "spmv_rowgather_kernel<int, false, false>", rnd, prof, label, None, cmd)
+        except SystemExit as exc:
+            print(f"(no passes for {key}: {exc})")
     out["workloads"] = wl
     with open(os.path.join(prof, "traffic_latest.json"), "w") as f:
         json.dump(out, f, indent=1)

@@ -201,6 +201,18 @@ def _colmajor_cost(hp, A, B, k, b_alg, direct_too=True):
         capi.call(f"hpcla_spmm_csr_f64_{sfx}", dptr(rp), dptr(cv), dptr(A.nzval), dptr(Br), k, ROW, dptr(Cr), k, ROW, n, A.nnz, k, 0, s)
         capi.call("hpcla_transpose_f64", dptr(Cr), k, ROW, dptr(Cc), n, COL, n, k, s)
 
+    def b_only():
+        capi.call("hpcla_transpose_f64", dptr(Bc), nb, COL, dptr(Br), k, ROW, nb, k, s)
+
+    def product_only():
+        capi.call(f"hpcla_spmm_csr_f64_{sfx}", dptr(rp), dptr(cv), dptr(A.nzval), dptr(Br), k, ROW, dptr(Cr), k, ROW, n, A.nnz, k, 0, s)
+
+    def ccol():
+        # round 5: B converted once, the product writes C column-major itself (csrc/spmm.hip CCOL) -- what the Julia extension
+        # calls for an unstructured matrix
+        capi.call("hpcla_transpose_f64", dptr(Bc), nb, COL, dptr(Br), k, ROW, nb, k, s)
+        capi.call(f"hpcla_spmm_csr_f64_{sfx}", dptr(rp), dptr(cv), dptr(A.nzval), dptr(Br), k, ROW, dptr(Cc), n, COL, n, A.nnz, k, 0, s)
+
     def timed(fn, reps=20):
         t_end = time.perf_counter() + SETTLE_MS * 1e-3
         while time.perf_counter() < t_end:
@@ -214,22 +226,73 @@ def _colmajor_cost(hp, A, B, k, b_alg, direct_too=True):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps
     converted()
-    if not direct_too:
-        ms_c = timed(converted, 10)
-        return {"via_two_layout_conversions_ms": round(ms_c, 4),
-                "frac_of_peak": round(b_alg / (ms_c * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "note": "the product as a column-major caller (Julia's Matrix) gets it on an UNSTRUCTURED matrix: B converted to "
-                        "row-major rows, the row-major product, C converted back (the direct column-major form would touch a line "
-                        "per (entry, column) pair here); the record's own ms_per_step is the row-major host layer"}
     ref = Cc.clone()
+    ccol()
+    same_ccol = bool(torch.equal(ref, Cc))
+    if not direct_too:
+        ms_c, ms_cc, ms_b, ms_p = timed(converted, 10), timed(ccol, 10), timed(b_only, 10), timed(product_only, 10)
+        return {"via_b_conversion_and_colmajor_store_ms": round(ms_cc, 4),
+                "frac_of_peak": round(b_alg / (ms_cc * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "same_bits": same_ccol,
+                "b_conversion_ms": round(ms_b, 4), "rowmajor_product_ms": round(ms_p, 4),
+                "via_two_layout_conversions_ms": round(ms_c, 4),
+                "kernel": "hpcla::spmm_rowblock_vec_kernel<..., CCOL = true>",
+                "note": "the product as a column-major caller (Julia's Matrix) gets it on an UNSTRUCTURED matrix: B converted to "
+                        "row-major rows, then the row-major-B product that stores C column-major itself (round 5; before: C "
+                        "converted back by a second transposition = via_two_layout_conversions_ms); the direct column-major form "
+                        "would touch a line per (entry, column) pair here; the record's own ms_per_step is the row-major host layer"}
     direct()
     same = bool(torch.equal(ref, Cc))
     ms_d, ms_c = timed(direct), timed(converted)
+    ms_cc = timed(ccol)
     return {"direct_ms": round(ms_d, 4), "direct_frac_of_peak": round(b_alg / (ms_d * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "kernel": "hpcla::rowgather_kernel<double, int, false, 16, 2>",
-            "via_two_layout_conversions_ms": round(ms_c, 4), "same_bits": same,
+            "via_two_layout_conversions_ms": round(ms_c, 4), "same_bits": same and same_ccol,
+            "via_b_conversion_and_colmajor_store_ms": round(ms_cc, 4),
             "note": "the product as a column-major caller (Julia's Matrix) gets it: on the blocks as they are (lanes = rows kernel) "
                     "against transpose + row-major product + transpose; the record's own ms_per_step is the row-major host layer"}
+
+
+def _sprand_spmv(hp, wl, job, A, ncols, backend, args):
+    """The unstructured matrix of config 5 times ONE vector (N = 1): the shape of the reference's own single-rank SpMV
+    benchmark (tools/benchmark_single_rank.jl:48-71: random columns, ~10 per row; here config 5's ~30), on the default
+    row-gather kernel.  Every stored entry gathers one x value from a random place: 8 useful bytes out of a 64-byte sector
+    (128-byte line), so the each-value-once algorithmic count is far from what the memory system serves -- the record carries
+    both, and the stored PMC traffic."""
+    import torch
+    xv = hp.HPCVector.zeros(np.array([0, ncols]), backend)
+    hp._capi.call("hpcla_fill_uniform_f64", xv.v.data_ptr(), 0, ncols, wl.SEED_X, torch.cuda.current_stream().cuda_stream)
+    yv = A @ xv
+    step = lambda: hp.mul_(yv, A, xv)
+    n_warm = warm_up(job, step, max(args.warmup, 5))
+    steps = min(args.steps, 50)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(steps):
+        step()
+    ev1.record()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    dev_ms = ev0.elapsed_time(ev1) / steps
+    plan = hp.get_vector_plan(A, xv)
+    b_alg = wl.spmv_algorithmic_bytes(A.nnz, A.nrows_local, A.ncols_compressed, 4)
+    b_sect = A.nnz * (12 + 64) + 12 * A.nrows_local
+    mall = ncols * 8 <= (1 << 25)           # the small sibling: x of 17 MB (8 L2s x 4 MiB hold most of it)
+    traffic, traffic_source = stored_traffic("sprand_spmv_mall_sized" if mall else "sprand_spmv_b2e24",
+                                             A.nrows_local == 2_097_152 and ncols in (2_097_152, 16_777_216))
+    return {"metric": "SpMV GFLOP/s (2*nnz/t), sprand ~29.8 nnz/row, fp64", "value": round(2.0 * A.nnz / (ms * 1e-3) / 1e9, 1),
+            "unit": "GFLOP/s", "steps": steps, "warmup": n_warm, "ms_per_step": round(ms, 4), "device_ms_per_step": round(dev_ms, 4),
+            "config": {"workload": f"sprand-like {A.nrows_local} x {ncols}, nnz={A.nnz}, CSR SpMV y=A*x, index=i32; x = {ncols * 8 / 1e6:.0f} MB "
+                                   + ("(about the size of the eight L2s together)" if mall else "(beyond the L2s, inside the 256 MiB Infinity Cache)"),
+                       "ncols_compressed": A.ncols_compressed},
+            "roofline": {"bound": "hbm", "achieved": round(b_alg / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel": "hpcla::spmv_rowgather_kernel<int, false, false>", "algorithmic_bytes_per_launch": b_alg,
+                         "block_order_group": int(getattr(plan, "block_group", 1)),
+                         "sector_gather_bytes_per_launch": b_sect, "sector_gather_gbs": round(b_sect / (ms * 1e-3) / 1e9, 1),
+                         "note": "achieved = algorithmic bytes (each x value once) / WALL time per step; sector_gather = 12 B + one 64-byte "
+                                 "sector of x per stored entry -- what a random gather asks of the memory system"}}
 
 
 def device_stencil(hp, torch, backend, dims, lo, hi):
@@ -428,32 +491,10 @@ def run_record(args, backend, rank, world, job):
         _sync_stamp("sprand: entries generated")
         A = hp.HPCSparseMatrix_local_device(rowptr, cols, vals, ncols, backend, col_window=(0, ncols - 1))
         del cols
-        if os.environ.get("HPCLA_SPRAND_SPMV", "") == "1":
-            # the same unstructured matrix times ONE vector (single GPU only): the x gather is one
-            # 64-byte sector per stored entry, far from the each-value-once algorithmic count
-            xv = hp.HPCVector.zeros(np.array([0, ncols]), backend)
-            hp._capi.call("hpcla_fill_uniform_f64", xv.v.data_ptr(), 0, ncols, wl.SEED_X,
-                          torch.cuda.current_stream().cuda_stream)
-            yv = A @ xv
-            for _ in range(args.warmup):
-                hp.mul_(yv, A, xv)
-            _sync_barrier(job)
-            steps = min(args.steps, 50)
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                hp.mul_(yv, A, xv)
-            _sync_barrier(job)
-            ms = (time.perf_counter() - t0) / steps * 1e3
-            b_alg = wl.spmv_algorithmic_bytes(A.nnz, A.nrows_local, A.ncols_compressed, 4)
-            b_sect = A.nnz * (12 + 64) + 12 * A.nrows_local
-            line = json.dumps({"metric": "SpMV GFLOP/s, sprand ~29.8 nnz/row", "value": round(2.0 * A.nnz / (ms * 1e-3) / 1e9, 1),
-                              "ms_per_step": round(ms, 4), "nnz": A.nnz, "ncols_compressed": A.ncols_compressed,
-                              "algorithmic_gbs": round(b_alg / (ms * 1e-3) / 1e9, 1),
-                              "frac_of_peak_algorithmic": round(b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                              "sector_gather_gbs": round(b_sect / (ms * 1e-3) / 1e9, 1),
-                              "note": "sector_gather = 12 B + one 64-byte sector of x per stored entry"})
+        if os.environ.get("HPCLA_SPRAND_SPMV", "") == "1":       # the SpMV record alone (PMC passes: benchmarks/collect_profiles.py)
+            rec = _sprand_spmv(hp, wl, job, A, ncols, backend, args)
             hp.clear_plan_cache()
-            return json.loads(line)
+            return rec
         b_rows = rows_loc * mult
         Bl = torch.empty((b_rows, k), dtype=torch.float64, device=dev)
         hp._capi.call("hpcla_fill_uniform_f64", Bl.data_ptr(), rank * b_rows * k, b_rows * k, wl.SEED_X,
@@ -475,6 +516,12 @@ def run_record(args, backend, rank, world, job):
                             share_note=("" if ncols in (16_777_216, 2_097_152) else
                                         f"the stored pass has B = 16777216 rows (the 8-GPU gather set), this run {ncols}: both far "
                                         "beyond the Infinity Cache, one 128-byte line per stored entry either way"))
+        if world == 1 and not order and os.environ.get("HPCLA_BENCH_SPRAND_SPMV", "1") != "0":
+            # the same matrix times one vector: the unstructured SpMV's current number
+            try:
+                out["spmv_same_matrix"] = _sprand_spmv(hp, wl, job, A, ncols, backend, args)
+            except Exception as exc:
+                out["spmv_same_matrix"] = {"error": f"{type(exc).__name__}: {exc}"}
         if order:
             out["config"]["workload"] += f"; HPCLA_SPMM_ORDER={order}"
             if saved_order is None:

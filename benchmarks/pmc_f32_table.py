@@ -39,14 +39,17 @@ def newest(tag, step, counter):
 
 def main():
     tag = sys.argv[1]
-    rnd = sys.argv[2] if len(sys.argv) > 2 else "r04"
+    rnd = sys.argv[2] if len(sys.argv) > 2 else "r05"
     prof = os.path.join(ROOT, "profiles")
     n = N * N
     nnz = 5 * n - 4 * N
     ns, nnzs = N * (N // 2), 5 * N * (N // 2) - 2 * N - 2 * (N // 2)
-    cases = [("spmv", "rowgather_f32_kernel<int, false, 1>", "SpMV, 5-point 4096^2, Float32 / Int32", nnz * 8 + (n + 1) * 4 + 8 * n),
+    # kernel names as rocprofv3 prints them: the lanes = rows kernels are instances of the shared template
+    # rowgather_kernel<T, I, SPLIT, KC, URX> (csrc/rowgather_t.h) since round 4's refactor
+    rg = lambda kc: "rowgather_kernel<float, int, false, %d, 0>" % kc
+    cases = [("spmv", rg(1), "SpMV, 5-point 4096^2, Float32 / Int32", nnz * 8 + (n + 1) * 4 + 8 * n),
              ("spmm", "rowmajor_f32_kernel<int, false, 4, 4>", "SpMM x 16 row-major, 5-point 4096 x 2048", nnzs * 8 + (ns + 1) * 4 + 128 * ns),
-             ("spmm", "rowgather_f32_kernel<int, false, 16>", "SpMM x 16 column-major, 5-point 4096 x 2048", nnzs * 8 + (ns + 1) * 4 + 128 * ns)]
+             ("spmm", rg(16), "SpMM x 16 column-major, 5-point 4096 x 2048", nnzs * 8 + (ns + 1) * 4 + 128 * ns)]
     out = {}
     print(f"# HBM traffic per launch of the Float32 kernels, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), tag {tag}")
     print("# FETCH_SIZE doubled (gfx950 counts 128-byte requests as 64), WRITE_SIZE exact, both KiB")

@@ -260,6 +260,22 @@ int hpcla_spmm_split_f64_i64(const int64_t *rowptr, const int64_t *colval_split,
                              const double *B_ghost, int64_t ldb_ghost, int64_t n_own, double *C,
                              int64_t ldc, int64_t nrows, int64_t nnz, int k, int index_base,
                              const int32_t *block_list, int64_t n_blocks, void *stream);
+/* hpcla_spmm_split_f64_* with a COLUMN-major result (element (r, c) at C[r + c * ldc], ldc >= nrows; the reference's dense
+ * block is a Julia Matrix, src/dense.jl:63) while B_own / B_ghost stay row-major rows: the product an UNSTRUCTURED matrix
+ * gets from a column-major caller -- B converted once (hpcla_transpose_f64; an unstructured matrix gathers whole B rows, so
+ * the row-major layout is the fast one), C written in the caller's layout by the product itself (even k <= 16: the block's
+ * results leave through LDS as k runs of 64 doubles; other k: the strided kernel).  Same sums, same order, same bits.
+ * hpcla_spmm_csr_f64_* with b_layout = HPCLA_LAYOUT_ROW, c_layout = HPCLA_LAYOUT_COL takes the same kernel. */
+int hpcla_spmm_split_ccol_f64_i32(const int32_t *rowptr, const int32_t *colval_split,
+                                  const double *nzval, const double *B_own, int64_t ldb_own,
+                                  const double *B_ghost, int64_t ldb_ghost, int64_t n_own, double *C,
+                                  int64_t ldc, int64_t nrows, int64_t nnz, int k, int index_base,
+                                  const int32_t *block_list, int64_t n_blocks, void *stream);
+int hpcla_spmm_split_ccol_f64_i64(const int64_t *rowptr, const int64_t *colval_split,
+                                  const double *nzval, const double *B_own, int64_t ldb_own,
+                                  const double *B_ghost, int64_t ldb_ghost, int64_t n_own, double *C,
+                                  int64_t ldc, int64_t nrows, int64_t nnz, int k, int index_base,
+                                  const int32_t *block_list, int64_t n_blocks, void *stream);
 /* RUN TILES (round 4; no reference counterpart -- the reference's A * B is a column loop over A * x,
  * src/sparse.jl:2391-2413): for banded / stencil matrices the 64 rows of an SpMM row block touch a few CONTIGUOUS runs of
  * B rows (5-point matrix: 194 rows in 3 runs, where its entries name 320).  Plan time, once per structure:

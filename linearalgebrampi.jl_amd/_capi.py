@@ -78,6 +78,8 @@ _SIGNATURES = {
     "hpcla_spmm_csr_f64_i64": [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _i64, _i32, _i64, _i64, _i32, _i32, _vp],
     "hpcla_spmm_split_f64_i32": [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _i64, _vp],
     "hpcla_spmm_split_f64_i64": [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _i64, _vp],
+    "hpcla_spmm_split_ccol_f64_i32": [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _i64, _vp],
+    "hpcla_spmm_split_ccol_f64_i64": [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _i64, _vp],
     "hpcla_spmm_split_colmajor_f64_i32": [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _i64, _vp],
     "hpcla_spmm_split_colmajor_f64_i64": [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _i64, _vp],
     "hpcla_halo_begin_strided_f64": [_vp, _vp, _i64, _i64, _vp, _vp],

@@ -51,6 +51,7 @@ uint64_t host_identity();
 int window_alloc(void **p, size_t bytes, bool uncached);
 int window_open(const WindowDesc &d, int peer_rank, int my_rank, void *my_base, PeerMap *out);
 void window_close(PeerMap *m);
+void window_free(void *win);                   // hipFree + forget the process-local registration
 int64_t spin_timeout_ticks();                  // HPCLA_PUSH_TIMEOUT_S (default 300 s) in wall_clock64 ticks
 
 }  // namespace hpcla

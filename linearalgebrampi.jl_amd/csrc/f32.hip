@@ -290,7 +290,7 @@ __device__ __forceinline__ double f_map(float a, float b, int negate)
 template <int OP>
 __device__ __forceinline__ double f_comb(double s, double v)
 {
-    if (OP == F_AMAX || OP == F_MAXV) return v > s ? v : s;
+    if (OP == F_AMAX || OP == F_MAXV) return (v > s || v != v) ? v : s;      // NaN-propagating (see vecops.hip red_comb)
     return s + v;
 }
 template <int OP>

@@ -212,7 +212,12 @@ typedef const vdouble2 __attribute__((address_space(1))) *gvec2_ptr;   // global
 // (c_rs == k <= tile width); K16 additionally folds the strides of the device-native shape to constants.
 // TAIL2: k is even but not a multiple of 4 (k = 2, 6, 10, 14 ...): the lane that holds the last column pair loads, adds
 // and stores only its first 16 bytes -- the reference's own SpMM test has k = 6 (test/test_new_operations.jl:43-59).
-template <typename I, bool SPLIT, int CHUNK_V, bool HALF64, bool CSTAGE, bool K16, int LPR, bool TAIL2>
+// CCOL (round 5): C is COLUMN-major -- the caller's Julia Matrix (src/dense.jl:63) -- while B stays row-major rows: the
+// block's 64 x k results leave through LDS anyway (CSTAGE), so they are parked there column by column and written as k
+// runs of 64 doubles (512 B) instead of 64 rows of k.  `c_rs` is then the COLUMN stride of C (its leading dimension).
+// The unstructured product of a column-major caller drops the conversion of C this way (B is still converted once: an
+// unstructured matrix gathers whole B rows).  Not with `accumulate` (the panel order runs on row-major C).
+template <typename I, bool SPLIT, int CHUNK_V, bool HALF64, bool CSTAGE, bool K16, int LPR, bool TAIL2, bool CCOL = false>
 __global__ __launch_bounds__(64 * LPR) void spmm_rowblock_vec_kernel(
     const I *__restrict__ rowptr, const I *__restrict__ colval, const double *__restrict__ nzval,
     const double *__restrict__ B_own, int64_t b_rs, const double *__restrict__ B_ghost, int64_t bg_rs,
@@ -223,13 +228,15 @@ __global__ __launch_bounds__(64 * LPR) void spmm_rowblock_vec_kernel(
     static_assert(!HALF64 || LPR == 4, "the 64-contiguous-bytes lane mapping needs four lanes per row");
     static_assert(!K16 || (CSTAGE && HALF64), "K16 is the device-native shape");
     static_assert(!TAIL2 || !HALF64, "the 64-contiguous-bytes mapping needs whole 16-column tiles");
+    static_assert(!CCOL || (CSTAGE && LPR == 4), "the column-major store goes through the LDS tile");
     __shared__ SpmmEntry s_ent[CHUNK_V];
 
     if (K16) {
         // the device-native shape (k = 16, B / ghost / C rows of exactly 16 doubles: checked by the launcher): strides
         // and the column-tile loop fold to constants (measured against a k = 16-only copy of this kernel in the tuning
         // harness, benchmarks/tune/spmm_variants.hip MODE 0: the generic form ran 3 % behind it)
-        k = KT; b_rs = KT; bg_rs = KT; c_rs = KT;
+        k = KT; b_rs = KT; bg_rs = KT;
+        if (!CCOL) c_rs = KT;
     }
     const int tid = threadIdx.x;
     const int g = tid / LPR, l = tid % LPR;   // g = row of the block (0..63)
@@ -291,7 +298,7 @@ __global__ __launch_bounds__(64 * LPR) void spmm_rowblock_vec_kernel(
         double acc[VCPL];
 #pragma unroll
         for (int q = 0; q < VCPL; ++q) acc[q] = 0.0;
-        if (accumulate && g < nr && col_ok) {
+        if (!CCOL && accumulate && g < nr && col_ok) {
             // panel order (hpcla_spmm_panel_*): this lane's four sums continue from what earlier panels left in C
             const double *cur = C + (r0 + g) * c_rs + c;
             const vdouble2 c0 = *reinterpret_cast<const vdouble2 *>(cur);
@@ -351,6 +358,38 @@ __global__ __launch_bounds__(64 * LPR) void spmm_rowblock_vec_kernel(
                 acc[3] += en.val * b1.y;
             }
         }
+        if (CCOL) {
+            // column-major C: park the tile column by column (s_c[c * 64 + g]; the four lanes of a row write four different
+            // columns at the same row offset: a 4-way bank conflict on 4 writes per lane, nothing next to the gathers),
+            // then every column leaves as one run of nr doubles -- a wave's store instruction covers two columns' 512 bytes
+            __syncthreads();                               // every lane has finished reading the records
+            double *s_c = reinterpret_cast<double *>(s_ent);
+            static_assert(sizeof(SpmmEntry) * CHUNK_V >= sizeof(double) * RPB_MM * KT, "C tile fits the record area");
+            if (col_ok) {
+                s_c[c * RPB_MM + g] = acc[0];
+                s_c[(c + 1) * RPB_MM + g] = acc[1];
+                if (two) {
+                    s_c[(c + SECOND / 8) * RPB_MM + g] = acc[2];
+                    s_c[(c + SECOND / 8 + 1) * RPB_MM + g] = acc[3];
+                }
+            }
+            __syncthreads();
+            const vdouble2 *src = reinterpret_cast<const vdouble2 *>(s_c);
+            const int count = k * (RPB_MM / 2);
+            if ((c_rs & 1) == 0) {
+                for (int i = tid; i < count; i += TPB) {
+                    const int cc = i / (RPB_MM / 2), gp = (i % (RPB_MM / 2)) * 2;
+                    double *dst = C + (int64_t)cc * c_rs + r0 + gp;
+                    if (gp + 1 < nr) __builtin_nontemporal_store(src[i], reinterpret_cast<vdouble2 *>(dst));
+                    else if (gp < nr) __builtin_nontemporal_store(src[i].x, dst);
+                }
+            } else {                                       // odd leading dimension: columns start 8-byte aligned only
+                for (int i = tid; i < k * RPB_MM; i += TPB) {
+                    const int cc = i / RPB_MM, gg = i % RPB_MM;
+                    if (gg < nr) __builtin_nontemporal_store(s_c[i], C + (int64_t)cc * c_rs + r0 + gg);
+                }
+            }
+        } else
         if (CSTAGE) {
             // C through LDS (k <= one column tile, C rows contiguous: c_rs == k): the block's 64 x k results form ONE
             // contiguous region of C (8 KiB at k = 16); written from the accumulators, a store instruction covers 16
@@ -742,7 +781,10 @@ static int spmm_launch(const I *rowptr, const I *colval, const double *nzval, co
     hipStream_t s = as_stream(stream);
     dim3 grid((uint32_t)launch_blocks), block(TPB_MM);
     // device-native layout: row-major B / C, k even (16-byte column pairs), everything 16-byte aligned
-    const bool vec_ok = b_cs == 1 && c_cs == 1 && (k % 2) == 0 && (b_rs % 2) == 0 && (c_rs % 2) == 0 &&
+    // ... or row-major B with a COLUMN-major C of up to one column tile (round 5: the column-major caller's unstructured
+    // product; CCOL in the kernel): c_rs == 1, c_cs = C's leading dimension
+    const bool c_col = c_rs == 1 && c_cs != 1 && k <= KT && !accumulate && c_cs >= nrows;
+    const bool vec_ok = b_cs == 1 && (c_col || (c_cs == 1 && (c_rs % 2) == 0)) && (k % 2) == 0 && (b_rs % 2) == 0 &&
                         (!split || (bg_rs % 2) == 0) &&
                         ((reinterpret_cast<uintptr_t>(B_own) | reinterpret_cast<uintptr_t>(C) |
                           (split ? reinterpret_cast<uintptr_t>(B_ghost) : 0)) & 15) == 0;
@@ -768,9 +810,9 @@ static int spmm_launch(const I *rowptr, const I *colval, const double *nzval, co
             const char *e = getenv("HPCLA_SPMM_LPR");
             return e ? atoi(e) : 0;
         }();
-        const int lpr = (k <= 8 && lpr_env != 4) ? 2 : 4;
+        const int lpr = (k <= 8 && lpr_env != 4 && !c_col) ? 2 : 4;
         const bool h64 = lpr == 4 && h64_env != 0 && (k % 16) == 0;
-        const bool cstage = cst_env != 0 && k <= 4 * lpr && c_rs == k;
+        const bool cstage = c_col || (cst_env != 0 && k <= 4 * lpr && c_rs == k);
         const bool k16 = h64 && cstage && k == KT && b_rs == KT && (!split || bg_rs == KT);
         const bool tail2 = (k % 4) != 0;                 // even k: the last column pair of a row is half a lane's share
         const int glog2 = spmm_group_log2(rowptr);
@@ -783,8 +825,17 @@ static int spmm_launch(const I *rowptr, const I *colval, const double *nzval, co
     spmm_rowblock_vec_kernel<I, SP, CH, H64, CST, K16F, LPRV, (T2)><<<grid, dim3(64 * LPRV), 0, s>>>(     \
         rowptr, colval, nzval, B_own, b_rs, SP ? B_ghost : nullptr, SP ? bg_rs : 0, SP ? n_own : 0, C, c_rs, \
         nrows, k, index_base, block_list, (uint32_t)launch_blocks, accumulate, glog2)
+#define HPCLA_SPMM_VECC(SP, CH, H64, K16F, T2)                                                           \
+    spmm_rowblock_vec_kernel<I, SP, CH, H64, true, K16F, 4, (T2), true><<<grid, dim3(256), 0, s>>>(       \
+        rowptr, colval, nzval, B_own, b_rs, SP ? B_ghost : nullptr, SP ? bg_rs : 0, SP ? n_own : 0, C, c_cs, \
+        nrows, k, index_base, block_list, (uint32_t)launch_blocks, 0, glog2)
 #define HPCLA_SPMM_VEC1(SP, CH)                                                                          \
     do {                                                                                                \
+        if (c_col) {                                                                                    \
+            if (k16) HPCLA_SPMM_VECC(SP, CH, true, true, false);                                        \
+            else if (tail2) HPCLA_SPMM_VECC(SP, CH, false, false, true);                                \
+            else HPCLA_SPMM_VECC(SP, CH, false, false, false);                                          \
+        } else                                                                                          \
         if (lpr == 2) { if (cstage) HPCLA_SPMM_VEC(SP, CH, false, true, false, 2); else HPCLA_SPMM_VEC(SP, CH, false, false, false, 2); } \
         else if (k16) HPCLA_SPMM_VEC(SP, CH, true, true, true, 4);                                      \
         else if (h64 && cstage) HPCLA_SPMM_VEC(SP, CH, true, true, false, 4);                           \
@@ -796,6 +847,7 @@ static int spmm_launch(const I *rowptr, const I *colval, const double *nzval, co
     do { if (small) HPCLA_SPMM_VEC1(SP, 512); else HPCLA_SPMM_VEC1(SP, 1536); } while (0)
         if (split) HPCLA_SPMM_VEC2(true); else HPCLA_SPMM_VEC2(false);
 #undef HPCLA_SPMM_VEC2
+#undef HPCLA_SPMM_VECC
 #undef HPCLA_SPMM_VEC1
 #undef HPCLA_SPMM_VEC
 #undef HPCLA_SPMM_VECT
@@ -967,6 +1019,34 @@ HPCLA_API int hpcla_spmm_split_f64_i64(const int64_t *rowptr, const int64_t *col
 {
     return spmm_launch<int64_t>(rowptr, colval_split, nzval, B_own, ldb_own, 1, B_ghost, ldb_ghost,
                                 n_own, true, C, ldc, 1, nrows, nnz, k, index_base, block_list,
+                                n_blocks, stream);
+}
+
+// row-major B rows (own block + ghost segment), COLUMN-major C (round 5): the unstructured product of a column-major caller
+// without the conversion of C (even k <= 16: the vec kernel's CCOL store; anything else: the generic strided kernel)
+HPCLA_API int hpcla_spmm_split_ccol_f64_i32(const int32_t *rowptr, const int32_t *colval_split,
+                                            const double *nzval, const double *B_own, int64_t ldb_own,
+                                            const double *B_ghost, int64_t ldb_ghost, int64_t n_own,
+                                            double *C, int64_t ldc, int64_t nrows, int64_t nnz, int k,
+                                            int index_base, const int32_t *block_list,
+                                            int64_t n_blocks, void *stream)
+{
+    if (ldc < nrows) return set_error(HPCLA_ERR_INVALID, "spmm_split_ccol: ldc < nrows");
+    return spmm_launch<int32_t>(rowptr, colval_split, nzval, B_own, ldb_own, 1, B_ghost, ldb_ghost,
+                                n_own, true, C, 1, ldc, nrows, nnz, k, index_base, block_list,
+                                n_blocks, stream);
+}
+
+HPCLA_API int hpcla_spmm_split_ccol_f64_i64(const int64_t *rowptr, const int64_t *colval_split,
+                                            const double *nzval, const double *B_own, int64_t ldb_own,
+                                            const double *B_ghost, int64_t ldb_ghost, int64_t n_own,
+                                            double *C, int64_t ldc, int64_t nrows, int64_t nnz, int k,
+                                            int index_base, const int32_t *block_list,
+                                            int64_t n_blocks, void *stream)
+{
+    if (ldc < nrows) return set_error(HPCLA_ERR_INVALID, "spmm_split_ccol: ldc < nrows");
+    return spmm_launch<int64_t>(rowptr, colval_split, nzval, B_own, ldb_own, 1, B_ghost, ldb_ghost,
+                                n_own, true, C, 1, ldc, nrows, nnz, k, index_base, block_list,
                                 n_blocks, stream);
 }
 

@@ -32,7 +32,9 @@ __device__ __forceinline__ double red_map(double a, double b, double p = 0.0)
 template <int OP>
 __device__ __forceinline__ double red_comb(double s, double v)
 {
-    if (OP == RED_MAX || OP == RED_MAXV) return v > s ? v : s;
+    // NaN-propagating like Julia's maximum / norm(., Inf) (src/vectors.jl:769-772): a plain `v > s ? v : s` never selects
+    // a NaN v, which would let rows poisoned by an expired halo wait (halo_poison) pass as a finite maximum
+    if (OP == RED_MAX || OP == RED_MAXV) return (v > s || v != v) ? v : s;
     if (OP == RED_PROD) return s * v;
     return s + v;
 }

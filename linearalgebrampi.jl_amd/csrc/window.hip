@@ -32,6 +32,10 @@
 #include <string.h>
 #include <unistd.h>
 
+#include <array>
+#include <map>
+#include <mutex>
+
 #include "comm_internal.h"
 #include "halo_wait.h"
 
@@ -111,11 +115,53 @@ int window_alloc(void **p, size_t bytes, bool uncached)
     return HPCLA_OK;
 }
 
+// Windows exported by THIS process, by IPC handle.  A handle cannot be opened in the process that made it, and a
+// process may host several ranks (one host thread per rank, each with its own communicator -- the arrangement of
+// tests/cabi/cabi_ranks_threads.c, which rehearses 8 ranks inside the box's limit on GPU processes): such peers
+// are reached through the exporter's own pointer.
+static std::mutex g_local_mu;
+static std::map<std::array<uint8_t, 64>, void *> g_local_windows;
+
+static void local_window_register(const uint8_t *ipc, void *base)
+{
+    std::array<uint8_t, 64> k;
+    memcpy(k.data(), ipc, 64);
+    std::lock_guard<std::mutex> lock(g_local_mu);
+    g_local_windows[k] = base;
+}
+
+static void local_window_forget(void *base)
+{
+    std::lock_guard<std::mutex> lock(g_local_mu);
+    for (auto it = g_local_windows.begin(); it != g_local_windows.end();)
+        it = it->second == base ? g_local_windows.erase(it) : std::next(it);
+}
+
+static void *local_window_find(const uint8_t *ipc)
+{
+    std::array<uint8_t, 64> k;
+    memcpy(k.data(), ipc, 64);
+    std::lock_guard<std::mutex> lock(g_local_mu);
+    auto it = g_local_windows.find(k);
+    return it == g_local_windows.end() ? nullptr : it->second;
+}
+
+void window_free(void *win)
+{
+    if (!win) return;
+    local_window_forget(win);
+    (void)hipFree(win);
+}
+
 int window_open(const WindowDesc &d, int peer_rank, int my_rank, void *my_base, PeerMap *out)
 {
     if (d.bytes == 0) return set_error(HPCLA_ERR_INVALID, "window_open: rank %d exported no window", peer_rank);
-    if (peer_rank == my_rank && d.pid == (uint64_t)getpid()) {
-        out->base = my_base;                   // a handle cannot be opened in the process that made it
+    if (d.pid == (uint64_t)getpid() && d.host_id == host_identity()) {
+        // a window of this process: mine, or that of another rank hosted here
+        void *base = peer_rank == my_rank ? my_base : local_window_find(d.ipc);
+        if (!base)
+            return set_error(HPCLA_ERR_INVALID, "window_open: rank %d's window is of this process but not registered", peer_rank);
+        out->base = base;
         out->opened = false;
         return HPCLA_OK;
     }
@@ -166,8 +212,12 @@ static void fill_desc(WindowDesc *d, void *win, size_t bytes)
     if (hipGetDevice(&cur) == hipSuccess) d->device_id = device_identity_of(cur);
     if (win) {
         hipIpcMemHandle_t h;
-        if (hipIpcGetMemHandle(&h, win) == hipSuccess) memcpy(d->ipc, &h, sizeof(h));
-        else d->bytes = 0;
+        if (hipIpcGetMemHandle(&h, win) == hipSuccess) {
+            memcpy(d->ipc, &h, sizeof(h));
+            local_window_register(d->ipc, win);
+        } else {
+            d->bytes = 0;
+        }
     }
 }
 
@@ -346,7 +396,7 @@ void push_free(hpcla_halo_plan *p)
     p->arrive = nullptr;
     p->epoch_dev = nullptr;
     if (p->win) {
-        (void)hipFree(p->win);
+        window_free(p->win);
         p->win = nullptr;
         p->ghost = nullptr;                    // lived inside the window
     }
@@ -392,7 +442,7 @@ __global__ __launch_bounds__(64) void window_allreduce_kernel(uint64_t *const *_
     if (j < count) {
         double acc = s_val[0][j];
         for (int r = 1; r < nranks; ++r)
-            acc = op == 0 ? acc + s_val[r][j] : (op == 2 ? acc * s_val[r][j] : (s_val[r][j] > acc ? s_val[r][j] : acc));
+            acc = op == 0 ? acc + s_val[r][j] : (op == 2 ? acc * s_val[r][j] : ((s_val[r][j] > acc || s_val[r][j] != s_val[r][j]) ? s_val[r][j] : acc));
         buf[j] = acc;
     }
     if (j == 0) __hip_atomic_store(done, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every lane has read it (barrier above)
@@ -421,7 +471,7 @@ void comm_window_free(hpcla_comm *comm)
     comm->peer_slots_dev = nullptr;
     if (comm->ar_done_dev) (void)hipFree(comm->ar_done_dev);
     comm->ar_done_dev = nullptr;
-    if (comm->win) (void)hipFree(comm->win);
+    window_free(comm->win);
     comm->win = nullptr;
     comm->win_attached = false;
 }
@@ -491,20 +541,26 @@ HPCLA_API int hpcla_comm_window_selftest(hpcla_comm_t *comm, double timeout_s, i
     double *buf = nullptr;
     HPCLA_CHECK_HIP(hipMalloc((void **)&buf, sizeof(double)));
     const double mine = (double)(comm->rank + 1);
-    hipError_t e = hipMemcpy(buf, &mine, sizeof(double), hipMemcpyHostToDevice);
+    // a stream of its own, not the null stream: ranks hosted by ONE process (a host thread each) would otherwise queue
+    // their test kernels behind each other on the process's null stream, the first spinning for partials the later ones
+    // cannot deliver
+    hipStream_t s = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMemcpyAsync(buf, &mine, sizeof(double), hipMemcpyHostToDevice, s);
     double got = 0.0;
     uint32_t st = 1;
     if (e == hipSuccess) {
         uint64_t *my_slots = reinterpret_cast<uint64_t *>(reinterpret_cast<uint8_t *>(comm->win) + WIN_LINE);
-        window_allreduce_kernel<<<1, 64, 0, nullptr>>>((uint64_t *const *)comm->peer_slots_dev, my_slots,
-                                                       reinterpret_cast<uint32_t *>(comm->win), buf, 1, 0,
-                                                       comm->nranks, comm->rank, comm->ar_done_dev,
-                                                       (int64_t)((timeout_s > 0 ? timeout_s : 5.0) * 1.0e8));
+        window_allreduce_kernel<<<1, 64, 0, s>>>((uint64_t *const *)comm->peer_slots_dev, my_slots,
+                                                 reinterpret_cast<uint32_t *>(comm->win), buf, 1, 0,
+                                                 comm->nranks, comm->rank, comm->ar_done_dev,
+                                                 (int64_t)((timeout_s > 0 ? timeout_s : 5.0) * 1.0e8));
         e = hipGetLastError();
-        if (e == hipSuccess) e = hipDeviceSynchronize();
-        if (e == hipSuccess) e = hipMemcpy(&got, buf, sizeof(double), hipMemcpyDeviceToHost);
-        if (e == hipSuccess) e = hipMemcpy(&st, comm->win, sizeof(st), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpyAsync(&got, buf, sizeof(double), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(&st, comm->win, sizeof(st), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
     }
+    if (s) (void)hipStreamDestroy(s);
     (void)hipFree(buf);
     if (e != hipSuccess) return set_error(HPCLA_ERR_HIP, "comm_window_selftest: %s", hipGetErrorString(e));
     const double want = 0.5 * comm->nranks * (comm->nranks + 1.0);

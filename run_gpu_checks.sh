@@ -54,6 +54,8 @@ for st in $STEPS; do
         run 300 gpurun_out/${TAG}_pmc_spmm2d_$c.log rocprofv3 --pmc $c --output-format csv -d gpurun_out/${TAG}_pmc_spmm2d_$c -- python3 bench.py --workload poisson2d_spmm --steps 5 --warmup 5
         HPCLA_SPMM_COLS_MULT=8 run 300 gpurun_out/${TAG}_pmc_sprand8_$c.log rocprofv3 --pmc $c --output-format csv -d gpurun_out/${TAG}_pmc_sprand8_$c -- python3 bench.py --workload sprand_spmm --steps 5 --warmup 5
         HPCLA_SPMM_COLS_MULT=1 run 300 gpurun_out/${TAG}_pmc_sprand1_$c.log rocprofv3 --pmc $c --output-format csv -d gpurun_out/${TAG}_pmc_sprand1_$c -- python3 bench.py --workload sprand_spmm --steps 5 --warmup 5
+        HPCLA_SPRAND_SPMV=1 HPCLA_SPMM_COLS_MULT=8 run 300 gpurun_out/${TAG}_pmc_sprandv8_$c.log rocprofv3 --pmc $c --output-format csv -d gpurun_out/${TAG}_pmc_sprandv8_$c -- python3 bench.py --workload sprand_spmm --steps 5 --warmup 5
+        HPCLA_SPRAND_SPMV=1 HPCLA_SPMM_COLS_MULT=1 run 300 gpurun_out/${TAG}_pmc_sprandv1_$c.log rocprofv3 --pmc $c --output-format csv -d gpurun_out/${TAG}_pmc_sprandv1_$c -- python3 bench.py --workload sprand_spmm --steps 5 --warmup 5
       done
       unset HPCLA_BLOCK_ORDER HPCLA_SPMM_BLOCK_ORDER HPCLA_BENCH_SETTLE_MS
       # keep what is merged back small: only the counter CSVs and the stats

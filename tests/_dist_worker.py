@@ -31,8 +31,14 @@ def main():
     hs = B.comm_allgather_bytes(comm, bytes([rank]) * 32)
     assert hs == [bytes([r]) * 32 for r in range(nranks)]
 
-    for kind in ("poisson", "sprand", "nonuniform"):
-        if kind == "poisson":
+    for kind in ("poisson", "sprand", "nonuniform", "config5"):
+        if kind == "config5":
+            # BASELINE config 5's shape: uniformly random columns, ~30 entries per row, so a rank touches ~98 % of EVERY
+            # other rank's slice -- at 8 ranks each rank has 7 send and 7 recv neighbours (src/sparse.jl:1875-1984)
+            n = 40 * nranks
+            gen = lambda lo, hi: orc.sprand_rows(n, 30.0 / n, lo, hi)
+            xp = orc.uniform_partition(n, nranks)
+        elif kind == "poisson":
             nx, ny = 16, 4 * nranks + 1
             n = nx * ny
             gen = lambda lo, hi: orc.poisson2d_rows(nx, ny, lo, hi)
@@ -57,6 +63,15 @@ def main():
             np.testing.assert_array_equal(a, b)
         np.testing.assert_array_equal(got.local_src_indices, want.local_src_indices)
         np.testing.assert_array_equal(got.local_dst_indices, want.local_dst_indices)
+        others = [r for r in range(nranks) if r != rank]
+        if kind == "config5":
+            # the target's shape: every rank exchanges with every other rank (7 neighbours each way at 8 ranks)
+            assert got.send_rank_ids == others and got.recv_rank_ids == others, (got.send_rank_ids, got.recv_rank_ids)
+        if kind == "poisson":
+            # row slabs of a 2-D grid: the ranks next door and nobody else, ghost = one grid line per neighbour
+            nb = [r for r in (rank - 1, rank + 1) if 0 <= r < nranks]
+            assert got.send_rank_ids == nb and got.recv_rank_ids == nb
+            assert all(len(p) == nx for p in got.recv_perm) and all(len(i) == nx for i in got.send_indices)
 
         # tag-21 value exchange over gloo, driven by the plan lists, must reproduce x[col_indices]
         import torch
@@ -77,6 +92,25 @@ def main():
         ghost = np.concatenate([b.numpy() for b in bufs]) if bufs else np.empty(0)
         ext = np.concatenate([xl, ghost])
         np.testing.assert_array_equal(ext[hp.split_column_map(got)], x[cis[rank]])
+
+        if kind == "config5":
+            # SpMM ghost rows (dense._spmm_plan): wishes -> Alltoall -> whole-slice lists, then the width-k exchange over
+            # gloo; every needed row of B must sit where the split column map of the SpMM says
+            from hpcla_amd.sparse import whole_slice_lists, whole_slice_wishes
+            wish = whole_slice_wishes(got, xp, nranks)
+            assert wish.tolist() == [0 if r == rank else 1 for r in range(nranks)], wish
+            granted = B.comm_alltoall_counts(comm, wish)
+            assert granted.tolist() == wish.tolist()
+            send_idx, recv_counts, cmap = whole_slice_lists(got, cis[rank], xp, wish, granted)
+            k = 3
+            Bg = orc.fill_uniform(0, n * k, 17).reshape(n, k)
+            Bl = Bg[xp[rank]:xp[rank + 1]]
+            for i in send_idx:                                       # whole slices leave B in place: one contiguous run
+                np.testing.assert_array_equal(i, np.arange(len(Bl)))
+            got_rows = B.comm_exchange_arrays(comm, got.send_rank_ids, [Bl[i].ravel() for i in send_idx],
+                                              got.recv_rank_ids, [c * k for c in recv_counts], np.float64)
+            ext = np.concatenate([Bl] + [g.reshape(-1, k) for g in got_rows])
+            np.testing.assert_array_equal(ext[cmap], Bg[cis[rank]])
 
         # structural hash agrees on every rank
         rows = gen(int(rp[rank]), int(rp[rank + 1]))

@@ -348,12 +348,16 @@ def timeout_case(torch, dist, hp, orc, rank, nranks):
         assert np.isnan(ws.hist[1:7].cpu().numpy()).all(), "CG history behind an expired exchange must be NaN"
         print(f"[rank 0] dead plan drains: 8 steps {dt_steps * 1e3:.1f} ms, 6 CG iterations {dt_cg:.2f} s "
               f"(bound {bound} s)", flush=True)
-        try:
-            hp.dot(y, y)
-        except hp.ExchangeTimeout as exc:
-            print(f"[rank 0] raised as it must: {exc}", flush=True)
-        else:
-            raise AssertionError("dot of a poisoned vector returned without raising ExchangeTimeout")
+        # every scalar that reaches the host from the poisoned vector raises -- the max reductions included (their
+        # comparator used to drop NaN, so norm(y, Inf) / maximum(y) returned a number after a timed-out exchange)
+        for what, fn in (("dot", lambda: hp.dot(y, y)), ("norm(y, Inf)", lambda: hp.norm(y, np.inf)),
+                         ("maximum", lambda: hp.maximum(y)), ("minimum", lambda: hp.minimum(y))):
+            try:
+                fn()
+            except hp.ExchangeTimeout as exc:
+                print(f"[rank 0] {what} raised as it must: {exc}", flush=True)
+            else:
+                raise AssertionError(f"{what} of a poisoned vector returned without raising ExchangeTimeout")
     dist.barrier()
     print(f"[rank {rank}/{nranks}] timeout case OK", flush=True)
     # the plan is dead: no collective teardown of its windows (a dead plan's peers may not show up either)

@@ -15,6 +15,10 @@ SRC_PAIR = os.path.join(ROOT, "tests", "cabi", "cabi_window_pair.c")
 EXE_PAIR = os.path.join(ROOT, "tests", "cabi", "_build", "cabi_window_pair")
 
 
+SRC_RANKS = os.path.join(ROOT, "tests", "cabi", "cabi_ranks_threads.c")
+EXE_RANKS = os.path.join(ROOT, "tests", "cabi", "_build", "cabi_ranks_threads")
+
+
 def _build(src=SRC, exe=EXE):
     os.makedirs(os.path.dirname(exe), exist_ok=True)
     # plain gcc: the header must be valid C; HIP enters only as the runtime API for hipMalloc/hipMemcpy
@@ -22,7 +26,7 @@ def _build(src=SRC, exe=EXE):
                            "-Werror=implicit-function-declaration",
                            "-D__HIP_PLATFORM_AMD__", src, "-I", os.path.join(ROOT, "include"),
                            "-I", "/opt/rocm/include", "-L", LIBDIR, "-lhpcla_rocm", "-L", "/opt/rocm/lib",
-                           "-lamdhip64", f"-Wl,-rpath,{LIBDIR}", "-Wl,-rpath,/opt/rocm/lib", "-lm", "-o", exe])
+                           "-lamdhip64", f"-Wl,-rpath,{LIBDIR}", "-Wl,-rpath,/opt/rocm/lib", "-lm", "-lpthread", "-o", exe])
 
 
 def test_cabi_program_builds():
@@ -31,6 +35,26 @@ def test_cabi_program_builds():
     assert os.path.exists(EXE)
     _build(SRC_PAIR, EXE_PAIR)
     assert os.path.exists(EXE_PAIR)
+    _build(SRC_RANKS, EXE_RANKS)
+    assert os.path.exists(EXE_RANKS)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nranks", [8, 3])
+def test_cabi_eight_ranks_seven_neighbours_in_one_process(nranks):
+    """The target's shape (BASELINE configs 3-5: 8 ranks; config 5: 7 neighbours each way), which one-process-per-rank
+    workers cannot reach on a box that allows 6 GPU processes: 8 ranks as 8 host threads of ONE process on one GPU, each
+    with its own communicator, stream and plans (tests/cabi/cabi_ranks_threads.c).  All-to-all plan (7 send + 7 recv
+    neighbours, scattered sends) and slab plan (neighbours next door): probe over every ghost slot, 6 fused distributed
+    SpMVs and 3 products with k = 16 bit-exact against the stored-order CPU loop, window all-reduce with 8 slots giving
+    identical dot bits on all ranks.  3 ranks: the same program at an odd count."""
+    if not os.path.exists(EXE_RANKS):
+        _build(SRC_RANKS, EXE_RANKS)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([EXE_RANKS, str(nranks)], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert f"C-ABI {nranks} ranks in one process PASS" in out.stdout
+    assert "alltoall:" in out.stdout and "slab:" in out.stdout
 
 
 @pytest.mark.gpu

@@ -1,4 +1,5 @@
-"""world_size-2 (and 3) gloo tests of the multi-rank host path on CPU."""
+"""world_size-2, 3 and 8 gloo tests of the multi-rank host path on CPU (8 = the rank count of BASELINE's multi-GPU
+configurations: 7-neighbour plans of config 5's shape, slab neighbours of configs 3/4)."""
 import os
 import subprocess
 import sys
@@ -10,7 +11,7 @@ sys.path.insert(0, ROOT)
 import hpcla_amd  # noqa: E402,F401  (makes hpcla_amd.launch importable)
 
 
-@pytest.mark.parametrize("nranks", [2, 3])
+@pytest.mark.parametrize("nranks", [2, 3, 8])
 def test_vector_plan_across_processes_gloo(nranks):
     env = dict(os.environ, OMP_NUM_THREADS="1")
     from hpcla_amd.launch import free_port

@@ -306,6 +306,14 @@ def test_reductions_and_updates_f32(hp, n):
     assert red("hpcla_amax_f32", xd.data_ptr(), n) == (float(np.abs(x64).max()) if n else 0.0)
     assert red("hpcla_maxval_f32", xd.data_ptr(), n, 0) == (float(x64.max()) if n else -np.inf)
     assert red("hpcla_maxval_f32", xd.data_ptr(), n, 1) == (float((-x64).max()) if n else -np.inf)
+    if n:
+        # one NaN element: the max reductions must return NaN like Julia's maximum / norm(., Inf) (`v > s ? v : s`
+        # never selected it, so rows poisoned by an expired halo wait passed as a finite maximum)
+        xn = x.copy()
+        xn[n // 2] = np.nan
+        xnd = _t(np.concatenate([xn, np.zeros(4, F32)]))[:n]
+        assert np.isnan(red("hpcla_amax_f32", xnd.data_ptr(), n))
+        assert np.isnan(red("hpcla_maxval_f32", xnd.data_ptr(), n, 0)) and np.isnan(red("hpcla_maxval_f32", xnd.data_ptr(), n, 1))
     # updates: separately rounded multiply and add in float -- numpy's float32 arithmetic, bit for bit
     z = torch.full((max(n, 1),), float("nan"), dtype=torch.float32, device="cuda")
     a, b = F32(1.7), F32(-0.3)

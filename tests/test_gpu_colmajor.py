@@ -210,3 +210,91 @@ def test_banded_block_count(hp, orc):
     assert got < 0.05 * blocks
     with pytest.raises(hp._capi.HPCLAError, match="max_runs"):
         count(p2, 0)
+
+
+@pytest.mark.parametrize("k", [1, 2, 5, 6, 12, 16, 17])
+@pytest.mark.parametrize("Ti", [np.int32, np.int64])
+def test_spmm_f64_rowmajor_B_colmajor_C(hp, orc, k, Ti):
+    """Round 5: row-major B rows, COLUMN-major C -- the unstructured product of a column-major caller without the conversion
+    of C (csrc/spmm.hip CCOL: even k <= 16 leave through LDS as k runs of 64 doubles; other k take the strided kernel).
+    hpcla_spmm_csr_f64_* (ROW, COL) and hpcla_spmm_split_ccol_f64_* with a ghost segment and block lists; long rows (several
+    LDS passes), empty rows, a last block of fewer than 64 rows, even and odd leading dimensions of C; untouched padding.
+    Bar: the oracle's bits (= the reference's column loop, src/sparse.jl:2391-2413)."""
+    import torch
+    sfx = "i32" if Ti == np.int32 else "i64"
+    rng = np.random.default_rng(100 + k)
+    ncols = 9_000
+    lens = rng.integers(0, 12, 333)
+    lens[[1, 7, 64, 130, 131, 255, 256, 300]] = [3000, 513, 1, 0, 1537, 3, 2000, 11]
+    lens[200:230] = 0
+    rowptr = np.concatenate([[0], np.cumsum(lens)])
+    colval = np.concatenate([np.sort(rng.choice(ncols, int(l), replace=False)) for l in lens]).astype(Ti)
+    vals = rng.random(len(colval)) - 0.5
+    B = rng.random((ncols, k)) - 0.5
+    n = len(lens)
+    want = orc.spmm(rowptr.astype(Ti), colval, vals, B)
+    rp, cv, nz, Bd = _t(rowptr.astype(Ti)), _t(colval), _t(vals), _t(B)
+    ROW, COL = hp._capi.LAYOUT_ROW, hp._capi.LAYOUT_COL
+    for ldc in (n, n + 3, n + 4):
+        C = torch.full((k, ldc), float("nan"), dtype=torch.float64, device="cuda")
+        hp._capi.call(f"hpcla_spmm_csr_f64_{sfx}", rp.data_ptr(), cv.data_ptr(), nz.data_ptr(), Bd.data_ptr(), k, ROW,
+                      C.data_ptr(), ldc, COL, n, len(vals), k, 0, _stream())
+        got = C.cpu().numpy()
+        np.testing.assert_array_equal(got[:, :n].T, want)
+        assert np.all(np.isnan(got[:, n:]))
+    # split form: columns >= n_own live in a ghost segment with its own leading dimension; interior / boundary block lists
+    n_own = 6_000
+    ldg = k + (k % 2) + 2
+    Bo = _t(B[:n_own])
+    Bg = np.full((ncols - n_own, ldg), np.nan)
+    Bg[:, :k] = B[n_own:]
+    Bgd = _t(Bg)
+    rpb = hp._capi.load().hpcla_spmm_rows_per_block()
+    nblk = (n + rpb - 1) // rpb
+    touches = np.array([np.any(colval[rowptr[b * rpb]:rowptr[min((b + 1) * rpb, n)]] >= n_own) for b in range(nblk)])
+    interior, boundary = _t(np.flatnonzero(~touches).astype(np.int32)), _t(np.flatnonzero(touches).astype(np.int32))
+    ldc = n + 2
+    C = torch.full((k, ldc), float("nan"), dtype=torch.float64, device="cuda")
+    for blocks in (interior, boundary):
+        if blocks.numel():
+            hp._capi.call(f"hpcla_spmm_split_ccol_f64_{sfx}", rp.data_ptr(), cv.data_ptr(), nz.data_ptr(), Bo.data_ptr(), k,
+                          Bgd.data_ptr(), ldg, n_own, C.data_ptr(), ldc, n, len(vals), k, 0, blocks.data_ptr(), blocks.numel(),
+                          _stream())
+    got = C.cpu().numpy()
+    np.testing.assert_array_equal(got[:, :n].T, want)
+    assert np.all(np.isnan(got[:, n:]))
+    with pytest.raises(hp._capi.HPCLAError):
+        hp._capi.call(f"hpcla_spmm_split_ccol_f64_{sfx}", rp.data_ptr(), cv.data_ptr(), nz.data_ptr(), Bo.data_ptr(), k,
+                      Bgd.data_ptr(), ldg, n_own, C.data_ptr(), n - 1, n, len(vals), k, 0, None, 0, _stream())
+
+
+def test_spmm_ccol_full_size_unstructured_same_bits_as_rowmajor(hp):
+    """The CCOL store at config 5's per-GPU shape in small (2^18 rows x 2^21 columns, ~30 entries per row, k = 16): the
+    column-major result equals the row-major kernel's, element for element (the row-major kernel is held to the oracle by
+    tests/test_gpu_parity.py; this run is about the store path under a full grid, block order hint included)."""
+    import torch
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(5)
+    n, ncols, k = 1 << 18, 1 << 21, 16
+    counts = torch.poisson(torch.full((n,), 29.8, dtype=torch.float64, device="cuda"), generator=gen).to(torch.int64)
+    rowptr = torch.zeros(n + 1, dtype=torch.int64, device="cuda")
+    torch.cumsum(counts, 0, out=rowptr[1:])
+    nnz = int(rowptr[-1].item())
+    rowid = torch.repeat_interleave(torch.arange(n, device="cuda", dtype=torch.int64), counts)
+    key = torch.sort(rowid * ncols + torch.randint(0, ncols, (nnz,), generator=gen, device="cuda", dtype=torch.int64)).values
+    cols = (key - rowid * ncols).to(torch.int32)
+    rp = rowptr.to(torch.int32)
+    vals = torch.rand(nnz, generator=gen, device="cuda", dtype=torch.float64) - 0.5
+    B = torch.rand((ncols, k), generator=gen, device="cuda", dtype=torch.float64) - 0.5
+    Cr = torch.empty((n, k), dtype=torch.float64, device="cuda")
+    Cc = torch.full((k, n), float("nan"), dtype=torch.float64, device="cuda")
+    ROW, COL = hp._capi.LAYOUT_ROW, hp._capi.LAYOUT_COL
+    for group in (0, 64):
+        hp._capi.call("hpcla_spmm_block_order_hint", rp.data_ptr(), group)
+        hp._capi.call("hpcla_spmm_csr_f64_i32", rp.data_ptr(), cols.data_ptr(), vals.data_ptr(), B.data_ptr(), k, ROW,
+                      Cr.data_ptr(), k, ROW, n, nnz, k, 0, _stream())
+        Cc.fill_(float("nan"))
+        hp._capi.call("hpcla_spmm_csr_f64_i32", rp.data_ptr(), cols.data_ptr(), vals.data_ptr(), B.data_ptr(), k, ROW,
+                      Cc.data_ptr(), n, COL, n, nnz, k, 0, _stream())
+        assert torch.equal(Cc.t(), Cr)
+    hp._capi.call("hpcla_spmm_block_order_hint", rp.data_ptr(), 0)

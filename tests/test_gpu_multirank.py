@@ -31,13 +31,19 @@ def _spawn(nranks, env_extra, timeout=600):
     return spawn_ranks([WORKER], nranks, env_extra=env_extra, timeout=timeout, forward_rank0_stdout=False)
 
 
-@pytest.mark.parametrize("nranks", [2, 3, 4])
+@pytest.mark.parametrize("nranks", [2, 3, 4, 5])
 def test_push_transport_ranks_exchange(nranks):
     """Default mode (push): halo by direct peer stores, scalar all-reduce through the communicator window.
     2 ranks run both index types (Int64 -- the reference's default Ti -- on NARROWED plans, i.e. the Int32 kernels);
     3 ranks Int64 with narrowing off (the Int64 kernels themselves), 4 ranks Int32 -- the ranks share the one GPU of
     the box by time-slicing, so wall time grows with ranks x cases."""
-    env = {"HPCLA_PUSH_TIMEOUT_S": "30", "HPCLA_MR_TYPES": {2: "i32,i64", 3: "i64wide", 4: "i32"}[nranks]}
+    env = {"HPCLA_PUSH_TIMEOUT_S": "30", "HPCLA_MR_TYPES": {2: "i32,i64", 3: "i64wide", 4: "i32", 5: "i32"}[nranks]}
+    if nranks == 5:
+        # the most one-process-per-rank workers this box allows next to the test runner (6 GPU processes per card): every rank
+        # of the unstructured case has 4 send and 4 recv neighbours; 8 ranks / 7 neighbours run as threads of one process
+        # (tests/test_cabi_from_c.py::test_cabi_eight_ranks_seven_neighbours_in_one_process) and, plans only, under gloo on
+        # the CPU (tests/test_distributed_cpu.py, world 8)
+        env["HPCLA_MR_CASES"] = "sprand,poisson2d,tiny"
     if nranks == 3:
         # every launch in the XCD-grouped block order (groups of 2 row blocks: the test matrices are far below the
         # size the plan would measure at), so the FUSED kernels' interior runs walk it too -- same bits required
@@ -105,3 +111,36 @@ def test_bench_launches_its_own_ranks():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["verified_vs_closed_form"] is True
     assert "step_breakdown_ms_max_over_ranks" in rec and "strong_scaling" in rec
+    _check_line_hygiene(rec)
+
+
+def _check_line_hygiene(rec):
+    """roofline.frac / achieved follow from ms_per_step (the clock of `value`), the HIP-event figure sits
+    beside them, and the digest of the other configurations is at the top level."""
+    rl = rec["roofline"]
+    want = rl["algorithmic_bytes_per_launch"] / (rec["ms_per_step"] * 1e-3) / 1e9
+    assert abs(rl["achieved"] - want) <= 1e-3 * want + 0.06, (rl["achieved"], want)        # ms_per_step is printed to 5 decimals
+    assert abs(rl["frac"] - want / rl["peak"]) <= 1e-3 * rl["frac"] + 1e-4
+    assert "frac_device_events" in rl and "achieved_device_events" in rl
+    assert rl["traffic"] is None or isinstance(rl["traffic"], (int, float))
+    assert set(rec["configs_digest"]) == {"cfg3_poisson8192_spmv_ms", "cfg4_cg_ms_per_iter", "cfg5_spmm_rowmajor_ms",
+                                          "cfg5_spmm_colmajor_caller_ms", "headline_int64_ms"}
+    assert rec["configs_digest"]["cfg3_poisson8192_spmv_ms"] == rec["strong_scaling"]["ms_per_step"]
+
+
+def test_bench_line_single_gpu_small_roofline_follows_from_ms_per_step():
+    """The N = 1 line on a small grid (seconds): one JSON line, cpu_baseline present and positive, roofline on the clock of
+    `value`, digest present."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "HPCLA_HALO_MODE"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "3", "--size", "1024",
+                          "--strong-size", "1024", "--no-extras", "--cpu-seconds", "1"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 1 and rec["verified_vs_closed_form"] is True
+    assert rec["cpu_baseline"]["value"] > 0 and rec["cpu_baseline"]["value_1core"] > 0
+    _check_line_hygiene(rec)

@@ -439,6 +439,21 @@ def test_dot_norm_golden_and_random(hp, orc, golden, gpu_backend_i32):
     assert hp.dot(xv, yv) == hp.dot(xv, yv)
 
 
+@pytest.mark.parametrize("n,where", [(1, 0), (64, 63), (513, 0), (513, 512), (100_003, 50_001), (4_000_001, 3_999_999)])
+def test_max_reductions_propagate_nan(hp, orc, gpu_backend_i32, n, where):
+    """`v > s ? v : s` never selected a NaN, so norm(v, Inf) / maximum / minimum of a vector holding one NaN
+    returned a finite number -- and with it the NaN rows an expired halo wait leaves in y.  Julia's maximum and
+    norm(., Inf) return NaN (src/vectors.jl:769-772, 815-836)."""
+    xg = orc.fill_uniform(0, n, 3) - 0.5
+    xg[where] = np.nan
+    v = hp.HPCVector.from_global(xg, gpu_backend_i32)
+    assert math.isnan(hp.norm(v, math.inf)) and math.isnan(hp.maximum(v)) and math.isnan(hp.minimum(v))
+    assert math.isnan(hp.norm(v)) and math.isnan(hp.norm(v, 1)) and math.isnan(hp.vsum(v))
+    xg[where] = 0.25                                   # ... and without the NaN the same calls are exact again
+    v = hp.HPCVector.from_global(xg, gpu_backend_i32)
+    assert hp.norm(v, math.inf) == np.abs(xg).max() and hp.maximum(v) == xg.max() and hp.minimum(v) == xg.min()
+
+
 def test_vector_ops_golden_and_random(hp, orc, golden, gpu_backend_i32):
     b = gpu_backend_i32
     c = golden["vector_ops"]

@@ -212,7 +212,7 @@ def test_check_partition_rejects_malformed_targets():
 
 
 # ---- whole-slice exchange lists for SpMM ("switch to all-gather of B") -----------------
-@pytest.mark.parametrize("nranks", [2, 4])
+@pytest.mark.parametrize("nranks", [2, 4, 8])
 def test_whole_slice_lists_reproduce_the_gathered_rows(hp, orc, nranks):
     """All ranks simulated in one process: wishes -> Alltoall -> lists; the emulated exchange must put
     every needed row of B where the SpMM's split column map expects it, whole-slice and requested-rows
@@ -252,7 +252,7 @@ def test_whole_slice_lists_reproduce_the_gathered_rows(hp, orc, nranks):
         np.testing.assert_array_equal(ext[cmap], Bg[cis[r]])
 
 
-@pytest.mark.parametrize("nranks,n_chunks", [(2, 4), (3, 3), (4, 5), (4, 1)])
+@pytest.mark.parametrize("nranks,n_chunks", [(2, 4), (3, 3), (4, 5), (4, 1), (8, 4)])
 def test_panel_chunk_lists_agree_on_both_ends_and_reproduce_the_exchange(hp, orc, nranks, n_chunks):
     """Panel-ordered SpMM (HPCLA_SPMM_ORDER=panel): every link's list is cut into chunk-sets on both ends by the same
     formula.  All ranks simulated: per chunk-set the sender's piece has the length the receiver expects, the emulated
