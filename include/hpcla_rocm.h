@@ -101,6 +101,24 @@ int hpcla_spmv_rows_per_block(void);
  * parked in LDS).  Bit-identical results.  Also HPCLA_SPMV_KERNEL=rowgather|quad in the environment. */
 int hpcla_set_spmv_kernel(int kind);
 int hpcla_get_spmv_kernel(void);      /* 0 / 1: the kernel the next aligned launch takes */
+/* OPT-IN long rows (round 5; NOT the default, NOT bit-identical to the reference).  The default kernels sum every row
+ * sequentially in stored order on one lane -- the reference's bits (acc += nzval[j] * x[colval[j]], src/sparse.jl:2059-2064)
+ * and the reference's cliff: its _spmv_kernel! is one work-item per row too, so an "arrow" matrix (one dense row of n
+ * entries) costs a whole sequential pass over that row.  This entry computes y = A*x with the rows listed in `long_rows`
+ * (device array of 0-based row indices, exactly the rows that hold >= long_min >= 928 entries; at most 65535) summed in TREE
+ * order -- 1024 contiguous pieces per row, wave shuffles inside a piece (north_star's "__shfl / segmented-scan row
+ * reductions") -- and every other row exactly as hpcla_spmv_split_f64_* does, bit for bit.  A long row's result is within
+ * 1e-12 * (|A||x|)_r of the sequential sum (tests: tests/test_gpu_parity.py::test_spmv_long_rows_opt_in).  x_ghost == NULL:
+ * unsplit column space.  work: hpcla_spmv_longrows_work_bytes(n_long) bytes of device scratch. */
+int64_t hpcla_spmv_longrows_work_bytes(int64_t n_long);
+int hpcla_spmv_longrows_f64_i32(const int32_t *rowptr, const int32_t *colval_split, const double *nzval,
+                                const double *x_own, const double *x_ghost, int64_t n_own, double *y,
+                                int64_t nrows, int64_t nnz, int index_base, const int64_t *long_rows,
+                                int64_t n_long, int64_t long_min, double *work, void *stream);
+int hpcla_spmv_longrows_f64_i64(const int64_t *rowptr, const int64_t *colval_split, const double *nzval,
+                                const double *x_own, const double *x_ghost, int64_t n_own, double *y,
+                                int64_t nrows, int64_t nnz, int index_base, const int64_t *long_rows,
+                                int64_t n_long, int64_t long_min, double *work, void *stream);
 int hpcla_spmm_rows_per_block(void);
 /* SpMM twins of the two block-order entries below (no reference counterpart: src/sparse.jl:2391-2413 is a column loop
  * over A*x in index order): the row blocks (hpcla_spmm_rows_per_block() rows each) of every SpMM launch over `rowptr`

@@ -50,6 +50,9 @@ _SIGNATURES = {
     "hpcla_spmv_split_f64_i32": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _i64, _vp],
     "hpcla_spmv_split_f64_i64": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _i64, _vp],
     "hpcla_spmv_rows_per_block": [],
+    "hpcla_spmv_longrows_work_bytes": [_i64],
+    "hpcla_spmv_longrows_f64_i32": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _i64, _i64, _vp, _vp],
+    "hpcla_spmv_longrows_f64_i64": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _i64, _i64, _vp, _vp],
     "hpcla_set_spmv_kernel": [_i32],
     "hpcla_get_spmv_kernel": [],
     "hpcla_spmv_block_order_hint": [_vp, _i32],
@@ -205,6 +208,7 @@ _RESTYPES = {
     "hpcla_spgemm_bin_cap": _i64,
     "hpcla_gemv_t_work_bytes": _i64,
     "hpcla_spmm_runs_desc_bytes": _i64,
+    "hpcla_spmv_longrows_work_bytes": _i64,
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

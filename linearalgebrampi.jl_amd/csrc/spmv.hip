@@ -310,13 +310,19 @@ constexpr int RG_CHW = 464;                         // entries per wave and pass
 constexpr int RG_NQ = (RG_CHW / 4 + 63) / 64;       // quads per lane per pass
 constexpr int RG_UR = 8;                            // entries per gather step
 
-template <typename I, bool SPLIT, bool WAIT>
+// LONGR (round 5, OPT-IN: hpcla_spmv_longrows_*): rows of at least `long_min` entries are LEFT OUT here -- their lanes sum
+// nothing and store nothing, and a pass that lies wholly inside such a row is skipped (the wave jumps to the pass that holds
+// the row's end) -- and are summed by spmv_longrow_partial/final_kernel below in TREE order instead.  The default
+// instantiations (LONGR = false) are the code they were: every row, however long, is one lane's sequential sum in stored
+// order -- the reference's bits, and its cliff (one work-item per row, src/sparse.jl:2055-2066).
+template <typename I, bool SPLIT, bool WAIT, bool LONGR = false>
 __global__ __launch_bounds__(RPB) void spmv_rowgather_kernel(
     const I *__restrict__ rowptr, const I *__restrict__ colval, const double *__restrict__ nzval,
     const double *__restrict__ x_own, const double *x_ghost, int64_t n_own,
     double *__restrict__ y, int64_t nrows, int64_t nnz, int base,
-    BlockSel bs, double *__restrict__ dot_partial, HaloWait hw, PushArgs push)
+    BlockSel bs, double *__restrict__ dot_partial, HaloWait hw, PushArgs push, int64_t long_min = 0)
 {
+    static_assert(!LONGR || !WAIT, "the long-row form is a plain launch");
     __shared__ __attribute__((aligned(16))) I s_col_all[(RPB / 64) * RG_CHW];
     __shared__ __attribute__((aligned(16))) double s_val_all[(RPB / 64) * RG_CHW];
     __shared__ double s_red[RPB / 64];
@@ -358,7 +364,18 @@ __global__ __launch_bounds__(RPB) void spmv_rowgather_kernel(
         const int ll = lane < nrw ? lane : nrw - 1;
         I rlo = rowptr[rw + ll], rhi = rowptr[rw + ll + 1];
         if (dot_partial) x_row = x_own[rw + ll];                         // the epilogue's x rides along with the stream
+        const bool is_long = LONGR && lane < nrw && (int64_t)rhi - (int64_t)rlo >= long_min;
         for (int64_t c = 0; c < total; c += RG_CHW) {
+            if (LONGR) {
+                // a pass wholly inside a long row holds nothing for this kernel: jump to the pass that holds the row's end
+                const int64_t lo_rel = (int64_t)rlo - base - pa, hi_rel = (int64_t)rhi - base - pa;
+                const uint64_t covers = __ballot(is_long && lo_rel <= c && hi_rel >= c + RG_CHW);
+                if (covers) {                                            // wave-uniform
+                    const int64_t hi_l = __shfl(hi_rel, __ffsll((unsigned long long)covers) - 1, 64);
+                    c = (hi_l / RG_CHW) * RG_CHW - RG_CHW;               // (>= c: the row reaches the end of this pass)
+                    continue;
+                }
+            }
             const int n = (int)((total - c) < RG_CHW ? (total - c) : RG_CHW);
             if (pa + c + ((n + 3) & ~3) <= nnz) {
                 // every quad of the pass lies inside the arrays: ALL of a lane's quads are requested before the first is
@@ -401,7 +418,8 @@ __global__ __launch_bounds__(RPB) void spmv_rowgather_kernel(
                 const int lo = lane < nrw ? (int)((int64_t)rlo - base - pa - c) : 0;
                 const int hi = lane < nrw ? (int)((int64_t)rhi - base - pa - c) : 0;
                 int j = lo > 0 ? lo : 0;
-                const int e = hi < n ? hi : n;
+                int e = hi < n ? hi : n;
+                if (LONGR && is_long) e = j;                             // summed by the long-row kernels
                 // RG_UR entries per step, each under its own lane predicate: the step's gathers leave together (a gather
                 // none of the wave's lanes needs is skipped), the sums follow in stored order
                 for (; j < e; j += RG_UR) {
@@ -421,12 +439,69 @@ __global__ __launch_bounds__(RPB) void spmv_rowgather_kernel(
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       // ... and the reads before the next pass's writes
             __builtin_amdgcn_wave_barrier();
         }
-        if (lane < nrw) {
+        if (lane < nrw && !(LONGR && is_long)) {
             if (bs.nt_y) __builtin_nontemporal_store(acc, y + rw + lane);
             else y[rw + lane] = acc;
         }
     }
     if (dot_partial) block_dot_epilogue(s_red, dot_partial, blk, lane < nrw ? acc * x_row : 0.0);
+}
+
+// ---- OPT-IN long rows (round 5): y[r] for the listed rows, summed in TREE order ---------------------------------------
+// north_star's "wavefront-level __shfl / segmented-scan row reductions", used where they are needed: a row of millions of
+// entries (an arrow matrix's dense row) is one lane's sequential sum in the default kernel -- the reference's order and its
+// cliff.  Here a long row is cut into LR_CHUNKS contiguous pieces (at least LR_MIN_CHUNK entries each), one workgroup per
+// piece: every thread sums its strided share in four independent chains, then a shuffle tree per wave and the four waves
+// in order; a second kernel adds the pieces' sums in order.  Deterministic, but NOT the reference's order: the result is
+// within k u / (1 - k u) of |A||x| with k ~ len / 1024 + 20 instead of len -- tests hold it to 1e-12 (|A||x|)_r.
+constexpr int LR_CHUNKS = 1024;
+constexpr int64_t LR_MIN_CHUNK = 4096;
+
+template <typename I, bool SPLIT>
+__global__ __launch_bounds__(256) void spmv_longrow_partial_kernel(
+    const I *__restrict__ rowptr, const I *__restrict__ colval, const double *__restrict__ nzval,
+    const double *__restrict__ x_own, const double *x_ghost, int64_t n_own, int base,
+    const int64_t *__restrict__ long_rows, double *__restrict__ partial)
+{
+    __shared__ double s_w[4];
+    const int64_t r = long_rows[blockIdx.y];
+    const int64_t p0 = (int64_t)rowptr[r] - base, p1 = (int64_t)rowptr[r + 1] - base, len = p1 - p0;
+    int64_t chunk = (len + LR_CHUNKS - 1) / LR_CHUNKS;
+    if (chunk < LR_MIN_CHUNK) chunk = LR_MIN_CHUNK;
+    const int64_t s = p0 + (int64_t)blockIdx.x * chunk;
+    const int64_t e = s + chunk < p1 ? s + chunk : p1;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int64_t i = s + threadIdx.x;
+    for (; i + 768 < e; i += 1024) {
+        const int64_t c0 = (int64_t)(I)(colval[i] - (I)base), c1 = (int64_t)(I)(colval[i + 256] - (I)base),
+                      c2 = (int64_t)(I)(colval[i + 512] - (I)base), c3 = (int64_t)(I)(colval[i + 768] - (I)base);
+        const double v0 = nzval[i], v1 = nzval[i + 256], v2 = nzval[i + 512], v3 = nzval[i + 768];
+        a0 += v0 * gather_x<SPLIT>(x_own, x_ghost, n_own, c0);
+        a1 += v1 * gather_x<SPLIT>(x_own, x_ghost, n_own, c1);
+        a2 += v2 * gather_x<SPLIT>(x_own, x_ghost, n_own, c2);
+        a3 += v3 * gather_x<SPLIT>(x_own, x_ghost, n_own, c3);
+    }
+    for (; i < e; i += 256) a0 += nzval[i] * gather_x<SPLIT>(x_own, x_ghost, n_own, (int64_t)(I)(colval[i] - (I)base));
+    double v = (a0 + a1) + (a2 + a3);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(int64_t)blockIdx.y * LR_CHUNKS + blockIdx.x] = ((s_w[0] + s_w[1]) + s_w[2]) + s_w[3];
+}
+
+__global__ __launch_bounds__(256) void spmv_longrow_final_kernel(const int64_t *__restrict__ long_rows,
+                                                                 const double *__restrict__ partial, double *__restrict__ y)
+{
+    __shared__ double s_w[4];
+    static_assert(LR_CHUNKS == 1024, "four pieces per thread");
+    const double *p = partial + (int64_t)blockIdx.x * LR_CHUNKS + threadIdx.x * 4;
+    double v = ((p[0] + p[1]) + p[2]) + p[3];              // contiguous pieces stay neighbours in the tree
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) y[long_rows[blockIdx.x]] = ((s_w[0] + s_w[1]) + s_w[2]) + s_w[3];
 }
 
 // ---- fallback kernel: element-per-lane loads, no alignment requirement --------------------------------
@@ -914,6 +989,75 @@ HPCLA_API int hpcla_spmv_split_f64_i64(const int64_t *rowptr, const int64_t *col
 {
     return spmv_split_i64(rowptr, colval_split, nzval, x_own, x_ghost, n_own, y, nrows, nnz,
                           index_base, block_list, n_blocks, stream, nullptr, -1);
+}
+
+// ---- OPT-IN long rows: y = A*x with the listed rows summed in tree order (see spmv_longrow_partial_kernel) ----------------
+template <typename I>
+static int spmv_longrows(const I *rowptr, const I *colval, const double *nzval, const double *x_own, const double *x_ghost,
+                         int64_t n_own, double *y, int64_t nrows, int64_t nnz, int index_base, const int64_t *long_rows,
+                         int64_t n_long, int64_t long_min, double *work, void *stream)
+{
+    if (nrows < 0 || nnz < 0 || n_long < 0 || n_long > 65535)
+        return set_error(HPCLA_ERR_INVALID, "spmv_longrows: bad sizes (at most 65535 long rows)");
+    if (index_base != 0 && index_base != 1) return set_error(HPCLA_ERR_INVALID, "spmv_longrows: index_base must be 0 or 1");
+    if (long_min < 2 * RG_CHW) return set_error(HPCLA_ERR_INVALID, "spmv_longrows: long_min must be at least 928 entries");
+    if (nrows == 0) return HPCLA_OK;
+    if (!rowptr || !y || (nnz > 0 && (!colval || !nzval || !x_own)) || (n_long > 0 && (!long_rows || !work)))
+        return set_error(HPCLA_ERR_INVALID, "spmv_longrows: null pointer");
+    const bool aligned = (reinterpret_cast<uintptr_t>(colval) % (4 * sizeof(I)) == 0) &&
+                         (reinterpret_cast<uintptr_t>(nzval) % 32 == 0);
+    if (!aligned) return set_error(HPCLA_ERR_UNSUPPORTED, "spmv_longrows: colval / nzval must be 16- / 32-byte aligned");
+    const int64_t all_blocks = (nrows + RPB - 1) / RPB;
+    if (all_blocks > 0x7fffffffLL) return set_error(HPCLA_ERR_INVALID, "spmv_longrows: too many blocks");
+    hipStream_t s = as_stream(stream);
+    const bool split = x_ghost != nullptr;
+    const BlockSel bs{nullptr, 0, nullptr, 0, 0, all_blocks, block_order_of(rowptr), spmv_nt_y(false)};
+    HaloWait nowait;
+    memset(&nowait, 0, sizeof(nowait));
+    PushArgs nopush;
+    memset(&nopush, 0, sizeof(nopush));
+    if (split)
+        spmv_rowgather_kernel<I, true, false, true><<<dim3((uint32_t)all_blocks), dim3(RPB), 0, s>>>(
+            rowptr, colval, nzval, x_own, x_ghost, n_own, y, nrows, nnz, index_base, bs, nullptr, nowait, nopush, long_min);
+    else
+        spmv_rowgather_kernel<I, false, false, true><<<dim3((uint32_t)all_blocks), dim3(RPB), 0, s>>>(
+            rowptr, colval, nzval, x_own, nullptr, 0, y, nrows, nnz, index_base, bs, nullptr, nowait, nopush, long_min);
+    HPCLA_CHECK_LAUNCH();
+    if (n_long > 0) {
+        if (split)
+            spmv_longrow_partial_kernel<I, true><<<dim3(LR_CHUNKS, (uint32_t)n_long), dim3(256), 0, s>>>(
+                rowptr, colval, nzval, x_own, x_ghost, n_own, index_base, long_rows, work);
+        else
+            spmv_longrow_partial_kernel<I, false><<<dim3(LR_CHUNKS, (uint32_t)n_long), dim3(256), 0, s>>>(
+                rowptr, colval, nzval, x_own, nullptr, 0, index_base, long_rows, work);
+        HPCLA_CHECK_LAUNCH();
+        spmv_longrow_final_kernel<<<dim3((uint32_t)n_long), dim3(256), 0, s>>>(long_rows, work, y);
+        HPCLA_CHECK_LAUNCH();
+    }
+    return HPCLA_OK;
+}
+
+HPCLA_API int64_t hpcla_spmv_longrows_work_bytes(int64_t n_long)
+{
+    return (n_long > 0 ? n_long : 1) * (int64_t)LR_CHUNKS * (int64_t)sizeof(double);
+}
+
+HPCLA_API int hpcla_spmv_longrows_f64_i32(const int32_t *rowptr, const int32_t *colval_split, const double *nzval,
+                                          const double *x_own, const double *x_ghost, int64_t n_own, double *y,
+                                          int64_t nrows, int64_t nnz, int index_base, const int64_t *long_rows,
+                                          int64_t n_long, int64_t long_min, double *work, void *stream)
+{
+    return spmv_longrows<int32_t>(rowptr, colval_split, nzval, x_own, x_ghost, n_own, y, nrows, nnz, index_base, long_rows,
+                                  n_long, long_min, work, stream);
+}
+
+HPCLA_API int hpcla_spmv_longrows_f64_i64(const int64_t *rowptr, const int64_t *colval_split, const double *nzval,
+                                          const double *x_own, const double *x_ghost, int64_t n_own, double *y,
+                                          int64_t nrows, int64_t nnz, int index_base, const int64_t *long_rows,
+                                          int64_t n_long, int64_t long_min, double *work, void *stream)
+{
+    return spmv_longrows<int64_t>(rowptr, colval_split, nzval, x_own, x_ghost, n_own, y, nrows, nnz, index_base, long_rows,
+                                  n_long, long_min, work, stream);
 }
 
 template <typename IN, typename OUT>

@@ -553,6 +553,7 @@ class HPCSparseMatrix:
         self.cached_transpose = None                     # src/sparse.jl:331, filled by transpose()
         self._packed = {}                                # plan cache key -> packed handle (opt-in)
         self.packed_reason = ""
+        self._long_rows = None                           # (device row list, min length, work buffer): enable_long_rows()
         self.nrows_local = int(rowptr_dev.numel()) - 1
         self.ncols_compressed = len(self.col_indices)
         self.backend = backend
@@ -624,6 +625,31 @@ class HPCSparseMatrix:
         if key not in self._packed and _PACKED_BY_ENV:
             self._packed_create(plan)
         return self._packed.get(key)
+
+    # -- OPT-IN long rows (csrc/spmv.hip LONGR).  NOT the reference's bits: the listed rows are summed in tree order.
+    def enable_long_rows(self, min_len: int = 4096) -> int:
+        """Sum rows of at least ``min_len`` stored entries in TREE order (1024 pieces per row, wave shuffles) instead of on one
+        lane: an arrow matrix's dense row is a sequential pass over n entries in the default kernel -- the reference's order
+        (src/sparse.jl:2059-2064) and its cliff.  Results of those rows then agree with the sequential sum to
+        1e-12 * (|A||x|)_r, every other row keeps its bits.  Single-rank plans (no halo), Float64.  Returns the number of
+        long rows (0: nothing changes)."""
+        torch = _torch()
+        if min_len < 928:
+            raise ValueError("enable_long_rows: min_len must be at least 928 (two passes of a wave)")
+        rp = self.rowptr_target
+        rows = torch.nonzero((rp[1:] - rp[:-1]) >= min_len).flatten().to(torch.int64).contiguous()
+        n_long = int(rows.numel())
+        if n_long > 65535:
+            raise ValueError("enable_long_rows: more than 65535 rows qualify; raise min_len")
+        if n_long == 0:
+            self._long_rows = None
+            return 0
+        work = torch.empty(_capi.load().hpcla_spmv_longrows_work_bytes(n_long) // 8, dtype=torch.float64, device=rp.device)
+        self._long_rows = (rows, int(min_len), work)
+        return n_long
+
+    def disable_long_rows(self) -> None:
+        self._long_rows = None
 
     def transpose(self):
         """Lazy ``transpose(A)`` (src/sparse.jl:2254-2258); ``transpose(A) @ x`` materialises and
@@ -757,6 +783,12 @@ def _spmv_into(y: HPCVector, A: HPCSparseMatrix, x: HPCVector, plan: VectorPlan)
                    dptr(plan.boundary), plan.n_boundary, None, None, current_stream_ptr())
         return
     sfx = "i64" if plan.is_i64 else "i32"
+    if A._long_rows is not None and not plan.has_halo:
+        rows, min_len, work = A._long_rows               # opt-in: the listed rows in tree order (enable_long_rows)
+        _capi.call(f"hpcla_spmv_longrows_f64_{sfx}", dptr(plan.rowptr_of(A)), dptr(plan.colval_split), dptr(A.nzval), dptr(x.v),
+                   None, plan.n_own, dptr(y.v), A.nrows_local, A.nnz, 0, dptr(rows), int(rows.numel()), min_len, dptr(work),
+                   current_stream_ptr())
+        return
     _capi.call(f"hpcla_spmv_dist_f64_{sfx}", plan.halo if plan.has_halo else None,
                dptr(plan.rowptr_of(A)), dptr(plan.colval_split), dptr(A.nzval), dptr(x.v), plan.n_own,
                dptr(y.v), A.nrows_local, A.nnz, 0, dptr(plan.interior), plan.n_interior,

@@ -3,7 +3,7 @@
 # into the steps below or deleted; benchmarks/EXPERIMENTS.md keeps the table of what each measured, its log under profiles/
 # and the commit that holds the variant).
 # usage: ./run_gpu_checks.sh TAG [steps...]   steps: pytest smoke bench driverbench torchrun2 validate pmc_all cgtrace
-#        rehearse2 rehearse4 tune ... (see the case list)
+#        rehearse2 rehearse4 rehearse6 arrow tune ... (see the case list)
 # Stops at the first step that is killed by its timeout (never start a GPU step after a hang).
 set -o pipefail
 mkdir -p gpurun_out
@@ -29,12 +29,13 @@ for st in $STEPS; do
       HPCLA_ALLOW_SHARED_GPU=1 run 600 gpurun_out/${TAG}_torchrun2.log python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 5 --warmup 2 ${REHEARSE_ARGS:---no-extras}
       grep "^{" gpurun_out/${TAG}_torchrun2.log | tail -1 > gpurun_out/${TAG}_torchrun2.json
       python3 benchmarks/digest_bench_line.py gpurun_out/${TAG}_torchrun2.json;;
-    rehearse2|rehearse4)  # bench.py starting its own ranks on the shared GPU
+    rehearse2|rehearse4|rehearse5|rehearse6)  # bench.py starting its own ranks on the shared GPU (6 = the box's limit on GPU processes)
       n=${st#rehearse}
-      HPCLA_ALLOW_SHARED_GPU=1 run 900 gpurun_out/${TAG}_reh$n.log python bench.py --gpus $n --steps 5 --warmup 2 ${REHEARSE_ARGS}
+      HPCLA_ALLOW_SHARED_GPU=1 run 900 gpurun_out/${TAG}_reh$n.log python bench.py --gpus $n ${REHEARSE_FLAGS:---steps 5 --warmup 2} ${REHEARSE_ARGS}
       grep "^{" gpurun_out/${TAG}_reh$n.log | tail -1 > gpurun_out/${TAG}_reh$n.json
       python3 benchmarks/digest_bench_line.py gpurun_out/${TAG}_reh$n.json;;
     validate) bash "$0" "$TAG" pytest smoke driverbench torchrun2;;
+    arrow) run 600 gpurun_out/${TAG}_arrow.log python benchmarks/bench_arrow.py; tail -1 gpurun_out/${TAG}_arrow.log;;
     pmc_all)       # kernel stats + FETCH_SIZE / WRITE_SIZE passes (separate runs) of the headline and of every sub-record;
                    # then: python benchmarks/collect_profiles.py TAG rNN   (-> profiles/, traffic_latest.json)
       cd /tmp && export TMPDIR=/tmp && cd - >/dev/null

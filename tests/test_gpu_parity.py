@@ -128,6 +128,66 @@ def test_spmv_long_rows_chunk_loop(hp, orc, gpu_backend_i32):
 
 
 @pytest.mark.parametrize("Ti", [np.int32, np.int64])
+def test_spmv_long_rows_opt_in(hp, orc, Ti):
+    """OPT-IN long rows (hpcla_spmv_longrows_f64_*, HPCSparseMatrix.enable_long_rows): rows of >= min_len entries are summed
+    in TREE order -- north_star's "__shfl / segmented-scan row reductions", where they are needed -- every other row keeps
+    the reference's bits.  Bar for a long row r: |y_r - sequential| <= 1e-12 * (|A||x|)_r (SURVEY 8d's componentwise
+    bound); bar for every other row: bit equality with the oracle.  Long rows at the start, across wave / block borders,
+    next to each other, at the very end; a long row whose pieces are shorter than the minimum piece; split column space
+    with a ghost segment through the raw ABI; the default path on the same matrix stays bit-exact."""
+    import torch
+    rng = np.random.default_rng(11)
+    n = 300_000
+    lens = rng.integers(0, 9, 1500)
+    long_at = {0: 5000, 63: 4096, 64: 300_000, 65: 4100, 255: 9000, 256: 70_000, 700: 1_100_000 // 4, 1499: 12_345}
+    for r, l in long_at.items():
+        lens[r] = l
+    lens[300:330] = 0
+    lens[400] = 4095                                   # one short of the threshold: stays sequential
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    cols = np.concatenate([np.sort(rng.choice(n, size=int(l), replace=False)) for l in lens if l]).astype(np.int64)
+    vals = rng.standard_normal(len(cols))
+    x = rng.standard_normal(n)
+    want = orc.spmv(rowptr.astype(Ti), cols.astype(Ti), vals, x)
+    bound = orc.spmv(rowptr.astype(Ti), cols.astype(Ti), np.abs(vals), np.abs(x))
+    is_long = lens >= 4096
+    assert is_long.sum() == len(long_at)
+    # host layer: default = the oracle's bits on every row; opted in = bits on the short rows, the bound on the long ones
+    backend = hp.backend_rocm_serial(np.float64, Ti)
+    A = hp.HPCSparseMatrix_local(rowptr, cols, vals, n, backend)
+    xv = hp.HPCVector.from_global(x, backend)
+    np.testing.assert_array_equal((A @ xv).local_values(), want)
+    assert A.enable_long_rows(4096) == len(long_at)
+    got = (A @ xv).local_values()
+    np.testing.assert_array_equal(got[~is_long], want[~is_long])
+    assert np.all(np.abs(got[is_long] - want[is_long]) <= 1e-12 * bound[is_long]), np.abs(got - want)[is_long] / bound[is_long]
+    assert np.array_equal((A @ xv).local_values(), got)                        # deterministic
+    A.disable_long_rows()
+    np.testing.assert_array_equal((A @ xv).local_values(), want)
+    assert A.enable_long_rows(2_000_000) == 0                                  # nothing qualifies: the default path
+    np.testing.assert_array_equal((A @ xv).local_values(), want)
+    with pytest.raises(ValueError):
+        A.enable_long_rows(100)
+    # raw ABI, split column space: columns >= n_own come from a ghost segment; index base 1
+    sfx = "i32" if Ti == np.int32 else "i64"
+    n_own = 200_000
+    s = torch.cuda.current_stream().cuda_stream
+    rp, cv, nz = _t((rowptr + 1).astype(Ti)), _t((cols + 1).astype(Ti)), _t(vals)
+    xo, xg = _t(x[:n_own]), _t(x[n_own:])
+    rows = _t(np.flatnonzero(is_long).astype(np.int64))
+    work = torch.empty(hp._capi.load().hpcla_spmv_longrows_work_bytes(int(rows.numel())) // 8, dtype=torch.float64, device="cuda")
+    y = torch.full((len(lens),), float("nan"), dtype=torch.float64, device="cuda")
+    hp._capi.call(f"hpcla_spmv_longrows_f64_{sfx}", rp.data_ptr(), cv.data_ptr(), nz.data_ptr(), xo.data_ptr(), xg.data_ptr(), n_own,
+                  y.data_ptr(), len(lens), len(vals), 1, rows.data_ptr(), int(rows.numel()), 4096, work.data_ptr(), s)
+    got = y.cpu().numpy()
+    np.testing.assert_array_equal(got[~is_long], want[~is_long])
+    assert np.all(np.abs(got[is_long] - want[is_long]) <= 1e-12 * bound[is_long])
+    with pytest.raises(hp._capi.HPCLAError):                                   # a threshold below two wave passes is refused
+        hp._capi.call(f"hpcla_spmv_longrows_f64_{sfx}", rp.data_ptr(), cv.data_ptr(), nz.data_ptr(), xo.data_ptr(), xg.data_ptr(), n_own,
+                      y.data_ptr(), len(lens), len(vals), 1, rows.data_ptr(), int(rows.numel()), 100, work.data_ptr(), s)
+
+
+@pytest.mark.parametrize("Ti", [np.int32, np.int64])
 def test_spmv_block_order_hint_is_a_bijection_with_the_same_bits(hp, orc, gpu_backend_i32, Ti):
     """hpcla_spmv_block_order_hint: XCD-grouped order of the row blocks.  Every group size must visit every row block
     exactly once -- y bit-identical to the natural order, incl. a ragged tail (block count not a multiple of 8 G),
