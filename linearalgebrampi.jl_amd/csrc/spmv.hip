@@ -415,10 +415,41 @@ __global__ __launch_bounds__(RPB) void spmv_rowgather_kernel(
             // compiler hoists the (loop-invariant) subtraction in front of the loop and with it a full memory round trip
             asm volatile("" : "+v"(rlo), "+v"(rhi));
             {
-                const int lo = lane < nrw ? (int)((int64_t)rlo - base - pa - c) : 0;
-                const int hi = lane < nrw ? (int)((int64_t)rhi - base - pa - c) : 0;
-                int j = lo > 0 ? lo : 0;
-                int e = hi < n ? hi : n;
+                // (64-bit until clamped: a row of > 2^31 entries may lie in front of or behind this pass)
+                const int64_t lo64 = lane < nrw ? (int64_t)rlo - base - pa - c : 0;
+                const int64_t hi64 = lane < nrw ? (int64_t)rhi - base - pa - c : 0;
+                const int lo = lo64 < 0 ? 0 : (lo64 > n ? n : (int)lo64);
+                const int hi = hi64 < 0 ? 0 : (hi64 > n ? n : (int)hi64);
+                // ONE row owns the whole pass (a row of more than a pass's entries: round 5, the arrow matrix's dense row):
+                // a lane walking it alone has eight gathers in flight and waits a memory round trip for each step (1.7 s for
+                // a row of 16.7 M entries, benchmarks/bench_arrow.py).  The wave multiplies the pass out TOGETHER -- every
+                // lane its share of the entries, the rounded products parked over the values in LDS -- and the owner then
+                // adds them in stored order: the same products, the same additions in the same order, the same bits.
+                const uint64_t whole = __ballot(lane < nrw && lo == 0 && hi == n && !(LONGR && is_long));
+                if (whole) {                                             // wave-uniform
+                    // (loops four wide at most: this branch must not cost the stencil path a register -- 61-64 VGPRs, 7 workgroups per
+                    // CU; unrolled freely it took 96 and the headline lost 7 %, profiles/r05_arrow_and_long_rows.log)
+#pragma unroll 4
+                    for (int e = lane; e < n; e += 64)
+                        s_val[e] = s_val[e] * gather_x<SPLIT>(x_own, x_ghost, n_own, (int64_t)(I)(s_col[e] - (I)base));
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane == __ffsll((unsigned long long)whole) - 1) {
+                        int j = 0;
+#pragma unroll 1
+                        for (; j + 4 <= n; j += 4) {
+                            const double p0 = s_val[j], p1 = s_val[j + 1], p2 = s_val[j + 2], p3 = s_val[j + 3];
+                            acc += p0; acc += p1; acc += p2; acc += p3;
+                        }
+#pragma unroll 1
+                        for (; j < n; ++j) acc += s_val[j];
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    continue;
+                }
+                int j = lo;
+                int e = hi;
                 if (LONGR && is_long) e = j;                             // summed by the long-row kernels
                 // RG_UR entries per step, each under its own lane predicate: the step's gathers leave together (a gather
                 // none of the wave's lanes needs is skipped), the sums follow in stored order
