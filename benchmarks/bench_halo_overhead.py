@@ -17,13 +17,23 @@ os.environ["HPCLA_FORCE_RCCL"] = "1"
 
 
 def main():
+    if len(sys.argv) > 2 and sys.argv[1] == "--slabs":
+        # round 5: the per-GPU shares of the strong-scaled problems -- e.g. 8192x1024 = config 3 at 8 GPUs --
+        # one after the other: plain kernel, the step with the self-exchange in every ordering; one summary line each
+        for spec in sys.argv[2].split(","):
+            nx, ny = (int(v) for v in spec.lower().split("x"))
+            run(nx, ny, False, summary=True)
+        return
+    run(4096, 4096, len(sys.argv) > 1 and sys.argv[1] == "--dim3")
+
+
+def run(nx_arg, ny_arg, dim3, summary=False):
     import torch
     import hpcla_amd as hp
     from hpcla_amd import workloads as wl
     backend = hp.backend_rocm_serial(np.float64, np.int32)
     capi, lib = hp._capi, hp._capi.load()
     s = torch.cuda.current_stream().cuda_stream
-    dim3 = len(sys.argv) > 1 and sys.argv[1] == "--dim3"
     if dim3:
         # config 4's per-GPU share: 512 x 512 x 64 slab of the 7-point matrix, ghost PLANES of 262 144 values (2 MiB)
         N, planes = 512, 64
@@ -32,7 +42,7 @@ def main():
         rowptr, colidx, vals = wl.poisson3d_rows(N, N, 3 * planes, nloc, 2 * nloc)
         print(f"3-D slab {N}x{N}x{planes}: ghost planes of {nx} values ({nx * 8 / 2**20:.1f} MiB each)")
     else:
-        nx = ny = 4096
+        nx, ny = nx_arg, ny_arg
         nloc = nx * ny
         # middle slab of a 3-slab grid: ghosts below (nx) and above (nx)
         rowptr, colidx, vals = wl.poisson2d_rows(nx, 3 * ny, nloc, 2 * nloc)
@@ -110,6 +120,21 @@ def main():
         print(f"{name:44s} {np.median(res):8.4f} ms/step (min {np.min(res):.4f})   host enqueue {host:.4f} ms/step", flush=True)
         return float(np.median(res))
 
+    if summary:
+        MODE = {"serial": 0, "overlap": 1, "push": 2}
+        res = {}
+        for rnd in range(2):
+            res.setdefault("plain", []).append(measure(f"[{nx}x{ny}] plain split kernel", plain))
+            for m in modes:
+                capi.call("hpcla_set_halo_mode", MODE[m])
+                res.setdefault(m, []).append(measure(f"[{nx}x{ny}] [{m}] halo + interior + boundary", dist))
+        capi.call("hpcla_set_halo_mode", -1)
+        med = {k: float(np.min(v)) for k, v in res.items()}
+        print(f"SLAB {nx}x{ny} rows={nloc} plain_ms={med['plain']:.4f} " +
+              " ".join(f"{m}_ms={med[m]:.4f} {m}_overhead_us={1e3 * (med[m] - med['plain']):+.1f}" for m in modes), flush=True)
+        torch.cuda.synchronize()
+        capi.call("hpcla_halo_plan_destroy", plan)
+        return
     base = measure("plain split kernel", plain)
     measure("interior blocks only (list)", interior_only)
     measure("boundary blocks only", boundary_only)

@@ -134,7 +134,8 @@ def _measure_spmm(args, job, hp, wl, A, B, k, world, dev, setup_s, metric, workl
                      "traffic": traffic, "traffic_source": traffic_source,
                      "algorithmic_bytes_per_launch": b_alg,
                      "block_order_group": int(job.max(hp.spmm_block_order_of(A, B))),
-                     "run_tiles": (lambda f: None if f is None else
+                     "run_tiles": (lambda f: {"used": False, "kernel": "hpcla::spmm_rowblock_vec_kernel",
+                                              "note": "run descriptors not built for this product (k != 16, Float32, or the panel order)"} if f is None else
                                    {"blocks_that_fit": f[0], "blocks": f[1], "used": bool(f[0] >= 0.99 * f[1]),
                                     "kernel": "hpcla::spmm_rowblock_runs_kernel" if f[0] >= 0.99 * f[1] else "hpcla::spmm_rowblock_vec_kernel"})(
                                        hp.spmm_runs_fit_of(A, B)),

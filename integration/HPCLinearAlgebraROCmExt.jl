@@ -574,29 +574,43 @@ function _spmm_colmajor(A::HPCSparseMatrix{T,Ti,B}, M::HPCMatrix{T,B}, plan, d::
     return HPCLinearAlgebra.HPCMatrix_local(C, A.backend)
 end
 
-function _spmm_split!(Crow, A::HPCSparseMatrix{T,Ti,B}, d, Brow, ghost::Ptr{Cvoid}, k::Int, blocks) where {T,Ti,B}
+# Row-major B rows (own block `Brow`, ghost segment `ghost`) times A into C.  `ccol` = false: `C` is row-major (k x nrows
+# column-major storage), run tiles where the structure allows them; `ccol` = true (round 5): `C` is the caller's column-major
+# nrows x k Matrix and the product stores it in that layout itself (hpcla_spmm_split_ccol_f64_*, csrc/spmm.hip CCOL) -- no
+# conversion of C afterwards.
+function _spmm_split!(C, A::HPCSparseMatrix{T,Ti,B}, d, Brow, ghost::Ptr{Cvoid}, k::Int, blocks, ccol::Bool=false) where {T,Ti,B}
     isempty(blocks) && return
     rp0 = d.rowptr0; nnz = length(A.nzval)
-    runs = k == 16 ? _spmm_runs(A, d) : nothing
-    if runs !== nothing && eltype(rp0) === Int32
+    runs = (k == 16 && !ccol) ? _spmm_runs(A, d) : nothing
+    if ccol && eltype(rp0) === Int32
+        _check(@ccall(LIB.hpcla_spmm_split_ccol_f64_i32(_ptr(rp0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
+               _ptr(A.nzval)::Ptr{Cvoid}, _ptr(Brow)::Ptr{Cvoid}, k::Int64, ghost::Ptr{Cvoid}, k::Int64, d.n_own::Int64,
+               _ptr(C)::Ptr{Cvoid}, max(A.nrows_local, 1)::Int64, A.nrows_local::Int64, nnz::Int64, k::Cint, 0::Cint,
+               _ptr(blocks)::Ptr{Cvoid}, length(blocks)::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_spmm_split_ccol_f64_i32")
+    elseif ccol
+        _check(@ccall(LIB.hpcla_spmm_split_ccol_f64_i64(_ptr(rp0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
+               _ptr(A.nzval)::Ptr{Cvoid}, _ptr(Brow)::Ptr{Cvoid}, k::Int64, ghost::Ptr{Cvoid}, k::Int64, d.n_own::Int64,
+               _ptr(C)::Ptr{Cvoid}, max(A.nrows_local, 1)::Int64, A.nrows_local::Int64, nnz::Int64, k::Cint, 0::Cint,
+               _ptr(blocks)::Ptr{Cvoid}, length(blocks)::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_spmm_split_ccol_f64_i64")
+    elseif runs !== nothing && eltype(rp0) === Int32
         _check(@ccall(LIB.hpcla_spmm_runs_k16_f64_i32(_ptr(rp0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
-               _ptr(A.nzval)::Ptr{Cvoid}, _ptr(Brow)::Ptr{Cvoid}, ghost::Ptr{Cvoid}, d.n_own::Int64, _ptr(Crow)::Ptr{Cvoid},
+               _ptr(A.nzval)::Ptr{Cvoid}, _ptr(Brow)::Ptr{Cvoid}, ghost::Ptr{Cvoid}, d.n_own::Int64, _ptr(C)::Ptr{Cvoid},
                A.nrows_local::Int64, nnz::Int64, 0::Cint, _ptr(runs)::Ptr{Cvoid}, _ptr(blocks)::Ptr{Cvoid},
                length(blocks)::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_spmm_runs_k16_f64_i32")
     elseif runs !== nothing
         _check(@ccall(LIB.hpcla_spmm_runs_k16_f64_i64(_ptr(rp0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
-               _ptr(A.nzval)::Ptr{Cvoid}, _ptr(Brow)::Ptr{Cvoid}, ghost::Ptr{Cvoid}, d.n_own::Int64, _ptr(Crow)::Ptr{Cvoid},
+               _ptr(A.nzval)::Ptr{Cvoid}, _ptr(Brow)::Ptr{Cvoid}, ghost::Ptr{Cvoid}, d.n_own::Int64, _ptr(C)::Ptr{Cvoid},
                A.nrows_local::Int64, nnz::Int64, 0::Cint, _ptr(runs)::Ptr{Cvoid}, _ptr(blocks)::Ptr{Cvoid},
                length(blocks)::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_spmm_runs_k16_f64_i64")
     elseif eltype(rp0) === Int32
         _check(@ccall(LIB.hpcla_spmm_split_f64_i32(_ptr(rp0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
                _ptr(A.nzval)::Ptr{Cvoid}, _ptr(Brow)::Ptr{Cvoid}, k::Int64, ghost::Ptr{Cvoid}, k::Int64, d.n_own::Int64,
-               _ptr(Crow)::Ptr{Cvoid}, k::Int64, A.nrows_local::Int64, nnz::Int64, k::Cint, 0::Cint,
+               _ptr(C)::Ptr{Cvoid}, k::Int64, A.nrows_local::Int64, nnz::Int64, k::Cint, 0::Cint,
                _ptr(blocks)::Ptr{Cvoid}, length(blocks)::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_spmm_split_f64_i32")
     else
         _check(@ccall(LIB.hpcla_spmm_split_f64_i64(_ptr(rp0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
                _ptr(A.nzval)::Ptr{Cvoid}, _ptr(Brow)::Ptr{Cvoid}, k::Int64, ghost::Ptr{Cvoid}, k::Int64, d.n_own::Int64,
-               _ptr(Crow)::Ptr{Cvoid}, k::Int64, A.nrows_local::Int64, nnz::Int64, k::Cint, 0::Cint,
+               _ptr(C)::Ptr{Cvoid}, k::Int64, A.nrows_local::Int64, nnz::Int64, k::Cint, 0::Cint,
                _ptr(blocks)::Ptr{Cvoid}, length(blocks)::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_spmm_split_f64_i64")
     end
 end
@@ -604,31 +618,292 @@ end
 function Base.:*(A::HPCSparseMatrix{T,Ti,B}, M::HPCMatrix{T,B}) where {T<:Float64,Ti,B<:ROCBackend}
     assert_backends_compatible(A.backend, M.backend)
     nloc, k = size(M.A)
-    let probe = HPCVector{T,B}(compute_partition_hash(M.row_partition), M.row_partition, similar(A.nzval, nloc), A.backend),
-        plan = get_vector_plan(A, probe), d = _device_plan(A, probe, plan)
-        k > 1 && _banded(A, d) && return _spmm_colmajor(A, M, plan, d)       # banded structure: no layout conversion
-    end
-    Brow = ROCMatrix{T}(undef, k, nloc)             # k x nloc column-major == nloc x k row-major (written whole: no zero fill)
-    _check(@ccall(LIB.hpcla_transpose_f64(_ptr(M.A)::Ptr{Cvoid}, nloc::Int64, 1::Cint, _ptr(Brow)::Ptr{Cvoid}, k::Int64,
-           0::Cint, nloc::Int64, k::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_transpose_f64")
-    Crow = ROCMatrix{T}(undef, k, A.nrows_local)
     # the vector plan for (A, B's row partition) provides neighbour lists and the split column space
     probe = HPCVector{T,B}(compute_partition_hash(M.row_partition), M.row_partition, similar(A.nzval, nloc), A.backend)   # plan key only
     plan = get_vector_plan(A, probe)
     d = _device_plan(A, probe, plan)
+    k > 1 && _banded(A, d) && return _spmm_colmajor(A, M, plan, d)       # banded structure: no layout conversion at all
+    # UNSTRUCTURED: B converted once to row-major rows (an unstructured matrix gathers whole B rows: one 128-byte line per
+    # stored entry at k = 16); C comes out of the product column-major (round 5: no second conversion -- config 5 through
+    # this path 2.25 -> 2.12 ms at N = 1 where the B conversion of all 2^24 rows costs 0.75 of them; at 8 GPUs a rank
+    # converts its own 2^21 rows, 0.09 ms)
+    Brow = ROCMatrix{T}(undef, k, nloc)             # k x nloc column-major == nloc x k row-major (written whole: no zero fill)
+    _check(@ccall(LIB.hpcla_transpose_f64(_ptr(M.A)::Ptr{Cvoid}, nloc::Int64, 1::Cint, _ptr(Brow)::Ptr{Cvoid}, k::Int64,
+           0::Cint, nloc::Int64, k::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_transpose_f64")
+    C = ROCMatrix{T}(undef, A.nrows_local, k)       # every row block is launched: no zero fill
     if isempty(plan.send_rank_ids) && isempty(plan.recv_rank_ids)
-        _spmm_split!(Crow, A, d, Brow, C_NULL, k, ROCVector(Int32.(0:cld(A.nrows_local, (@ccall LIB.hpcla_spmm_rows_per_block()::Cint))-1)))
+        _spmm_split!(C, A, d, Brow, C_NULL, k, ROCVector(Int32.(0:cld(A.nrows_local, (@ccall LIB.hpcla_spmm_rows_per_block()::Cint))-1)), true)
     else
         halo, interior, boundary, _, ghost = _spmm_halo(A, plan, d, k, (@ccall LIB.hpcla_spmm_rows_per_block()::Cint))
         _check(@ccall(LIB.hpcla_halo_begin(halo::Ptr{Cvoid}, _ptr(Brow)::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_halo_begin")
-        _spmm_split!(Crow, A, d, Brow, ghost, k, interior)         # rows without ghost columns overlap the exchange
+        _spmm_split!(C, A, d, Brow, ghost, k, interior, true)      # rows without ghost columns overlap the exchange
         _check(@ccall(LIB.hpcla_halo_end(halo::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_halo_end")
-        _spmm_split!(Crow, A, d, Brow, ghost, k, boundary)
+        _spmm_split!(C, A, d, Brow, ghost, k, boundary, true)      # ghost rows arrived row-major: nothing else is converted
     end
-    C = ROCMatrix{T}(undef, A.nrows_local, k)
-    _check(@ccall(LIB.hpcla_transpose_f64(_ptr(Crow)::Ptr{Cvoid}, k::Int64, 0::Cint, _ptr(C)::Ptr{Cvoid},
-           A.nrows_local::Int64, 1::Cint, A.nrows_local::Int64, k::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_transpose_f64")
     return HPCLinearAlgebra.HPCMatrix_local(C, A.backend)
+end
+
+# ==== structural hash without the host pass over colval  (replaces the local Blake3 pass of compute_structural_hash,
+# src/sparse.jl:97-121, for DeviceROCm matrices; SURVEY 8 a6) ===============================================================
+# The reference hashes row_partition, col_indices, rowptr and colval on the host -- at config 3 that is 335 MB of colval per
+# rank read on first use.  colval already lives on the device (colval_target): hpcla_digest_* reduces it there to four 64-bit
+# order-sensitive words (csrc/construct.hip digest_kernel), and those words stand in for its bytes in the rank-local hash; the
+# Allgather of the local hashes and the hash of hashes are the reference's.  A memoization key only (compared for equality):
+# all ranks take this method together, so the key is uniform across ranks like the reference's.  Other index types: parent.
+function HPCLinearAlgebra._ensure_hash(A::HPCSparseMatrix{T,Ti,B}) where {T,Ti,B<:ROCBackend}
+    A.structural_hash === nothing || return A.structural_hash
+    (Ti === Int32 || Ti === Int64) && A.colval_target isa ROCVector ||
+        return invoke(HPCLinearAlgebra._ensure_hash, Tuple{HPCSparseMatrix}, A)
+    words = zeros(UInt64, 4); n = length(A.colval_target)
+    if Ti === Int32
+        _check(@ccall(LIB.hpcla_digest_i32(_ptr(A.colval_target)::Ptr{Cvoid}, n::Int64, words::Ptr{UInt64}, _stream()::Ptr{Cvoid})::Cint),
+               "hpcla_digest_i32")
+    else
+        _check(@ccall(LIB.hpcla_digest_i64(_ptr(A.colval_target)::Ptr{Cvoid}, n::Int64, words::Ptr{UInt64}, _stream()::Ptr{Cvoid})::Cint),
+               "hpcla_digest_i64")
+    end
+    ctx = HPCLinearAlgebra.Blake3Ctx()                      # length-prefixed pieces, as src/sparse.jl:103-111
+    for piece in (A.row_partition, A.col_indices, A.rowptr)
+        HPCLinearAlgebra.update!(ctx, reinterpret(UInt8, Int[length(piece)]))
+        HPCLinearAlgebra.update!(ctx, reinterpret(UInt8, piece))
+    end
+    HPCLinearAlgebra.update!(ctx, reinterpret(UInt8, Int[n]))
+    HPCLinearAlgebra.update!(ctx, reinterpret(UInt8, words))
+    all_hashes = HPCLinearAlgebra.comm_allgather(A.backend.comm, HPCLinearAlgebra.digest(ctx))
+    ctx2 = HPCLinearAlgebra.Blake3Ctx()
+    HPCLinearAlgebra.update!(ctx2, reduce(vcat, all_hashes))
+    A.structural_hash = HPCLinearAlgebra.Blake3Hash(HPCLinearAlgebra.digest(ctx2))
+    return A.structural_hash
+end
+
+# ==== HPCSparseMatrix_local on the device  (SURVEY 8f rank 2; replaces `unique!(sort(copy(rowval)))` + one binary search per
+# stored entry, src/sparse.jl:501-509, 137-144) ============================================================================
+# The caller's rows arrive as CSR with GLOBAL columns (the parent's contract, :454-470).  The column compression -- which
+# columns occur, and the local index of every entry -- runs on the device: presence bitmap over the rows' column window,
+# exclusive scan, emit (hpcla_compress_columns_*, csrc/construct.hip): O(nnz + window) instead of O(nnz log nnz) on one host
+# core; at 4 x 10^7 entries per rank the host version is seconds of the time to the first product.  Everything else is the
+# parent's constructor, step by step: row partition from an Allgather of the local sizes, host copies of rowptr / colval /
+# col_indices (the struct's "always CPU" fields), lazy structural hash.  Falls through to the parent when the column window is
+# out of proportion to the entries (its scratch grows with the window), for empty matrices and for index types other than Int32 / Int64.
+function HPCLinearAlgebra.HPCSparseMatrix_local(A_local::HPCLinearAlgebra.SparseMatrixCSR{T,Timat}, backend::B;
+        col_partition::Vector{Int}=HPCLinearAlgebra.uniform_partition(A_local.parent.m, comm_size(backend.comm))) where {T,Timat,B<:ROCBackend}
+    Ti = indextype_backend(backend)
+    AT = A_local.parent                                     # CSC of the transpose: colptr = row pointers, rowval = global columns
+    nnz = length(AT.rowval)
+    parent_path() = invoke(HPCLinearAlgebra.HPCSparseMatrix_local, Tuple{HPCLinearAlgebra.SparseMatrixCSR{T,Timat},HPCBackend}, A_local, backend;
+                           col_partition=col_partition)
+    (nnz > 0 && (Ti === Int32 || Ti === Int64)) || return parent_path()
+    lo, hi = extrema(AT.rowval)                             # one host pass; 1-based global columns
+    window = Int64(hi - lo + 1)
+    # the bitmap / scan scratch grows with the WINDOW, not with nnz: a few scattered columns over a huge range stay on the host
+    window <= 64 * Int64(nnz) + (Int64(1) << 24) || return parent_path()
+    work_bytes = @ccall LIB.hpcla_colspace_work_bytes(window::Int64)::Int64
+    comm = backend.comm; nranks = comm_size(comm)
+    all_info = reshape(HPCLinearAlgebra.comm_allgather(comm, Int32[AT.n, AT.m]), 2, nranks)
+    all(c == all_info[2, 1] for c in all_info[2, :]) ||
+        error("HPCSparseMatrix_local: All ranks must have the same number of columns. Got column counts: $(all_info[2, :])")
+    row_partition = Vector{Int}(undef, nranks + 1); row_partition[1] = 1
+    for r in 1:nranks; row_partition[r+1] = row_partition[r] + all_info[1, r]; end
+    cols_dev = ROCVector(Int64.(AT.rowval) .- 1)            # 0-based global columns
+    colval_target = ROCVector{Ti}(undef, nnz)
+    ci_dev = ROCVector{Int64}(undef, window); work = ROCVector{UInt8}(undef, work_bytes)
+    ncomp = Ref{Int64}(0)
+    if Ti === Int32
+        _check(@ccall(LIB.hpcla_compress_columns_i32(_ptr(cols_dev)::Ptr{Cvoid}, nnz::Int64, Int64(lo - 1)::Int64, window::Int64,
+               _ptr(colval_target)::Ptr{Cvoid}, 1::Cint, _ptr(ci_dev)::Ptr{Cvoid}, ncomp::Ptr{Int64}, _ptr(work)::Ptr{Cvoid},
+               _stream()::Ptr{Cvoid})::Cint), "hpcla_compress_columns_i32")
+    else
+        _check(@ccall(LIB.hpcla_compress_columns_i64(_ptr(cols_dev)::Ptr{Cvoid}, nnz::Int64, Int64(lo - 1)::Int64, window::Int64,
+               _ptr(colval_target)::Ptr{Cvoid}, 1::Cint, _ptr(ci_dev)::Ptr{Cvoid}, ncomp::Ptr{Int64}, _ptr(work)::Ptr{Cvoid},
+               _stream()::Ptr{Cvoid})::Cint), "hpcla_compress_columns_i64")
+    end
+    col_indices = Int.(Array(ci_dev[1:ncomp[]])) .+ 1       # ascending global columns, 1-based (src/sparse.jl:501)
+    rowptr = convert(Vector{Ti}, AT.colptr)
+    colval = Array(colval_target)                           # the struct's host copy (compress_AT's rowval, :137-144)
+    nzval = HPCLinearAlgebra._convert_array(AT.nzval, backend.device)
+    rowptr_target = HPCLinearAlgebra._to_target_device(rowptr, backend.device)
+    return HPCSparseMatrix{T,Ti,B}(nothing, row_partition, col_partition, col_indices, rowptr, colval, nzval, AT.n, length(col_indices),
+                                   nothing, nothing, rowptr_target, colval_target, backend)
+end
+
+# ==== sparse A * B  (SURVEY 8f rank 3; replaces the CPU SparseArrays multiply inside src/sparse.jl:991-1059) ===============
+# The parent's memoized MatrixPlan (src/sparse.jl:554-978) keeps gathering the rows of B that A.col_indices names; its
+# execute_plan! takes a device target (:917-975), so the gathered values are written into device memory.  What changes is the
+# LOCAL product: `CT = plan.AT * A_csc` (:1011 -- on the CPU for GPU backends too) becomes hpcla_spgemm_ub / _numeric /
+# _compact on the device (csrc/spgemm.hip: Gustavson per row, k ascending, so every C(i, j) is summed in the reference's
+# order), and the result's column space is compressed on the device.  From the third product on a structure the per-entry
+# product lists are built once (host, plan time) and the numeric product is one streaming pass (hpcla_spgemm_numeric_mapped_f64).
+# Mirrors linearalgebrampi.jl_amd/matmat.py, which is executed and held to the oracle's bits by the GPU tests.  Falls through
+# to the parent -- all ranks together -- when an output row has more candidate entries than the largest bin handles, and for
+# index types other than Int32 / Int64.
+mutable struct ROCSpgemmState
+    g_rowptr::Any            # ROCVector{Int64}: row pointers of the gathered rows G, 0-based
+    g_col::Any               # ROCVector{Int64}: G's GLOBAL columns, 0-based
+    bins::Vector{Any}        # (bin::Cint, rows::ROCVector{Int32}): output rows by candidate count
+    ub_prefix::Any           # ROCVector{Int64}: slots of the first product (upper bounds); nothing afterwards
+    total_ub::Int64
+    cnt::Any                 # ROCVector{Int64}: entries per output row
+    result::Any              # nothing | NamedTuple (structure of C, kept for repeated products)
+    repeats::Int
+    map::Any                 # nothing: not tried | :none: not built | (pair_ptr, pairs, ptr_is_i64)
+end
+const _spgemm_cache = IdDict{Any,Any}()    # reference MatrixPlan -> ROCSpgemmState | nothing (parent path)
+
+function _spgemm_symbolic(A::HPCSparseMatrix{T,Ti,B}, plan) where {T,Ti,B}
+    nrows = A.nrows_local
+    g_rowptr = ROCVector(Int64.(plan.AT.colptr) .- 1)
+    g_col = ROCVector(Int64.(plan.AT.rowval) .- 1)
+    ub = AMDGPU.zeros(Int64, max(nrows, 1))
+    if Ti === Int32
+        _check(@ccall(LIB.hpcla_spgemm_ub_i32(_ptr(A.rowptr_target)::Ptr{Cvoid}, _ptr(A.colval_target)::Ptr{Cvoid}, nrows::Int64,
+               1::Cint, _ptr(g_rowptr)::Ptr{Cvoid}, _ptr(ub)::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_spgemm_ub_i32")
+    else
+        _check(@ccall(LIB.hpcla_spgemm_ub_i64(_ptr(A.rowptr_target)::Ptr{Cvoid}, _ptr(A.colval_target)::Ptr{Cvoid}, nrows::Int64,
+               1::Cint, _ptr(g_rowptr)::Ptr{Cvoid}, _ptr(ub)::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_spgemm_ub_i64")
+    end
+    ub_h = Array(ub)[1:nrows]
+    caps = Int64[]
+    while true                                              # the bins are the library's to define
+        c = @ccall LIB.hpcla_spgemm_bin_cap(length(caps)::Cint)::Int64
+        c < 0 && break
+        push!(caps, c)
+    end
+    # the limit is checked COLLECTIVELY: every rank learns the worst row of any rank, all take the same path
+    worst = HPCLinearAlgebra.comm_allreduce(A.backend.comm, isempty(ub_h) ? Int64(0) : maximum(ub_h), max)
+    worst > caps[end] && return nothing
+    bins = Any[]; lo = Int64(-1)
+    for (b, cap) in enumerate(caps)
+        rows = Int32.(findall(u -> lo < u <= cap, ub_h) .- 1)
+        lo = cap
+        isempty(rows) || push!(bins, (Cint(b - 1), ROCVector(rows)))
+    end
+    ub_prefix_h = vcat(Int64[0], cumsum(ub_h))
+    return ROCSpgemmState(g_rowptr, g_col, bins, ROCVector(ub_prefix_h), ub_prefix_h[end], AMDGPU.zeros(Int64, max(nrows, 1)),
+                          nothing, 0, nothing)
+end
+
+function _spgemm_numeric!(st::ROCSpgemmState, A::HPCSparseMatrix{T,Ti,B}, gval, offsets, col_out, val_out) where {T,Ti,B}
+    for (b, rows) in st.bins
+        if Ti === Int32
+            _check(@ccall(LIB.hpcla_spgemm_numeric_i32(b::Cint, _ptr(A.rowptr_target)::Ptr{Cvoid}, _ptr(A.colval_target)::Ptr{Cvoid},
+                   _ptr(A.nzval)::Ptr{Cvoid}, 1::Cint, _ptr(st.g_rowptr)::Ptr{Cvoid}, _ptr(st.g_col)::Ptr{Cvoid}, _ptr(gval)::Ptr{Cvoid},
+                   _ptr(rows)::Ptr{Cvoid}, length(rows)::Int64, _ptr(offsets)::Ptr{Cvoid}, _ptr(col_out)::Ptr{Cvoid},
+                   _ptr(val_out)::Ptr{Cvoid}, _ptr(st.cnt)::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_spgemm_numeric_i32")
+        else
+            _check(@ccall(LIB.hpcla_spgemm_numeric_i64(b::Cint, _ptr(A.rowptr_target)::Ptr{Cvoid}, _ptr(A.colval_target)::Ptr{Cvoid},
+                   _ptr(A.nzval)::Ptr{Cvoid}, 1::Cint, _ptr(st.g_rowptr)::Ptr{Cvoid}, _ptr(st.g_col)::Ptr{Cvoid}, _ptr(gval)::Ptr{Cvoid},
+                   _ptr(rows)::Ptr{Cvoid}, length(rows)::Int64, _ptr(offsets)::Ptr{Cvoid}, _ptr(col_out)::Ptr{Cvoid},
+                   _ptr(val_out)::Ptr{Cvoid}, _ptr(st.cnt)::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_spgemm_numeric_i64")
+        end
+    end
+end
+
+# Per result entry the list of its products as (index into A.nzval, index into the gathered values), 0-based, in ascending A
+# entry (= ascending k: the order the numeric kernels add in).  Host, once per structure: expand every A entry over its G row,
+# stable sort by (row, result column), run lengths.  Returns nothing when the lists would exceed `max_products` or Int32.
+function _spgemm_product_lists(A::HPCSparseMatrix{T,Ti,B}, plan, res, max_products::Int) where {T,Ti,B}
+    g_rp = Int64.(plan.AT.colptr); g_cl = Int64.(plan.AT.rowval)           # 1-based
+    lens = [g_rp[k+1] - g_rp[k] for k in A.colval]                        # A.colval: 1-based rows of G
+    total = sum(lens)
+    (total == 0 || total > max_products || total > typemax(Int32) || length(g_cl) > typemax(Int32)) && return nothing
+    ai = Vector{Int32}(undef, total); gi = Vector{Int32}(undef, total); key = Vector{Int64}(undef, total)
+    width = Int64(max(maximum(g_cl), maximum(res.c_col_h)) + 1)
+    t = 0
+    for r in 1:A.nrows_local, e in A.rowptr[r]:(A.rowptr[r+1]-1)
+        k = A.colval[e]
+        for g in g_rp[k]:(g_rp[k+1]-1)
+            t += 1
+            ai[t] = e - 1; gi[t] = g - 1; key[t] = Int64(r) * width + (g_cl[g] - 1)       # 0-based column, like res.c_col_h
+        end
+    end
+    perm = sortperm(key; alg=MergeSort)                                    # stable: products of one entry stay in ascending k
+    ptr = zeros(Int64, res.nnz + 1)
+    e = 0; last = Int64(-1)
+    for i in perm
+        if key[i] != last
+            e += 1; last = key[i]
+            e <= res.nnz || return nothing
+            key[i] == Int64(res.c_row_h[e]) * width + res.c_col_h[e] || return nothing     # safety net: must reproduce C's structure
+        end
+        ptr[e+1] += 1
+    end
+    e == res.nnz || return nothing
+    cumsum!(ptr, ptr)
+    pairs = Matrix{Int32}(undef, 2, total)                                  # column t = (A entry, G entry): 8 bytes per product
+    for (j, i) in enumerate(perm); pairs[1, j] = ai[i]; pairs[2, j] = gi[i]; end
+    return (ROCVector(ptr), ROCMatrix(pairs), true)
+end
+
+function Base.:*(A::HPCSparseMatrix{T,Ti,B}, Bm::HPCSparseMatrix{T,Ti,B}) where {T<:Float64,Ti,B<:ROCBackend}
+    assert_backends_compatible(A.backend, Bm.backend)
+    parent_path() = invoke(*, Tuple{HPCSparseMatrix{T,Ti,B},HPCSparseMatrix{T,Ti,B}} where {T,Ti,B}, A, Bm)
+    (Ti === Int32 || Ti === Int64) || return parent_path()
+    plan = HPCLinearAlgebra.MatrixPlan(A, Bm)               # memoized, collective on first use (src/sparse.jl:900-910)
+    st = get!(() -> _spgemm_symbolic(A, plan), _spgemm_cache, plan)
+    st === nothing && return parent_path()                  # (decided collectively in _spgemm_symbolic)
+    gval = ROCVector{T}(undef, max(length(plan.AT.nzval), 1))
+    HPCLinearAlgebra.execute_plan!(plan, Bm, gval)          # values of the gathered rows, into device memory
+    nrows = A.nrows_local
+    if st.result === nothing
+        c_col_tmp = ROCVector{Int64}(undef, max(st.total_ub, 1)); c_val_tmp = ROCVector{T}(undef, max(st.total_ub, 1))
+        _spgemm_numeric!(st, A, gval, st.ub_prefix, c_col_tmp, c_val_tmp)
+        cnt_h = Array(st.cnt)[1:nrows]
+        c_rowptr_h = vcat(Int64[0], cumsum(cnt_h)); nnzc = Int(c_rowptr_h[end])
+        c_rowptr = ROCVector(c_rowptr_h)
+        c_col = ROCVector{Int64}(undef, max(nnzc, 1)); c_val = ROCVector{T}(undef, nnzc)
+        _check(@ccall(LIB.hpcla_spgemm_compact(_ptr(c_rowptr)::Ptr{Cvoid}, _ptr(st.ub_prefix)::Ptr{Cvoid}, nrows::Int64,
+               _ptr(c_col_tmp)::Ptr{Cvoid}, _ptr(c_val_tmp)::Ptr{Cvoid}, _ptr(c_col)::Ptr{Cvoid}, _ptr(c_val)::Ptr{Cvoid},
+               _stream()::Ptr{Cvoid})::Cint), "hpcla_spgemm_compact")
+        # the result's column space (src/sparse.jl:1027-1040: unique(sort(rowval)) + a compress map) on the device
+        c_col_h = Array(c_col)[1:nnzc]
+        if nnzc == 0
+            col_indices = Int[]; colval_target = ROCVector{Ti}(undef, 0); colval = Ti[]
+        else
+            lo, hi = extrema(c_col_h); window = Int64(hi - lo + 1)
+            work = ROCVector{UInt8}(undef, @ccall LIB.hpcla_colspace_work_bytes(window::Int64)::Int64)
+            ci_dev = ROCVector{Int64}(undef, window); colval_target = ROCVector{Ti}(undef, nnzc); ncomp = Ref{Int64}(0)
+            if Ti === Int32
+                _check(@ccall(LIB.hpcla_compress_columns_i32(_ptr(c_col)::Ptr{Cvoid}, nnzc::Int64, lo::Int64, window::Int64,
+                       _ptr(colval_target)::Ptr{Cvoid}, 1::Cint, _ptr(ci_dev)::Ptr{Cvoid}, ncomp::Ptr{Int64}, _ptr(work)::Ptr{Cvoid},
+                       _stream()::Ptr{Cvoid})::Cint), "hpcla_compress_columns_i32")
+            else
+                _check(@ccall(LIB.hpcla_compress_columns_i64(_ptr(c_col)::Ptr{Cvoid}, nnzc::Int64, lo::Int64, window::Int64,
+                       _ptr(colval_target)::Ptr{Cvoid}, 1::Cint, _ptr(ci_dev)::Ptr{Cvoid}, ncomp::Ptr{Int64}, _ptr(work)::Ptr{Cvoid},
+                       _stream()::Ptr{Cvoid})::Cint), "hpcla_compress_columns_i64")
+            end
+            col_indices = Int.(Array(ci_dev[1:ncomp[]])) .+ 1
+            colval = Array(colval_target)
+        end
+        colptr = Ti.(c_rowptr_h .+ 1)
+        c_row_h = [r for r in 1:nrows for _ in 1:cnt_h[r]]
+        st.result = (c_rowptr64=c_rowptr, nnz=nnzc, col_indices=col_indices, colptr=colptr, colval=colval,
+                     rowptr_target=HPCLinearAlgebra._to_target_device(colptr, A.backend.device), colval_target=colval_target,
+                     scratch_col=c_col, c_col_h=c_col_h, c_row_h=c_row_h, hash=Ref{Any}(nothing))
+        st.ub_prefix = nothing                              # upper-bound slots: first product only
+    else
+        res = st.result
+        c_val = ROCVector{T}(undef, res.nnz)
+        st.repeats += 1
+        if st.map === nothing && st.repeats >= 2            # a structure multiplied a third time will be multiplied again
+            lists = get(ENV, "HPCLA_SPGEMM_MAP", "1") == "0" || res.nnz == 0 ? nothing :
+                    _spgemm_product_lists(A, plan, res, Int(parse(Float64, get(ENV, "HPCLA_SPGEMM_MAP_MAX", "5e7"))))
+            st.map = lists === nothing ? :none : lists
+        end
+        if st.map isa Tuple
+            ptr, pairs, ptr64 = st.map
+            _check(@ccall(LIB.hpcla_spgemm_numeric_mapped_f64(_ptr(ptr)::Ptr{Cvoid}, (ptr64 ? 1 : 0)::Cint, _ptr(pairs)::Ptr{Cvoid},
+                   _ptr(A.nzval)::Ptr{Cvoid}, _ptr(gval)::Ptr{Cvoid}, _ptr(c_val)::Ptr{Cvoid}, res.nnz::Int64,
+                   _stream()::Ptr{Cvoid})::Cint), "hpcla_spgemm_numeric_mapped_f64")
+        else
+            # the rows' final offsets are known: the numeric kernels write the compacted arrays directly
+            _spgemm_numeric!(st, A, gval, res.c_rowptr64, res.scratch_col, c_val)
+        end
+    end
+    res = st.result
+    C = HPCSparseMatrix{T,Ti,B}(res.hash[], A.row_partition, Bm.col_partition, res.col_indices, res.colptr, res.colval, c_val,
+                                nrows, length(res.col_indices), nothing, nothing, res.rowptr_target, res.colval_target, A.backend)
+    res.hash[] === nothing && (res.hash[] = HPCLinearAlgebra._ensure_hash(C))   # collective, once per structure (device digest)
+    return C
 end
 
 # ==== Float32 backends (csrc/f32.hip) ====================================================================================
@@ -824,6 +1099,7 @@ function clear_rocm_plan_cache!()
         d isa ROCVectorPlan && @ccall LIB.hpcla_spmv_block_order_hint(_ptr(d.rowptr0)::Ptr{Cvoid}, 0::Cint)::Cint
     end
     empty!(_rocm_plans); empty!(_spmm_plans); empty!(_rocm_exec); empty!(_merge_lists); empty!(_spmm_runs_cache); empty!(_stage32); empty!(_banded_cache)
+    empty!(_spgemm_cache)
     return nothing
 end
 

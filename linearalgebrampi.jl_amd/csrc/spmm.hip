@@ -1200,7 +1200,10 @@ template <typename T>
 __global__ __launch_bounds__(RELAY_ROWS) void relayout_narrow_to_rows_kernel(const T *__restrict__ src, T *__restrict__ dst,
                                                                               int64_t ld_col, int64_t rows, int cols)
 {
-    __shared__ T tile[RELAY_ROWS * (RELAY_MAXC + 1)];
+    // tile sized by the launch from the ACTUAL pitch (a static 256 x 33 tile is 67.6 KB whatever `cols` is -- two
+    // workgroups per CU at k = 16 where 34.8 KB allow four, and more than a 64 KiB-LDS part can allocate at all)
+    extern __shared__ __attribute__((aligned(16))) unsigned char relay_tile_raw[];
+    T *tile = reinterpret_cast<T *>(relay_tile_raw);
     const int pitch = cols | 1;                           // odd
     const int64_t r0 = (int64_t)blockIdx.x * RELAY_ROWS;
     const int nr = (int)((rows - r0) < RELAY_ROWS ? (rows - r0) : RELAY_ROWS);
@@ -1228,9 +1231,17 @@ static int transpose_impl(const T *src, int64_t ld_src, int src_layout, T *dst, 
         ld_dst == cols && ld_src >= rows) {
         const int64_t nb = (rows + RELAY_ROWS - 1) / RELAY_ROWS;
         if (nb <= 0x7fffffffLL) {
-            relayout_narrow_to_rows_kernel<T><<<(uint32_t)nb, RELAY_ROWS, 0, as_stream(stream)>>>(src, dst, ld_src, rows, (int)cols);
+            const size_t lds = (size_t)RELAY_ROWS * (size_t)((int)cols | 1) * sizeof(T);
+            static_assert((size_t)RELAY_ROWS * (RELAY_MAXC + 1) * sizeof(double) <= 160 * 1024, "tile exceeds gfx950's LDS");
+            // more than 64 KiB of dynamic LDS (31-32 Float64 columns) has to be allowed once per kernel
+            static const hipError_t allowed = hipFuncSetAttribute(
+                reinterpret_cast<const void *>(&relayout_narrow_to_rows_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                (int)((size_t)RELAY_ROWS * (RELAY_MAXC + 1) * sizeof(T)));
+            if (allowed == hipSuccess || lds <= 64 * 1024) {
+            relayout_narrow_to_rows_kernel<T><<<(uint32_t)nb, RELAY_ROWS, lds, as_stream(stream)>>>(src, dst, ld_src, rows, (int)cols);
             HPCLA_CHECK_LAUNCH();
             return HPCLA_OK;
+            }
         }
     }
     int64_t srs, scs, drs, dcs;

@@ -566,6 +566,22 @@ def spmm_exchange_bytes(A, B: HPCMatrix):
     return ent[6] * k * 8, ent[7] * k * 8, ent[8][0], ent[8][1]
 
 
+def _spmm_apply_order(plan, rowptr, k: int) -> None:
+    """The library keeps ONE SpMM block-order hint per rowptr array (csrc/spmm.hip g_mm_order) while the host measures
+    one per (k, rowptr): before a product whose (k, rowptr) has a measured order, put THAT order in force if the last
+    measurement or product on this structure left another one (a later k's tuning silently overwrote the order
+    earlier k's launches ran under).  Every order is a bijection of the row blocks: results never depend on it."""
+    cache = plan.__dict__.get("_spmm_order")
+    if not cache:
+        return
+    ptr = rowptr.data_ptr()
+    want = cache.get((k, ptr))
+    in_force = plan.__dict__.setdefault("_spmm_order_in_force", {})
+    if want is not None and in_force.get(ptr) != want:
+        _capi.call("hpcla_spmm_block_order_hint", ptr, 0 if want <= 1 else want)
+        in_force[ptr] = want
+
+
 def _spmm_block_order(A, plan, rowptr, colval_split, is_i64, Bc, ghost, C, k, blocks) -> int:
     """Block order of the SpMM launches over this structure, MEASURED once per (plan, k) after the first product
     (``hpcla_spmm_tune_block_order_*``: the plan's own launch -- contiguous, or the larger of its two block lists --
@@ -594,6 +610,7 @@ def _spmm_block_order(A, plan, rowptr, colval_split, is_i64, Bc, ghost, C, k, bl
             import sys
             sys.stderr.write(f"hpcla: SpMM block-order measurement failed ({exc}); natural order\n")
     cache[key] = group
+    plan.__dict__.setdefault("_spmm_order_in_force", {})[rowptr.data_ptr()] = group     # what the library holds now
     if group > 1:
         import weakref
         from .sparse import _unhint_spmm_block_order
@@ -707,6 +724,7 @@ def spmm(A, B: HPCMatrix) -> HPCMatrix:
             _capi.call(f"hpcla_spmm_runs_k16_f64_{sfx}", dptr(plan.rowptr_of(A)), dptr(plan.colval_split), dptr(A.nzval),
                        dptr(Bc), None, plan.n_own, dptr(C), A.nrows_local, A.nnz, 0, dptr(runs), None, 0, s)
             return out
+        _spmm_apply_order(plan, plan.rowptr_of(A), k)
         _capi.call(f"hpcla_spmm_csr_f64_{sfx}", dptr(plan.rowptr_of(A)), dptr(plan.colval_split),
                    dptr(A.nzval), dptr(Bc), k, _capi.LAYOUT_ROW, dptr(C), k, _capi.LAYOUT_ROW,
                    A.nrows_local, A.nnz, k, 0, s)
@@ -725,6 +743,8 @@ def spmm(A, B: HPCMatrix) -> HPCMatrix:
             _capi.call(f"hpcla_spmm_split_f64_{sfx}", dptr(rowptr), dptr(colval_split),
                        dptr(A.nzval), dptr(Bc), k, ghost, k, plan.n_own, dptr(C), k, A.nrows_local,
                        A.nnz, k, 0, dptr(blocks), int(blocks.numel()), s)
+    if runs is None:
+        _spmm_apply_order(plan, rowptr, k)
     _capi.call("hpcla_halo_begin", halo, dptr(Bc), s)
     if interior.numel():
         blocks_launch(interior)

@@ -759,9 +759,39 @@ def test_spmm_plan_measures_block_order(hp, orc, gpu_backend_i32, gpu_backend_i6
     hp.clear_plan_cache()
 
 
+def test_spmm_block_order_is_kept_per_k_on_one_structure(hp, orc, gpu_backend_i32, monkeypatch):
+    """the library holds ONE SpMM order hint per rowptr array, the host layer measures one per (k, rowptr) -- a
+    later k's measurement used to overwrite the order earlier k's launches ran under.  Orders forced through
+    HPCLA_SPMM_BLOCK_ORDER (64 for k = 4, 16 for k = 6): every product puts its own k's order back in force first
+    (bookkeeping checked on the plan), and the bits never depend on it."""
+    from hpcla_amd.sparse import get_vector_plan
+    N = 640
+    rows = orc.poisson2d_rows(N, N, 0, N * N)
+    A = hp.HPCSparseMatrix_local(rows.rowptr, rows.colidx, rows.vals, N * N, gpu_backend_i32)
+    prod = {}
+    for k, group in ((4, "64"), (6, "16")):
+        Bg = orc.fill_uniform(0, N * N * k, 5 + k).reshape(N * N, k)
+        prod[k] = (hp.HPCMatrix.from_global(Bg, gpu_backend_i32),
+                   orc.spmm(rows.rowptr.astype(np.int32), rows.colidx.astype(np.int32), rows.vals, Bg))
+        monkeypatch.setenv("HPCLA_SPMM_BLOCK_ORDER", group)
+        np.testing.assert_array_equal((A @ prod[k][0]).local_values(), prod[k][1])
+        assert hp.spmm_block_order_of(A, prod[k][0]) == int(group)
+    monkeypatch.delenv("HPCLA_SPMM_BLOCK_ORDER")
+    plan = get_vector_plan(A, hp.HPCVector.from_global(np.zeros(N * N), gpu_backend_i32))
+    ptr = plan.rowptr_of(A).data_ptr()
+    assert plan._spmm_order_in_force[ptr] == 16                       # k = 6 was tuned last
+    for k, group in ((4, 64), (6, 16), (6, 16), (4, 64)):
+        np.testing.assert_array_equal((A @ prod[k][0]).local_values(), prod[k][1])
+        assert plan._spmm_order_in_force[ptr] == group, (k, plan._spmm_order_in_force)
+    hp.clear_spmm_cache()
+    hp.clear_plan_cache()
+
+
 def test_transpose_layout_conversion(hp, gpu_backend_i32):
     import torch
-    for rows, cols in ((1, 1), (33, 16), (1000, 16), (65, 70)):
+    # (the narrow column-major -> row-major kernel takes rows >= 256, cols <= 32; its LDS tile is sized from cols -- 31 / 32
+    #  Float64 columns need more than 64 KiB of dynamic LDS)
+    for rows, cols in ((1, 1), (33, 16), (1000, 16), (65, 70), (2000, 32), (777, 31), (300, 5), (256, 1), (513, 17)):
         M = np.arange(rows * cols, dtype=np.float64).reshape(rows, cols) * 0.5
         src = _t(np.asfortranarray(M).ravel(order="F"))
         dst = torch.empty(rows * cols, dtype=torch.float64, device="cuda")

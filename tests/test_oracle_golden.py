@@ -304,3 +304,32 @@ def test_spgemm_oracle_pinned_on_the_published_product(orc, pin_large):
     np.testing.assert_array_equal(rp, sq.rowptr)
     np.testing.assert_array_equal(col, sq.colidx)
     np.testing.assert_array_equal(val, sq.vals)
+
+
+def test_float32_reductions_double_accumulation_vs_pure_float32_recurrence(golden, orc):
+    """the Float32 dot / norm / sum of csrc/f32.hip form products and squares in DOUBLE and round once, where the
+    reference computes them in T (local BLAS dot / nrm2 in Float32, then the all-reduce, src/vectors.jl:758-812).  No
+    fixture of the reference holds Float32 outputs, so this is PARITY UNPINNED (tolerance only); what CAN be pinned is the
+    size of the deviation: |double-accumulated, rounded once  -  sequential Float32 recurrence| against the reference's own
+    Float32 tolerance (rtol 1e-4, test/test_utils.jl:156) -- on the reference tests' closed-form inputs and on 10^5 random
+    entries, the same bound for the alpha / beta scalars of a composed Float32 CG step."""
+    F = np.float32
+    d = golden["dot"]
+    cases = [(np.array(d["x"]), np.array(d["y"])), (np.array(golden["norms"]["x"]), np.array(golden["norms"]["x"])),
+             (orc.fill_uniform(0, 100_000, 3) - 0.5, orc.fill_uniform(0, 100_000, 4) - 0.25)]
+    for xg, yg in cases:
+        x, y = xg.astype(F), yg.astype(F)
+        dbl = F(np.dot(x.astype(np.float64), y.astype(np.float64)))          # what hpcla_dot_f32 + one rounding gives
+        seq = F(0.0)
+        for a, b in zip(x, y):                                               # the recurrence in T, sequential
+            seq = F(seq + F(a * b))
+        scale = float(np.dot(np.abs(x).astype(np.float64), np.abs(y).astype(np.float64)))
+        assert abs(float(dbl) - float(seq)) <= 1e-4 * scale, (dbl, seq)
+        n2_dbl = F(np.sqrt(np.dot(x.astype(np.float64), x.astype(np.float64))))
+        sq = F(0.0)
+        for a in x:
+            sq = F(sq + F(a * a))
+        assert abs(float(n2_dbl) - float(F(np.sqrt(sq)))) <= 1e-4 * float(n2_dbl)
+        # a CG step's scalars: alpha = rr / pAp formed from such reductions differs by the same relative amount
+        if float(seq) != 0.0 and float(dbl) != 0.0:
+            assert abs(float(sq) / float(seq) - float(n2_dbl) ** 2 / float(dbl)) <= 3e-4 * abs(float(sq) / float(seq))
