@@ -559,6 +559,16 @@ def spmv_kernel_name(hp):
     return "spmv_rowgather_kernel" if hp._capi.load().hpcla_get_spmv_kernel() == 0 else "spmv_rowblock_quad_kernel"
 
 
+def spmv_kernel_instance(hp, is_i64=False, split=False, wait=False):
+    """The launched instantiation as rocprofv3 prints it: <index type, SPLIT, WAIT> for the quad kernel,
+    <index type, SPLIT, WAIT, LONGR = false> for the row-gather kernel (round 5 added the opt-in long-row flag)."""
+    name = spmv_kernel_name(hp)
+    args = ["long" if is_i64 else "int", "true" if split else "false", "true" if wait else "false"]
+    if name == "spmv_rowgather_kernel":
+        args.append("false")
+    return "hpcla::%s<%s>" % (name, ", ".join(args))
+
+
 def f32_kernel_name(kc, index="int", split=False):
     """Float32 lanes = rows kernel as rocprofv3 prints it: the element type is a template argument of the shared row-gather
     template since round 4 (csrc/rowgather_t.h: rowgather_kernel<T, I, SPLIT, KC, URX>), not a kernel of its own."""
@@ -617,7 +627,7 @@ def int64_record(hp, wl, job, args, N, steps, warmup):
            "roofline": {"bound": "hbm", "achieved": round(run.b_alg_loc / (launch_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(run.b_alg_loc / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                         "traffic": traffic, "traffic_source": traffic_source,
-                        "kernel": "hpcla::%s<%s, false, false>" % (spmv_kernel_name(hp), "long" if run.plan.is_i64 else "int"),
+                        "kernel": spmv_kernel_instance(hp, run.plan.is_i64),
                         "block_order_group": run.plan.block_group,
                         "algorithmic_bytes_per_launch": run.b_alg_loc,
                         "algorithmic_bytes_if_int64_were_streamed": run.b_alg_matrix_index_type,
@@ -840,9 +850,7 @@ def _run(args, budget):
         traffic_source += (f"; N = {world}: the SINGLE-RANK passes of the same per-GPU share (one {N}x{N} slab; the "
                            "distributed launch adds two ghost rows of x and the push stores, < 0.01 % of the bytes)")
 
-    kernel = "hpcla::%s<%s, %s, %s>" % (spmv_kernel_name(hp),
-        "long" if plan.is_i64 else "int", "true" if plan.has_halo else "false",
-        "true" if getattr(plan, "push", False) else "false")
+    kernel = spmv_kernel_instance(hp, plan.is_i64, plan.has_halo, getattr(plan, "push", False))
     nx, ny, ny_loc, n_glob = run.nx, run.ny, run.ny_loc, run.n_glob
     result = {
         "metric": "SpMV GFLOP/s (2*nnz/t), 2-D 5-pt Poisson, fp64",

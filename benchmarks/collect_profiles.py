@@ -16,7 +16,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL = "spmv_rowgather_kernel<int, false, false>"     # <index type, SPLIT, WAIT>: the single-GPU headline kernel (round 4: row gather)
+KERNEL = "spmv_rowgather_kernel<int, false, false, false>"     # <index type, SPLIT, WAIT, LONGR>: the single-GPU headline kernel (row gather; round 5 added LONGR)
 B_ALG = 1_341_980_676          # config 2, Int32
 ORDER_NOTE = ("block order fixed for the profiled runs (HPCLA_BLOCK_ORDER=32, 64 for the 3-D slab: what the plans' measurement picks on "
               "these matrices) so that no launch of the plan-time measurement sits in the per-kernel means")
@@ -145,7 +145,7 @@ def main():
     out["by_block_order"] = by_order
     wl = {}
     wl["poisson2d_spmv_int64"] = workload_single_kernel(
-        tag, "i64", "spmv_rowgather_kernel<long, false, false>", rnd, prof, "headline matrix, Int64 indices STREAMED (HPCLA_NARROW_INDICES=0)", 1_744_568_328,
+        tag, "i64", "spmv_rowgather_kernel<long, false, false, false>", rnd, prof, "headline matrix, Int64 indices STREAMED (HPCLA_NARROW_INDICES=0)", 1_744_568_328,
         "HPCLA_NARROW_INDICES=0 python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-strong --no-extras --no-packed --index i64")
     n3, nnz3 = 16_777_216, 116_785_152
     b_spmv3 = 12 * nnz3 + 4 * (n3 + 1) + 8 * n3 + 8 * n3
@@ -160,13 +160,13 @@ def main():
         tag, "sprand1", "spmm_rowblock_vec_kernel", rnd, prof, "sprand 2 097 152 rows x 29.8, B = 2 097 152 rows x 16 (Infinity-Cache-sized)", 1_295_259_584,
         "HPCLA_SPMM_COLS_MULT=1 python3 bench.py --workload sprand_spmm --steps 5 --warmup 5")
     # round 5: the unstructured matrix times ONE vector (bench.py's `spmv_same_matrix` records); absent passes leave the keys out
-    for key, step, label, cmd in (
-            ("sprand_spmv_b2e24", "sprandv8", "sprand 2 097 152 rows x 29.8 times a vector of 2^24 entries (x = 134 MB)",
+    for key, step, label, alg, cmd in (
+            ("sprand_spmv_b2e24", "sprandv8", "sprand 2 097 152 rows x 29.8 times a vector of 2^24 entries (x = 134 MB)", 906_150_080,
              "HPCLA_SPRAND_SPMV=1 HPCLA_SPMM_COLS_MULT=8 python3 bench.py --workload sprand_spmm --steps 5 --warmup 5"),
-            ("sprand_spmv_mall_sized", "sprandv1", "sprand 2 097 152 rows x 29.8 times a vector of 2^21 entries (x = 17 MB)",
+            ("sprand_spmv_mall_sized", "sprandv1", "sprand 2 097 152 rows x 29.8 times a vector of 2^21 entries (x = 17 MB)", 791_943_104,
              "HPCLA_SPRAND_SPMV=1 HPCLA_SPMM_COLS_MULT=1 python3 bench.py --workload sprand_spmm --steps 5 --warmup 5")):
         try:
-            wl[key] = workload_single_kernel(tag, step, "spmv_rowgather_kernel<int, false, false>", rnd, prof, label, None, cmd)
+            wl[key] = workload_single_kernel(tag, step, KERNEL, rnd, prof, label, alg, cmd)
         except SystemExit as exc:
             print(f"(no passes for {key}: {exc})")
     out["workloads"] = wl

@@ -289,7 +289,7 @@ def _sprand_spmv(hp, wl, job, A, ncols, backend, args):
                        "ncols_compressed": A.ncols_compressed},
             "roofline": {"bound": "hbm", "achieved": round(b_alg / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": "hpcla::spmv_rowgather_kernel<int, false, false>", "algorithmic_bytes_per_launch": b_alg,
+                         "kernel": "hpcla::spmv_rowgather_kernel<int, false, false, false>", "algorithmic_bytes_per_launch": b_alg,
                          "block_order_group": int(getattr(plan, "block_group", 1)),
                          "sector_gather_bytes_per_launch": b_sect, "sector_gather_gbs": round(b_sect / (ms * 1e-3) / 1e9, 1),
                          "note": "achieved = algorithmic bytes (each x value once) / WALL time per step; sector_gather = 12 B + one 64-byte "

@@ -46,7 +46,7 @@ def main(tag, out=None):
     names = [c["case"] for c in cases]
     nnz = {c["case"]: c["nnz"] for c in cases}
     lines = []
-    lines.append(f"# counters per launch of hpcla::{man.get('kernel', 'spmv_rowblock_quad_kernel')}<int, false, false>, mean over launches 2..n of each case; block order: "
+    lines.append(f"# counters per launch of hpcla::{man.get('kernel', 'spmv_rowblock_quad_kernel')}<int, false, false(, false)>, mean over launches 2..n of each case; block order: "
                  f"2-D groups of {man['order2d']}, 3-D groups of {man['order3d']}")
     lines.append("# cases: " + "; ".join(f"{c['case']}: {c['rows']} rows, {c['nnz']} entries, {c['algorithmic_bytes']} algorithmic bytes" for c in cases))
     lines.append("# event_ms (no profiler, same process): " + json.dumps({k: round(v, 4) for k, v in man["event_ms"].items()}))

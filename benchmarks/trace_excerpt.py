@@ -10,7 +10,7 @@ def main():
     rows = list(csv.DictReader(open(sys.argv[1], newline="")))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     name = lambda r: r["Kernel_Name"]
-    fused = [i for i, r in enumerate(rows) if ("spmv_rowgather_kernel<int, true, true>" in name(r) or "spmv_rowblock_quad_kernel<int, true, true>" in name(r))]
+    fused = [i for i, r in enumerate(rows) if ("spmv_rowgather_kernel<int, true, true" in name(r) or "spmv_rowblock_quad_kernel<int, true, true>" in name(r))]
     rccl = [i for i, r in enumerate(rows) if "rcclGenericKernel" in name(r) or "ncclDevKernel" in name(r)]
     out = []
 
