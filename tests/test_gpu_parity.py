@@ -128,6 +128,56 @@ def test_spmv_long_rows_chunk_loop(hp, orc, gpu_backend_i32):
 
 
 @pytest.mark.parametrize("Ti", [np.int32, np.int64])
+@pytest.mark.parametrize("kernel", [0, 1])
+def test_spmv_whole_pass_rows_split_and_dot_epilogue(hp, orc, Ti, kernel):
+    """Rows that own whole passes of a wave (round 5: the row-gather kernel multiplies such a pass out with all 64 lanes and
+    the owner adds the parked products in stored order) in the forms the first test of this file does not reach: the SPLIT
+    column space (own x + ghost segment, 1-based arrays, block lists) and the fused x.y epilogue -- rows of exactly one pass
+    (464), one short of / one past it, several passes, a long row as the LAST row of a wave and as the first of the next.
+    Same bits as the oracle under both kernels (the quad kernel is the cross-check)."""
+    import ctypes
+    import torch
+    rng = np.random.default_rng(77)
+    n = 12_000                                        # square: the x.y epilogue pairs x[r] with y[r]
+    lens = rng.integers(0, 9, n)
+    for r, l in {0: 464, 1: 463, 2: 465, 63: 3000, 64: 2500, 200: 928, 255: 10_000, 256: 929, 699: 1857, n - 1: 700}.items():
+        lens[r] = l
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    cols = np.concatenate([np.sort(rng.choice(n, size=int(l), replace=False)) for l in lens if l]).astype(np.int64)
+    vals = rng.standard_normal(len(cols))
+    x = rng.standard_normal(n)
+    want = orc.spmv(rowptr.astype(Ti), cols.astype(Ti), vals, x)
+    sfx = "i32" if Ti == np.int32 else "i64"
+    s = torch.cuda.current_stream().cuda_stream
+    lib = hp._capi.load()
+    prev = lib.hpcla_get_spmv_kernel()
+    hp._capi.call("hpcla_set_spmv_kernel", kernel)
+    try:
+        n_own = 7_000
+        rp, cv, nz = _t((rowptr + 1).astype(Ti)), _t((cols + 1).astype(Ti)), _t(vals)
+        xo, xg = _t(x[:n_own]), _t(x[n_own:])
+        nrows = len(lens)
+        nblk = (nrows + lib.hpcla_spmv_rows_per_block() - 1) // lib.hpcla_spmv_rows_per_block()
+        y = torch.full((nrows,), float("nan"), dtype=torch.float64, device="cuda")
+        for blocks in (_t(np.arange(0, nblk, 2, dtype=np.int32)), _t(np.arange(1, nblk, 2, dtype=np.int32))):
+            hp._capi.call(f"hpcla_spmv_split_f64_{sfx}", rp.data_ptr(), cv.data_ptr(), nz.data_ptr(), xo.data_ptr(), xg.data_ptr(), n_own,
+                          y.data_ptr(), nrows, len(vals), 1, blocks.data_ptr(), blocks.numel(), s)
+        np.testing.assert_array_equal(y.cpu().numpy(), want)
+        # fused x.y epilogue, unsplit
+        work = torch.empty(lib.hpcla_spmv_dot_work_bytes(nrows) // 8 + 1, dtype=torch.float64, device="cuda")
+        out = torch.zeros(1, dtype=torch.float64, device="cuda")
+        xs = _t(x)
+        y.fill_(float("nan"))
+        hp._capi.call(f"hpcla_spmv_dist_dot_f64_{sfx}", None, None, rp.data_ptr(), cv.data_ptr(), nz.data_ptr(), xs.data_ptr(), n,
+                      y.data_ptr(), nrows, len(vals), 1, None, 0, None, 0, out.data_ptr(), work.data_ptr(), s)
+        np.testing.assert_array_equal(y.cpu().numpy(), want)
+        ref = float(np.dot(x, want))
+        assert abs(out.item() - ref) <= 1e-12 * float(np.abs(x) @ np.abs(want))
+    finally:
+        hp._capi.call("hpcla_set_spmv_kernel", prev)
+
+
+@pytest.mark.parametrize("Ti", [np.int32, np.int64])
 def test_spmv_long_rows_opt_in(hp, orc, Ti):
     """OPT-IN long rows (hpcla_spmv_longrows_f64_*, HPCSparseMatrix.enable_long_rows): rows of >= min_len entries are summed
     in TREE order -- north_star's "__shfl / segmented-scan row reductions", where they are needed -- every other row keeps
