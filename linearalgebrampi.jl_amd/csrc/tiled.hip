@@ -18,7 +18,6 @@
 // The copy (plan time, device-built): the entries of each R-row group re-ordered by (tile, row, column) as three coalesced
 // streams -- column (u32, split column space), value (f64), row within the group (u16) -- 14 B per entry, each group padded to
 // a multiple of 64.  It snapshots the VALUES, so it belongs to the matrix object, not to the structure-keyed plan.
-#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -34,16 +33,13 @@ struct hpcla_tiled {
     uint32_t *t_col = nullptr;           // device, total
     double *t_val = nullptr;             // device, total
     uint16_t *t_row = nullptr;           // device, total (0xFFFF = padding)
-    uint32_t *done = nullptr;            // device, n_groups: the tile every wave is working on (pacing; zeroed per launch)
 };
 
 namespace hpcla {
 
 constexpr int TL_WAVES = 4;              // waves (= row groups) per workgroup
 constexpr uint16_t TL_PAD = 0xFFFF;
-constexpr int TL_U = 1;                  // steps of 64 entries in flight per wave (4 measured no faster; 1 keeps a wave's x window at one tile)
-constexpr int TL_LOOK = 2;               // a wave starts tile t once most waves of its XCD have finished tile t - TL_LOOK
-constexpr int TL_MAXPOLL = 200;         // the pacing is ADVISORY: a bounded number of polls, results never depend on it
+constexpr int TL_U = 4;                  // steps of 64 entries in flight per wave
 constexpr int TL_MAX_TILES = 2048;       // cursors per wave in the builder's LDS (8 KiB per wave)
 
 template <bool SPLIT>
@@ -135,23 +131,12 @@ template <bool SPLIT>
 __global__ __launch_bounds__(64 * TL_WAVES) void spmv_tiled_kernel(
     const int64_t *__restrict__ group_off, const uint32_t *__restrict__ t_col, const double *__restrict__ t_val,
     const uint16_t *__restrict__ t_row, const double *__restrict__ x_own, const double *__restrict__ x_ghost, int64_t n_own,
-    double *__restrict__ y, int64_t nrows, int R, int64_t n_groups, int tile_shift, uint32_t *__restrict__ done, int T)
+    double *__restrict__ y, int64_t nrows, int R, int64_t n_groups, int tile_shift)
 {
     extern __shared__ double tl_acc_all[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t g = (int64_t)blockIdx.x * TL_WAVES + wave;
     if (g >= n_groups) return;
-    // PACING (advisory, lock-free): workgroups are dealt round-robin over the 8 XCDs, each with its own 4 MiB L2.  Every wave
-    // publishes the tile it is working on in a slot of its own (a plain store: counting finished tiles with atomics on one
-    // address per tile serialised 1024 waves per XCD and cost 0.1 ms per tile, profiles/r05_tile_stream.log) and, before it
-    // gathers from tile t, SAMPLES the slots of 64 other waves of its XCD (one load instruction, a lane each): while more than
-    // a tenth of the sample is still more than TL_LOOK tiles behind, it waits -- a bounded number of polls.  Only timing
-    // depends on it: a wave that gives up just gathers through the fabric like the CSR kernel does.
-    const int xcd = (int)(blockIdx.x & 7);
-    uint32_t *prog = done;                                   // one slot per row group
-    const int64_t nb = (n_groups + TL_WAVES - 1) / TL_WAVES;
-    const int64_t wgs_x = (nb - xcd + 7) / 8;               // workgroups with blockIdx.x % 8 == xcd
-    uint32_t salt = (uint32_t)g * 2654435761u;
     double *acc = tl_acc_all + (size_t)wave * R;
     for (int i = lane; i < R; i += 64) acc[i] = 0.0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -172,22 +157,6 @@ __global__ __launch_bounds__(64 * TL_WAVES) void spmv_tiled_kernel(
             cc[u] = in ? __builtin_nontemporal_load(t_col + q) : 0u;
             vv[u] = in ? __builtin_nontemporal_load(t_val + q) : 0.0;
             rr[u] = in ? __builtin_nontemporal_load(t_row + q) : TL_PAD;
-        }
-        if (prog) {
-            const uint32_t t_first = __builtin_amdgcn_readfirstlane(cc[0]) >> tile_shift;    // (a group's stream starts unpadded)
-            if (lane == 0) __hip_atomic_store(prog + g, t_first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (t_first > (uint32_t)TL_LOOK) {
-                for (int polls = 0; polls < TL_MAXPOLL; ++polls) {
-                    salt = salt * 1664525u + 1013904223u;
-                    const int64_t j = (int64_t)(((uint64_t)(salt >> 8) * (uint64_t)(lane * 2 + 1)) % (uint64_t)wgs_x);
-                    const int64_t gs = ((int64_t)xcd + 8 * j) * TL_WAVES + (lane & (TL_WAVES - 1));
-                    uint32_t other = 0xFFFFFFF0u;
-                    if (lane < 8 && gs < n_groups) other = __hip_atomic_load(prog + gs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const int behind = __builtin_popcountll(__ballot(other + (uint32_t)TL_LOOK < t_first));
-                    if (behind <= 1) break;
-                    __builtin_amdgcn_s_sleep(100);
-                }
-            }
         }
 #pragma unroll
         for (int u = 0; u < TL_U; ++u) {
@@ -227,7 +196,6 @@ __global__ __launch_bounds__(64 * TL_WAVES) void spmv_tiled_kernel(
             }
         }
     }
-    if (prog && lane == 0) __hip_atomic_store(prog + g, 0xFFFFFFF0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // past every tile
     const int64_t r0 = g * R;
     for (int i = lane; i < R; i += 64)
         if (r0 + i < nrows) __builtin_nontemporal_store(acc[i], y + r0 + i);
@@ -240,7 +208,6 @@ static void tiled_free(hpcla_tiled *t)
     if (t->t_col) (void)hipFree(t->t_col);
     if (t->t_val) (void)hipFree(t->t_val);
     if (t->t_row) (void)hipFree(t->t_row);
-    if (t->done) (void)hipFree(t->done);
     delete t;
 }
 
@@ -292,7 +259,6 @@ static int tiled_create(hpcla_tiled **out, const I *rowptr, const I *colval, con
     if (e == hipSuccess) e = hipMalloc((void **)&t->t_col, (size_t)tot * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc((void **)&t->t_val, (size_t)tot * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void **)&t->t_row, (size_t)tot * sizeof(uint16_t));
-    if (e == hipSuccess) e = hipMalloc((void **)&t->done, (size_t)(G + 1) * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemcpyAsync(t->group_off, off.data(), (size_t)(G + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemsetAsync(t->t_col, 0, (size_t)tot * sizeof(uint32_t), s);      // padding gathers x[0] (never used)
     if (e == hipSuccess) e = hipMemsetAsync(t->t_val, 0, (size_t)tot * sizeof(double), s);
@@ -356,18 +322,12 @@ HPCLA_API int hpcla_spmv_tiled_f64(const hpcla_tiled_t *t, const double *x_own, 
     const int64_t nb = (t->n_groups + TL_WAVES - 1) / TL_WAVES;
     const size_t lds = (size_t)TL_WAVES * t->rows_per_group * sizeof(double);
     hipStream_t s = as_stream(stream);
-    static const int pace = [] {
-        const char *e = getenv("HPCLA_TILED_PACE");
-        return e ? atoi(e) : 1;
-    }();
-    uint32_t *done = (pace && t->n_tiles > TL_LOOK) ? t->done : nullptr;
-    if (done) HPCLA_CHECK_HIP(hipMemsetAsync(done, 0, (size_t)(t->n_groups + 1) * sizeof(uint32_t), s));
     if (x_ghost)
         spmv_tiled_kernel<true><<<(uint32_t)nb, 64 * TL_WAVES, lds, s>>>(t->group_off, t->t_col, t->t_val, t->t_row, x_own, x_ghost,
-                                                                       n_own, y, t->nrows, t->rows_per_group, t->n_groups, t->tile_shift, done, t->n_tiles);
+                                                                       n_own, y, t->nrows, t->rows_per_group, t->n_groups, t->tile_shift);
     else
         spmv_tiled_kernel<false><<<(uint32_t)nb, 64 * TL_WAVES, lds, s>>>(t->group_off, t->t_col, t->t_val, t->t_row, x_own, nullptr,
-                                                                        0, y, t->nrows, t->rows_per_group, t->n_groups, t->tile_shift, done, t->n_tiles);
+                                                                        0, y, t->nrows, t->rows_per_group, t->n_groups, t->tile_shift);
     HPCLA_CHECK_LAUNCH();
     return HPCLA_OK;
 }
