@@ -7,7 +7,6 @@
 * sprand_spmm   -- unstructured sprand-like matrix, 2 097 152 rows per GPU, ~29.8 nnz/row, columns
   uniform over the global 2 097 152*N columns, B with k = 16 dense columns (row-major on device).
 """
-import ctypes
 import json
 import os
 import sys
@@ -278,37 +277,6 @@ def _sprand_spmv(hp, wl, job, A, ncols, backend, args):
     ms = (time.perf_counter() - t0) / steps * 1e3
     dev_ms = ev0.elapsed_time(ev1) / steps
     plan = hp.get_vector_plan(A, xv)
-    # OPT-IN tile stream (csrc/tiled.hip): the same product, same bits, cache-blocked by column tile
-    tiled = None
-    if os.environ.get("HPCLA_BENCH_TILED", "1") != "0":
-        try:
-            want = yv.v.clone()
-            t_b = time.perf_counter()
-            A.enable_tiled(xv)
-            torch.cuda.synchronize()
-            build_ms = (time.perf_counter() - t_b) * 1e3
-            step()
-            same = bool(torch.equal(yv.v, want))
-            warm_up(job, step, max(args.warmup, 5))
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            torch.cuda.synchronize()
-            t_w = time.perf_counter()
-            e0.record()
-            for _ in range(steps):
-                step()
-            e1.record()
-            torch.cuda.synchronize()
-            t_ms = (time.perf_counter() - t_w) / steps * 1e3
-            nb, nt, rpg = ctypes.c_int64(), ctypes.c_int(), ctypes.c_int()
-            hp._capi.call("hpcla_tiled_info", A._tiled[next(iter(A._tiled))][0], ctypes.byref(nb), ctypes.byref(nt), ctypes.byref(rpg))
-            tiled = {"ms_per_step": round(t_ms, 4), "device_ms_per_step": round(e0.elapsed_time(e1) / steps, 4),
-                     "speedup_vs_csr": round(ms / t_ms, 3), "verified_same_bits": same, "copy_bytes": int(nb.value),
-                     "tiles": int(nt.value), "rows_per_wave": int(rpg.value), "build_ms": round(build_ms, 2),
-                     "kernel": "hpcla::spmv_tiled_kernel<false>"}
-        except Exception as exc:
-            tiled = {"error": f"{type(exc).__name__}: {exc}"}
-        finally:
-            A.disable_tiled()
     b_alg = wl.spmv_algorithmic_bytes(A.nnz, A.nrows_local, A.ncols_compressed, 4)
     b_sect = A.nnz * (12 + 64) + 12 * A.nrows_local
     mall = ncols * 8 <= (1 << 25)           # the small sibling: x of 17 MB (8 L2s x 4 MiB hold most of it)
@@ -319,8 +287,6 @@ def _sprand_spmv(hp, wl, job, A, ncols, backend, args):
             "config": {"workload": f"sprand-like {A.nrows_local} x {ncols}, nnz={A.nnz}, CSR SpMV y=A*x, index=i32; x = {ncols * 8 / 1e6:.0f} MB "
                                    + ("(about the size of the eight L2s together)" if mall else "(beyond the L2s, inside the 256 MiB Infinity Cache)"),
                        "ncols_compressed": A.ncols_compressed},
-            "tile_stream_opt_in": (dict(tiled, frac_of_peak_algorithmic=round(b_alg / (tiled["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
-                                   if tiled and "ms_per_step" in tiled else tiled),
             "roofline": {"bound": "hbm", "achieved": round(b_alg / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "hpcla::spmv_rowgather_kernel<int, false, false, false>", "algorithmic_bytes_per_launch": b_alg,

@@ -588,25 +588,6 @@ int hpcla_spmv_dist_dot_f64_i64(hpcla_halo_plan_t *plan, hpcla_comm_t *comm, con
  * fp64 numbers summed in the same order, so results stay bit-identical to the CSR path.
  * create returns HPCLA_ERR_UNSUPPORTED when the matrix (restricted to `block_list`, NULL = all row
  * blocks) is not packable.  Int32 indices only.  Reported separately from the CSR numbers. */
-/* ---- OPT-IN tile stream: the SpMV of UNSTRUCTURED matrices, cache-blocked by column tile (csrc/tiled.hip; round 5) ----------
- * No reference counterpart (the reference launches one work-item per row, src/sparse.jl:2081-2082).  On uniformly random
- * columns the CSR kernel fetches a 128-byte line for every gathered x value -- 9.5 x the algorithmic bytes on config 5's matrix
- * times a vector, the shape of the reference's own SpMV benchmark (tools/benchmark_single_rank.jl:48-71).  The copy re-orders the
- * entries of each R-row group by (column tile, row, column) -- 14 B per entry: column u32 (split column space), value f64, row
- * in group u16 -- so that all waves of a launch gather from the same few tiles of x (1 MiB each by default) at the same time
- * and x comes out of the L2s.  A row's entries are still added in stored order to one running sum: the reference's bits
- * (src/sparse.jl:2059-2064).  The copy snapshots nzval (rebuild it when the values change).  `ncols` = size of the split
- * column space (n_own + ghost entries); tile_cols <= 0: default.  x_ghost == NULL: every column is owned. */
-typedef struct hpcla_tiled hpcla_tiled_t;
-int hpcla_tiled_create_i32(hpcla_tiled_t **out, const int32_t *rowptr, const int32_t *colval_split, const double *nzval,
-                           int64_t nrows, int64_t nnz, int64_t ncols, int index_base, int64_t tile_cols, void *stream);
-int hpcla_tiled_create_i64(hpcla_tiled_t **out, const int64_t *rowptr, const int64_t *colval_split, const double *nzval,
-                           int64_t nrows, int64_t nnz, int64_t ncols, int index_base, int64_t tile_cols, void *stream);
-int hpcla_tiled_destroy(hpcla_tiled_t *t);
-int hpcla_tiled_info(const hpcla_tiled_t *t, int64_t *bytes, int *n_tiles, int *rows_per_group);
-int hpcla_spmv_tiled_f64(const hpcla_tiled_t *t, const double *x_own, const double *x_ghost, int64_t n_own, double *y,
-                         void *stream);
-
 typedef struct hpcla_packed hpcla_packed_t;
 int hpcla_packed_create_i32(hpcla_packed_t **out, const int32_t *rowptr, const int32_t *colval_split,
                             const double *nzval, int64_t nrows, int64_t nnz, int64_t n_own,

@@ -50,11 +50,6 @@ _SIGNATURES = {
     "hpcla_spmv_split_f64_i32": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _i64, _vp],
     "hpcla_spmv_split_f64_i64": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _i64, _vp],
     "hpcla_spmv_rows_per_block": [],
-    "hpcla_tiled_create_i32": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i64, _vp],
-    "hpcla_tiled_create_i64": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i64, _vp],
-    "hpcla_tiled_destroy": [_vp],
-    "hpcla_tiled_info": [_vp, _vp, _vp, _vp],
-    "hpcla_spmv_tiled_f64": [_vp, _vp, _vp, _i64, _vp, _vp],
     "hpcla_spmv_longrows_work_bytes": [_i64],
     "hpcla_spmv_longrows_f64_i32": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _i64, _i64, _vp, _vp],
     "hpcla_spmv_longrows_f64_i64": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _i64, _i64, _vp, _vp],

@@ -33,7 +33,6 @@ from .vectors import HPCVector, current_stream_ptr, dptr
 import os as _os
 
 _PACKED_BY_ENV = _os.environ.get("HPCLA_SPMV_PACKED", "") == "1"
-_TILED_BY_ENV = _os.environ.get("HPCLA_SPMV_TILED", "") == "1"
 
 
 def _torch():
@@ -532,13 +531,6 @@ def execute_plan(plan: VectorPlan, x: HPCVector):
     return gathered
 
 
-def _destroy_tiled(handle_value: int) -> None:
-    try:
-        _capi.load().hpcla_tiled_destroy(ctypes.c_void_p(handle_value))
-    except Exception:                                        # interpreter shutdown: the process is going away anyway
-        pass
-
-
 # =====================================================================================================
 # HPCSparseMatrix
 # =====================================================================================================
@@ -561,9 +553,7 @@ class HPCSparseMatrix:
         self.cached_transpose = None                     # src/sparse.jl:331, filled by transpose()
         self._packed = {}                                # plan cache key -> packed handle (opt-in)
         self.packed_reason = ""
-        self.tiled_reason = ""
         self._long_rows = None                           # (device row list, min length, work buffer): enable_long_rows()
-        self._tiled = {}                                 # plan cache key -> (tile-stream handle, nzval version) (opt-in)
         self.nrows_local = int(rowptr_dev.numel()) - 1
         self.ncols_compressed = len(self.col_indices)
         self.backend = backend
@@ -635,55 +625,6 @@ class HPCSparseMatrix:
         if key not in self._packed and _PACKED_BY_ENV:
             self._packed_create(plan)
         return self._packed.get(key)
-
-    # -- OPT-IN tile stream (csrc/tiled.hip): the SpMV of UNSTRUCTURED matrices cache-blocked by column tile.  Same bits as
-    #    the CSR kernels.  Like the packed copy it snapshots the values, so it lives on the matrix object; the copy is rebuilt
-    #    when nzval's version counter has moved (in-place writes through torch).
-    def enable_tiled(self, x: HPCVector, tile_cols: int = 0) -> bool:
-        """Build the tile-stream copy (14 B per stored entry) for the plan of ``(A, x.partition)``: every wave of the launch
-        walks its rows' entries column tile by column tile, so x is gathered out of the L2s instead of one 128-byte line
-        per stored entry from HBM (config 5's matrix times a vector: 9.5 x the algorithmic bytes with the CSR kernel).
-        Single-rank plans (no halo), Float64.  Returns False (``self.tiled_reason``) when not applicable."""
-        return self._tiled_create(get_vector_plan(self, x), tile_cols)
-
-    def _tiled_create(self, plan, tile_cols: int = 0) -> bool:
-        key = _plan_key(plan)
-        self._tiled_drop(key)
-        if plan.has_halo or plan.is_f32 or self.nnz == 0:
-            self.tiled_reason = "needs a single-rank Float64 plan with stored entries"
-            return False
-        h = ctypes.c_void_p()
-        sfx = "i64" if plan.is_i64 else "i32"
-        _capi.call(f"hpcla_tiled_create_{sfx}", ctypes.byref(h), dptr(plan.rowptr_of(self)), dptr(plan.colval_split),
-                   dptr(self.nzval), self.nrows_local, self.nnz, plan.n_own, 0, int(tile_cols), current_stream_ptr())
-        import weakref
-        # the copy is as large as the matrix: it goes with the matrix object even if disable_tiled() is never called
-        fin = weakref.finalize(self, _destroy_tiled, h.value)
-        self._tiled[key] = (h, int(self.nzval._version), int(tile_cols), fin)
-        return True
-
-    def _tiled_drop(self, key) -> None:
-        ent = self._tiled.pop(key, None)
-        if ent is not None:
-            ent[3]()                                         # runs hpcla_tiled_destroy once and detaches the finalizer
-
-    def disable_tiled(self) -> None:
-        for key in list(self._tiled):
-            self._tiled_drop(key)
-
-    def _tiled_for(self, plan):
-        """Tile-stream handle for this plan or None; HPCLA_SPMV_TILED=1 opts every eligible matrix in."""
-        key = _plan_key(plan)
-        ent = self._tiled.get(key)
-        if ent is None:
-            if not _TILED_BY_ENV or plan.has_halo or plan.is_f32 or self.nnz == 0:
-                return None
-            self._tiled_create(plan)
-            ent = self._tiled.get(key)
-        elif ent[1] != int(self.nzval._version):             # the values were written in place since the copy was made
-            self._tiled_create(plan, ent[2])
-            ent = self._tiled.get(key)
-        return ent[0] if ent is not None else None
 
     # -- OPT-IN long rows (csrc/spmv.hip LONGR).  NOT the reference's bits: the listed rows are summed in tree order.
     def enable_long_rows(self, min_len: int = 4096) -> int:
@@ -842,10 +783,6 @@ def _spmv_into(y: HPCVector, A: HPCSparseMatrix, x: HPCVector, plan: VectorPlan)
                    dptr(plan.boundary), plan.n_boundary, None, None, current_stream_ptr())
         return
     sfx = "i64" if plan.is_i64 else "i32"
-    tl = A._tiled_for(plan) if (A._tiled or _TILED_BY_ENV) else None
-    if tl is not None:
-        _capi.call("hpcla_spmv_tiled_f64", tl, dptr(x.v), None, plan.n_own, dptr(y.v), current_stream_ptr())
-        return
     if A._long_rows is not None and not plan.has_halo:
         rows, min_len, work = A._long_rows               # opt-in: the listed rows in tree order (enable_long_rows)
         _capi.call(f"hpcla_spmv_longrows_f64_{sfx}", dptr(plan.rowptr_of(A)), dptr(plan.colval_split), dptr(A.nzval), dptr(x.v),
