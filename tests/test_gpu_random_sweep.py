@@ -1,7 +1,7 @@
 """Randomised sweep through the raw C ABI: ragged CSR shapes (empty matrices, empty rows, single rows, rows around the
 464-entry wave pass and the 2048-entry workgroup pass, duplicate-free ascending columns), both index types and bases, every
 kernel family -- Float64 SpMV (row-gather and quad), Float32 SpMV, SpMM in Float64 and Float32 on row-major and column-major
-blocks with ragged k -- each bit for bit against the oracle's loops (src/sparse.jl:2055-2066, 2391-2413).  Fixed seeds: a
+blocks with ragged k, the row-major-B / column-major-C product and the opt-in long-row entry (its short rows) -- each bit for bit against the oracle's loops (src/sparse.jl:2055-2066, 2391-2413).  Fixed seeds: a
 failure names its case.
 """
 import numpy as np
@@ -78,3 +78,29 @@ def test_random_shapes_every_kernel_family(hp, orc, seed):
             got = C.cpu().numpy()
             got = got[:nrows * k].reshape(nrows, k) if lay == ROW else got.reshape(k, max(nrows, 1))[:, :nrows].T
             np.testing.assert_array_equal(got, want, err_msg=f"seed {seed} {dt} spmm {name}-major k={k}")
+        if dt == "f64":
+            # round 5: row-major B, COLUMN-major C (the CCOL store for even k <= 16, the strided kernel otherwise)
+            Bd = _t(Bt)
+            ldc = max(nrows, 1) + seed % 3
+            C = torch.full((k * ldc,), float("nan"), dtype=tT, device="cuda")
+            capi.call(f"hpcla_spmm_csr_f64_{sfx}", rp.data_ptr(), cv.data_ptr(), nz.data_ptr(), Bd.data_ptr(), k, ROW, C.data_ptr(), ldc, COL,
+                      nrows, nnz, k, base, s)
+            got = C.cpu().numpy().reshape(k, ldc)
+            np.testing.assert_array_equal(got[:, :nrows].T, want, err_msg=f"seed {seed} spmm row-major B, column-major C, k={k}")
+            assert np.all(np.isnan(got[:, nrows:])), f"seed {seed}: the column-major store wrote into the padding"
+            # round 5: the OPT-IN long-row entry -- rows of >= 928 entries in tree order (1e-12 |A||x|), every other row bit-exact
+            if nrows:
+                lens = np.diff(rowptr)
+                long_rows = np.flatnonzero(lens >= 928).astype(np.int64)
+                lr = _t(long_rows if len(long_rows) else np.zeros(1, np.int64))
+                work = torch.empty(capi.load().hpcla_spmv_longrows_work_bytes(len(long_rows)) // 8, dtype=torch.float64, device="cuda")
+                y = torch.full((nrows,), float("nan"), dtype=tT, device="cuda")
+                capi.call(f"hpcla_spmv_longrows_f64_{sfx}", rp.data_ptr(), cv.data_ptr(), nz.data_ptr(), x.data_ptr(), None, ncols, y.data_ptr(),
+                          nrows, nnz, base, lr.data_ptr(), len(long_rows), 928, work.data_ptr(), s)
+                got = y.cpu().numpy()
+                short = np.ones(nrows, bool)
+                short[long_rows] = False
+                np.testing.assert_array_equal(got[short], want[short, 0], err_msg=f"seed {seed} long-row entry, short rows")
+                if len(long_rows):
+                    bound = orc.spmv(rowptr.astype(Ti), colval.astype(Ti), np.abs(v), np.abs(np.ascontiguousarray(Bt[:, 0])))
+                    assert np.all(np.abs(got[long_rows] - want[long_rows, 0]) <= 1e-12 * bound[long_rows]), f"seed {seed} long rows"
