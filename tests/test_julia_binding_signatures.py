@@ -146,3 +146,23 @@ def test_classifier_call_uses_one_index_base_for_both_arrays():
         args = _split_top_level(m.group(1))
         assert "_ptr(rp0)" in args[0] and "rowptr_target" not in args[0], args[0]
         assert args[3].strip().startswith("0::Cint"), args[3]
+
+
+def test_integration_md_export_tiers_add_up():
+    """INTEGRATION.md section 5 sorts the header's exports by need; its three counts must be the header's: (A) the minimal
+    drop-in listed there, (B) the rest of what the extension file binds, (C) everything the extension does not bind."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    sec = text[text.index("## 5. Which of the"):]
+    total = int(re.search(r"## 5\. Which of the (\d+) exports", sec).group(1))
+    n_a = int(re.search(r"(\d+) symbols with their", sec).group(1))
+    n_b = int(re.search(r"beyond that \((\d+) more symbols\)", sec).group(1))
+    n_c = int(re.search(r"Not bound by the extension \((\d+) symbols\)", sec).group(1))
+    header = open(os.path.join(root, "include", "hpcla_rocm.h")).read()
+    exported = set(re.findall(r"\b(hpcla_[a-z0-9_]+)\s*\(", header))
+    ext = open(os.path.join(root, "integration", "HPCLinearAlgebraROCmExt.jl")).read()
+    used = set(re.findall(r"LIB\.(hpcla_[a-z0-9_]+)", ext))
+    assert used <= exported
+    assert total == len(exported) == n_a + n_b + n_c, (total, len(exported), n_a, n_b, n_c)
+    assert n_a + n_b == len(used) and n_c == len(exported - used)
