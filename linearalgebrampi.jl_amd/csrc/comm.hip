@@ -423,6 +423,7 @@ static int halo_plan_create_impl(hpcla_halo_plan_t **plan, hpcla_comm_t *comm, i
         HALO_HIP(hipMalloc((void **)&p->ghost, p->n_ghost * width * sizeof(double)));
         HALO_HIP(hipMemset(p->ghost, 0, p->n_ghost * width * sizeof(double)));
     }
+    HALO_HIP(hipStreamSynchronize(nullptr));     // plan-time fills are on the null stream; the caller's stream may be non-blocking
     {
         // highest stream priority, so that side-stream work is dispatched ahead of the caller's queued
         // workgroups wherever a CU has room for it (next to the SpMV kernel none has: spmv_dist_impl)

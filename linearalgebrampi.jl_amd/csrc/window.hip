@@ -254,6 +254,9 @@ int push_plan_alloc(hpcla_halo_plan *p)
     // step counter {done, ticket}: ordinary device memory, only this rank's kernels touch it
     hipError_t e = hipMalloc((void **)&p->epoch_dev, EPOCH_BYTES);
     if (e == hipSuccess) e = hipMemset(p->epoch_dev, 0, EPOCH_BYTES);
+    // plan-time fills run on the null stream; the plan's kernels run on the CALLER's stream, which may be a non-blocking
+    // one (AMDGPU.jl's task streams, the threads-as-ranks test): settle the fill before anything can be launched over it
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
     if (e != hipSuccess) return set_error(HPCLA_ERR_HIP, "window step counter: %s", hipGetErrorString(e));
     return HPCLA_OK;
 }
@@ -522,6 +525,7 @@ HPCLA_API int hpcla_comm_window_attach(hpcla_comm_t *comm, const uint8_t *all_de
     if (e == hipSuccess) e = hipMemcpy(comm->peer_slots_dev, slots.data(), sizeof(void *) * n, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void **)&comm->ar_done_dev, sizeof(uint64_t));
     if (e == hipSuccess) e = hipMemset(comm->ar_done_dev, 0, sizeof(uint64_t));
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);      // null-stream fill, non-blocking caller streams (see push_plan_alloc)
     if (e != hipSuccess) {
         comm_window_free(comm);
         return set_error(HPCLA_ERR_HIP, "comm_window_attach: %s", hipGetErrorString(e));
@@ -722,6 +726,7 @@ HPCLA_API int hpcla_halo_plan_attach(hpcla_halo_plan_t *plan, const uint8_t *all
     ATT_HIP(hipMemcpy(p->push_block_map_dev, bmap.data(), sizeof(int32_t) * bmap.size(), hipMemcpyHostToDevice));
     ATT_HIP(hipMalloc((void **)&p->arrive, sizeof(uint64_t) * (ns ? ns : 1)));
     ATT_HIP(hipMemset(p->arrive, 0, sizeof(uint64_t) * (ns ? ns : 1)));
+    ATT_HIP(hipStreamSynchronize(nullptr));                      // null-stream fill, non-blocking caller streams (see push_plan_alloc)
 #undef ATT_HIP
     p->push_blocks = (int64_t)(bmap.size() / 2);
     // keep the mappings (closed at destroy)
