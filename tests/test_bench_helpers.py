@@ -203,3 +203,36 @@ def test_n_gt_1_records_carry_roofline_traffic_from_the_single_rank_passes():
         assert t1 == t8 and t1 > 1e9
         assert "SINGLE-RANK" in s8 and "N = 8" in s8 and "note about the share" in s8 and "SINGLE-RANK" not in s1
     assert stored_traffic("no such workload", True, 8)[0] is None
+
+
+def test_profiled_kernel_names_follow_the_kernel_templates():
+    """a record named a kernel that no longer existed after a template refactor, and the PMC table script
+    matched zero rows.  The names bench.py prints and benchmarks/collect_profiles.py matches must carry as many template
+    arguments as the kernels have parameters in csrc/ (rocprofv3 prints every argument, defaults included)."""
+    import re
+    import types
+    import bench
+    csrc = os.path.join(ROOT, "linearalgebrampi.jl_amd", "csrc")
+
+    def n_template_params(path, kernel):
+        text = open(os.path.join(csrc, path)).read()
+        m = re.search(r"template <([^>]*)>\s*\n__global__[^\n]*void %s\(" % kernel, text)
+        assert m, (path, kernel)
+        return len([p for p in m.group(1).split(",") if p.strip()])
+
+    n_rg = n_template_params("spmv.hip", "spmv_rowgather_kernel")
+    n_quad = n_template_params("spmv.hip", "spmv_rowblock_quad_kernel")
+    n_t = n_template_params("rowgather_t.h", "rowgather_kernel")
+    for kind, name, n in ((0, "spmv_rowgather_kernel", n_rg), (1, "spmv_rowblock_quad_kernel", n_quad)):
+        fake = types.SimpleNamespace(_capi=types.SimpleNamespace(load=lambda k=kind: types.SimpleNamespace(hpcla_get_spmv_kernel=lambda: k)))
+        inst = bench.spmv_kernel_instance(fake, is_i64=True, split=True, wait=False)
+        assert inst.startswith(f"hpcla::{name}<long, true, false") and inst.count(",") == n - 1, (inst, n)
+    assert bench.f32_kernel_name(16).count(",") == n_t - 1
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("collect_profiles", os.path.join(ROOT, "benchmarks", "collect_profiles.py"))
+    cp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cp)
+    assert cp.KERNEL.startswith("spmv_rowgather_kernel<") and cp.KERNEL.count(",") == n_rg - 1
+    table = open(os.path.join(ROOT, "benchmarks", "pmc_f32_table.py")).read()
+    m = re.search(r'rg = lambda kc: "rowgather_kernel<([^"]*)>"', table)
+    assert m and m.group(1).count(",") == n_t - 1
