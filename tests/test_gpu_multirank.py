@@ -38,6 +38,11 @@ def test_push_transport_ranks_exchange(nranks):
     3 ranks Int64 with narrowing off (the Int64 kernels themselves), 4 ranks Int32 -- the ranks share the one GPU of
     the box by time-slicing, so wall time grows with ranks x cases."""
     env = {"HPCLA_PUSH_TIMEOUT_S": "30", "HPCLA_MR_TYPES": {2: "i32,i64", 3: "i64wide", 4: "i32", 5: "i32"}[nranks]}
+    if nranks == 5 and int(os.environ.get("HPCLA_MR_MAX_RANKS", "4")) < 5:
+        # 5 workers + this test runner are exactly the 6 GPU processes a box of this pool allows: one more GPU-holding process
+        # around the runner (a profiler, a monitor) and the guard kills the whole run.  Opt-in; the round's own runs of it
+        # (and of 6 ranks outside the runner) are on record: DESIGN.md section 4, profiles/r05_six_process_ranks_host_layer.log
+        pytest.skip("5 one-process ranks leave no margin under the 6-process guard: set HPCLA_MR_MAX_RANKS=5 to run")
     if nranks == 5:
         # the most one-process-per-rank workers this box allows next to the test runner (6 GPU processes per card): every rank
         # of the unstructured case has 4 send and 4 recv neighbours; 8 ranks / 7 neighbours run as threads of one process
