@@ -159,11 +159,13 @@ int window_open(const WindowDesc &d, int peer_rank, int my_rank, void *my_base, 
     if (d.pid == (uint64_t)getpid() && d.host_id == host_identity()) {
         // a window of this process: mine, or that of another rank hosted here
         void *base = peer_rank == my_rank ? my_base : local_window_find(d.ipc);
-        if (!base)
-            return set_error(HPCLA_ERR_INVALID, "window_open: rank %d's window is of this process but not registered", peer_rank);
-        out->base = base;
-        out->opened = false;
-        return HPCLA_OK;
+        if (base) {
+            out->base = base;
+            out->opened = false;
+            return HPCLA_OK;
+        }
+        // not exported here: ANOTHER process that happens to carry this pid (ranks in separate PID namespaces) -- open it
+        // over IPC like any other peer
     }
     if (d.host_id != host_identity())
         return set_error(HPCLA_ERR_UNSUPPORTED, "window_open: rank %d is on another node (push transport is per node)",
