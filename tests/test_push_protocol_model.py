@@ -192,3 +192,32 @@ def test_window_allreduce_two_parities_suffice(n):
 def test_window_allreduce_one_parity_is_not_enough():
     """Mutation check: with ONE slot per writer a rank that is one all-reduce ahead overwrites a partial its peer has not read."""
     assert any(_allreduce_model(8, 50, random.Random(seed), parities=1)[1] for seed in range(20))
+
+
+# ---- the plan's step counter: two-level release counting (csrc/halo_wait.h epoch_release) -------------------------------------
+def test_two_level_release_counter_fires_exactly_once_on_the_last_release():
+    """epoch_release: reader i bumps shard i % 64; the release that completes a shard (in_shard = readers with that residue)
+    resets it and bumps the top counter; the release that completes the top (min(n_readers, 64) active shards) resets it and
+    stores done = e.  For every reader count and any release order exactly ONE release may store `done`, and it must be the
+    LAST one -- nobody may still need the epoch number when it moves on.  The arithmetic below is the kernel's, line by line."""
+    SHARDS = 64
+    rng = random.Random(3)
+    for n_readers in list(range(1, 200)) + [255, 256, 257, 2048, 2049, 65536 + 7]:
+        shards, top, fired = [0] * SHARDS, 0, []
+        order = list(range(n_readers))
+        rng.shuffle(order)
+        for k, reader in enumerate(order):
+            sh = reader % SHARDS
+            in_shard = (n_readers - sh + SHARDS - 1) // SHARDS
+            shards[sh] += 1
+            if shards[sh] != in_shard:
+                continue
+            shards[sh] = 0
+            active = n_readers if n_readers < SHARDS else SHARDS
+            top += 1
+            if top != active:
+                continue
+            top = 0
+            fired.append(k)
+        assert fired == [n_readers - 1], (n_readers, fired)
+        assert top == 0 and not any(shards)               # the counters are back at zero for the next step
