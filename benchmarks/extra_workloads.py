@@ -173,6 +173,11 @@ def _measure_spmm(args, job, hp, wl, A, B, k, world, dev, setup_s, metric, workl
     return out
 
 
+def _spmm_order_in_force(plan, rowptr):
+    """The SpMM block-order group the host layer has set in the library for this rowptr (0 = natural)."""
+    return int(plan.__dict__.get("_spmm_order_in_force", {}).get(rowptr.data_ptr(), 0))
+
+
 def _colmajor_cost(hp, A, B, k, b_alg, direct_too=True):
     """What the same product costs a COLUMN-major caller -- Julia's Matrix, the layout of the reference's dense block
     (src/dense.jl:63) -- through the raw C ABI on the plan's own arrays: (a) the product on the column-major blocks as they are
@@ -245,12 +250,37 @@ def _colmajor_cost(hp, A, B, k, b_alg, direct_too=True):
     same = bool(torch.equal(ref, Cc))
     ms_d, ms_c = timed(direct), timed(converted)
     ms_cc = timed(ccol)
-    return {"direct_ms": round(ms_d, 4), "direct_frac_of_peak": round(b_alg / (ms_d * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            "kernel": "hpcla::rowgather_kernel<double, int, false, 16, 2>",
-            "via_two_layout_conversions_ms": round(ms_c, 4), "same_bits": same and same_ccol,
-            "via_b_conversion_and_colmajor_store_ms": round(ms_cc, 4),
-            "note": "the product as a column-major caller (Julia's Matrix) gets it: on the blocks as they are (lanes = rows kernel) "
-                    "against transpose + row-major product + transpose; the record's own ms_per_step is the row-major host layer"}
+    out = {"direct_ms": round(ms_d, 4), "direct_frac_of_peak": round(b_alg / (ms_d * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+           "kernel": "hpcla::rowgather_kernel<double, int, false, 16, 2>",
+           "via_two_layout_conversions_ms": round(ms_c, 4), "same_bits": same and same_ccol,
+           "via_b_conversion_and_colmajor_store_ms": round(ms_cc, 4),
+           "note": "the product as a column-major caller (Julia's Matrix) gets it: on the blocks as they are (lanes = rows kernel; "
+                   "run_tiles_ms: the run tiles on the column-major blocks, round 5 -- what the Julia extension calls at k = 16 on a "
+                   "structure whose blocks fit) against transpose + row-major product + transpose; the record's own ms_per_step is "
+                   "the row-major host layer"}
+    # round 5: the run tiles on the column-major blocks (k = 16, every column owned here, B's columns on the 16-byte grid)
+    from hpcla_amd.dense import _spmm_runs
+    desc = _spmm_runs(A, plan, rp, cv, plan.is_i64) if k == 16 else None
+    if desc is not None and nb % 2 == 0 and Bc.data_ptr() % 16 == 0 and plan.n_own == nb:
+        def runs_direct():
+            capi.call(f"hpcla_spmm_runs_colmajor_k16_f64_{sfx}", dptr(rp), dptr(cv), dptr(A.nzval), dptr(Bc), nb, None, 0, nb, dptr(Cc), n, n,
+                      A.nnz, 0, dptr(desc), None, 0, s)
+        import ctypes
+        in_force = _spmm_order_in_force(plan, rp)
+        chosen = ctypes.c_int(1)
+        Cc.fill_(float("nan"))
+        # plan time, as the Julia extension does it: the launch timed under five block orders, the fastest stays set for rowptr
+        capi.call(f"hpcla_spmm_runs_colmajor_tune_block_order_f64_{sfx}", dptr(rp), dptr(cv), dptr(A.nzval), dptr(Bc), nb, None, 0, nb,
+                  dptr(Cc), n, n, A.nnz, 0, dptr(desc), None, 0, s, ctypes.byref(chosen))
+        out["same_bits"] = out["same_bits"] and bool(torch.equal(ref, Cc))
+        Cc.fill_(float("nan"))
+        runs_direct()
+        out["same_bits"] = out["same_bits"] and bool(torch.equal(ref, Cc))
+        ms_r = timed(runs_direct)
+        capi.call("hpcla_spmm_block_order_hint", dptr(rp), in_force)      # the host layer's own (row-major) order back in force
+        out.update({"run_tiles_ms": round(ms_r, 4), "run_tiles_block_order_group": int(chosen.value), "run_tiles_frac_of_peak": round(b_alg / (ms_r * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "run_tiles_kernel": "hpcla::spmm_runs_colmajor_kernel<int, false>" if sfx == "i32" else "hpcla::spmm_runs_colmajor_kernel<long, false>"})
+    return out
 
 
 def _sprand_spmv(hp, wl, job, A, ncols, backend, args):

@@ -328,6 +328,36 @@ int hpcla_spmm_runs_k16_f64_i64(const int64_t *rowptr, const int64_t *colval_spl
                                 const double *B_own, const double *B_ghost, int64_t n_own, double *C, int64_t nrows,
                                 int64_t nnz, int index_base, const void *desc, const int32_t *block_list,
                                 int64_t n_blocks, void *stream);
+/* The run tiles on a COLUMN-major caller's blocks (Julia's Matrix, src/dense.jl:63; round 5): hpcla_spmm_split_colmajor_f64_*
+ * for k = 16 with the descriptors of hpcla_spmm_runs_build_* -- B_own (n_own rows, ALWAYS the row count of B_own here, also
+ * with B_ghost == NULL) and C column-major with leading dimensions ldb_own / ldc, B_ghost the plan's row-major ghost segment
+ * (ldb_ghost >= 16) or NULL.  Every own run is widened to an even first row and an even end so that the 16-byte LDS-DMA
+ * applies to a column's run: B_own must be 16-byte aligned and ldb_own even (HPCLA_ERR_UNSUPPORTED otherwise: take
+ * hpcla_spmm_split_colmajor_f64_*).  Same sums in the same order, same bits.  `block_list` over blocks of
+ * hpcla_spmm_rows_per_block() rows, as in hpcla_spmm_runs_k16_f64_*. */
+int hpcla_spmm_runs_colmajor_k16_f64_i32(const int32_t *rowptr, const int32_t *colval_split, const double *nzval,
+                                         const double *B_own, int64_t ldb_own, const double *B_ghost, int64_t ldb_ghost,
+                                         int64_t n_own, double *C, int64_t ldc, int64_t nrows, int64_t nnz, int index_base,
+                                         const void *desc, const int32_t *block_list, int64_t n_blocks, void *stream);
+int hpcla_spmm_runs_colmajor_k16_f64_i64(const int64_t *rowptr, const int64_t *colval_split, const double *nzval,
+                                         const double *B_own, int64_t ldb_own, const double *B_ghost, int64_t ldb_ghost,
+                                         int64_t n_own, double *C, int64_t ldc, int64_t nrows, int64_t nnz, int index_base,
+                                         const void *desc, const int32_t *block_list, int64_t n_blocks, void *stream);
+/* Plan-time block order of hpcla_spmm_runs_colmajor_k16_f64_*, by measurement (the twin of hpcla_spmm_tune_block_order_f64_*,
+ * whose launch is the row-major gather kernel): the product's own arguments; the launch is timed under the natural order and
+ * groups of 8 / 32 / 128 / 512 row blocks, the fastest stays set for `rowptr` (hpcla_spmm_block_order_hint overrides it),
+ * *chosen_group receives it (1 = natural).  C receives the product.  Synchronises the stream; launches of fewer than 4096
+ * blocks are run once and keep the natural order. */
+int hpcla_spmm_runs_colmajor_tune_block_order_f64_i32(const int32_t *rowptr, const int32_t *colval_split, const double *nzval,
+                                                      const double *B_own, int64_t ldb_own, const double *B_ghost,
+                                                      int64_t ldb_ghost, int64_t n_own, double *C, int64_t ldc, int64_t nrows,
+                                                      int64_t nnz, int index_base, const void *desc, const int32_t *block_list,
+                                                      int64_t n_blocks, void *stream, int *chosen_group);
+int hpcla_spmm_runs_colmajor_tune_block_order_f64_i64(const int64_t *rowptr, const int64_t *colval_split, const double *nzval,
+                                                      const double *B_own, int64_t ldb_own, const double *B_ghost,
+                                                      int64_t ldb_ghost, int64_t n_own, double *C, int64_t ldc, int64_t nrows,
+                                                      int64_t nnz, int index_base, const void *desc, const int32_t *block_list,
+                                                      int64_t n_blocks, void *stream, int *chosen_group);
 /* A * B on the CALLER's column-major blocks (Julia's Matrix, src/dense.jl:63), no layout conversion (csrc/colmajor.hip):
  * lanes = rows, so the 64 rows of a wave read one contiguous run of a column per gather instruction wherever the matrix is
  * banded; same bits as the row-major kernels.  hpcla_spmm_csr_f64_* takes this path by itself when both layouts are

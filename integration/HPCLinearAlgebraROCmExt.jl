@@ -508,6 +508,7 @@ _spmm_runs(A, d) = get(ENV, "HPCLA_SPMM_RUNS", "1") == "0" ? nothing : ((desc, f
 # 1.52 ms; 7-point: 0.99 against 1.63); an unstructured matrix touches a line per (entry, column) pair in that layout and
 # keeps the conversions.  HPCLA_SPMM_COLMAJOR=0 switches the direct path off.
 const _banded_cache = IdDict{Any,Bool}()       # device plan -> banded?
+const _spmm_cm_tuned = IdDict{Any,Int}()       # device plan -> block-order group measured for the column-major run tiles
 function _banded(A, d::ROCVectorPlan{Tk}) where {Tk}
     get(ENV, "HPCLA_SPMM_COLMAJOR", "1") == "0" && return false
     get!(_banded_cache, d) do
@@ -532,8 +533,42 @@ function _spmm_colmajor(A::HPCSparseMatrix{T,Ti,B}, M::HPCMatrix{T,B}, plan, d::
     nloc, k = size(M.A)
     C = ROCMatrix{T}(undef, A.nrows_local, k)          # every row block is launched: no zero fill
     nnz = length(A.nzval); ldb = max(nloc, 1); ldc = max(A.nrows_local, 1)
+    # k = 16, Float64, every block within the run-tile limits (a 5-point matrix: 3 runs per block) and B's columns on the
+    # 16-byte grid: the run tiles on the column-major blocks (hpcla_spmm_runs_colmajor_k16_f64_*, round 5: 0.56 ms against
+    # 0.64 on the 5-point matrix x 16, same bits) -- block lists over its 64-row blocks
+    runs = (T === Float64 && k == 16 && iseven(ldb) && UInt(_ptr(M.A)) % 16 == 0) ? _spmm_runs(A, d) : nothing
+    rpb = runs === nothing ? (@ccall LIB.hpcla_spmv_rows_per_block()::Cint) : (@ccall LIB.hpcla_spmm_rows_per_block()::Cint)
     function launch(ghost::Ptr{Cvoid}, blocks::Ptr{Cvoid}, nblocks::Int64)
-        if T === Float64 && Tk === Int32
+        if runs !== nothing
+            # the first launch without a ghost segment (the whole product, or the interior list while the exchange is in
+            # flight) goes through the plan-time tuner: the same launch timed under five block orders, the fastest stays set
+            tune = ghost == C_NULL && !haskey(_spmm_cm_tuned, d)
+            chosen = Ref{Cint}(1)
+            if tune && Tk === Int32
+                _check(@ccall(LIB.hpcla_spmm_runs_colmajor_tune_block_order_f64_i32(_ptr(d.rowptr0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
+                       _ptr(A.nzval)::Ptr{Cvoid}, _ptr(M.A)::Ptr{Cvoid}, ldb::Int64, ghost::Ptr{Cvoid}, k::Int64, d.n_own::Int64,
+                       _ptr(C)::Ptr{Cvoid}, ldc::Int64, A.nrows_local::Int64, nnz::Int64, 0::Cint, _ptr(runs)::Ptr{Cvoid},
+                       blocks::Ptr{Cvoid}, nblocks::Int64, _stream()::Ptr{Cvoid}, chosen::Ptr{Cint})::Cint),
+                       "hpcla_spmm_runs_colmajor_tune_block_order_f64_i32")
+            elseif tune
+                _check(@ccall(LIB.hpcla_spmm_runs_colmajor_tune_block_order_f64_i64(_ptr(d.rowptr0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
+                       _ptr(A.nzval)::Ptr{Cvoid}, _ptr(M.A)::Ptr{Cvoid}, ldb::Int64, ghost::Ptr{Cvoid}, k::Int64, d.n_own::Int64,
+                       _ptr(C)::Ptr{Cvoid}, ldc::Int64, A.nrows_local::Int64, nnz::Int64, 0::Cint, _ptr(runs)::Ptr{Cvoid},
+                       blocks::Ptr{Cvoid}, nblocks::Int64, _stream()::Ptr{Cvoid}, chosen::Ptr{Cint})::Cint),
+                       "hpcla_spmm_runs_colmajor_tune_block_order_f64_i64")
+            elseif Tk === Int32
+                _check(@ccall(LIB.hpcla_spmm_runs_colmajor_k16_f64_i32(_ptr(d.rowptr0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
+                       _ptr(A.nzval)::Ptr{Cvoid}, _ptr(M.A)::Ptr{Cvoid}, ldb::Int64, ghost::Ptr{Cvoid}, k::Int64, d.n_own::Int64,
+                       _ptr(C)::Ptr{Cvoid}, ldc::Int64, A.nrows_local::Int64, nnz::Int64, 0::Cint, _ptr(runs)::Ptr{Cvoid},
+                       blocks::Ptr{Cvoid}, nblocks::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_spmm_runs_colmajor_k16_f64_i32")
+            else
+                _check(@ccall(LIB.hpcla_spmm_runs_colmajor_k16_f64_i64(_ptr(d.rowptr0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
+                       _ptr(A.nzval)::Ptr{Cvoid}, _ptr(M.A)::Ptr{Cvoid}, ldb::Int64, ghost::Ptr{Cvoid}, k::Int64, d.n_own::Int64,
+                       _ptr(C)::Ptr{Cvoid}, ldc::Int64, A.nrows_local::Int64, nnz::Int64, 0::Cint, _ptr(runs)::Ptr{Cvoid},
+                       blocks::Ptr{Cvoid}, nblocks::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_spmm_runs_colmajor_k16_f64_i64")
+            end
+            tune && (_spmm_cm_tuned[d] = Int(chosen[]))
+        elseif T === Float64 && Tk === Int32
             _check(@ccall(LIB.hpcla_spmm_split_colmajor_f64_i32(_ptr(d.rowptr0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
                    _ptr(A.nzval)::Ptr{Cvoid}, _ptr(M.A)::Ptr{Cvoid}, ldb::Int64, ghost::Ptr{Cvoid}, k::Int64, d.n_own::Int64,
                    _ptr(C)::Ptr{Cvoid}, ldc::Int64, A.nrows_local::Int64, nnz::Int64, k::Cint, 0::Cint, blocks::Ptr{Cvoid},
@@ -558,7 +593,7 @@ function _spmm_colmajor(A::HPCSparseMatrix{T,Ti,B}, M::HPCMatrix{T,B}, plan, d::
     if d.halo == C_NULL
         launch(C_NULL, C_NULL, Int64(0))                         # every row block, every column owned
     else
-        halo, interior, boundary, _, ghost = _spmm_halo(A, plan, d, k, (@ccall LIB.hpcla_spmv_rows_per_block()::Cint))
+        halo, interior, boundary, _, ghost = _spmm_halo(A, plan, d, k, rpb)
         stage = _stage(d, d.n_own * k)
         if T === Float64
             _check(@ccall(LIB.hpcla_halo_begin_strided_f64(halo::Ptr{Cvoid}, _ptr(M.A)::Ptr{Cvoid}, 1::Int64, ldb::Int64,
@@ -1097,8 +1132,9 @@ function clear_rocm_plan_cache!()
     for st in values(_rocm_exec); destroy(st[1]); end
     for d in values(_rocm_plans)    # the plans' rowptr copies carry the block-order hints: removed before the arrays go
         d isa ROCVectorPlan && @ccall LIB.hpcla_spmv_block_order_hint(_ptr(d.rowptr0)::Ptr{Cvoid}, 0::Cint)::Cint
+        d isa ROCVectorPlan && haskey(_spmm_cm_tuned, d) && @ccall LIB.hpcla_spmm_block_order_hint(_ptr(d.rowptr0)::Ptr{Cvoid}, 0::Cint)::Cint
     end
-    empty!(_rocm_plans); empty!(_spmm_plans); empty!(_rocm_exec); empty!(_merge_lists); empty!(_spmm_runs_cache); empty!(_stage32); empty!(_banded_cache)
+    empty!(_rocm_plans); empty!(_spmm_plans); empty!(_rocm_exec); empty!(_merge_lists); empty!(_spmm_runs_cache); empty!(_stage32); empty!(_banded_cache); empty!(_spmm_cm_tuned)
     empty!(_spgemm_cache)
     return nothing
 end

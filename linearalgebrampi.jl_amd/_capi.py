@@ -66,6 +66,10 @@ _SIGNATURES = {
     "hpcla_spmm_banded_blocks_i64": [_vp, _vp, _i64, _i64, _i32, _i64, _i32, _vp, _vp],
     "hpcla_spmm_runs_k16_f64_i32": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _i64, _vp],
     "hpcla_spmm_runs_k16_f64_i64": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _i64, _vp],
+    "hpcla_spmm_runs_colmajor_k16_f64_i32": [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _vp, _vp, _i64, _vp],
+    "hpcla_spmm_runs_colmajor_k16_f64_i64": [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _vp, _vp, _i64, _vp],
+    "hpcla_spmm_runs_colmajor_tune_block_order_f64_i32": [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _vp, _vp, _i64, _vp, _vp],
+    "hpcla_spmm_runs_colmajor_tune_block_order_f64_i64": [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _vp, _vp, _i64, _vp, _vp],
     "hpcla_spmm_block_order_hint": [_vp, _i32],
     "hpcla_spmm_tune_block_order_f64_i32": [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32,
                                             _vp, _i64, _vp, _vp],

@@ -571,6 +571,167 @@ __global__ __launch_bounds__(TPB_MM) void spmm_rowblock_runs_kernel(
     }
 }
 
+// RUN TILES for a COLUMN-major caller (round 5; Julia's Matrix, src/dense.jl:63): B_own and C column-major, the ghost rows the
+// halo plan's ordinary row-major segment.  Same descriptors, same sums in the same order (the reference's bits,
+// src/sparse.jl:2391-2413), other shape:
+//   * a run of ONE column is a contiguous piece of memory, but it starts on any 8-byte boundary, which left the first form of
+//     this kernel global_load_lds's 4-byte variant (144 wave-instructions per workgroup, 1.78 ms on the 5-point matrix x 16:
+//     profiles/r04_colmajor.log).  Here every own run is widened to an EVEN first row and an even end (at most two rows more
+//     per run: B_own 16-byte aligned, ldb even -- the launcher checks), so the 16-byte LDS-DMA applies: the tile is the
+//     block's runs of column 0, then of column 1, ... back to back (Tpad rows each), 64 row pairs per wave-instruction
+//     (lanes past the tile's end are masked off: a masked lane neither loads nor writes its LDS slot);
+//   * lanes = rows, waves = column quads: a lane reads its entries' four B values out of LDS (64 lanes on consecutive tile
+//     rows of one column: no bank conflicts), and C leaves as 512-byte runs straight from the registers;
+//   * ghost columns are not staged: their entries (boundary blocks only) read the row-major ghost row from memory.
+// A block whose widened runs exceed the tile, or would read past row n_own of a column (the last block, n_own odd), takes
+// the per-entry path.  The tile keeps RUNS_TILE_ROWS rows: 31 744 bytes of LDS per workgroup = 5 workgroups per CU; at
+// 32 768 the fifth does not fit and the product takes 0.625 ms instead of 0.563 (profiles/r05_colmajor_run_tiles.log).
+constexpr int RUNS_CM_TILE_ROWS = RUNS_TILE_ROWS;
+
+template <typename I, bool SPLIT>
+__global__ __launch_bounds__(TPB_MM) void spmm_runs_colmajor_kernel(
+    const I *__restrict__ rowptr, const I *__restrict__ colval, const double *__restrict__ nzval,
+    const double *__restrict__ B_own, int64_t ldb, const double *__restrict__ B_ghost, int64_t ldg, int64_t n_own,
+    double *__restrict__ C, int64_t ldc, int64_t nrows, int base, const SpmmRunDesc *__restrict__ runs,
+    const int32_t *__restrict__ block_list, uint32_t nblocks, int group_log2)
+{
+    static_assert(KT == 4 * (TPB_MM / 64), "one wave per column quad");
+    static_assert(RPB_MM == 64, "lanes = rows");
+    __shared__ __attribute__((aligned(16))) double s_tile[RUNS_CM_TILE_ROWS * KT];   // column c of the widened runs at [c * Tpad, (c + 1) * Tpad)
+    __shared__ int32_t s_off[RUNS_EMAX];                                             // per entry: tile row, or -(ghost row) - 1
+    __shared__ double s_val[RUNS_EMAX];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar loop control below)
+    int64_t blk = (int64_t)blockIdx.x;
+    if (group_log2 > 0) {                                  // XCD-grouped order of the launch's positions (as in the row-major kernel)
+        const int64_t span = (int64_t)1 << (3 + group_log2), nb = (int64_t)nblocks;
+        if (blk < nb - (nb & (span - 1))) {
+            const int64_t xcd = blk & 7, q = blk >> 3;
+            blk = ((((q >> group_log2) << 3) + xcd) << group_log2) + (q & (((int64_t)1 << group_log2) - 1));
+        }
+    }
+    if (block_list) blk = (int64_t)block_list[blk];
+    const int64_t r0 = blk * RPB_MM;
+    const int nr = (int)((nrows - r0) < RPB_MM ? (nrows - r0) : RPB_MM);
+    const SpmmRunDesc d = runs[blk];
+    const int64_t p0 = (int64_t)rowptr[r0] - base, p1 = (int64_t)rowptr[r0 + nr] - base;
+    I rlo = 0, rhi = 0;
+    if (lane < nr) { rlo = rowptr[r0 + lane]; rhi = rowptr[r0 + lane + 1]; }
+    const int total = (int)(p1 - p0);
+
+    // the own runs, widened to even first rows and even ends; o[i]: tile row where run i begins
+    int64_t a[RUNS_MAX];
+    int o[RUNS_MAX + 1];
+    bool fits = d.len[0] >= 0;
+    o[0] = 0;
+#pragma unroll
+    for (int i = 0; i < RUNS_MAX; ++i) {
+        const bool own = d.len[i] > 0 && (!SPLIT || (int64_t)d.start[i] < n_own);
+        const int64_t ai = (int64_t)d.start[i] & ~(int64_t)1, ei = ((int64_t)d.start[i] + d.len[i] + 1) & ~(int64_t)1;
+        a[i] = ai;
+        o[i + 1] = o[i] + (own ? (int)(ei - ai) : 0);
+        if (own && ei > n_own) fits = false;               // the widened run would read past the column's last row
+    }
+    const int Tpad = o[RUNS_MAX];
+    if (Tpad > RUNS_CM_TILE_ROWS) fits = false;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    double *Cq = C + (int64_t)(4 * wave) * ldc + r0 + lane;
+
+    if (!fits) {
+        // workgroup-uniform, rare (the host layers use this kernel when >= 99 % of the blocks fit): per-entry reads from memory
+        if (lane < nr) {
+            const double *Bq = B_own + (int64_t)(4 * wave) * ldb;
+            for (int64_t j = (int64_t)rlo - base; j < (int64_t)rhi - base; ++j) {
+                const double v = nzval[j];
+                const int64_t c = (int64_t)colval[j] - base;
+                double b0, b1, b2, b3;
+                if (SPLIT && c >= n_own) {
+                    const double *row = B_ghost + (c - n_own) * ldg + 4 * wave;
+                    b0 = row[0]; b1 = row[1]; b2 = row[2]; b3 = row[3];
+                } else {
+                    b0 = Bq[c]; b1 = Bq[ldb + c]; b2 = Bq[2 * ldb + c]; b3 = Bq[3 * ldb + c];
+                }
+                acc[0] += v * b0; acc[1] += v * b1; acc[2] += v * b2; acc[3] += v * b3;
+            }
+            Cq[0] = acc[0]; Cq[ldc] = acc[1]; Cq[2 * ldc] = acc[2]; Cq[3 * ldc] = acc[3];
+        }
+        return;
+    }
+
+    // B -> LDS: one wave-instruction = 64 row pairs (1 KiB) of the tile's linear space; pair P = rows {2 pr, 2 pr + 1} of column c
+    {
+        const unsigned halfT = (unsigned)Tpad >> 1, pairs = halfT * KT;
+        const int npieces = (int)((pairs + 63) >> 6);
+        for (int q = wave; q < npieces; q += TPB_MM / 64) {
+            const unsigned P = (unsigned)q * 64 + lane;
+            if (P < pairs) {
+                const unsigned c = P / halfT;
+                const int t = (int)(2 * (P - c * halfT));
+                const int64_t sr = t < o[1] ? a[0] + t : (t < o[2] ? a[1] + (t - o[1]) : (t < o[3] ? a[2] + (t - o[2]) : a[3] + (t - o[3])));
+                const double *src = B_own + (int64_t)c * ldb + sr;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(s_tile + q * 128), 16, 0, 0);
+            }
+        }
+    }
+    // A entries -> {tile row | ghost row, value}; both of a thread's entries requested unconditionally (see the row-major kernel)
+    if (total > 0) {                                        // workgroup-uniform
+        static_assert(RUNS_EMAX == 2 * TPB_MM, "two entries per thread");
+        const int i0 = tid, i1 = tid + TPB_MM;
+        const int j0 = i0 < total ? i0 : total - 1, j1 = i1 < total ? i1 : total - 1;
+        const I cr0 = __builtin_nontemporal_load(colval + p0 + j0);
+        const double v0 = __builtin_nontemporal_load(nzval + p0 + j0);
+        const I cr1 = __builtin_nontemporal_load(colval + p0 + j1);
+        const double v1 = __builtin_nontemporal_load(nzval + p0 + j1);
+        auto tile_row = [&](int64_t c) -> int {
+            if (SPLIT && c >= n_own) return -(int)(c - n_own) - 1;
+            if (d.len[3] > 0 && c >= d.start[3]) return o[3] + (int)(c - a[3]);
+            if (d.len[2] > 0 && c >= d.start[2]) return o[2] + (int)(c - a[2]);
+            if (d.len[1] > 0 && c >= d.start[1]) return o[1] + (int)(c - a[1]);
+            return (int)(c - a[0]);
+        };
+        const int t0 = tile_row((int64_t)cr0 - base), t1 = tile_row((int64_t)cr1 - base);
+        if (i0 < total) { s_off[i0] = t0; s_val[i0] = v0; }
+        if (i1 < total) { s_off[i1] = t1; s_val[i1] = v1; }
+    }
+    __syncthreads();                                        // (drains the LDS-DMA too)
+
+    if (lane < nr) {
+        const double *q0 = s_tile + (4 * wave) * Tpad, *q1 = q0 + Tpad, *q2 = q1 + Tpad, *q3 = q2 + Tpad;
+        auto fetch = [&](int off, double &b0, double &b1, double &b2, double &b3) {
+            if (!SPLIT || off >= 0) { b0 = q0[off]; b1 = q1[off]; b2 = q2[off]; b3 = q3[off]; }
+            else {
+                const double *row = B_ghost + (int64_t)(-off - 1) * ldg + 4 * wave;
+                b0 = row[0]; b1 = row[1]; b2 = row[2]; b3 = row[3];
+            }
+        };
+        int j = (int)((int64_t)rlo - base - p0);
+        const int e = (int)((int64_t)rhi - base - p0);
+        for (; j + 2 <= e; j += 2) {
+            const int oa = s_off[j], ob = s_off[j + 1];
+            const double va = s_val[j], vb = s_val[j + 1];
+            double a0, a1, a2, a3, b0, b1, b2, b3;
+            fetch(oa, a0, a1, a2, a3);
+            fetch(ob, b0, b1, b2, b3);
+            acc[0] += va * a0; acc[1] += va * a1; acc[2] += va * a2; acc[3] += va * a3;
+            acc[0] += vb * b0; acc[1] += vb * b1; acc[2] += vb * b2; acc[3] += vb * b3;
+        }
+        for (; j < e; ++j) {
+            const int oa = s_off[j];
+            const double va = s_val[j];
+            double a0, a1, a2, a3;
+            fetch(oa, a0, a1, a2, a3);
+            acc[0] += va * a0; acc[1] += va * a1; acc[2] += va * a2; acc[3] += va * a3;
+        }
+    }
+    if (lane < nr) {
+        __builtin_nontemporal_store(acc[0], Cq);
+        __builtin_nontemporal_store(acc[1], Cq + ldc);
+        __builtin_nontemporal_store(acc[2], Cq + 2 * ldc);
+        __builtin_nontemporal_store(acc[3], Cq + 3 * ldc);
+    }
+}
+
 // Plan time, once per structure: the run descriptor of every 64-row block.  One workgroup per block: the block's (split)
 // columns are sorted in LDS (bitonic, <= RUNS_EMAX keys), an element starts a run where it is neither equal to nor the
 // successor of its predecessor, or where it crosses the own / ghost boundary; runs are ranked by wave ballots.
@@ -882,6 +1043,49 @@ HPCLA_API int hpcla_spmm_block_order_hint(const void *rowptr, int group)
     return HPCLA_OK;
 }
 
+// The measuring loop of the plan-time tuners: `launch` (the launch the plan will make; every call writes the complete, correct
+// product) under each candidate group (log2; 0 = natural order), interleaved, round 0 not counted, median of three; natural
+// unless a grouped order is >= 1 % faster.  Leaves the chosen order set for `rowptr`.
+template <typename Launch>
+static int tune_order_measured(const void *rowptr, const int *cand, int nc, void *stream, int *chosen_group, const char *who,
+                               Launch launch)
+{
+    constexpr int NC_MAX = 8, ROUNDS = 4, REPS = 2;
+    if (nc > NC_MAX) nc = NC_MAX;
+    float ms[NC_MAX][ROUNDS];
+    hipEvent_t e0, e1;
+    HPCLA_CHECK_HIP(hipEventCreate(&e0));
+    HPCLA_CHECK_HIP(hipEventCreate(&e1));
+    hipStream_t s = as_stream(stream);
+    int rc = HPCLA_OK;
+    for (int r = 0; r < ROUNDS && rc == HPCLA_OK; ++r)
+        for (int c = 0; c < nc && rc == HPCLA_OK; ++c) {
+            set_spmm_block_order(rowptr, cand[c]);
+            if (hipEventRecord(e0, s) != hipSuccess) { rc = set_error(HPCLA_ERR_HIP, "%s: event", who); break; }
+            for (int i = 0; i < REPS && rc == HPCLA_OK; ++i) rc = launch();
+            if (rc != HPCLA_OK) break;
+            if (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+                hipEventElapsedTime(&ms[c][r], e0, e1) != hipSuccess)
+                rc = set_error(HPCLA_ERR_HIP, "%s: timing", who);
+        }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    set_spmm_block_order(rowptr, 0);
+    if (rc != HPCLA_OK) return rc;
+    float med[NC_MAX];
+    for (int c = 0; c < nc; ++c) {                           // median of the three counted rounds
+        float a = ms[c][1], b = ms[c][2], d = ms[c][3];
+        med[c] = a > b ? (b > d ? b : (a > d ? d : a)) : (a > d ? a : (b > d ? d : b));
+    }
+    int best = 0;
+    for (int c = 1; c < nc; ++c)
+        if (med[c] < med[best]) best = c;
+    if (best != 0 && med[best] > 0.99f * med[0]) best = 0;
+    set_spmm_block_order(rowptr, cand[best]);
+    if (chosen_group) *chosen_group = 1 << cand[best];
+    return HPCLA_OK;
+}
+
 // Plan-time choice of the SpMM block order BY MEASUREMENT, the SpMV tuner's twin (spmv.hip tune_block_order): the launch
 // the plan will make -- same arguments, results into the caller's C (every launch writes the complete, correct product) --
 // under the natural order and groups of 16 / 64 / 256 row blocks (of 64 rows), interleaved; natural unless a grouped order
@@ -902,42 +1106,11 @@ static int spmm_tune_block_order(const I *rowptr, const I *colval_split, const d
     if (launch_blocks < 4096 || nnz == 0 || k < 2 || (k & 1)) return HPCLA_OK;
     const bool split = B_ghost != nullptr;                   // no ghost segment: the unsplit instantiation, like hpcla_spmm_csr_*
     if (!C || !B_own) return set_error(HPCLA_ERR_INVALID, "spmm_tune_block_order: null B / C");
-    constexpr int NC = 4, ROUNDS = 4, REPS = 2;              // round 0 warms up and is not counted
-    const int cand[NC] = {0, 4, 6, 8};
-    float ms[NC][ROUNDS];
-    hipEvent_t e0, e1;
-    HPCLA_CHECK_HIP(hipEventCreate(&e0));
-    HPCLA_CHECK_HIP(hipEventCreate(&e1));
-    hipStream_t s = as_stream(stream);
-    int rc = HPCLA_OK;
-    for (int r = 0; r < ROUNDS && rc == HPCLA_OK; ++r)
-        for (int c = 0; c < NC && rc == HPCLA_OK; ++c) {
-            set_spmm_block_order(rowptr, cand[c]);
-            if (hipEventRecord(e0, s) != hipSuccess) { rc = set_error(HPCLA_ERR_HIP, "spmm_tune_block_order: event"); break; }
-            for (int i = 0; i < REPS && rc == HPCLA_OK; ++i)
-                rc = spmm_launch<I>(rowptr, colval_split, nzval, B_own, ldb_own, 1, B_ghost, ldb_ghost, n_own, split, C, ldc,
-                                    1, nrows, nnz, k, index_base, block_list, n_blocks, stream);
-            if (rc != HPCLA_OK) break;
-            if (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
-                hipEventElapsedTime(&ms[c][r], e0, e1) != hipSuccess)
-                rc = set_error(HPCLA_ERR_HIP, "spmm_tune_block_order: timing");
-        }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    set_spmm_block_order(rowptr, 0);
-    if (rc != HPCLA_OK) return rc;
-    float med[NC];
-    for (int c = 0; c < NC; ++c) {                           // median of the three counted rounds
-        float a = ms[c][1], b = ms[c][2], d = ms[c][3];
-        med[c] = a > b ? (b > d ? b : (a > d ? d : a)) : (a > d ? a : (b > d ? d : b));
-    }
-    int best = 0;
-    for (int c = 1; c < NC; ++c)
-        if (med[c] < med[best]) best = c;
-    if (best != 0 && med[best] > 0.99f * med[0]) best = 0;
-    set_spmm_block_order(rowptr, cand[best]);
-    if (chosen_group) *chosen_group = 1 << cand[best];
-    return HPCLA_OK;
+    const int cand[4] = {0, 4, 6, 8};
+    return tune_order_measured(rowptr, cand, 4, stream, chosen_group, "spmm_tune_block_order", [&]() {
+        return spmm_launch<I>(rowptr, colval_split, nzval, B_own, ldb_own, 1, B_ghost, ldb_ghost, n_own, split, C, ldc, 1, nrows, nnz, k,
+                              index_base, block_list, n_blocks, stream);
+    });
 }
 
 HPCLA_API int hpcla_spmm_tune_block_order_f64_i32(const int32_t *rowptr, const int32_t *colval_split, const double *nzval,
@@ -1163,6 +1336,113 @@ HPCLA_API int hpcla_spmm_runs_k16_f64_i64(const int64_t *rowptr, const int64_t *
 {
     return spmm_runs_launch<int64_t>(rowptr, colval_split, nzval, B_own, B_ghost, n_own, C, nrows, nnz, index_base, desc,
                                      block_list, n_blocks, stream);
+}
+
+// the run tiles on a column-major caller's blocks (spmm_runs_colmajor_kernel)
+template <typename I>
+static int spmm_runs_colmajor_launch(const I *rowptr, const I *colval_split, const double *nzval, const double *B_own,
+                                     int64_t ldb_own, const double *B_ghost, int64_t ldb_ghost, int64_t n_own, double *C,
+                                     int64_t ldc, int64_t nrows, int64_t nnz, int index_base, const void *desc,
+                                     const int32_t *block_list, int64_t n_blocks, void *stream)
+{
+    const char *who = "spmm_runs_colmajor";
+    if (nrows < 0 || nnz < 0 || n_own < 0) return set_error(HPCLA_ERR_INVALID, "%s: negative size", who);
+    if (index_base != 0 && index_base != 1) return set_error(HPCLA_ERR_INVALID, "%s: index_base must be 0 or 1", who);
+    if (nrows == 0) return HPCLA_OK;
+    if (!rowptr || !C || !desc) return set_error(HPCLA_ERR_INVALID, "%s: null rowptr / C / descriptors", who);
+    if (nnz > 0 && (!colval_split || !nzval || !B_own)) return set_error(HPCLA_ERR_INVALID, "%s: null colval / nzval / B with nnz > 0", who);
+    if (ldb_own < n_own || ldc < nrows) return set_error(HPCLA_ERR_INVALID, "%s: leading dimension smaller than the row count", who);
+    if (B_ghost && ldb_ghost < KT) return set_error(HPCLA_ERR_INVALID, "%s: ldb_ghost < 16", who);
+    if (n_own > 0x7fffffffLL) return set_error(HPCLA_ERR_UNSUPPORTED, "%s: split columns beyond Int32", who);
+    if ((reinterpret_cast<uintptr_t>(B_own) & 15) != 0 || (ldb_own & 1) != 0)
+        return set_error(HPCLA_ERR_UNSUPPORTED, "%s: B_own must be 16-byte aligned with an even leading dimension "
+                                                "(hpcla_spmm_split_colmajor_f64_* takes any)", who);
+    const int64_t all_blocks = (nrows + RPB_MM - 1) / RPB_MM;
+    int64_t launch_blocks = all_blocks;
+    if (block_list) {
+        if (n_blocks < 0 || n_blocks > all_blocks) return set_error(HPCLA_ERR_INVALID, "%s: n_blocks out of range", who);
+        launch_blocks = n_blocks;
+    }
+    if (launch_blocks == 0) return HPCLA_OK;
+    HPCLA_CHECK_GRID(launch_blocks, who);
+    hipStream_t s = as_stream(stream);
+    const SpmmRunDesc *rd = reinterpret_cast<const SpmmRunDesc *>(desc);
+    const int glog2 = spmm_group_log2(rowptr);
+    if (B_ghost)
+        spmm_runs_colmajor_kernel<I, true><<<(uint32_t)launch_blocks, TPB_MM, 0, s>>>(
+            rowptr, colval_split, nzval, B_own, ldb_own, B_ghost, ldb_ghost, n_own, C, ldc, nrows, index_base, rd, block_list,
+            (uint32_t)launch_blocks, glog2);
+    else
+        spmm_runs_colmajor_kernel<I, false><<<(uint32_t)launch_blocks, TPB_MM, 0, s>>>(
+            rowptr, colval_split, nzval, B_own, ldb_own, nullptr, 0, n_own, C, ldc, nrows, index_base, rd, block_list,
+            (uint32_t)launch_blocks, glog2);
+    HPCLA_CHECK_LAUNCH();
+    return HPCLA_OK;
+}
+
+HPCLA_API int hpcla_spmm_runs_colmajor_k16_f64_i32(const int32_t *rowptr, const int32_t *colval_split, const double *nzval,
+                                                   const double *B_own, int64_t ldb_own, const double *B_ghost,
+                                                   int64_t ldb_ghost, int64_t n_own, double *C, int64_t ldc, int64_t nrows,
+                                                   int64_t nnz, int index_base, const void *desc, const int32_t *block_list,
+                                                   int64_t n_blocks, void *stream)
+{
+    return spmm_runs_colmajor_launch<int32_t>(rowptr, colval_split, nzval, B_own, ldb_own, B_ghost, ldb_ghost, n_own, C, ldc,
+                                              nrows, nnz, index_base, desc, block_list, n_blocks, stream);
+}
+
+HPCLA_API int hpcla_spmm_runs_colmajor_k16_f64_i64(const int64_t *rowptr, const int64_t *colval_split, const double *nzval,
+                                                   const double *B_own, int64_t ldb_own, const double *B_ghost,
+                                                   int64_t ldb_ghost, int64_t n_own, double *C, int64_t ldc, int64_t nrows,
+                                                   int64_t nnz, int index_base, const void *desc, const int32_t *block_list,
+                                                   int64_t n_blocks, void *stream)
+{
+    return spmm_runs_colmajor_launch<int64_t>(rowptr, colval_split, nzval, B_own, ldb_own, B_ghost, ldb_ghost, n_own, C, ldc,
+                                              nrows, nnz, index_base, desc, block_list, n_blocks, stream);
+}
+
+// Plan-time block order of the column-major run tiles, BY MEASUREMENT (tune_order_measured): this kernel's best group depends
+// on the grid's width like the others' -- 5-point matrix x 16, 4096 x 2048 rows: natural 0.60-0.64 ms, groups of 8 blocks
+// 0.563; 2896 x 2896: natural 0.708, 8: 0.670, 128: 0.570 (profiles/r05_colmajor_run_tiles.log) -- and differs from the
+// gather kernel's, which hpcla_spmm_tune_block_order_* measures.  Same arguments as the product; C receives the product.
+template <typename I>
+static int spmm_runs_colmajor_tune(const I *rowptr, const I *colval_split, const double *nzval, const double *B_own,
+                                   int64_t ldb_own, const double *B_ghost, int64_t ldb_ghost, int64_t n_own, double *C, int64_t ldc,
+                                   int64_t nrows, int64_t nnz, int index_base, const void *desc, const int32_t *block_list,
+                                   int64_t n_blocks, void *stream, int *chosen_group)
+{
+    if (chosen_group) *chosen_group = 1;
+    if (!rowptr) return set_error(HPCLA_ERR_INVALID, "spmm_runs_colmajor_tune_block_order: null rowptr");
+    set_spmm_block_order(rowptr, 0);
+    auto launch = [&]() {
+        return spmm_runs_colmajor_launch<I>(rowptr, colval_split, nzval, B_own, ldb_own, B_ghost, ldb_ghost, n_own, C, ldc, nrows, nnz,
+                                            index_base, desc, block_list, n_blocks, stream);
+    };
+    const int64_t launch_blocks = block_list ? n_blocks : (nrows + RPB_MM - 1) / RPB_MM;
+    if (launch_blocks < 4096 || nnz <= 0) return launch();    // small launches live in the caches: natural order, arguments checked
+    const int cand[5] = {0, 3, 5, 7, 9};
+    return tune_order_measured(rowptr, cand, 5, stream, chosen_group, "spmm_runs_colmajor_tune_block_order", launch);
+}
+
+HPCLA_API int hpcla_spmm_runs_colmajor_tune_block_order_f64_i32(const int32_t *rowptr, const int32_t *colval_split,
+                                                                const double *nzval, const double *B_own, int64_t ldb_own,
+                                                                const double *B_ghost, int64_t ldb_ghost, int64_t n_own, double *C,
+                                                                int64_t ldc, int64_t nrows, int64_t nnz, int index_base,
+                                                                const void *desc, const int32_t *block_list, int64_t n_blocks,
+                                                                void *stream, int *chosen_group)
+{
+    return spmm_runs_colmajor_tune<int32_t>(rowptr, colval_split, nzval, B_own, ldb_own, B_ghost, ldb_ghost, n_own, C, ldc, nrows, nnz,
+                                            index_base, desc, block_list, n_blocks, stream, chosen_group);
+}
+
+HPCLA_API int hpcla_spmm_runs_colmajor_tune_block_order_f64_i64(const int64_t *rowptr, const int64_t *colval_split,
+                                                                const double *nzval, const double *B_own, int64_t ldb_own,
+                                                                const double *B_ghost, int64_t ldb_ghost, int64_t n_own, double *C,
+                                                                int64_t ldc, int64_t nrows, int64_t nnz, int index_base,
+                                                                const void *desc, const int32_t *block_list, int64_t n_blocks,
+                                                                void *stream, int *chosen_group)
+{
+    return spmm_runs_colmajor_tune<int64_t>(rowptr, colval_split, nzval, B_own, ldb_own, B_ghost, ldb_ghost, n_own, C, ldc, nrows, nnz,
+                                            index_base, desc, block_list, n_blocks, stream, chosen_group);
 }
 
 // One PANEL of a product in panel order (the opt-in order of the distributed SpMM): a CSR

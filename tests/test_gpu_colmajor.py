@@ -298,3 +298,149 @@ def test_spmm_ccol_full_size_unstructured_same_bits_as_rowmajor(hp):
                       Cc.data_ptr(), n, COL, n, nnz, k, 0, _stream())
         assert torch.equal(Cc.t(), Cr)
     hp._capi.call("hpcla_spmm_block_order_hint", rp.data_ptr(), 0)
+
+
+@pytest.mark.parametrize("Ti", [np.int32, np.int64])
+def test_spmm_run_tiles_on_colmajor_blocks(hp, orc, Ti):
+    """hpcla_spmm_runs_colmajor_k16_f64_* (round 5): the run tiles for a column-major caller -- own runs widened to even
+    rows and staged by the 16-byte LDS-DMA, lanes = rows, ghost entries read from the row-major ghost segment.  Bar: the
+    oracle's bits (= the reference's column loop, src/sparse.jl:2391-2413).  Cases: every column owned with even and odd row
+    counts (the odd one sends its last block down the per-entry path: a widened run would read past the column), padded
+    leading dimensions filled with NaN (a widened run READS one row of padding or a neighbour's row; nothing of it may reach
+    a sum), a rank's slab with the own / ghost cut inside a run (even and odd n_own), both index bases, permuted block lists,
+    structures whose blocks do not fit (7-point, unstructured, > 512 entries), and the alignment refusals."""
+    import ctypes
+    import torch
+    k = 16
+    s = _stream()
+    sfx = "i32" if Ti == np.int32 else "i64"
+    lib = hp._capi.load()
+
+    def run_case(rows, n_own, base, lists=True, pad_b=2):
+        n = rows.nrows
+        ci, cv = orc.compress_columns(rows)
+        ncomp = len(ci)
+        Bg = orc.fill_uniform(0, ncomp * k, 21).reshape(ncomp, k)
+        want = orc.spmm(rows.rowptr.astype(np.int32), cv.astype(np.int32), rows.vals, Bg)
+        rp, dcv, nz = _t((rows.rowptr + base).astype(Ti)), _t((cv + base).astype(Ti)), _t(rows.vals)
+        ldb = n_own + (n_own & 1) + pad_b                    # even, >= n_own
+        ldg, ldc = k + 2, n + 3
+        Bo = np.full((k, max(ldb, 2)), np.nan)
+        Bo[:, :n_own] = Bg[:n_own].T
+        dB_own = _t(Bo)
+        dB_gh = None
+        if n_own < ncomp:
+            G = np.full((ncomp - n_own, ldg), np.nan)
+            G[:, :k] = Bg[n_own:]
+            dB_gh = _t(G)
+        desc = torch.empty(lib.hpcla_spmm_runs_desc_bytes(n), dtype=torch.uint8, device="cuda")
+        n_fit = ctypes.c_int64(-1)
+        hp._capi.call(f"hpcla_spmm_runs_build_{sfx}", rp.data_ptr(), dcv.data_ptr(), n, rows.nnz, base, n_own, desc.data_ptr(),
+                      ctypes.byref(n_fit), s)
+        nblk = (n + 63) // 64
+        perm = np.random.default_rng(4).permutation(nblk).astype(np.int32)
+        for lst in ([None, _t(perm)] if lists else [None]):
+            C = torch.full((k, ldc), float("nan"), dtype=torch.float64, device="cuda")
+            hp._capi.call(f"hpcla_spmm_runs_colmajor_k16_f64_{sfx}", rp.data_ptr(), dcv.data_ptr(), nz.data_ptr(), dB_own.data_ptr(), Bo.shape[1],
+                          dB_gh.data_ptr() if dB_gh is not None else None, ldg, n_own, C.data_ptr(), ldc, n, rows.nnz, base,
+                          desc.data_ptr(), lst.data_ptr() if lst is not None else None, nblk if lst is not None else 0, s)
+            got = C.cpu().numpy()
+            np.testing.assert_array_equal(got[:, :n].T, want)
+            assert np.all(np.isnan(got[:, n:]))
+        return int(n_fit.value), nblk, (rp, dcv, nz, dB_own, desc)
+
+    # 5-point matrix, every column owned: even row count, then odd (200 x 37 = 7400; 201 x 37 = 7437), no padding at all
+    for nx, ny in ((200, 37), (201, 37)):
+        rows = orc.poisson2d_rows(nx, ny, 0, nx * ny)
+        fit, nblk, _ = run_case(rows, nx * ny, 0, pad_b=0)
+        assert fit == nblk
+        run_case(rows, nx * ny, 1, lists=False)
+    # a rank's slab: ghost lines above and below, the own / ghost cut INSIDE a run of consecutive columns; even and odd n_own
+    nx, ny = 200, 37
+    for lo, hi in ((5 * nx + 13, 21 * nx + 150), (5 * nx + 13, 21 * nx + 151)):
+        slab = orc.poisson2d_rows(nx, ny, lo, hi)
+        ci, _ = orc.compress_columns(slab)
+        for n_own in (int(np.searchsorted(ci, hi)), int(np.searchsorted(ci, hi)) - 1):
+            run_case(slab, n_own, 0)
+    # structures whose blocks do not fit: every block takes the per-entry path, still the right product
+    r3 = orc.poisson3d_rows(24, 24, 6, 0, 24 * 24 * 6)
+    fit, nblk, _ = run_case(r3, 24 * 24 * 6, 0, lists=False)
+    assert fit < nblk
+    run_case(orc.sprand_rows(3000, 0.004, 0, 700), 2000, 0, lists=False)
+    rng = np.random.default_rng(3)
+    lens = np.full(130, 3, dtype=np.int64)
+    lens[70] = 600
+    rpx = np.concatenate([[0], np.cumsum(lens)])
+    colsx = np.concatenate([np.sort(rng.choice(5000, size=l, replace=False)) for l in lens])
+    _, _, (rp, dcv, nz, dB, desc) = run_case(orc.LocalRows(rpx, colsx.astype(np.int64), rng.standard_normal(int(rpx[-1])), 5000), 700, 0,
+                                             lists=False)
+    # refusals: an odd leading dimension, a B_own off the 16-byte grid, a leading dimension below the row count
+    C = torch.empty((k, 130), dtype=torch.float64, device="cuda")
+    fn = f"hpcla_spmm_runs_colmajor_k16_f64_{sfx}"
+    with pytest.raises(hp._capi.HPCLAError, match="even leading dimension"):
+        hp._capi.call(fn, rp.data_ptr(), dcv.data_ptr(), nz.data_ptr(), dB.data_ptr(), 701, None, 0, 700, C.data_ptr(), 130, 130, int(rpx[-1]), 0,
+                      desc.data_ptr(), None, 0, s)
+    with pytest.raises(hp._capi.HPCLAError, match="16-byte aligned"):
+        hp._capi.call(fn, rp.data_ptr(), dcv.data_ptr(), nz.data_ptr(), dB.data_ptr() + 8, 702, None, 0, 700, C.data_ptr(), 130, 130, int(rpx[-1]), 0,
+                      desc.data_ptr(), None, 0, s)
+    with pytest.raises(hp._capi.HPCLAError, match="leading dimension smaller"):
+        hp._capi.call(fn, rp.data_ptr(), dcv.data_ptr(), nz.data_ptr(), dB.data_ptr(), 702, None, 0, 700, C.data_ptr(), 129, 130, int(rpx[-1]), 0,
+                      desc.data_ptr(), None, 0, s)
+    assert lib.hpcla_spmm_runs_colmajor_k16_f64_i32(None, None, None, None, 0, None, 0, 0, None, 5, 5, 5, 0, None, None, 0, None) != 0
+
+
+def test_spmm_run_tiles_colmajor_full_size_same_bits_as_direct(hp):
+    """Config 4 in small (5-point matrix 2048 x 1024 rows x 16): the column-major run tiles under a full
+    grid against the lanes = rows kernel (held to the oracle above and in tests/test_gpu_parity.py), element for element,
+    with the block-order hint off and on."""
+    import ctypes
+    import torch
+    nx, ny, k = 2048, 1024, 16
+    n = nx * ny
+    s = _stream()
+    lib = hp._capi.load()
+    nnz = lib.hpcla_poisson2d_nnz(nx, ny, 0, n)
+    rp64 = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    ci = torch.empty(nnz, dtype=torch.int64, device="cuda")
+    va = torch.empty(nnz, dtype=torch.float64, device="cuda")
+    hp._capi.call("hpcla_gen_poisson2d", nx, ny, 0, n, rp64.data_ptr(), ci.data_ptr(), va.data_ptr(), s)
+    rp, cv = rp64.to(torch.int32), ci.to(torch.int32)
+    B = torch.empty((k, n), dtype=torch.float64, device="cuda")
+    hp._capi.call("hpcla_fill_uniform_f64", B.data_ptr(), 0, n * k, 99, s)
+    desc = torch.empty(lib.hpcla_spmm_runs_desc_bytes(n), dtype=torch.uint8, device="cuda")
+    n_fit = ctypes.c_int64(-1)
+    hp._capi.call("hpcla_spmm_runs_build_i32", rp.data_ptr(), cv.data_ptr(), n, nnz, 0, n, desc.data_ptr(), ctypes.byref(n_fit), s)
+    assert n_fit.value == n // 64
+    C0 = torch.full((k, n), float("nan"), dtype=torch.float64, device="cuda")
+    hp._capi.call("hpcla_spmm_split_colmajor_f64_i32", rp.data_ptr(), cv.data_ptr(), va.data_ptr(), B.data_ptr(), n, None, k, n, C0.data_ptr(), n,
+                  n, nnz, k, 0, None, 0, s)
+    for group in (0, 32):
+        hp._capi.call("hpcla_spmm_block_order_hint", rp.data_ptr(), group)
+        C1 = torch.full((k, n), float("nan"), dtype=torch.float64, device="cuda")
+        hp._capi.call("hpcla_spmm_runs_colmajor_k16_f64_i32", rp.data_ptr(), cv.data_ptr(), va.data_ptr(), B.data_ptr(), n, None, 0, n,
+                      C1.data_ptr(), n, n, nnz, 0, desc.data_ptr(), None, 0, s)
+        assert torch.equal(C0, C1)
+    hp._capi.call("hpcla_spmm_block_order_hint", rp.data_ptr(), 0)
+    # the plan-time tuner: the same launch under five block orders; C holds the product afterwards, the chosen group stays
+    # set for this rowptr (a bijection of the row blocks whichever it is), and a following product runs under it
+    chosen = ctypes.c_int(-1)
+    C2 = torch.full((k, n), float("nan"), dtype=torch.float64, device="cuda")
+    hp._capi.call("hpcla_spmm_runs_colmajor_tune_block_order_f64_i32", rp.data_ptr(), cv.data_ptr(), va.data_ptr(), B.data_ptr(), n, None, 0, n,
+                  C2.data_ptr(), n, n, nnz, 0, desc.data_ptr(), None, 0, s, ctypes.byref(chosen))
+    assert chosen.value in (1, 8, 32, 128, 512), chosen.value
+    assert torch.equal(C0, C2)
+    C2.fill_(float("nan"))
+    hp._capi.call("hpcla_spmm_runs_colmajor_k16_f64_i32", rp.data_ptr(), cv.data_ptr(), va.data_ptr(), B.data_ptr(), n, None, 0, n,
+                  C2.data_ptr(), n, n, nnz, 0, desc.data_ptr(), None, 0, s)
+    assert torch.equal(C0, C2)
+    hp._capi.call("hpcla_spmm_block_order_hint", rp.data_ptr(), 0)
+    # a small launch (< 4096 blocks) is run once under the natural order; bad arguments are refused like the product's
+    few = torch.arange(100, dtype=torch.int32, device="cuda")
+    C2.fill_(float("nan"))
+    hp._capi.call("hpcla_spmm_runs_colmajor_tune_block_order_f64_i32", rp.data_ptr(), cv.data_ptr(), va.data_ptr(), B.data_ptr(), n, None, 0, n,
+                  C2.data_ptr(), n, n, nnz, 0, desc.data_ptr(), few.data_ptr(), 100, s, ctypes.byref(chosen))
+    assert chosen.value == 1
+    assert torch.equal(C0[:, :6400], C2[:, :6400]) and bool(torch.isnan(C2[:, 6400:]).all())
+    with pytest.raises(hp._capi.HPCLAError, match="even leading dimension"):
+        hp._capi.call("hpcla_spmm_runs_colmajor_tune_block_order_f64_i32", rp.data_ptr(), cv.data_ptr(), va.data_ptr(), B.data_ptr(), n + 1, None, 0,
+                      n, C2.data_ptr(), n, n, nnz, 0, desc.data_ptr(), None, 0, s, ctypes.byref(chosen))

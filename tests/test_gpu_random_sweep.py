@@ -1,7 +1,7 @@
 """Randomised sweep through the raw C ABI: ragged CSR shapes (empty matrices, empty rows, single rows, rows around the
 464-entry wave pass and the 2048-entry workgroup pass, duplicate-free ascending columns), both index types and bases, every
 kernel family -- Float64 SpMV (row-gather and quad), Float32 SpMV, SpMM in Float64 and Float32 on row-major and column-major
-blocks with ragged k, the row-major-B / column-major-C product and the opt-in long-row entry (its short rows) -- each bit for bit against the oracle's loops (src/sparse.jl:2055-2066, 2391-2413).  Fixed seeds: a
+blocks with ragged k, the row-major-B / column-major-C product, the run tiles on column-major blocks and the opt-in long-row entry (its short rows) -- each bit for bit against the oracle's loops (src/sparse.jl:2055-2066, 2391-2413).  Fixed seeds: a
 failure names its case.
 """
 import numpy as np
@@ -88,6 +88,30 @@ def test_random_shapes_every_kernel_family(hp, orc, seed):
             got = C.cpu().numpy().reshape(k, ldc)
             np.testing.assert_array_equal(got[:, :nrows].T, want, err_msg=f"seed {seed} spmm row-major B, column-major C, k={k}")
             assert np.all(np.isnan(got[:, nrows:])), f"seed {seed}: the column-major store wrote into the padding"
+            # round 5: the run tiles on COLUMN-major blocks (k = 16; most of these ragged blocks do not fit and take the per-entry
+            # path, a few do): own block column-major with an even leading dimension, ghost rows row-major, odd / even n_own
+            if nrows:
+                import ctypes
+                rng16 = np.random.default_rng(1000 + seed)
+                B16 = rng16.random((ncols, 16)) - 0.5
+                want16 = orc.spmm(rowptr.astype(Ti), colval.astype(Ti), v, B16)
+                n_own = int(rng16.integers(1, ncols + 1))
+                ldb16 = n_own + (n_own & 1) + 2 * (seed % 2)
+                Bo = np.full((16, ldb16), np.nan)
+                Bo[:, :n_own] = B16[:n_own].T
+                Bgh = np.full((max(ncols - n_own, 1), 18), np.nan)
+                Bgh[:ncols - n_own, :16] = B16[n_own:]
+                dBo, dBg = _t(Bo), _t(Bgh)
+                desc = torch.empty(capi.load().hpcla_spmm_runs_desc_bytes(nrows), dtype=torch.uint8, device="cuda")
+                n_fit = ctypes.c_int64(-1)
+                capi.call(f"hpcla_spmm_runs_build_{sfx}", rp.data_ptr(), cv.data_ptr(), nrows, nnz, base, n_own, desc.data_ptr(), ctypes.byref(n_fit), s)
+                ldc16 = nrows + seed % 3
+                C16 = torch.full((16, ldc16), float("nan"), dtype=tT, device="cuda")
+                capi.call(f"hpcla_spmm_runs_colmajor_k16_f64_{sfx}", rp.data_ptr(), cv.data_ptr(), nz.data_ptr(), dBo.data_ptr(), ldb16,
+                          dBg.data_ptr() if n_own < ncols else None, 18, n_own, C16.data_ptr(), ldc16, nrows, nnz, base, desc.data_ptr(), None, 0, s)
+                got = C16.cpu().numpy()
+                np.testing.assert_array_equal(got[:, :nrows].T, want16, err_msg=f"seed {seed} run tiles on column-major blocks (fit {n_fit.value})")
+                assert np.all(np.isnan(got[:, nrows:]))
             # round 5: the OPT-IN long-row entry -- rows of >= 928 entries in tree order (1e-12 |A||x|), every other row bit-exact
             if nrows:
                 lens = np.diff(rowptr)
