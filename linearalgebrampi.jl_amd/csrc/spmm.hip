@@ -26,7 +26,9 @@ namespace hpcla {
 
 constexpr int TPB_MM = 256;
 constexpr int RPB_MM = 64;                  // rows per workgroup (the granularity of the callers' block lists)
-constexpr int CHUNK_MM = 2048;              // entries staged per pass: 2048 * 12 B = 24 KiB
+constexpr int CHUNK_MM = 1984;              // entries staged per pass: 1984 * 16 B = 31 744 B of LDS = 5 workgroups per CU.  (2048 =
+                                            // 32 768 B looks like five, runs as four: the generic kernel took 1.088 ms on the 5-point
+                                            // matrix x 15 columns, 0.946 now; profiles/r05_lds_footprint.log)
 constexpr int KT = 16;                      // columns per tile (one per lane of a group)
 
 // The four rows of a lane-group advance TOGETHER, two entries each per step, so a lane has up to 8

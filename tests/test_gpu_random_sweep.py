@@ -1,5 +1,5 @@
 """Randomised sweep through the raw C ABI: ragged CSR shapes (empty matrices, empty rows, single rows, rows around the
-464-entry wave pass and the 2048-entry workgroup pass, duplicate-free ascending columns), both index types and bases, every
+464-entry wave pass and the 1984- / 2048-entry workgroup passes, duplicate-free ascending columns), both index types and bases, every
 kernel family -- Float64 SpMV (row-gather and quad), Float32 SpMV, SpMM in Float64 and Float32 on row-major and column-major
 blocks with ragged k, the row-major-B / column-major-C product, the run tiles on column-major blocks and the opt-in long-row entry (its short rows) -- each bit for bit against the oracle's loops (src/sparse.jl:2055-2066, 2391-2413).  Fixed seeds: a
 failure names its case.
@@ -28,7 +28,7 @@ def _case(seed):
     elif kind == 2:
         lens = rng.integers(0, min(ncols, 9) + 1, nrows)
         for r in rng.integers(0, max(nrows, 1), min(nrows, 3)):
-            lens[r] = min(ncols, int(rng.choice([463, 464, 465, 929, 2047, 2048, 2049])))
+            lens[r] = min(ncols, int(rng.choice([463, 464, 465, 929, 1983, 1984, 1985, 2047, 2048, 2049])))
     else:
         lens = np.full(nrows, min(ncols, 7))
     rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
