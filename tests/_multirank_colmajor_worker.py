@@ -3,7 +3,8 @@ The distributed A * B of a column-major caller (what integration/HPCLinearAlgebr
 through the raw C ABI on the host layer's plans: own block and result COLUMN-major, the exchange posted from the column-major
 block (hpcla_halo_begin_strided_*: the rows the plan sends are staged row-major), interior 256-row blocks while it is in
 flight, boundary blocks behind hpcla_halo_end with the plan's row-major ghost segment.  Float64 and Float32, Int32 and Int64
-kernel indices, k = 16 and 3, two different B back to back; bit-exact against the oracle's column loop."""
+kernel indices, k = 16 and 3, two different B back to back; at k = 16 in Float64 also through the run tiles on the column-major
+blocks (round 5); bit-exact against the oracle's column loop."""
 import ctypes
 import os
 import sys
@@ -84,6 +85,49 @@ def main():
                     want = orc.spmm(rows.rowptr.astype(Ti), cv.astype(Ti), rows.vals.astype(T), np.ascontiguousarray(Bg[ci]))
                     got = C.cpu().numpy()[:, :A.nrows_local].T
                     assert np.array_equal(got, want), f"{tag} {name} k={k}: column-major A*B differs"
+                if T == np.float64 and k == 16:              # (a rank-uniform condition: the exchange below is collective)
+                    # round 5: the same product through the RUN TILES on the column-major blocks (hpcla_spmm_runs_colmajor_k16_f64_*):
+                    # descriptors of the plan's split column space, block lists over ITS 64-row blocks, interior blocks while
+                    # the exchange is in flight (the first of them through the plan-time tuner), boundary blocks with the
+                    # ghost segment.  The random pattern's blocks do not fit the tile and take the per-entry path.
+                    rpb64 = capi.load().hpcla_spmm_rows_per_block()
+                    nb64 = (A.nrows_local + rpb64 - 1) // rpb64
+                    desc = torch.empty(capi.load().hpcla_spmm_runs_desc_bytes(A.nrows_local), dtype=torch.uint8, device="cuda")
+                    n_fit = ctypes.c_int64(-1)
+                    capi.call(f"hpcla_spmm_runs_build_{sfx}", dptr(rowptr), dptr(colval_split), A.nrows_local, A.nnz, 0, plan.n_own,
+                              dptr(desc), ctypes.byref(n_fit), s)
+                    if name == "poisson2d":
+                        assert n_fit.value == nb64, f"{tag}: {n_fit.value} of {nb64} blocks fit"
+                    flags64 = torch.zeros(max(nb64, 1), dtype=torch.int32, device="cuda")
+                    capi.call(f"hpcla_classify_blocks_{sfx}", dptr(rowptr), dptr(colval_split), A.nrows_local, 0, plan.n_own, rpb64,
+                              dptr(flags64), s)
+                    int64_ = torch.nonzero(flags64[:nb64] == 0).flatten().to(torch.int32).contiguous()
+                    bnd64 = torch.nonzero(flags64[:nb64] != 0).flatten().to(torch.int32).contiguous()
+                    fnr = f"hpcla_spmm_runs_colmajor_k16_f64_{sfx}"
+                    chosen = ctypes.c_int(-1)
+                    ldp = max(nloc + (nloc & 1), 2)              # an EVEN leading dimension: one row of NaN padding where nloc is odd
+                    for it, (Bg, (Bc0, _)) in enumerate(zip(Bgs, outs)):
+                        Bc = torch.full((k, ldp), float("nan"), dtype=tT, device="cuda")
+                        Bc[:, :nloc] = Bc0
+                        assert Bc.data_ptr() % 16 == 0
+                        C = torch.full((k, max(A.nrows_local, 1)), float("nan"), dtype=tT, device="cuda")
+                        capi.call("hpcla_halo_begin_strided_f64", halo, dptr(Bc), 1, ldp, dptr(stage), s)
+                        if int64_.numel() and it == 0:
+                            capi.call(f"hpcla_spmm_runs_colmajor_tune_block_order_f64_{sfx}", dptr(rowptr), dptr(colval_split), dptr(A.nzval),
+                                      dptr(Bc), ldp, None, k, plan.n_own, dptr(C), max(A.nrows_local, 1), A.nrows_local, A.nnz, 0, dptr(desc),
+                                      dptr(int64_), int(int64_.numel()), s, ctypes.byref(chosen))
+                        elif int64_.numel():
+                            capi.call(fnr, dptr(rowptr), dptr(colval_split), dptr(A.nzval), dptr(Bc), ldp, None, k, plan.n_own, dptr(C),
+                                      max(A.nrows_local, 1), A.nrows_local, A.nnz, 0, dptr(desc), dptr(int64_), int(int64_.numel()), s)
+                        capi.call("hpcla_halo_end", halo, s)
+                        if bnd64.numel():
+                            capi.call(fnr, dptr(rowptr), dptr(colval_split), dptr(A.nzval), dptr(Bc), ldp, ghost, k, plan.n_own, dptr(C),
+                                      max(A.nrows_local, 1), A.nrows_local, A.nnz, 0, dptr(desc), dptr(bnd64), int(bnd64.numel()), s)
+                        torch.cuda.synchronize()
+                        want = orc.spmm(rows.rowptr.astype(Ti), cv.astype(Ti), rows.vals.astype(T), np.ascontiguousarray(Bg[ci]))
+                        got = C.cpu().numpy()[:, :A.nrows_local].T
+                        assert np.array_equal(got, want), f"{tag} {name}: run tiles on column-major blocks differ (pass {it})"
+                    capi.call("hpcla_spmm_block_order_hint", dptr(rowptr), 0)
                 flag = ctypes.c_int(0)
                 capi.call("hpcla_halo_status", halo, ctypes.byref(flag))
                 assert flag.value == 0, f"{tag} {name}: an exchange timed out"
