@@ -85,6 +85,7 @@ def main():
                      ("product on column-major operands directly", prod_col)):
         ms = timed(fn, args.reps)
         print(f"{name:58s} {ms:8.4f} ms   {alg / ms / 1e6 / 8000:6.3f} of 8 TB/s by the product's algorithmic bytes", flush=True)
+    to_row()
     prod_row()
     to_col()
     ref = Cc.clone()
