@@ -362,6 +362,14 @@ def test_spmm_run_tiles_on_colmajor_blocks(hp, orc, Ti):
         ci, _ = orc.compress_columns(slab)
         for n_own in (int(np.searchsorted(ci, hi)), int(np.searchsorted(ci, hi)) - 1):
             run_case(slab, n_own, 0)
+    # four runs of 50 rows with ODD first rows: the descriptor fits (200 tile rows) but the widened runs need 208 -> that block takes
+    # the per-entry path; with 49-row runs (widened: 50 each = 200) it is staged.
+    for run_len in (50, 49):
+        rowsx = 70
+        colsx = np.concatenate([[1 + 100 * r + (i % run_len) for r in range(4)] for i in range(rowsx)] + [np.arange(400)]).astype(np.int64)
+        rpx = np.concatenate([np.arange(rowsx + 1) * 4, 4 * rowsx + 1 + np.arange(400)]).astype(np.int64)   # + 400 one-entry rows: every column is touched
+        fit, nblk, _ = run_case(orc.LocalRows(rpx, colsx, np.random.default_rng(run_len).standard_normal(len(colsx)), 400), 400, 0, lists=False)
+        assert fit == nblk == (rowsx + 400 + 63) // 64
     # structures whose blocks do not fit: every block takes the per-entry path, still the right product
     r3 = orc.poisson3d_rows(24, 24, 6, 0, 24 * 24 * 6)
     fit, nblk, _ = run_case(r3, 24 * 24 * 6, 0, lists=False)
