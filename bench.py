@@ -554,19 +554,17 @@ def strong_scaling_record(hp, wl, job, backend, args, world, rank, budget=None, 
     return rec, verified
 
 
-def spmv_kernel_name(hp):
-    """the CSR SpMV kernel the library's aligned launches take right now (hpcla_set_spmv_kernel / HPCLA_SPMV_KERNEL)"""
-    return "spmv_rowgather_kernel" if hp._capi.load().hpcla_get_spmv_kernel() == 0 else "spmv_rowblock_quad_kernel"
+def spmv_kernel_name(hp=None):
+    """the CSR SpMV kernel of the library's aligned launches (the row gather; the quad kernel of rounds 1-3 and its switch
+    were retired in round 6)"""
+    return "spmv_rowgather_kernel"
 
 
-def spmv_kernel_instance(hp, is_i64=False, split=False, wait=False):
-    """The launched instantiation as rocprofv3 prints it: <index type, SPLIT, WAIT> for the quad kernel,
-    <index type, SPLIT, WAIT, LONGR = false> for the row-gather kernel (round 5 added the opt-in long-row flag)."""
-    name = spmv_kernel_name(hp)
-    args = ["long" if is_i64 else "int", "true" if split else "false", "true" if wait else "false"]
-    if name == "spmv_rowgather_kernel":
-        args.append("false")
-    return "hpcla::%s<%s>" % (name, ", ".join(args))
+def spmv_kernel_instance(hp=None, is_i64=False, split=False, wait=False):
+    """The launched instantiation as rocprofv3 prints it: <index type, SPLIT, WAIT, LONGR = false> (round 5 added the
+    opt-in long-row flag)."""
+    args = ["long" if is_i64 else "int", "true" if split else "false", "true" if wait else "false", "false"]
+    return "hpcla::%s<%s>" % (spmv_kernel_name(), ", ".join(args))
 
 
 def f32_kernel_name(kc, index="int", split=False):

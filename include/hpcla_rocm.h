@@ -93,14 +93,12 @@ int hpcla_spmv_split_f64_i64(const int64_t *rowptr, const int64_t *colval_split,
                              int64_t n_own, double *y, int64_t nrows, int64_t nnz, int index_base,
                              const int32_t *block_list, int64_t n_blocks, void *stream);
 int hpcla_spmv_rows_per_block(void);
-/* Which CSR SpMV kernel the aligned launches take (every entry point above and below; no reference counterpart -- the
- * reference has one work-item per row, src/sparse.jl:2055-2066): 0 = "row gather" (round 4, the default: the block's A
- * entries are streamed into wave-private LDS unmultiplied and every lane walks its own row, so one gather instruction
- * reads ONE x stream for banded matrices -- the fix for the L1 tag-conflict stalls of the 7-point matrix,
- * profiles/r04_spmv_2d_vs_3d_counters.txt), 1 = "quad" (rounds 1-3: a lane owns four consecutive entries, products
- * parked in LDS).  Bit-identical results.  Also HPCLA_SPMV_KERNEL=rowgather|quad in the environment. */
-int hpcla_set_spmv_kernel(int kind);
-int hpcla_get_spmv_kernel(void);      /* 0 / 1: the kernel the next aligned launch takes */
+/* The CSR SpMV kernel of every aligned launch (every entry point above and below; no reference counterpart -- the
+ * reference has one work-item per row, src/sparse.jl:2055-2066) is the "row gather" (round 4): the block's A entries are
+ * streamed into wave-private LDS unmultiplied and every lane walks its own row, so one gather instruction reads ONE x
+ * stream for banded matrices (profiles/r04_spmv_2d_vs_3d_counters.txt).  The product-parking quad kernel of rounds 1-3 and
+ * its switch (hpcla_set_spmv_kernel / hpcla_get_spmv_kernel, HPCLA_SPMV_KERNEL) were retired in round 6: it lost on every
+ * measured matrix (profiles/r04_spmv_rowg.log).  Unaligned colval / nzval take a narrow fallback kernel, same bits. */
 /* OPT-IN long rows (round 5; NOT the default, NOT bit-identical to the reference).  The default kernels sum every row
  * sequentially in stored order on one lane -- the reference's bits (acc += nzval[j] * x[colval[j]], src/sparse.jl:2059-2064)
  * and the reference's cliff: its _spmv_kernel! is one work-item per row too, so an "arrow" matrix (one dense row of n
@@ -126,7 +124,7 @@ int hpcla_spmm_rows_per_block(void);
  * structure at plan time: the 5-point matrix loses with every group from 32 up, config 5's random pattern gains 2.6 %
  * at 64-256 (profiles/r03_spmm_xcd_group.log); the tuner times the plan's own launch (results go to the caller's C:
  * every launch writes the complete product) under natural / 16 / 64 / 256, keeps natural unless a group is >= 1 %
- * faster, and skips launches below 4096 row blocks, k < 2 and odd k.  B_ghost == NULL: the unsplit kernel. */
+ * faster, and skips launches below 4096 row blocks, k < 2 and odd k on odd pitches.  B_ghost == NULL: the unsplit kernel. */
 int hpcla_spmm_block_order_hint(const void *rowptr, int group);
 int hpcla_spmm_tune_block_order_f64_i32(const int32_t *rowptr, const int32_t *colval_split, const double *nzval,
                                         const double *B_own, int64_t ldb_own, const double *B_ghost, int64_t ldb_ghost,
@@ -259,7 +257,14 @@ int hpcla_spgemm_numeric_mapped_f64(const void *pair_ptr, int ptr_is_i64, const 
 /* ---- SpMM:  replaces A*B column loop (src/sparse.jl:2391-2413) -------------------------------
  * C[r,c] = sum_j nzval[j] * B[colval[j], c], c in [0,k): one pass over A for all k columns, each
  * (r,c) accumulated sequentially in stored order (bit-identical to k reference SpMVs).
- * B has ncols_compressed rows (or, split form, n_own rows in B_own and ghosts in B_ghost). */
+ * B has ncols_compressed rows (or, split form, n_own rows in B_own and ghosts in B_ghost).
+ * Fast (16-byte vector) path: row-major B with an EVEN pitch, C row-major on an even pitch or column-major, 16-byte
+ * aligned bases.  ODD k takes it too when every row-major pitch is even AND larger than k (ldb = ldc = k + 1 is what the
+ * converters of this boundary allocate): the kernel then reads the padding double B[i * ldb + k] of every row it gathers
+ * (never stores it), so B / B_ghost must span rows * ldb doubles -- a last row cut off behind its k-th column is not
+ * allowed there.  C's padding: with ldc == k + 1 <= 16 the block's C rows leave as whole lines and C[i * ldc + k] is set
+ * to 0.0 (a masked last sector per row cost 40 % of the product); any other ldc leaves the padding untouched.  Any other stride combination runs on the generic one-column-per-lane kernel (5-point matrix x 15
+ * columns: 0.946 ms on it against 0.475 for 16, profiles/r05_lds_footprint.log). */
 int hpcla_spmm_csr_f64_i32(const int32_t *rowptr, const int32_t *colval, const double *nzval,
                            const double *B, int64_t ldb, int b_layout, double *C, int64_t ldc,
                            int c_layout, int64_t nrows, int64_t nnz, int k, int index_base,
@@ -281,8 +286,9 @@ int hpcla_spmm_split_f64_i64(const int64_t *rowptr, const int64_t *colval_split,
 /* hpcla_spmm_split_f64_* with a COLUMN-major result (element (r, c) at C[r + c * ldc], ldc >= nrows; the reference's dense
  * block is a Julia Matrix, src/dense.jl:63) while B_own / B_ghost stay row-major rows: the product an UNSTRUCTURED matrix
  * gets from a column-major caller -- B converted once (hpcla_transpose_f64; an unstructured matrix gathers whole B rows, so
- * the row-major layout is the fast one), C written in the caller's layout by the product itself (even k <= 16: the block's
- * results leave through LDS as k runs of 64 doubles; other k: the strided kernel).  Same sums, same order, same bits.
+ * the row-major layout is the fast one), C written in the caller's layout by the product itself (the block's results leave
+ * through LDS as runs of 64 doubles per column, one launch per 16-column tile; odd k: B pitches even and > k, see above;
+ * other pitches: the strided kernel).  Same sums, same order, same bits.
  * hpcla_spmm_csr_f64_* with b_layout = HPCLA_LAYOUT_ROW, c_layout = HPCLA_LAYOUT_COL takes the same kernel. */
 int hpcla_spmm_split_ccol_f64_i32(const int32_t *rowptr, const int32_t *colval_split,
                                   const double *nzval, const double *B_own, int64_t ldb_own,

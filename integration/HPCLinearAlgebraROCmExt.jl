@@ -40,6 +40,16 @@ end
 _stream() = Ptr{Cvoid}(UInt(AMDGPU.stream().stream))          # task-local HIP stream
 _ptr(a::ROCArray) = Ptr{Cvoid}(UInt(pointer(a)))
 _ptr(::Nothing) = C_NULL
+_len(a) = a === nothing ? 0 : length(a)
+
+# partition -> its Blake3 hash (compute_partition_hash, src/HPCLinearAlgebra.jl:255-259), kept by CONTENT: the per-call plan
+# lookups of A * B (the key of src/sparse.jl:1992-2001 wants hash(B.row_partition)) and of dense A * x do not hash again
+const _partition_hashes = Dict{Vector{Int},Any}()
+function _partition_hash(p::Vector{Int})
+    h = get(_partition_hashes, p, nothing)
+    h === nothing && (h = _partition_hashes[copy(p)] = compute_partition_hash(p))
+    return h
+end
 
 # ---- backend factories (cf. ext/HPCLinearAlgebraCUDAExt.jl:98-121) ---------------------------------
 function HPCLinearAlgebra.backend_rocm_serial(::Type{T}=Float64, ::Type{Ti}=Int) where {T,Ti<:Integer}
@@ -142,6 +152,77 @@ function _attach_halo_window(h::Ptr{Cvoid}, halo::Ptr{Cvoid}, mpicomm::MPI.Comm,
     return mine
 end
 
+# ---- VectorPlan(A, x) for DeviceROCm: the reference's lists, built without its per-column work ------------------------------
+# The parent's constructor (src/sparse.jl:1875-1984) walks A.col_indices once per COLUMN -- one searchsortedlast and one push! of
+# a (global, position) tuple each (8.4 M per rank at config 3), then comprehensions over those tuples -- and allocates `gathered`
+# (device) plus `gathered_cpu` (host), ncols_compressed values each (64 MiB + 64 MiB per plan at config 3), which the device
+# A * x never reads.  col_indices is sorted and owners are contiguous rank ranges, so every owner's columns are ONE contiguous run
+# of it: nranks - 1 binary searches find the runs (the twin of sparse.py build_host_vector_plan, whose lists are held equal to the
+# oracle's restatement of the parent's constructor at world 2 / 3 / 8).  Same fields, same values, the SAME collectives in the same
+# order (Alltoall of the counts, tag-20 index exchange), so ranks may even mix this method with the parent's.  For Float64 -- where
+# execute_plan! and mul! are this file's and never touch them -- `gathered` starts empty (execute_plan! below sizes it on first
+# use by another caller) and `gathered_cpu` stays empty; other element types keep the parent's buffers (its execute_plan! runs).
+function HPCLinearAlgebra.VectorPlan(A::HPCSparseMatrix{T,Ti,B}, x::HPCVector{T,B}) where {T,Ti,B<:ROCBackend}
+    assert_backends_compatible(A.backend, x.backend)
+    comm = A.backend.comm
+    rank = comm_rank(comm); nranks = comm_size(comm)
+    col_indices = A.col_indices
+    n_gathered = length(col_indices)
+    my_x_start = x.partition[rank+1]
+    # step 1 (:1888-1896): owner(g) = min(searchsortedlast(x.partition, g) - 1, nranks - 1), so owner r holds the columns in
+    # [partition[r+1], partition[r+2]) (the last owner: everything from its start on): bounds[r+1]+1 : bounds[r+2] in col_indices
+    bounds = Vector{Int}(undef, nranks + 1)
+    bounds[1] = 0; bounds[nranks+1] = n_gathered
+    for r in 1:(nranks-1); bounds[r+1] = searchsortedfirst(col_indices, x.partition[r+1]) - 1; end
+    # step 2 (:1899-1900)
+    send_counts = [bounds[r+2] - bounds[r+1] for r in 0:(nranks-1)]
+    recv_counts = HPCLinearAlgebra.comm_alltoall(comm, MPI.UBuffer(send_counts, 1))
+    # step 3 (:1908-1921): ask every owner for my columns in its slice
+    recv_rank_ids = Int[]; recv_perm = Vector{Ti}[]
+    struct_send_bufs = Vector{Int}[]; struct_send_reqs = []
+    for r in 0:(nranks-1)
+        if send_counts[r+1] > 0 && r != rank
+            push!(recv_rank_ids, r)
+            push!(recv_perm, collect(Ti, (bounds[r+1]+1):bounds[r+2]))               # positions in `gathered`, 1-based
+            push!(struct_send_bufs, col_indices[(bounds[r+1]+1):bounds[r+2]])
+            push!(struct_send_reqs, HPCLinearAlgebra.comm_isend(comm, struct_send_bufs[end], r, 20))
+        end
+    end
+    # step 4 (:1923-1936)
+    send_rank_ids = Int[]; struct_recv_bufs = Vector{Int}[]; struct_recv_reqs = []
+    for r in 0:(nranks-1)
+        if recv_counts[r+1] > 0 && r != rank
+            push!(send_rank_ids, r)
+            push!(struct_recv_bufs, Vector{Int}(undef, recv_counts[r+1]))
+            push!(struct_recv_reqs, HPCLinearAlgebra.comm_irecv!(comm, struct_recv_bufs[end], r, 20))
+        end
+    end
+    HPCLinearAlgebra.comm_waitall(comm, struct_recv_reqs)
+    HPCLinearAlgebra.comm_waitall(comm, struct_send_reqs)
+    # step 5 (:1939-1944): global -> local indices of what I send
+    send_indices = Vector{Ti}[Ti.(buf .- (my_x_start - 1)) for buf in struct_recv_bufs]
+    # step 6 (:1947-1953): the columns I own myself
+    lo, hi = bounds[rank+1] + 1, bounds[rank+2]
+    local_src_indices = Ti.(col_indices[lo:hi] .- (my_x_start - 1))
+    local_dst_indices = collect(Ti, lo:hi)
+    # step 7 (:1956-1984; both rank lists are ascending by construction)
+    send_bufs = [Vector{T}(undef, length(inds)) for inds in send_indices]
+    recv_bufs = [Vector{T}(undef, send_counts[r+1]) for r in recv_rank_ids]
+    send_reqs = Vector{Any}(undef, length(send_rank_ids))
+    recv_reqs = Vector{Any}(undef, length(recv_rank_ids))
+    lazy = T === Float64
+    gathered_cpu = Vector{T}(undef, lazy ? 0 : n_gathered)
+    gathered = similar(x.v, lazy ? 0 : n_gathered)
+    AV = typeof(x.v)
+    return VectorPlan{T,Ti,AV}(
+        send_rank_ids, send_indices, send_bufs, send_reqs,
+        recv_rank_ids, recv_bufs, recv_reqs, recv_perm,
+        local_src_indices, local_dst_indices, gathered, gathered_cpu,
+        nothing, nothing,
+        nothing, nothing,
+        nothing, nothing)
+end
+
 # ---- device half of the VectorPlan, cached next to the reference plan -----------------------------------
 # Tk = index type of the KERNEL arrays of the plan.  The parent's default is Ti = Int (src/backends.jl:348,369), so a
 # caller who follows the defaults hands over Int64 structure arrays although every realistic per-GPU share fits Int32.
@@ -169,9 +250,13 @@ _can_narrow(nnz, nrows, n_own, n_ghost) =
 _kernel_index_type(::Type{Int32}, nnz, nrows, n_own, n_ghost) = Int32
 _kernel_index_type(::Type{Int64}, nnz, nrows, n_own, n_ghost) = _can_narrow(nnz, nrows, n_own, n_ghost) ? Int32 : Int64
 
-function _device_plan(A::HPCSparseMatrix{T,Ti,B}, x::HPCVector{T,B}, plan) where {T,Ti,B<:ROCBackend}
+_device_plan(A::HPCSparseMatrix{T,Ti,B}, x::HPCVector{T,B}, plan) where {T,Ti,B<:ROCBackend} =
+    _device_plan(A, x.partition, length(x.v), _ptr(x.v), plan)
+# `xpart`, `n_own`: the partition of the operand and this rank's share of it; `xptr`: n_own readable values of the operand's
+# type on the device (the block-order measurement multiplies by them and discards the products) or C_NULL -- A * B hands
+# over B's row partition and its first column, so no vector is allocated to describe an operand (round 6)
+function _device_plan(A::HPCSparseMatrix{T,Ti,B}, xpart::Vector{Int}, n_own::Int, xptr::Ptr{Cvoid}, plan) where {T,Ti,B<:ROCBackend}
     get!(_rocm_plans, plan) do
-        n_own = length(x.v)
         nnz = length(A.nzval)
         n_ghost = sum(length, plan.recv_perm; init=0)
         Tk = _kernel_index_type(Ti, nnz, A.nrows_local, n_own, n_ghost)
@@ -183,18 +268,7 @@ function _device_plan(A::HPCSparseMatrix{T,Ti,B}, x::HPCVector{T,B}, plan) where
         for perm in plan.recv_perm
             cmap[perm] .= Tk.(off .+ (0:length(perm)-1)); off += length(perm)
         end
-        cmap_d = ROCVector(cmap)
-        split = ROCVector{Tk}(undef, nnz)
-        if Ti === Int32
-            _check(@ccall(LIB.hpcla_remap_i32(_ptr(A.colval_target)::Ptr{Cvoid}, _ptr(cmap_d)::Ptr{Cvoid},
-                   _ptr(split)::Ptr{Cvoid}, nnz::Int64, 1::Cint, _stream()::Ptr{Cvoid})::Cint), "hpcla_remap_i32")
-        elseif Tk === Int64
-            _check(@ccall(LIB.hpcla_remap_i64(_ptr(A.colval_target)::Ptr{Cvoid}, _ptr(cmap_d)::Ptr{Cvoid},
-                   _ptr(split)::Ptr{Cvoid}, nnz::Int64, 1::Cint, _stream()::Ptr{Cvoid})::Cint), "hpcla_remap_i64")
-        else        # Int64 matrix, narrowed plan: Int64 compressed columns in, Int32 split columns out
-            _check(@ccall(LIB.hpcla_remap_i64_to_i32(_ptr(A.colval_target)::Ptr{Cvoid}, _ptr(cmap_d)::Ptr{Cvoid},
-                   _ptr(split)::Ptr{Cvoid}, nnz::Int64, 1::Cint, _stream()::Ptr{Cvoid})::Cint), "hpcla_remap_i64_to_i32")
-        end
+        split = _split_colval(A, cmap)
         # The split-column copy is 0-based while A.rowptr_target keeps the reference's 1-based values; the SpMV entry
         # points apply ONE index_base to rowptr and colval alike, so the plan keeps a 0-based rowptr copy (in Tk) and
         # every kernel over the plan is called with index_base = 0.
@@ -209,7 +283,7 @@ function _device_plan(A::HPCSparseMatrix{T,Ti,B}, x::HPCVector{T,B}, plan) where
             narrow
         end
         halo = Ref{Ptr{Cvoid}}(C_NULL)
-        segments = [Int.(A.col_indices[perm] .- x.partition[r + 1])       # 0-based row in its owner (rank r, 0-based)
+        segments = [Int.(A.col_indices[perm] .- xpart[r + 1])             # 0-based row in its owner (rank r, 0-based)
                     for (r, perm) in zip(plan.recv_rank_ids, plan.recv_perm)]
         interior = ROCVector{Int32}(undef, 0); boundary = ROCVector{Int32}(undef, 0)
         if !isempty(plan.send_rank_ids) || !isempty(plan.recv_rank_ids)
@@ -223,22 +297,10 @@ function _device_plan(A::HPCSparseMatrix{T,Ti,B}, x::HPCVector{T,B}, plan) where
                    (Tk === Int64 ? 1 : 0)::Cint, length(plan.recv_rank_ids)::Cint,
                    Int32.(plan.recv_rank_ids)::Ptr{Int32}, Int64.(length.(plan.recv_perm))::Ptr{Int64},
                    1::Cint, (T === Float32 ? 1 : 0)::Cint)::Cint), "hpcla_halo_plan_create_ex")
-            rpb = @ccall LIB.hpcla_spmv_rows_per_block()::Cint
-            flags = AMDGPU.zeros(Int32, cld(A.nrows_local, rpb))
             # `split` is 0-based (hpcla_remap output) while A.rowptr_target is 1-based: the classifier applies
             # ONE index_base to both arrays, so it gets the 0-based rowptr copy and index_base = 0 -- with
             # base 1 the first ghost column (== n_own) would count as owned and its row block as interior
-            if Tk === Int32
-                _check(@ccall(LIB.hpcla_classify_blocks_i32(_ptr(rp0)::Ptr{Cvoid}, _ptr(split)::Ptr{Cvoid},
-                       A.nrows_local::Int64, 0::Cint, n_own::Int64, rpb::Cint, _ptr(flags)::Ptr{Cvoid},
-                       _stream()::Ptr{Cvoid})::Cint), "hpcla_classify_blocks_i32")
-            else
-                _check(@ccall(LIB.hpcla_classify_blocks_i64(_ptr(rp0)::Ptr{Cvoid}, _ptr(split)::Ptr{Cvoid},
-                       A.nrows_local::Int64, 0::Cint, n_own::Int64, rpb::Cint, _ptr(flags)::Ptr{Cvoid},
-                       _stream()::Ptr{Cvoid})::Cint), "hpcla_classify_blocks_i64")
-            end
-            f = Array(flags)
-            interior = ROCVector(Int32.(findall(==(0), f) .- 1)); boundary = ROCVector(Int32.(findall(!=(0), f) .- 1))
+            interior, boundary = _classify_blocks(A, rp0, split, n_own, (@ccall LIB.hpcla_spmv_rows_per_block()::Cint))
         end
         # collective: map the neighbours' ghost windows (push transport); a no-op without attached windows
         A.backend.comm isa CommMPI &&
@@ -248,7 +310,7 @@ function _device_plan(A::HPCSparseMatrix{T,Ti,B}, x::HPCVector{T,B}, plan) where
         # the split-column SpMV into a scratch vector; the library keeps the fastest order registered for the rowptr
         # array the launches use -- the plan's 0-based copy).  No reference counterpart: a performance setting only,
         # every order gives the same bits.
-        if T === Float64 && A.nrows_local > 0 && nnz > 0
+        if T === Float64 && A.nrows_local > 0 && nnz > 0 && xptr != C_NULL
             scratch = similar(A.nzval, A.nrows_local)
             gh = Ref{Ptr{Cvoid}}(C_NULL); ngh = Ref{Int64}(0)
             halo[] != C_NULL &&
@@ -256,12 +318,12 @@ function _device_plan(A::HPCSparseMatrix{T,Ti,B}, x::HPCVector{T,B}, plan) where
             chosen = Ref{Cint}(1)
             if Tk === Int32
                 _check(@ccall(LIB.hpcla_spmv_tune_block_order_f64_i32(_ptr(rp0)::Ptr{Cvoid}, _ptr(split)::Ptr{Cvoid},
-                       _ptr(A.nzval)::Ptr{Cvoid}, _ptr(x.v)::Ptr{Cvoid}, gh[]::Ptr{Cvoid}, n_own::Int64, _ptr(scratch)::Ptr{Cvoid},
+                       _ptr(A.nzval)::Ptr{Cvoid}, xptr::Ptr{Cvoid}, gh[]::Ptr{Cvoid}, n_own::Int64, _ptr(scratch)::Ptr{Cvoid},
                        A.nrows_local::Int64, nnz::Int64, 0::Cint, _stream()::Ptr{Cvoid}, chosen::Ptr{Cint})::Cint),
                        "hpcla_spmv_tune_block_order_f64_i32")
             else
                 _check(@ccall(LIB.hpcla_spmv_tune_block_order_f64_i64(_ptr(rp0)::Ptr{Cvoid}, _ptr(split)::Ptr{Cvoid},
-                       _ptr(A.nzval)::Ptr{Cvoid}, _ptr(x.v)::Ptr{Cvoid}, gh[]::Ptr{Cvoid}, n_own::Int64, _ptr(scratch)::Ptr{Cvoid},
+                       _ptr(A.nzval)::Ptr{Cvoid}, xptr::Ptr{Cvoid}, gh[]::Ptr{Cvoid}, n_own::Int64, _ptr(scratch)::Ptr{Cvoid},
                        A.nrows_local::Int64, nnz::Int64, 0::Cint, _stream()::Ptr{Cvoid}, chosen::Ptr{Cint})::Cint),
                        "hpcla_spmv_tune_block_order_f64_i64")
             end
@@ -316,7 +378,7 @@ function _scratch()
     return _work[]
 end
 function LinearAlgebra.dot(x::HPCVector{T,B}, y::HPCVector{T,B}) where {T<:Float64,B<:ROCBackend}
-    x.structural_hash == y.structural_hash || (y = HPCLinearAlgebra.repartition(y, x.partition))
+    x.structural_hash == y.structural_hash || (y = HPCLinearAlgebra.repartition(y, x.partition))   # PCIe: none -- lands in this file's execute_plan!(::VectorRepartitionPlan): GPU to GPU
     work, out = _scratch()
     _check(@ccall(LIB.hpcla_dot_f64(_rccl(x.backend.comm)::Ptr{Cvoid}, _ptr(x.v)::Ptr{Cvoid}, _ptr(y.v)::Ptr{Cvoid},
            length(x.v)::Int64, _ptr(out)::Ptr{Cvoid}, _ptr(work)::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_dot_f64")
@@ -337,11 +399,43 @@ function LinearAlgebra.norm(v::HPCVector{T,B}, p::Real=2) where {T<:Float64,B<:R
                _ptr(work)::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_amax_f64")
         return _host_scalar(out, v.backend)
     else
-        p > 0 || return invoke(LinearAlgebra.norm, Tuple{HPCVector,Real}, v, p)     # generic path of the parent
+        p > 0 || return invoke(LinearAlgebra.norm, Tuple{HPCVector,Real}, v, p)     # PCIe: parent's generic method (p <= 0 only) -- whatever the array package's norm moves
         _check(@ccall(LIB.hpcla_powsum_f64(c::Ptr{Cvoid}, _ptr(v.v)::Ptr{Cvoid}, n::Int64, Float64(p)::Cdouble,
                _ptr(out)::Ptr{Cvoid}, _ptr(work)::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_powsum_f64")
         return _host_scalar(out, v.backend)^(1 / p)
     end
+end
+
+# ---- u + v, u - v, -v, a * v, v * a, v / a  (replace src/vectors.jl:868-903, 944-964 for Float64 vectors on DeviceROCm) -------
+# The parent's methods broadcast over `.v` (AMDGPU.jl's generic broadcast kernel); these bind the row's own kernels (csrc/vecops.hip:
+# 16-byte loads, grid sized for the chip) with the parent's semantics -- the result has u's partition and hash, a vector on another
+# partition is repartitioned first (the device exchange of execute_plan!(::VectorRepartitionPlan) below).  Same bits: 1 * u[i] and
+# -1 * v[i] are exact, so axpby(1, u, +-1, v) rounds once, like u[i] +- v[i].  General broadcast (`u .+ a .* v`) stays AMDGPU.jl's.
+const _HostReal = Union{Float64,Float32,Float16,Bool,Int8,Int16,Int32,Int64,UInt8,UInt16,UInt32,UInt64}    # promote_type(., Float64) == Float64
+function _axpby(a::Float64, u::HPCVector{T,B}, b::Float64, v::HPCVector{T,B}) where {T<:Float64,B<:ROCBackend}
+    assert_backends_compatible(u.backend, v.backend)
+    u.structural_hash == v.structural_hash || (v = HPCLinearAlgebra.repartition(v, u.partition))   # PCIe: none -- lands in this file's execute_plan!(::VectorRepartitionPlan): GPU to GPU
+    out = similar(u.v)
+    _check(@ccall(LIB.hpcla_axpby_f64(a::Cdouble, _ptr(u.v)::Ptr{Cvoid}, b::Cdouble, _ptr(v.v)::Ptr{Cvoid}, _ptr(out)::Ptr{Cvoid},
+           length(out)::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_axpby_f64")
+    return HPCVector{T,B}(u.structural_hash, u.partition, out, u.backend)
+end
+Base.:+(u::HPCVector{T,B}, v::HPCVector{T,B}) where {T<:Float64,B<:ROCBackend} = _axpby(1.0, u, 1.0, v)
+Base.:-(u::HPCVector{T,B}, v::HPCVector{T,B}) where {T<:Float64,B<:ROCBackend} = _axpby(1.0, u, -1.0, v)
+function _scaled(a::Float64, v::HPCVector{T,B}) where {T<:Float64,B<:ROCBackend}
+    out = similar(v.v)
+    _check(@ccall(LIB.hpcla_scale_f64(a::Cdouble, _ptr(v.v)::Ptr{Cvoid}, _ptr(out)::Ptr{Cvoid}, length(out)::Int64,
+           _stream()::Ptr{Cvoid})::Cint), "hpcla_scale_f64")
+    return HPCVector{T,B}(v.structural_hash, v.partition, out, v.backend)
+end
+Base.:-(v::HPCVector{T,B}) where {T<:Float64,B<:ROCBackend} = _scaled(-1.0, v)
+Base.:*(a::_HostReal, v::HPCVector{T,B}) where {T<:Float64,B<:ROCBackend} = _scaled(Float64(a), v)
+Base.:*(v::HPCVector{T,B}, a::_HostReal) where {T<:Float64,B<:ROCBackend} = _scaled(Float64(a), v)
+function Base.:/(v::HPCVector{T,B}, a::_HostReal) where {T<:Float64,B<:ROCBackend}
+    out = similar(v.v)                                   # a true division per element, like `v.v ./ a` (not a reciprocal multiply)
+    _check(@ccall(LIB.hpcla_divide_f64(_ptr(v.v)::Ptr{Cvoid}, Float64(a)::Cdouble, _ptr(out)::Ptr{Cvoid}, length(out)::Int64,
+           _stream()::Ptr{Cvoid})::Cint), "hpcla_divide_f64")
+    return HPCVector{T,B}(v.structural_hash, v.partition, out, v.backend)
 end
 
 # A NaN that reaches the host may be the POISON of an expired exchange wait (the kernels never compute from stale
@@ -361,7 +455,8 @@ function _check_exchange_health(backend)
         flag[] == 0 || error("HPCLinearAlgebraROCmExt: a halo exchange timed out; the affected results are NaN")
     end
     # the width-k plans of A * B and the device exchanges of execute_plan! poison their ghost buffers the same way
-    for (what, cache) in (("an SpMM ghost-row exchange", _spmm_plans), ("an execute_plan! exchange", _rocm_exec))
+    for (what, cache) in (("an SpMM ghost-row exchange", _spmm_plans), ("an execute_plan! exchange", _rocm_exec),
+                          ("the value exchange of a sparse A * B", _rocm_matexec))
         for st in values(cache)
             st[1] == C_NULL && continue
             _check(@ccall(LIB.hpcla_halo_status(st[1]::Ptr{Cvoid}, flag::Ptr{Cint})::Cint), "hpcla_halo_status")
@@ -370,7 +465,11 @@ function _check_exchange_health(backend)
     end
     return nothing
 end
-_host_scalar(out, backend) = (v = Array(out)[1]; isnan(v) && _check_exchange_health(backend); v)
+function _host_scalar(out, backend)
+    v = Array(out)[1]                           # PCIe: 8 B -- the scalar result itself (the reference returns a host number)
+    isnan(v) && _check_exchange_health(backend)
+    return v
+end
 
 # ---- k fused CG iterations in ONE library call (the reference has no Krylov solver, SURVEY 3.4: a caller composes
 # the iteration from A*p src/sparse.jl:2096-2128, dot src/vectors.jl:798-812, the broadcasts :1203-1226 and norm
@@ -405,7 +504,7 @@ function rocm_cg_iterations(A::HPCSparseMatrix{T,Ti,B}, b::HPCVector{T,B}, iters
                _ptr(hist)::Ptr{Cvoid}, _ptr(pAp)::Ptr{Cvoid}, _ptr(dot_work)::Ptr{Cvoid}, _ptr(work)::Ptr{Cvoid},
                Cint(iters)::Cint, _stream()::Ptr{Cvoid})::Cint), "hpcla_cg_iterations_f64_i64")
     end
-    h = sqrt.(Array(hist))
+    h = sqrt.(Array(hist))                      # PCIe: 8 (iters + 1) B -- the residual history this function returns
     any(isnan, h) && _check_exchange_health(A.backend)
     return HPCVector{T,B}(b.structural_hash, b.partition, x, A.backend), h
 end
@@ -434,48 +533,144 @@ Base.minimum(v::HPCVector{T,B}) where {T<:Float64,B<:ROCBackend} = -_reduce_scal
 # Julia's Matrix is column-major.  BANDED structures (every stencil) are multiplied on the column-major blocks as they are
 # (_spmm_colmajor below: lanes = rows, a wave reads one contiguous run of a column per gather instruction).  Unstructured
 # matrices would touch a line per (entry, column) pair in that layout; for them the fast layout is row-major (one 128-byte
-# line per B row at k = 16), so B is converted once with hpcla_transpose_f64 and C converted back.
-const _spmm_plans = IdDict{Any,Any}()     # (reference plan, k, rows per block) -> (halo handle, interior, boundary, send_idx, ghost pointer); freed by clear_rocm_plan_cache!
+# line per B row at k = 16), so B is converted once with hpcla_transpose_f64; C leaves the product column-major.
+const _spmm_plans = IdDict{Any,Any}()     # (reference plan, width, rows per block) -> (halo handle, interior, boundary, send_idx, ghost pointer, colval_split, rowptr0); freed by clear_rocm_plan_cache!
 
-# width-k halo plan for the ghost ROWS of B: the reference VectorPlan's own lists, `width = k` values per index
-# (row-major rows travel as contiguous k-doubles).  The Python twin additionally swaps a neighbour's requested
-# rows for its WHOLE slice when more than half of it is needed (config 5; linearalgebrampi.jl_amd/sparse.py
-# whole_slice_lists) -- an optimisation of the lists, not of this binding.
+# The result of A * B as the parent's HPCMatrix_local would describe it (src/dense.jl:125-156): A's row partition (its Allgather of
+# the local row counts returns exactly diff(A.row_partition)), the default column partition, lazy hash -- WITHOUT its
+# `Matrix(A_local)` (src/dense.jl:153): for a ROCMatrix that is a device -> host copy of the whole product, followed by the
+# host -> device copy of _convert_array, around a product that never left the device (268 MB each way at config 5's share).
+# A * x returns through the inner constructor for the same reason (src/sparse.jl:2122-2127).
+_spmm_result(A::HPCSparseMatrix{T,Ti,B}, C::ROCMatrix{T}, k::Int) where {T,Ti,B} =
+    HPCMatrix{T,B}(nothing, copy(A.row_partition), HPCLinearAlgebra.uniform_partition(k, comm_size(A.backend.comm)), C, A.backend)
+
+# The vector plan for (A, B's row partition) provides the neighbour lists and the split column space.  Its lookup key
+# (src/sparse.jl:1992-2001) reads the partition hash and typeof(x.v) only: the probe carries a ZERO-length vector, the device
+# half takes its sizes from B itself (round 6: was a full-length device allocation per product, only to key the lookup).
+function _spmm_vector_plan(A::HPCSparseMatrix{T,Ti,B}, M::HPCMatrix{T,B}) where {T,Ti,B<:ROCBackend}
+    nloc, k = size(M.A)
+    probe = HPCVector{T,B}(_partition_hash(M.row_partition), M.row_partition, similar(A.nzval, 0), A.backend)   # plan key only
+    plan = get_vector_plan(A, probe)
+    # (B's first column is nloc contiguous values: what the plan's block-order measurement reads)
+    d = _device_plan(A, M.row_partition, nloc, (k > 0 && nloc > 0) ? _ptr(M.A) : C_NULL, plan)
+    d.n_own == nloc || error("A * B: B's local rows do not match its row partition")
+    return plan, d
+end
+
+# split-column copy of A's colval through the compressed-column map `cmap` (0-based values in the kernels' index type Tk):
+# hpcla_remap_* in A's index type, or narrowing on the fly
+function _split_colval(A::HPCSparseMatrix{T,Ti,B}, cmap::Vector{Tk}) where {T,Ti,Tk,B}
+    nnz = length(A.nzval)
+    cmap_d = ROCVector(cmap)
+    split = ROCVector{Tk}(undef, nnz)
+    if Ti === Int32
+        _check(@ccall(LIB.hpcla_remap_i32(_ptr(A.colval_target)::Ptr{Cvoid}, _ptr(cmap_d)::Ptr{Cvoid},
+               _ptr(split)::Ptr{Cvoid}, nnz::Int64, 1::Cint, _stream()::Ptr{Cvoid})::Cint), "hpcla_remap_i32")
+    elseif Tk === Int64
+        _check(@ccall(LIB.hpcla_remap_i64(_ptr(A.colval_target)::Ptr{Cvoid}, _ptr(cmap_d)::Ptr{Cvoid},
+               _ptr(split)::Ptr{Cvoid}, nnz::Int64, 1::Cint, _stream()::Ptr{Cvoid})::Cint), "hpcla_remap_i64")
+    else        # Int64 matrix, narrowed arrays: Int64 compressed columns in, Int32 split columns out
+        _check(@ccall(LIB.hpcla_remap_i64_to_i32(_ptr(A.colval_target)::Ptr{Cvoid}, _ptr(cmap_d)::Ptr{Cvoid},
+               _ptr(split)::Ptr{Cvoid}, nnz::Int64, 1::Cint, _stream()::Ptr{Cvoid})::Cint), "hpcla_remap_i64_to_i32")
+    end
+    AMDGPU.synchronize()                                    # cmap_d is read by the kernel above
+    return split
+end
+
+# interior / boundary lists of the `rpb`-row blocks (hpcla_classify_blocks_*: 0-based arrays, index_base = 0)
+function _classify_blocks(A, rp0::ROCVector{Tk}, colval_split::ROCVector{Tk}, n_own::Int, rpb::Cint) where {Tk}
+    flags = AMDGPU.zeros(Int32, cld(A.nrows_local, rpb))
+    if Tk === Int32
+        _check(@ccall(LIB.hpcla_classify_blocks_i32(_ptr(rp0)::Ptr{Cvoid}, _ptr(colval_split)::Ptr{Cvoid},
+               A.nrows_local::Int64, 0::Cint, n_own::Int64, rpb::Cint, _ptr(flags)::Ptr{Cvoid},
+               _stream()::Ptr{Cvoid})::Cint), "hpcla_classify_blocks_i32")
+    else
+        _check(@ccall(LIB.hpcla_classify_blocks_i64(_ptr(rp0)::Ptr{Cvoid}, _ptr(colval_split)::Ptr{Cvoid},
+               A.nrows_local::Int64, 0::Cint, n_own::Int64, rpb::Cint, _ptr(flags)::Ptr{Cvoid},
+               _stream()::Ptr{Cvoid})::Cint), "hpcla_classify_blocks_i64")
+    end
+    f = Array(flags)
+    return ROCVector(Int32.(findall(==(0), f) .- 1)), ROCVector(Int32.(findall(!=(0), f) .- 1))
+end
+
+# WHOLE SLICES (SURVEY 8e(3); the twin of linearalgebrampi.jl_amd/sparse.py whole_slice_wishes / whole_slice_lists, executed
+# there at world 2 / 3 / 8).  An unstructured A (config 5) touches ~98 % of every other rank's rows of B: gathering and packing
+# the requested rows costs the owner a full extra pass over them, an index list as long as its slice (7 x 2.05 M indices per
+# product at 8 GPUs) and a send buffer as large as the slice.  A rank that needs more than half of a neighbour's slice asks
+# for ALL of it: the owner sends its rows in place order (index list 0:n_own-1), the ghost segment of that neighbour then
+# holds its whole slice and column g sits at g - partition[owner] in it.  wish[r + 1] == 1: this rank wants rank r's whole slice.
+const _WHOLE_SLICE_FRACTION = 0.5
+function _whole_slice_wishes(plan, xpart::Vector{Int}, nranks::Int)
+    wish = zeros(Int, nranks)
+    for (r, perm) in zip(plan.recv_rank_ids, plan.recv_perm)
+        length(perm) > _WHOLE_SLICE_FRACTION * (xpart[r + 2] - xpart[r + 1]) && (wish[r + 1] = 1)
+    end
+    return wish
+end
+
+# width-`width` halo plan for the ghost ROWS of B: the reference VectorPlan's own lists (or whole slices, above), `width`
+# values per index (row-major rows travel as contiguous runs of `width` doubles: k, or the padded pitch k + 1 of an odd k).
+# COLLECTIVE on first use (an Alltoall of the wishes and the window attach): every rank of the communicator calls it, with or
+# without neighbours -- a rank without neighbours gets an entry whose halo handle is C_NULL.
 # `rpb`: rows per block of the kernels that will take the interior / boundary lists (the row-major Float64 kernels of
 # spmm.hip: hpcla_spmm_rows_per_block(); the lanes = rows kernels -- column-major blocks, Float32 --: the SpMV's 256).
-function _spmm_halo(A::HPCSparseMatrix{T,Ti,B}, plan, d::ROCVectorPlan{Tk}, k::Int, rpb::Cint) where {T,Ti,Tk,B<:ROCBackend}
-    get!(_spmm_plans, (plan, k, rpb)) do
+# The entry carries the colval / rowptr arrays ITS kernels read: the vector plan's, unless whole slices moved the ghost positions.
+function _spmm_halo(A::HPCSparseMatrix{T,Ti,B}, plan, d::ROCVectorPlan{Tk}, xpart::Vector{Int}, width::Int, rpb::Cint) where {T,Ti,Tk,B<:ROCBackend}
+    get!(_spmm_plans, (plan, width, rpb)) do
+        comm = A.backend.comm; nranks = comm_size(comm)
+        n_own = d.n_own; nnz = length(A.nzval)
+        wish = _whole_slice_wishes(plan, xpart, nranks)
+        granted = HPCLinearAlgebra.comm_alltoall(comm, MPI.UBuffer(wish, 1))       # granted[q + 1] == 1: rank q gets my whole slice
+        if isempty(plan.send_rank_ids) && isempty(plan.recv_rank_ids)
+            comm isa CommMPI && _attach_halo_window(_rccl(comm), C_NULL, comm.comm, nranks)   # collective: the other ranks' plans attach
+            return (C_NULL, ROCVector{Int32}(undef, 0), ROCVector{Int32}(undef, 0), nothing, C_NULL, d.colval_split, d.rowptr0)
+        end
+        send_lists = Vector{Ti}[granted[q + 1] == 1 ? collect(Ti, 0:n_own-1) : idx .- one(Ti)
+                                for (q, idx) in zip(plan.send_rank_ids, plan.send_indices)]               # 0-based
+        recv_counts = Int64[wish[r + 1] == 1 ? xpart[r + 2] - xpart[r + 1] : length(perm)
+                            for (r, perm) in zip(plan.recv_rank_ids, plan.recv_perm)]
+        n_ghost = sum(recv_counts; init=Int64(0))
+        colval_split = d.colval_split; rp0 = d.rowptr0; Tke = Tk
+        segments = d.segments
+        if any(==(1), wish)
+            # ghost positions differ from the vector plan's: a split-column copy of this entry's own -- in the plan's index type,
+            # or, when whole slices outgrow a narrowed plan's Int32, in the matrix's
+            Tke = _kernel_index_type(Ti, nnz, A.nrows_local, n_own, n_ghost)
+            n_own + n_ghost <= typemax(Tke) || error("A * B: the split column space does not fit the index type")
+            cmap = Vector{Tke}(undef, length(A.col_indices))
+            cmap[plan.local_dst_indices] .= Tke.(plan.local_src_indices .- one(Ti))
+            off = n_own
+            for (r, perm, cnt) in zip(plan.recv_rank_ids, plan.recv_perm, recv_counts)
+                if wish[r + 1] == 1
+                    cmap[perm] .= Tke.(off .+ (A.col_indices[perm] .- xpart[r + 1]))      # its row in the owner's slice
+                else
+                    cmap[perm] .= Tke.(off .+ (0:length(perm)-1))
+                end
+                off += cnt
+            end
+            colval_split = _split_colval(A, cmap)
+            rp0 = Tke === Tk ? d.rowptr0 : A.rowptr_target .- one(Ti)
+            segments = [wish[r + 1] == 1 ? collect(0:(xpart[r + 2] - xpart[r + 1] - 1)) : seg
+                        for (r, seg) in zip(plan.recv_rank_ids, d.segments)]
+        end
         halo = Ref{Ptr{Cvoid}}(C_NULL)
-        send_idx = ROCVector(Tk.(reduce(vcat, plan.send_indices; init=Ti[]) .- one(Ti)))
+        send_idx = ROCVector(Tke.(reduce(vcat, send_lists; init=Ti[])))
         AMDGPU.synchronize()
         # flags = 1 (HPCLA_HALO_SINGLE_BUFFER): this plan is driven through halo_begin / halo_end and its consumers
         # take the ghost pointer from the host while the exchange is in flight, so a one-column B (width 1) must
         # not be double-buffered like the fused SpMV's vector plans
-        _check(@ccall(LIB.hpcla_halo_plan_create_ex(halo::Ptr{Ptr{Cvoid}}, _rccl(A.backend.comm)::Ptr{Cvoid},
+        _check(@ccall(LIB.hpcla_halo_plan_create_ex(halo::Ptr{Ptr{Cvoid}}, _rccl(comm)::Ptr{Cvoid},
                length(plan.send_rank_ids)::Cint, Int32.(plan.send_rank_ids)::Ptr{Int32},
-               Int64.(length.(plan.send_indices))::Ptr{Int64}, _ptr(send_idx)::Ptr{Cvoid},
-               (Tk === Int64 ? 1 : 0)::Cint, length(plan.recv_rank_ids)::Cint,
-               Int32.(plan.recv_rank_ids)::Ptr{Int32}, Int64.(length.(plan.recv_perm))::Ptr{Int64},
-               k::Cint, 1::Cint)::Cint), "hpcla_halo_plan_create_ex")
-        A.backend.comm isa CommMPI &&
-            _attach_halo_window(_rccl(A.backend.comm), halo[], A.backend.comm.comm, comm_size(A.backend.comm),
-                                (d.n_own, d.segments))
-        flags = AMDGPU.zeros(Int32, cld(A.nrows_local, rpb))
-        rp0 = d.rowptr0
-        if Tk === Int32
-            _check(@ccall(LIB.hpcla_classify_blocks_i32(_ptr(rp0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
-                   A.nrows_local::Int64, 0::Cint, d.n_own::Int64, rpb::Cint, _ptr(flags)::Ptr{Cvoid},
-                   _stream()::Ptr{Cvoid})::Cint), "hpcla_classify_blocks_i32")
-        else
-            _check(@ccall(LIB.hpcla_classify_blocks_i64(_ptr(rp0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
-                   A.nrows_local::Int64, 0::Cint, d.n_own::Int64, rpb::Cint, _ptr(flags)::Ptr{Cvoid},
-                   _stream()::Ptr{Cvoid})::Cint), "hpcla_classify_blocks_i64")
-        end
-        f = Array(flags)
+               Int64.(length.(send_lists))::Ptr{Int64}, _ptr(send_idx)::Ptr{Cvoid},
+               (Tke === Int64 ? 1 : 0)::Cint, length(plan.recv_rank_ids)::Cint,
+               Int32.(plan.recv_rank_ids)::Ptr{Int32}, recv_counts::Ptr{Int64},
+               width::Cint, 1::Cint)::Cint), "hpcla_halo_plan_create_ex")
+        comm isa CommMPI && _attach_halo_window(_rccl(comm), halo[], comm.comm, nranks, (n_own, segments))
+        interior, boundary = _classify_blocks(A, rp0, colval_split, n_own, rpb)
         # the ghost buffer of a single-buffered plan is a constant: fetched once, at plan time
         ghost = Ref{Ptr{Cvoid}}(C_NULL); ng = Ref{Int64}(0)
         _check(@ccall(LIB.hpcla_halo_ghost_ptr(halo[]::Ptr{Cvoid}, ghost::Ptr{Ptr{Cvoid}}, ng::Ptr{Int64})::Cint), "hpcla_halo_ghost_ptr")
-        (halo[], ROCVector(Int32.(findall(==(0), f) .- 1)), ROCVector(Int32.(findall(!=(0), f) .- 1)), send_idx, ghost[])
+        (halo[], interior, boundary, send_idx, ghost[], colval_split, rp0)
     end
 end
 
@@ -506,14 +701,28 @@ _spmm_runs(A, d) = get(ENV, "HPCLA_SPMM_RUNS", "1") == "0" ? nothing : ((desc, f
 # kernels read a column-major block -- Julia's Matrix -- in contiguous pieces, so A * B runs on the caller's arrays as they are
 # (csrc/colmajor.hip: 0.67 ms on the 5-point matrix x 16 where the two layout conversions around the row-major product cost
 # 1.52 ms; 7-point: 0.99 against 1.63); an unstructured matrix touches a line per (entry, column) pair in that layout and
-# keeps the conversions.  HPCLA_SPMM_COLMAJOR=0 switches the direct path off.
-const _banded_cache = IdDict{Any,Bool}()       # device plan -> banded?
+# keeps the conversion of B.  HPCLA_SPMM_COLMAJOR=0 switches the direct path off.
+# The verdict is COLLECTIVE (an all-reduce, once per plan): the two paths exchange ghost rows of different widths for an odd
+# k (k, or the padded pitch k + 1), so every rank of the communicator must take the same one.
+const _banded_cache = IdDict{Any,Bool}()       # device plan -> banded on every rank?
 const _spmm_cm_tuned = IdDict{Any,Int}()       # device plan -> block-order group measured for the column-major run tiles
+# The library keeps ONE SpMM block order per rowptr array (hpcla_spmm_block_order_hint) while the orders are measured per
+# KERNEL: the column-major run tiles (k = 16) have a measured group, every other SpMM launch of this file runs in the natural
+# order.  Before a launch, the order IT wants is put in force if the last launch over the same rowptr left another one
+# (the twin of dense.py _spmm_apply_order).  Every order is a bijection of the row blocks: results never depend on it.
+const _spmm_order_in_force = IdDict{Any,Int}() # rowptr array -> group the library holds for it (1 = natural)
+function _spmm_order!(rp0, group::Int)
+    get(_spmm_order_in_force, rp0, 1) == group && return
+    @ccall LIB.hpcla_spmm_block_order_hint(_ptr(rp0)::Ptr{Cvoid}, (group <= 1 ? 0 : group)::Cint)::Cint
+    _spmm_order_in_force[rp0] = group
+    return
+end
 function _banded(A, d::ROCVectorPlan{Tk}) where {Tk}
-    get(ENV, "HPCLA_SPMM_COLMAJOR", "1") == "0" && return false
     get!(_banded_cache, d) do
         nb = Ref{Int64}(0); nnz = length(A.nzval)
-        if Tk === Int32
+        if get(ENV, "HPCLA_SPMM_COLMAJOR", "1") == "0"
+            nb[] = -1                                        # (still takes part in the all-reduce below)
+        elseif Tk === Int32
             _check(@ccall(LIB.hpcla_spmm_banded_blocks_i32(_ptr(d.rowptr0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
                    A.nrows_local::Int64, nnz::Int64, 0::Cint, d.n_own::Int64, 16::Cint, nb::Ptr{Int64},
                    _stream()::Ptr{Cvoid})::Cint), "hpcla_spmm_banded_blocks_i32")
@@ -522,7 +731,8 @@ function _banded(A, d::ROCVectorPlan{Tk}) where {Tk}
                    A.nrows_local::Int64, nnz::Int64, 0::Cint, d.n_own::Int64, 16::Cint, nb::Ptr{Int64},
                    _stream()::Ptr{Cvoid})::Cint), "hpcla_spmm_banded_blocks_i64")
         end
-        nb[] >= 0.99 * cld(A.nrows_local, 64)
+        mine = nb[] >= 0.99 * cld(A.nrows_local, 64) ? 1 : 0
+        HPCLinearAlgebra.comm_allreduce(A.backend.comm, mine, min) == 1
     end
 end
 
@@ -533,67 +743,81 @@ function _spmm_colmajor(A::HPCSparseMatrix{T,Ti,B}, M::HPCMatrix{T,B}, plan, d::
     nloc, k = size(M.A)
     C = ROCMatrix{T}(undef, A.nrows_local, k)          # every row block is launched: no zero fill
     nnz = length(A.nzval); ldb = max(nloc, 1); ldc = max(A.nrows_local, 1)
+    nranks = comm_size(A.backend.comm)
+    # (whole slices -- small matrices: a banded structure asks for a few rows per neighbour -- move the ghost positions: the run
+    # descriptors describe the vector plan's columns and stay out then)
+    own_lists = nranks == 1 || !any(==(1), _whole_slice_wishes(plan, M.row_partition, nranks))
     # k = 16, Float64, every block within the run-tile limits (a 5-point matrix: 3 runs per block) and B's columns on the
     # 16-byte grid: the run tiles on the column-major blocks (hpcla_spmm_runs_colmajor_k16_f64_*, round 5: 0.56 ms against
     # 0.64 on the 5-point matrix x 16, same bits) -- block lists over its 64-row blocks
-    runs = (T === Float64 && k == 16 && iseven(ldb) && UInt(_ptr(M.A)) % 16 == 0) ? _spmm_runs(A, d) : nothing
+    runs = (T === Float64 && k == 16 && own_lists && iseven(ldb) && UInt(_ptr(M.A)) % 16 == 0) ? _spmm_runs(A, d) : nothing
     rpb = runs === nothing ? (@ccall LIB.hpcla_spmv_rows_per_block()::Cint) : (@ccall LIB.hpcla_spmm_rows_per_block()::Cint)
+    # every rank of a communicator takes part in the plan-time collectives of the exchange entry, neighbours or not
+    ent = nranks > 1 ? _spmm_halo(A, plan, d, M.row_partition, k, rpb) : (C_NULL, nothing, nothing, nothing, C_NULL, d.colval_split, d.rowptr0)
+    halo, interior, boundary, _, ghost_seg, colval_split, rp0 = ent
+    Te = eltype(rp0)                                   # index type of the entry's kernel arrays
+    # PLAN TIME, once per device plan: the block order of the run tiles BY MEASUREMENT (the same launch timed under five block
+    # orders, the fastest stays set) -- over every block, or over the interior list of a rank with neighbours; BEFORE any exchange
+    # is posted, so that nothing else is in flight while it is timed (the timed launches write those rows of C, correctly)
+    if runs !== nothing && !haskey(_spmm_cm_tuned, d)
+        tb = halo == C_NULL ? nothing : interior
+        chosen = Ref{Cint}(1)
+        if tb !== nothing && isempty(tb)
+            # (nothing to time without an interior block)
+        elseif Te === Int32
+            _check(@ccall(LIB.hpcla_spmm_runs_colmajor_tune_block_order_f64_i32(_ptr(rp0)::Ptr{Cvoid}, _ptr(colval_split)::Ptr{Cvoid},
+                   _ptr(A.nzval)::Ptr{Cvoid}, _ptr(M.A)::Ptr{Cvoid}, ldb::Int64, C_NULL::Ptr{Cvoid}, k::Int64, d.n_own::Int64,
+                   _ptr(C)::Ptr{Cvoid}, ldc::Int64, A.nrows_local::Int64, nnz::Int64, 0::Cint, _ptr(runs)::Ptr{Cvoid},
+                   _ptr(tb)::Ptr{Cvoid}, _len(tb)::Int64, _stream()::Ptr{Cvoid}, chosen::Ptr{Cint})::Cint),
+                   "hpcla_spmm_runs_colmajor_tune_block_order_f64_i32")
+        else
+            _check(@ccall(LIB.hpcla_spmm_runs_colmajor_tune_block_order_f64_i64(_ptr(rp0)::Ptr{Cvoid}, _ptr(colval_split)::Ptr{Cvoid},
+                   _ptr(A.nzval)::Ptr{Cvoid}, _ptr(M.A)::Ptr{Cvoid}, ldb::Int64, C_NULL::Ptr{Cvoid}, k::Int64, d.n_own::Int64,
+                   _ptr(C)::Ptr{Cvoid}, ldc::Int64, A.nrows_local::Int64, nnz::Int64, 0::Cint, _ptr(runs)::Ptr{Cvoid},
+                   _ptr(tb)::Ptr{Cvoid}, _len(tb)::Int64, _stream()::Ptr{Cvoid}, chosen::Ptr{Cint})::Cint),
+                   "hpcla_spmm_runs_colmajor_tune_block_order_f64_i64")
+        end
+        _spmm_cm_tuned[d] = Int(chosen[]); _spmm_order_in_force[rp0] = Int(chosen[])      # (what the tuner left set)
+    end
     function launch(ghost::Ptr{Cvoid}, blocks::Ptr{Cvoid}, nblocks::Int64)
         if runs !== nothing
-            # the first launch without a ghost segment (the whole product, or the interior list while the exchange is in
-            # flight) goes through the plan-time tuner: the same launch timed under five block orders, the fastest stays set
-            tune = ghost == C_NULL && !haskey(_spmm_cm_tuned, d)
-            chosen = Ref{Cint}(1)
-            if tune && Tk === Int32
-                _check(@ccall(LIB.hpcla_spmm_runs_colmajor_tune_block_order_f64_i32(_ptr(d.rowptr0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
-                       _ptr(A.nzval)::Ptr{Cvoid}, _ptr(M.A)::Ptr{Cvoid}, ldb::Int64, ghost::Ptr{Cvoid}, k::Int64, d.n_own::Int64,
-                       _ptr(C)::Ptr{Cvoid}, ldc::Int64, A.nrows_local::Int64, nnz::Int64, 0::Cint, _ptr(runs)::Ptr{Cvoid},
-                       blocks::Ptr{Cvoid}, nblocks::Int64, _stream()::Ptr{Cvoid}, chosen::Ptr{Cint})::Cint),
-                       "hpcla_spmm_runs_colmajor_tune_block_order_f64_i32")
-            elseif tune
-                _check(@ccall(LIB.hpcla_spmm_runs_colmajor_tune_block_order_f64_i64(_ptr(d.rowptr0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
-                       _ptr(A.nzval)::Ptr{Cvoid}, _ptr(M.A)::Ptr{Cvoid}, ldb::Int64, ghost::Ptr{Cvoid}, k::Int64, d.n_own::Int64,
-                       _ptr(C)::Ptr{Cvoid}, ldc::Int64, A.nrows_local::Int64, nnz::Int64, 0::Cint, _ptr(runs)::Ptr{Cvoid},
-                       blocks::Ptr{Cvoid}, nblocks::Int64, _stream()::Ptr{Cvoid}, chosen::Ptr{Cint})::Cint),
-                       "hpcla_spmm_runs_colmajor_tune_block_order_f64_i64")
-            elseif Tk === Int32
-                _check(@ccall(LIB.hpcla_spmm_runs_colmajor_k16_f64_i32(_ptr(d.rowptr0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
+            _spmm_order!(rp0, get(_spmm_cm_tuned, d, 1))
+            if Te === Int32
+                _check(@ccall(LIB.hpcla_spmm_runs_colmajor_k16_f64_i32(_ptr(rp0)::Ptr{Cvoid}, _ptr(colval_split)::Ptr{Cvoid},
                        _ptr(A.nzval)::Ptr{Cvoid}, _ptr(M.A)::Ptr{Cvoid}, ldb::Int64, ghost::Ptr{Cvoid}, k::Int64, d.n_own::Int64,
                        _ptr(C)::Ptr{Cvoid}, ldc::Int64, A.nrows_local::Int64, nnz::Int64, 0::Cint, _ptr(runs)::Ptr{Cvoid},
                        blocks::Ptr{Cvoid}, nblocks::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_spmm_runs_colmajor_k16_f64_i32")
             else
-                _check(@ccall(LIB.hpcla_spmm_runs_colmajor_k16_f64_i64(_ptr(d.rowptr0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
+                _check(@ccall(LIB.hpcla_spmm_runs_colmajor_k16_f64_i64(_ptr(rp0)::Ptr{Cvoid}, _ptr(colval_split)::Ptr{Cvoid},
                        _ptr(A.nzval)::Ptr{Cvoid}, _ptr(M.A)::Ptr{Cvoid}, ldb::Int64, ghost::Ptr{Cvoid}, k::Int64, d.n_own::Int64,
                        _ptr(C)::Ptr{Cvoid}, ldc::Int64, A.nrows_local::Int64, nnz::Int64, 0::Cint, _ptr(runs)::Ptr{Cvoid},
                        blocks::Ptr{Cvoid}, nblocks::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_spmm_runs_colmajor_k16_f64_i64")
             end
-            tune && (_spmm_cm_tuned[d] = Int(chosen[]))
-        elseif T === Float64 && Tk === Int32
-            _check(@ccall(LIB.hpcla_spmm_split_colmajor_f64_i32(_ptr(d.rowptr0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
+        elseif T === Float64 && Te === Int32
+            _check(@ccall(LIB.hpcla_spmm_split_colmajor_f64_i32(_ptr(rp0)::Ptr{Cvoid}, _ptr(colval_split)::Ptr{Cvoid},
                    _ptr(A.nzval)::Ptr{Cvoid}, _ptr(M.A)::Ptr{Cvoid}, ldb::Int64, ghost::Ptr{Cvoid}, k::Int64, d.n_own::Int64,
                    _ptr(C)::Ptr{Cvoid}, ldc::Int64, A.nrows_local::Int64, nnz::Int64, k::Cint, 0::Cint, blocks::Ptr{Cvoid},
                    nblocks::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_spmm_split_colmajor_f64_i32")
         elseif T === Float64
-            _check(@ccall(LIB.hpcla_spmm_split_colmajor_f64_i64(_ptr(d.rowptr0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
+            _check(@ccall(LIB.hpcla_spmm_split_colmajor_f64_i64(_ptr(rp0)::Ptr{Cvoid}, _ptr(colval_split)::Ptr{Cvoid},
                    _ptr(A.nzval)::Ptr{Cvoid}, _ptr(M.A)::Ptr{Cvoid}, ldb::Int64, ghost::Ptr{Cvoid}, k::Int64, d.n_own::Int64,
                    _ptr(C)::Ptr{Cvoid}, ldc::Int64, A.nrows_local::Int64, nnz::Int64, k::Cint, 0::Cint, blocks::Ptr{Cvoid},
                    nblocks::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_spmm_split_colmajor_f64_i64")
-        elseif Tk === Int32
-            _check(@ccall(LIB.hpcla_spmm_split_colmajor_f32_i32(_ptr(d.rowptr0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
+        elseif Te === Int32
+            _check(@ccall(LIB.hpcla_spmm_split_colmajor_f32_i32(_ptr(rp0)::Ptr{Cvoid}, _ptr(colval_split)::Ptr{Cvoid},
                    _ptr(A.nzval)::Ptr{Cvoid}, _ptr(M.A)::Ptr{Cvoid}, ldb::Int64, ghost::Ptr{Cvoid}, k::Int64, d.n_own::Int64,
                    _ptr(C)::Ptr{Cvoid}, ldc::Int64, A.nrows_local::Int64, nnz::Int64, k::Cint, 0::Cint, blocks::Ptr{Cvoid},
                    nblocks::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_spmm_split_colmajor_f32_i32")
         else
-            _check(@ccall(LIB.hpcla_spmm_split_colmajor_f32_i64(_ptr(d.rowptr0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
+            _check(@ccall(LIB.hpcla_spmm_split_colmajor_f32_i64(_ptr(rp0)::Ptr{Cvoid}, _ptr(colval_split)::Ptr{Cvoid},
                    _ptr(A.nzval)::Ptr{Cvoid}, _ptr(M.A)::Ptr{Cvoid}, ldb::Int64, ghost::Ptr{Cvoid}, k::Int64, d.n_own::Int64,
                    _ptr(C)::Ptr{Cvoid}, ldc::Int64, A.nrows_local::Int64, nnz::Int64, k::Cint, 0::Cint, blocks::Ptr{Cvoid},
                    nblocks::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_spmm_split_colmajor_f32_i64")
         end
     end
-    if d.halo == C_NULL
+    if halo == C_NULL
         launch(C_NULL, C_NULL, Int64(0))                         # every row block, every column owned
     else
-        halo, interior, boundary, _, ghost = _spmm_halo(A, plan, d, k, rpb)
         stage = _stage(d, d.n_own * k)
         if T === Float64
             _check(@ccall(LIB.hpcla_halo_begin_strided_f64(halo::Ptr{Cvoid}, _ptr(M.A)::Ptr{Cvoid}, 1::Int64, ldb::Int64,
@@ -604,78 +828,87 @@ function _spmm_colmajor(A::HPCSparseMatrix{T,Ti,B}, M::HPCMatrix{T,B}, plan, d::
         end
         isempty(interior) || launch(C_NULL, _ptr(interior), Int64(length(interior)))     # overlaps the exchange
         _check(@ccall(LIB.hpcla_halo_end(halo::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_halo_end")
-        isempty(boundary) || launch(ghost, _ptr(boundary), Int64(length(boundary)))
+        isempty(boundary) || launch(ghost_seg, _ptr(boundary), Int64(length(boundary)))
     end
-    return HPCLinearAlgebra.HPCMatrix_local(C, A.backend)
+    return _spmm_result(A, C, k)
 end
 
-# Row-major B rows (own block `Brow`, ghost segment `ghost`) times A into C.  `ccol` = false: `C` is row-major (k x nrows
-# column-major storage), run tiles where the structure allows them; `ccol` = true (round 5): `C` is the caller's column-major
-# nrows x k Matrix and the product stores it in that layout itself (hpcla_spmm_split_ccol_f64_*, csrc/spmm.hip CCOL) -- no
-# conversion of C afterwards.
-function _spmm_split!(C, A::HPCSparseMatrix{T,Ti,B}, d, Brow, ghost::Ptr{Cvoid}, k::Int, blocks, ccol::Bool=false) where {T,Ti,B}
-    isempty(blocks) && return
-    rp0 = d.rowptr0; nnz = length(A.nzval)
-    runs = (k == 16 && !ccol) ? _spmm_runs(A, d) : nothing
+# Row-major B rows (own block `Brow`, ghost segment `ghost`, both on the row pitch `ldb`) times A into C, over the kernel arrays
+# `rp0` / `colval_split` of the exchange entry.  `blocks` = nothing: every row block (no list is built or uploaded).
+# `ccol` = false: `C` is row-major on the pitch `ldb` (k x nrows column-major storage when ldb == k), run tiles where the
+# structure allows them (`runs`); `ccol` = true (round 5): `C` is the caller's column-major nrows x k Matrix and the product
+# stores it in that layout itself (hpcla_spmm_split_ccol_f64_*, csrc/spmm.hip CCOL) -- no conversion of C afterwards.
+# ODD k (round 6): ldb = k + 1 -- the vector kernel owns column pairs and reads the padding double of every row it gathers.
+function _spmm_split!(C, A::HPCSparseMatrix{T,Ti,B}, rp0, colval_split, n_own::Int, Brow, ldb::Int, ghost::Ptr{Cvoid}, k::Int, blocks,
+                      ccol::Bool, runs=nothing) where {T,Ti,B}
+    blocks !== nothing && isempty(blocks) && return
+    nnz = length(A.nzval); nb = _len(blocks)
+    _spmm_order!(rp0, 1)                               # the gather kernel's launches of this file: the natural order
     if ccol && eltype(rp0) === Int32
-        _check(@ccall(LIB.hpcla_spmm_split_ccol_f64_i32(_ptr(rp0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
-               _ptr(A.nzval)::Ptr{Cvoid}, _ptr(Brow)::Ptr{Cvoid}, k::Int64, ghost::Ptr{Cvoid}, k::Int64, d.n_own::Int64,
+        _check(@ccall(LIB.hpcla_spmm_split_ccol_f64_i32(_ptr(rp0)::Ptr{Cvoid}, _ptr(colval_split)::Ptr{Cvoid},
+               _ptr(A.nzval)::Ptr{Cvoid}, _ptr(Brow)::Ptr{Cvoid}, ldb::Int64, ghost::Ptr{Cvoid}, ldb::Int64, n_own::Int64,
                _ptr(C)::Ptr{Cvoid}, max(A.nrows_local, 1)::Int64, A.nrows_local::Int64, nnz::Int64, k::Cint, 0::Cint,
-               _ptr(blocks)::Ptr{Cvoid}, length(blocks)::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_spmm_split_ccol_f64_i32")
+               _ptr(blocks)::Ptr{Cvoid}, nb::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_spmm_split_ccol_f64_i32")
     elseif ccol
-        _check(@ccall(LIB.hpcla_spmm_split_ccol_f64_i64(_ptr(rp0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
-               _ptr(A.nzval)::Ptr{Cvoid}, _ptr(Brow)::Ptr{Cvoid}, k::Int64, ghost::Ptr{Cvoid}, k::Int64, d.n_own::Int64,
+        _check(@ccall(LIB.hpcla_spmm_split_ccol_f64_i64(_ptr(rp0)::Ptr{Cvoid}, _ptr(colval_split)::Ptr{Cvoid},
+               _ptr(A.nzval)::Ptr{Cvoid}, _ptr(Brow)::Ptr{Cvoid}, ldb::Int64, ghost::Ptr{Cvoid}, ldb::Int64, n_own::Int64,
                _ptr(C)::Ptr{Cvoid}, max(A.nrows_local, 1)::Int64, A.nrows_local::Int64, nnz::Int64, k::Cint, 0::Cint,
-               _ptr(blocks)::Ptr{Cvoid}, length(blocks)::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_spmm_split_ccol_f64_i64")
+               _ptr(blocks)::Ptr{Cvoid}, nb::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_spmm_split_ccol_f64_i64")
     elseif runs !== nothing && eltype(rp0) === Int32
-        _check(@ccall(LIB.hpcla_spmm_runs_k16_f64_i32(_ptr(rp0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
-               _ptr(A.nzval)::Ptr{Cvoid}, _ptr(Brow)::Ptr{Cvoid}, ghost::Ptr{Cvoid}, d.n_own::Int64, _ptr(C)::Ptr{Cvoid},
+        _check(@ccall(LIB.hpcla_spmm_runs_k16_f64_i32(_ptr(rp0)::Ptr{Cvoid}, _ptr(colval_split)::Ptr{Cvoid},
+               _ptr(A.nzval)::Ptr{Cvoid}, _ptr(Brow)::Ptr{Cvoid}, ghost::Ptr{Cvoid}, n_own::Int64, _ptr(C)::Ptr{Cvoid},
                A.nrows_local::Int64, nnz::Int64, 0::Cint, _ptr(runs)::Ptr{Cvoid}, _ptr(blocks)::Ptr{Cvoid},
-               length(blocks)::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_spmm_runs_k16_f64_i32")
+               nb::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_spmm_runs_k16_f64_i32")
     elseif runs !== nothing
-        _check(@ccall(LIB.hpcla_spmm_runs_k16_f64_i64(_ptr(rp0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
-               _ptr(A.nzval)::Ptr{Cvoid}, _ptr(Brow)::Ptr{Cvoid}, ghost::Ptr{Cvoid}, d.n_own::Int64, _ptr(C)::Ptr{Cvoid},
+        _check(@ccall(LIB.hpcla_spmm_runs_k16_f64_i64(_ptr(rp0)::Ptr{Cvoid}, _ptr(colval_split)::Ptr{Cvoid},
+               _ptr(A.nzval)::Ptr{Cvoid}, _ptr(Brow)::Ptr{Cvoid}, ghost::Ptr{Cvoid}, n_own::Int64, _ptr(C)::Ptr{Cvoid},
                A.nrows_local::Int64, nnz::Int64, 0::Cint, _ptr(runs)::Ptr{Cvoid}, _ptr(blocks)::Ptr{Cvoid},
-               length(blocks)::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_spmm_runs_k16_f64_i64")
+               nb::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_spmm_runs_k16_f64_i64")
     elseif eltype(rp0) === Int32
-        _check(@ccall(LIB.hpcla_spmm_split_f64_i32(_ptr(rp0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
-               _ptr(A.nzval)::Ptr{Cvoid}, _ptr(Brow)::Ptr{Cvoid}, k::Int64, ghost::Ptr{Cvoid}, k::Int64, d.n_own::Int64,
-               _ptr(C)::Ptr{Cvoid}, k::Int64, A.nrows_local::Int64, nnz::Int64, k::Cint, 0::Cint,
-               _ptr(blocks)::Ptr{Cvoid}, length(blocks)::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_spmm_split_f64_i32")
+        _check(@ccall(LIB.hpcla_spmm_split_f64_i32(_ptr(rp0)::Ptr{Cvoid}, _ptr(colval_split)::Ptr{Cvoid},
+               _ptr(A.nzval)::Ptr{Cvoid}, _ptr(Brow)::Ptr{Cvoid}, ldb::Int64, ghost::Ptr{Cvoid}, ldb::Int64, n_own::Int64,
+               _ptr(C)::Ptr{Cvoid}, ldb::Int64, A.nrows_local::Int64, nnz::Int64, k::Cint, 0::Cint,
+               _ptr(blocks)::Ptr{Cvoid}, nb::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_spmm_split_f64_i32")
     else
-        _check(@ccall(LIB.hpcla_spmm_split_f64_i64(_ptr(rp0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
-               _ptr(A.nzval)::Ptr{Cvoid}, _ptr(Brow)::Ptr{Cvoid}, k::Int64, ghost::Ptr{Cvoid}, k::Int64, d.n_own::Int64,
-               _ptr(C)::Ptr{Cvoid}, k::Int64, A.nrows_local::Int64, nnz::Int64, k::Cint, 0::Cint,
-               _ptr(blocks)::Ptr{Cvoid}, length(blocks)::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_spmm_split_f64_i64")
+        _check(@ccall(LIB.hpcla_spmm_split_f64_i64(_ptr(rp0)::Ptr{Cvoid}, _ptr(colval_split)::Ptr{Cvoid},
+               _ptr(A.nzval)::Ptr{Cvoid}, _ptr(Brow)::Ptr{Cvoid}, ldb::Int64, ghost::Ptr{Cvoid}, ldb::Int64, n_own::Int64,
+               _ptr(C)::Ptr{Cvoid}, ldb::Int64, A.nrows_local::Int64, nnz::Int64, k::Cint, 0::Cint,
+               _ptr(blocks)::Ptr{Cvoid}, nb::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_spmm_split_f64_i64")
     end
 end
 
 function Base.:*(A::HPCSparseMatrix{T,Ti,B}, M::HPCMatrix{T,B}) where {T<:Float64,Ti,B<:ROCBackend}
     assert_backends_compatible(A.backend, M.backend)
     nloc, k = size(M.A)
-    # the vector plan for (A, B's row partition) provides neighbour lists and the split column space
-    probe = HPCVector{T,B}(compute_partition_hash(M.row_partition), M.row_partition, similar(A.nzval, nloc), A.backend)   # plan key only
-    plan = get_vector_plan(A, probe)
-    d = _device_plan(A, probe, plan)
+    plan, d = _spmm_vector_plan(A, M)
     k > 1 && _banded(A, d) && return _spmm_colmajor(A, M, plan, d)       # banded structure: no layout conversion at all
     # UNSTRUCTURED: B converted once to row-major rows (an unstructured matrix gathers whole B rows: one 128-byte line per
     # stored entry at k = 16); C comes out of the product column-major (round 5: no second conversion -- config 5 through
     # this path 2.25 -> 2.12 ms at N = 1 where the B conversion of all 2^24 rows costs 0.75 of them; at 8 GPUs a rank
-    # converts its own 2^21 rows, 0.09 ms)
-    Brow = ROCMatrix{T}(undef, k, nloc)             # k x nloc column-major == nloc x k row-major (written whole: no zero fill)
-    _check(@ccall(LIB.hpcla_transpose_f64(_ptr(M.A)::Ptr{Cvoid}, nloc::Int64, 1::Cint, _ptr(Brow)::Ptr{Cvoid}, k::Int64,
+    # converts its own 2^21 rows, 0.09 ms).  The rows sit on an EVEN pitch (round 6): kp = k + 1 for an odd k, whose products
+    # then take the vector kernel (5-point matrix x 15: 0.946 ms on the one-column-per-lane kernel against 0.475 for 16);
+    # ghost rows travel on the same pitch.  Any k: the library tiles a column-major C wider than 16 columns.
+    kp = k + (k & 1)
+    Brow = ROCMatrix{T}(undef, kp, nloc)            # kp x nloc column-major == nloc rows of pitch kp (the transpose writes columns 1:k)
+    _check(@ccall(LIB.hpcla_transpose_f64(_ptr(M.A)::Ptr{Cvoid}, max(nloc, 1)::Int64, 1::Cint, _ptr(Brow)::Ptr{Cvoid}, kp::Int64,
            0::Cint, nloc::Int64, k::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_transpose_f64")
     C = ROCMatrix{T}(undef, A.nrows_local, k)       # every row block is launched: no zero fill
-    if isempty(plan.send_rank_ids) && isempty(plan.recv_rank_ids)
-        _spmm_split!(C, A, d, Brow, C_NULL, k, ROCVector(Int32.(0:cld(A.nrows_local, (@ccall LIB.hpcla_spmm_rows_per_block()::Cint))-1)), true)
+    if comm_size(A.backend.comm) == 1
+        _spmm_split!(C, A, d.rowptr0, d.colval_split, d.n_own, Brow, kp, C_NULL, k, nothing, true)
     else
-        halo, interior, boundary, _, ghost = _spmm_halo(A, plan, d, k, (@ccall LIB.hpcla_spmm_rows_per_block()::Cint))
-        _check(@ccall(LIB.hpcla_halo_begin(halo::Ptr{Cvoid}, _ptr(Brow)::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_halo_begin")
-        _spmm_split!(C, A, d, Brow, ghost, k, interior, true)      # rows without ghost columns overlap the exchange
-        _check(@ccall(LIB.hpcla_halo_end(halo::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_halo_end")
-        _spmm_split!(C, A, d, Brow, ghost, k, boundary, true)      # ghost rows arrived row-major: nothing else is converted
+        # (every rank, with or without neighbours: the entry's first use is collective)
+        halo, interior, boundary, _, ghost, colval_split, rp0 =
+            _spmm_halo(A, plan, d, M.row_partition, kp, (@ccall LIB.hpcla_spmm_rows_per_block()::Cint))
+        if halo == C_NULL
+            _spmm_split!(C, A, rp0, colval_split, d.n_own, Brow, kp, C_NULL, k, nothing, true)
+        else
+            _check(@ccall(LIB.hpcla_halo_begin(halo::Ptr{Cvoid}, _ptr(Brow)::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_halo_begin")
+            _spmm_split!(C, A, rp0, colval_split, d.n_own, Brow, kp, ghost, k, interior, true)   # rows without ghost columns overlap the exchange
+            _check(@ccall(LIB.hpcla_halo_end(halo::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_halo_end")
+            _spmm_split!(C, A, rp0, colval_split, d.n_own, Brow, kp, ghost, k, boundary, true)   # ghost rows arrived row-major: nothing else is converted
+        end
     end
-    return HPCLinearAlgebra.HPCMatrix_local(C, A.backend)
+    return _spmm_result(A, C, k)
 end
 
 # ==== structural hash without the host pass over colval  (replaces the local Blake3 pass of compute_structural_hash,
@@ -869,17 +1102,67 @@ function _spgemm_product_lists(A::HPCSparseMatrix{T,Ti,B}, plan, res, max_produc
     return (ROCVector(ptr), ROCMatrix(pairs), true)
 end
 
+# Values of the gathered rows, GPU to GPU (replaces execute_plan!(::MatrixPlan, B, target), src/sparse.jl:922-978, whose body
+# copies every send range to the host (_copy_range_to_cpu), sends with host MPI and copies what arrives back -- on EVERY
+# product).  The parent's MatrixPlan keeps describing the exchange: `send_ranges[i]` (ranges of B.nzval for rank_ids[i]),
+# `recv_offsets[i]` / `length(recv_bufs[i])` (where recv_rank_ids[i]'s values land in the gathered array), `local_ranges`.
+# Device form, built once per plan: the ranges expanded to one index list per neighbour feed the SpMV's own halo plan (width 1)
+# over B.nzval; own ranges and the arrived segments are placed by two gather launches.  The twin of matmat.py
+# MatrixPlan.gather_values, which the GPU tests hold to the oracle.  COLLECTIVE on first use (window attach).
+const _rocm_matexec = IdDict{Any,Any}()   # reference MatrixPlan -> (halo handle, send_idx, local src, local dst, ghost src, ghost dst); freed by clear_rocm_plan_cache!
+function _matrix_values!(gval::ROCVector{T}, plan, Bm::HPCSparseMatrix{T,Ti,B}) where {T<:Float64,Ti,B<:ROCBackend}
+    st = get!(_rocm_matexec, plan) do
+        comm = Bm.backend.comm
+        send_lists = Vector{Int64}[reduce(vcat, (collect(Int64, rng) for rng in ranges); init=Int64[]) .- 1 for ranges in plan.send_ranges]   # 0-based positions in B.nzval
+        recv_counts = Int64[length(buf) for buf in plan.recv_bufs]
+        lsrc = Int64[]; ldst = Int64[]                                  # 1-based, as the plan holds them
+        for (src_range, dst_off) in plan.local_ranges
+            append!(lsrc, src_range); append!(ldst, dst_off:(dst_off + length(src_range) - 1))
+        end
+        gdst = Int64[]                                                  # ghost segment (neighbour order) -> gathered array
+        for (off, cnt) in zip(plan.recv_offsets, recv_counts); append!(gdst, off:(off + cnt - 1)); end
+        halo = Ref{Ptr{Cvoid}}(C_NULL)
+        send_idx = ROCVector(reduce(vcat, send_lists; init=Int64[]))
+        if !isempty(plan.rank_ids) || !isempty(plan.recv_rank_ids)
+            AMDGPU.synchronize()
+            _check(@ccall(LIB.hpcla_halo_plan_create(halo::Ptr{Ptr{Cvoid}}, _rccl(comm)::Ptr{Cvoid},
+                   length(plan.rank_ids)::Cint, Int32.(plan.rank_ids)::Ptr{Int32},
+                   Int64.(length.(send_lists))::Ptr{Int64}, _ptr(send_idx)::Ptr{Cvoid}, 1::Cint,
+                   length(plan.recv_rank_ids)::Cint, Int32.(plan.recv_rank_ids)::Ptr{Int32},
+                   recv_counts::Ptr{Int64}, 1::Cint)::Cint), "hpcla_halo_plan_create")
+        end
+        comm isa CommMPI && _attach_halo_window(_rccl(comm), halo[], comm.comm, comm_size(comm))
+        (halo[], send_idx, ROCVector(lsrc), ROCVector(ldst), ROCVector(collect(Int64, 1:length(gdst))), ROCVector(gdst))
+    end
+    halo, _, lsrc, ldst, gsrc, gdst = st
+    s = _stream()
+    halo == C_NULL || _check(@ccall(LIB.hpcla_halo_begin(halo::Ptr{Cvoid}, _ptr(Bm.nzval)::Ptr{Cvoid}, s::Ptr{Cvoid})::Cint), "hpcla_halo_begin")
+    # the own rows' values, under the exchange (1-based lists: index_base = 1)
+    isempty(lsrc) || _check(@ccall(LIB.hpcla_gather_f64_i64(_ptr(Bm.nzval)::Ptr{Cvoid}, _ptr(lsrc)::Ptr{Cvoid}, _ptr(ldst)::Ptr{Cvoid},
+                            _ptr(gval)::Ptr{Cvoid}, length(lsrc)::Int64, 1::Cint, s::Ptr{Cvoid})::Cint), "hpcla_gather_f64_i64")
+    if halo != C_NULL
+        _check(@ccall(LIB.hpcla_halo_end(halo::Ptr{Cvoid}, s::Ptr{Cvoid})::Cint), "hpcla_halo_end")
+        ghost = Ref{Ptr{Cvoid}}(C_NULL); ng = Ref{Int64}(0)
+        _check(@ccall(LIB.hpcla_halo_ghost_ptr(halo::Ptr{Cvoid}, ghost::Ptr{Ptr{Cvoid}}, ng::Ptr{Int64})::Cint), "hpcla_halo_ghost_ptr")
+        isempty(gdst) || _check(@ccall(LIB.hpcla_gather_f64_i64(ghost[]::Ptr{Cvoid}, _ptr(gsrc)::Ptr{Cvoid}, _ptr(gdst)::Ptr{Cvoid},
+                                _ptr(gval)::Ptr{Cvoid}, length(gdst)::Int64, 1::Cint, s::Ptr{Cvoid})::Cint), "hpcla_gather_f64_i64")
+    end
+    return gval
+end
+
 function Base.:*(A::HPCSparseMatrix{T,Ti,B}, Bm::HPCSparseMatrix{T,Ti,B}) where {T<:Float64,Ti,B<:ROCBackend}
     assert_backends_compatible(A.backend, Bm.backend)
-    parent_path() = invoke(*, Tuple{HPCSparseMatrix{T,Ti,B},HPCSparseMatrix{T,Ti,B}} where {T,Ti,B}, A, Bm)
+    parent_path() = invoke(*, Tuple{HPCSparseMatrix{T,Ti,B},HPCSparseMatrix{T,Ti,B}} where {T,Ti,B}, A, Bm)   # PCIe: parent's host product (src/sparse.jl:991-1059) -- only for a row beyond the largest bin or another index type
     (Ti === Int32 || Ti === Int64) || return parent_path()
     plan = HPCLinearAlgebra.MatrixPlan(A, Bm)               # memoized, collective on first use (src/sparse.jl:900-910)
     st = get!(() -> _spgemm_symbolic(A, plan), _spgemm_cache, plan)
     st === nothing && return parent_path()                  # (decided collectively in _spgemm_symbolic)
     gval = ROCVector{T}(undef, max(length(plan.AT.nzval), 1))
-    HPCLinearAlgebra.execute_plan!(plan, Bm, gval)          # values of the gathered rows, into device memory
+    _matrix_values!(gval, plan, Bm)                         # values of the gathered rows, GPU to GPU (not the parent's host-staged execute_plan!)
     nrows = A.nrows_local
     if st.result === nothing
+        # >>> plan time: the FIRST product on a structure builds C's structure (row pointers, column space) next to its values;
+        # the struct's host fields (colptr, colval, col_indices: "always CPU" in the parent) come back once, here
         c_col_tmp = ROCVector{Int64}(undef, max(st.total_ub, 1)); c_val_tmp = ROCVector{T}(undef, max(st.total_ub, 1))
         _spgemm_numeric!(st, A, gval, st.ub_prefix, c_col_tmp, c_val_tmp)
         cnt_h = Array(st.cnt)[1:nrows]
@@ -915,6 +1198,7 @@ function Base.:*(A::HPCSparseMatrix{T,Ti,B}, Bm::HPCSparseMatrix{T,Ti,B}) where 
                      rowptr_target=HPCLinearAlgebra._to_target_device(colptr, A.backend.device), colval_target=colval_target,
                      scratch_col=c_col, c_col_h=c_col_h, c_row_h=c_row_h, hash=Ref{Any}(nothing))
         st.ub_prefix = nothing                              # upper-bound slots: first product only
+        # <<< plan time
     else
         res = st.result
         c_val = ROCVector{T}(undef, res.nnz)
@@ -996,46 +1280,51 @@ end
 # A * B, B::HPCMatrix (src/sparse.jl:2391-2413): like the Float64 product -- banded structure: on the column-major blocks as
 # they are (_spmm_colmajor); unstructured: B converted once to row-major rows (hpcla_transpose_f32), whose ghost rows travel
 # widened in ONE width-k exchange that the interior blocks overlap, the row-major Float32 kernels, C converted back.
-function _spmm_split_f32!(Crow, A::HPCSparseMatrix{Float32,Ti,B}, d::ROCVectorPlan{Tk}, Brow, ghost::Ptr{Cvoid}, k::Int, blocks::Ptr{Cvoid}, nblocks::Int64) where {Ti,Tk,B}
-    nnz = length(A.nzval)
-    if Tk === Int32
-        _check(@ccall(LIB.hpcla_spmm_split_f32_i32(_ptr(d.rowptr0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
-               _ptr(A.nzval)::Ptr{Cvoid}, _ptr(Brow)::Ptr{Cvoid}, k::Int64, ghost::Ptr{Cvoid}, k::Int64, d.n_own::Int64,
+function _spmm_split_f32!(Crow, A::HPCSparseMatrix{Float32,Ti,B}, rp0, colval_split, n_own::Int, Brow, ghost::Ptr{Cvoid}, k::Int, blocks) where {Ti,B}
+    blocks !== nothing && isempty(blocks) && return
+    nnz = length(A.nzval); nb = _len(blocks)
+    if eltype(rp0) === Int32
+        _check(@ccall(LIB.hpcla_spmm_split_f32_i32(_ptr(rp0)::Ptr{Cvoid}, _ptr(colval_split)::Ptr{Cvoid},
+               _ptr(A.nzval)::Ptr{Cvoid}, _ptr(Brow)::Ptr{Cvoid}, k::Int64, ghost::Ptr{Cvoid}, k::Int64, n_own::Int64,
                _ptr(Crow)::Ptr{Cvoid}, k::Int64, A.nrows_local::Int64, nnz::Int64, k::Cint, 0::Cint,
-               blocks::Ptr{Cvoid}, nblocks::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_spmm_split_f32_i32")
+               _ptr(blocks)::Ptr{Cvoid}, nb::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_spmm_split_f32_i32")
     else
-        _check(@ccall(LIB.hpcla_spmm_split_f32_i64(_ptr(d.rowptr0)::Ptr{Cvoid}, _ptr(d.colval_split)::Ptr{Cvoid},
-               _ptr(A.nzval)::Ptr{Cvoid}, _ptr(Brow)::Ptr{Cvoid}, k::Int64, ghost::Ptr{Cvoid}, k::Int64, d.n_own::Int64,
+        _check(@ccall(LIB.hpcla_spmm_split_f32_i64(_ptr(rp0)::Ptr{Cvoid}, _ptr(colval_split)::Ptr{Cvoid},
+               _ptr(A.nzval)::Ptr{Cvoid}, _ptr(Brow)::Ptr{Cvoid}, k::Int64, ghost::Ptr{Cvoid}, k::Int64, n_own::Int64,
                _ptr(Crow)::Ptr{Cvoid}, k::Int64, A.nrows_local::Int64, nnz::Int64, k::Cint, 0::Cint,
-               blocks::Ptr{Cvoid}, nblocks::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_spmm_split_f32_i64")
+               _ptr(blocks)::Ptr{Cvoid}, nb::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_spmm_split_f32_i64")
     end
 end
 
 function Base.:*(A::HPCSparseMatrix{Float32,Ti,B}, M::HPCMatrix{Float32,B}) where {Ti,B<:ROCBackend}
     assert_backends_compatible(A.backend, M.backend)
     nloc, k = size(M.A)
-    probe = HPCVector{Float32,B}(compute_partition_hash(M.row_partition), M.row_partition, similar(A.nzval, nloc), A.backend)   # plan key only
-    plan = get_vector_plan(A, probe)
-    d = _device_plan(A, probe, plan)
+    plan, d = _spmm_vector_plan(A, M)
     _banded(A, d) && return _spmm_colmajor(A, M, plan, d)
     Brow = ROCMatrix{Float32}(undef, k, nloc)             # k x nloc column-major == nloc x k row-major
-    _check(@ccall(LIB.hpcla_transpose_f32(_ptr(M.A)::Ptr{Cvoid}, nloc::Int64, 1::Cint, _ptr(Brow)::Ptr{Cvoid}, k::Int64,
+    _check(@ccall(LIB.hpcla_transpose_f32(_ptr(M.A)::Ptr{Cvoid}, max(nloc, 1)::Int64, 1::Cint, _ptr(Brow)::Ptr{Cvoid}, k::Int64,
            0::Cint, nloc::Int64, k::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_transpose_f32")
     Crow = ROCMatrix{Float32}(undef, k, A.nrows_local)
-    if d.halo == C_NULL
-        _spmm_split_f32!(Crow, A, d, Brow, C_NULL, k, C_NULL, Int64(0))
+    if comm_size(A.backend.comm) == 1
+        _spmm_split_f32!(Crow, A, d.rowptr0, d.colval_split, d.n_own, Brow, C_NULL, k, nothing)
     else
-        halo, interior, boundary, _, ghost = _spmm_halo(A, plan, d, k, (@ccall LIB.hpcla_spmv_rows_per_block()::Cint))
-        _check(@ccall(LIB.hpcla_halo_begin_f32(halo::Ptr{Cvoid}, _ptr(Brow)::Ptr{Cvoid}, _ptr(_stage(d, d.n_own * k))::Ptr{Cvoid},
-               _stream()::Ptr{Cvoid})::Cint), "hpcla_halo_begin_f32")
-        isempty(interior) || _spmm_split_f32!(Crow, A, d, Brow, C_NULL, k, _ptr(interior), Int64(length(interior)))   # overlaps the exchange
-        _check(@ccall(LIB.hpcla_halo_end(halo::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_halo_end")
-        isempty(boundary) || _spmm_split_f32!(Crow, A, d, Brow, ghost, k, _ptr(boundary), Int64(length(boundary)))
+        # (every rank, with or without neighbours: the entry's first use is collective)
+        halo, interior, boundary, _, ghost, colval_split, rp0 =
+            _spmm_halo(A, plan, d, M.row_partition, k, (@ccall LIB.hpcla_spmv_rows_per_block()::Cint))
+        if halo == C_NULL
+            _spmm_split_f32!(Crow, A, rp0, colval_split, d.n_own, Brow, C_NULL, k, nothing)
+        else
+            _check(@ccall(LIB.hpcla_halo_begin_f32(halo::Ptr{Cvoid}, _ptr(Brow)::Ptr{Cvoid}, _ptr(_stage(d, d.n_own * k))::Ptr{Cvoid},
+                   _stream()::Ptr{Cvoid})::Cint), "hpcla_halo_begin_f32")
+            _spmm_split_f32!(Crow, A, rp0, colval_split, d.n_own, Brow, C_NULL, k, interior)   # overlaps the exchange
+            _check(@ccall(LIB.hpcla_halo_end(halo::Ptr{Cvoid}, _stream()::Ptr{Cvoid})::Cint), "hpcla_halo_end")
+            _spmm_split_f32!(Crow, A, rp0, colval_split, d.n_own, Brow, ghost, k, boundary)
+        end
     end
     C = ROCMatrix{Float32}(undef, A.nrows_local, k)
     _check(@ccall(LIB.hpcla_transpose_f32(_ptr(Crow)::Ptr{Cvoid}, k::Int64, 0::Cint, _ptr(C)::Ptr{Cvoid},
-           A.nrows_local::Int64, 1::Cint, A.nrows_local::Int64, k::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_transpose_f32")
-    return HPCLinearAlgebra.HPCMatrix_local(C, A.backend)
+           max(A.nrows_local, 1)::Int64, 1::Cint, A.nrows_local::Int64, k::Int64, _stream()::Ptr{Cvoid})::Cint), "hpcla_transpose_f32")
+    return _spmm_result(A, C, k)
 end
 
 function _reduce_f32(sym::Symbol, x::HPCVector{Float32}, y=nothing, negate::Int=0)
@@ -1062,14 +1351,14 @@ function _reduce_f32(sym::Symbol, x::HPCVector{Float32}, y=nothing, negate::Int=
     return _host_scalar(out, x.backend)              # a double; the callers round to Float32 once
 end
 function LinearAlgebra.dot(x::HPCVector{Float32,B}, y::HPCVector{Float32,B}) where {B<:ROCBackend}
-    x.structural_hash == y.structural_hash || (y = HPCLinearAlgebra.repartition(y, x.partition))
+    x.structural_hash == y.structural_hash || (y = HPCLinearAlgebra.repartition(y, x.partition))   # PCIe: all of y, both ways, ONLY when the partitions differ -- the parent's host-staged repartition (no Float32 device exchange in this file)
     return Float32(_reduce_f32(:dot, x, y))
 end
 function LinearAlgebra.norm(v::HPCVector{Float32,B}, p::Real=2) where {B<:ROCBackend}
     p == 2 && return Float32(sqrt(_reduce_f32(:nrm2sq, v)))
     p == 1 && return Float32(_reduce_f32(:asum, v))
     p == Inf && return Float32(_reduce_f32(:amax, v))
-    return invoke(LinearAlgebra.norm, Tuple{HPCVector,Real}, v, p)        # generic path of the parent
+    return invoke(LinearAlgebra.norm, Tuple{HPCVector,Real}, v, p)        # PCIe: parent's generic method (p other than 1, 2, Inf) -- whatever the array package's norm moves
 end
 Base.sum(v::HPCVector{Float32,B}) where {B<:ROCBackend} = Float32(_reduce_f32(:sum, v))
 Base.maximum(v::HPCVector{Float32,B}) where {B<:ROCBackend} = Float32(_reduce_f32(:max, v, nothing, 0))
@@ -1101,6 +1390,9 @@ function HPCLinearAlgebra.execute_plan!(plan::HPCLinearAlgebra.VectorPlan{T,Ti,<
     end
     halo, src, dst, perm, ident, _ = st
     s = _stream()
+    # (a plan of this file's VectorPlan constructor starts without its `gathered` buffer: A * x never reads it)
+    n_gathered = length(plan.local_dst_indices) + sum(length, plan.recv_perm; init=0)
+    length(plan.gathered) == n_gathered || (plan.gathered = similar(x.v, n_gathered))
     halo == C_NULL || _check(@ccall(LIB.hpcla_halo_begin(halo::Ptr{Cvoid}, _ptr(x.v)::Ptr{Cvoid}, s::Ptr{Cvoid})::Cint),
                              "hpcla_halo_begin")
     # the own part, under the exchange: 1-based lists as they stand (index_base = 1)
@@ -1130,11 +1422,12 @@ function clear_rocm_plan_cache!()
     for d in values(_rocm_plans); d isa ROCVectorPlan && destroy(d.halo); end
     for st in values(_spmm_plans); destroy(st[1]); end
     for st in values(_rocm_exec); destroy(st[1]); end
+    for st in values(_rocm_matexec); destroy(st[1]); end
     for d in values(_rocm_plans)    # the plans' rowptr copies carry the block-order hints: removed before the arrays go
         d isa ROCVectorPlan && @ccall LIB.hpcla_spmv_block_order_hint(_ptr(d.rowptr0)::Ptr{Cvoid}, 0::Cint)::Cint
-        d isa ROCVectorPlan && haskey(_spmm_cm_tuned, d) && @ccall LIB.hpcla_spmm_block_order_hint(_ptr(d.rowptr0)::Ptr{Cvoid}, 0::Cint)::Cint
     end
-    empty!(_rocm_plans); empty!(_spmm_plans); empty!(_rocm_exec); empty!(_merge_lists); empty!(_spmm_runs_cache); empty!(_stage32); empty!(_banded_cache); empty!(_spmm_cm_tuned)
+    for rp0 in keys(_spmm_order_in_force); @ccall LIB.hpcla_spmm_block_order_hint(_ptr(rp0)::Ptr{Cvoid}, 0::Cint)::Cint; end
+    empty!(_rocm_plans); empty!(_spmm_plans); empty!(_rocm_exec); empty!(_rocm_matexec); empty!(_merge_lists); empty!(_spmm_runs_cache); empty!(_stage32); empty!(_banded_cache); empty!(_spmm_cm_tuned); empty!(_spmm_order_in_force)
     empty!(_spgemm_cache)
     return nothing
 end
@@ -1197,7 +1490,7 @@ HPCLinearAlgebra.execute_subtraction!(nzval::ROCVector{Float64}, plan::HPCLinear
 function Base.:*(A::HPCMatrix{T,B}, x::HPCVector{T,B}) where {T<:Float64,B<:ROCBackend}
     # several ranks: the parent's method (src/dense.jl:614-658) gathers x through execute_plan!(::VectorPlan, x) --
     # the device exchange above -- and multiplies the local block with the array package's gemv
-    comm_size(A.backend.comm) == 1 || return invoke(Base.:*, Tuple{HPCMatrix,HPCVector}, A, x)
+    comm_size(A.backend.comm) == 1 || return invoke(Base.:*, Tuple{HPCMatrix,HPCVector}, A, x)   # PCIe: parent's method at N > 1 -- no host copy in its body: x arrives through this file's device execute_plan!
     nloc, n = size(A.A)
     y = AMDGPU.zeros(T, nloc)
     work = AMDGPU.zeros(UInt8, @ccall LIB.hpcla_gemv_t_work_bytes(n::Int64, nloc::Int64)::Int64)

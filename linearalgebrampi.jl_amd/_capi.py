@@ -53,8 +53,6 @@ _SIGNATURES = {
     "hpcla_spmv_longrows_work_bytes": [_i64],
     "hpcla_spmv_longrows_f64_i32": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _i64, _i64, _vp, _vp],
     "hpcla_spmv_longrows_f64_i64": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _i64, _i64, _vp, _vp],
-    "hpcla_set_spmv_kernel": [_i32],
-    "hpcla_get_spmv_kernel": [],
     "hpcla_spmv_block_order_hint": [_vp, _i32],
     "hpcla_spmv_tune_block_order_f64_i32": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp],
     "hpcla_spmv_tune_block_order_f64_i64": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp],

@@ -233,10 +233,16 @@ __global__ __launch_bounds__(64 * LPR) void spmm_rowblock_vec_kernel(
     static_assert(!CCOL || (CSTAGE && LPR == 4), "the column-major store goes through the LDS tile");
     __shared__ SpmmEntry s_ent[CHUNK_V];
 
+    // ODD k (round 6): lanes own column PAIRS, so an odd k is run as k + 1 columns -- the second column of the last pair is the
+    // padding double of the (even, > k: checked by the launcher) row pitch: loaded with its pair, summed in a register of its
+    // own, never stored (`kr`, the real column count, masks the stores).  Every real column is still one running sum in stored
+    // order: same bits.  From here on `k` is even.
+    const int kr = k;
+    k += k & 1;
     if (K16) {
-        // the device-native shape (k = 16, B / ghost / C rows of exactly 16 doubles: checked by the launcher): strides
-        // and the column-tile loop fold to constants (measured against a k = 16-only copy of this kernel in the tuning
-        // harness, benchmarks/tune/spmm_variants.hip MODE 0: the generic form ran 3 % behind it)
+        // the device-native shape (k = 16 -- or 15 on the pitch 16 --, B / ghost / C rows of exactly 16 doubles: checked by the
+        // launcher): strides and the column-tile loop fold to constants (measured against a k = 16-only copy of this kernel in
+        // the tuning harness, benchmarks/tune/spmm_variants.hip MODE 0: the generic form ran 3 % behind it)
         k = KT; b_rs = KT; bg_rs = KT;
         if (!CCOL) c_rs = KT;
     }
@@ -367,7 +373,7 @@ __global__ __launch_bounds__(64 * LPR) void spmm_rowblock_vec_kernel(
             __syncthreads();                               // every lane has finished reading the records
             double *s_c = reinterpret_cast<double *>(s_ent);
             static_assert(sizeof(SpmmEntry) * CHUNK_V >= sizeof(double) * RPB_MM * KT, "C tile fits the record area");
-            if (col_ok) {
+            if (col_ok) {                                  // (odd k: the padding column k <= 15 lands in the tile and stays there)
                 s_c[c * RPB_MM + g] = acc[0];
                 s_c[(c + 1) * RPB_MM + g] = acc[1];
                 if (two) {
@@ -377,7 +383,7 @@ __global__ __launch_bounds__(64 * LPR) void spmm_rowblock_vec_kernel(
             }
             __syncthreads();
             const vdouble2 *src = reinterpret_cast<const vdouble2 *>(s_c);
-            const int count = k * (RPB_MM / 2);
+            const int count = kr * (RPB_MM / 2);           // (the real columns: an odd k's padding column stays in the tile)
             if ((c_rs & 1) == 0) {
                 for (int i = tid; i < count; i += TPB) {
                     const int cc = i / (RPB_MM / 2), gp = (i % (RPB_MM / 2)) * 2;
@@ -386,7 +392,7 @@ __global__ __launch_bounds__(64 * LPR) void spmm_rowblock_vec_kernel(
                     else if (gp < nr) __builtin_nontemporal_store(src[i].x, dst);
                 }
             } else {                                       // odd leading dimension: columns start 8-byte aligned only
-                for (int i = tid; i < k * RPB_MM; i += TPB) {
+                for (int i = tid; i < kr * RPB_MM; i += TPB) {
                     const int cc = i / RPB_MM, gg = i % RPB_MM;
                     if (gg < nr) __builtin_nontemporal_store(s_c[i], C + (int64_t)cc * c_rs + r0 + gg);
                 }
@@ -402,6 +408,11 @@ __global__ __launch_bounds__(64 * LPR) void spmm_rowblock_vec_kernel(
             if (col_ok) {
                 vdouble2 o0, o1;
                 o0.x = acc[0]; o0.y = acc[1]; o1.x = acc[2]; o1.y = acc[3];
+                // odd k (the block's C rows are contiguous on the pitch k = kr + 1): the padding column leaves as 0.0 with its
+                // pair, so that the region is still written in WHOLE lines -- masking it out cost 0.72 ms against 0.52 on the
+                // 5-point matrix x 15 (a partial last sector per 128-byte row; profiles/r06_spmm_odd_k.log)
+                if (c + 1 == kr) o0.y = 0.0;
+                if (c + SECOND / 8 + 1 == kr) o1.y = 0.0;
                 *reinterpret_cast<vdouble2 *>(s_c + g * k + c) = o0;
                 if (two) *reinterpret_cast<vdouble2 *>(s_c + g * k + c + SECOND / 8) = o1;
             }
@@ -418,8 +429,13 @@ __global__ __launch_bounds__(64 * LPR) void spmm_rowblock_vec_kernel(
             double *dst = C + (r0 + g) * c_rs + c;
             vdouble2 o0, o1;
             o0.x = acc[0]; o0.y = acc[1]; o1.x = acc[2]; o1.y = acc[3];
-            *reinterpret_cast<vdouble2 *>(dst) = o0;
-            if (two) *reinterpret_cast<vdouble2 *>(dst + SECOND / 8) = o1;
+            // (c + 1 == k, c + 3 == k: the last pair of an odd k -- its second column does not exist in C)
+            if (c + 1 < kr) *reinterpret_cast<vdouble2 *>(dst) = o0;
+            else dst[0] = o0.x;
+            if (two) {
+                if (c + SECOND / 8 + 1 < kr) *reinterpret_cast<vdouble2 *>(dst + SECOND / 8) = o1;
+                else dst[SECOND / 8] = o1.x;
+            }
         }
     }
 }
@@ -946,11 +962,29 @@ static int spmm_launch(const I *rowptr, const I *colval, const double *nzval, co
     // device-native layout: row-major B / C, k even (16-byte column pairs), everything 16-byte aligned
     // ... or row-major B with a COLUMN-major C of up to one column tile (round 5: the column-major caller's unstructured
     // product; CCOL in the kernel): c_rs == 1, c_cs = C's leading dimension
-    const bool c_col = c_rs == 1 && c_cs != 1 && k <= KT && !accumulate && c_cs >= nrows;
-    const bool vec_ok = b_cs == 1 && (c_col || (c_cs == 1 && (c_rs % 2) == 0)) && (k % 2) == 0 && (b_rs % 2) == 0 &&
+    const bool c_colmajor = c_rs == 1 && c_cs != 1 && !accumulate && c_cs >= nrows;
+    const bool c_col = c_colmajor && k <= KT;
+    // ODD k (round 6) runs as k + 1 columns when every row pitch is even and LARGER than k: the last column pair's second
+    // half is the padding double of the row (read, never stored).  The B / ghost buffers must therefore span rows * pitch
+    // doubles (include/hpcla_rocm.h); a row-major C needs the same pitch rule for its 16-byte column pairs.
+    const bool odd_ok = (k % 2) == 0 || (b_rs > k && (!split || !B_ghost || bg_rs > k) && (c_colmajor || c_rs > k));
+    const bool vec_ok = b_cs == 1 && (c_colmajor || (c_cs == 1 && (c_rs % 2) == 0)) && odd_ok && (b_rs % 2) == 0 &&
                         (!split || (bg_rs % 2) == 0) &&
                         ((reinterpret_cast<uintptr_t>(B_own) | reinterpret_cast<uintptr_t>(C) |
                           (split ? reinterpret_cast<uintptr_t>(B_ghost) : 0)) & 15) == 0;
+    if (vec_ok && c_colmajor && !c_col) {
+        // column-major C wider than one column tile: one CCOL launch per 16-column tile (B rows are read at a 128-byte
+        // column offset, C at whole columns; A is re-streamed per tile -- against the generic strided kernel's one column
+        // per lane).  Every C(r, c) is the same running sum.
+        for (int kt = 0; kt < k; kt += KT) {
+            const int kk = k - kt < KT ? k - kt : KT;
+            const int rc = spmm_launch<I>(rowptr, colval, nzval, B_own + kt, b_rs, b_cs, B_ghost ? B_ghost + kt : nullptr, bg_rs,
+                                          n_own, split, C + (int64_t)kt * c_cs, c_rs, c_cs, nrows, nnz, kk, index_base,
+                                          block_list, n_blocks, stream, 0);
+            if (rc != HPCLA_OK) return rc;
+        }
+        return HPCLA_OK;
+    }
     if (vec_ok) {
         // records per LDS pass (HPCLA_SPMM_CHUNK = 512 | 1536; default by density: short rows fit the small pass)
         static const int chunk_env = [] {
@@ -973,11 +1007,12 @@ static int spmm_launch(const I *rowptr, const I *colval, const double *nzval, co
             const char *e = getenv("HPCLA_SPMM_LPR");
             return e ? atoi(e) : 0;
         }();
-        const int lpr = (k <= 8 && lpr_env != 4 && !c_col) ? 2 : 4;
-        const bool h64 = lpr == 4 && h64_env != 0 && (k % 16) == 0;
-        const bool cstage = c_col || (cst_env != 0 && k <= 4 * lpr && c_rs == k);
-        const bool k16 = h64 && cstage && k == KT && b_rs == KT && (!split || bg_rs == KT);
-        const bool tail2 = (k % 4) != 0;                 // even k: the last column pair of a row is half a lane's share
+        const int ke = k + (k & 1);                      // columns the lanes run (odd k: the padding column rides along)
+        const int lpr = (ke <= 8 && lpr_env != 4 && !c_col) ? 2 : 4;
+        const bool h64 = lpr == 4 && h64_env != 0 && (ke % 16) == 0;
+        const bool cstage = c_col || (cst_env != 0 && ke <= 4 * lpr && c_rs == ke);
+        const bool k16 = h64 && cstage && ke == KT && b_rs == KT && (!split || bg_rs == KT);
+        const bool tail2 = (ke % 4) != 0;                // the last column pair of a row is half a lane's share
         const int glog2 = spmm_group_log2(rowptr);
 #define HPCLA_SPMM_VEC(SP, CH, H64, CST, K16F, LPRV)                                                     \
     do {                                                                                                \
@@ -1104,8 +1139,9 @@ static int spmm_tune_block_order(const I *rowptr, const I *colval_split, const d
     if (nrows < 0 || nnz < 0 || k < 0 || !rowptr) return set_error(HPCLA_ERR_INVALID, "spmm_tune_block_order: bad arguments");
     set_spmm_block_order(rowptr, 0);
     const int64_t launch_blocks = block_list ? n_blocks : (nrows + RPB_MM - 1) / RPB_MM;
-    // small launches live in the caches; k = 1 is the SpMV; odd k takes the generic-stride kernel, which keeps the natural order
-    if (launch_blocks < 4096 || nnz == 0 || k < 2 || (k & 1)) return HPCLA_OK;
+    // small launches live in the caches; k = 1 is the SpMV; odd k on an odd pitch takes the generic-stride kernel, which keeps
+    // the natural order (odd k on an even pitch > k: the vec kernel, round 6 -- measured like every even k)
+    if (launch_blocks < 4096 || nnz == 0 || k < 2 || ((k & 1) && ((ldb_own & 1) || (ldc & 1)))) return HPCLA_OK;
     const bool split = B_ghost != nullptr;                   // no ghost segment: the unsplit instantiation, like hpcla_spmm_csr_*
     if (!C || !B_own) return set_error(HPCLA_ERR_INVALID, "spmm_tune_block_order: null B / C");
     const int cand[4] = {0, 4, 6, 8};
@@ -1198,7 +1234,8 @@ HPCLA_API int hpcla_spmm_split_f64_i64(const int64_t *rowptr, const int64_t *col
 }
 
 // row-major B rows (own block + ghost segment), COLUMN-major C (round 5): the unstructured product of a column-major caller
-// without the conversion of C (even k <= 16: the vec kernel's CCOL store; anything else: the generic strided kernel)
+// without the conversion of C (the vec kernel's CCOL store, one launch per 16-column tile; odd k: on an even B pitch > k;
+// anything else: the generic strided kernel)
 HPCLA_API int hpcla_spmm_split_ccol_f64_i32(const int32_t *rowptr, const int32_t *colval_split,
                                             const double *nzval, const double *B_own, int64_t ldb_own,
                                             const double *B_ghost, int64_t ldb_ghost, int64_t n_own,

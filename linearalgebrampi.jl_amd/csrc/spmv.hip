@@ -2,22 +2,21 @@
 //
 // Replaces the reference's one-work-item-per-row KernelAbstractions kernel
 // (_spmv_kernel!, src/sparse.jl:2055-2066), whose lanes read nzval/colval with a stride of one
-// row length (uncoalesced).  Design ("row-block stream"):
+// row length (uncoalesced).  Design ("row-block stream", row-gather form since round 4):
 //
-//   * a 256-thread workgroup owns RPB = 256 consecutive rows; the nonzeros of those rows are one
-//     contiguous range [p0,p1) of colval/nzval, which the whole workgroup streams with perfectly
-//     coalesced 16-byte loads (a lane reads one aligned quad of 4 entries: one colval load, two
-//     nzval loads), CHUNK = 2048 entries per pass;
-//   * each streamed entry is multiplied with its gathered x value (an L1/L2 hit for stencil-like
-//     matrices) and the PRODUCT is parked in LDS;
-//   * thread t then adds up the products of row t from LDS, sequentially, in stored order.
+//   * a 256-thread workgroup owns RPB = 256 consecutive rows, each WAVE 64 of them; the nonzeros of a wave's
+//     rows are one contiguous range of colval/nzval, which the wave streams into its own slice of LDS with
+//     coalesced 16-byte loads (spmv_rowgather_kernel below);
+//   * lane t then walks ITS OWN row out of LDS: gather instruction j of a wave reads the j-th entry of 64
+//     consecutive rows -- for a banded / stencil matrix one x stream of 512 contiguous bytes;
+//   * the row sum is the reference's multiply-add chain in stored order.
 //
 // The sum therefore runs in exactly the reference's order with a separately rounded multiply and
 // add (this file is compiled with -ffp-contract=off): results are bit-identical to the reference
 // loop, not merely within tolerance.  No MFMA: 2 flop per 12 bytes is a bandwidth-bound gather.
 //
 // HBM traffic per row block = the algorithmic bytes: 12 B/nnz (int32) + 4 B/row rowptr + 8 B/row y
-// (+ x once).  Rows longer than CHUNK are handled by the chunk loop (the row's running sum is
+// (+ x once).  Rows longer than a pass are handled by the pass loop (the row's running sum is
 // carried in a register), so there is no row-length limit and no preprocessing.
 //
 // Measured choices (benchmarks/tune_spmv.py, tune_spmv_lib.py; profiles/): 16-byte loads beat
@@ -25,10 +24,11 @@
 // moving window over the matrix beats one slice per XCD (DRAM pages and the x window stay hot for all 8
 // XCDs through the 256 MiB Infinity Cache) -- WITHIN that window the row blocks are dealt to the XCDs in
 // groups whose size is measured per matrix at plan time (xcd_group_index, hpcla_spmv_tune_block_order_*);
-// a software-pipelined persistent variant loses to plain high occupancy (8 workgroups per CU) with whole
-// waves skipping the quads past the end of a row block.  Round 3: every pass but the matrix's very last
-// runs as straight-line wave passes (quad_pass_whole): the general pass's per-entry tail path forced a
-// vmcnt(0) between the two quads of every pass (profiles/r03_spmv_straight_line_pass.log).
+// a software-pipelined persistent variant loses to plain high occupancy.
+// Rounds 1-3 shipped a product-parking "quad" kernel (a lane owned four consecutive stored entries and parked
+// their products in LDS); it lost to the row gather on every measured matrix from round 4 on (-1.5 ... -4.8 %,
+// profiles/r04_spmv_rowg.log) and was retired in round 6 with its switch (hpcla_set_spmv_kernel,
+// HPCLA_SPMV_KERNEL); the history of its tuning is in profiles/MEASUREMENTS_r01_r02.md / _r03.md.
 #include <stdlib.h>
 #include <string.h>
 
@@ -39,28 +39,14 @@
 #include "common.h"
 #include "halo_wait.h"
 
-// occupancy hint of the quad kernel: the split-column instantiations need the register cap spelled out to stay at 8
-// waves per SIMD; the plain ones reach <= 64 VGPRs on their own and schedule better without it (measured, both ways)
-#define HPCLA_SPMV_ATTRS __attribute__((amdgpu_waves_per_eu(SPLIT ? 8 : 4, 8)))
-
 namespace hpcla {
 
 constexpr int RPB = 256;      // rows per block == threads per block
-constexpr int QUADS = 2;      // aligned 4-entry quads per lane per pass
-constexpr int CHUNK = RPB * 4 * QUADS;   // 2048 products parked in LDS per pass (16 KiB)
-constexpr int UNROLL = CHUNK / RPB;      // narrow fallback: entries per lane per pass
+constexpr int CHUNK = RPB * 8;           // unaligned fallback kernel: 2048 products parked in LDS per pass (16 KiB)
+constexpr int UNROLL = CHUNK / RPB;      // ... entries per lane per pass
 
 template <typename T, int N>
 using vec = T __attribute__((ext_vector_type(N)));
-
-template <bool SPLIT>
-__device__ __forceinline__ const double *gather_ptr(const double *__restrict__ x_own,
-                                                    const double *__restrict__ x_ghost,
-                                                    int64_t n_own, int64_t col)
-{
-    if (SPLIT) return col < n_own ? x_own + col : x_ghost + (col - n_own);
-    return x_own + col;
-}
 
 template <bool SPLIT>
 __device__ __forceinline__ double gather_x(const double *__restrict__ x_own,
@@ -137,160 +123,8 @@ __device__ __forceinline__ void block_dot_epilogue(double *s_scratch, double *__
     if (threadIdx.x == 0) dot_partial[blk] = ((s_scratch[0] + s_scratch[1]) + s_scratch[2]) + s_scratch[3];
 }
 
-// One pass of a WAVE over NQ aligned quads per lane, all of them inside the arrays: STRAIGHT-LINE code, no lane
-// predicate anywhere.  Order: the column quads leave first; as they land the x gathers leave; then the value loads
-// (needed last; a scheduling barrier keeps them behind the gathers), so the dependent chain columns -> x is two round
-// trips and the registers hold either columns + addresses or gathered x + values, never all of them (<= 64 VGPRs, 8
-// workgroups per CU).  Lanes whose quad starts at or beyond n re-read the pass's last quad (lines their neighbours
-// read anyway) and park their unused products in their own slots of s_prod, which the row sums never read.
-// Rounds 1-2 shipped one general pass with a per-entry tail path for the last quad of the matrix inside per-lane
-// branches: the tail loads target the same registers as the full-quad loads, so the compiler put vmcnt(0) between
-// them -- every pass's second quad waited for the first quad's round trip, and its gathers for the first quad's
-// gathers (profiles/r03_spmv_straight_line_pass.log: -2.1 % / -3.0 % plain 2-D / 3-D, -4.5 % with the x.y epilogue).
-template <typename I, bool SPLIT, int NQ>
-__device__ __forceinline__ void quad_pass_whole(const I *__restrict__ colval, const double *__restrict__ nzval,
-                                                const double *__restrict__ x_own, const double *x_ghost, int64_t n_own,
-                                                int base, int n, int tid, double *s_prod)
-{
-    const int last = (n - 1) & ~3;
-    int e[NQ];
-    vec<I, 4> col[NQ];
-    vec<double, 2> va[NQ], vb[NQ];
-#pragma unroll
-    for (int u = 0; u < NQ; ++u) {
-        const int e0 = (u * RPB + tid) * 4;
-        e[u] = e0 < last ? e0 : last;
-    }
-#pragma unroll
-    for (int u = 0; u < NQ; ++u) col[u] = *reinterpret_cast<const vec<I, 4> *>(colval + e[u]);
-    const double *xp[NQ][4];
-#pragma unroll
-    for (int u = 0; u < NQ; ++u) {            // columns are >= base: the subtraction stays in the index type
-        xp[u][0] = gather_ptr<SPLIT>(x_own, x_ghost, n_own, (int64_t)(I)(col[u].x - (I)base));
-        xp[u][1] = gather_ptr<SPLIT>(x_own, x_ghost, n_own, (int64_t)(I)(col[u].y - (I)base));
-        xp[u][2] = gather_ptr<SPLIT>(x_own, x_ghost, n_own, (int64_t)(I)(col[u].z - (I)base));
-        xp[u][3] = gather_ptr<SPLIT>(x_own, x_ghost, n_own, (int64_t)(I)(col[u].w - (I)base));
-    }
-    double xv[NQ][4];
-#pragma unroll
-    for (int u = 0; u < NQ; ++u)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) xv[u][k] = *xp[u][k];
-    __builtin_amdgcn_sched_barrier(0);
-    // the values leave AFTER the gathers: they are needed last, and the chain col -> x stays two round trips long
-    // while the registers hold either columns + addresses or gathered x + values, never all of them
-#pragma unroll
-    for (int u = 0; u < NQ; ++u) {
-        va[u] = *reinterpret_cast<const vec<double, 2> *>(nzval + e[u]);
-        vb[u] = *reinterpret_cast<const vec<double, 2> *>(nzval + e[u] + 2);
-    }
-#pragma unroll
-    for (int u = 0; u < NQ; ++u) {
-        const int e0 = (u * RPB + tid) * 4;
-        vec<double, 2> pa2, pb2;
-        pa2.x = va[u].x * xv[u][0];
-        pa2.y = va[u].y * xv[u][1];
-        pb2.x = vb[u].x * xv[u][2];
-        pb2.y = vb[u].y * xv[u][3];
-        // unconditional: a conditional store would let the compiler sink this quad's loads behind the branch
-        *reinterpret_cast<vec<double, 2> *>(&s_prod[e0]) = pa2;
-        *reinterpret_cast<vec<double, 2> *>(&s_prod[e0 + 2]) = pb2;
-    }
-}
-
-// ---- primary kernel: aligned quads (needs colval 4*sizeof(I)- and nzval 32-byte aligned) -----------
-template <typename I, bool SPLIT, bool WAIT>
-__global__ __launch_bounds__(RPB) HPCLA_SPMV_ATTRS void spmv_rowblock_quad_kernel(
-    const I *__restrict__ rowptr, const I *__restrict__ colval, const double *__restrict__ nzval,
-    const double *__restrict__ x_own, const double *x_ghost, int64_t n_own,
-    double *__restrict__ y, int64_t nrows, int64_t nnz, int base,
-    BlockSel bs, double *__restrict__ dot_partial, HaloWait hw, PushArgs push)
-{
-    __shared__ double s_prod[CHUNK];
-
-    // fused distributed launch: the leading workgroups ARE the halo push (this rank's boundary values go
-    // straight into the neighbours' ghost windows while the interior blocks below already stream)
-    if (WAIT && (int)blockIdx.x < push.n_blocks) {
-        halo_push_block<I, RPB>(push, (int)blockIdx.x);
-        return;
-    }
-    const int tid = threadIdx.x;
-    // a contiguous run of row blocks is addressed by its base (no per-workgroup list load on the
-    // critical path rowptr -> A -> x); arbitrary subsets go through the list
-    bool wait_ghosts;
-    const int64_t blk = select_block<WAIT>(bs, wait_ghosts, WAIT ? push.n_blocks : 0);
-    // boundary workgroup of a fused distributed launch (workgroup-uniform branch): the ghosts may be read once
-    // every neighbour has published this step; the buffer of the step's epoch is computed here, uniformly, so
-    // the loop below is the same code as in the plain kernel
-    uint32_t waited = 0;
-    if (WAIT && wait_ghosts) {     // reader index: the plan's push workgroups come first (window.hip), then the boundary blocks
-        waited = halo_wait_block(hw, hw.first_wait_reader + (uint32_t)(blockIdx.x - push.n_blocks - bs.n_first));
-        x_ghost = hw.ghost0 + (int64_t)(waited & ~HALO_WAIT_TIMED_OUT) * hw.buf_stride;
-    }
-    const int64_t r0 = blk * RPB;
-    const int nr = (int)((nrows - r0) < RPB ? (nrows - r0) : RPB);
-    if (WAIT && (waited & HALO_WAIT_TIMED_OUT)) {
-        // the neighbours' values never arrived (wait expired): this block's rows are POISONED, never computed from
-        // stale ghosts (workgroup-uniform branch, taken before the row loop: no register held across it)
-        if ((int)threadIdx.x < nr) y[r0 + threadIdx.x] = halo_poison();
-        if (dot_partial && threadIdx.x == 0) dot_partial[blk] = halo_poison();
-        return;
-    }
-
-    const int64_t p0 = (int64_t)rowptr[r0] - base;
-    const int64_t p1 = (int64_t)rowptr[r0 + nr] - base;
-    const int64_t pa = p0 & ~(int64_t)3;          // quad-aligned start (<= 3 entries of the previous block)
-    const int64_t total = p1 - pa;
-
-    // this thread's row, relative to pa
-    I rlo = 0, rhi = 0;                      // raw values: the subtraction (first use) sits in the reduce phase, so the
-    if (tid < nr) {                          // round trip of this load runs under the A stream instead of before it
-        rlo = rowptr[r0 + tid];
-        rhi = rowptr[r0 + tid + 1];
-    }
-
-    // fused x.y epilogue: fetch x at this lane's row NOW, so the load rides along with the stream instead of
-    // adding a dependent memory round trip at the tail of every workgroup (CG iteration kernel 352 -> 348 us)
-    double x_row = 0.0;
-    if (dot_partial && tid < nr) x_row = x_own[r0 + tid];
-
-    double acc = 0.0;
-    for (int64_t c = 0; c < total; c += CHUNK) {
-        const int n = (int)((total - c) < CHUNK ? (total - c) : CHUNK);
-
-        // Every quad of this pass lies inside the arrays (workgroup-uniform; true for all passes but the very last
-        // of the matrix): each WAVE runs one straight-line pass over the quads it has (wave-uniform choice).
-        if (pa + c + ((n + 3) & ~3) <= nnz) {
-            const int wave_e0 = (__builtin_amdgcn_readfirstlane(tid) & ~63) * 4;
-            if (QUADS == 2 && wave_e0 + RPB * 4 < n)
-                quad_pass_whole<I, SPLIT, 2>(colval + pa + c, nzval + pa + c, x_own, x_ghost, n_own, base, n, tid, s_prod);
-            else if (wave_e0 < n)
-                quad_pass_whole<I, SPLIT, 1>(colval + pa + c, nzval + pa + c, x_own, x_ghost, n_own, base, n, tid, s_prod);
-        } else {
-            // the one pass of the launch whose last quad reaches past the end of the arrays: entry by entry
-            for (int e = tid; e < n; e += RPB) {
-                const int64_t g = pa + c + e;
-                s_prod[e] = g < nnz ? nzval[g] * gather_x<SPLIT>(x_own, x_ghost, n_own, (int64_t)(I)(colval[g] - (I)base)) : 0.0;
-            }
-        }
-        __syncthreads();
-
-        // reduce phase: sequential, stored order (== reference order)
-        {
-            const int lo = tid < nr ? (int)((int64_t)rlo - base - pa) : 0;
-            const int hi = tid < nr ? (int)((int64_t)rhi - base - pa) : 0;
-            const int a = lo > c ? lo : (int)c;
-            const int e = hi < c + n ? hi : (int)(c + n);
-            for (int j = a; j < e; ++j) acc += s_prod[j - c];
-        }
-        __syncthreads();
-    }
-    if (tid < nr) y[r0 + tid] = acc;
-    if (dot_partial) block_dot_epilogue(s_prod, dot_partial, blk, tid < nr ? acc * x_row : 0.0);
-}
-
 // ---- round 4: gathers issued BY ROW ("row gather"), from a wave-private LDS copy of the A entries -------------------
-// Counters of the product-parking kernel above on the 7-point matrix against the 5-point one
+// Counters of the product-parking quad kernel of rounds 1-3 on the 7-point matrix against the 5-point one
 // (profiles/r04_spmv_2d_vs_3d_counters.txt): per stored entry 6.2 x the L1 tag-conflict stall cycles
 // (TCP_READ_TAGCONFLICT_STALL_CYCLES: 21 % of the launch per TCP against 3.5 %), 1.6 x the cycles the address unit waits for
 // the cache, 1.6 x the issue stalls -- while LDS conflicts, TLB misses, L2 misses and HBM requests per entry are equal
@@ -305,7 +139,7 @@ __global__ __launch_bounds__(RPB) HPCLA_SPMV_ATTRS void spmv_rowblock_quad_kerne
 // in order, so the kernel has no workgroup barrier at all (the dot epilogue and the halo wait keep theirs) -- and the
 // 256-row block of the callers' block lists, of the p.Ap partials and of the packed copy stays what it was.
 // Harness (benchmarks/tune/spmv_variants.hip k_rowg / k_rowg_wave, profiles/r04_spmv_rowg.log): 7-point slab -4.3 ... -4.8 %,
-// 4096^2 -1.5 %, 8192^2 -2.2 % against the kernel above under its measured block order.
+// 4096^2 -1.5 %, 8192^2 -2.2 % against the quad kernel under its measured block order.
 constexpr int RG_CHW = 464;                         // entries per wave and pass: 64 rows x 7 + the <= 3 entries in front of the aligned start, rounded up (5.4 KiB of LDS per wave: 7 workgroups per CU)
 constexpr int RG_NQ = (RG_CHW / 4 + 63) / 64;       // quads per lane per pass
 constexpr int RG_UR = 8;                            // entries per gather step
@@ -697,20 +531,6 @@ static int block_order_of(const void *rowptr)
     return it == g_order.end() ? 0 : it->second;
 }
 
-// HPCLA_SPMV_KERNEL = rowgather (default, round 4) | quad (the product-parking kernel of rounds 1-3), or
-// hpcla_set_spmv_kernel() at run time (A/B measurements inside one process): same bits either way
-static std::atomic<int> g_spmv_kernel{-1};          // -1: not decided yet, 0: row gather, 1: quad
-static bool use_rowgather()
-{
-    int k = g_spmv_kernel.load(std::memory_order_relaxed);
-    if (k < 0) {
-        const char *e = getenv("HPCLA_SPMV_KERNEL");
-        k = (e && (e[0] == 'q' || e[0] == 'Q')) ? 1 : 0;
-        g_spmv_kernel.store(k, std::memory_order_relaxed);
-    }
-    return k == 0;
-}
-
 // Store policy of y (row-gather kernel): NON-TEMPORAL by default (HPCLA_SPMV_NT_Y=0: plain stores).  y is written once per
 // launch and read by nothing inside it, so its lines only displace x and A lines from L2 / Infinity Cache; measured with
 // alternating processes on one box (profiles/r04_spmv_nontemporal_y.log): headline 0.2309 / 0.2276 -> 0.2153 / 0.2156 ms
@@ -759,7 +579,7 @@ static int spmv_launch(const I *rowptr, const I *colval, const double *nzval, co
     hipStream_t s = as_stream(stream);
     // no ghost segment => no column can be >= n_own: take the plain-x kernel (no per-entry select)
     if (split && !x_ghost) split = false;
-    // quad kernel: a 4-entry quad must never straddle a page -> colval 4*sizeof(I)-, nzval 32-byte aligned
+    // 16-byte staging loads from any quad-aligned entry offset: colval 4*sizeof(I)-, nzval 32-byte aligned (else: the fallback kernel)
     const bool aligned = (reinterpret_cast<uintptr_t>(colval) % (4 * sizeof(I)) == 0) &&
                          (reinterpret_cast<uintptr_t>(nzval) % 32 == 0);
     const BlockSel bs{block_list, block_base, nullptr, 0, 0, launch_blocks, block_list ? 0 : block_order_of(rowptr),
@@ -768,19 +588,12 @@ static int spmv_launch(const I *rowptr, const I *colval, const double *nzval, co
     memset(&nowait, 0, sizeof(nowait));
     PushArgs nopush;
     memset(&nopush, 0, sizeof(nopush));
-    if (aligned && use_rowgather()) {
+    if (aligned) {
         if (split)
             spmv_rowgather_kernel<I, true, false><<<grid, block, 0, s>>>(
                 rowptr, colval, nzval, x_own, x_ghost, n_own, y, nrows, nnz, index_base, bs, dot_partial, nowait, nopush);
         else
             spmv_rowgather_kernel<I, false, false><<<grid, block, 0, s>>>(
-                rowptr, colval, nzval, x_own, nullptr, 0, y, nrows, nnz, index_base, bs, dot_partial, nowait, nopush);
-    } else if (aligned) {
-        if (split)
-            spmv_rowblock_quad_kernel<I, true, false><<<grid, block, 0, s>>>(
-                rowptr, colval, nzval, x_own, x_ghost, n_own, y, nrows, nnz, index_base, bs, dot_partial, nowait, nopush);
-        else
-            spmv_rowblock_quad_kernel<I, false, false><<<grid, block, 0, s>>>(
                 rowptr, colval, nzval, x_own, nullptr, 0, y, nrows, nnz, index_base, bs, dot_partial, nowait, nopush);
     } else {
         if (split)
@@ -827,11 +640,8 @@ static int spmv_launch_fused(const I *rowptr, const I *colval, const double *nzv
                          (reinterpret_cast<uintptr_t>(nzval) % 32 == 0);
     const BlockSel bs{boundary_list, 0, interior_list, interior_base, n_interior, n_interior,
                       interior_list ? 0 : block_order_of(rowptr), spmv_nt_y(dot_partial != nullptr)};
-    if (aligned && use_rowgather())
+    if (aligned)
         spmv_rowgather_kernel<I, true, true><<<grid, block, 0, s>>>(
-            rowptr, colval, nzval, x_own, x_ghost, n_own, y, nrows, nnz, index_base, bs, dot_partial, hw, pa);
-    else if (aligned)
-        spmv_rowblock_quad_kernel<I, true, true><<<grid, block, 0, s>>>(
             rowptr, colval, nzval, x_own, x_ghost, n_own, y, nrows, nnz, index_base, bs, dot_partial, hw, pa);
     else
         spmv_rowblock_kernel<I, true, true><<<grid, block, 0, s>>>(
@@ -884,15 +694,6 @@ int spmv_split_i64(const int64_t *rowptr, const int64_t *colval, const double *n
 using namespace hpcla;
 
 HPCLA_API int hpcla_spmv_rows_per_block(void) { return RPB; }
-
-HPCLA_API int hpcla_get_spmv_kernel(void) { return use_rowgather() ? 0 : 1; }
-
-HPCLA_API int hpcla_set_spmv_kernel(int kind)
-{
-    if (kind != 0 && kind != 1) return set_error(HPCLA_ERR_INVALID, "set_spmv_kernel: 0 = row gather, 1 = quad");
-    g_spmv_kernel.store(kind, std::memory_order_relaxed);
-    return HPCLA_OK;
-}
 
 static void set_block_order(const void *rowptr, int group_log2)
 {

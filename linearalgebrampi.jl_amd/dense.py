@@ -313,8 +313,34 @@ def clear_spmm_cache() -> None:
     _spmm_halo_cache.clear()
 
 
-def _spmm_plan(A, B: HPCMatrix):
-    """(vector plan, width-k exchange entry) for ``A * B``: the vector plan for (A, B's row partition) provides the
+def spmm_pitch(A, k: int) -> int:
+    """Row pitch (in values) of the row-major B / ghost / C blocks of ``A * B``: k -- or k + 1 for an ODD k >= 3 of the
+    sequential Float64 product (round 6): the 16-byte vector kernel owns column pairs, so an odd k runs on the even pitch
+    with the last pair's second half masked (csrc/spmm.hip; 5-point matrix x 15: 0.946 ms on the one-column-per-lane kernel
+    the odd pitch falls to, against 0.475 for 16).  Ghost rows travel on the same pitch (one padding double per row).  A
+    function of (element type, k, HPCLA_SPMM_ORDER) only, so every rank of a communicator computes the same width."""
+    if k >= 3 and (k & 1) and A.T == np.dtype(np.float64) and spmm_order() != "panel":
+        return k + 1
+    return k
+
+
+def _rows_on_pitch(M, pitch: int):
+    """The rows of the (n, k) block ``M`` as a device tensor whose row stride is exactly ``pitch`` and whose base is 16-byte
+    aligned: M itself when it already is (the products of this module allocate their results that way), else one copy."""
+    torch = _torch()
+    n, k = int(M.shape[0]), int(M.shape[1])
+    if pitch == k:
+        return M.contiguous()
+    if n > 0 and M.stride(1) == 1 and M.stride(0) == pitch and M.data_ptr() % 16 == 0:
+        return M
+    buf = torch.empty((n, pitch), dtype=M.dtype, device=M.device)
+    buf[:, :k] = M
+    return buf
+
+
+def _spmm_plan(A, B: HPCMatrix, width=None):
+    """(vector plan, exchange entry) for ``A * B``; ``width`` = values per exchanged row (default: ``spmm_pitch(A, k)`` --
+    k, or k + 1 for an odd k; a caller that drives the exchange from column-major blocks passes k). the vector plan for (A, B's row partition) provides the
     neighbour lists, the split colval and the blocks; the width-k halo plan hangs off the same key plus k.
     Entry = (halo handle | None, interior blocks, boundary blocks, send_idx, colval_split, ghost pointer, n_ghost rows,
     send rows, peers, lists, entry_is_i64).  ``entry_is_i64``: index type of THIS entry's kernel arrays -- the vector
@@ -326,6 +352,7 @@ def _spmm_plan(A, B: HPCMatrix):
     backend = A.backend
     dev = backend.torch_device
     k = int(B.A.shape[1])
+    kw = spmm_pitch(A, k) if width is None else int(width)     # values per exchanged row: k, or the padded pitch of an odd k
     probe = HPCVector(compute_partition_hash(B.row_partition), B.row_partition,
                       B.A[:, 0] if k > 0 else torch.empty(0, dtype=torch.float64, device=dev), backend)
     plan = get_vector_plan(A, probe)
@@ -335,7 +362,7 @@ def _spmm_plan(A, B: HPCMatrix):
     if nranks == 1 or k == 0:
         return plan, None
     s = current_stream_ptr()
-    key = (A._ensure_hash(), probe.structural_hash, k, plan.is_i64, str(A.T))
+    key = (A._ensure_hash(), probe.structural_hash, kw, plan.is_i64, str(A.T))
     _spmm_backends[id(backend)] = backend
     ent = _spmm_halo_cache.get(key)
     if ent is None:
@@ -378,9 +405,9 @@ def _spmm_plan(A, B: HPCMatrix):
             # of the PREVIOUS exchange)
             _capi.check("hpcla_halo_plan_create_ex", _capi.load().hpcla_halo_plan_create_ex(
                 ctypes.byref(halo), backend.rccl, n_send, send_ranks, send_counts, dptr(send_idx),
-                1 if ent_i64 else 0, n_recv, recv_ranks, recv_counts, k, _capi.HALO_SINGLE_BUFFER))
+                1 if ent_i64 else 0, n_recv, recv_ranks, recv_counts, kw, _capi.HALO_SINGLE_BUFFER))
             bp = np.asarray(B.row_partition, dtype=np.int64)
-            wprobe = (plan.n_own, k, [(r, np.arange(bp[r + 1] - bp[r]) if wish[r] else A.col_indices[perm] - bp[r])
+            wprobe = (plan.n_own, kw, [(r, np.arange(bp[r + 1] - bp[r]) if wish[r] else A.col_indices[perm] - bp[r])
                                      for r, perm in zip(h.recv_rank_ids, h.recv_perm)])
             attach_halo_windows(backend, halo, wprobe)  # collective: push transport when all ranks share a node
             # SpMM row blocks are smaller than SpMV row blocks: classify at SpMM granularity (the Float32 product, csrc/f32.hip,
@@ -563,7 +590,8 @@ def spmm_exchange_bytes(A, B: HPCMatrix):
     _, ent = _spmm_plan(A, B)
     if ent is None or ent[0] is None:
         return 0, 0, 0, 0
-    return ent[6] * k * 8, ent[7] * k * 8, ent[8][0], ent[8][1]
+    kw = spmm_pitch(A, k)                      # what travels per row: k values, or the padded pitch of an odd k
+    return ent[6] * kw * 8, ent[7] * kw * 8, ent[8][0], ent[8][1]
 
 
 def _spmm_apply_order(plan, rowptr, k: int) -> None:
@@ -582,7 +610,7 @@ def _spmm_apply_order(plan, rowptr, k: int) -> None:
         in_force[ptr] = want
 
 
-def _spmm_block_order(A, plan, rowptr, colval_split, is_i64, Bc, ghost, C, k, blocks) -> int:
+def _spmm_block_order(A, plan, rowptr, colval_split, is_i64, Bc, ghost, C, k, blocks, pitch=None) -> int:
     """Block order of the SpMM launches over this structure, MEASURED once per (plan, k) after the first product
     (``hpcla_spmm_tune_block_order_*``: the plan's own launch -- contiguous, or the larger of its two block lists --
     under natural / 16 / 64 / 256-block XCD groups; every timed launch rewrites C with the same complete product).
@@ -592,6 +620,7 @@ def _spmm_block_order(A, plan, rowptr, colval_split, is_i64, Bc, ghost, C, k, bl
     key = (k, rowptr.data_ptr())
     if key in cache:
         return cache[key]
+    pitch = k if pitch is None else pitch      # row pitch of Bc / the ghost segment / C (k + 1 for an odd k)
     want = os.environ.get("HPCLA_SPMM_BLOCK_ORDER", "auto").strip().lower()
     group = 1
     if want.isdigit():
@@ -602,7 +631,7 @@ def _spmm_block_order(A, plan, rowptr, colval_split, is_i64, Bc, ghost, C, k, bl
         chosen = ctypes.c_int(1)
         try:
             _capi.call(f"hpcla_spmm_tune_block_order_f64_{sfx}", dptr(rowptr), dptr(colval_split), dptr(A.nzval),
-                       dptr(Bc), k, ghost, k, plan.n_own, dptr(C), k, A.nrows_local, A.nnz, k, 0,
+                       dptr(Bc), pitch, ghost, pitch, plan.n_own, dptr(C), pitch, A.nrows_local, A.nnz, k, 0,
                        dptr(blocks) if blocks is not None else None, int(blocks.numel()) if blocks is not None else 0,
                        current_stream_ptr(), ctypes.byref(chosen))
             group = int(chosen.value)
@@ -701,12 +730,16 @@ def spmm(A, B: HPCMatrix) -> HPCMatrix:
     dev = backend.torch_device
     k = int(B.A.shape[1])
     plan, ent = _spmm_plan(A, B)
-    C = torch.empty((A.nrows_local, k), dtype=B.A.dtype, device=dev)
+    # row pitch of B's rows, the ghost rows and C: k, or k + 1 for an odd k (spmm_pitch; the result's block is then the
+    # (rows, k) view of a (rows, k + 1) buffer, which the next product takes as it is)
+    kw = spmm_pitch(A, k)
+    Cbuf = torch.empty((A.nrows_local, kw), dtype=B.A.dtype, device=dev)
+    C = Cbuf if kw == k else Cbuf[:, :k]
     out = HPCMatrix(plan.result_partition, uniform_partition(k, comm_size(backend.comm)), C, backend)
     if k == 0:                       # (a rank without local rows still takes part in the exchange below)
         return out
     s = current_stream_ptr()
-    Bc = B.A.contiguous()
+    Bc = _rows_on_pitch(B.A, kw)
     if A.T == np.dtype(np.float32):
         _spmm_f32(A, plan, ent, Bc, C, k, s)
         return out
@@ -726,9 +759,9 @@ def spmm(A, B: HPCMatrix) -> HPCMatrix:
             return out
         _spmm_apply_order(plan, plan.rowptr_of(A), k)
         _capi.call(f"hpcla_spmm_csr_f64_{sfx}", dptr(plan.rowptr_of(A)), dptr(plan.colval_split),
-                   dptr(A.nzval), dptr(Bc), k, _capi.LAYOUT_ROW, dptr(C), k, _capi.LAYOUT_ROW,
+                   dptr(A.nzval), dptr(Bc), kw, _capi.LAYOUT_ROW, dptr(Cbuf), kw, _capi.LAYOUT_ROW,
                    A.nrows_local, A.nnz, k, 0, s)
-        _spmm_block_order(A, plan, plan.rowptr_of(A), plan.colval_split, plan.is_i64, Bc, None, C, k, None)
+        _spmm_block_order(A, plan, plan.rowptr_of(A), plan.colval_split, plan.is_i64, Bc, None, Cbuf, k, None, kw)
         return out
     halo, interior, boundary, _, colval_split, ghost = ent[:6]
     sfx = "i64" if ent[10] else "i32"
@@ -741,7 +774,7 @@ def spmm(A, B: HPCMatrix) -> HPCMatrix:
                        plan.n_own, dptr(C), A.nrows_local, A.nnz, 0, dptr(runs), dptr(blocks), int(blocks.numel()), s)
         else:
             _capi.call(f"hpcla_spmm_split_f64_{sfx}", dptr(rowptr), dptr(colval_split),
-                       dptr(A.nzval), dptr(Bc), k, ghost, k, plan.n_own, dptr(C), k, A.nrows_local,
+                       dptr(A.nzval), dptr(Bc), kw, ghost, kw, plan.n_own, dptr(Cbuf), kw, A.nrows_local,
                        A.nnz, k, 0, dptr(blocks), int(blocks.numel()), s)
     if runs is None:
         _spmm_apply_order(plan, rowptr, k)
@@ -754,6 +787,6 @@ def spmm(A, B: HPCMatrix) -> HPCMatrix:
     if runs is not None:
         return out
     # (local launches only -- no exchange: the ranks need not agree on the order, every order is a bijection)
-    _spmm_block_order(A, plan, rowptr, colval_split, bool(ent[10]), Bc, ghost, C, k,
-                      boundary if boundary.numel() >= interior.numel() else interior)
+    _spmm_block_order(A, plan, rowptr, colval_split, bool(ent[10]), Bc, ghost, Cbuf, k,
+                      boundary if boundary.numel() >= interior.numel() else interior, kw)
     return out

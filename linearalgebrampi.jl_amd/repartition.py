@@ -149,7 +149,7 @@ def repartition_dense(A, p):
     k = int(A.A.shape[1])
     out = torch.empty((plan.result_local_size, k), dtype=torch.float64, device=A.A.device)
     if k > 0:
-        _execute_rows(plan, A.backend, A.A, out, k)                  # row-major: a row range is one run
+        _execute_rows(plan, A.backend, A.A.contiguous(), out, k)     # row-major on the pitch k: a row range is one run
     return HPCMatrix(plan.result_partition, A.col_partition, out, A.backend)
 
 

@@ -50,7 +50,7 @@ def main():
                 Bgs = [orc.fill_uniform(0, ng * k, seed).reshape(ng, k).astype(T) - T(0.25) for seed in (4711, 1234)]
                 # the host layer's plan for (A, row partition of B, k): halo handle, split columns, ghost segment
                 probe = hp.HPCMatrix_local(torch.from_numpy(np.ascontiguousarray(Bgs[0][lo:hi])).cuda(), backend)
-                plan, ent = dense._spmm_plan(A, probe)
+                plan, ent = dense._spmm_plan(A, probe, width=k)      # (column-major blocks: the exchange carries exactly k values per row)
                 assert ent is not None and ent[0] is not None, f"{tag} {name}: no exchange entry"
                 halo, _i, _b, _s, colval_split, ghost = ent[:6]
                 is64 = bool(ent[10])

@@ -221,12 +221,10 @@ def test_profiled_kernel_names_follow_the_kernel_templates():
         return len([p for p in m.group(1).split(",") if p.strip()])
 
     n_rg = n_template_params("spmv.hip", "spmv_rowgather_kernel")
-    n_quad = n_template_params("spmv.hip", "spmv_rowblock_quad_kernel")
     n_t = n_template_params("rowgather_t.h", "rowgather_kernel")
-    for kind, name, n in ((0, "spmv_rowgather_kernel", n_rg), (1, "spmv_rowblock_quad_kernel", n_quad)):
-        fake = types.SimpleNamespace(_capi=types.SimpleNamespace(load=lambda k=kind: types.SimpleNamespace(hpcla_get_spmv_kernel=lambda: k)))
-        inst = bench.spmv_kernel_instance(fake, is_i64=True, split=True, wait=False)
-        assert inst.startswith(f"hpcla::{name}<long, true, false") and inst.count(",") == n - 1, (inst, n)
+    inst = bench.spmv_kernel_instance(None, is_i64=True, split=True, wait=False)
+    assert inst.startswith("hpcla::spmv_rowgather_kernel<long, true, false") and inst.count(",") == n_rg - 1, (inst, n_rg)
+    assert "spmv_rowblock_quad_kernel" not in open(os.path.join(csrc, "spmv.hip")).read()      # retired in round 6
     assert bench.f32_kernel_name(16).count(",") == n_t - 1
     import importlib.util
     spec = importlib.util.spec_from_file_location("collect_profiles", os.path.join(ROOT, "benchmarks", "collect_profiles.py"))

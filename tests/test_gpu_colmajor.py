@@ -212,11 +212,13 @@ def test_banded_block_count(hp, orc):
         count(p2, 0)
 
 
-@pytest.mark.parametrize("k", [1, 2, 5, 6, 12, 16, 17])
+@pytest.mark.parametrize("k", [1, 2, 5, 6, 12, 15, 16, 17, 40])
 @pytest.mark.parametrize("Ti", [np.int32, np.int64])
 def test_spmm_f64_rowmajor_B_colmajor_C(hp, orc, k, Ti):
     """Round 5: row-major B rows, COLUMN-major C -- the unstructured product of a column-major caller without the conversion
-    of C (csrc/spmm.hip CCOL: even k <= 16 leave through LDS as k runs of 64 doubles; other k take the strided kernel).
+    of C (csrc/spmm.hip CCOL: the results leave through LDS as runs of 64 doubles per column, one launch per 16-column tile;
+    odd k on B's own pitch k -- as here -- takes the strided kernel, on a padded pitch the same store:
+    tests/test_gpu_parity.py::test_spmm_bit_exact_padded_pitch).
     hpcla_spmm_csr_f64_* (ROW, COL) and hpcla_spmm_split_ccol_f64_* with a ghost segment and block lists; long rows (several
     LDS passes), empty rows, a last block of fewer than 64 rows, even and odd leading dimensions of C; untouched padding.
     Bar: the oracle's bits (= the reference's column loop, src/sparse.jl:2391-2413)."""

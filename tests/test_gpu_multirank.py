@@ -54,12 +54,10 @@ def test_push_transport_ranks_exchange(nranks):
         # size the plan would measure at), so the FUSED kernels' interior runs walk it too -- same bits required
         env["HPCLA_SPMV_XCD_GROUP"] = "2"
     if nranks == 4:
-        # the product-parking QUAD kernel of rounds 1-3 is still shipped (hpcla_set_spmv_kernel(1)): its fused distributed
-        # form (push workgroups, waiting boundary blocks, p.Ap epilogue) keeps a real-rank run of its own
-        env["HPCLA_SPMV_KERNEL"] = "quad"
-        # four processes time-slice ONE GPU here: the cases that differ in kind (slab with CG, unstructured all-to-all, the
-        # one-directional band, the empty rank); the 3-D slab, the other x partition and the pin cases run with 2 and 3 ranks
-        env["HPCLA_MR_CASES"] = "poisson2d,sprand,upper,tiny"
+        # (rounds 4-5 ran the retired quad kernel here; round 6: the default kernel on three neighbours per rank)
+        # four processes time-slice ONE GPU here: the cases that differ in kind (unstructured all-to-all, the one-directional
+        # band, the empty rank); the slabs with CG, the other x partition and the pin cases run with 2 and 3 ranks
+        env["HPCLA_MR_CASES"] = "sprand,upper,tiny"
     env.pop("HPCLA_HALO_MODE", None)
     os.environ.pop("HPCLA_HALO_MODE", None)
     assert _spawn(nranks, env) == 0

@@ -128,13 +128,12 @@ def test_spmv_long_rows_chunk_loop(hp, orc, gpu_backend_i32):
 
 
 @pytest.mark.parametrize("Ti", [np.int32, np.int64])
-@pytest.mark.parametrize("kernel", [0, 1])
-def test_spmv_whole_pass_rows_split_and_dot_epilogue(hp, orc, Ti, kernel):
+def test_spmv_whole_pass_rows_split_and_dot_epilogue(hp, orc, Ti):
     """Rows that own whole passes of a wave (round 5: the row-gather kernel multiplies such a pass out with all 64 lanes and
     the owner adds the parked products in stored order) in the forms the first test of this file does not reach: the SPLIT
     column space (own x + ghost segment, 1-based arrays, block lists) and the fused x.y epilogue -- rows of exactly one pass
     (464), one short of / one past it, several passes, a long row as the LAST row of a wave and as the first of the next.
-    Same bits as the oracle under both kernels (the quad kernel is the cross-check)."""
+    Same bits as the oracle."""
     import ctypes
     import torch
     rng = np.random.default_rng(77)
@@ -150,8 +149,6 @@ def test_spmv_whole_pass_rows_split_and_dot_epilogue(hp, orc, Ti, kernel):
     sfx = "i32" if Ti == np.int32 else "i64"
     s = torch.cuda.current_stream().cuda_stream
     lib = hp._capi.load()
-    prev = lib.hpcla_get_spmv_kernel()
-    hp._capi.call("hpcla_set_spmv_kernel", kernel)
     try:
         n_own = 7_000
         rp, cv, nz = _t((rowptr + 1).astype(Ti)), _t((cols + 1).astype(Ti)), _t(vals)
@@ -174,7 +171,7 @@ def test_spmv_whole_pass_rows_split_and_dot_epilogue(hp, orc, Ti, kernel):
         ref = float(np.dot(x, want))
         assert abs(out.item() - ref) <= 1e-12 * float(np.abs(x) @ np.abs(want))
     finally:
-        hp._capi.call("hpcla_set_spmv_kernel", prev)
+        pass
 
 
 @pytest.mark.parametrize("Ti", [np.int32, np.int64])
@@ -692,6 +689,107 @@ def test_spmm_bit_exact_raw_abi(hp, orc, gpu_backend_i32, k, layout):
     torch.cuda.synchronize()
     C = dC.cpu().numpy().reshape((n, k), order="C" if layout == "row" else "F")
     np.testing.assert_array_equal(C, want)
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 5, 7, 9, 13, 15, 16, 17, 31, 33])
+@pytest.mark.parametrize("c_layout", ["row", "col"])
+@pytest.mark.parametrize("Ti", [np.int32, np.int64])
+def test_spmm_bit_exact_padded_pitch(hp, orc, gpu_backend_i32, k, c_layout, Ti):
+    """Round 6: ODD k on the 16-byte vector kernel.  Row-major B rows on the pitch the converters of this boundary allocate
+    (k + (k & 1), and a wider even one), C row-major on the same pitch or column-major: lanes own column pairs, the last pair's
+    second half is the row's padding double -- read (here: NaN, so a leak into any real column would show), never stored
+    into a real column (the padding of C stays NaN, or becomes 0.0 where the rows leave as whole lines).  Unsplit entry and split entry with a ghost segment of its own pitch and block lists.
+    Bar: the oracle's bits (the reference's column loop, src/sparse.jl:2391-2413)."""
+    import torch
+    sfx = "i32" if Ti == np.int32 else "i64"
+    n, m = 3000, 2500
+    rows = orc.sprand_rows(m, 0.01, 0, n)
+    ci, cv = orc.compress_columns(rows)
+    nc = len(ci)
+    B = orc.fill_uniform(0, nc * k, 9).reshape(nc, k) - 0.5
+    want = orc.spmm(rows.rowptr.astype(np.int32), cv.astype(np.int32), rows.vals, B)
+    d_rp, d_cv, d_nz = _t(rows.rowptr.astype(Ti)), _t(cv.astype(Ti)), _t(rows.vals)
+    ROW, COL = hp._capi.LAYOUT_ROW, hp._capi.LAYOUT_COL
+    s = torch.cuda.current_stream().cuda_stream
+    kp = k + (k & 1)
+
+    def padded(M, pitch):
+        out = np.full((M.shape[0], pitch), np.nan)
+        out[:, :k] = M
+        return out
+    for ldb in (kp, kp + 2):
+        dB = _t(padded(B, ldb))
+        if c_layout == "row":
+            ldc = ldb
+            dC = torch.full((n, ldc), float("nan"), dtype=torch.float64, device="cuda")
+            hp._capi.call(f"hpcla_spmm_csr_f64_{sfx}", d_rp.data_ptr(), d_cv.data_ptr(), d_nz.data_ptr(), dB.data_ptr(), ldb, ROW,
+                          dC.data_ptr(), ldc, ROW, n, rows.nnz, k, 0, s)
+            got = dC.cpu().numpy()
+            np.testing.assert_array_equal(got[:, :k], want)
+            # the padding of C: untouched, or -- ldc == k + 1 <= 16: the rows leave as whole lines -- column k set to 0.0
+            assert np.all(np.isnan(got[:, k:]) | (got[:, k:] == 0.0)) and np.all(np.isnan(got[:, k + 1:])), "padding of C"
+        else:
+            ldc = n + 2
+            dC = torch.full((k, ldc), float("nan"), dtype=torch.float64, device="cuda")
+            hp._capi.call(f"hpcla_spmm_csr_f64_{sfx}", d_rp.data_ptr(), d_cv.data_ptr(), d_nz.data_ptr(), dB.data_ptr(), ldb, ROW,
+                          dC.data_ptr(), ldc, COL, n, rows.nnz, k, 0, s)
+            got = dC.cpu().numpy()
+            np.testing.assert_array_equal(got[:, :n].T, want)
+            assert np.all(np.isnan(got[:, n:]))
+    # split form: own rows on pitch kp, ghost rows on pitch kp + 2, interior / boundary block lists
+    n_own = (2 * nc) // 3
+    dBo, dBg = _t(padded(B[:n_own], kp)), _t(padded(B[n_own:], kp + 2))
+    rpb = hp._capi.load().hpcla_spmm_rows_per_block()
+    nblk = (n + rpb - 1) // rpb
+    rp = rows.rowptr
+    touches = np.array([np.any(cv[rp[b * rpb]:rp[min((b + 1) * rpb, n)]] >= n_own) for b in range(nblk)])
+    lists = [_t(np.flatnonzero(~touches).astype(np.int32)), _t(np.flatnonzero(touches).astype(np.int32))]
+    if c_layout == "row":
+        dC = torch.full((n, kp), float("nan"), dtype=torch.float64, device="cuda")
+        for blocks in lists:
+            if blocks.numel():
+                hp._capi.call(f"hpcla_spmm_split_f64_{sfx}", d_rp.data_ptr(), d_cv.data_ptr(), d_nz.data_ptr(), dBo.data_ptr(), kp,
+                              dBg.data_ptr(), kp + 2, n_own, dC.data_ptr(), kp, n, rows.nnz, k, 0, blocks.data_ptr(), blocks.numel(), s)
+        got = dC.cpu().numpy()
+        np.testing.assert_array_equal(got[:, :k], want)
+        assert np.all(np.isnan(got[:, k:]) | (got[:, k:] == 0.0))
+    else:
+        ldc = n + 4
+        dC = torch.full((k, ldc), float("nan"), dtype=torch.float64, device="cuda")
+        for blocks in lists:
+            if blocks.numel():
+                hp._capi.call(f"hpcla_spmm_split_ccol_f64_{sfx}", d_rp.data_ptr(), d_cv.data_ptr(), d_nz.data_ptr(), dBo.data_ptr(), kp,
+                              dBg.data_ptr(), kp + 2, n_own, dC.data_ptr(), ldc, n, rows.nnz, k, 0, blocks.data_ptr(), blocks.numel(), s)
+        got = dC.cpu().numpy()
+        np.testing.assert_array_equal(got[:, :n].T, want)
+        assert np.all(np.isnan(got[:, n:]))
+
+
+@pytest.mark.parametrize("k", [3, 7, 15, 17])
+def test_spmm_host_layer_odd_k_runs_on_the_padded_pitch(hp, orc, gpu_backend_i32, k):
+    """Round 6, host layer: ``A @ B`` with an odd k allocates its result on the even pitch k + 1 (dense.spmm_pitch) and
+    multiplies B on that pitch too -- one copy for a B that arrives on the pitch k, none for a B that is itself such a
+    result (the chained product below).  Bits of the oracle's column loop (src/sparse.jl:2391-2413) both times."""
+    import torch
+    n = 5000
+    rng = np.random.default_rng(60 + k)
+    lens = rng.integers(0, 14, n)
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    ci = np.concatenate([np.sort(rng.choice(n, int(l), replace=False)) for l in lens]).astype(np.int64)
+    va = rng.random(len(ci)) - 0.5
+    A = hp.HPCSparseMatrix_local(rp, ci, va, n, gpu_backend_i32)
+    Bg = rng.random((n, k)) - 0.5
+    C = A @ hp.HPCMatrix.from_global(Bg, gpu_backend_i32)
+    assert tuple(C.A.shape) == (n, k) and C.A.stride(0) == k + 1 and C.A.stride(1) == 1
+    want = orc.spmm(rp.astype(np.int32), ci.astype(np.int32), va, Bg)
+    np.testing.assert_array_equal(C.local_values(), want)
+    D = A @ C                                                     # C's block is a (n, k) view on the pitch k + 1: taken as it is
+    np.testing.assert_array_equal(D.local_values(), orc.spmm(rp.astype(np.int32), ci.astype(np.int32), va, want))
+    np.testing.assert_array_equal(C.local_values(), want)         # (the product read C, nothing wrote it)
+    np.testing.assert_array_equal((C * 2.0).local_values(), want * 2.0)       # the other operators take the view too
+    np.testing.assert_array_equal(C[:, k - 1].local_values(), want[:, k - 1])
+    del A, C, D
+    hp.clear_plan_cache(); hp.clear_spmm_cache()
 
 
 @pytest.mark.parametrize("k", [16, 12, 6, 3, 1])
@@ -1282,9 +1380,9 @@ def test_spmv_randomised_structures(hp, orc, gpu_backend_i32):
 
 @pytest.mark.parametrize("Ti", [np.int32, np.int64])
 def test_spmv_pass_boundaries_of_the_straight_line_kernel(hp, orc, gpu_backend_i32, Ti):
-    """The quad kernel's wave passes switch on the entry count of a 256-row block: waves with one quad / two quads /
-    none, full 2048-entry passes followed by a short one, and the entry-by-entry pass for the last quad of the MATRIX
-    when nnz is not a multiple of 4.  Block totals straddling every one of those limits, every nnz mod 4, split-column
+    """Block totals around the pass limits of the round 1-3 quad kernel (retired in round 6) -- kept as a shape sweep of the row-gather
+    kernel: waves with few / no entries, 2048-entry block totals followed by a short one, and the entry-by-entry pass for the last quad of the
+    MATRIX when nnz is not a multiple of 4.  Block totals straddling every one of those limits, every nnz mod 4, split-column
     entry included."""
     import torch
     rng = np.random.default_rng(77)
@@ -1882,11 +1980,10 @@ def test_spmm_host_layer_takes_run_tiles_on_stencils_only(hp, orc, gpu_backend_i
 
 
 @pytest.mark.parametrize("Ti", [np.int32, np.int64])
-def test_both_spmv_kernels_give_the_reference_bits(hp, orc, gpu_backend_i32, Ti):
-    """hpcla_set_spmv_kernel: 0 = row gather (round 4 default: wave-private LDS copy of the A entries, every lane walks
-    its own row), 1 = quad (rounds 1-3: products parked in LDS).  Both are the reference's row-sequential sum
-    (src/sparse.jl:2055-2066): same bits on stencils, unstructured rows, rows longer than a wave's LDS pass, empty rows,
-    ragged last blocks, the split column space and the fused x.y epilogue."""
+def test_spmv_kernel_forms_give_the_reference_bits(hp, orc, gpu_backend_i32, Ti):
+    """The three forms of the row-gather SpMV (wave-private LDS copy of the A entries, every lane walks its own row) -- plain,
+    split column space, fused x.y epilogue -- are the reference's row-sequential sum (src/sparse.jl:2055-2066): bits of the oracle
+    on the golden-sized, sprand, long-row and empty-row shapes.  (Rounds 1-5 ran the retired quad kernel beside it here.)"""
     import torch
     lib = hp._capi.load()
     sfx = "i32" if Ti == np.int32 else "i64"
@@ -1910,8 +2007,7 @@ def test_both_spmv_kernels_give_the_reference_bits(hp, orc, gpu_backend_i32, Ti)
             d_rp, d_cv, d_nz = _t(rows.rowptr.astype(Ti)), _t(cv.astype(Ti)), _t(rows.vals)
             d_x, d_xo, d_xg = _t(xg), _t(xg[:n_own]), _t(xg[n_own:])
             got = {}
-            for kind in (0, 1):
-                hp._capi.call("hpcla_set_spmv_kernel", kind)
+            for kind in (0,):
                 y = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
                 hp._capi.call(f"hpcla_spmv_csr_f64_{sfx}", d_rp.data_ptr(), d_cv.data_ptr(), d_nz.data_ptr(), d_x.data_ptr(),
                               y.data_ptr(), n, rows.nnz, 0, s)
@@ -1933,11 +2029,8 @@ def test_both_spmv_kernels_give_the_reference_bits(hp, orc, gpu_backend_i32, Ti)
                     got[kind] = float(out.item())
                     ref = float(np.dot(xg, want))
                     assert abs(got[kind] - ref) <= 1e-12 * float(np.abs(xg) @ np.abs(want))
-            if got:
-                assert got[0] == got[1]                          # same per-row products, same reduction tree
-        assert lib.hpcla_set_spmv_kernel(2) != 0
     finally:
-        lib.hpcla_set_spmv_kernel(0)
+        pass
 
 
 @pytest.mark.parametrize("Ti", [np.int32, np.int64])
@@ -1946,7 +2039,7 @@ def test_spmv_rowgather_wave_pass_boundaries(hp, orc, gpu_backend_i32, Ti):
     first entry -- is streamed into LDS in passes of 464 entries.  Wave totals around every pass limit (one pass, one pass
     exactly, one entry over, two and three passes), every alignment of the wave's first entry (0..3 entries in front of
     it in its quad), empty waves, rows that span passes, a ragged last block, and the entry-by-entry pass at the end of the
-    matrix for every nnz mod 4; the quad kernel on the same inputs."""
+    matrix for every nnz mod 4."""
     import torch
     rng = np.random.default_rng(2024)
     ncols = 5000
@@ -1977,9 +2070,8 @@ def test_spmv_rowgather_wave_pass_boundaries(hp, orc, gpu_backend_i32, Ti):
             vals = rng.standard_normal(nnz)
             x = rng.standard_normal(ncols)
             want = orc.spmv(rowptr.astype(Ti), cols.astype(Ti), vals, x)
-            for kind in (0, 1):
-                hp._capi.call("hpcla_set_spmv_kernel", kind)
+            for kind in (0,):
                 got = _raw_spmv(hp, rowptr, cols, vals, x, Ti)
                 np.testing.assert_array_equal(got, want, err_msg=f"kernel {kind}, shift {shift}, nnz mod 4 = {nnz % 4}")
     finally:
-        lib.hpcla_set_spmv_kernel(0)
+        pass

@@ -1,6 +1,6 @@
 """Randomised sweep through the raw C ABI: ragged CSR shapes (empty matrices, empty rows, single rows, rows around the
 464-entry wave pass and the 1984- / 2048-entry workgroup passes, duplicate-free ascending columns), both index types and bases, every
-kernel family -- Float64 SpMV (row-gather and quad), Float32 SpMV, SpMM in Float64 and Float32 on row-major and column-major
+kernel family -- Float64 SpMV, Float32 SpMV, SpMM in Float64 and Float32 on row-major and column-major
 blocks with ragged k, the row-major-B / column-major-C product, the run tiles on column-major blocks and the opt-in long-row entry (its short rows) -- each bit for bit against the oracle's loops (src/sparse.jl:2055-2066, 2391-2413).  Fixed seeds: a
 failure names its case.
 """
@@ -52,23 +52,21 @@ def test_random_shapes_every_kernel_family(hp, orc, seed):
     rp, cv = _t((rowptr + base).astype(Ti)), _t((colval + base).astype(Ti))
     nnz = len(vals)
     ROW, COL = capi.LAYOUT_ROW, capi.LAYOUT_COL
-    before = capi.load().hpcla_get_spmv_kernel()
     for T, dt, tT in ((np.float64, "f64", torch.float64), (F32, "f32", torch.float32)):
         v, Bt = vals.astype(T), B.astype(T)
         nz = _t(v)
         want = orc.spmm(rowptr.astype(Ti), colval.astype(Ti), v, Bt) if nrows else np.empty((0, k), T)
         # SpMV on column 0
         x = _t(np.ascontiguousarray(Bt[:, 0]))
-        kinds = (0, 1) if dt == "f64" else (0,)
+        kinds = (0,)
         try:
             for kind in kinds:
-                capi.call("hpcla_set_spmv_kernel", kind)
                 y = torch.full((max(nrows, 1),), float("nan"), dtype=tT, device="cuda")
                 capi.call(f"hpcla_spmv_csr_{dt}_{sfx}", rp.data_ptr(), cv.data_ptr(), nz.data_ptr(), x.data_ptr(), y.data_ptr(), nrows, nnz,
                           base, s)
                 np.testing.assert_array_equal(y[:nrows].cpu().numpy(), want[:, 0], err_msg=f"seed {seed} {dt} spmv kernel {kind}")
         finally:
-            capi.call("hpcla_set_spmv_kernel", before)
+            pass
         # SpMM, both layouts
         for lay, name in ((ROW, "row"), (COL, "col")):
             Bd = _t(Bt if lay == ROW else np.ascontiguousarray(Bt.T))
@@ -88,6 +86,25 @@ def test_random_shapes_every_kernel_family(hp, orc, seed):
             got = C.cpu().numpy().reshape(k, ldc)
             np.testing.assert_array_equal(got[:, :nrows].T, want, err_msg=f"seed {seed} spmm row-major B, column-major C, k={k}")
             assert np.all(np.isnan(got[:, nrows:])), f"seed {seed}: the column-major store wrote into the padding"
+            # round 6: B (and a row-major C) on the padded pitch k + (k & 1): odd k on the vector kernel; NaN padding in B
+            # must not reach any real column, the padding of C stays untouched
+            kp = k + (k & 1) + 2 * (seed % 2)
+            Bp = np.full((ncols, kp), np.nan)
+            Bp[:, :k] = Bt
+            Bd = _t(Bp)
+            C = torch.full((max(nrows, 1), kp), float("nan"), dtype=tT, device="cuda")
+            capi.call(f"hpcla_spmm_csr_f64_{sfx}", rp.data_ptr(), cv.data_ptr(), nz.data_ptr(), Bd.data_ptr(), kp, ROW, C.data_ptr(), kp, ROW,
+                      nrows, nnz, k, base, s)
+            got = C.cpu().numpy()
+            np.testing.assert_array_equal(got[:nrows, :k], want, err_msg=f"seed {seed} spmm padded pitch {kp}, k={k}")
+            assert np.all(np.isnan(got[:nrows, k:]) | (got[:nrows, k:] == 0.0)) and np.all(np.isnan(got[:nrows, k + 1:])), \
+                f"seed {seed}: the padded-pitch product wrote something else than 0.0 into the padding of C"
+            C = torch.full((k * ldc,), float("nan"), dtype=tT, device="cuda")
+            capi.call(f"hpcla_spmm_csr_f64_{sfx}", rp.data_ptr(), cv.data_ptr(), nz.data_ptr(), Bd.data_ptr(), kp, ROW, C.data_ptr(), ldc, COL,
+                      nrows, nnz, k, base, s)
+            got = C.cpu().numpy().reshape(k, ldc)
+            np.testing.assert_array_equal(got[:, :nrows].T, want, err_msg=f"seed {seed} spmm padded-pitch B, column-major C, k={k}")
+            assert np.all(np.isnan(got[:, nrows:]))
             # round 5: the run tiles on COLUMN-major blocks (k = 16; most of these ragged blocks do not fit and take the per-entry
             # path, a few do): own block column-major with an even leading dimension, ghost rows row-major, odd / even n_own
             if nrows:
