@@ -107,7 +107,9 @@ int hpcla_spmv_rows_per_block(void);
  * order -- 1024 contiguous pieces per row, wave shuffles inside a piece (north_star's "__shfl / segmented-scan row
  * reductions") -- and every other row exactly as hpcla_spmv_split_f64_* does, bit for bit.  A long row's result is within
  * 1e-12 * (|A||x|)_r of the sequential sum (tests: tests/test_gpu_parity.py::test_spmv_long_rows_opt_in).  x_ghost == NULL:
- * unsplit column space.  work: hpcla_spmv_longrows_work_bytes(n_long) bytes of device scratch. */
+ * unsplit column space.  work: hpcla_spmv_longrows_work_bytes(n_long) bytes of device scratch.
+ * A row of >= long_min entries that `long_rows` omits is not summed by anybody: its y is set to NaN (never left at a stale
+ * value).  colval / nzval that are not 16- / 32-byte aligned take the default entry's fallback kernel (every row sequential). */
 int64_t hpcla_spmv_longrows_work_bytes(int64_t n_long);
 int hpcla_spmv_longrows_f64_i32(const int32_t *rowptr, const int32_t *colval_split, const double *nzval,
                                 const double *x_own, const double *x_ghost, int64_t n_own, double *y,

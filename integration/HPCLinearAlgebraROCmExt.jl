@@ -1016,6 +1016,25 @@ mutable struct ROCSpgemmState
     map::Any                 # nothing: not tried | :none: not built | (pair_ptr, pairs, ptr_is_i64)
 end
 const _spgemm_cache = IdDict{Any,Any}()    # reference MatrixPlan -> ROCSpgemmState | nothing (parent path)
+# What a state pins until clear_rocm_plan_cache!: the gathered rows' structure (g_rowptr, g_col), the bins, the result's
+# STRUCTURE -- and, the large part, the per-entry product lists (8 B per product, up to HPCLA_SPGEMM_MAP_MAX = 5e7 products =
+# 400 MB per structure).  The lists are bounded across structures: at most HPCLA_SPGEMM_MAP_KEEP (default 4) states hold
+# them, least recently multiplied first out -- an evicted structure goes back to the numeric kernels (same bits) and
+# rebuilds its lists if it is multiplied three more times.
+# The result matrices of one structure SHARE their structure arrays (col_indices, colptr / rowptr, colval and the device copies):
+# the parent treats those fields as immutable after construction (every operator builds new arrays, none writes into an
+# operand's), and its own cached plans alias structure the same way (AdditionPlan results, cached_transpose); only nzval is
+# fresh per product.  A caller that mutates a result's structure in place must copy it first.
+const _spgemm_map_lru = Any[]              # states holding product lists, least recently used first
+function _spgemm_touch_lists!(st)
+    filter!(s -> s !== st, _spgemm_map_lru); push!(_spgemm_map_lru, st)
+    keep = max(1, parse(Int, get(ENV, "HPCLA_SPGEMM_MAP_KEEP", "4")))
+    while length(_spgemm_map_lru) > keep
+        old = popfirst!(_spgemm_map_lru)
+        old.map = nothing; old.repeats = 0                 # lists released; the numeric kernels take over (same bits)
+    end
+    return
+end
 
 function _spgemm_symbolic(A::HPCSparseMatrix{T,Ti,B}, plan) where {T,Ti,B}
     nrows = A.nrows_local
@@ -1110,7 +1129,7 @@ end
 # over B.nzval; own ranges and the arrived segments are placed by two gather launches.  The twin of matmat.py
 # MatrixPlan.gather_values, which the GPU tests hold to the oracle.  COLLECTIVE on first use (window attach).
 const _rocm_matexec = IdDict{Any,Any}()   # reference MatrixPlan -> (halo handle, send_idx, local src, local dst, ghost src, ghost dst); freed by clear_rocm_plan_cache!
-function _matrix_values!(gval::ROCVector{T}, plan, Bm::HPCSparseMatrix{T,Ti,B}) where {T<:Float64,Ti,B<:ROCBackend}
+function _matrix_values!(gval::ROCVector{T}, plan::HPCLinearAlgebra.MatrixPlan, Bm::HPCSparseMatrix{T,Ti,B}) where {T<:Float64,Ti,B<:ROCBackend}
     st = get!(_rocm_matexec, plan) do
         comm = Bm.backend.comm
         send_lists = Vector{Int64}[reduce(vcat, (collect(Int64, rng) for rng in ranges); init=Int64[]) .- 1 for ranges in plan.send_ranges]   # 0-based positions in B.nzval
@@ -1209,6 +1228,7 @@ function Base.:*(A::HPCSparseMatrix{T,Ti,B}, Bm::HPCSparseMatrix{T,Ti,B}) where 
             st.map = lists === nothing ? :none : lists
         end
         if st.map isa Tuple
+            _spgemm_touch_lists!(st)
             ptr, pairs, ptr64 = st.map
             _check(@ccall(LIB.hpcla_spgemm_numeric_mapped_f64(_ptr(ptr)::Ptr{Cvoid}, (ptr64 ? 1 : 0)::Cint, _ptr(pairs)::Ptr{Cvoid},
                    _ptr(A.nzval)::Ptr{Cvoid}, _ptr(gval)::Ptr{Cvoid}, _ptr(c_val)::Ptr{Cvoid}, res.nnz::Int64,
@@ -1428,7 +1448,7 @@ function clear_rocm_plan_cache!()
     end
     for rp0 in keys(_spmm_order_in_force); @ccall LIB.hpcla_spmm_block_order_hint(_ptr(rp0)::Ptr{Cvoid}, 0::Cint)::Cint; end
     empty!(_rocm_plans); empty!(_spmm_plans); empty!(_rocm_exec); empty!(_rocm_matexec); empty!(_merge_lists); empty!(_spmm_runs_cache); empty!(_stage32); empty!(_banded_cache); empty!(_spmm_cm_tuned); empty!(_spmm_order_in_force)
-    empty!(_spgemm_cache)
+    empty!(_spgemm_cache); empty!(_spgemm_map_lru)
     return nothing
 end
 

@@ -45,6 +45,7 @@ static_assert(sizeof(WindowDesc) == HPCLA_WINDOW_DESC_BYTES, "WindowDesc size");
 struct PeerMap {                               // a peer's window mapped into this process
     void *base = nullptr;                      // peer's allocation base in MY address space
     bool opened = false;                       // hipIpcOpenMemHandle'd (false: same process, local pointer)
+    bool local_ref = false;                    // holds a reference on another in-process rank's window (window_close releases it)
 };
 
 uint64_t host_identity();

@@ -118,39 +118,80 @@ int window_alloc(void **p, size_t bytes, bool uncached)
 // Windows exported by THIS process, by IPC handle.  A handle cannot be opened in the process that made it, and a
 // process may host several ranks (one host thread per rank, each with its own communicator -- the arrangement of
 // tests/cabi/cabi_ranks_threads.c, which rehearses 8 ranks inside the box's limit on GPU processes): such peers
-// are reached through the exporter's own pointer.
+// are reached through the exporter's own pointer.  An IPC mapping keeps the peer's memory alive until it is closed; the
+// raw pointer does not, so the registry COUNTS the in-process peers that hold it: window_free by the owner while a peer
+// still maps the window only marks it, and the last window_close frees it (a peer's push or ack kernels may
+// still be in flight when the owner destroys its plan).
+struct LocalWindow {
+    void *base;
+    int refs;               // in-process peers that hold `base` (window_open .. window_close)
+    bool owner_freed;       // the owner called window_free while refs > 0: hipFree is owed
+};
 static std::mutex g_local_mu;
-static std::map<std::array<uint8_t, 64>, void *> g_local_windows;
+static std::map<std::array<uint8_t, 64>, LocalWindow> g_local_windows;
 
 static void local_window_register(const uint8_t *ipc, void *base)
 {
     std::array<uint8_t, 64> k;
     memcpy(k.data(), ipc, 64);
     std::lock_guard<std::mutex> lock(g_local_mu);
-    g_local_windows[k] = base;
+    g_local_windows[k] = LocalWindow{base, 0, false};
 }
 
-static void local_window_forget(void *base)
-{
-    std::lock_guard<std::mutex> lock(g_local_mu);
-    for (auto it = g_local_windows.begin(); it != g_local_windows.end();)
-        it = it->second == base ? g_local_windows.erase(it) : std::next(it);
-}
-
-static void *local_window_find(const uint8_t *ipc)
+static void *local_window_acquire(const uint8_t *ipc)
 {
     std::array<uint8_t, 64> k;
     memcpy(k.data(), ipc, 64);
     std::lock_guard<std::mutex> lock(g_local_mu);
     auto it = g_local_windows.find(k);
-    return it == g_local_windows.end() ? nullptr : it->second;
+    if (it == g_local_windows.end() || it->second.owner_freed) return nullptr;
+    ++it->second.refs;
+    return it->second.base;
+}
+
+static void local_window_release(void *base)
+{
+    void *to_free = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_local_mu);
+        for (auto it = g_local_windows.begin(); it != g_local_windows.end(); ++it) {
+            if (it->second.base != base) continue;
+            if (--it->second.refs <= 0 && it->second.owner_freed) {
+                to_free = base;
+                g_local_windows.erase(it);
+            }
+            break;
+        }
+    }
+    if (to_free) (void)hipFree(to_free);
 }
 
 void window_free(void *win)
 {
     if (!win) return;
-    local_window_forget(win);
+    {
+        std::lock_guard<std::mutex> lock(g_local_mu);
+        for (auto it = g_local_windows.begin(); it != g_local_windows.end(); ++it) {
+            if (it->second.base != win) continue;
+            if (it->second.refs > 0) {                // an in-process peer still maps it: its last window_close frees it
+                it->second.owner_freed = true;
+                return;
+            }
+            g_local_windows.erase(it);
+            break;
+        }
+    }
     (void)hipFree(win);
+}
+
+// This process's device index whose identity is `device_id`, or -1 (not visible here).
+static int local_device_of(uint64_t device_id)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess) return -1;
+    for (int dev = 0; dev < ndev; ++dev)
+        if (device_identity_of(dev) == device_id) return dev;
+    return -1;
 }
 
 int window_open(const WindowDesc &d, int peer_rank, int my_rank, void *my_base, PeerMap *out)
@@ -158,10 +199,36 @@ int window_open(const WindowDesc &d, int peer_rank, int my_rank, void *my_base, 
     if (d.bytes == 0) return set_error(HPCLA_ERR_INVALID, "window_open: rank %d exported no window", peer_rank);
     if (d.pid == (uint64_t)getpid() && d.host_id == host_identity()) {
         // a window of this process: mine, or that of another rank hosted here
-        void *base = peer_rank == my_rank ? my_base : local_window_find(d.ipc);
+        if (peer_rank == my_rank) {
+            out->base = my_base;
+            out->opened = false;
+            out->local_ref = false;
+            return HPCLA_OK;
+        }
+        void *base = local_window_acquire(d.ipc);
         if (base) {
+            // The exporter's own pointer carries none of what an IPC mapping provides.  If the hosted rank runs on ANOTHER
+            // device of this process, stores through the pointer need peer access between the two devices: checked and
+            // enabled here, refused -- an error code, not a GPU fault -- where the runtime reports none.
+            int cur = 0;
+            if (d.device_id != 0 && hipGetDevice(&cur) == hipSuccess && d.device_id != device_identity_of(cur)) {
+                const int dev = local_device_of(d.device_id);
+                int can = 0;
+                if (dev < 0 || hipDeviceCanAccessPeer(&can, cur, dev) != hipSuccess || !can) {
+                    local_window_release(base);
+                    return set_error(HPCLA_ERR_UNSUPPORTED,
+                                     "window_open: device %d has no peer access to the device of in-process rank %d", cur, peer_rank);
+                }
+                const hipError_t pe = hipDeviceEnablePeerAccess(dev, 0);
+                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) {
+                    local_window_release(base);
+                    return set_error(HPCLA_ERR_HIP, "hipDeviceEnablePeerAccess(rank %d) failed: %s", peer_rank, hipGetErrorString(pe));
+                }
+                (void)hipGetLastError();      // (already enabled: clear the sticky error)
+            }
             out->base = base;
             out->opened = false;
+            out->local_ref = true;
             return HPCLA_OK;
         }
         // not exported here: ANOTHER process that happens to carry this pid (ranks in separate PID namespaces) -- open it
@@ -173,17 +240,13 @@ int window_open(const WindowDesc &d, int peer_rank, int my_rank, void *my_base, 
     // The peer's GPU, if this process can see it: refuse the mapping when the runtime reports no peer access
     // between the two devices (stores through such a mapping would fault the GPU instead of returning an error).
     // An invisible peer device (HIP_VISIBLE_DEVICES per rank) cannot be asked about; the IPC open then decides.
-    int cur = 0, ndev = 0;
-    if (d.device_id != 0 && hipGetDevice(&cur) == hipSuccess && hipGetDeviceCount(&ndev) == hipSuccess &&
-        d.device_id != device_identity_of(cur)) {
-        for (int dev = 0; dev < ndev; ++dev) {
-            if (dev == cur || device_identity_of(dev) != d.device_id) continue;
-            int can = 0;
-            if (hipDeviceCanAccessPeer(&can, cur, dev) == hipSuccess && !can)
-                return set_error(HPCLA_ERR_UNSUPPORTED, "window_open: device %d has no peer access to rank %d's device %d",
-                                 cur, peer_rank, dev);
-            break;
-        }
+    int cur = 0;
+    if (d.device_id != 0 && hipGetDevice(&cur) == hipSuccess && d.device_id != device_identity_of(cur)) {
+        const int dev = local_device_of(d.device_id);
+        int can = 0;
+        if (dev >= 0 && dev != cur && hipDeviceCanAccessPeer(&can, cur, dev) == hipSuccess && !can)
+            return set_error(HPCLA_ERR_UNSUPPORTED, "window_open: device %d has no peer access to rank %d's device %d",
+                             cur, peer_rank, dev);
     }
     hipIpcMemHandle_t h;
     static_assert(sizeof(h) == 64, "hipIpcMemHandle_t size");
@@ -194,14 +257,17 @@ int window_open(const WindowDesc &d, int peer_rank, int my_rank, void *my_base, 
         return set_error(HPCLA_ERR_HIP, "hipIpcOpenMemHandle(rank %d) failed: %s", peer_rank, hipGetErrorString(e));
     out->base = p;
     out->opened = true;
+    out->local_ref = false;
     return HPCLA_OK;
 }
 
 void window_close(PeerMap *m)
 {
     if (m->opened && m->base) (void)hipIpcCloseMemHandle(m->base);
+    if (m->local_ref && m->base) local_window_release(m->base);
     m->base = nullptr;
     m->opened = false;
+    m->local_ref = false;
 }
 
 static void fill_desc(WindowDesc *d, void *win, size_t bytes)

@@ -632,8 +632,14 @@ class HPCSparseMatrix:
         lane: an arrow matrix's dense row is a sequential pass over n entries in the default kernel -- the reference's order
         (src/sparse.jl:2059-2064) and its cliff.  Results of those rows then agree with the sequential sum to
         1e-12 * (|A||x|)_r, every other row keeps its bits.  Single-rank plans (no halo), Float64.  Returns the number of
-        long rows (0: nothing changes)."""
+        long rows (0: nothing changes).  The list is derived HERE from the device rowptr (one pass), so it is exactly the set
+        the kernels leave out; a product over a plan with neighbours, the packed copy and Float32 do not honour the switch
+        (they keep the default order) -- said once, on stderr, when the matrix's backend has more than one rank."""
         torch = _torch()
+        if comm_size(self.backend.comm) > 1 or self.T != np.dtype(np.float64):
+            import sys
+            sys.stderr.write("hpcla: enable_long_rows applies to single-rank Float64 products only; this matrix's products over "
+                             "plans with neighbours (and Float32 / packed products) keep the default row order\n")
         if min_len < 928:
             raise ValueError("enable_long_rows: min_len must be at least 928 (two passes of a wave)")
         rp = self.rowptr_target

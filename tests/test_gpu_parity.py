@@ -232,6 +232,31 @@ def test_spmv_long_rows_opt_in(hp, orc, Ti):
     with pytest.raises(hp._capi.HPCLAError):                                   # a threshold below two wave passes is refused
         hp._capi.call(f"hpcla_spmv_longrows_f64_{sfx}", rp.data_ptr(), cv.data_ptr(), nz.data_ptr(), xo.data_ptr(), xg.data_ptr(), n_own,
                       y.data_ptr(), len(lens), len(vals), 1, rows.data_ptr(), int(rows.numel()), 100, work.data_ptr(), s)
+    # round 6: a qualifying row the caller's list OMITS is summed by nobody -- its y must read NaN, not the value an
+    # earlier product left there; every listed and every short row as before
+    y.fill_(12345.0)
+    fewer = rows[1:].contiguous()
+    hp._capi.call(f"hpcla_spmv_longrows_f64_{sfx}", rp.data_ptr(), cv.data_ptr(), nz.data_ptr(), xo.data_ptr(), xg.data_ptr(), n_own,
+                  y.data_ptr(), len(lens), len(vals), 1, fewer.data_ptr(), int(fewer.numel()), 4096, work.data_ptr(), s)
+    got = y.cpu().numpy()
+    omitted = int(rows[0].item())
+    assert np.isnan(got[omitted])
+    keep = np.ones(len(lens), bool)
+    keep[omitted] = False
+    np.testing.assert_array_equal(got[keep & ~is_long], want[keep & ~is_long])
+    assert np.all(np.abs(got[keep & is_long] - want[keep & is_long]) <= 1e-12 * bound[keep & is_long])
+    # unaligned colval / nzval (a view one entry into a larger buffer): the entry falls back to the default order -- every row
+    # sequential, hence the oracle's bits on ALL rows -- instead of refusing the product
+    pad_cv = torch.empty(len(vals) + 1, dtype=cv.dtype, device="cuda")
+    pad_nz = torch.empty(len(vals) + 1, dtype=torch.float64, device="cuda")
+    pad_cv[1:] = cv
+    pad_nz[1:] = nz
+    ucv, unz = pad_cv[1:], pad_nz[1:]
+    assert unz.data_ptr() % 32 != 0
+    y.fill_(float("nan"))
+    hp._capi.call(f"hpcla_spmv_longrows_f64_{sfx}", rp.data_ptr(), ucv.data_ptr(), unz.data_ptr(), xo.data_ptr(), xg.data_ptr(), n_own,
+                  y.data_ptr(), len(lens), len(vals), 1, rows.data_ptr(), int(rows.numel()), 4096, work.data_ptr(), s)
+    np.testing.assert_array_equal(y.cpu().numpy(), want)
 
 
 @pytest.mark.parametrize("Ti", [np.int32, np.int64])

@@ -379,3 +379,65 @@ def test_every_private_helper_the_extension_calls_is_defined_in_it():
     used = set(re.findall(r"(?<![\w.])(_\w+!?)\(", text))
     assert len(used) > 20
     assert not (used - defined), f"called but not defined in the extension: {sorted(used - defined)}"
+
+
+def _function_body(text, header_regex):
+    """text of the top-level `function ...` whose header matches, up to its closing `end` at column 0"""
+    m = re.search(header_regex, text, flags=re.M)
+    assert m, header_regex
+    end = re.search(r"^end\b", text[m.start():], flags=re.M)
+    return text[m.start():m.start() + end.end()]
+
+
+def test_vector_plan_constructor_override_builds_the_reference_struct_with_the_reference_collectives():
+    """Round 6: the extension overrides `VectorPlan(A, x)` for DeviceROCm backends (binary searches instead of one push! per
+    compressed column).  Checked against the parent's constructor (src/sparse.jl:1875-1984) as text: the 18 arguments of the
+    final `VectorPlan{T,Ti,AV}(...)` call are the struct's fields in declaration order (the twelve lists / buffers by name,
+    six `nothing`s for the lazily filled fields), and the collectives appear in the parent's order with the parent's tag --
+    Alltoall of the counts, isend / irecv of the requested indices with tag 20, waitall on the receives, waitall on the
+    sends -- so that ranks running either method meet in every collective."""
+    ext = _ext_text()
+    ref = _ref_text()
+    fields = reference_structs(ref)["VectorPlan"]
+    assert len(fields) == 18, fields
+    body = _function_body(ext, r"^function HPCLinearAlgebra\.VectorPlan\(A::HPCSparseMatrix\{T,Ti,B\}, x::HPCVector\{T,B\}\) where \{T,Ti,B<:ROCBackend\}")
+    call = body[body.rindex("VectorPlan{T,Ti,AV}("):]
+    i = call.index("(")
+    args = [a.strip() for a, _ in _split_top(call[i + 1:_match_paren(call, i) - 1]) if a.strip()]
+    assert len(args) == 18, args
+    assert args[:12] == fields[:12], (args[:12], fields[:12])
+    assert args[12:] == ["nothing"] * 6, args[12:]
+    ref_body = _function_body(ref, r"^function VectorPlan\(A::HPCSparseMatrix\{T,Ti,B\}, x::HPCVector\{T,Bx\}\)")
+
+    def collectives(text):
+        out = []
+        for m in re.finditer(r"comm_(alltoall|isend|irecv!|waitall)\(([^\n]*)", text):
+            kind, rest = m.group(1), m.group(2)
+            if kind in ("isend", "irecv!"):
+                tag = re.search(r",\s*(\d+)\)", rest)
+                out.append((kind, tag.group(1) if tag else None))
+            elif kind == "waitall":
+                out.append((kind, "recv" if "recv" in rest else "send"))
+            else:
+                out.append((kind, None))
+        return out
+    mine, theirs = collectives(body), collectives(ref_body)
+    assert theirs == [("alltoall", None), ("isend", "20"), ("irecv!", "20"), ("waitall", "recv"), ("waitall", "send")], theirs
+    assert mine == theirs, (mine, theirs)
+    # the lazily sized buffers: only for Float64, where this file's execute_plan! / mul! never read gathered_cpu
+    assert re.search(r"lazy = T === Float64", body) and "similar(x.v, lazy ? 0 : n_gathered)" in body
+
+
+def test_spmm_result_passes_the_fields_of_hpcmatrix_in_order():
+    """`_spmm_result` builds HPCMatrix{T,B} with the inner constructor (src/dense.jl:59-69): five arguments in field order --
+    hash (lazy: nothing), row partition, column partition, the local block, the backend."""
+    ref = _ref_text()
+    fields = reference_structs(ref)["HPCMatrix"]
+    assert fields == ["structural_hash", "row_partition", "col_partition", "A", "backend"], fields
+    ext = _ext_text()
+    m = re.search(r"_spmm_result\(A::HPCSparseMatrix\{T,Ti,B\}, C::ROCMatrix\{T\}, k::Int\) where \{T,Ti,B\} =\s*HPCMatrix\{T,B\}\(", ext)
+    assert m
+    i = m.end() - 1
+    args = [a.strip() for a, _ in _split_top(ext[i + 1:_match_paren(ext, i) - 1])]
+    assert len(args) == 5 and args[0] == "nothing" and args[1] == "copy(A.row_partition)" and args[3] == "C" and args[4] == "A.backend", args
+    assert args[2].startswith("HPCLinearAlgebra.uniform_partition(k,"), args[2]
