@@ -40,6 +40,25 @@ def stored_traffic(key, applicable=True, world=1, share_note=""):
     return rec["hbm_bytes"], src
 
 
+TRAFFIC_CONVENTION = ("traffic = 2 x FETCH_SIZE + WRITE_SIZE: the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE counts 128-byte "
+                      "requests at 64 B), calibrated on WIDE streaming reads.  A random gather fetches one 64-byte sector per "
+                      "gathered value, for which the doubling overcounts: the bytes actually moved lie between "
+                      "traffic_undoubled_fetch (= FETCH_SIZE + WRITE_SIZE as counted) and traffic")
+
+
+def stored_traffic_undoubled(key, applicable=True):
+    """FETCH_SIZE + WRITE_SIZE of the stored passes AS COUNTED (no gfx950 doubling), or None: the lower bracket of a
+    gather-dominated record's HBM bytes."""
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic_latest.json")
+    try:
+        rec = json.load(open(path)).get("workloads", {}).get(key)
+        if not applicable or not rec:
+            return None
+        return int(round((rec["FETCH_SIZE_KB_mean"] + rec["WRITE_SIZE_KB_mean"]) * 1024))
+    except Exception:
+        return None
+
+
 _T0 = time.perf_counter()
 
 
@@ -132,6 +151,8 @@ def _measure_spmm(args, job, hp, wl, A, B, k, world, dev, setup_s, metric, workl
         "roofline": {"bound": "hbm", "achieved": round(b_alg / (device_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(b_alg / (device_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                      "traffic": traffic, "traffic_source": traffic_source,
+                     **({"traffic_undoubled_fetch": stored_traffic_undoubled(traffic_key), "traffic_convention": TRAFFIC_CONVENTION}
+                        if (traffic_key or "").startswith("sprand") and traffic is not None else {}),
                      "algorithmic_bytes_per_launch": b_alg,
                      "block_order_group": int(job.max(hp.spmm_block_order_of(A, B))),
                      "run_tiles": (lambda f: {"used": False, "kernel": "hpcla::spmm_rowblock_vec_kernel",
@@ -310,8 +331,9 @@ def _sprand_spmv(hp, wl, job, A, ncols, backend, args):
     b_alg = wl.spmv_algorithmic_bytes(A.nnz, A.nrows_local, A.ncols_compressed, 4)
     b_sect = A.nnz * (12 + 64) + 12 * A.nrows_local
     mall = ncols * 8 <= (1 << 25)           # the small sibling: x of 17 MB (8 L2s x 4 MiB hold most of it)
-    traffic, traffic_source = stored_traffic("sprand_spmv_mall_sized" if mall else "sprand_spmv_b2e24",
-                                             A.nrows_local == 2_097_152 and ncols in (2_097_152, 16_777_216))
+    tkey = "sprand_spmv_mall_sized" if mall else "sprand_spmv_b2e24"
+    stored_shape = A.nrows_local == 2_097_152 and ncols in (2_097_152, 16_777_216)
+    traffic, traffic_source = stored_traffic(tkey, stored_shape)
     return {"metric": "SpMV GFLOP/s (2*nnz/t), sprand ~29.8 nnz/row, fp64", "value": round(2.0 * A.nnz / (ms * 1e-3) / 1e9, 1),
             "unit": "GFLOP/s", "steps": steps, "warmup": n_warm, "ms_per_step": round(ms, 4), "device_ms_per_step": round(dev_ms, 4),
             "config": {"workload": f"sprand-like {A.nrows_local} x {ncols}, nnz={A.nnz}, CSR SpMV y=A*x, index=i32; x = {ncols * 8 / 1e6:.0f} MB "
@@ -319,6 +341,7 @@ def _sprand_spmv(hp, wl, job, A, ncols, backend, args):
                        "ncols_compressed": A.ncols_compressed},
             "roofline": {"bound": "hbm", "achieved": round(b_alg / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                         "traffic_undoubled_fetch": stored_traffic_undoubled(tkey, stored_shape), "traffic_convention": TRAFFIC_CONVENTION,
                          "kernel": "hpcla::spmv_rowgather_kernel<int, false, false, false>", "algorithmic_bytes_per_launch": b_alg,
                          "block_order_group": int(getattr(plan, "block_group", 1)),
                          "sector_gather_bytes_per_launch": b_sect, "sector_gather_gbs": round(b_sect / (ms * 1e-3) / 1e9, 1),

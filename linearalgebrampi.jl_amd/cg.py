@@ -126,7 +126,7 @@ def cg_fixed_iterations(A, b: HPCVector, iters: int, record_history: bool = True
     the stream it is given (no allocation, no host sync) and the exchange epoch lives in device memory, so
     whole distributed iterations are capturable.  Same kernels, same arguments, hence the same bits as the
     eager loop.  It pays off where an iteration is shorter than the host time to issue its launches (small
-    systems); DESIGN.md section 6 has the measurement for large ones, where eager stays the default."""
+    systems); profiles/MEASUREMENTS_r03.md has the measurement for large ones, where eager stays the default."""
     if A.backend.T == np.dtype(np.float32):
         return _cg_composed_f32(A, b, iters, record_history)
     torch = _torch()

@@ -102,9 +102,11 @@ SETS
     cgtrace)       # kernel timeline of the CG iteration (fixed block order: see pmc_all)
       cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
       rm -rf gpurun_out/${TAG}_cgtrace
-      HPCLA_BLOCK_ORDER=${PMC_ORDER_3D:-64} run 300 gpurun_out/${TAG}_cgtrace.log rocprofv3 --kernel-trace --output-format csv -d gpurun_out/${TAG}_cgtrace -- python3 bench.py --workload poisson3d_cg --steps 40 --warmup 8
+      HPCLA_BLOCK_ORDER=${PMC_ORDER_3D:-64} run 300 gpurun_out/${TAG}_cgtrace.log rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_cgtrace -- python3 bench.py --workload poisson3d_cg --steps 40 --warmup 8
       t=$(find gpurun_out/${TAG}_cgtrace -name '*kernel_trace.csv' | head -1)
-      python benchmarks/trace_gaps.py "$t" "CG 512x512x64, eager (${TAG})" > gpurun_out/${TAG}_cg_gaps.txt 2>&1
+      python benchmarks/trace_gaps.py "$t" "CG 512x512x64, one hpcla_cg_iterations call per timed window (${TAG})" > gpurun_out/${TAG}_cg_gaps.txt 2>&1
+      st=$(find gpurun_out/${TAG}_cgtrace -name '*kernel_stats.csv' | head -1); [ -n "$st" ] && cp "$st" gpurun_out/${TAG}_cg_kernel_stats.csv
+      grep "^{" gpurun_out/${TAG}_cgtrace.log | tail -1 > gpurun_out/${TAG}_cg_under_trace.json
       rm -rf gpurun_out/${TAG}_cgtrace; head -20 gpurun_out/${TAG}_cg_gaps.txt;;
     bench)  run 600 gpurun_out/${TAG}_bench.log python bench.py --steps 100 --warmup 10; tail -3 gpurun_out/${TAG}_bench.log;;
     tune)   run 600 gpurun_out/${TAG}_tune.log python benchmarks/tune_spmv.py ${TUNE_ARGS}; tail -25 gpurun_out/${TAG}_tune.log;;

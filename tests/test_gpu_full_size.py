@@ -12,7 +12,7 @@ size or through their pieces ("parity caveats"):
   bit-equal to the sequential row sum;
 * the packed copy with nnz % 8 != 0, arrays followed by NaN / wrong-column guard entries, so an octet
   load that strays past the end changes the result instead of faulting (the r01q fault's tail case,
-  DESIGN.md section 9).
+  profiles/MEASUREMENTS_r04.md section C).
 """
 import numpy as np
 import pytest

@@ -21,7 +21,7 @@ U = 2.0 ** -53
 
 def _raw_spmv(hp, rowptr, colval, vals, x, Ti, base=0):
     """hpcla_spmv_csr_f64_{i32,i64} directly (the entry point a Julia @ccall binds); operands stay bound to names
-    until after the synchronising read-back."""
+    until after the synchronising read-back (profiles/MEASUREMENTS_r04.md section C, r01a)."""
     import torch
     sfx = "i32" if Ti == np.int32 else "i64"
     rp = torch.from_numpy((rowptr + base).astype(Ti)).cuda()
