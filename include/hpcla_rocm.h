@@ -564,7 +564,10 @@ int hpcla_halo_status(hpcla_halo_plan_t *plan, int *timed_out);
  * indices.  Constant for RCCL plans, for dense (width > 1) push plans and for HPCLA_HALO_SINGLE_BUFFER plans;
  * a double-buffered vector push plan reads its device step counter here, i.e. the call SYNCHRONISES the device
  * and is only meaningful AFTER hpcla_halo_end of the exchange in question -- only the API-parity path
- * (execute_plan!'s `gathered`) asks, the fused SpMV finds its buffer in the kernel. */
+ * (execute_plan!'s `gathered`) asks, the fused SpMV finds its buffer in the kernel.  NEVER inside a collective when
+ * ranks are threads of one process (a device-wide wait then covers the other ranks' waiting kernels: round 6 found
+ * hpcla_halo_plan_probe stalling that way); plans driven through halo_begin / halo_end should be created with
+ * HPCLA_HALO_SINGLE_BUFFER, whose pointer is a constant fetched once at plan time. */
 int hpcla_halo_ghost_ptr(hpcla_halo_plan_t *plan, double **ghost, int64_t *n_ghost);
 /* begin: after everything already enqueued on `stream`, pack x[send_idx] and post the
  * ncclSend/ncclRecv group on the plan's side stream (tag-21 exchange, src/vectors.jl:431-446).

@@ -1144,16 +1144,21 @@ function _matrix_values!(gval::ROCVector{T}, plan::HPCLinearAlgebra.MatrixPlan, 
         send_idx = ROCVector(reduce(vcat, send_lists; init=Int64[]))
         if !isempty(plan.rank_ids) || !isempty(plan.recv_rank_ids)
             AMDGPU.synchronize()
-            _check(@ccall(LIB.hpcla_halo_plan_create(halo::Ptr{Ptr{Cvoid}}, _rccl(comm)::Ptr{Cvoid},
+            # SINGLE-buffered (flags = 1): the plan is driven through halo_begin / halo_end and its ghost pointer is then a
+            # constant, fetched once below -- on a double-buffered plan hpcla_halo_ghost_ptr reads the device step counter,
+            # i.e. synchronises the device and copies 8 bytes to the host on EVERY call
+            _check(@ccall(LIB.hpcla_halo_plan_create_ex(halo::Ptr{Ptr{Cvoid}}, _rccl(comm)::Ptr{Cvoid},
                    length(plan.rank_ids)::Cint, Int32.(plan.rank_ids)::Ptr{Int32},
                    Int64.(length.(send_lists))::Ptr{Int64}, _ptr(send_idx)::Ptr{Cvoid}, 1::Cint,
                    length(plan.recv_rank_ids)::Cint, Int32.(plan.recv_rank_ids)::Ptr{Int32},
-                   recv_counts::Ptr{Int64}, 1::Cint)::Cint), "hpcla_halo_plan_create")
+                   recv_counts::Ptr{Int64}, 1::Cint, 1::Cint)::Cint), "hpcla_halo_plan_create_ex")
         end
         comm isa CommMPI && _attach_halo_window(_rccl(comm), halo[], comm.comm, comm_size(comm))
-        (halo[], send_idx, ROCVector(lsrc), ROCVector(ldst), ROCVector(collect(Int64, 1:length(gdst))), ROCVector(gdst))
+        ghost = Ref{Ptr{Cvoid}}(C_NULL); ng = Ref{Int64}(0)
+        halo[] == C_NULL || _check(@ccall(LIB.hpcla_halo_ghost_ptr(halo[]::Ptr{Cvoid}, ghost::Ptr{Ptr{Cvoid}}, ng::Ptr{Int64})::Cint), "hpcla_halo_ghost_ptr")
+        (halo[], send_idx, ROCVector(lsrc), ROCVector(ldst), ROCVector(collect(Int64, 1:length(gdst))), ROCVector(gdst), ghost[])
     end
-    halo, _, lsrc, ldst, gsrc, gdst = st
+    halo, _, lsrc, ldst, gsrc, gdst, ghost = st
     s = _stream()
     halo == C_NULL || _check(@ccall(LIB.hpcla_halo_begin(halo::Ptr{Cvoid}, _ptr(Bm.nzval)::Ptr{Cvoid}, s::Ptr{Cvoid})::Cint), "hpcla_halo_begin")
     # the own rows' values, under the exchange (1-based lists: index_base = 1)
@@ -1161,9 +1166,7 @@ function _matrix_values!(gval::ROCVector{T}, plan::HPCLinearAlgebra.MatrixPlan, 
                             _ptr(gval)::Ptr{Cvoid}, length(lsrc)::Int64, 1::Cint, s::Ptr{Cvoid})::Cint), "hpcla_gather_f64_i64")
     if halo != C_NULL
         _check(@ccall(LIB.hpcla_halo_end(halo::Ptr{Cvoid}, s::Ptr{Cvoid})::Cint), "hpcla_halo_end")
-        ghost = Ref{Ptr{Cvoid}}(C_NULL); ng = Ref{Int64}(0)
-        _check(@ccall(LIB.hpcla_halo_ghost_ptr(halo::Ptr{Cvoid}, ghost::Ptr{Ptr{Cvoid}}, ng::Ptr{Int64})::Cint), "hpcla_halo_ghost_ptr")
-        isempty(gdst) || _check(@ccall(LIB.hpcla_gather_f64_i64(ghost[]::Ptr{Cvoid}, _ptr(gsrc)::Ptr{Cvoid}, _ptr(gdst)::Ptr{Cvoid},
+        isempty(gdst) || _check(@ccall(LIB.hpcla_gather_f64_i64(ghost::Ptr{Cvoid}, _ptr(gsrc)::Ptr{Cvoid}, _ptr(gdst)::Ptr{Cvoid},
                                 _ptr(gval)::Ptr{Cvoid}, length(gdst)::Int64, 1::Cint, s::Ptr{Cvoid})::Cint), "hpcla_gather_f64_i64")
     end
     return gval
@@ -1396,11 +1399,13 @@ function HPCLinearAlgebra.execute_plan!(plan::HPCLinearAlgebra.VectorPlan{T,Ti,<
         send_idx = ROCVector(Int64.(reduce(vcat, plan.send_indices; init=Ti[])) .- 1)      # 0-based, kept alive with the plan
         if !isempty(plan.send_rank_ids) || !isempty(plan.recv_rank_ids)
             AMDGPU.synchronize()
-            _check(@ccall(LIB.hpcla_halo_plan_create(halo::Ptr{Ptr{Cvoid}}, _rccl(x.backend.comm)::Ptr{Cvoid},
+            # SINGLE-buffered (flags = 1): begin / end driven; the ghost pointer is a constant fetched once below (a
+            # double-buffered plan's hpcla_halo_ghost_ptr synchronises the device and reads 8 bytes back on every call)
+            _check(@ccall(LIB.hpcla_halo_plan_create_ex(halo::Ptr{Ptr{Cvoid}}, _rccl(x.backend.comm)::Ptr{Cvoid},
                    length(plan.send_rank_ids)::Cint, Int32.(plan.send_rank_ids)::Ptr{Int32},
                    Int64.(length.(plan.send_indices))::Ptr{Int64}, _ptr(send_idx)::Ptr{Cvoid}, 1::Cint,
                    length(plan.recv_rank_ids)::Cint, Int32.(plan.recv_rank_ids)::Ptr{Int32},
-                   Int64.(length.(plan.recv_perm))::Ptr{Int64}, 1::Cint)::Cint), "hpcla_halo_plan_create")
+                   Int64.(length.(plan.recv_perm))::Ptr{Int64}, 1::Cint, 1::Cint)::Cint), "hpcla_halo_plan_create_ex")
         end
         x.backend.comm isa CommMPI &&
             _attach_halo_window(_rccl(x.backend.comm), halo[], x.backend.comm.comm, comm_size(x.backend.comm))

@@ -310,6 +310,8 @@ static void halo_free(hpcla_halo_plan *p)
     if (p->send_idx) (void)hipFree(p->send_idx);
     if (p->send_buf) (void)hipFree(p->send_buf);
     push_free(p);                                  // peer mappings + the window (which holds the ghost)
+    for (void *q : p->probe_scratch) (void)hipFree(q);
+    p->probe_scratch.clear();
     if (p->ghost) (void)hipFree(p->ghost);
     if (p->ev_ready) (void)hipEventDestroy(p->ev_ready);
     if (p->ev_done) (void)hipEventDestroy(p->ev_done);
@@ -594,6 +596,12 @@ HPCLA_API int hpcla_halo_end(hpcla_halo_plan_t *plan, void *stream)
 
 // ---- connection test of ONE plan on the real topology ---------------------------------------------------
 // x[e] = rank * 2^40 + e (+ shift): a ghost slot filled by rank r from its row i holds r * 2^40 + i*w + j.
+__global__ void probe_reset_kernel(unsigned long long *bad)
+{
+    bad[0] = 0ULL;           // mismatches seen
+    bad[1] = ~0ULL;          // first mismatching ghost element (minimum)
+}
+
 __global__ void probe_fill_kernel(double *x, int64_t n, double base, double shift)
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -605,10 +613,16 @@ __global__ void probe_fill_kernel(double *x, int64_t n, double base, double shif
 // rewrites a single-buffered (cacheable, fine-grained) dense ghost window with DIFFERENT values -- reads them WARM on
 // every XCD.  A line a peer's xGMI store failed to invalidate here shows up as a wrong value, the plan fails its
 // connection test on the real topology and stays on RCCL.  (Vector ghost windows are uncached and double-buffered.)
-__global__ void probe_check_kernel(const double *ghost, const int64_t *slots, const int64_t *rows,
+// The ghost buffer of the exchange completed last is found HERE, from the plan's device-resident step counter (`done`, written
+// by the wait kernel that precedes this launch on the stream): buffer done % nbuf.  The host's way to the same pointer --
+// hpcla_halo_ghost_ptr on a double-buffered plan -- synchronises the whole DEVICE, which a collective must not do (below).
+__global__ void probe_check_kernel(const double *ghost0, int64_t buf_stride, int nbuf, const uint64_t *done,
+                                   const int64_t *slots, const int64_t *rows,
                                    const int32_t *owners, int64_t n_check, int w, double shift,
                                    unsigned long long *bad)      // bad[0] = count, bad[1] = first wrong element
 {
+    const uint64_t completed = (done && nbuf > 1) ? __hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    const double *ghost = ghost0 + (int64_t)(completed % (uint64_t)(nbuf > 1 ? nbuf : 1)) * buf_stride;
     const int64_t total = n_check * w;
     for (int64_t e = threadIdx.x; e < total; e += blockDim.x) {
         const int64_t t = e / w;
@@ -652,15 +666,34 @@ HPCLA_API int hpcla_halo_plan_probe(hpcla_halo_plan_t *plan, int64_t n_local_row
     int64_t *d_slots = nullptr, *d_rows = nullptr;
     int32_t *d_own = nullptr;
     unsigned long long *d_bad = nullptr;
-    hipError_t e = hipMalloc((void **)&x, (size_t)nx * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void **)&d_bad, 2 * sizeof(unsigned long long));
+    // COLLECTIVE HYGIENE (round 6).  Ranks may be host threads of ONE process sharing the device (tests/cabi/
+    // cabi_ranks_threads.c: how 8 ranks are rehearsed on a box that allows 6 GPU processes).  Between the first launch of
+    // this function and its last read-back some rank's kernel may be spinning for a launch another rank has not made yet,
+    // so nothing in here may wait for the DEVICE: a device-wide wait on a slow rank includes a fast rank's wait kernel,
+    // which spins for the slow rank's NEXT push -- a cycle only the spin bound breaks.  That was the stall of round 6:
+    // hpcla_halo_ghost_ptr on a double-buffered plan is hipDeviceSynchronize + a read of the step counter, and the probe
+    // called it once per round (8 of 24 probes timed out in round 1 at 8 thread-ranks; 0 of 24 since the check kernel finds
+    // the buffer itself: profiles/MEASUREMENTS_r06.md section E).  For the same reason: no hipFree in here (with in-process
+    // peers the scratch goes at the plan's destroy), no blocking copy on the process-wide null stream, no async copy to or
+    // from pageable host memory behind a waiting kernel.  Copies run on the CALLER's stream while it is idle.
+    std::vector<void *> mine;
+    auto scratch = [&](void **q, size_t bytes) {
+        hipError_t a = hipMalloc(q, bytes);
+        if (a == hipSuccess) mine.push_back(*q);
+        return a;
+    };
+    hipError_t e = scratch((void **)&x, (size_t)nx * sizeof(double));
+    if (e == hipSuccess) e = scratch((void **)&d_bad, 2 * sizeof(unsigned long long));
     if (e == hipSuccess && n_check) {
-        e = hipMalloc((void **)&d_slots, (size_t)n_check * sizeof(int64_t));
-        if (e == hipSuccess) e = hipMalloc((void **)&d_rows, (size_t)n_check * sizeof(int64_t));
-        if (e == hipSuccess) e = hipMalloc((void **)&d_own, (size_t)n_check * sizeof(int32_t));
-        if (e == hipSuccess) e = hipMemcpy(d_slots, check_slots_host, (size_t)n_check * sizeof(int64_t), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(d_rows, check_rows_host, (size_t)n_check * sizeof(int64_t), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(d_own, owners.data(), (size_t)n_check * sizeof(int32_t), hipMemcpyHostToDevice);
+        e = scratch((void **)&d_slots, (size_t)n_check * sizeof(int64_t));
+        if (e == hipSuccess) e = scratch((void **)&d_rows, (size_t)n_check * sizeof(int64_t));
+        if (e == hipSuccess) e = scratch((void **)&d_own, (size_t)n_check * sizeof(int32_t));
+        // (the caller's stream is idle here -- nothing of this plan has been launched yet -- and a copy from pageable memory
+        //  returns once the host buffer has been read: `owners` may go out of scope afterwards)
+        if (e == hipSuccess) e = hipMemcpyAsync(d_slots, check_slots_host, (size_t)n_check * sizeof(int64_t), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_rows, check_rows_host, (size_t)n_check * sizeof(int64_t), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_own, owners.data(), (size_t)n_check * sizeof(int32_t), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
     }
     int rc = HPCLA_OK;
     bool good = (e == hipSuccess);
@@ -669,25 +702,28 @@ HPCLA_API int hpcla_halo_plan_probe(hpcla_halo_plan_t *plan, int64_t n_local_row
     // one's, so a stale buffer cannot pass.  Every rank with a plan makes the same two exchanges.
     for (int round = 0; round < 2 && e == hipSuccess && rc == HPCLA_OK; ++round) {
         const double shift = round ? 0.25 : 0.0;
-        const unsigned long long init[2] = {0ULL, ~0ULL};
-        e = hipMemcpyAsync(d_bad, init, sizeof(init), hipMemcpyHostToDevice, s);
-        if (e != hipSuccess) break;
+        // (a kernel, not a copy from pageable host memory: see the read-back below)
+        probe_reset_kernel<<<1, 1, 0, s>>>(d_bad);
         int64_t g = (nx + 255) / 256;
         probe_fill_kernel<<<(uint32_t)(g > 4096 ? 4096 : g), 256, 0, s>>>(x, nx, (double)plan->comm->rank * 1099511627776.0, shift);
         rc = hpcla_halo_begin(plan, x, stream);
         if (rc == HPCLA_OK) rc = hpcla_halo_end(plan, stream);
-        double *ghost = nullptr;
-        if (rc == HPCLA_OK) rc = hpcla_halo_ghost_ptr(plan, &ghost, nullptr);
         if (rc != HPCLA_OK) break;
+        // (NOT hpcla_halo_ghost_ptr: COLLECTIVE HYGIENE above; the check kernel derives the buffer from the step counter)
+        const bool attached = plan->attached && plan->win;
+        const int nbuf = attached ? plan->nbuf : 1;
+        const int64_t stride = nbuf > 1 ? (int64_t)(hpcla::halo_window_buf_bytes((uint64_t)plan->n_ghost, (uint32_t)plan->width) / sizeof(double)) : 0;
         if (n_check)
-            probe_check_kernel<<<PROBE_CHECK_BLOCKS, 256, 0, s>>>(ghost, d_slots, d_rows, d_own, n_check, w, shift, d_bad);
+            probe_check_kernel<<<PROBE_CHECK_BLOCKS, 256, 0, s>>>(plan->ghost, stride, nbuf, attached ? plan->epoch_dev : nullptr,
+                                                                  d_slots, d_rows, d_own, n_check, w, shift, d_bad);
+        // read-backs on the caller's stream AFTER it has drained (an idle stream: the copies start at once)
         unsigned long long bad[2] = {0, 0};
-        e = hipMemcpyAsync(bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, s);
+        uint32_t timed_out = 0;
+        e = hipStreamSynchronize(s);
+        if (e == hipSuccess) e = hipMemcpyAsync(bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess && plan->status) e = hipMemcpyAsync(&timed_out, plan->status, sizeof(timed_out), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) break;
-        int timed_out = 0;
-        rc = hpcla_halo_status(plan, &timed_out);
-        if (rc != HPCLA_OK) break;
         if (timed_out) {
             good = false;
             snprintf(why, sizeof(why), "halo_plan_probe: a push or a wait timed out in round %d", round);
@@ -700,7 +736,13 @@ HPCLA_API int hpcla_halo_plan_probe(hpcla_halo_plan_t *plan, int64_t n_local_row
             break;
         }
     }
-    (void)hipFree(x); (void)hipFree(d_bad); (void)hipFree(d_slots); (void)hipFree(d_rows); (void)hipFree(d_own);
+    // the scratch (n_local_rows * width doubles: 2 GB for config 5's width-16 plan): freed here when every peer is another
+    // PROCESS -- its kernels are not this process's to wait for --, kept until the plan's destroy when a peer is a thread of
+    // this process (COLLECTIVE HYGIENE above: hipFree waits for the whole device)
+    bool in_process_peer = false;
+    for (const auto &m : plan->peer_maps) in_process_peer = in_process_peer || m.local_ref;
+    if (in_process_peer) plan->probe_scratch.insert(plan->probe_scratch.end(), mine.begin(), mine.end());
+    else for (void *q : mine) (void)hipFree(q);
     if (e != hipSuccess) return set_error(HPCLA_ERR_HIP, "halo_plan_probe: %s", hipGetErrorString(e));
     if (rc != HPCLA_OK) return rc;
     if (!good) (void)set_error(HPCLA_ERR_INVALID, "%s", why);        // the reason, for hpcla_last_error()

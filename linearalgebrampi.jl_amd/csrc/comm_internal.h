@@ -49,6 +49,7 @@ struct PeerMap {                               // a peer's window mapped into th
 };
 
 uint64_t host_identity();
+size_t halo_window_buf_bytes(uint64_t n_ghost, uint32_t width);
 int window_alloc(void **p, size_t bytes, bool uncached);
 int window_open(const WindowDesc &d, int peer_rank, int my_rank, void *my_base, PeerMap *out);
 void window_close(PeerMap *m);
@@ -116,6 +117,9 @@ struct hpcla_halo_plan {
     uint64_t *arrive = nullptr;                // device, local: arrival counters, one per send neighbour
     bool attached = false;
     uint64_t *epoch_dev = nullptr;             // device {done, top, shard counters}: the plan's step counter (halo_wait.h)
+    // scratch of hpcla_halo_plan_probe, released with the plan: freeing inside the probe would be a device-wide
+    // synchronisation in the middle of a collective (comm.hip, hpcla_halo_plan_probe)
+    std::vector<void *> probe_scratch;
 };
 
 namespace hpcla {

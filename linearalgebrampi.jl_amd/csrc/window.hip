@@ -169,11 +169,15 @@ static void local_window_release(void *base)
 void window_free(void *win)
 {
     if (!win) return;
+    static const bool defer = [] {
+        const char *e = getenv("HPCLA_WINDOW_DEFER_FREE");       // 0: the owner's free is immediate (diagnostics)
+        return !(e && e[0] == '0');
+    }();
     {
         std::lock_guard<std::mutex> lock(g_local_mu);
         for (auto it = g_local_windows.begin(); it != g_local_windows.end(); ++it) {
             if (it->second.base != win) continue;
-            if (it->second.refs > 0) {                // an in-process peer still maps it: its last window_close frees it
+            if (defer && it->second.refs > 0) {       // an in-process peer still maps it: its last window_close frees it
                 it->second.owner_freed = true;
                 return;
             }
@@ -300,6 +304,8 @@ static size_t halo_buf_bytes(uint64_t n_ghost, uint32_t width)
 {
     return round_up((size_t)n_ghost * width * sizeof(double), 256);
 }
+// (for comm.hip's probe: doubles between the two ghost buffers of a double-buffered window)
+size_t halo_window_buf_bytes(uint64_t n_ghost, uint32_t width) { return halo_buf_bytes(n_ghost, width); }
 
 int push_plan_alloc(hpcla_halo_plan *p)
 {
@@ -602,6 +608,8 @@ HPCLA_API int hpcla_comm_window_attach(hpcla_comm_t *comm, const uint8_t *all_de
     return HPCLA_OK;
 }
 
+__global__ void selftest_set_kernel(double *p, double v) { *p = v; }
+
 // Connection test, run once after attach: an all-reduce of (rank + 1) through the windows with its own
 // (short) timeout.  *ok = 1 iff every peer's store arrived here and the sum is n(n+1)/2.  The host layer
 // all-gathers `ok` and, unless every rank passed, detaches the windows everywhere and stays on RCCL.
@@ -618,19 +626,22 @@ HPCLA_API int hpcla_comm_window_selftest(hpcla_comm_t *comm, double timeout_s, i
     // cannot deliver
     hipStream_t s = nullptr;
     hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipMemcpyAsync(buf, &mine, sizeof(double), hipMemcpyHostToDevice, s);
+    // The operand goes in as a kernel argument and the results come back behind the stream's synchronisation: nothing is
+    // parked behind the waiting kernel on behalf of the host (collective hygiene for thread-ranks of one process: comm.hip,
+    // hpcla_halo_plan_probe)
     double got = 0.0;
     uint32_t st = 1;
     if (e == hipSuccess) {
+        selftest_set_kernel<<<1, 1, 0, s>>>(buf, mine);
         uint64_t *my_slots = reinterpret_cast<uint64_t *>(reinterpret_cast<uint8_t *>(comm->win) + WIN_LINE);
         window_allreduce_kernel<<<1, 64, 0, s>>>((uint64_t *const *)comm->peer_slots_dev, my_slots,
                                                  reinterpret_cast<uint32_t *>(comm->win), buf, 1, 0,
                                                  comm->nranks, comm->rank, comm->ar_done_dev,
                                                  (int64_t)((timeout_s > 0 ? timeout_s : 5.0) * 1.0e8));
         e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync(&got, buf, sizeof(double), hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipMemcpyAsync(&st, comm->win, sizeof(st), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e == hipSuccess) e = hipMemcpy(&got, buf, sizeof(double), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(&st, comm->win, sizeof(st), hipMemcpyDeviceToHost);
     }
     if (s) (void)hipStreamDestroy(s);
     (void)hipFree(buf);

@@ -43,6 +43,18 @@ static int g_ok[MAXR];
 static double g_dots[MAXR][8];
 
 static void barrier(void) { pthread_barrier_wait(&g_bar); }
+/* where every rank is (kind * 1000 + phase * 10 + detail): printed by a rank whose connection test fails, so that a timeout
+ * names the rank the others were waiting for and the call it was in */
+static volatile int g_stage[MAXR];
+static int g_kind_now[MAXR];
+#define STAGE(phase) (g_stage[rank] = g_kind_now[rank] * 1000 + (phase))
+static void print_stages(int rank, const char *what)
+{
+    char line[512];
+    int n = snprintf(line, sizeof(line), "rank %d: %s; stages:", rank, what);
+    for (int r = 0; r < R && n < (int)sizeof(line) - 16; ++r) n += snprintf(line + n, sizeof(line) - (size_t)n, " r%d=%d", r, g_stage[r]);
+    fprintf(stderr, "%s\n", line);
+}
 
 static uint64_t splitmix64(uint64_t z)
 {
@@ -164,19 +176,28 @@ static int block_lists(int rank, const int32_t *d_rp, const int32_t *d_split, in
 }
 
 /* export / all-gather / attach / probe of one plan; `width` values per index */
-static int connect_plan(int rank, hpcla_halo_plan_t *plan, const int64_t *ghost, int64_t n_ghost, hipStream_t s)
+static int connect_plan(int rank, hpcla_halo_plan_t *plan, const int64_t *ghost, int64_t n_ghost, hipStream_t s, int phase0)
 {
+    STAGE(phase0 + 1);
     CHECK(hpcla_halo_plan_export(plan, g_desc + rank * HPCLA_WINDOW_DESC_BYTES, g_tab + (size_t)rank * HPCLA_WINDOW_TABLE_ROWS * R));
+    STAGE(phase0 + 2);
     barrier();
+    STAGE(phase0 + 3);
     int rc = hpcla_halo_plan_attach(plan, g_desc, g_tab);
+    STAGE(phase0 + 4);
     if (rc) fprintf(stderr, "rank %d: attach: %s\n", rank, hpcla_last_error());
     if (!all_ok(rank, rc == 0)) return 1;
+    STAGE(phase0 + 5);
     /* connection test over EVERY ghost slot: slot t holds local row (column - owner's first row) of its owner */
     int64_t *slots = (int64_t *)malloc((size_t)(n_ghost ? n_ghost : 1) * 8), *rows = (int64_t *)malloc((size_t)(n_ghost ? n_ghost : 1) * 8);
     for (int64_t t = 0; t < n_ghost; ++t) { slots[t] = t; rows[t] = ghost[t] % M; }
     int ok = 0;
     rc = hpcla_halo_plan_probe(plan, M, slots, rows, n_ghost, s, &ok);
-    if (rc || !ok) fprintf(stderr, "rank %d: plan probe failed: %s\n", rank, hpcla_last_error());
+    STAGE(phase0 + 6);
+    if (rc || !ok) {
+        fprintf(stderr, "rank %d: plan probe failed: %s\n", rank, hpcla_last_error());
+        print_stages(rank, "probe failed");
+    }
     free(slots); free(rows);
     return all_ok(rank, rc == 0 && ok) ? 0 : 1;
 }
@@ -184,6 +205,8 @@ static int connect_plan(int rank, hpcla_halo_plan_t *plan, const int64_t *ghost,
 static int run_matrix(int rank, int kind, hpcla_comm_t *comm, hipStream_t s)
 {
     const char *name = kind == ALLTOALL ? "alltoall" : "slab";
+    g_kind_now[rank] = kind + 1;
+    STAGE(1);
     const int64_t lo = rank * M, hi = lo + M, n = M * R;
     /* ---- local CSR in the split column space (own -> offset in x.v, ghost -> M + position in the ghost segment) ---- */
     int64_t *ghost = NULL;
@@ -238,10 +261,11 @@ static int run_matrix(int rank, int kind, hpcla_comm_t *comm, hipStream_t s)
 
     /* ---- vector plan (double-buffered window, fused SpMV) -------------------------------------------------------- */
     hpcla_halo_plan_t *plan = NULL, *plan16 = NULL;
+    STAGE(90);
     int rc = hpcla_halo_plan_create(&plan, comm, n_send, send_ranks, send_counts, d_send, 0, n_recv, recv_ranks, recv_counts, 1);
     if (rc) fprintf(stderr, "rank %d %s: plan create: %s\n", rank, name, hpcla_last_error());
     if (!all_ok(rank, rc == 0)) return 1;
-    if (connect_plan(rank, plan, ghost, n_ghost, s)) return 1;
+    if (connect_plan(rank, plan, ghost, n_ghost, s, 100)) return 1;
     int32_t *d_int, *d_bnd;
     int64_t n_int, n_bnd;
     if (block_lists(rank, d_rp, d_split, hpcla_spmv_rows_per_block(), &d_int, &n_int, &d_bnd, &n_bnd, s)) return 1;
@@ -254,13 +278,17 @@ static int run_matrix(int rank, int kind, hpcla_comm_t *comm, hipStream_t s)
     int bad = 0;
     barrier();
     for (int step = 0; step < 6; ++step) {
+        STAGE(200 + step);
         const uint64_t seed = 0xC0FFEEULL + 977ULL * (uint64_t)step + 31ULL * (uint64_t)kind;
         CHECK(hpcla_fill_uniform_f64(d_x, lo, M, seed, s));
         CHECK(hpcla_spmv_dist_f64_i32(plan, d_rp, d_split, d_vals, d_x, M, d_y, M, nnz, 0, d_int, n_int, d_bnd, n_bnd, s));
         CHECK(hpcla_dot_f64(comm, d_x, d_y, M, d_out, d_work, s));
-        HIPCHECK(hipMemcpyAsync(h_y, d_y, (size_t)M * 8, hipMemcpyDeviceToHost, s));
-        HIPCHECK(hipMemcpyAsync(&g_dots[rank][step], d_out, 8, hipMemcpyDeviceToHost, s));
+        /* read-backs BEHIND the synchronisation: nothing of the host's is parked behind the waiting kernels (the rank threads
+         * of this process share the runtime's locks; the stall this test showed in round 6 was a device-wide wait inside the
+         * library's probe, comm.hip hpcla_halo_plan_probe) */
         HIPCHECK(hipStreamSynchronize(s));
+        HIPCHECK(hipMemcpy(h_y, d_y, (size_t)M * 8, hipMemcpyDeviceToHost));
+        HIPCHECK(hipMemcpy((void *)&g_dots[rank][step], d_out, 8, hipMemcpyDeviceToHost));
         for (int64_t g = 0; g < n; ++g) xg[g] = u01(seed, g);
         for (int64_t r = 0; r < M; ++r) {                 /* stored order, multiply then add: the kernel's order */
             double acc = 0.0;
@@ -291,11 +319,13 @@ static int run_matrix(int rank, int kind, hpcla_comm_t *comm, hipStream_t s)
 
     /* ---- A*B, k = 16: ghost ROWS through a width-16 single-buffered plan ---------------------------------------- */
     const int K = 16;
+    STAGE(280);
     rc = hpcla_halo_plan_create_ex(&plan16, comm, n_send, send_ranks, send_counts, d_send, 0, n_recv, recv_ranks, recv_counts, K,
                                    HPCLA_HALO_SINGLE_BUFFER);
     if (rc) fprintf(stderr, "rank %d %s: width-16 plan create: %s\n", rank, name, hpcla_last_error());
     if (!all_ok(rank, rc == 0)) return 1;
-    if (connect_plan(rank, plan16, ghost, n_ghost, s)) return 1;
+    STAGE(290);
+    if (connect_plan(rank, plan16, ghost, n_ghost, s, 300)) return 1;
     int32_t *d_int16, *d_bnd16;
     int64_t n_int16, n_bnd16;
     if (block_lists(rank, d_rp, d_split, hpcla_spmm_rows_per_block(), &d_int16, &n_int16, &d_bnd16, &n_bnd16, s)) return 1;
@@ -307,6 +337,7 @@ static int run_matrix(int rank, int kind, hpcla_comm_t *comm, hipStream_t s)
     if (ng != n_ghost) { fprintf(stderr, "rank %d %s: ghost of %lld rows, expected %lld\n", rank, name, (long long)ng, (long long)n_ghost); ++bad; }
     barrier();
     for (int rep = 0; rep < 3; ++rep) {                  /* three products, other B each time: a stale ghost row cannot pass */
+        STAGE(400 + rep);
         const uint64_t seed = 4711ULL + 13ULL * (uint64_t)rep;
         CHECK(hpcla_fill_uniform_f64(d_B, lo * K, M * K, seed, s));      /* B[g, c] = u01(seed, g*K + c), row-major */
         CHECK(hpcla_halo_begin(plan16, d_B, s));
@@ -315,8 +346,8 @@ static int run_matrix(int rank, int kind, hpcla_comm_t *comm, hipStream_t s)
         CHECK(hpcla_halo_end(plan16, s));
         if (n_bnd16)
             CHECK(hpcla_spmm_split_f64_i32(d_rp, d_split, d_vals, d_B, K, d_ghost, K, M, d_C, K, M, nnz, K, 0, d_bnd16, n_bnd16, s));
-        HIPCHECK(hipMemcpyAsync(h_C, d_C, (size_t)M * K * 8, hipMemcpyDeviceToHost, s));
         HIPCHECK(hipStreamSynchronize(s));
+        HIPCHECK(hipMemcpy(h_C, d_C, (size_t)M * K * 8, hipMemcpyDeviceToHost));
         for (int64_t r = 0; r < M; ++r)
             for (int c = 0; c < K; ++c) {
                 double acc = 0.0;
@@ -331,9 +362,13 @@ static int run_matrix(int rank, int kind, hpcla_comm_t *comm, hipStream_t s)
     CHECK(hpcla_comm_status(comm, &t3));
     if (t1 || t2 || t3) { fprintf(stderr, "rank %d %s: a spin timed out (%d %d %d)\n", rank, name, t1, t2, t3); ++bad; }
     HIPCHECK(hipStreamSynchronize(s));
+    STAGE(500);
     const int ok = all_ok(rank, bad == 0);                /* everybody done before anybody unmaps */
+    STAGE(510);
     CHECK(hpcla_halo_plan_destroy(plan16));
+    STAGE(520);
     CHECK(hpcla_halo_plan_destroy(plan));
+    STAGE(530);
     if (ok && rank == 0)
         printf("%s: %d ranks, %d neighbours each way on rank 0, %lld ghost values: 6 SpMVs + 3 products (k = 16) bit-exact, dots identical on all ranks\n",
                name, R, n_recv, (long long)n_ghost);

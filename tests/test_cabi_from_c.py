@@ -50,7 +50,9 @@ def test_cabi_eight_ranks_seven_neighbours_in_one_process(nranks):
     identical dot bits on all ranks.  3 ranks: the same program at an odd count."""
     if not os.path.exists(EXE_RANKS):
         _build(SRC_RANKS, EXE_RANKS)
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # (GPU_MAX_HW_QUEUES in the ENVIRONMENT, not only by the program's own setenv: the HIP runtime may read its flags when the
+    #  library's code object registers itself, before main(); every rank's streams need hardware queues of their own)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", GPU_MAX_HW_QUEUES=os.environ.get("GPU_MAX_HW_QUEUES", "32"))
     out = subprocess.run([EXE_RANKS, str(nranks)], capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     assert f"C-ABI {nranks} ranks in one process PASS" in out.stdout
