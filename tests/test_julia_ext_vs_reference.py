@@ -441,3 +441,216 @@ def test_spmm_result_passes_the_fields_of_hpcmatrix_in_order():
     args = [a.strip() for a, _ in _split_top(ext[i + 1:_match_paren(ext, i) - 1])]
     assert len(args) == 5 and args[0] == "nothing" and args[1] == "copy(A.row_partition)" and args[3] == "C" and args[4] == "A.backend", args
     assert args[2].startswith("HPCLinearAlgebra.uniform_partition(k,"), args[2]
+
+
+def _unbound_type_variables(text):
+    """[(definition, line, missing names)] -- see test_type_variables_are_bound"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import test_julia_no_host_staging as audit
+    names = ("T", "Ti", "Tk", "B", "Timat", "AV")
+    problems = []
+    for name, first, last, body in audit.parse_functions(text):
+        code = [audit._code(l) for l in body]
+        sig = re.sub(r"^function\s+", "", " ".join(code[:10]))
+        i = sig.index("(")
+        j = audit._match_close(sig, i)
+        bound = set()
+        m = re.match(r"\s*where\s*", sig[j:])
+        if m:
+            k = j + m.end()
+            if sig[k] == "{":
+                depth, e = 0, k
+                while True:
+                    depth += {"{": 1, "}": -1}.get(sig[e], 0)
+                    e += 1
+                    if depth == 0:
+                        break
+                inner, depth, cur, parts = sig[k + 1:e - 1], 0, "", []
+                for ch in inner:
+                    depth += {"{": 1, "}": -1}.get(ch, 0)
+                    if ch == "," and depth == 0:
+                        parts.append(cur)
+                        cur = ""
+                    else:
+                        cur += ch
+                parts.append(cur)
+                bound = {re.match(r"\s*(\w+)", q).group(1) for q in parts if q.strip()}
+            else:
+                bound = {re.match(r"(\w+)", sig[k:]).group(1)}
+        whole = "\n".join(code)
+        assigned = set(re.findall(r"(?<![\w.])(%s)\s*=(?!=)" % "|".join(names), whole))
+        argnames = set(re.findall(r"[(,]\s*(\w+)\s*(?:::|[,)=])", sig[i:j]))
+        used = set(re.findall(r"(?<![\w.:\"])(%s)(?![\w(\"])" % "|".join(names), whole))
+        missing = used - bound - assigned - argnames
+        if missing:
+            problems.append((name, first, sorted(missing), sorted(bound)))
+    return problems
+
+
+def test_type_variables_are_bound():
+    """A Julia method whose signature or body names a type variable that its `where` clause does not bind is an UndefVarError
+    at the first call -- invisible to every other static check of this file.  For every top-level definition of the extension:
+    the conventional type-variable names it uses (T, Ti, Tk, B, Timat, AV) must be bound by the where clause (balanced braces:
+    `T<:Union{Float32,Float64}`), be the name of an argument, or be assigned in the body (`Ti = indextype_backend(B)`).
+    Nested closures (`function launch(...)` inside a method, `do` blocks) see the enclosing method's variables."""
+    text = open(EXT).read()
+    problems = _unbound_type_variables(text)
+    assert not problems, "\n".join(f"{n} (line {l}): {m} used but not bound by `where` ({b}) nor assigned" for n, l, m, b in problems)
+    # the check must be able to fail: drop `Tk` from one where clause, use an unbound `Ti` in a body
+    old = "d::ROCVectorPlan{Tk}, xpart::Vector{Int}, width::Int, rpb::Cint) where {T,Ti,Tk,B<:ROCBackend}"
+    assert text.count(old) == 1
+    got = _unbound_type_variables(text.replace(old, old.replace("{T,Ti,Tk,B<:ROCBackend}", "{T,Ti,B<:ROCBackend}")))
+    assert any(n == "_spmm_halo" and "Tk" in m for n, l, m, b in got), got
+    old2 = "function _classify_blocks(A, rp0::ROCVector{Tk}, colval_split::ROCVector{Tk}, n_own::Int, rpb::Cint) where {Tk}\n"
+    assert text.count(old2) == 1
+    got = _unbound_type_variables(text.replace(old2, old2 + "    z = zero(Ti)\n"))
+    assert any(n == "_classify_blocks" and "Ti" in m for n, l, m, b in got), got
+
+def _undefined_names(text):
+    """[(definition, line, names)]: identifiers a top-level definition of the extension uses that are neither its arguments,
+    type variables, names assigned anywhere in it (plain / tuple / augmented assignment, `for` variables, `do` and `->`
+    arguments, nested function definitions and their arguments), module-level names of the file (functions, consts, structs,
+    the `using HPCLinearAlgebra:` list, the imported modules) nor one of the Base / AMDGPU names the file is known to use."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import test_julia_no_host_staging as t
+    code_all = "\n".join(t._code(l) for l in text.split("\n"))
+    funcs = t.parse_functions(text)
+    KEYWORDS=set("function end if else elseif for while in return where do let begin try catch finally const mutable struct module using import export true false nothing isa break continue local global quote macro new".split())
+    # module-level names
+    modnames=set(re.findall(r"^const\s+(\w+)",code_all,flags=re.M))|set(re.findall(r"^(?:mutable\s+)?struct\s+(\w+)",code_all,flags=re.M))
+    modnames|={f[0].split(".")[-1].lstrip(":") for f in funcs}
+    m=re.search(r"using\s+HPCLinearAlgebra\s*:\s*((?:[\w!]+\s*,\s*)*[\w!]+)",code_all)
+    modnames|={n.strip() for n in m.group(1).split(",")}
+    modnames|={"HPCLinearAlgebra","AMDGPU","MPI","LinearAlgebra","SparseArrays","Base","LIB","ROCBackend"}
+    BASE=set("""Ptr Cvoid Cint Cdouble Cstring Cfloat UInt UInt8 UInt32 UInt64 Int Int8 Int16 Int32 Int64 Float16 Float32 Float64 Bool Any Real Number Integer
+    Vector Matrix Array Dict IdDict Ref Type Union Tuple NamedTuple Symbol AbstractString AbstractVector AbstractMatrix UnitRange Nothing
+    ROCArray ROCVector ROCMatrix C_NULL ENV Inf
+    error get get! haskey length size zeros fill similar copy push! append! empty! filter! popfirst! sum minimum maximum extrema any all isempty zip enumerate
+    reduce vcat cld iseven isnan sqrt parse max min unsafe_string pointer reshape findall unique rand sortperm cumsum cumsum! reinterpret convert
+    collect eltype typemax one zero values keys first last invoke MergeSort searchsortedfirst searchsortedlast undef typeof diff
+    isa @ccall @inbounds ccall string print println abs Threads""".split())
+    probs=[]
+    for name,first,last,body in funcs:
+        code=[t._code(l) for l in body]
+        whole="\n".join(code)
+        # strip @ccall type annotations noise: keep
+        ids=set(re.findall(r"(?<![\w.:@])([A-Za-z_]\w*!?)(?![\w!])",whole))
+        # remove field accesses (after a dot) -- handled by lookbehind; remove keyword-arg names `name=` inside calls? keep
+        sig=re.sub(r"^function\s+","",whole)
+        i=sig.index("("); j=t._match_close(sig,i)
+        args=set()
+        depth=0; cur=""
+        for ch in sig[i+1:j-1]:
+            if ch in "({[": depth+=1
+            elif ch in ")}]": depth-=1
+            if ch in ",;" and depth==0:
+                mm=re.match(r"\s*(\w+)",cur); 
+                if mm: args.add(mm.group(1))
+                cur=""
+            else: cur+=ch
+        mm=re.match(r"\s*(\w+)",cur)
+        if mm: args.add(mm.group(1))
+        wherev=set(re.findall(r"\b(\w+)\s*(?:<:|[,}])",sig[j:j+200].split("\n")[0])) if "where" in sig[j:j+200].split("\n")[0] else set()
+        assigned=set(re.findall(r"(?<![\w.])(\w+)\s*(?:=(?!=)|\+=|-=|\*=|\|=|&=)",whole))
+        # tuple assignments a, b = ... / (a, b) = / for (a, b) in
+        for mm in re.finditer(r"(?:^|\n|;)\s*((?:\w+\s*,\s*)+\w+)\s*=(?!=)",whole):
+            assigned|=set(re.findall(r"\w+",mm.group(1)))
+        for mm in re.finditer(r"\(\s*((?:\w+\s*,\s*)+\w+)\s*\)\s*(?:=(?!=)|in\b)",whole):
+            assigned|=set(re.findall(r"\w+",mm.group(1)))
+        for mm in re.finditer(r"\bfor\s+(\w+)\s+in\b|\bfor\s+(\w+)\s*=",whole):
+            assigned|={g for g in mm.groups() if g}
+        for mm in re.finditer(r"\bfor\s+\(([^)]*)\)\s+in\b",whole):
+            assigned|=set(re.findall(r"\w+",mm.group(1)))
+        for mm in re.finditer(r"\bfor\s+((?:\w+\s*,\s*)+\w+)\s+in\b",whole):
+            assigned|=set(re.findall(r"\w+",mm.group(1)))
+        for mm in re.finditer(r"\bdo\s+((?:\w+\s*,?\s*)*)$",whole,flags=re.M):
+            assigned|=set(re.findall(r"\w+",mm.group(1)))
+        for mm in re.finditer(r"(\w+)\s*->",whole): assigned.add(mm.group(1))
+        for mm in re.finditer(r"\(\s*((?:\w+\s*,\s*)*\w+)\s*\)\s*->",whole): assigned|=set(re.findall(r"\w+",mm.group(1)))
+        # nested function definitions and their args
+        for mm in re.finditer(r"\bfunction\s+(\w+)\(([^)]*)\)",whole):
+            assigned.add(mm.group(1)); assigned|=set(re.findall(r"(\w+)\s*(?:::|,|$)",mm.group(2)))
+        for mm in re.finditer(r"(?:^|\n)\s*(\w+)\(([^)]*)\)\s*=(?!=)",whole):
+            assigned.add(mm.group(1)); assigned|=set(re.findall(r"(\w+)\s*(?:::|,|$)",mm.group(2)))
+        # keyword arguments in calls: name=value inside parentheses -> `name` appears as assigned (acceptable)
+        unknown=ids-KEYWORDS-modnames-BASE-args-wherev-assigned
+        unknown={u for u in unknown if not u.startswith("hpcla_") and not re.fullmatch(r"\d\w*",u)}
+        if unknown: probs.append((name,first,sorted(unknown)))
+    
+    return probs
+
+
+def test_no_undefined_names_in_the_extension():
+    """No Julia here to run the file: a misspelt local (`n_ghosts` for `n_ghost`) would be an UndefVarError at the first call.
+    Every identifier of every definition must resolve (see _undefined_names); two mutations check that the scan can fail."""
+    text = open(EXT).read()
+    probs = _undefined_names(text)
+    assert not probs, "\n".join(f"{n} (line {l}): undefined {names}" for n, l, names in probs)
+    old = "        n_ghost = sum(recv_counts; init=Int64(0))\n"
+    assert text.count(old) == 1
+    got = _undefined_names(text.replace(old, "        n_ghosts = sum(recv_counts; init=Int64(0))\n"))
+    assert any(n == "_spmm_halo" and "n_ghost" in names for n, l, names in got), got
+    old2 = "    nnz = length(A.nzval); nb = _len(blocks)\n    _spmm_order!(rp0, 1)"
+    assert text.count(old2) == 1
+    got = _undefined_names(text.replace(old2, "    nnz = length(A.nzval); nb = _len(blocks)\n    _spmm_order!(rpo, 1)"))
+    assert any(n == "_spmm_split!" and "rpo" in names for n, l, names in got), got
+
+def _helper_call_arity_problems(text):
+    """Calls of the file's own helpers (`_name(...)`, `rocm_...`, `clear_rocm_plan_cache!`) with a number of positional
+    arguments that none of the helper's methods accepts."""
+    code = _julia_code_tokens(text)
+    defs = {}
+    for m in re.finditer(r"^(?:function\s+)?((?:_\w+|rocm_\w+|clear_rocm_plan_cache)!?)\(", code, flags=re.M):
+        i = m.end() - 1
+        j = _match_paren(code, i)
+        is_def = m.group(0).startswith("function") or re.match(r"\s*(?:where\s*(?:\{.*?\}|\w+)\s*)?=(?!=)", code[j:j + 200])
+        if is_def:
+            defs.setdefault(m.group(1), []).append(_arity(code[i + 1:j - 1]))
+    # nested closures (`function launch(ghost, blocks, nblocks)` inside a method)
+    for m in re.finditer(r"^\s+function\s+(\w+!?)\(", code, flags=re.M):
+        i = m.end() - 1
+        defs.setdefault(m.group(1), []).append(_arity(code[i + 1:_match_paren(code, i) - 1]))
+    problems = []
+    for name, arities in defs.items():
+        for c in re.finditer(r"(?<![\w.!])%s\(" % re.escape(name), code):
+            line_start = code.rfind("\n", 0, c.start()) + 1
+            if code[line_start:c.start()].strip().startswith("function") or code[line_start:c.start()].strip() == "":
+                k = c.end() - 1
+                after = code[_match_paren(code, k):_match_paren(code, k) + 120]
+                if code[line_start:c.start()].strip().startswith("function") or re.match(r"\s*(?:where\s*(?:\{.*?\}|\w+)\s*)?=(?!=)", after):
+                    continue                                  # a definition, not a call
+            k = c.end() - 1
+            inner = code[k + 1:_match_paren(code, k) - 1]
+            pos = 0
+            for a, sep in _split_top(inner):
+                if sep == ";" and a.strip():
+                    pos += 1
+                    break
+                if not a.strip():
+                    if sep == ";":
+                        break
+                    continue
+                if re.match(r"\s*\w+\s*=(?!=)", a):            # keyword argument written after a comma
+                    continue
+                pos += 1
+                if sep == ";":
+                    break
+            if not any(lo <= pos and (hi is None or pos <= hi) for lo, hi in arities):
+                problems.append(f"line {code.count(chr(10), 0, c.start()) + 1}: {name} called with {pos} positional arguments, methods take {sorted(set(arities), key=str)}")
+    return problems, defs
+
+
+def test_helper_calls_match_a_method_arity():
+    """Every call of one of the file's own helpers passes a number of positional arguments some method of it accepts (round 6
+    rewrote several helper signatures -- `_spmm_split!`, `_spmm_halo`, `_device_plan` -- in a file that cannot be run)."""
+    text = open(EXT).read()
+    problems, defs = _helper_call_arity_problems(text)
+    assert len(defs) >= 40, len(defs)
+    assert not problems, "\n".join(problems)
+    old = "_spmm_split!(C, A, rp0, colval_split, d.n_own, Brow, kp, ghost, k, interior, true)"
+    assert text.count(old) == 1
+    got, _ = _helper_call_arity_problems(text.replace(old, "_spmm_split!(C, A, rp0, colval_split, d.n_own, Brow, ghost, k, interior, true)"))
+    assert got and "_spmm_split!" in got[0], got
+
