@@ -705,7 +705,7 @@ def float32_record(hp, wl, job, args, N, steps, warmup):
 
 
 def configs_digest(result):
-    """The other BASELINE configurations of this line as FIVE numbers at its top level (ms per step; None = not run or
+    """The other BASELINE configurations of this line as numbers at its top level (ms per step; None = not run or
     skipped), so that a parsed record carries them and not only the sub-records' key names: config 3 (8192^2 over the N
     GPUs; at N = 1 the whole problem on one GPU), config 4 (CG ms per iteration), config 5 (SpMM k = 16: row-major host
     layer, and as a column-major caller gets it), and the headline matrix with the reference's default Int64 indices."""
@@ -717,6 +717,9 @@ def configs_digest(result):
         "cfg5_spmm_rowmajor_ms": get(oc, "sprand_spmm", "ms_per_step"),
         "cfg5_spmm_colmajor_caller_ms": get(oc, "sprand_spmm", "column_major_caller", "via_b_conversion_and_colmajor_store_ms"),
         "headline_int64_ms": get(oc, "int64", "ms_per_step"),
+        # round 6: the 5-point matrix x 16 (run tiles) and x 15 (odd k on the padded pitch; was 2 x the time of 16 before)
+        "stencil_spmm_k16_ms": get(oc, "poisson2d_spmm", "device_ms_per_step"),
+        "stencil_spmm_k15_ms": get(oc, "poisson2d_spmm", "odd_k", "device_ms_per_step"),
     }
 
 

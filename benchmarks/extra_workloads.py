@@ -501,6 +501,36 @@ def run_record(args, backend, rank, world, job):
                             "SpMM GFLOP/s (2*k*nnz/t), 2-D 5-pt Poisson, k=16, fp64",
                             f"poisson2d 5-pt {nx}x{ny_loc} slab per GPU, nnz/GPU={A.nnz}, k={k}, C = A*B",
                             traffic_key="poisson2d_spmm" if N == 4096 else None)
+        # ODD k (round 6): the same matrix times 15 columns through the host layer -- B's rows on the padded pitch 16
+        # (dense.spmm_pitch), the vector kernel with the last column pair's second half masked; before round 6 every odd k ran
+        # on the one-column-per-lane kernel (0.95 ms on this shape where 16 columns took 0.52 on the same gather kernel)
+        try:
+            k15 = 15
+            B15 = hp.HPCMatrix_local(Bl[:, :k15].contiguous(), backend)
+            C15 = A @ B15                                    # plan build + (first product of a result on the padded pitch)
+            B15p = hp.HPCMatrix(B15.row_partition, B15.col_partition, hp.dense._rows_on_pitch(B15.A, hp.dense.spmm_pitch(A, k15))[:, :k15],
+                                backend)                     # as a chained product finds it: already on the pitch, no copy
+            for _ in range(3):
+                C15 = A @ B15p
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n15 = max(5, min(args.steps, 20))
+            job.barrier()
+            ev0.record()
+            for _ in range(n15):
+                C15 = A @ B15p
+            ev1.record()
+            torch.cuda.synchronize()
+            ms15 = job.max(ev0.elapsed_time(ev1) / n15)
+            b15 = wl.spmm_algorithmic_bytes(A.nnz, A.nrows_local, A.ncols_compressed, k15, 4)
+            out["odd_k"] = {"k": k15, "row_pitch": int(B15p.A.stride(0)), "device_ms_per_step": round(ms15, 4),
+                            "frac": round(b15 / (ms15 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": b15,
+                            "vs_k16_this_record": round(ms15 / out["device_ms_per_step"], 3),
+                            "kernel": "hpcla::spmm_rowblock_vec_kernel (K16 shape, kr = 15)",
+                            "note": "k = 16 above takes the run-tile kernel; on the same gather kernel 16 columns take what 15 take "
+                                    "(profiles/r06_spmm_odd_k.log: 0.518 / 0.519 ms at 4096 x 2048 rows)"}
+            del B15, B15p, C15
+        except Exception as exc:                              # an extra: never takes the record down with it
+            out["odd_k"] = {"error": f"{type(exc).__name__}: {exc}"}
     elif args.workload == "sprand_spmm":
         k = 16
         rows_loc = args.size or 2_097_152

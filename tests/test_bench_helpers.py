@@ -51,13 +51,15 @@ def test_configs_digest_carries_five_numbers_to_the_top_level():
     import bench
     line = {"strong_scaling": {"ms_per_step": 0.9},
             "other_configs": {"poisson3d_cg": {"ms_per_step": 0.48}, "int64": {"ms_per_step": 0.23},
+                              "poisson2d_spmm": {"device_ms_per_step": 0.475, "odd_k": {"device_ms_per_step": 0.52}},
                               "sprand_spmm": {"ms_per_step": 1.47, "column_major_caller": {"via_b_conversion_and_colmajor_store_ms": 2.05}}}}
     d = bench.configs_digest(line)
     assert d == {"cfg3_poisson8192_spmv_ms": 0.9, "cfg4_cg_ms_per_iter": 0.48, "cfg5_spmm_rowmajor_ms": 1.47,
-                 "cfg5_spmm_colmajor_caller_ms": 2.05, "headline_int64_ms": 0.23}
+                 "cfg5_spmm_colmajor_caller_ms": 2.05, "headline_int64_ms": 0.23, "stencil_spmm_k16_ms": 0.475,
+                 "stencil_spmm_k15_ms": 0.52}
     d = bench.configs_digest({"strong_scaling": {"skipped": "budget"}, "other_configs": {"sprand_spmm": {"error": "x"}}})
     assert set(d) == {"cfg3_poisson8192_spmv_ms", "cfg4_cg_ms_per_iter", "cfg5_spmm_rowmajor_ms", "cfg5_spmm_colmajor_caller_ms",
-                      "headline_int64_ms"} and all(v is None for v in d.values())
+                      "headline_int64_ms", "stencil_spmm_k16_ms", "stencil_spmm_k15_ms"} and all(v is None for v in d.values())
     assert all(v is None for v in bench.configs_digest({}).values())
 
 

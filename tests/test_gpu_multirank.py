@@ -127,7 +127,8 @@ def _check_line_hygiene(rec):
     assert "frac_device_events" in rl and "achieved_device_events" in rl
     assert rl["traffic"] is None or isinstance(rl["traffic"], (int, float))
     assert set(rec["configs_digest"]) == {"cfg3_poisson8192_spmv_ms", "cfg4_cg_ms_per_iter", "cfg5_spmm_rowmajor_ms",
-                                          "cfg5_spmm_colmajor_caller_ms", "headline_int64_ms"}
+                                          "cfg5_spmm_colmajor_caller_ms", "headline_int64_ms", "stencil_spmm_k16_ms",
+                                          "stencil_spmm_k15_ms"}
     assert rec["configs_digest"]["cfg3_poisson8192_spmv_ms"] == rec["strong_scaling"]["ms_per_step"]
 
 
