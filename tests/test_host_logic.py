@@ -416,3 +416,29 @@ def test_element_type_of_a_backend_and_what_float32_covers(hp):
                 assert mine[-2] is hp._capi._vp
                 mine = mine[:-2] + mine[-1:]
             assert mine == norm(twin), name
+
+
+def test_spmm_pitch_and_rows_on_pitch(hp, monkeypatch):
+    """Round 6: odd k runs on the even row pitch k + 1 (dense.spmm_pitch, dense._rows_on_pitch) -- host logic, CPU tensors:
+    the pitch is a function of (element type, k, order) only (every rank computes the same exchange width); a block that
+    already sits on the pitch is taken as it is, any other is copied once; the padding is never part of the block."""
+    import types
+    import torch
+    dense = hp.dense
+    A64 = types.SimpleNamespace(T=np.dtype(np.float64))
+    A32 = types.SimpleNamespace(T=np.dtype(np.float32))
+    monkeypatch.delenv("HPCLA_SPMM_ORDER", raising=False)
+    assert [dense.spmm_pitch(A64, k) for k in (0, 1, 2, 3, 4, 5, 15, 16, 17)] == [0, 1, 2, 4, 4, 6, 16, 16, 18]
+    assert [dense.spmm_pitch(A32, k) for k in (1, 3, 15)] == [1, 3, 15]            # Float32 kernels keep the pitch k
+    monkeypatch.setenv("HPCLA_SPMM_ORDER", "panel")
+    assert dense.spmm_pitch(A64, 15) == 15                                        # the panel order keeps the pitch k
+    monkeypatch.delenv("HPCLA_SPMM_ORDER")
+    M = torch.arange(35, dtype=torch.float64).reshape(7, 5)
+    P = dense._rows_on_pitch(M, 6)
+    assert tuple(P.shape) == (7, 6) and P.stride(0) == 6 and torch.equal(P[:, :5], M)
+    V = P[:, :5]                                                                   # a result as spmm() hands it out
+    assert dense._rows_on_pitch(V, 6).data_ptr() == V.data_ptr()                   # already on the pitch: no copy
+    assert dense._rows_on_pitch(V, 5).is_contiguous() and torch.equal(dense._rows_on_pitch(V, 5), M)
+    E = dense._rows_on_pitch(torch.empty((0, 5), dtype=torch.float64), 6)
+    assert tuple(E.shape) == (0, 6)
+
