@@ -1391,7 +1391,7 @@ Base.minimum(v::HPCVector{Float32,B}) where {B<:ROCBackend} = Float32(-_reduce_f
 # the plan: vector operands with different partitions :870-876, dense A*x, ...; A*x above never needs `gathered`)
 # gathered[local_dst] = x[local_src] and gathered[recv_perm[i]] = what neighbour i sent, GPU to GPU; the CPU
 # staging buffer `gathered_cpu` is never touched.  Collective like the reference's.
-const _rocm_exec = IdDict{Any,Any}()      # reference plan -> (halo handle, device index lists); freed by clear_rocm_plan_cache!
+const _rocm_exec = IdDict{Any,Any}()      # reference plan -> (halo handle, device index lists, send_idx, ghost pointer); freed by clear_rocm_plan_cache!
 function HPCLinearAlgebra.execute_plan!(plan::HPCLinearAlgebra.VectorPlan{T,Ti,<:ROCVector},
                                         x::HPCVector{T,B}) where {T<:Float64,Ti,B<:ROCBackend}
     st = get!(_rocm_exec, plan) do
@@ -1410,10 +1410,13 @@ function HPCLinearAlgebra.execute_plan!(plan::HPCLinearAlgebra.VectorPlan{T,Ti,<
         x.backend.comm isa CommMPI &&
             _attach_halo_window(_rccl(x.backend.comm), halo[], x.backend.comm.comm, comm_size(x.backend.comm))
         perm = Int64.(reduce(vcat, plan.recv_perm; init=Ti[]))
+        ghost = Ref{Ptr{Cvoid}}(C_NULL); ng = Ref{Int64}(0)
+        halo[] == C_NULL || _check(@ccall(LIB.hpcla_halo_ghost_ptr(halo[]::Ptr{Cvoid}, ghost::Ptr{Ptr{Cvoid}}, ng::Ptr{Int64})::Cint),
+                                   "hpcla_halo_ghost_ptr")
         (halo[], ROCVector(Int64.(plan.local_src_indices)), ROCVector(Int64.(plan.local_dst_indices)),
-         ROCVector(perm), ROCVector(collect(Int64, 1:length(perm))), send_idx)
+         ROCVector(perm), ROCVector(collect(Int64, 1:length(perm))), send_idx, ghost[])
     end
-    halo, src, dst, perm, ident, _ = st
+    halo, src, dst, perm, ident, _, ghost = st
     s = _stream()
     # (a plan of this file's VectorPlan constructor starts without its `gathered` buffer: A * x never reads it)
     n_gathered = length(plan.local_dst_indices) + sum(length, plan.recv_perm; init=0)
@@ -1426,10 +1429,7 @@ function HPCLinearAlgebra.execute_plan!(plan::HPCLinearAlgebra.VectorPlan{T,Ti,<
                            "hpcla_gather_f64_i64")
     if halo != C_NULL
         _check(@ccall(LIB.hpcla_halo_end(halo::Ptr{Cvoid}, s::Ptr{Cvoid})::Cint), "hpcla_halo_end")
-        ghost = Ref{Ptr{Cvoid}}(C_NULL); ng = Ref{Int64}(0)
-        _check(@ccall(LIB.hpcla_halo_ghost_ptr(halo::Ptr{Cvoid}, ghost::Ptr{Ptr{Cvoid}}, ng::Ptr{Int64})::Cint),
-               "hpcla_halo_ghost_ptr")
-        isempty(perm) || _check(@ccall(LIB.hpcla_gather_f64_i64(ghost[]::Ptr{Cvoid}, _ptr(ident)::Ptr{Cvoid},
+        isempty(perm) || _check(@ccall(LIB.hpcla_gather_f64_i64(ghost::Ptr{Cvoid}, _ptr(ident)::Ptr{Cvoid},
                                 _ptr(perm)::Ptr{Cvoid}, _ptr(plan.gathered)::Ptr{Cvoid}, length(perm)::Int64, 1::Cint,
                                 s::Ptr{Cvoid})::Cint), "hpcla_gather_f64_i64")
     end
