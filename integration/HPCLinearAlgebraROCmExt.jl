@@ -378,6 +378,7 @@ function _scratch()
     return _work[]
 end
 function LinearAlgebra.dot(x::HPCVector{T,B}, y::HPCVector{T,B}) where {T<:Float64,B<:ROCBackend}
+    assert_backends_compatible(x.backend, y.backend)
     x.structural_hash == y.structural_hash || (y = HPCLinearAlgebra.repartition(y, x.partition))   # PCIe: none -- lands in this file's execute_plan!(::VectorRepartitionPlan): GPU to GPU
     work, out = _scratch()
     _check(@ccall(LIB.hpcla_dot_f64(_rccl(x.backend.comm)::Ptr{Cvoid}, _ptr(x.v)::Ptr{Cvoid}, _ptr(y.v)::Ptr{Cvoid},
@@ -411,7 +412,8 @@ end
 # 16-byte loads, grid sized for the chip) with the parent's semantics -- the result has u's partition and hash, a vector on another
 # partition is repartitioned first (the device exchange of execute_plan!(::VectorRepartitionPlan) below).  Same bits: 1 * u[i] and
 # -1 * v[i] are exact, so axpby(1, u, +-1, v) rounds once, like u[i] +- v[i].  General broadcast (`u .+ a .* v`) stays AMDGPU.jl's.
-const _HostReal = Union{Float64,Float32,Float16,Bool,Int8,Int16,Int32,Int64,UInt8,UInt16,UInt32,UInt64}    # promote_type(., Float64) == Float64
+# (Bool stays with the parent's broadcast: `false * x` is a STRONG zero in Julia -- false * NaN == 0.0 -- which 0.0 * x is not)
+const _HostReal = Union{Float64,Float32,Float16,Int8,Int16,Int32,Int64,UInt8,UInt16,UInt32,UInt64}    # promote_type(., Float64) == Float64
 function _axpby(a::Float64, u::HPCVector{T,B}, b::Float64, v::HPCVector{T,B}) where {T<:Float64,B<:ROCBackend}
     assert_backends_compatible(u.backend, v.backend)
     u.structural_hash == v.structural_hash || (v = HPCLinearAlgebra.repartition(v, u.partition))   # PCIe: none -- lands in this file's execute_plan!(::VectorRepartitionPlan): GPU to GPU
@@ -1374,6 +1376,7 @@ function _reduce_f32(sym::Symbol, x::HPCVector{Float32}, y=nothing, negate::Int=
     return _host_scalar(out, x.backend)              # a double; the callers round to Float32 once
 end
 function LinearAlgebra.dot(x::HPCVector{Float32,B}, y::HPCVector{Float32,B}) where {B<:ROCBackend}
+    assert_backends_compatible(x.backend, y.backend)
     x.structural_hash == y.structural_hash || (y = HPCLinearAlgebra.repartition(y, x.partition))   # PCIe: all of y, both ways, ONLY when the partitions differ -- the parent's host-staged repartition (no Float32 device exchange in this file)
     return Float32(_reduce_f32(:dot, x, y))
 end
