@@ -654,3 +654,143 @@ def test_helper_calls_match_a_method_arity():
     got, _ = _helper_call_arity_problems(text.replace(old, "_spmm_split!(C, A, rp0, colval_split, d.n_own, Brow, ghost, k, interior, true)"))
     assert got and "_spmm_split!" in got[0], got
 
+
+
+# ---- tuples built against the tuples taken apart ----------------------------------------------------------------------------------
+def _count_top(expr):
+    """number of top-level comma-separated items of `expr` (one enclosing pair of parentheses removed when it spans all of it)"""
+    e = expr.strip()
+    if e.startswith("(") and _match_paren(e, 0) == len(e):
+        e = e[1:-1]
+    return len([a for a, _ in _split_top(e) if a.strip()])
+
+
+def _joined_statement(lines, idx):
+    """the statement that starts on lines[idx], continuation lines joined while its brackets are open"""
+    s = lines[idx].strip()
+    depth = sum(s.count(c) for c in "([{") - sum(s.count(c) for c in ")]}")
+    j = idx
+    while depth > 0 and j + 1 < len(lines):
+        j += 1
+        t = lines[j].strip()
+        depth += sum(t.count(c) for c in "([{") - sum(t.count(c) for c in ")]}")
+        s += " " + t
+    return s, j
+
+
+def _tuple_arities(body):
+    """sizes of the tuples a block of code can evaluate to: `return a, b`, `return (a, b)`, and a parenthesised tuple that is the
+    last statement before an `end` (the value of a `do` block or of a function)"""
+    out = set()
+    lines = body.splitlines()
+    idx = 0
+    while idx < len(lines):
+        s, last = _joined_statement(lines, idx)
+        expr = None
+        m = re.match(r"(?:.*?&&\s*|.*?\|\|\s*)?return\s+(.+)$", s)
+        if m:
+            expr = m.group(1)
+        elif s.startswith("(") and _match_paren(s, 0) == len(s):
+            nxt = next((l.strip() for l in lines[last + 1:] if l.strip()), "")
+            if nxt == "end" or nxt.startswith("end "):
+                expr = s
+        if expr is not None and " ? " not in expr:
+            n = _count_top(expr)
+            if n >= 2:
+                out.add(n)
+        idx = last + 1
+    return out
+
+
+def _top_level_functions(code):
+    """[(name, first line index, last line index)] of every `function name(...) ... end` that starts in column 0"""
+    lines = code.splitlines()
+    out = []
+    for i, line in enumerate(lines):
+        m = re.match(r"function\s+([\w.:!*+\-/]+)\(", line)
+        if m:
+            j = next(q for q in range(i + 1, len(lines)) if lines[q].rstrip() == "end")
+            out.append((m.group(1).split(".")[-1].lstrip(":"), i, j))
+    return out
+
+
+def _destructuring_problems(text):
+    """`a, b, c = F(...)` / `a, b, c = v` where F is one of the file's functions (or v a local bound to a `get!(...) do` block, or to
+    `cond ? F(...) : (tuple)`) and the number of names differs from the size of a tuple F / the block can return.  Julia accepts
+    FEWER names than elements silently and throws on more; here the counts must be equal."""
+    code = _julia_code_tokens(text)
+    lines = code.splitlines()
+    funcs = _top_level_functions(code)
+    produced = {}
+    for name, i, j in funcs:
+        body = "\n".join(lines[i:j + 1])
+        sizes = _tuple_arities(body)
+        # `return NAME[]` of a cell filled with `NAME[] = (a, b)` in the same function (the reduction scratch)
+        for cell in re.findall(r"return\s+(\w+)\[\]", body):
+            for mm in re.finditer(r"%s\[\]\s*=\s*\(" % cell, body):
+                k = mm.end() - 1
+                sizes.add(_count_top(body[k:_match_paren(body, k)]))
+        produced.setdefault(name, set()).update(sizes)
+    # a tuple kept in a struct field between the function that builds it and the one that takes it apart
+    FIELD_PRODUCERS = {"st.map": "_spgemm_product_lists"}
+    problems, checked = [], 0
+    for idx, line in enumerate(lines):
+        m = re.match(r"(?:.*?[;(]\s*|\s*)\(?\s*((?:\w+\s*,\s*)+\w+)\s*\)?\s*=(?!=)\s*(.*)$", line)
+        if not m or re.match(r"\s*(for|function)\b", line):
+            continue
+        names = len(re.findall(r"\w+", m.group(1)))
+        rhs = m.group(2).strip()
+        if not rhs:                                           # `a, b, c =` with the call on the next line
+            rhs, _ = _joined_statement(lines, idx + 1)
+        else:
+            stmt, _ = _joined_statement(lines, idx)
+            rhs = stmt[stmt.index(m.group(1)) + len(m.group(1)):].split("=", 1)[1].strip()
+        owner = next(((n, i, j) for n, i, j in funcs if i <= idx <= j), ("<top level>", idx, idx))
+        sizes = set()
+        call = re.match(r"([\w.]+!?)\(", rhs)
+        if call and call.group(1).split(".")[-1] in produced:
+            sizes = produced[call.group(1).split(".")[-1]]
+        elif rhs in FIELD_PRODUCERS:
+            sizes = produced[FIELD_PRODUCERS[rhs]]
+        elif re.fullmatch(r"\w+", rhs):
+            # a local: `v = get!(...) do` ... `end` at the same indentation, or `v = cond ? F(...) : (tuple)`
+            for k in range(idx - 1, owner[1] - 1, -1):
+                mm = re.match(r"(\s*)%s\s*=(?!=)\s*(.+)$" % re.escape(rhs), lines[k])
+                if not mm:
+                    continue
+                stmt, _ = _joined_statement(lines, k)
+                val = stmt.split("=", 1)[1].strip()
+                if re.match(r"get!\(.*\)\s+do\b", val):
+                    ind = mm.group(1)
+                    stop = next(q for q in range(k + 1, len(lines)) if lines[q].rstrip() == ind + "end")
+                    sizes = _tuple_arities("\n".join(lines[k + 1:stop + 1]))
+                else:
+                    t = re.match(r".+?\?\s*([\w.]+!?)\((?:.*)\)\s*:\s*(\(.*\))$", val)
+                    if t and t.group(1).split(".")[-1] in produced:
+                        sizes = set(produced[t.group(1).split(".")[-1]]) | {_count_top(t.group(2))}
+                break
+        if not sizes:
+            continue
+        checked += 1
+        if sizes != {names}:
+            problems.append(f"{owner[0]} (line {idx + 1}): `{line.strip()[:90]}` takes {names} names from a tuple of {sorted(sizes)}")
+    return problems, checked
+
+
+def test_tuples_are_taken_apart_with_as_many_names_as_they_have_elements():
+    """The cached plan entries of the extension are plain tuples (`_spmm_halo`'s seven fields, the entries of `_rocm_exec` and
+    `_rocm_matexec`, ...), built in one place and destructured in several.  A field added on one side only is a BoundsError -- or,
+    with fewer names than fields, silently the wrong field -- at the first call, which nothing here can make.  Held statically,
+    with two mutations that must be caught."""
+    text = open(EXT).read()
+    problems, checked = _destructuring_problems(text)
+    assert checked >= 14, f"only {checked} destructuring assignments were resolved: the parser lost track of the file"
+    assert not problems, "\n".join(problems)
+    old = "ROCVector(perm), ROCVector(collect(Int64, 1:length(perm))), send_idx, ghost[])"
+    assert text.count(old) == 1
+    got, _ = _destructuring_problems(text.replace(old, "ROCVector(perm), ROCVector(collect(Int64, 1:length(perm))), send_idx)"))
+    assert any("execute_plan!" in p for p in got), got
+    old2 = "        (halo[], interior, boundary, send_idx, ghost[], colval_split, rp0)\n"
+    assert text.count(old2) == 1
+    got, _ = _destructuring_problems(text.replace(old2, "        (halo[], interior, boundary, send_idx, ghost[], colval_split)\n"))
+    assert len(got) >= 3 and all("_spmm_halo" in p or "ent" in p or "*" in p for p in got), got
